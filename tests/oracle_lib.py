@@ -1,0 +1,345 @@
+"""ctypes binding of the CPU oracle (oracle/libma_oracle.so) — test infrastructure only.
+
+The oracle is the checker: tests, `__graft_entry__.smoke()` and bench.py's cpu_baseline leg
+are the only importers. Product code under math_audio_amd/ never touches it.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(_ORACLE_DIR, "libma_oracle.so")
+
+
+class c64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class IntegrationResult(C.Structure):
+    _fields_ = [("g", c64), ("dg_dn", c64), ("dg_dnx", c64), ("d2g", c64), ("rhs", c64)]
+
+    def as_array(self):
+        return np.array([complex(z.re, z.im) for z in (self.g, self.dg_dn, self.dg_dnx, self.d2g, self.rhs)])
+
+
+class Subelement(C.Structure):
+    _fields_ = [("xi_center", C.c_double), ("eta_center", C.c_double), ("factor", C.c_double),
+                ("gauss_order", C.c_int), ("has_tri", C.c_int), ("tri", C.c_double * 6)]
+
+
+class GmresInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("restarts", C.c_int), ("converged", C.c_int), ("residual", C.c_double)]
+
+
+def build():
+    """Compile the oracle if the .so is missing or older than its sources."""
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        L.mao_wave_number.restype = C.c_double
+        L.mao_wave_number.argtypes = [C.c_double, C.c_double]
+        for f in ("mao_burton_miller_beta",):
+            getattr(L, f).restype = c64
+            getattr(L, f).argtypes = [C.c_double] * 3
+        L.mao_burton_miller_beta_scaled.restype = c64
+        L.mao_burton_miller_beta_scaled.argtypes = [C.c_double] * 4
+        L.mao_burton_miller_beta_adaptive.restype = c64
+        L.mao_burton_miller_beta_adaptive.argtypes = [C.c_double] * 4 + [C.POINTER(C.c_double)]
+        L.mao_spherical_bessel_j.restype = C.c_double
+        L.mao_spherical_bessel_j.argtypes = [C.c_int, C.c_double]
+        L.mao_spherical_bessel_y.restype = C.c_double
+        L.mao_spherical_bessel_y.argtypes = [C.c_int, C.c_double]
+        L.mao_legendre_p.restype = C.c_double
+        L.mao_legendre_p.argtypes = [C.c_int, C.c_double]
+    return _lib
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _cz(z):
+    z = complex(z)
+    return c64(z.real, z.imag)
+
+
+# ---------------------------------------------------------------- quadrature
+def gauss_legendre(order):
+    x = np.zeros(20); w = np.zeros(20)
+    n = lib().mao_gauss_legendre(order, _p(x), _p(w))
+    return x[:n].copy(), w[:n].copy()
+
+
+def triangle_quadrature(order):
+    q = np.zeros(39)
+    n = lib().mao_triangle_quadrature(order, _p(q))
+    return q[:3 * n].reshape(n, 3).copy()
+
+
+def quad_quadrature(order):
+    q = np.zeros(3 * 400)
+    n = lib().mao_quad_quadrature(order, _p(q))
+    return q[:3 * n].reshape(n, 3).copy()
+
+
+# ---------------------------------------------------------------- physics
+def wave_number(f, c=343.0):
+    return lib().mao_wave_number(f, c)
+
+
+def beta_adaptive(k, radius, harmonic=1.0, tau=1.0):
+    s = C.c_double(0)
+    z = lib().mao_burton_miller_beta_adaptive(k, harmonic, tau, radius, C.byref(s))
+    return complex(z.re, z.im), s.value
+
+
+def beta_scaled(k, scale, harmonic=1.0, tau=1.0):
+    z = lib().mao_burton_miller_beta_scaled(k, harmonic, tau, scale)
+    return complex(z.re, z.im)
+
+
+# ---------------------------------------------------------------- meshes
+class Mesh:
+    """SoA mesh as the reference's `Mesh`/`Element` flatten to (types.rs:330-391)."""
+
+    def __init__(self, nodes, conn):
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        n = self.conn.shape[0]
+        self.n_elem = n
+        self.center = np.zeros((n, 3)); self.normal = np.zeros((n, 3)); self.area = np.zeros(n)
+        lib().mao_element_geometry(n, _p(self.nodes), _p(self.conn, C.c_int), _p(self.center), _p(self.normal), _p(self.area))
+        self.dof = np.arange(n, dtype=np.int32)
+        self.bc_type = np.zeros(n, dtype=np.uint8)            # Velocity
+        self.bc_values = np.zeros((n, 4), dtype=np.complex128)  # vec![0+0i]
+        self.bc_len = np.ones(n, dtype=np.int32)
+        self.is_eval = np.zeros(n, dtype=np.uint8)
+
+    def coords(self, e):
+        nn = 3 if self.conn[e, 3] < 0 else 4
+        return np.ascontiguousarray(self.nodes[self.conn[e, :nn]])
+
+
+def icosphere(radius, subdivisions):
+    nn = C.c_int(); ne = C.c_int()
+    lib().mao_icosphere_counts(subdivisions, C.byref(nn), C.byref(ne))
+    nodes = np.zeros((nn.value, 3)); conn = np.zeros((ne.value, 4), dtype=np.int32)
+    lib().mao_icosphere(C.c_double(radius), subdivisions, _p(nodes), _p(conn, C.c_int))
+    return Mesh(nodes, conn)
+
+
+def uv_sphere(radius, n_theta, n_phi):
+    nn = C.c_int(); ne = C.c_int()
+    lib().mao_uv_sphere_counts(n_theta, n_phi, C.byref(nn), C.byref(ne))
+    nodes = np.zeros((nn.value, 3)); conn = np.zeros((ne.value, 4), dtype=np.int32)
+    lib().mao_uv_sphere(C.c_double(radius), n_theta, n_phi, _p(nodes), _p(conn, C.c_int))
+    return Mesh(nodes, conn)
+
+
+# ---------------------------------------------------------------- panel integrals
+def generate_subelements(x, coords, area):
+    x = np.ascontiguousarray(x, dtype=np.float64); coords = np.ascontiguousarray(coords, dtype=np.float64)
+    out = (Subelement * 110)()
+    n = lib().mao_generate_subelements(_p(x), _p(coords), coords.shape[0], C.c_double(area), out)
+    return [out[i] for i in range(n)]
+
+
+def regular_integration(x, nx, coords, area, k, harmonic=1.0, tau=1.0, bc=None, bc_type=0):
+    x = np.ascontiguousarray(x, dtype=np.float64); nx = np.ascontiguousarray(nx, dtype=np.float64)
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    res = IntegrationResult()
+    bcv = None if bc is None else np.ascontiguousarray(bc, dtype=np.complex128)
+    lib().mao_regular_integration(_p(x), _p(nx), _p(coords), coords.shape[0], C.c_double(area), C.c_double(k),
+                                  C.c_double(harmonic), C.c_double(tau), _vp(bcv), 0 if bcv is None else len(bcv),
+                                  bc_type, 0 if bcv is None else 1, C.byref(res))
+    return res.as_array()
+
+
+def singular_integration(x, nx, coords, k, harmonic=1.0, tau=1.0, bc=None, bc_type=0, params=None):
+    x = np.ascontiguousarray(x, dtype=np.float64); nx = np.ascontiguousarray(nx, dtype=np.float64)
+    coords = np.ascontiguousarray(coords, dtype=np.float64)
+    res = IntegrationResult()
+    bcv = None if bc is None else np.ascontiguousarray(bc, dtype=np.complex128)
+    args = [_p(x), _p(nx), _p(coords), coords.shape[0], C.c_double(k), C.c_double(harmonic), C.c_double(tau),
+            _vp(bcv), 0 if bcv is None else len(bcv), bc_type, 0 if bcv is None else 1]
+    if params is None:
+        lib().mao_singular_integration(*args, C.byref(res))
+    else:
+        lib().mao_singular_integration_with_params(*args, *[int(p) for p in params], C.byref(res))
+    return res.as_array()
+
+
+# ---------------------------------------------------------------- assembly / rhs
+def build_tbem_system_with_beta(mesh, k, beta, harmonic=1.0, tau=1.0, nthreads=1, rows=None, A=None, rhs=None):
+    n = mesh.n_elem
+    nd = int((mesh.is_eval == 0).sum())
+    if A is None:
+        A = np.zeros((nd, nd), dtype=np.complex128)
+    if rhs is None:
+        rhs = np.zeros(nd, dtype=np.complex128)
+    r0, r1 = (0, n) if rows is None else rows
+    beta = complex(beta)
+    rc = lib().mao_build_tbem_system_with_beta(
+        n, _p(mesh.nodes), _p(mesh.conn, C.c_int), _p(mesh.center), _p(mesh.normal), _p(mesh.area),
+        _p(mesh.dof, C.c_int), _p(mesh.bc_type, C.c_ubyte), _vp(mesh.bc_values), _p(mesh.bc_len, C.c_int),
+        _p(mesh.is_eval, C.c_ubyte), C.c_double(k), C.c_double(harmonic), C.c_double(tau),
+        C.c_double(beta.real), C.c_double(beta.imag), _vp(A), _vp(rhs), nd, r0, r1, nthreads)
+    assert rc == 0
+    return A, rhs
+
+
+def compute_rhs_with_beta(centers, normals, k, beta, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, tau=1.0):
+    centers = np.ascontiguousarray(centers, dtype=np.float64); normals = np.ascontiguousarray(normals, dtype=np.float64)
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    out = np.zeros(centers.shape[0], dtype=np.complex128)
+    lib().mao_compute_rhs_with_beta(kind, _p(v), _cz(amp), centers.shape[0], _p(centers), _p(normals),
+                                    C.c_double(k), C.c_double(tau), _cz(beta), _vp(out))
+    return out
+
+
+def incident_pressure(points, k, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0):
+    points = np.ascontiguousarray(points, dtype=np.float64)
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    out = np.zeros(points.shape[0], dtype=np.complex128)
+    lib().mao_incident_pressure(kind, _p(v), _cz(amp), points.shape[0], _p(points), C.c_double(k), _vp(out))
+    return out
+
+
+# ---------------------------------------------------------------- dense solve
+def zgesv(A, b, nthreads=1):
+    """Returns (x, ipiv, status); A is copied."""
+    A = np.array(A, dtype=np.complex128, order="C"); x = np.array(b, dtype=np.complex128)
+    n = A.shape[0]
+    ipiv = np.zeros(max(n, 1), dtype=np.int32)
+    rc = lib().mao_zgesv(n, _vp(A), _vp(x), _p(ipiv, C.c_int), nthreads)
+    return x, ipiv, rc
+
+
+def lu_solve_fallback(A, b):
+    A = np.ascontiguousarray(A, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    x = np.zeros_like(b)
+    rc = lib().mao_lu_solve_fallback(A.shape[0], _vp(A), _vp(b), _vp(x))
+    return x, rc
+
+
+# ---------------------------------------------------------------- Mie
+def sphere_scattering_3d(k, radius, num_terms, r, theta):
+    r = np.ascontiguousarray(r, dtype=np.float64); theta = np.ascontiguousarray(theta, dtype=np.float64)
+    out = np.zeros(len(r) * len(theta), dtype=np.complex128)
+    lib().mao_sphere_scattering_3d(C.c_double(k), C.c_double(radius), num_terms, len(r), _p(r), len(theta), _p(theta), _vp(out))
+    return out.reshape(len(r), len(theta))
+
+
+def compute_scattered_field(eval_points, mesh, surface_pressure, k, surface_velocity=None, harmonic=1.0):
+    ep = np.ascontiguousarray(eval_points, dtype=np.float64)
+    ps = np.ascontiguousarray(surface_pressure, dtype=np.complex128)
+    vs = None if surface_velocity is None else np.ascontiguousarray(surface_velocity, dtype=np.complex128)
+    out = np.zeros(ep.shape[0], dtype=np.complex128)
+    lib().mao_compute_scattered_field(ep.shape[0], _p(ep), mesh.n_elem, _p(mesh.nodes), _p(mesh.conn, C.c_int),
+                                      _p(mesh.is_eval, C.c_ubyte), _vp(ps), _vp(vs), C.c_double(k), C.c_double(harmonic), _vp(out))
+    return out
+
+
+# ---------------------------------------------------------------- CSR / smoothers / GMRES
+def _csr_args(rp, col, val):
+    rp = np.ascontiguousarray(rp, dtype=np.int64); col = np.ascontiguousarray(col, dtype=np.int64)
+    val = np.ascontiguousarray(val, dtype=np.complex128)
+    return rp, col, val
+
+
+def csr_matvec(rp, col, val, x, nthreads=1):
+    rp, col, val = _csr_args(rp, col, val)
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    y = np.zeros(len(rp) - 1, dtype=np.complex128)
+    lib().mao_csr_matvec(len(rp) - 1, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), _vp(x), _vp(y), nthreads)
+    return y
+
+
+def helmholtz_values(K, M, k):
+    K = np.ascontiguousarray(K, dtype=np.float64); M = np.ascontiguousarray(M, dtype=np.float64)
+    k = complex(k)
+    out = np.zeros(len(K), dtype=np.complex128)
+    lib().mao_helmholtz_values(C.c_longlong(len(K)), _p(K), _p(M), C.c_double(k.real), C.c_double(k.imag), _vp(out))
+    return out
+
+
+def amg_jacobi(rp, col, val, x, b, omega, sweeps, nthreads=1):
+    rp, col, val = _csr_args(rp, col, val)
+    x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    lib().mao_amg_jacobi(len(rp) - 1, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), _vp(x), _vp(b),
+                         C.c_double(omega), sweeps, nthreads)
+    return x
+
+
+def amg_l1_jacobi(rp, col, val, x, b, sweeps, nthreads=1):
+    rp, col, val = _csr_args(rp, col, val)
+    x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    lib().mao_amg_l1_jacobi(len(rp) - 1, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), _vp(x), _vp(b), sweeps, nthreads)
+    return x
+
+
+def amg_sym_gauss_seidel(rp, col, val, x, b, sweeps):
+    rp, col, val = _csr_args(rp, col, val)
+    x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    lib().mao_amg_sym_gauss_seidel(len(rp) - 1, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), _vp(x), _vp(b), sweeps)
+    return x
+
+
+def fem_smooth(n, rows, cols, vals, x, b, kind=0, iterations=2, omega=2.0 / 3.0):
+    rows = np.ascontiguousarray(rows, dtype=np.int64); cols = np.ascontiguousarray(cols, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.complex128)
+    x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    lib().mao_fem_smooth(n, C.c_longlong(len(rows)), _p(rows, C.c_longlong), _p(cols, C.c_longlong), _vp(vals),
+                         _vp(x), _vp(b), kind, iterations, C.c_double(omega))
+    return x
+
+
+def fem_residual(n, rows, cols, vals, x, b):
+    rows = np.ascontiguousarray(rows, dtype=np.int64); cols = np.ascontiguousarray(cols, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.complex128)
+    x = np.ascontiguousarray(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    r = np.zeros(n, dtype=np.complex128)
+    lib().mao_fem_residual(n, C.c_longlong(len(rows)), _p(rows, C.c_longlong), _p(cols, C.c_longlong), _vp(vals), _vp(x), _vp(b), _vp(r))
+    return r
+
+
+def gmres(b, dense=None, csr=None, x0=None, restart=30, max_iterations=100, tol=1e-6):
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    n = len(b)
+    x = np.zeros(n, dtype=np.complex128)
+    info = GmresInfo()
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    if dense is not None:
+        d = np.ascontiguousarray(dense, dtype=np.complex128)
+        lib().mao_gmres(n, 0, _vp(d), None, None, None, _vp(b), _vp(x0a), restart, max_iterations, C.c_double(tol), _vp(x), C.byref(info))
+    else:
+        rp, col, val = _csr_args(*csr)
+        lib().mao_gmres(n, 1, None, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), _vp(b), _vp(x0a), restart,
+                        max_iterations, C.c_double(tol), _vp(x), C.byref(info))
+    return x, info
+
+
+def room_build_matrix(center, normal, area, k, nthreads=1):
+    center = np.ascontiguousarray(center, dtype=np.float64); normal = np.ascontiguousarray(normal, dtype=np.float64)
+    area = np.ascontiguousarray(area, dtype=np.float64)
+    n = len(area)
+    A = np.zeros((n, n), dtype=np.complex128)
+    lib().mao_room_build_matrix(n, _p(center), _p(normal), _p(area), C.c_double(k), _vp(A), nthreads)
+    return A
