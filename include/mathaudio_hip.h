@@ -1,0 +1,162 @@
+/* mathaudio_hip.h — C-ABI of libmathaudio_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of pierreaubert/math-audio: the math-bem dense
+ * Burton–Miller (TBEM) assembly, the math-solvers dense complex solve it feeds, and the
+ * CSR SpMV / Jacobi smoothers of the FEM side. The reference has no FFI today; each entry
+ * point below names the Rust function or trait method it replaces (paths relative to the
+ * reference root). The Rust-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions:
+ *  - Complex64 is #[repr(C)] {re: f64, im: f64} == ma_c64 == C `double _Complex`.
+ *  - Dense matrices are ndarray C-order: row-major, A[i*n + j].
+ *  - All host pointers are caller-owned borrows; the library never retains or frees them.
+ *  - Device memory lives behind opaque handles (or caller-provided device pointers in the
+ *    *_dev variants, passed as void*; streams are hipStream_t passed as void*).
+ *  - No unwinding across the boundary: every call returns an int status; the text of the last
+ *    error on the calling thread is available from ma_last_error_string().
+ *  - Every entry point is re-entrant; a handle may be used from one thread at a time.
+ *  - There is NO CPU fallback: without a usable gfx950 device every compute call fails with
+ *    MA_ERR_NO_DEVICE.
+ */
+#ifndef MATHAUDIO_HIP_H
+#define MATHAUDIO_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } ma_c64;
+
+/* status codes; the mapping onto the reference's error enums is part of the contract */
+enum {
+  MA_OK              = 0,
+  MA_ERR_SINGULAR    = 1,  /* -> LuError::SingularMatrix            (math-solvers/src/direct/lu.rs:16-21)  */
+  MA_ERR_DIM         = 2,  /* -> LuError::DimensionMismatch / SolverError::DimensionMismatch               */
+  MA_ERR_INVALID     = 3,  /* null pointer, negative size, bad enum  -> BemError::InvalidConfiguration      */
+  MA_ERR_UNSUPPORTED = 4,  /* input class not handled by the device path yet (listed per function)         */
+  MA_ERR_HIP         = 5,  /* a HIP runtime call failed; text in ma_last_error_string()                    */
+  MA_ERR_NO_DEVICE   = 6,  /* no gfx950 device visible                                                     */
+  MA_ERR_NOMEM       = 7   /* device or host allocation failed                                             */
+};
+
+const char* ma_last_error_string(void);
+const char* ma_version(void);
+int ma_device_count(int* count);                 /* MA_OK and *count = 0 on a host without GPUs */
+
+/* ------------------------------------------------------------------------------------------
+ * Mesh and physics — flattened `&[Element]` + `nodes: Array2<f64>` (math-bem/src/core/types.rs:330-351)
+ * A Rust shim fills this from the AoS `Element`s (connectivity, center, normal, area,
+ * dof_addresses[0], boundary_condition, property).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t        n_nodes;
+  const double*  nodes;      /* n_nodes*3, row-major (Array2<f64>)                                   */
+  int32_t        n_elem;
+  const int32_t* conn;       /* n_elem*4 node indices; 4th = -1 for Tri3                             */
+  const double*  center;     /* n_elem*3  Element.center (collocation point)                         */
+  const double*  normal;     /* n_elem*3  Element.normal (stored, outward-flipped: generators.rs:590) */
+  const double*  area;       /* n_elem    Element.area                                               */
+  const int32_t* dof;        /* n_elem    Element.dof_addresses[0]; must enumerate 0..num_dofs-1 over
+                                          the non-evaluation elements                                */
+  const uint8_t* bc_type;    /* n_elem    0 Velocity, 1 Pressure, 2 other (tbem.rs:234-244)          */
+  const ma_c64*  bc_values;  /* n_elem*4  BoundaryCondition values (first bc_len[e] are used); may be
+                                          NULL = all zero                                            */
+  const int32_t* bc_len;     /* n_elem    length of the BC Vec (>=1); may be NULL = all 1            */
+  const uint8_t* is_eval;    /* n_elem    ElementProperty::Evaluation flag; may be NULL = none       */
+} ma_mesh_t;
+
+typedef struct {
+  double wave_number;        /* PhysicsParams.wave_number   (types.rs:24)  */
+  double harmonic_factor;    /* PhysicsParams.harmonic_factor (+1)         */
+  double tau;                /* +1 exterior, -1 interior    (types.rs:45)  */
+  double gamma;              /* PhysicsParams::gamma() = 1  (types.rs:216) */
+} ma_physics_t;
+
+/* ------------------------------------------------------------------------------------------
+ * TBEM assembly.
+ * Replaces: build_tbem_system_with_beta(&[Element], &Array2<f64>, &PhysicsParams, Complex64)
+ *           -> TbemSystem        math-bem/src/core/assembly/tbem.rs:96-222
+ * (and through it build_tbem_system :45, _bounded :64, _scaled :85; callers bem_solver.rs:367,
+ *  bin/qa_suite.rs:228,355).
+ * A: num_dofs*num_dofs row-major [[source_dof, field_dof]] (tbem.rs:340), overwritten.
+ * rhs: num_dofs, overwritten (TbemSystem.rhs: BC contributions; zero for rigid scatterers).
+ * MA_ERR_UNSUPPORTED: Quad4 elements; non-zero BC values (the rhs_contribution path).
+ * ------------------------------------------------------------------------------------------ */
+int ma_bem_assemble_tbem(const ma_mesh_t* mesh, const ma_physics_t* physics,
+                         double beta_re, double beta_im, ma_c64* A, ma_c64* rhs);
+
+/* Device-resident form for frequency sweeps: geometry, the near-pair list and all
+ * frequency-independent tables stay in HBM behind the plan. */
+typedef struct ma_bem_plan ma_bem_plan_t;
+int ma_bem_plan_create(const ma_mesh_t* mesh, int device, ma_bem_plan_t** out);
+int ma_bem_plan_destroy(ma_bem_plan_t* plan);
+int ma_bem_plan_num_dofs(const ma_bem_plan_t* plan, int32_t* num_dofs);
+int ma_bem_plan_num_near_pairs(const ma_bem_plan_t* plan, int64_t* n);
+/* d_A (num_dofs^2 ma_c64) and d_rhs (num_dofs) are DEVICE pointers; work is enqueued on `stream`. */
+int ma_bem_plan_assemble_dev(ma_bem_plan_t* plan, const ma_physics_t* physics, double beta_re, double beta_im,
+                             void* d_A, void* d_rhs, void* stream);
+
+/* Incident field RHS.
+ * Replaces: IncidentField::compute_rhs_with_beta(centers, normals, physics, beta)
+ *           math-bem/src/core/incident.rs:317-342 (PlaneWave / PointSource :93-280).
+ * kind 0: plane wave, vec3 = unit direction; kind 1: point source, vec3 = position.
+ * d_rhs[i] (+)= -(gamma p_inc + beta tau dp_inc/dn); accumulate != 0 adds to d_rhs (the QA suite's
+ * `&system.rhs + &rhs`, bin/qa_suite.rs:247). */
+int ma_bem_plan_incident_rhs_dev(ma_bem_plan_t* plan, const ma_physics_t* physics, double beta_re, double beta_im,
+                                 int kind, const double* vec3, double amp_re, double amp_im,
+                                 int accumulate, void* d_rhs, void* stream);
+int ma_bem_incident_rhs(int n, const double* centers, const double* normals, const ma_physics_t* physics,
+                        double beta_re, double beta_im, int kind, const double* vec3,
+                        double amp_re, double amp_im, ma_c64* rhs);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense complex solve.
+ * Replaces: lu_solve(&Array2<Complex64>, &Array1<Complex64>) -> Result<Array1<_>, LuError>
+ *           math-solvers/src/direct/lu.rs:142-153 (native: LAPACK zgesv through ndarray-linalg).
+ * A_rowmajor is destroyed (holds the LU factors), b_inout receives x. ipiv may be NULL.
+ * Returns MA_OK, MA_ERR_SINGULAR or MA_ERR_DIM.
+ * ------------------------------------------------------------------------------------------ */
+int ma_zgesv(int32_t n, ma_c64* A_rowmajor, ma_c64* b_inout, int32_t* ipiv_or_null);
+
+typedef struct ma_lu_plan ma_lu_plan_t;           /* workspace for device-resident solves of size n */
+int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out);
+int ma_lu_plan_destroy(ma_lu_plan_t* plan);
+/* Factor d_A in place (row-major, device) and solve for nrhs right-hand sides stored as
+ * d_B[nrhs][n] (each contiguous). Asynchronous on `stream`; the singularity flag is reported by
+ * ma_lu_plan_status(), which synchronises the stream. */
+int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_t nrhs, void* stream);
+int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Parity-test hooks (no counterpart in the reference API): raw panel integrals computed by the
+ * device kernels, comparable to IntegrationResult of regular_integration / singular_integration
+ * (math-bem/src/core/integration/regular.rs:33, singular.rs:123; types.rs:722-734).
+ *  probe_pairs: pairs = npairs x (i, j), i != j, panel indices in plan order; out5 = npairs x 5
+ *               complex {number of sub-elements, G, H, H^T, E}.
+ *  probe_self:  out5 = num_dofs x 5 complex {number of kernel points, G, H, H^T, E}.
+ *  get_near_pairs: the (i, j) list whose level-0 distance ratio is < 3 (singular.rs:553-556).
+ * ------------------------------------------------------------------------------------------ */
+int ma_bem_plan_probe_pairs(ma_bem_plan_t* plan, const ma_physics_t* physics, int64_t npairs,
+                            const int32_t* pairs, ma_c64* out5);
+int ma_bem_plan_probe_self(ma_bem_plan_t* plan, const ma_physics_t* physics, ma_c64* out5);
+int ma_bem_plan_get_near_pairs(const ma_bem_plan_t* plan, int32_t* out_pairs);
+
+/* ------------------------------------------------------------------------------------------
+ * Diagnostics used by bench.py / tests: elapsed GPU time (ms) of the tagged phases of the most
+ * recent call on the plan, measured with HIP events on the plan's stream when timing is enabled.
+ * ------------------------------------------------------------------------------------------ */
+int ma_bem_plan_set_timing(ma_bem_plan_t* plan, int enable);
+/* out[0]=far kernel, out[1]=near kernel, out[2]=self kernel ms of the last assemble */
+int ma_bem_plan_last_timing(ma_bem_plan_t* plan, double* out3);
+int ma_lu_plan_set_timing(ma_lu_plan_t* plan, int enable);
+/* out[0]=panel, out[1]=row swaps, out[2]=trsm, out[3]=trailing zgemm, out[4]=triangular solves (ms);
+ * out[5]=number of zgemm launches */
+int ma_lu_plan_last_timing(ma_lu_plan_t* plan, double* out6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATHAUDIO_HIP_H */

@@ -1,0 +1,260 @@
+"""math_audio_amd — ctypes view of libmathaudio_hip.so (the C-ABI in include/mathaudio_hip.h).
+
+This package is plumbing: it loads the in-tree shared library (built by
+`__graft_entry__.build()` / `make -C math_audio_amd/csrc`) and exposes the C entry points
+with NumPy / raw-device-pointer arguments for the tests and bench.py. The compiled host
+mirror of the reference's Rust API lives in math_audio_amd/host/*.hpp (C++), because the
+reference is compiled code; see INTEGRATION.md.
+
+There is no CPU fallback: a missing library raises at import of `lib()`, and every compute
+call returns MA_ERR_NO_DEVICE on a host without a gfx950 GPU.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmathaudio_hip.so")
+
+MA_OK, MA_ERR_SINGULAR, MA_ERR_DIM, MA_ERR_INVALID, MA_ERR_UNSUPPORTED, MA_ERR_HIP, MA_ERR_NO_DEVICE, MA_ERR_NOMEM = range(8)
+_STATUS_NAMES = ["MA_OK", "MA_ERR_SINGULAR", "MA_ERR_DIM", "MA_ERR_INVALID", "MA_ERR_UNSUPPORTED", "MA_ERR_HIP",
+                 "MA_ERR_NO_DEVICE", "MA_ERR_NOMEM"]
+
+
+class MaError(RuntimeError):
+    def __init__(self, status, text):
+        self.status = status
+        name = _STATUS_NAMES[status] if 0 <= status < len(_STATUS_NAMES) else str(status)
+        super().__init__("%s: %s" % (name, text))
+
+
+class ma_c64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class ma_mesh_t(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("nodes", C.c_void_p), ("n_elem", C.c_int32), ("conn", C.c_void_p),
+                ("center", C.c_void_p), ("normal", C.c_void_p), ("area", C.c_void_p), ("dof", C.c_void_p),
+                ("bc_type", C.c_void_p), ("bc_values", C.c_void_p), ("bc_len", C.c_void_p), ("is_eval", C.c_void_p)]
+
+
+class ma_physics_t(C.Structure):
+    _fields_ = [("wave_number", C.c_double), ("harmonic_factor", C.c_double), ("tau", C.c_double), ("gamma", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmathaudio_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ma_last_error_string.restype = C.c_char_p
+        L.ma_version.restype = C.c_char_p
+        vp, dbl, i32, i64 = C.c_void_p, C.c_double, C.c_int32, C.c_int64
+        P = C.POINTER
+        sig = {
+            "ma_device_count": [P(C.c_int)],
+            "ma_bem_assemble_tbem": [P(ma_mesh_t), P(ma_physics_t), dbl, dbl, vp, vp],
+            "ma_bem_plan_create": [P(ma_mesh_t), C.c_int, P(vp)],
+            "ma_bem_plan_destroy": [vp],
+            "ma_bem_plan_num_dofs": [vp, P(i32)],
+            "ma_bem_plan_num_near_pairs": [vp, P(i64)],
+            "ma_bem_plan_assemble_dev": [vp, P(ma_physics_t), dbl, dbl, vp, vp, vp],
+            "ma_bem_plan_incident_rhs_dev": [vp, P(ma_physics_t), dbl, dbl, C.c_int, vp, dbl, dbl, C.c_int, vp, vp],
+            "ma_bem_incident_rhs": [C.c_int, vp, vp, P(ma_physics_t), dbl, dbl, C.c_int, vp, dbl, dbl, vp],
+            "ma_bem_plan_probe_pairs": [vp, P(ma_physics_t), i64, vp, vp],
+            "ma_bem_plan_probe_self": [vp, P(ma_physics_t), vp],
+            "ma_bem_plan_get_near_pairs": [vp, vp],
+            "ma_bem_plan_set_timing": [vp, C.c_int],
+            "ma_bem_plan_last_timing": [vp, vp],
+            "ma_zgesv": [i32, vp, vp, vp],
+            "ma_lu_plan_create": [i32, C.c_int, P(vp)],
+            "ma_lu_plan_destroy": [vp],
+            "ma_lu_plan_factor_solve_dev": [vp, vp, vp, i32, vp],
+            "ma_lu_plan_status": [vp, vp],
+            "ma_lu_plan_set_timing": [vp, C.c_int],
+            "ma_lu_plan_last_timing": [vp, vp],
+        }
+        for name, args in sig.items():
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.argtypes = args
+                f.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != MA_OK:
+        raise MaError(status, lib().ma_last_error_string().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().ma_device_count(C.byref(n)))
+    return n.value
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class MeshArrays:
+    """Keeps the NumPy arrays behind an ma_mesh_t alive (the C side only borrows them)."""
+
+    def __init__(self, nodes, conn, center, normal, area, dof=None, bc_type=None, bc_values=None, bc_len=None, is_eval=None):
+        n = int(np.asarray(conn).shape[0])
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.center = np.ascontiguousarray(center, dtype=np.float64)
+        self.normal = np.ascontiguousarray(normal, dtype=np.float64)
+        self.area = np.ascontiguousarray(area, dtype=np.float64)
+        self.dof = np.ascontiguousarray(np.arange(n) if dof is None else dof, dtype=np.int32)
+        self.bc_type = np.ascontiguousarray(np.zeros(n) if bc_type is None else bc_type, dtype=np.uint8)
+        self.bc_values = None if bc_values is None else np.ascontiguousarray(bc_values, dtype=np.complex128)
+        self.bc_len = None if bc_len is None else np.ascontiguousarray(bc_len, dtype=np.int32)
+        self.is_eval = None if is_eval is None else np.ascontiguousarray(is_eval, dtype=np.uint8)
+        self.n_elem = n
+        self.c = ma_mesh_t(self.nodes.shape[0], _vp(self.nodes), n, _vp(self.conn), _vp(self.center), _vp(self.normal),
+                           _vp(self.area), _vp(self.dof), _vp(self.bc_type), _vp(self.bc_values), _vp(self.bc_len),
+                           _vp(self.is_eval))
+
+
+def physics(k, harmonic=1.0, tau=1.0, gamma=1.0):
+    return ma_physics_t(float(k), float(harmonic), float(tau), float(gamma))
+
+
+def assemble_tbem(mesh, k, beta, harmonic=1.0, tau=1.0):
+    """Host-buffer drop-in of build_tbem_system_with_beta (tbem.rs:96): returns (A, rhs)."""
+    nd = mesh.n_elem if mesh.is_eval is None else int((mesh.is_eval == 0).sum())
+    A = np.empty((nd, nd), dtype=np.complex128)
+    rhs = np.empty(nd, dtype=np.complex128)
+    ph = physics(k, harmonic, tau)
+    beta = complex(beta)
+    check(lib().ma_bem_assemble_tbem(C.byref(mesh.c), C.byref(ph), beta.real, beta.imag, _vp(A), _vp(rhs)))
+    return A, rhs
+
+
+def incident_rhs(centers, normals, k, beta, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, harmonic=1.0, tau=1.0):
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    normals = np.ascontiguousarray(normals, dtype=np.float64)
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    out = np.empty(centers.shape[0], dtype=np.complex128)
+    ph = physics(k, harmonic, tau)
+    beta = complex(beta); amp = complex(amp)
+    check(lib().ma_bem_incident_rhs(centers.shape[0], _vp(centers), _vp(normals), C.byref(ph), beta.real, beta.imag,
+                                    kind, _vp(v), amp.real, amp.imag, _vp(out)))
+    return out
+
+
+class BemPlan:
+    """ma_bem_plan_t: geometry + near-pair plan resident in HBM; assemble per frequency."""
+
+    def __init__(self, mesh, device=0):
+        self.mesh = mesh
+        self.h = C.c_void_p()
+        check(lib().ma_bem_plan_create(C.byref(mesh.c), device, C.byref(self.h)))
+        n = C.c_int32()
+        check(lib().ma_bem_plan_num_dofs(self.h, C.byref(n)))
+        self.num_dofs = n.value
+        m = C.c_int64()
+        check(lib().ma_bem_plan_num_near_pairs(self.h, C.byref(m)))
+        self.num_near_pairs = m.value
+
+    def close(self):
+        if self.h:
+            lib().ma_bem_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def assemble_dev(self, k, beta, d_A, d_rhs, stream=0, harmonic=1.0, tau=1.0):
+        ph = physics(k, harmonic, tau); beta = complex(beta)
+        check(lib().ma_bem_plan_assemble_dev(self.h, C.byref(ph), beta.real, beta.imag, C.c_void_p(d_A), C.c_void_p(d_rhs),
+                                             C.c_void_p(stream)))
+
+    def incident_rhs_dev(self, k, beta, d_rhs, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=0,
+                         harmonic=1.0, tau=1.0):
+        ph = physics(k, harmonic, tau); beta = complex(beta); amp = complex(amp)
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        check(lib().ma_bem_plan_incident_rhs_dev(self.h, C.byref(ph), beta.real, beta.imag, kind, _vp(v), amp.real, amp.imag,
+                                                 1 if accumulate else 0, C.c_void_p(d_rhs), C.c_void_p(stream)))
+
+    def probe_pairs(self, k, pairs, harmonic=1.0, tau=1.0):
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((pairs.shape[0], 5), dtype=np.complex128)
+        ph = physics(k, harmonic, tau)
+        check(lib().ma_bem_plan_probe_pairs(self.h, C.byref(ph), pairs.shape[0], _vp(pairs), _vp(out)))
+        return out
+
+    def probe_self(self, k, harmonic=1.0, tau=1.0):
+        out = np.empty((self.num_dofs, 5), dtype=np.complex128)
+        ph = physics(k, harmonic, tau)
+        check(lib().ma_bem_plan_probe_self(self.h, C.byref(ph), _vp(out)))
+        return out
+
+    def near_pairs(self):
+        out = np.empty((self.num_near_pairs, 2), dtype=np.int32)
+        check(lib().ma_bem_plan_get_near_pairs(self.h, _vp(out)))
+        return out
+
+    def set_timing(self, on=True):
+        check(lib().ma_bem_plan_set_timing(self.h, 1 if on else 0))
+
+    def last_timing(self):
+        out = np.zeros(3)
+        check(lib().ma_bem_plan_last_timing(self.h, _vp(out)))
+        return out
+
+
+def zgesv(A, b):
+    """Host-buffer drop-in of lu_solve (lu.rs:142): returns x; raises MaError(MA_ERR_SINGULAR / MA_ERR_DIM)."""
+    A = np.array(A, dtype=np.complex128, order="C")
+    x = np.array(b, dtype=np.complex128)
+    if A.ndim != 2 or A.shape[0] != A.shape[1] or x.shape != (A.shape[0],):
+        raise MaError(MA_ERR_DIM, "A must be n x n and b of length n")
+    check(lib().ma_zgesv(A.shape[0], _vp(A), _vp(x), None))
+    return x
+
+
+class LuPlan:
+    """ma_lu_plan_t: workspace for device-resident factor+solve of an n x n complex128 system."""
+
+    def __init__(self, n, device=0):
+        self.n = n
+        self.h = C.c_void_p()
+        check(lib().ma_lu_plan_create(n, device, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ma_lu_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def factor_solve_dev(self, d_A, d_B, nrhs=1, stream=0):
+        check(lib().ma_lu_plan_factor_solve_dev(self.h, C.c_void_p(d_A), C.c_void_p(d_B), nrhs, C.c_void_p(stream)))
+
+    def status(self, stream=0):
+        return lib().ma_lu_plan_status(self.h, C.c_void_p(stream))
+
+    def set_timing(self, on=True):
+        check(lib().ma_lu_plan_set_timing(self.h, 1 if on else 0))
+
+    def last_timing(self):
+        out = np.zeros(6)
+        check(lib().ma_lu_plan_last_timing(self.h, _vp(out)))
+        return out

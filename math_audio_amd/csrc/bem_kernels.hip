@@ -1,0 +1,536 @@
+// bem_kernels.hip — TBEM (Burton–Miller) dense assembly kernels for gfx950.
+//
+// What is computed follows the reference's build_tbem_system_with_beta
+// (math-bem/src/core/assembly/tbem.rs:96-222) and the panel integrals it calls
+// (integration/regular.rs:33-182, integration/singular.rs:123-394, :497-660). How it is
+// computed is laid out for CDNA4:
+//   K1 tbem_far_kernel   every (collocation i, field panel j) pair with the un-subdivided
+//                        13-point rule; one lane per field panel (coalesced 16-B stores along
+//                        a matrix row), the collocation point in SGPRs, a strip of rows per block.
+//   K2 tbem_near_kernel  one wavefront per near pair (level-0 distance ratio < 3): the
+//                        reference's level-by-level 4-way subdivision run lane-per-triangle
+//                        (<= 60 per level fits one 64-wide wave), leaves collected in LDS, then
+//                        all (leaf, point) tasks spread over the lanes and reduced with DPP
+//                        butterflies. Overwrites the K1 value.
+//   K3 tbem_self_kernel  one wavefront per panel for the singular self term (edge line
+//                        integrals + collapsed-square sub-triangle rule) plus the free term.
+// The near-pair list depends on geometry only and is built once per mesh (plan kernels below).
+#include "bem_kernels.hpp"
+#include "ma_device_math.hpp"
+
+namespace ma {
+
+// ------------------------------------------------------------------ constant tables (device)
+// 13-point triangle rule, weights already scaled by 0.5 (reference gauss.rs:67-89, 386-400);
+// uploaded by bem_upload_tables().
+__constant__ double c_tri13[13][3];
+__constant__ double c_gl_x[94];
+__constant__ double c_gl_w[94];
+__constant__ int c_gl_index[21][2];
+
+int bem_upload_tables(const double tri13_scaled[13][3], const double* glx, const double* glw, const int glidx[21][2]) {
+  MA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tri13), tri13_scaled, sizeof(double) * 39));
+  MA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gl_x), glx, sizeof(double) * 94));
+  MA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gl_w), glw, sizeof(double) * 94));
+  MA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_gl_index), glidx, sizeof(int) * 42));
+  return MA_OK;
+}
+
+#define MA_INV4PI 0.07957747154594767280
+
+// ------------------------------------------------------------------ per-point Green's kernels
+// One quadrature point of regular.rs:113-154 given d = y - x, the weight w (= rule weight x
+// Jacobian / 4pi), the two normals and m = n_x . n_y. Accumulates G, dG/dn_y, dG/dn_x, d2G/dn_x dn_y.
+struct Acc4 { dc g, h, ht, e; };
+
+__device__ __forceinline__ void green_point(double dx, double dy, double dz, double w4pi, double k, double k2,
+                                            double nyx, double nyy, double nyz, double nxx, double nxy, double nxz,
+                                            double m, Acc4& acc) {
+  double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+  if (!(r2 >= 1e-30)) return;                       // dis_fsp < 1e-15 -> continue (regular.rs:120)
+  double r, ri;
+  sqrt_rsqrt(r2, r, ri);
+  double sn, cs;
+  sincos_fast(k * r, sn, cs);
+  double gsc = w4pi * ri;
+  double gre = cs * gsc, gim = sn * gsc;             // zg
+  // zhh_base = zg * (-1/r + i k)
+  double bre = -(gre * ri) - gim * k;
+  double bim = gre * k - gim * ri;
+  double a = (dx * nyx + dy * nyy + dz * nyz) * ri;  // (y-x).n_y / r
+  double b = -((dx * nxx + dy * nxy + dz * nxz) * ri);
+  double rq = a * b;
+  double ri2 = ri * ri;
+  double fr = (3.0 * ri2 - k2) * rq + m * ri2;
+  double fi = -(k * ri) * (3.0 * rq + m);
+  acc.g.re += gre; acc.g.im += gim;
+  acc.h.re = __builtin_fma(bre, a, acc.h.re); acc.h.im = __builtin_fma(bim, a, acc.h.im);
+  acc.ht.re = __builtin_fma(bre, b, acc.ht.re); acc.ht.im = __builtin_fma(bim, b, acc.ht.im);
+  acc.e.re += gre * fr - gim * fi;
+  acc.e.im += gre * fi + gim * fr;
+}
+
+// Burton–Miller coefficient of one pair (assemble_tbem, tbem.rs:311-345; sign switch :203)
+__device__ __forceinline__ dc bm_coeff(const Acc4& s, int field_bc, const BemPhys& ph) {
+  double gt = ph.gamma * ph.tau;
+  if (field_bc == 0) {
+    dc hh = s.h * ph.sign;
+    return dc_make(hh.re * gt + (s.e.re * ph.beta_re - s.e.im * ph.beta_im),
+                   hh.im * gt + (s.e.re * ph.beta_im + s.e.im * ph.beta_re));
+  } else if (field_bc == 1) {
+    return dc_make(-(s.g.re * gt + (s.ht.re * ph.beta_re - s.ht.im * ph.beta_im)),
+                   -(s.g.im * gt + (s.ht.re * ph.beta_im + s.ht.im * ph.beta_re)));
+  }
+  return dc_make(0.0, 0.0);
+}
+
+// ------------------------------------------------------------------ K1: far pairs
+// grid.x: strips of 256 field panels, grid.y: strips of `rows_per_block` collocation rows.
+__global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block) {
+  const int np = g.np;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = j < np;
+  const int jj = valid ? j : np - 1;
+  const double p0x = g.p0[0][jj], p0y = g.p0[1][jj], p0z = g.p0[2][jj];
+  const double e1x = g.e1[0][jj], e1y = g.e1[1][jj], e1z = g.e1[2][jj];
+  const double e2x = g.e2[0][jj], e2y = g.e2[1][jj], e2z = g.e2[2][jj];
+  const double nyx = g.ny[0][jj], nyy = g.ny[1][jj], nyz = g.ny[2][jj];
+  const double jw = g.jac[jj] * MA_INV4PI;
+  const int fbc = g.bc_type[jj];
+  const long long col = g.dof[jj];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;   // wavruim, k^2 (regular.rs:44-45)
+  const int i0 = blockIdx.y * rows_per_block;
+  const int i1 = min(i0 + rows_per_block, np);
+  for (int i = i0; i < i1; ++i) {
+    // wave-uniform collocation data (scalar loads)
+    const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+    const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+    const double d0x = p0x - cx, d0y = p0y - cy, d0z = p0z - cz;
+    const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+    Acc4 s;
+    s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < 13; ++q) {
+      const double xi = c_tri13[q][0], eta = c_tri13[q][1], w = c_tri13[q][2];
+      double dx = __builtin_fma(eta, e2x, __builtin_fma(xi, e1x, d0x));
+      double dy = __builtin_fma(eta, e2y, __builtin_fma(xi, e1y, d0y));
+      double dz = __builtin_fma(eta, e2z, __builtin_fma(xi, e1z, d0z));
+      green_point(dx, dy, dz, w * jw, k, k2, nyx, nyy, nyz, nxx, nxy, nxz, m, s);
+    }
+    dc coeff = bm_coeff(s, fbc, ph);
+    if (valid) A[(long long)g.dof[i] * g.nd + col] = coeff;
+  }
+}
+
+// ------------------------------------------------------------------ level-0 near test
+// Bit-for-bit the reference's criterion (singular.rs:542-556 at the first level): centre of the
+// un-split element in local coordinates, mapped with the shape functions, distance to the
+// collocation point divided by sqrt(area). Contraction is off so that every product and sum is
+// rounded exactly as the CPU restatement rounds it: the decision, not just the value, must agree.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double tri_ratio(double s0, double t0, double s1, double t1, double s2, double t2,
+                                            const double* v /* p0,p1,p2 = 9 */, double cx, double cy, double cz,
+                                            double sq_arels) {
+  double scent = (((0.0 + s0) + s1) + s2) / 3.0;
+  double tcent = (((0.0 + t0) + t1) + t2) / 3.0;
+  double n0 = 1.0 - scent - tcent;
+  double px = ((0.0 + n0 * v[0]) + scent * v[3]) + tcent * v[6];
+  double py = ((0.0 + n0 * v[1]) + scent * v[4]) + tcent * v[7];
+  double pz = ((0.0 + n0 * v[2]) + scent * v[5]) + tcent * v[8];
+  double dx = px - cx, dy = py - cy, dz = pz - cz;
+  double dist = __builtin_sqrt(((0.0 + dx * dx) + dy * dy) + dz * dz);
+  return dist / sq_arels;
+}
+
+__device__ __forceinline__ bool pair_is_near(const BemGeom& g, int i, int j) {
+  double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
+  double faclin = 2.0 * 0.5;
+  double arels = g.area[j] * faclin * faclin;
+  double r = tri_ratio(0.0, 0.0, 1.0, 0.0, 0.0, 1.0, v, g.c[0][i], g.c[1][i], g.c[2][i], __builtin_sqrt(arels));
+  return r < 3.0;
+}
+#pragma clang fp contract(fast)
+
+// One wavefront per collocation row: count / list the field panels j != i that need subdivision.
+// pass 0: counts[i]; pass 1: pairs[offsets[i] + ...] in increasing j.
+__global__ __launch_bounds__(256) void near_list_kernel(BemGeom g, int pass, int* __restrict__ counts,
+                                                        const long long* __restrict__ offsets, int2* __restrict__ pairs) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= g.np) return;
+  long long base = pass ? offsets[i] : 0;
+  int cnt = 0;
+  for (int j0 = 0; j0 < g.np; j0 += 64) {
+    int j = j0 + lane;
+    bool near = (j < g.np) && (j != i) && pair_is_near(g, i, j);
+    unsigned long long m = __ballot(near);
+    if (pass && near) {
+      int pos = __popcll(m & lanemask_lt());
+      pairs[base + cnt + pos] = make_int2(i, j);
+    }
+    cnt += __popcll(m);
+  }
+  if (!pass && lane == 0) counts[i] = cnt;
+}
+
+// ------------------------------------------------------------------ K2: near pairs
+// LDS per wave: leaf list (110 x 6 doubles) and the next level's slots (60 x 6 doubles).
+#define MA_MAX_LEAVES 110
+#define MA_MAX_NSE 60
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// PROBE = true: instead of the matrix entry, write the leaf count and the four raw integrals
+// (G, H, H^T, E) of pair pid to out[5*pid..] — used by the parity tests on arbitrary (i != j) pairs.
+template <bool PROBE>
+__global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs,
+                                                        long long npairs, dc* __restrict__ A) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][6];
+  __shared__ double s_next[4][MA_MAX_NSE][6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;                         // whole wave leaves; no block barrier below
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
+  const double area = g.area[j];
+
+  // ---- generate_subelements (singular.rs:497-660), one lane per sub-triangle of the level
+  double s0 = 0.0, t0 = 0.0, s1 = 1.0, t1 = 0.0, s2 = 0.0, t2 = 1.0;
+  int nsel = 1, nleaf = 0;
+  double faclin = 2.0;
+  for (;;) {
+    faclin *= 0.5;
+    double sq;
+    {
+#pragma clang fp contract(off)
+      double arels = area * faclin * faclin;
+      sq = __builtin_sqrt(arels);
+    }
+    const bool active = lane < nsel;
+    double ratio = active ? tri_ratio(s0, t0, s1, t1, s2, t2, v, cx, cy, cz, sq) : 1e300;
+    const bool split = active && (ratio < 3.0);
+    const unsigned long long smask = __ballot(split);
+    const int nsplit = __popcll(smask);
+    const int rank = __popcll(smask & lanemask_lt());
+    // `ndie > 15 => break` abandons the rest of the level from the 16th element that wants a split
+    int cut = 64;
+    if (nsplit > 15) {
+      unsigned long long mm = smask;
+      for (int q = 0; q < 15; ++q) mm &= mm - 1;     // clear the 15 lowest set bits
+      cut = __builtin_ctzll(mm);
+    }
+    const bool isleaf = active && !split && lane < cut;
+    const unsigned long long lmask = __ballot(isleaf);
+    const int lrank = nleaf + __popcll(lmask & lanemask_lt());
+    if (isleaf && lrank < MA_MAX_LEAVES) {
+      double* L = s_leaf[wave][lrank];
+      L[0] = s0; L[1] = t0; L[2] = s1; L[3] = t1; L[4] = s2; L[5] = t2;
+    }
+    nleaf += __popcll(lmask);
+    if (nleaf >= MA_MAX_LEAVES) { nleaf = MA_MAX_LEAVES; break; }   // early return at 110 stored
+    if (nsplit == 0) break;
+    if (split && rank < 15) {
+      // midpoints m0=(v0+v1)/2, m1=(v1+v2)/2, m2=(v2+v0)/2; children in slot order
+      // [v0,m0,m2] [v1,m1,m0] [v2,m2,m1] [m0,m1,m2]   (singular.rs:567-611)
+      double m0s = (s0 + s1) / 2.0, m0t = (t0 + t1) / 2.0;
+      double m1s = (s1 + s2) / 2.0, m1t = (t1 + t2) / 2.0;
+      double m2s = (s2 + s0) / 2.0, m2t = (t2 + t0) / 2.0;
+      double* Cn = s_next[wave][rank * 4];
+      Cn[0] = s0;  Cn[1] = t0;  Cn[2] = m0s; Cn[3] = m0t; Cn[4] = m2s; Cn[5] = m2t;
+      Cn[6] = s1;  Cn[7] = t1;  Cn[8] = m1s; Cn[9] = m1t; Cn[10] = m0s; Cn[11] = m0t;
+      Cn[12] = s2; Cn[13] = t2; Cn[14] = m2s; Cn[15] = m2t; Cn[16] = m1s; Cn[17] = m1t;
+      Cn[18] = m0s; Cn[19] = m0t; Cn[20] = m1s; Cn[21] = m1t; Cn[22] = m2s; Cn[23] = m2t;
+    }
+    wave_lds_sync();
+    nsel = (nsplit > 15 ? 15 : nsplit) * 4;
+    if (lane < nsel) {
+      const double* Cn = s_next[wave][lane];
+      s0 = Cn[0]; t0 = Cn[1]; s1 = Cn[2]; t1 = Cn[3]; s2 = Cn[4]; t2 = Cn[5];
+    }
+    wave_lds_sync();
+  }
+  wave_lds_sync();
+
+  // ---- integrate: tasks = (leaf, point); affine map of the 13-point rule into each leaf
+  // (regular.rs:76-96), shape functions of the parent triangle (regular.rs:193-260).
+  const double e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
+  const double e2x = v[6] - v[0], e2y = v[7] - v[1], e2z = v[8] - v[2];
+  const double nyx = g.ny[0][j], nyy = g.ny[1][j], nyz = g.ny[2][j];
+  const double jw = g.jac[j] * MA_INV4PI;
+  const double d0x = v[0] - cx, d0y = v[1] - cy, d0z = v[2] - cz;
+  const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  Acc4 s;
+  s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+  const int ntask = nleaf * 13;
+  for (int t = lane; t < ntask; t += 64) {
+    const int lf = t / 13, q = t - lf * 13;
+    const double* L = s_leaf[wave][lf];
+    const double a0 = L[0], b0 = L[1], a1 = L[2], b1 = L[3], a2 = L[4], b2 = L[5];
+    const double xi = c_tri13[q][0], eta = c_tri13[q][1], w = c_tri13[q][2];
+    const double l0 = 1.0 - xi - eta;
+    const double xio = a0 * l0 + a1 * xi + a2 * eta;
+    const double eto = b0 * l0 + b1 * xi + b2 * eta;
+    const double det = __builtin_fabs((a1 - a0) * (b2 - b0) - (a2 - a0) * (b1 - b0));
+    double dx = __builtin_fma(eto, e2x, __builtin_fma(xio, e1x, d0x));
+    double dy = __builtin_fma(eto, e2y, __builtin_fma(xio, e1y, d0y));
+    double dz = __builtin_fma(eto, e2z, __builtin_fma(xio, e1z, d0z));
+    green_point(dx, dy, dz, w * det * jw, k, k2, nyx, nyy, nyz, nxx, nxy, nxz, m, s);
+  }
+  s.g.re = wave_sum(s.g.re); s.g.im = wave_sum(s.g.im);
+  s.h.re = wave_sum(s.h.re); s.h.im = wave_sum(s.h.im);
+  s.ht.re = wave_sum(s.ht.re); s.ht.im = wave_sum(s.ht.im);
+  s.e.re = wave_sum(s.e.re); s.e.im = wave_sum(s.e.im);
+  if (lane == 0) {
+    if (PROBE) {
+      dc* o = A + 5 * pid;
+      o[0] = dc_make((double)nleaf, 0.0); o[1] = s.g; o[2] = s.h; o[3] = s.ht; o[4] = s.e;
+    } else {
+      A[(long long)g.dof[i] * g.nd + g.dof[j]] = bm_coeff(s, g.bc_type[j], ph);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K3: self terms
+// singular_integration_with_params (singular.rs:154-394) for Tri3, QuadratureParams::for_ka (:48-82)
+// from ka = k x mean edge length (:730-745). One wavefront per panel; the flattened point list
+// (3 edges x [edge-line points | sub-triangle tensor points]) is strided over the lanes.
+__device__ __constant__ double c_csi6[6] = {0.0, 1.0, 0.0, 0.5, 0.5, 0.0};
+__device__ __constant__ double c_eta6[6] = {0.0, 0.0, 1.0, 0.0, 0.5, 0.5};
+
+template <bool PROBE>
+__global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + wave;
+  if (e >= g.np) return;
+  const double cx = g.c[0][e], cy = g.c[1][e], cz = g.c[2][e];
+  const double nxx = g.nx[0][e], nxy = g.nx[1][e], nxz = g.nx[2][e];
+  const double P[3][3] = {{g.p0[0][e], g.p0[1][e], g.p0[2][e]}, {g.p1[0][e], g.p1[1][e], g.p1[2][e]}, {g.p2[0][e], g.p2[1][e], g.p2[2][e]}};
+  const double nyx = g.ny[0][e], nyy = g.ny[1][e], nyz = g.ny[2][e];
+  const double jac = g.jac[e];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  // mean edge length -> quadrature tier
+  double el = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int b = (a + 1) % 3;
+    double ddx = P[b][0] - P[a][0], ddy = P[b][1] - P[a][1], ddz = P[b][2] - P[a][2];
+    el += __builtin_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+  }
+  const double ka = ph.k * (el / 3.0);
+  int ngpo1, ngausin, nsec1, nsec2;
+  if (ka < 0.3)      { ngpo1 = 3; ngausin = 4; nsec1 = 4;  nsec2 = 2; }
+  else if (ka < 1.0) { ngpo1 = 4; ngausin = 5; nsec1 = 6;  nsec2 = 2; }
+  else if (ka < 2.0) { ngpo1 = 5; ngausin = 6; nsec1 = 8;  nsec2 = 3; }
+  else               { ngpo1 = 6; ngausin = 7; nsec1 = 10; nsec2 = 4; }
+  const int eo = c_gl_index[ngpo1][0], so = c_gl_index[ngausin][0];
+  const int ne = c_gl_index[ngpo1][1], ns = c_gl_index[ngausin][1];
+  const int n_edge_pts = nsec1 * ne;
+  const int per_edge = n_edge_pts + nsec2 * ns * ns;
+  const int ntask = 3 * per_edge;
+  const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+
+  dc sg = dc_make(0, 0), sh = dc_make(0, 0), sht = dc_make(0, 0), se = dc_make(0, 0);
+  for (int t = lane; t < ntask; t += 64) {
+    const int ieg = t / per_edge;
+    const int u = t - ieg * per_edge;
+    const int ig1 = (ieg + 1) % 3, ig2 = ieg + 3;
+    if (u < n_edge_pts) {
+      // ---- hypersingular part as an edge line integral (singular.rs:182-254)
+      const int isec = u / ne, ig = u - isec * ne;
+      double dpx = P[ig1][0] - P[ieg][0], dpy = P[ig1][1] - P[ieg][1], dpz = P[ig1][2] - P[ieg][2];
+      double len = __builtin_sqrt(dpx * dpx + dpy * dpy + dpz * dpz);
+      double ox = dpx / len, oy = dpy / len, oz = dpz / len;
+      double lens = len / (2.0 * (double)nsec1);
+      double delsec = 2.0 / (double)nsec1;
+      double secmid = -1.0 - delsec / 2.0;
+      for (int q = 0; q <= isec; ++q) secmid += delsec;
+      double sga = secmid + c_gl_x[eo + ig] / (double)nsec1;
+      double wga = c_gl_w[eo + ig] * lens;
+      double f = (sga + 1.0) / 2.0;
+      double dx = (P[ieg][0] + dpx * f) - cx, dy = (P[ieg][1] + dpy * f) - cy, dz = (P[ieg][2] + dpz * f) - cz;
+      double r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 >= 1e-30) {
+        double r, ri; sqrt_rsqrt(r2, r, ri);
+        double sn, cs; sincos_fast(k * r, sn, cs);
+        double gs = MA_INV4PI * ri;
+        double gre = cs * gs, gim = sn * gs;
+        double fre = -(gre * ri) - gim * k, fim = gre * k - gim * ri;   // zg * (-1/r + ik)
+        double ux = dx * ri, uy = dy * ri, uz = dz * ri;
+        // ((grad G) x edge_dir) . n_x  = zg_factor * ((u x o) . n_x)
+        double wx = uy * oz - uz * oy, wy = uz * ox - ux * oz, wz = ux * oy - uy * ox;
+        double sc = (wx * nxx + wy * nxy + wz * nxz) * wga;
+        se.re += fre * sc; se.im += fim * sc;
+      }
+    } else {
+      // ---- G, H, H^T on the collapsed-square sub-triangles (singular.rs:257-357)
+      const int v2 = u - n_edge_pts;
+      const int isec = v2 / (ns * ns);
+      const int ij = v2 - isec * ns * ns;
+      const int ii = ij / ns, jj = ij - ii * ns;
+      const double aresub = 1.0 / 24.0 / (double)nsec2;
+      const double ss0 = 1.0 / 3.0, ts0 = 1.0 / 3.0;
+      double ss1, ss2, ts1, ts2;
+      if (isec == 0) { ss1 = c_csi6[ieg]; ss2 = c_csi6[ig2]; ts1 = c_eta6[ieg]; ts2 = c_eta6[ig2]; }
+      else           { ss1 = c_csi6[ig2]; ss2 = c_csi6[ig1]; ts1 = c_eta6[ig2]; ts2 = c_eta6[ig1]; }
+      const double sga = c_gl_x[so + ii], tga = c_gl_x[so + jj];
+      const double wei = c_gl_w[so + ii] * c_gl_w[so + jj];
+      const double sgg = 0.5 * (1.0 - sga) * ss0 + 0.25 * (1.0 + sga) * ((1.0 - tga) * ss1 + (1.0 + tga) * ss2);
+      const double tgg = 0.5 * (1.0 - sga) * ts0 + 0.25 * (1.0 + sga) * ((1.0 - tga) * ts1 + (1.0 + tga) * ts2);
+      const double n0 = 1.0 - sgg - tgg;
+      double dx = (n0 * P[0][0] + sgg * P[1][0] + tgg * P[2][0]) - cx;
+      double dy = (n0 * P[0][1] + sgg * P[1][1] + tgg * P[2][1]) - cy;
+      double dz = (n0 * P[0][2] + sgg * P[1][2] + tgg * P[2][2]) - cz;
+      const double wga = wei * (1.0 + sga) * aresub * jac;
+      double r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 >= 1e-30) {
+        double r, ri; sqrt_rsqrt(r2, r, ri);
+        double sn, cs; sincos_fast(k * r, sn, cs);
+        double gs = wga * MA_INV4PI * ri;
+        double gre = cs * gs, gim = sn * gs;
+        double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
+        double a = (dx * nyx + dy * nyy + dz * nyz) * ri;
+        double b = -((dx * nxx + dy * nxy + dz * nxz) * ri);
+        sg.re += gre; sg.im += gim;
+        sh.re += bre * a; sh.im += bim * a;
+        sht.re += bre * b; sht.im += bim * b;
+        se.re += gre * k2 * m; se.im += gim * k2 * m;       // E += zg k^2 (n_x . n_y)  (singular.rs:357)
+      }
+    }
+  }
+  Acc4 s;
+  s.g = dc_make(wave_sum(sg.re), wave_sum(sg.im));
+  s.h = dc_make(wave_sum(sh.re), wave_sum(sh.im));
+  s.ht = dc_make(wave_sum(sht.re), wave_sum(sht.im));
+  s.e = dc_make(wave_sum(se.re), wave_sum(se.im));
+  if (PROBE) {
+    if (lane == 0) {
+      dc* o = A + 5 * (long long)e;
+      o[0] = dc_make((double)ntask, 0.0); o[1] = s.g; o[2] = s.h; o[3] = s.ht; o[4] = s.e;
+    }
+    return;
+  }
+  if (lane == 0) {
+    const int bc = g.bc_type[e];
+    dc coeff = bm_coeff(s, bc, ph);
+    // free term (add_free_terms, tbem.rs:273-304): velocity -gamma/2, pressure -beta tau/2
+    dc fr = dc_make(0.0, 0.0);
+    if (bc == 0) fr = dc_make(-(ph.gamma * 0.5), 0.0);
+    else if (bc == 1) fr = dc_make(-(ph.beta_re * ph.tau * 0.5), -(ph.beta_im * ph.tau * 0.5));
+    const long long d = g.dof[e];
+    A[d * g.nd + d] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
+  }
+}
+
+// ------------------------------------------------------------------ right-hand sides
+__global__ void fill_zero_kernel(dc* __restrict__ v, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = dc_make(0.0, 0.0);
+}
+
+// IncidentField::compute_rhs_with_beta (incident.rs:317-342), plane wave (:103-117,188-207) or
+// point source (:119-133,209-233); rhs = -(gamma p + beta tau dp/dn)
+__global__ void incident_rhs_kernel(BemGeom g, BemPhys ph, int kind, double vx, double vy, double vz,
+                                    double are, double aim, int accumulate, dc* __restrict__ rhs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.np) return;
+  const double px = g.c[0][i], py = g.c[1][i], pz = g.c[2][i];
+  const double nx = g.nx[0][i], ny = g.nx[1][i], nz = g.nx[2][i];
+  const double k = ph.k;
+  dc p = dc_make(0.0, 0.0), d = dc_make(0.0, 0.0);
+  if (kind == 0) {
+    double kdx = k * (vx * px + vy * py + vz * pz);
+    double kdn = k * (vx * nx + vy * ny + vz * nz);
+    double sn, cs; sincos(kdx, &sn, &cs);
+    p = dc_make(are, aim) * dc_make(cs, sn);
+    d = dc_make(0.0, kdn) * p;
+  } else {
+    double dx = px - vx, dy = py - vy, dz = pz - vz;
+    double r = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
+    if (r > 1e-10) {
+      double kr = k * r;
+      double sn, cs; sincos(kr, &sn, &cs);
+      double den = 4.0 * 3.14159265358979323846 * r;
+      dc gg = dc_make(cs / den, sn / den);
+      p = dc_make(are, aim) * gg;
+      dc dgdr = dc_make(-1.0 / r, k) * gg;
+      double drdn = (dx * nx + dy * ny + dz * nz) / r;
+      d = (dc_make(are, aim) * dgdr) * drdn;
+    }
+  }
+  dc bt = dc_make(ph.beta_re * ph.tau, ph.beta_im * ph.tau);
+  dc v = dc_neg(p * ph.gamma + bt * d);
+  const long long di = g.dof[i];
+  if (accumulate) v = v + rhs[di];
+  rhs[di] = v;
+}
+
+// ------------------------------------------------------------------ launchers
+int bem_launch_near_list(const BemGeom& g, int pass, int* counts, const long long* offsets, int2* pairs, hipStream_t st) {
+  dim3 grid((g.np + 3) / 4), block(256);
+  hipLaunchKernelGGL(near_list_kernel, grid, block, 0, st, g, pass, counts, offsets, pairs);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) {
+  const int rpb = 32;
+  dim3 grid((g.np + 255) / 256, (g.np + rpb - 1) / rpb), block(256);
+  hipLaunchKernelGGL(tbem_far_kernel, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A), rpb);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st) {
+  if (npairs <= 0) return MA_OK;
+  dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
+  hipLaunchKernelGGL(tbem_near_kernel<false>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st) {
+  if (npairs <= 0) return MA_OK;
+  dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
+  hipLaunchKernelGGL(tbem_near_kernel<true>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out5));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st) {
+  dim3 grid((g.np + 3) / 4), block(256);
+  hipLaunchKernelGGL(tbem_self_kernel<true>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out5));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) {
+  dim3 grid((g.np + 3) / 4), block(256);
+  hipLaunchKernelGGL(tbem_self_kernel<false>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_zero(c64* v, int n, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<dc*>(v), n);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int bem_launch_incident(const BemGeom& g, const BemPhys& ph, int kind, const double* v, double are, double aim,
+                        int accumulate, c64* rhs, hipStream_t st) {
+  hipLaunchKernelGGL(incident_rhs_kernel, dim3((g.np + 255) / 256), dim3(256), 0, st, g, ph, kind, v[0], v[1], v[2],
+                     are, aim, accumulate, reinterpret_cast<dc*>(rhs));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+}  // namespace ma

@@ -1,0 +1,46 @@
+// bem_kernels.hpp — device-side views and launchers of the TBEM assembly kernels.
+#pragma once
+#include "ma_common.hpp"
+
+namespace ma {
+
+// Panel geometry in HBM, structure-of-arrays over the np non-evaluation Tri3 panels.
+// Field side (integration over panel j): vertices p0,p1,p2 in connectivity order, edges
+// e1 = p1-p0, e2 = p2-p0, n_y = (e1 x e2)/|e1 x e2| (NOT flipped, regular.rs:249-257),
+// jac = |e1 x e2|. Collocation side (row i): stored centre c and stored outward-flipped
+// normal nx (generators.rs:590-600), stored area (subdivision criterion, singular.rs:535).
+struct BemGeom {
+  int np;                 // panels
+  int nd;                 // num_dofs (== np) = leading dimension of A
+  const double* p0[3];
+  const double* p1[3];
+  const double* p2[3];
+  const double* e1[3];
+  const double* e2[3];
+  const double* ny[3];
+  const double* jac;
+  const double* c[3];
+  const double* nx[3];
+  const double* area;
+  const int* dof;
+  const unsigned char* bc_type;
+};
+
+struct BemPhys {
+  double k, harmonic, tau, gamma;
+  double beta_re, beta_im;
+  double sign;            // dg_dn_sign (tbem.rs:108-123)
+};
+
+int bem_upload_tables(const double tri13_scaled[13][3], const double* glx, const double* glw, const int glidx[21][2]);
+int bem_launch_near_list(const BemGeom& g, int pass, int* counts, const long long* offsets, int2* pairs, hipStream_t st);
+int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
+int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st);
+int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
+int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st);
+int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st);
+int bem_launch_zero(c64* v, int n, hipStream_t st);
+int bem_launch_incident(const BemGeom& g, const BemPhys& ph, int kind, const double* v, double are, double aim,
+                        int accumulate, c64* rhs, hipStream_t st);
+
+}  // namespace ma

@@ -1,0 +1,113 @@
+"""GPU parity of the TBEM assembly (K1 far, K2 near, K3 self) against the CPU oracle.
+
+Mirrors how the reference exercises build_tbem_system_with_beta: icosphere meshes from
+generate_icosphere_mesh, rigid BC, beta from burton_miller_beta_adaptive (bin/qa_suite.rs:216-228).
+Tolerances (complex f64): entries <= 1e-11 (far) / 1e-9 (near, self)
+relative to the row's largest entry.
+"""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from helpers import to_ma_mesh, k_from_ka, rowscaled_maxerr, RADIUS
+
+pytestmark = pytest.mark.gpu
+
+TOL_FAR = 1e-11
+TOL_NEAR = 1e-9
+
+
+@pytest.mark.parametrize("sub,ka", [(1, 0.2), (2, 0.2), (2, 1.0), (2, 3.0)])
+def test_assemble_matches_oracle(gpu, sub, ka):
+    om = O.icosphere(RADIUS, sub)
+    k = k_from_ka(ka)
+    beta, _ = O.beta_adaptive(k, RADIUS)
+    A_ref, rhs_ref = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    A, rhs = ma.assemble_tbem(to_ma_mesh(om), k, beta)
+    assert A.shape == A_ref.shape
+    assert np.all(np.isfinite(A.view(np.float64)))
+    plan = ma.BemPlan(to_ma_mesh(om))
+    near = plan.near_pairs()
+    mask = np.zeros(A.shape, dtype=bool)
+    mask[near[:, 0], near[:, 1]] = True
+    np.fill_diagonal(mask, True)
+    scale = np.abs(A_ref).max(axis=1, keepdims=True)
+    err = np.abs(A - A_ref) / scale
+    assert err[~mask].max() <= TOL_FAR, "far entries"
+    assert err[mask].max() <= TOL_NEAR, "near/self entries"
+    assert np.abs(rhs).max() == 0.0 and np.abs(rhs_ref).max() == 0.0
+    plan.close()
+
+
+def test_near_pair_list_is_the_oracles(gpu):
+    """The level-0 split decision (singular.rs:553-556) must agree pair for pair."""
+    om = O.icosphere(RADIUS, 2)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    near = set(map(tuple, plan.near_pairs().tolist()))
+    ref = set()
+    for i in range(om.n_elem):
+        for j in range(om.n_elem):
+            if i == j:
+                continue
+            subs = O.generate_subelements(om.center[i], om.coords(j), om.area[j])
+            if not (len(subs) == 1 and abs(subs[0].factor - 1.0) < 1e-10):
+                ref.add((i, j))
+    assert near == ref
+    plan.close()
+
+
+def test_raw_integrals_match_oracle(gpu):
+    """IntegrationResult level (G, H, H^T, E and sub-element count) for far, near and self pairs."""
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(1.0)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    near = plan.near_pairs()
+    rng = np.random.default_rng(7)
+    far = []
+    nearset = set(map(tuple, near.tolist()))
+    while len(far) < 200:
+        i, j = rng.integers(0, om.n_elem, 2)
+        if i != j and (int(i), int(j)) not in nearset:
+            far.append((int(i), int(j)))
+    pick = near[rng.choice(len(near), 300, replace=False)]
+    pairs = np.array(far + pick.tolist(), dtype=np.int32)
+    out = plan.probe_pairs(k, pairs)
+    for q, (i, j) in enumerate(pairs):
+        ref = O.regular_integration(om.center[i], om.normal[i], om.coords(j), om.area[j], k)[:4]
+        nsub = len(O.generate_subelements(om.center[i], om.coords(j), om.area[j]))
+        assert int(round(out[q, 0].real)) == nsub
+        got = out[q, 1:5]
+        tol = 1e-12 if q < len(far) else 1e-10
+        assert np.all(np.abs(got - ref) <= tol * np.abs(ref).max()), (i, j, got, ref)
+    selfs = plan.probe_self(k)
+    for e in range(0, om.n_elem, 7):
+        ref = O.singular_integration(om.center[e], om.normal[e], om.coords(e), k)[:4]
+        got = selfs[e, 1:5]
+        assert np.all(np.abs(got - ref) <= 1e-10 * np.abs(ref).max()), (e, got, ref)
+    plan.close()
+
+
+def test_incident_rhs_matches_oracle(gpu):
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(1.0)
+    beta, _ = O.beta_adaptive(k, RADIUS)
+    ref = O.compute_rhs_with_beta(om.center, om.normal, k, beta)
+    got = ma.incident_rhs(om.center, om.normal, k, beta)
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    src = (0.05, -0.3, 0.4)
+    ref = O.compute_rhs_with_beta(om.center, om.normal, k, beta, kind=1, vec=src, amp=2.0 - 1.0j)
+    got = ma.incident_rhs(om.center, om.normal, k, beta, kind=1, vec=src, amp=2.0 - 1.0j)
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_unsupported_inputs_fail_loudly(gpu):
+    om = O.icosphere(RADIUS, 1)
+    om.bc_values[3, 0] = 1.0
+    with pytest.raises(ma.MaError) as e:
+        ma.assemble_tbem(to_ma_mesh(om), 10.0, 0.4j)
+    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    om = O.icosphere(RADIUS, 1)
+    om.conn[0, 3] = 2
+    with pytest.raises(ma.MaError) as e:
+        ma.assemble_tbem(to_ma_mesh(om), 10.0, 0.4j)
+    assert e.value.status == ma.MA_ERR_UNSUPPORTED
