@@ -144,6 +144,12 @@ int ma_bem_plan_probe_pairs(ma_bem_plan_t* plan, const ma_physics_t* physics, in
 int ma_bem_plan_probe_self(ma_bem_plan_t* plan, const ma_physics_t* physics, ma_c64* out5);
 int ma_bem_plan_get_near_pairs(const ma_bem_plan_t* plan, int32_t* out_pairs);
 
+/* Test hook: C <- C - A*B (row-major, tight leading dimensions, host buffers) through the f64 MFMA
+ * trailing-update kernel of the LU. */
+int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma_c64* B, ma_c64* C);
+/* Measured issue rate of v_mfma_f64_16x16x4_f64 over the whole chip, TFLOP/s (roofline peak check). */
+int ma_probe_mfma_f64(int device, double* tflops);
+
 /* ------------------------------------------------------------------------------------------
  * Diagnostics used by bench.py / tests: elapsed GPU time (ms) of the tagged phases of the most
  * recent call on the plan, measured with HIP events on the plan's stream when timing is enabled.

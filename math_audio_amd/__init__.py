@@ -79,6 +79,8 @@ def lib():
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],
+            "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
+            "ma_probe_mfma_f64": [C.c_int, P(dbl)],
         }
         for name, args in sig.items():
             if hasattr(L, name):
@@ -258,3 +260,17 @@ class LuPlan:
         out = np.zeros(6)
         check(lib().ma_lu_plan_last_timing(self.h, _vp(out)))
         return out
+
+
+def test_zgemm_sub(A, B, Cm):
+    """C - A @ B through the MFMA trailing-update kernel (test hook)."""
+    A = np.ascontiguousarray(A, dtype=np.complex128); B = np.ascontiguousarray(B, dtype=np.complex128)
+    out = np.array(Cm, dtype=np.complex128, order="C")
+    check(lib().ma_test_zgemm_sub(A.shape[0], B.shape[1], A.shape[1], _vp(A), _vp(B), _vp(out)))
+    return out
+
+
+def probe_mfma_f64(device=0):
+    t = C.c_double(0)
+    check(lib().ma_probe_mfma_f64(device, C.byref(t)))
+    return t.value

@@ -1,0 +1,519 @@
+// lu_kernels.hip — dense complex128 LU (partial pivoting) and triangular solves for gfx950.
+//
+// Replaces the arithmetic behind lu_solve (math-solvers/src/direct/lu.rs:142-153 -> LAPACK zgesv).
+// The matrix is ndarray C-order (row-major) and stays resident in HBM; pivoting is by rows
+// (swaps are contiguous 16-B-per-lane row copies). Per panel of nb <= 128 columns:
+//   lu_panel_kernel    co-resident workgroups, each keeping its <= 72 rows of the panel in LDS
+//                      (160 KB/CU makes the whole 10k x 128 panel on-chip); one chip-wide
+//                      gather per column (sc1 write-through stores, one counter, sc1 loads)
+//                      picks the pivot and hands every workgroup the pivot row.
+//   lu_perm_kernel     one wavefront folds the panel's swap sequence into a gather list;
+//   lu_gather/scatter  apply it to the columns left and right of the panel (and to the RHS).
+//   lu_trsm_kernel     U12 = L11^-1 A12, one lane per column, 16-row register blocks.
+//   zgemm_sub_kernel   A22 -= L21 U12 on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex tile
+//                      product), 128x128 tiles staged through LDS, 8 wavefronts per workgroup.
+#include "lu_kernels.hpp"
+#include "ma_device_math.hpp"
+#include <climits>
+
+namespace ma {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ void st_sc1(u64* p, double v) { __hip_atomic_store(p, (u64)__double_as_longlong(v), RLX_AGENT); }
+__device__ __forceinline__ double ld_sc1(const u64* p) { return __longlong_as_double((long long)__hip_atomic_load(p, RLX_AGENT)); }
+__device__ __forceinline__ double cabs1(dc z) { return __builtin_fabs(z.re) + __builtin_fabs(z.im); }
+
+// reciprocal of a complex number the way LAPACK forms ONE / A(j,j) (Smith's division)
+__device__ __forceinline__ dc crecip(dc z) {
+  if (__builtin_fabs(z.im) < __builtin_fabs(z.re)) {
+    double e = z.im / z.re, f = z.re + z.im * e;
+    return dc_make(1.0 / f, -e / f);
+  }
+  double e = z.re / z.im, f = z.im + z.re * e;
+  return dc_make(e / f, -1.0 / f);
+}
+
+// better (value, row) candidate: larger value, ties -> lower row (izamax takes the first maximum)
+__device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) { return v > bv || (v == bv && r < br); }
+
+// ------------------------------------------------------------------ panel factorisation
+// Dynamic LDS: P[rpb][nb+1] | urow[nb] | drow[nb] | small ints.
+__global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, int n, int k0, int nb, int rpb, LuPanelWs ws,
+                                                          int* __restrict__ ipiv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int pitch = nb + 1;
+  dc* P = reinterpret_cast<dc*>(smem);
+  dc* urow = P + (size_t)rpb * pitch;
+  dc* drow = urow + nb;
+  double* s_wv = reinterpret_cast<double*>(drow + nb);   // [4] wave maxima
+  int* s_wr = reinterpret_cast<int*>(s_wv + 4);          // [4] rows
+  int* s_wb = s_wr + 4;                                  // [4] blocks
+  int* s_misc = s_wb + 4;                                // [0] best row, [1] pivot row, [2] winner block, [3] fail
+  double* s_bestv = reinterpret_cast<double*>(s_misc + 4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, nblk = gridDim.x;
+  const int r0 = k0 + b * rpb;
+  const int nrows = min(rpb, n - r0);
+
+  for (int idx = tid; idx < nrows * nb; idx += 256) {
+    int rr = idx / nb, j = idx - rr * nb;
+    P[rr * pitch + j] = A[(size_t)(r0 + rr) * n + k0 + j];
+  }
+  if (tid == 0) s_misc[3] = 0;
+  __syncthreads();
+
+  for (int c = 0; c < nb; ++c) {
+    const int gc = k0 + c;
+    const int buf = c & 1;
+    // ---- 1. local candidate: largest |re|+|im| of column c among this workgroup's rows >= gc
+    {
+      double v = -1.0; int row = INT_MAX;
+      if (tid < nrows && r0 + tid >= gc) { v = cabs1(P[tid * pitch + c]); row = r0 + tid; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(v, off, 64); int orow = __shfl_xor(row, off, 64);
+        if (cand_better(ov, orow, v, row)) { v = ov; row = orow; }
+      }
+      if (lane == 0) { s_wv[wave] = v; s_wr[wave] = row; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_wv[0]; int row = s_wr[0];
+      for (int w = 1; w < 4; ++w) if (cand_better(s_wv[w], s_wr[w], v, row)) { v = s_wv[w]; row = s_wr[w]; }
+      s_bestv[0] = v; s_misc[0] = row;
+    }
+    __syncthreads();
+    // ---- 2. publish {value, row, the candidate row's nb entries}; the owner of row gc publishes it too
+    {
+      const double bv = s_bestv[0]; const int br = s_misc[0];
+      u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + b) * 2;
+      if (tid == 0) { st_sc1(cand, bv); __hip_atomic_store(cand + 1, (u64)(unsigned)br, RLX_AGENT); }
+      if (br != INT_MAX) {
+        const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
+        u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
+        for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
+      }
+      if (gc >= r0 && gc < r0 + nrows) {
+        const double* src = reinterpret_cast<const double*>(P + (size_t)(gc - r0) * pitch);
+        u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+        for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
+    __syncthreads();
+    // ---- 3. arrive + wait for every workgroup's candidate of this column (monotonic counter)
+    if (tid == 0) {
+      __hip_atomic_fetch_add(ws.counter, 1u, RLX_AGENT);
+      const unsigned target = (unsigned)nblk * (unsigned)(c + 1);
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(ws.counter, RLX_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {       // 4 s at 100 MHz: give up, never hang
+          __hip_atomic_store(ws.timeout, 1u, RLX_AGENT);
+          s_misc[3] = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_misc[3]) return;                               // uniform: the whole workgroup leaves
+    // ---- 4. every workgroup reduces the candidates to the same pivot
+    {
+      double v = -1.0; int row = INT_MAX; int blk = 0;
+      if (tid < nblk) {
+        const u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + tid) * 2;
+        v = ld_sc1(cand); row = (int)(unsigned)__hip_atomic_load(cand + 1, RLX_AGENT); blk = tid;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_xor(v, off, 64); int orow = __shfl_xor(row, off, 64); int ob = __shfl_xor(blk, off, 64);
+        if (cand_better(ov, orow, v, row)) { v = ov; row = orow; blk = ob; }
+      }
+      if (lane == 0) { s_wv[wave] = v; s_wr[wave] = row; s_wb[wave] = blk; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double v = s_wv[0]; int row = s_wr[0]; int blk = s_wb[0];
+      for (int w = 1; w < 4; ++w) if (cand_better(s_wv[w], s_wr[w], v, row)) { v = s_wv[w]; row = s_wr[w]; blk = s_wb[w]; }
+      s_misc[1] = row; s_misc[2] = blk;
+    }
+    __syncthreads();
+    const int p = s_misc[1], wb = s_misc[2];
+    // ---- 5. fetch the pivot row (and the displaced diagonal row) with sc1 loads
+    {
+      const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX);
+      double* dst = reinterpret_cast<double*>(urow);
+      for (int t = tid; t < 2 * nb; t += 256) dst[t] = ld_sc1(src + t);
+      if (p != gc) {
+        const u64* s2 = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+        double* d2 = reinterpret_cast<double*>(drow);
+        for (int t = tid; t < 2 * nb; t += 256) d2[t] = ld_sc1(s2 + t);
+      }
+    }
+    __syncthreads();
+    // ---- 6. interchange inside the panel
+    if (p != gc) {
+      if (p >= r0 && p < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(p - r0) * pitch + t] = drow[t];
+      if (gc >= r0 && gc < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(gc - r0) * pitch + t] = urow[t];
+    }
+    if (b == 0 && tid == 0) ipiv[gc] = p;
+    const dc piv = urow[c];
+    const bool singular = (piv.re == 0.0 && piv.im == 0.0);
+    if (singular && b == 0 && tid == 0) atomicCAS(ws.info, 0, gc + 1);   // first zero pivot, as zgetf2's INFO
+    __syncthreads();
+    if (singular) continue;
+    // ---- 7. multipliers l = a / pivot (reciprocal scaling, zgetf2)
+    if (tid < nrows && r0 + tid > gc) {
+      const dc ri = crecip(piv);
+      P[tid * pitch + c] = P[tid * pitch + c] * ri;
+    }
+    __syncthreads();
+    // ---- 8. rank-1 update of the columns to the right, inside the panel
+    for (int rr = wave; rr < nrows; rr += 4) {
+      if (r0 + rr <= gc) continue;
+      const dc l = P[rr * pitch + c];
+      for (int j = c + 1 + lane; j < nb; j += 64) {
+        dc a = P[rr * pitch + j]; const dc u = urow[j];
+        a.re = a.re - (l.re * u.re - l.im * u.im);
+        a.im = a.im - (l.re * u.im + l.im * u.re);
+        P[rr * pitch + j] = a;
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nrows * nb; idx += 256) {
+    int rr = idx / nb, j = idx - rr * nb;
+    A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
+  }
+}
+
+// ------------------------------------------------------------------ row interchanges outside the panel
+// One wavefront replays the panel's nb interchanges on an index map and emits (dst,src) row lists:
+// after the sequence, row dst holds what row src held before it. m <= 2 nb entries.
+__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */) {
+  __shared__ int top[LU_NB_MAX];       // content of row k0+c
+  __shared__ int ext_row[LU_NB_MAX];   // rows >= k0+nb that were touched
+  __shared__ int ext_src[LU_NB_MAX];
+  const int lane = threadIdx.x;
+  for (int c = lane; c < nb; c += 64) top[c] = k0 + c;
+  int next = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (int c = 0; c < nb; ++c) {
+    const int p = ipiv[k0 + c];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (p == k0 + c) continue;
+    if (p < k0 + nb) {
+      if (lane == 0) { int t = top[c]; top[c] = top[p - k0]; top[p - k0] = t; }
+    } else {
+      // find p among the touched external rows (2 per lane)
+      int hit = -1;
+      for (int e = lane; e < next; e += 64) if (ext_row[e] == p) hit = e;
+      unsigned long long m = __ballot(hit >= 0);
+      int e;
+      if (m) { int src_lane = __builtin_ctzll(m); e = __shfl(hit, src_lane, 64); }
+      else { e = next; if (lane == 0) { ext_row[e] = p; ext_src[e] = p; } next += 1; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane == 0) { int t = top[c]; top[c] = ext_src[e]; ext_src[e] = t; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // compact: only rows whose content changed
+  int* dst = lists + 1; int* src = lists + 1 + 2 * LU_NB_MAX;
+  int m = 0;
+  for (int base = 0; base < nb + next; base += 64) {
+    int i = base + lane;
+    int d = -1, s = -1;
+    if (i < nb) { d = k0 + i; s = top[i]; }
+    else if (i < nb + next) { d = ext_row[i - nb]; s = ext_src[i - nb]; }
+    bool keep = (d >= 0) && (d != s);
+    unsigned long long bm = __ballot(keep);
+    if (keep) { int pos = m + __popcll(bm & lanemask_lt()); dst[pos] = d; src[pos] = s; }
+    m += __popcll(bm);
+  }
+  if (lane == 0) lists[0] = m;
+}
+
+// tmp[idx][col] = M[src[idx]][col] for the columns outside [k0, k0+nb) plus the nrhs RHS "columns"
+__global__ __launch_bounds__(256) void lu_gather_rows_kernel(const dc* __restrict__ A, int n, int k0, int nb, const int* __restrict__ lists,
+                                                             dc* __restrict__ tmp, const dc* __restrict__ B, int nrhs) {
+  const int m = lists[0];
+  const int idx = blockIdx.y;
+  if (idx >= m) return;
+  const int s = lists[1 + 2 * LU_NB_MAX + idx];
+  const int ncol = n - nb + nrhs;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < ncol; q += gridDim.x * 256) {
+    dc v;
+    if (q < n - nb) { int col = q < k0 ? q : q + nb; v = A[(size_t)s * n + col]; }
+    else v = B[(size_t)(q - (n - nb)) * n + s];
+    tmp[(size_t)idx * (n + nrhs) + q] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A, int n, int k0, int nb, const int* __restrict__ lists,
+                                                              const dc* __restrict__ tmp, dc* __restrict__ B, int nrhs) {
+  const int m = lists[0];
+  const int idx = blockIdx.y;
+  if (idx >= m) return;
+  const int d = lists[1 + idx];
+  const int ncol = n - nb + nrhs;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < ncol; q += gridDim.x * 256) {
+    dc v = tmp[(size_t)idx * (n + nrhs) + q];
+    if (q < n - nb) { int col = q < k0 ? q : q + nb; A[(size_t)d * n + col] = v; }
+    else B[(size_t)(q - (n - nb)) * n + d] = v;
+  }
+}
+
+// ------------------------------------------------------------------ triangular solve with a small triangle
+// X <- T^-1 X for the nb x ncols block X (element (r, j) at X[r*ldx + j*incx]); T = the nb x nb
+// triangle at Tm (row-major, ld = ldt). UPPER=false: unit lower (forward); UPPER=true: non-unit
+// upper (backward). One lane per column, 16-row register blocks, T rows staged in LDS.
+template <bool UPPER>
+__global__ __launch_bounds__(256) void lu_trsm_kernel(const dc* __restrict__ Tm, int ldt, int nb, dc* __restrict__ X, size_t ldx, size_t incx, int ncols) {
+  __shared__ dc sT[16][LU_NB_MAX + 1];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool act = j < ncols;
+  dc* Xj = X + (act ? (size_t)j * incx : 0);
+  const int nblk16 = (nb + 15) / 16;
+  for (int bi = 0; bi < nblk16; ++bi) {
+    const int rb = UPPER ? (nblk16 - 1 - bi) : bi;
+    const int rlo = rb * 16, rhi = min(rlo + 16, nb), nr = rhi - rlo;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nr * nb; idx += 256) { int i = idx / nb, c = idx - i * nb; sT[i][c] = Tm[(size_t)(rlo + i) * ldt + c]; }
+    __syncthreads();
+    if (!act) continue;
+    dc x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = (i < nr) ? Xj[(size_t)(rlo + i) * ldx] : dc_make(0.0, 0.0);
+    if (!UPPER) {
+      for (int p = 0; p < rlo; ++p) {
+        const dc xp = Xj[(size_t)p * ldx];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const dc t = sT[i][p]; x[i].re -= t.re * xp.re - t.im * xp.im; x[i].im -= t.re * xp.im + t.im * xp.re; }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < nr) {
+#pragma unroll
+          for (int p = 0; p < i; ++p) { const dc t = sT[i][rlo + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
+        }
+      }
+    } else {
+      for (int p = rhi; p < nb; ++p) {
+        const dc xp = Xj[(size_t)p * ldx];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const dc t = sT[i][p]; x[i].re -= t.re * xp.re - t.im * xp.im; x[i].im -= t.re * xp.im + t.im * xp.re; }
+      }
+#pragma unroll
+      for (int i = 15; i >= 0; --i) {
+        if (i < nr) {
+#pragma unroll
+          for (int p = 15; p > i; --p) if (p < nr) { const dc t = sT[i][rlo + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
+          x[i] = x[i] * crecip(sT[i][rlo + i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i < nr) Xj[(size_t)(rlo + i) * ldx] = x[i];
+  }
+}
+
+// ------------------------------------------------------------------ C -= A * B on the f64 matrix cores
+// A: M x K (lda), B: K x N (ldb), C: M x N (ldc), row-major complex128. Workgroup tile 128 x 128,
+// K in steps of 8 (two v_mfma_f64_16x16x4 k-steps), 512 threads = 8 wavefronts as 4 (M) x 2 (N);
+// each wavefront owns 32 x 64 = 2 x 4 MFMA tiles with separate real/imaginary accumulators.
+// LDS: As[2][8][128] (k-major: the A fragment of a tile is 16 consecutive complex), Bs[2][8][128].
+// Operand fragment of v_mfma_f64_16x16x4_f64: lane l holds A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; result register r of lane l is D[(l >> 4) + 4 r][l & 15].
+#define ZG_BM 128
+#define ZG_BN 128
+#define ZG_BK 8
+
+__global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
+                                                           const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
+  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][ZG_BM];
+  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][ZG_BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;           // 4 x 2 wave grid
+  const int m0 = blockIdx.y * ZG_BM, n0 = blockIdx.x * ZG_BN;
+  const int li = lane & 15, lk = lane >> 4;
+
+  v4d accr[2][4], acci[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { accr[a][b] = (v4d){0, 0, 0, 0}; acci[a][b] = (v4d){0, 0, 0, 0}; }
+
+  // staging assignment: 1024 A elements and 1024 B elements per stage, 2 + 2 per thread
+  dc ra[2], rb[2];
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int e = tid + 512 * s;
+      const int row = e >> 3, kk = e & 7;                       // A: 8 consecutive k of one row = 128 B
+      const int gm = m0 + row, gk = k0 + kk;
+      ra[s] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : dc_make(0.0, 0.0);
+      const int bk = e >> 7, bn = e & 127;                      // B: 128 consecutive n of one k-row
+      const int gn = n0 + bn, gk2 = k0 + bk;
+      rb[s] = (gn < N && gk2 < K) ? B[(size_t)gk2 * ldb + gn] : dc_make(0.0, 0.0);
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int e = tid + 512 * s;
+      As[buf][e & 7][e >> 3] = ra[s];
+      Bs[buf][e >> 7][e & 127] = rb[s];
+    }
+  };
+
+  const int nstage = (K + ZG_BK - 1) / ZG_BK;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) load_stage((st + 1) * ZG_BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = ks * 4 + lk;
+      dc af[2], bf[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = As[buf][kk][wm * 32 + a * 16 + li];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = Bs[buf][kk][wn * 64 + b * 16 + li];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double nai = -af[a].im;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          accr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].re, bf[b].re, accr[a][b], 0, 0, 0);
+          accr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bf[b].im, accr[a][b], 0, 0, 0);
+          acci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].re, bf[b].im, acci[a][b], 0, 0, 0);
+          acci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].im, bf[b].re, acci[a][b], 0, 0, 0);
+        }
+      }
+    }
+    if (st + 1 < nstage) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: C -= acc
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm * 32 + a * 16 + lk + 4 * r;
+        const int gn = n0 + wn * 64 + b * 16 + li;
+        if (gm < M && gn < N) {
+          dc* pc = C + (size_t)gm * ldc + gn;
+          dc c = *pc;
+          c.re -= accr[a][b][r]; c.im -= acci[a][b][r];
+          *pc = c;
+        }
+      }
+}
+
+// thin-N variant for the right-hand sides (N = nrhs small): y[m] -= sum_k A[m][k] x[k]; one wave per row
+__global__ __launch_bounds__(256) void zgemv_sub_kernel(int M, int K, const dc* __restrict__ A, size_t lda, const dc* __restrict__ x, dc* __restrict__ y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  double sr = 0.0, si = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const dc a = A[(size_t)m * lda + k]; const dc v = x[k];
+    sr += a.re * v.re - a.im * v.im; si += a.re * v.im + a.im * v.re;
+  }
+  sr = wave_sum(sr); si = wave_sum(si);
+  if (lane == 0) { dc c = y[m]; c.re -= sr; c.im -= si; y[m] = c; }
+}
+
+// MFMA f64 issue-rate probe: each wave runs `iters` x 16 independent v_mfma_f64_16x16x4_f64
+__global__ __launch_bounds__(256) void mfma_f64_probe_kernel(double* out, int iters) {
+  v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0, 0, 0, 0};
+  double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ launchers
+size_t lu_panel_lds_bytes(int nb, int rpb) {
+  return (size_t)rpb * (nb + 1) * sizeof(dc) + 2 * (size_t)nb * sizeof(dc) + 4 * sizeof(double) + 12 * sizeof(int) + sizeof(double) + 64;
+}
+
+int lu_panel_configure() {
+  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return MA_OK;
+}
+
+int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, hipStream_t st) {
+  MA_HIP(hipMemsetAsync(ws.counter, 0, 16, st));           // counter + timeout words share one 16-byte block
+  const size_t lds = lu_panel_lds_bytes(nb, rpb);
+  hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(A), n, k0, nb, rpb, ws, ipiv);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, hipStream_t st) {
+  hipLaunchKernelGGL(lu_perm_kernel, dim3(1), dim3(64), 0, st, ipiv, k0, nb, lists);
+  MA_HIP(hipGetLastError());
+  const int ncol = n - nb + nrhs;
+  if (ncol <= 0) return MA_OK;
+  int gx = (ncol + 255) / 256; if (gx > 64) gx = 64;
+  dim3 grid(gx, 2 * nb);
+  hipLaunchKernelGGL(lu_gather_rows_kernel, grid, dim3(256), 0, st, reinterpret_cast<const dc*>(A), n, k0, nb, lists, reinterpret_cast<dc*>(tmp),
+                     reinterpret_cast<const dc*>(B), nrhs);
+  MA_HIP(hipGetLastError());
+  hipLaunchKernelGGL(lu_scatter_rows_kernel, grid, dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, lists, reinterpret_cast<const dc*>(tmp),
+                     reinterpret_cast<dc*>(B), nrhs);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int lu_launch_trsm(bool upper, const c64* T, int ldt, int nb, c64* X, size_t ldx, size_t incx, int ncols, hipStream_t st) {
+  if (ncols <= 0 || nb <= 0) return MA_OK;
+  dim3 grid((ncols + 255) / 256), block(256);
+  if (upper) hipLaunchKernelGGL(lu_trsm_kernel<true>, grid, block, 0, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, incx, ncols);
+  else hipLaunchKernelGGL(lu_trsm_kernel<false>, grid, block, 0, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, incx, ncols);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
+  dim3 grid((N + ZG_BN - 1) / ZG_BN, (M + ZG_BM - 1) / ZG_BM), block(512);
+  hipLaunchKernelGGL(zgemm_sub_kernel, grid, block, 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+                     reinterpret_cast<dc*>(C), ldc);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st) {
+  if (M <= 0 || K <= 0) return MA_OK;
+  hipLaunchKernelGGL(zgemv_sub_kernel, dim3((M + 3) / 4), dim3(256), 0, st, M, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(x),
+                     reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+}  // namespace ma

@@ -1,0 +1,31 @@
+// lu_kernels.hpp — launchers of the dense LU kernels.
+#pragma once
+#include "ma_common.hpp"
+
+#define LU_NB_MAX 128
+
+namespace ma {
+
+// Global scratch shared by the co-resident workgroups of lu_panel_kernel. `counter` and `timeout`
+// live in one 16-byte block that is zeroed before every launch (arrival counter is monotonic
+// within a launch); `info` persists over a factorisation (first zero pivot, 1-based; 0 = none).
+struct LuPanelWs {
+  unsigned* counter;            // [0] arrivals, [1] timeout flag (same 16-byte block)
+  unsigned* timeout;
+  int* info;
+  unsigned long long* cand;     // [2][max_blocks][2]   {|re|+|im| bits, row}
+  unsigned long long* candrow;  // [2][max_blocks][2*LU_NB_MAX] candidate row of the panel
+  unsigned long long* diagrow;  // [2][2*LU_NB_MAX]            current diagonal row of the panel
+  int max_blocks;
+};
+
+size_t lu_panel_lds_bytes(int nb, int rpb);
+int lu_panel_configure();
+int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, hipStream_t st);
+int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, hipStream_t st);
+int lu_launch_trsm(bool upper, const c64* T, int ldt, int nb, c64* X, size_t ldx, size_t incx, int ncols, hipStream_t st);
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st);
+int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st);
+int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st);
+
+}  // namespace ma

@@ -1,0 +1,287 @@
+// lu_plan.hip — host driver of the blocked right-looking LU and the C-ABI of the dense solve
+// (replaces lu_solve, math-solvers/src/direct/lu.rs:142-153).
+#include "lu_kernels.hpp"
+#include <vector>
+#include <new>
+
+using namespace ma;
+
+struct ma_lu_plan {
+  int device = 0;
+  int n = 0;
+  int ncu = 256;
+  void* ws_block = nullptr;       // one allocation: sync words | info | cand | candrow | diagrow | lists | ipiv
+  LuPanelWs pws{};
+  int* d_lists = nullptr;
+  int* d_ipiv = nullptr;
+  c64* d_tmp = nullptr;           // 2*NB rows x (n + nrhs_max) for the row interchanges
+  int nrhs_max = 4;
+  bool timing = false;
+  std::vector<hipEvent_t> ev;     // event pool for per-phase timing
+  std::vector<int> ev_phase;      // phase id of interval i (between ev[i] and ev[i+1])
+  int n_gemm_launch = 0;
+  bool ev_valid = false;
+};
+
+namespace {
+
+// Panel geometry: widest panel (128/64/32/16) whose rows fit the co-resident workgroups' LDS.
+void panel_shape(int R, int ncu, int want_nb, int* nb_out, int* rpb_out, int* nblk_out) {
+  const int widths[4] = {128, 64, 32, 16};
+  for (int w = 0; w < 4; ++w) {
+    int nb = widths[w];
+    int rpb_max = (int)((150000 - 2 * nb * 16) / ((nb + 1) * 16));
+    if (rpb_max > 256) rpb_max = 256;
+    long long cap = (long long)rpb_max * ncu;
+    if (cap >= R || w == 3) {
+      int rpb = rpb_max < 64 ? rpb_max : 64;          // prefer <= 64 rows per workgroup, more workgroups
+      int nblk = (R + rpb - 1) / rpb;
+      if (nblk > ncu) { rpb = (R + ncu - 1) / ncu; nblk = (R + rpb - 1) / rpb; }
+      if (nb > want_nb) nb = want_nb;
+      *nb_out = nb; *rpb_out = rpb; *nblk_out = nblk;
+      return;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  MA_REQUIRE(n > 0, MA_ERR_DIM, "n must be positive (got %d)", n);
+  int rc = use_device(device);
+  if (rc) return rc;
+  hipDeviceProp_t prop;
+  MA_HIP(hipGetDeviceProperties(&prop, device));
+  const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  MA_REQUIRE((long long)n <= 256LL * ncu, MA_ERR_UNSUPPORTED, "n = %d exceeds the co-resident panel capacity (%d rows)", n, 256 * ncu);
+  ma_lu_plan* P = new (std::nothrow) ma_lu_plan();
+  MA_REQUIRE(P, MA_ERR_NOMEM, "host allocation failed");
+  P->device = device; P->n = n; P->ncu = ncu;
+  const int mb = ncu;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_sync = take(16), o_info = take(16), o_cand = take(sizeof(unsigned long long) * 2 * mb * 2),
+               o_crow = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX), o_drow = take(sizeof(unsigned long long) * 2 * 2 * LU_NB_MAX),
+               o_lists = take(sizeof(int) * (1 + 4 * LU_NB_MAX)), o_ipiv = take(sizeof(int) * (size_t)n);
+  hipError_t e = hipMalloc(&P->ws_block, off);
+  if (e == hipSuccess) e = hipMalloc(&P->d_tmp, sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + P->nrhs_max));
+  if (e != hipSuccess) {
+    set_error("hipMalloc of the LU workspace failed: %s", hipGetErrorString(e));
+    if (P->ws_block) (void)hipFree(P->ws_block);
+    delete P;
+    return MA_ERR_NOMEM;
+  }
+  char* base = (char*)P->ws_block;
+  P->pws.counter = (unsigned*)(base + o_sync);
+  P->pws.timeout = P->pws.counter + 1;
+  P->pws.info = (int*)(base + o_info);
+  P->pws.cand = (unsigned long long*)(base + o_cand);
+  P->pws.candrow = (unsigned long long*)(base + o_crow);
+  P->pws.diagrow = (unsigned long long*)(base + o_drow);
+  P->pws.max_blocks = mb;
+  P->d_lists = (int*)(base + o_lists);
+  P->d_ipiv = (int*)(base + o_ipiv);
+  rc = lu_panel_configure();
+  if (rc) { (void)hipFree(P->ws_block); (void)hipFree(P->d_tmp); delete P; return rc; }
+  *out = P;
+  return MA_OK;
+}
+
+int ma_lu_plan_destroy(ma_lu_plan_t* P) {
+  if (!P) return MA_OK;
+  (void)hipSetDevice(P->device);
+  for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
+  if (P->d_tmp) (void)hipFree(P->d_tmp);
+  if (P->ws_block) (void)hipFree(P->ws_block);
+  delete P;
+  return MA_OK;
+}
+
+int ma_lu_plan_set_timing(ma_lu_plan_t* P, int enable) {
+  MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
+  P->timing = enable != 0;
+  P->ev_valid = false;
+  return MA_OK;
+}
+
+static int mark(ma_lu_plan* P, size_t* cursor, int phase, hipStream_t st) {
+  if (!P->timing) return MA_OK;
+  if (*cursor >= P->ev.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); P->ev.push_back(e); }
+  MA_HIP(hipEventRecord(P->ev[*cursor], st));
+  if (*cursor >= P->ev_phase.size()) P->ev_phase.push_back(phase); else P->ev_phase[*cursor] = phase;
+  ++*cursor;
+  return MA_OK;
+}
+
+// Factor d_A in place and solve for nrhs right-hand sides (d_B[nrhs][n]); everything asynchronous.
+int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrhs, void* stream) {
+  MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
+  MA_REQUIRE(nrhs == 0 || dB, MA_ERR_INVALID, "d_B is NULL");
+  MA_HIP(hipSetDevice(P->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int n = P->n;
+  c64* A = (c64*)dA; c64* B = (c64*)dB;
+  int rc;
+  MA_HIP(hipMemsetAsync(P->pws.info, 0, 16, st));
+  size_t cur = 0; P->n_gemm_launch = 0;
+  // phases: 0 panel, 1 swaps, 2 trsm, 3 zgemm, 4 rhs/triangular solves, 5 end marker
+  std::vector<int> k0s, nbs;
+  for (int k0 = 0; k0 < n;) {
+    int nb, rpb, nblk;
+    panel_shape(n - k0, P->ncu, n - k0 < LU_NB_MAX ? n - k0 : LU_NB_MAX, &nb, &rpb, &nblk);
+    if ((rc = mark(P, &cur, 0, st))) return rc;
+    if ((rc = lu_launch_panel(A, n, k0, nb, rpb, nblk, P->pws, P->d_ipiv, st))) return rc;
+    if ((rc = mark(P, &cur, 1, st))) return rc;
+    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv, P->d_lists, P->d_tmp, B, nrhs, st))) return rc;
+    const int nright = n - k0 - nb;
+    if ((rc = mark(P, &cur, 2, st))) return rc;
+    const c64* T = A + (size_t)k0 * n + k0;
+    if (nright > 0 && (rc = lu_launch_trsm(false, T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, 1, nright, st))) return rc;
+    if ((rc = mark(P, &cur, 4, st))) return rc;
+    // forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b, b[below] -= L21 b[k0:k0+nb]
+    if (nrhs > 0) {
+      if ((rc = lu_launch_trsm(false, T, n, nb, B + k0, 1, (size_t)n, nrhs, st))) return rc;
+      for (int r = 0; r < nrhs && nright > 0; ++r)
+        if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
+    }
+    if ((rc = mark(P, &cur, 3, st))) return rc;
+    if (nright > 0) {
+      if ((rc = lu_launch_zgemm_sub(nright, nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, A + (size_t)k0 * n + k0 + nb, (size_t)n,
+                                    A + (size_t)(k0 + nb) * n + k0 + nb, (size_t)n, st))) return rc;
+      P->n_gemm_launch++;
+    }
+    k0s.push_back(k0); nbs.push_back(nb);
+    k0 += nb;
+  }
+  // backward substitution U x = y, block rows from the bottom
+  if ((rc = mark(P, &cur, 4, st))) return rc;
+  if (nrhs > 0) {
+    for (int q = (int)k0s.size() - 1; q >= 0; --q) {
+      const int k0 = k0s[q], nb = nbs[q];
+      if ((rc = lu_launch_trsm(true, A + (size_t)k0 * n + k0, n, nb, B + k0, 1, (size_t)n, nrhs, st))) return rc;
+      for (int r = 0; r < nrhs && k0 > 0; ++r)
+        if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
+    }
+  }
+  if ((rc = mark(P, &cur, 5, st))) return rc;
+  if (P->timing) { P->ev.resize(P->ev.size()); P->ev_phase.resize(cur); P->ev_valid = true; }
+  return MA_OK;
+}
+
+int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
+  MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
+  MA_HIP(hipSetDevice(P->device));
+  MA_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int info = 0; unsigned sync[2] = {0, 0};
+  MA_HIP(hipMemcpy(&info, P->pws.info, sizeof(int), hipMemcpyDeviceToHost));
+  MA_HIP(hipMemcpy(sync, P->pws.counter, sizeof(sync), hipMemcpyDeviceToHost));
+  MA_REQUIRE(sync[1] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
+  MA_REQUIRE(info == 0, MA_ERR_SINGULAR, "matrix is singular: zero pivot at column %d", info - 1);
+  return MA_OK;
+}
+
+int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out6) {
+  MA_REQUIRE(P && out6, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(P->ev_valid && P->ev_phase.size() >= 2, MA_ERR_INVALID, "no timed factorisation has run on this plan");
+  MA_HIP(hipSetDevice(P->device));
+  const size_t m = P->ev_phase.size();
+  MA_HIP(hipEventSynchronize(P->ev[m - 1]));
+  for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+  for (size_t i = 0; i + 1 < m; ++i) {
+    float ms = 0.f;
+    MA_HIP(hipEventElapsedTime(&ms, P->ev[i], P->ev[i + 1]));
+    int ph = P->ev_phase[i];
+    if (ph >= 0 && ph < 5) out6[ph] += ms;
+  }
+  out6[5] = P->n_gemm_launch;
+  return MA_OK;
+}
+
+int ma_zgesv(int32_t n, ma_c64* A, ma_c64* b, int32_t* ipiv) {
+  MA_REQUIRE(n >= 0, MA_ERR_DIM, "n is negative");
+  if (n == 0) return MA_OK;
+  MA_REQUIRE(A && b, MA_ERR_INVALID, "A or b is NULL");
+  int dev = 0;
+  if (const char* s = getenv("MA_DEVICE")) dev = atoi(s);
+  ma_lu_plan_t* P = nullptr;
+  int rc = ma_lu_plan_create(n, dev, &P);
+  if (rc) return rc;
+  void *dA = nullptr, *db = nullptr;
+  const size_t nn = (size_t)n;
+  hipError_t e = hipMalloc(&dA, nn * nn * sizeof(c64));
+  if (e == hipSuccess) e = hipMalloc(&db, nn * sizeof(c64));
+  if (e != hipSuccess) {
+    set_error("hipMalloc for a %d x %d system failed: %s", n, n, hipGetErrorString(e));
+    if (dA) (void)hipFree(dA);
+    ma_lu_plan_destroy(P);
+    return MA_ERR_NOMEM;
+  }
+  e = hipMemcpy(dA, A, nn * nn * sizeof(c64), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(db, b, nn * sizeof(c64), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; }
+  if (!rc) rc = ma_lu_plan_factor_solve_dev(P, dA, db, 1, nullptr);
+  if (!rc) rc = ma_lu_plan_status(P, nullptr);
+  if (!rc || rc == MA_ERR_SINGULAR) {
+    // the factors are returned in either case (LAPACK leaves them in A); x only when non-singular
+    hipError_t e2 = hipMemcpy(A, dA, nn * nn * sizeof(c64), hipMemcpyDeviceToHost);
+    if (e2 == hipSuccess && !rc) e2 = hipMemcpy(b, db, nn * sizeof(c64), hipMemcpyDeviceToHost);
+    if (e2 == hipSuccess && ipiv) e2 = hipMemcpy(ipiv, P->d_ipiv, nn * sizeof(int), hipMemcpyDeviceToHost);
+    if (e2 != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e2)); rc = MA_ERR_HIP; }
+  }
+  (void)hipFree(dA); (void)hipFree(db);
+  ma_lu_plan_destroy(P);
+  return rc;
+}
+
+// Test hook: C <- C - A B with the MFMA kernel on host buffers (row-major, tight leading dimensions).
+int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma_c64* B, ma_c64* C) {
+  MA_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, MA_ERR_INVALID, "bad argument");
+  int dev = 0;
+  if (const char* s = getenv("MA_DEVICE")) dev = atoi(s);
+  int rc = use_device(dev);
+  if (rc) return rc;
+  c64 *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  MA_HIP(hipMalloc(&dA, sizeof(c64) * (size_t)M * K));
+  MA_HIP(hipMalloc(&dB, sizeof(c64) * (size_t)K * N));
+  MA_HIP(hipMalloc(&dC, sizeof(c64) * (size_t)M * N));
+  MA_HIP(hipMemcpy(dA, A, sizeof(c64) * (size_t)M * K, hipMemcpyHostToDevice));
+  MA_HIP(hipMemcpy(dB, B, sizeof(c64) * (size_t)K * N, hipMemcpyHostToDevice));
+  MA_HIP(hipMemcpy(dC, C, sizeof(c64) * (size_t)M * N, hipMemcpyHostToDevice));
+  rc = lu_launch_zgemm_sub(M, N, K, dA, (size_t)K, dB, (size_t)N, dC, (size_t)N, nullptr);
+  if (!rc) { hipError_t e = hipMemcpy(C, dC, sizeof(c64) * (size_t)M * N, hipMemcpyDeviceToHost); if (e != hipSuccess) { set_error("copy back: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; } }
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  return rc;
+}
+
+// MFMA f64 issue-rate probe (bench.py uses it to state the measured matrix-core peak next to the
+// datasheet figure): returns TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on every CU.
+int ma_probe_mfma_f64(int device, double* tflops) {
+  MA_REQUIRE(tflops, MA_ERR_INVALID, "NULL argument");
+  int rc = use_device(device);
+  if (rc) return rc;
+  hipDeviceProp_t prop;
+  MA_HIP(hipGetDeviceProperties(&prop, device));
+  const int blocks = prop.multiProcessorCount * 2, iters = 4000;
+  double* d = nullptr;
+  MA_HIP(hipMalloc(&d, sizeof(double) * 256 * (size_t)blocks));
+  hipEvent_t a, b;
+  MA_HIP(hipEventCreate(&a)); MA_HIP(hipEventCreate(&b));
+  rc = lu_launch_mfma_probe(d, blocks, 200, nullptr);   // warm-up
+  MA_HIP(hipEventRecord(a, nullptr));
+  if (!rc) rc = lu_launch_mfma_probe(d, blocks, iters, nullptr);
+  MA_HIP(hipEventRecord(b, nullptr));
+  MA_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  MA_HIP(hipEventElapsedTime(&ms, a, b));
+  const double flops = (double)blocks * 4.0 * iters * 16.0 * (2.0 * 16 * 16 * 4);
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""GPU parity of the dense complex solve (ma_zgesv / LU plan) against LAPACK semantics.
+
+Mirrors math-solvers/src/direct/lu.rs:163-240 (residual <= 1e-10 on small real/complex systems,
+identity, singular => Err) and adds BEM-sized systems checked against the CPU oracle's zgesv and
+NumPy's LAPACK.
+"""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(n, seed, cond_shift=0.0):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A += cond_shift * np.eye(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    return A, b
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 8), (128, 128, 128), (200, 333, 96), (37, 515, 19), (1000, 1, 128)])
+def test_zgemm_sub_kernel(gpu, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((M, K)) + 1j * rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    Cm = rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))
+    got = ma.test_zgemm_sub(A, B, Cm)
+    ref = Cm - A @ B
+    assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
+
+
+def test_lu_solve_real_2x2(gpu):            # lu.rs:163-175
+    A = np.array([[4.0, 1.0], [1.0, 3.0]]); b = np.array([1.0, 2.0])
+    x = ma.zgesv(A, b)
+    assert np.abs(A @ x - b).max() <= 1e-10
+
+
+def test_lu_solve_complex_2x2(gpu):         # lu.rs:177-193
+    A = np.array([[4 + 1j, 1 + 0j], [1 + 0j, 3 - 1j]]); b = np.array([1 + 1j, 2 - 1j])
+    x = ma.zgesv(A, b)
+    assert np.abs(A @ x - b).max() <= 1e-10
+
+
+def test_lu_identity(gpu):                  # lu.rs:195-206
+    n = 5
+    x = ma.zgesv(np.eye(n), np.arange(1, n + 1, dtype=float))
+    assert np.abs(x - np.arange(1, n + 1)).max() <= 1e-10
+
+
+def test_lu_singular_is_an_error(gpu):      # lu.rs:208-216
+    with pytest.raises(ma.MaError) as e:
+        ma.zgesv(np.array([[1.0, 2.0], [2.0, 4.0]]), np.array([1.0, 2.0]))
+    assert e.value.status == ma.MA_ERR_SINGULAR
+
+
+def test_lu_dimension_mismatch(gpu):
+    with pytest.raises(ma.MaError) as e:
+        ma.zgesv(np.eye(3), np.ones(2))
+    assert e.value.status == ma.MA_ERR_DIM
+
+
+@pytest.mark.parametrize("n", [1, 3, 17, 64, 127, 128, 129, 300, 777, 1280])
+def test_lu_random_matches_lapack(gpu, n):
+    A, b = _rand(n, n)
+    x = ma.zgesv(A, b)
+    xr = np.linalg.solve(A, b)
+    xo, _, rc = O.zgesv(A, b, nthreads=8)
+    assert rc == 0
+    res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
+    assert res <= 1e-14 * n
+    # forward error relative to LAPACK within a few condition-number-scaled ulps
+    kappa = np.linalg.cond(A) if n <= 400 else 1e4
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-13 * kappa
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-13 * kappa
+
+
+def test_lu_needs_pivoting(gpu):
+    """Zero leading diagonal forces interchanges across workgroups and across panels."""
+    n = 400
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A[np.arange(n), np.arange(n)] = 0.0
+    A = np.roll(A, 7, axis=0)
+    b = rng.standard_normal(n) + 0j
+    x = ma.zgesv(A, b)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) <= 1e-10
+
+
+def test_lu_on_bem_system_matches_oracle(gpu):
+    """Config #2: S1 sphere system, x vs the CPU restatement <= 1e-8 relative L2."""
+    from helpers import k_from_ka, RADIUS
+    om = O.icosphere(RADIUS, 3)
+    k = k_from_ka(1.0)
+    beta, _ = O.beta_adaptive(k, RADIUS)
+    A, rhs0 = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    rhs = rhs0 + O.compute_rhs_with_beta(om.center, om.normal, k, beta)
+    xo, _, rc = O.zgesv(A, rhs, nthreads=8)
+    assert rc == 0
+    x = ma.zgesv(A, rhs)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
