@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — BEM frequency-sweep throughput on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[2]): S10 = UV sphere r = 0.1 m,
+n_theta = 51, n_phi = 100 -> 10 000 Tri3 panels; frequencies taken from the 64 log-spaced
+points 100 Hz .. 8 kHz; rigid BC, beta = 4i/k (BemSolver default), plane wave +z.
+One step = one frequency: TBEM assembly (far + near + self kernels) + incident RHS + dense
+complex LU solve, everything resident in HBM (geometry and the near-pair plan are uploaded once
+before the timed region; nothing crosses PCIe inside it).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Frequencies shard over ranks (rank r takes points r, r+N, ...): no data-path collective;
+"scaling": "weak" (K frequencies per GPU whatever N is). Rank 0 prints ONE JSON line.
+PyTorch is plumbing here: device buffers, the stream handle and torch.distributed.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C_SOUND = 343.0
+RADIUS = 0.1
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet FP64 matrix (= FP64 vector) peak, dense
+
+
+def lu_flops(n):
+    return (8.0 / 3.0) * n ** 3 + 8.0 * n ** 2          # zgetrf + zgetrs, real flops
+
+
+def gemm_flops(n, nb=128):
+    """Real flops of the trailing updates A22 -= L21 U12 of a right-looking LU with panel width nb."""
+    f, k0 = 0.0, 0
+    while k0 < n:
+        w = min(nb, n - k0)
+        r = n - k0 - w
+        f += 8.0 * w * r * r
+        k0 += w
+    return f
+
+
+def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
+    """Reference algorithm on this host's cores: the C restatement (oracle, kind "port") assembles a
+    bounded strip of rows of the SAME mesh at one sweep frequency with every core (rows over threads =
+    rayon par_iter over rows); the dense solve is timed with the host LAPACK (zgesv family via SciPy /
+    NumPy = what lu_solve calls, lu.rs:145) on a smaller system and scaled by the flop count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    om = O.uv_sphere(RADIUS, n_theta, n_phi)
+    n = om.n_elem
+    k = O.wave_number(freq, C_SOUND)
+    beta = O.beta_scaled(k, 4.0)
+    A = np.zeros((n, n), dtype=np.complex128)
+    rhs = np.zeros(n, dtype=np.complex128)
+    rows = min(n, 16 * cores)
+    t0 = time.perf_counter()
+    O.build_tbem_system_with_beta(om, k, beta, nthreads=cores, rows=(0, rows), A=A, rhs=rhs)
+    t_probe = time.perf_counter() - t0
+    rate = rows * n / t_probe
+    rows2 = int(min(n, max(rows, rate * seconds_target * 0.6 / n)))
+    if rows2 > rows:
+        t0 = time.perf_counter()
+        O.build_tbem_system_with_beta(om, k, beta, nthreads=cores, rows=(0, rows2), A=A, rhs=rhs)
+        t_probe = time.perf_counter() - t0
+        rows = rows2
+    asm_pairs_per_s = rows * n / t_probe
+    del A
+    # dense solve: LAPACK on a 3000 x 3000 complex system
+    ns = min(n, 3000)
+    rng = np.random.default_rng(0)
+    M = rng.standard_normal((ns, ns)) + 1j * rng.standard_normal((ns, ns)) + ns * np.eye(ns)
+    b = rng.standard_normal(ns) + 0j
+    try:
+        import scipy.linalg as sl
+        t0 = time.perf_counter(); lu, piv = sl.lu_factor(M, check_finite=False); sl.lu_solve((lu, piv), b, check_finite=False)
+        t_lu = time.perf_counter() - t0
+        lib = "scipy.linalg.lu_factor/lu_solve (LAPACK zgetrf/zgetrs)"
+    except Exception:
+        t0 = time.perf_counter(); np.linalg.solve(M, b); t_lu = time.perf_counter() - t0
+        lib = "numpy.linalg.solve (LAPACK zgesv)"
+    solve_gflops = lu_flops(ns) / t_lu / 1e9
+    t_step = n * n / asm_pairs_per_s + lu_flops(n) / (solve_gflops * 1e9)
+    return {
+        "value": n * n / t_step, "unit": "panel-pairs/s", "cores": cores, "kind": "port",
+        "sample": "oracle C restatement of build_tbem_system_with_beta: %d of %d rows at %.0f Hz on %d threads (%.1f s) -> %.3e pairs/s; "
+                  "dense solve: %s, n=%d, %.2f s -> %.1f GFLOP/s; step time = N^2/asm + ((8/3)N^3+8N^2)/solve" % (
+                      rows, n, freq, cores, t_probe, asm_pairs_per_s, lib, ns, t_lu, solve_gflops),
+        "assembly_pairs_per_s": asm_pairs_per_s, "solve_gflops": solve_gflops,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-theta", type=int, default=51)
+    ap.add_argument("--n-phi", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import math_audio_amd as ma
+    from math_audio_amd import mesh as mm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    mesh = mm.generate_sphere_mesh(RADIUS, args.n_theta, args.n_phi)
+    n = mesh.n_elem
+    freqs = mm.log_space(100.0, 8000.0, 64)
+    plan = ma.BemPlan(mesh, device=local_rank)
+    lu = ma.LuPlan(n, device=local_rank)
+    A = torch.empty(n * n, dtype=torch.complex128, device=dev)
+    x = torch.empty(n, dtype=torch.complex128, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(s):
+        f = freqs[(rank + s * world) % len(freqs)]
+        k = mm.wave_number(f, C_SOUND)
+        beta = mm.burton_miller_beta_scaled(k, 4.0)
+        plan.assemble_dev(k, beta, A.data_ptr(), x.data_ptr(), stream=stream)
+        plan.incident_rhs_dev(k, beta, x.data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
+        lu.factor_solve_dev(A.data_ptr(), x.data_ptr(), 1, stream=stream)
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    st = lu.status(stream)
+    if st != ma.MA_OK:
+        raise SystemExit("warm-up solve failed: %s" % ma.lib().ma_last_error_string().decode())
+
+    timing = not args.no_timing
+    plan.set_timing(timing); lu.set_timing(timing)
+    asm_ms = np.zeros(3); lu_ms = np.zeros(6)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+        if timing:
+            # reading the events waits for this step's kernels only; no extra work enters the stream
+            asm_ms += plan.last_timing(); lu_ms += lu.last_timing()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if lu.status(stream) != ma.MA_OK:
+        raise SystemExit("solve failed: %s" % ma.lib().ma_last_error_string().decode())
+    xs = x.cpu().numpy()
+    if not np.all(np.isfinite(xs.view(np.float64))):
+        raise SystemExit("non-finite solution")
+
+    if rank == 0:
+        K = args.steps
+        total_pairs = float(n) * n * K * world
+        out = {
+            "metric": "bem_sweep_panel_pairs_per_s", "value": total_pairs / elapsed, "unit": "panel-pairs/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+            "config": {"workload": "S10 UV-sphere r=0.1 n_theta=%d n_phi=%d -> %d Tri3 panels; 64 log-spaced frequencies 100 Hz-8 kHz sharded "
+                                   "f -> rank f mod N; rigid BC, beta=4i/k, plane wave +z; step = TBEM assembly + incident RHS + dense complex LU "
+                                   "solve (zgesv) of one frequency, device-resident" % (args.n_theta, args.n_phi, n),
+                       "panels": n, "frequencies_per_gpu": K, "sharding": "frequency sweep, no data-path collective"},
+        }
+        if timing:
+            asm_t = asm_ms.sum() / K * 1e-3
+            gemm_t = lu_ms[3] / K * 1e-3
+            lu_t = lu_ms[:5].sum() / K * 1e-3
+            n_gemm = max(1.0, lu_ms[5] / K)
+            gf = gemm_flops(n)
+            out["assembly_pairs_per_s"] = n * n / asm_t
+            out["solve_gflops"] = lu_flops(n) / lu_t / 1e9
+            out["phase_ms_per_step"] = {"assembly_far": asm_ms[0] / K, "assembly_near": asm_ms[1] / K, "assembly_self": asm_ms[2] / K,
+                                        "lu_panel": lu_ms[0] / K, "lu_swaps": lu_ms[1] / K, "lu_trsm": lu_ms[2] / K, "lu_zgemm": lu_ms[3] / K,
+                                        "lu_rhs_and_triangular": lu_ms[4] / K}
+            ach = gf / gemm_t / 1e12
+            out["roofline"] = {"kernel": "zgemm_sub_kernel (LU trailing update, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": ach,
+                               "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+                               "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
+                               "algorithmic_flops_per_step": gf}
+            far_t = asm_ms[0] / K * 1e-3
+            out["roofline_assembly"] = {"kernel": "tbem_far_kernel", "bound": "hbm", "achieved": 16.0 * n * n / far_t / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                        "note": "16 B written per pair; the kernel is FP64-VALU/transcendental bound (SURVEY §8d): ~1.2 kflop per pair",
+                                        "fp64_valu_tflops_equiv": 1.2e3 * n * n / far_t / 1e12}
+            try:
+                out["mfma_f64_probe_tflops"] = ma.probe_mfma_f64(local_rank)
+            except Exception as e:      # diagnostics only
+                out["mfma_f64_probe_tflops"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n_theta, args.n_phi, freqs[32])
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

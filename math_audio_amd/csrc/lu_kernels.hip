@@ -9,7 +9,8 @@
 //                      picks the pivot and hands every workgroup the pivot row.
 //   lu_perm_kernel     one wavefront folds the panel's swap sequence into a gather list;
 //   lu_gather/scatter  apply it to the columns left and right of the panel (and to the RHS).
-//   lu_trsm_kernel     U12 = L11^-1 A12, one lane per column, 16-row register blocks.
+//   lu_trsm_strip      U12 = L11^-1 A12, a 64-column strip resident in LDS per workgroup;
+//   lu_trsv_kernel     the nb x nb triangular solves of the right-hand sides, one wavefront each.
 //   zgemm_sub_kernel   A22 -= L21 U12 on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex tile
 //                      product), 128x128 tiles staged through LDS, 8 wavefronts per workgroup.
 #include "lu_kernels.hpp"
@@ -41,7 +42,24 @@ __device__ __forceinline__ dc crecip(dc z) {
 __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) { return v > bv || (v == bv && r < br); }
 
 // ------------------------------------------------------------------ panel factorisation
-// Dynamic LDS: P[rpb][nb+1] | urow[nb] | drow[nb] | small ints.
+// Dynamic LDS: P[rpb][nb+1] | urow[nb] | drow[nb] | small scalars.
+// Per column c every workgroup publishes its best pivot candidate (value, row, the row's nb panel
+// entries) and, if it owns it, the current diagonal row; one arrival counter; then every
+// workgroup reduces the candidates to the same pivot and fetches the pivot row. The candidate of
+// column c+1 is published BEFORE the bulk of step c's rank-1 update (only column c+1 and the two
+// rows that are about to be published are brought up to date first), so the chip-wide wait
+// overlaps the local update.
+struct PanelCand { double v; int row; };
+
+__device__ __forceinline__ PanelCand wave_best(PanelCand c) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_xor(c.v, off, 64); int orow = __shfl_xor(c.row, off, 64);
+    if (cand_better(ov, orow, c.v, c.row)) { c.v = ov; c.row = orow; }
+  }
+  return c;
+}
+
 __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, int n, int k0, int nb, int rpb, LuPanelWs ws,
                                                           int* __restrict__ ipiv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,14 +69,14 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
   dc* drow = urow + nb;
   double* s_wv = reinterpret_cast<double*>(drow + nb);   // [4] wave maxima
   int* s_wr = reinterpret_cast<int*>(s_wv + 4);          // [4] rows
-  int* s_wb = s_wr + 4;                                  // [4] blocks
-  int* s_misc = s_wb + 4;                                // [0] best row, [1] pivot row, [2] winner block, [3] fail
+  int* s_misc = s_wr + 4;                                // [0] best row, [3] fail
   double* s_bestv = reinterpret_cast<double*>(s_misc + 4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, nblk = gridDim.x;
   const int r0 = k0 + b * rpb;
   const int nrows = min(rpb, n - r0);
+  const int myrow = r0 + tid;                            // thread-per-row phases
 
   for (int idx = tid; idx < nrows * nb; idx += 256) {
     int rr = idx / nb, j = idx - rr * nb;
@@ -67,20 +85,12 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
   if (tid == 0) s_misc[3] = 0;
   __syncthreads();
 
-  for (int c = 0; c < nb; ++c) {
-    const int gc = k0 + c;
-    const int buf = c & 1;
-    // ---- 1. local candidate: largest |re|+|im| of column c among this workgroup's rows >= gc
-    {
-      double v = -1.0; int row = INT_MAX;
-      if (tid < nrows && r0 + tid >= gc) { v = cabs1(P[tid * pitch + c]); row = r0 + tid; }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        double ov = __shfl_xor(v, off, 64); int orow = __shfl_xor(row, off, 64);
-        if (cand_better(ov, orow, v, row)) { v = ov; row = orow; }
-      }
-      if (lane == 0) { s_wv[wave] = v; s_wr[wave] = row; }
-    }
+  // local candidate of column `col` among rows >= k0+col -> s_bestv[0], s_misc[0] (after the barriers)
+  auto scan_column = [&](int col) {
+    PanelCand cd; cd.v = -1.0; cd.row = INT_MAX;
+    if (tid < nrows && myrow >= k0 + col) { cd.v = cabs1(P[tid * pitch + col]); cd.row = myrow; }
+    cd = wave_best(cd);
+    if (lane == 0) { s_wv[wave] = cd.v; s_wr[wave] = cd.row; }
     __syncthreads();
     if (tid == 0) {
       double v = s_wv[0]; int row = s_wr[0];
@@ -88,31 +98,41 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       s_bestv[0] = v; s_misc[0] = row;
     }
     __syncthreads();
-    // ---- 2. publish {value, row, the candidate row's nb entries}; the owner of row gc publishes it too
-    {
-      const double bv = s_bestv[0]; const int br = s_misc[0];
-      u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + b) * 2;
-      if (tid == 0) { st_sc1(cand, bv); __hip_atomic_store(cand + 1, (u64)(unsigned)br, RLX_AGENT); }
-      if (br != INT_MAX) {
-        const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
-        u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
-        for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
-      }
-      if (gc >= r0 && gc < r0 + nrows) {
-        const double* src = reinterpret_cast<const double*>(P + (size_t)(gc - r0) * pitch);
-        u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-        for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
-      }
+  };
+  // publish the candidate (and the diagonal row, if owned) of column `col`, then arrive
+  auto publish = [&](int col) {
+    const int buf = col & 1;
+    const double bv = s_bestv[0]; const int br = s_misc[0];
+    u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + b) * 2;
+    if (tid == 0) { st_sc1(cand, bv); __hip_atomic_store(cand + 1, (u64)(unsigned)br, RLX_AGENT); }
+    if (br != INT_MAX) {
+      const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
+      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
+      for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
+    }
+    const int gd = k0 + col;
+    if (gd >= r0 && gd < r0 + nrows) {
+      const double* src = reinterpret_cast<const double*>(P + (size_t)(gd - r0) * pitch);
+      u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+      for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
     __syncthreads();
-    // ---- 3. arrive + wait for every workgroup's candidate of this column (monotonic counter)
+    if (tid == 0) __hip_atomic_fetch_add(ws.counter, 1u, RLX_AGENT);
+  };
+
+  scan_column(0);
+  publish(0);
+
+  for (int c = 0; c < nb; ++c) {
+    const int gc = k0 + c;
+    const int buf = c & 1;
+    // ---- wait for every workgroup's candidate of column c (monotonic counter)
     if (tid == 0) {
-      __hip_atomic_fetch_add(ws.counter, 1u, RLX_AGENT);
       const unsigned target = (unsigned)nblk * (unsigned)(c + 1);
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
       while (__hip_atomic_load(ws.counter, RLX_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {       // 4 s at 100 MHz: give up, never hang
           __hip_atomic_store(ws.timeout, 1u, RLX_AGENT);
           s_misc[3] = 1;
@@ -122,29 +142,23 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     }
     __syncthreads();
     if (s_misc[3]) return;                               // uniform: the whole workgroup leaves
-    // ---- 4. every workgroup reduces the candidates to the same pivot
+    // ---- every wavefront reduces all candidates to the same pivot (no cross-wave step needed)
+    int p, wb;
     {
       double v = -1.0; int row = INT_MAX; int blk = 0;
-      if (tid < nblk) {
-        const u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + tid) * 2;
-        v = ld_sc1(cand); row = (int)(unsigned)__hip_atomic_load(cand + 1, RLX_AGENT); blk = tid;
+      for (int t = lane; t < nblk; t += 64) {
+        const u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + t) * 2;
+        const double cv = ld_sc1(cand); const int cr = (int)(unsigned)__hip_atomic_load(cand + 1, RLX_AGENT);
+        if (cand_better(cv, cr, v, row)) { v = cv; row = cr; blk = t; }
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         double ov = __shfl_xor(v, off, 64); int orow = __shfl_xor(row, off, 64); int ob = __shfl_xor(blk, off, 64);
         if (cand_better(ov, orow, v, row)) { v = ov; row = orow; blk = ob; }
       }
-      if (lane == 0) { s_wv[wave] = v; s_wr[wave] = row; s_wb[wave] = blk; }
+      p = row; wb = blk;
     }
-    __syncthreads();
-    if (tid == 0) {
-      double v = s_wv[0]; int row = s_wr[0]; int blk = s_wb[0];
-      for (int w = 1; w < 4; ++w) if (cand_better(s_wv[w], s_wr[w], v, row)) { v = s_wv[w]; row = s_wr[w]; blk = s_wb[w]; }
-      s_misc[1] = row; s_misc[2] = blk;
-    }
-    __syncthreads();
-    const int p = s_misc[1], wb = s_misc[2];
-    // ---- 5. fetch the pivot row (and the displaced diagonal row) with sc1 loads
+    // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads
     {
       const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX);
       double* dst = reinterpret_cast<double*>(urow);
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       }
     }
     __syncthreads();
-    // ---- 6. interchange inside the panel
+    // ---- interchange inside the panel
     if (p != gc) {
       if (p >= r0 && p < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(p - r0) * pitch + t] = drow[t];
       if (gc >= r0 && gc < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(gc - r0) * pitch + t] = urow[t];
@@ -166,22 +180,52 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     const bool singular = (piv.re == 0.0 && piv.im == 0.0);
     if (singular && b == 0 && tid == 0) atomicCAS(ws.info, 0, gc + 1);   // first zero pivot, as zgetf2's INFO
     __syncthreads();
-    if (singular) continue;
-    // ---- 7. multipliers l = a / pivot (reciprocal scaling, zgetf2)
-    if (tid < nrows && r0 + tid > gc) {
-      const dc ri = crecip(piv);
-      P[tid * pitch + c] = P[tid * pitch + c] * ri;
+    // ---- multipliers l = a / pivot (reciprocal scaling, zgetf2) and the update of column c+1 only
+    const bool more = c + 1 < nb;
+    if (!singular && tid < nrows && myrow > gc) {
+      const dc l = P[tid * pitch + c] * crecip(piv);
+      P[tid * pitch + c] = l;
+      if (more) {
+        dc a = P[tid * pitch + c + 1]; const dc u = urow[c + 1];
+        a.re -= l.re * u.re - l.im * u.im; a.im -= l.re * u.im + l.im * u.re;
+        P[tid * pitch + c + 1] = a;
+      }
     }
-    __syncthreads();
-    // ---- 8. rank-1 update of the columns to the right, inside the panel
-    for (int rr = wave; rr < nrows; rr += 4) {
-      if (r0 + rr <= gc) continue;
-      const dc l = P[rr * pitch + c];
-      for (int j = c + 1 + lane; j < nb; j += 64) {
-        dc a = P[rr * pitch + j]; const dc u = urow[j];
-        a.re = a.re - (l.re * u.re - l.im * u.im);
-        a.im = a.im - (l.re * u.im + l.im * u.re);
-        P[rr * pitch + j] = a;
+    int br = INT_MAX;
+    if (more) {
+      scan_column(c + 1);
+      br = s_misc[0];
+      // ---- bring the two rows that are about to be published fully up to date (columns c+2..)
+      if (!singular) {
+        const int rowsel[2] = {br, gc + 1};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int gr = rowsel[q];
+          if (gr == INT_MAX || gr < r0 || gr >= r0 + nrows || gr <= gc || (q == 1 && gr == br)) continue;
+          const int rr = gr - r0;
+          const dc l = P[rr * pitch + c];
+          for (int j = c + 2 + tid; j < nb; j += 256) {
+            dc a = P[rr * pitch + j]; const dc u = urow[j];
+            a.re -= l.re * u.re - l.im * u.im; a.im -= l.re * u.im + l.im * u.re;
+            P[rr * pitch + j] = a;
+          }
+        }
+      }
+      __syncthreads();
+      publish(c + 1);
+    }
+    // ---- bulk rank-1 update (overlaps the other workgroups' arrival)
+    if (!singular) {
+      const int jfirst = more ? c + 2 : nb;
+      for (int rr = wave; rr < nrows; rr += 4) {
+        const int gr = r0 + rr;
+        if (gr <= gc || gr == br || gr == gc + 1) continue;
+        const dc l = P[rr * pitch + c];
+        for (int j = jfirst + lane; j < nb; j += 64) {
+          dc a = P[rr * pitch + j]; const dc u = urow[j];
+          a.re -= l.re * u.re - l.im * u.im; a.im -= l.re * u.im + l.im * u.re;
+          P[rr * pitch + j] = a;
+        }
       }
     }
     __syncthreads();
@@ -269,58 +313,102 @@ __global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A
   }
 }
 
-// ------------------------------------------------------------------ triangular solve with a small triangle
-// X <- T^-1 X for the nb x ncols block X (element (r, j) at X[r*ldx + j*incx]); T = the nb x nb
-// triangle at Tm (row-major, ld = ldt). UPPER=false: unit lower (forward); UPPER=true: non-unit
-// upper (backward). One lane per column, 16-row register blocks, T rows staged in LDS.
-template <bool UPPER>
-__global__ __launch_bounds__(256) void lu_trsm_kernel(const dc* __restrict__ Tm, int ldt, int nb, dc* __restrict__ X, size_t ldx, size_t incx, int ncols) {
-  __shared__ dc sT[16][LU_NB_MAX + 1];
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool act = j < ncols;
-  dc* Xj = X + (act ? (size_t)j * incx : 0);
+// ------------------------------------------------------------------ U12 = L11^-1 A12 (strip kernel)
+// One workgroup owns a strip of 64 columns of A12 and keeps the whole nb x 64 strip in LDS
+// (128 KB at nb = 128: the strip never leaves the CU during the solve). Lane = column, the 4
+// wavefronts split the rows. Per 16-row block: every thread solves the 16 x 16 unit-lower diagonal
+// block for its own column in registers (the small triangle sits in LDS, read as broadcasts), then
+// the rows below are updated with the 16 multipliers of their row fetched on the scalar path
+// (the row index is wave-uniform, so L[r][rlo..rlo+16) arrives in SGPRs).
+__global__ __launch_bounds__(256, 1) void lu_trsm_strip_kernel(const dc* __restrict__ T, int ldt, int nb, dc* __restrict__ X, size_t ldx, int ncols) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  dc* Xs = reinterpret_cast<dc*>(smem);                 // [nb][64]
+  dc* Ds = Xs + (size_t)nb * 64;                        // [16][16] diagonal block
+  const int tid = threadIdx.x, cg = tid & 63;
+  const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = blockIdx.x * 64;
+  const bool act = c0 + cg < ncols;
+  for (int r = rg; r < nb; r += 4) Xs[r * 64 + cg] = act ? X[(size_t)r * ldx + c0 + cg] : dc_make(0.0, 0.0);
   const int nblk16 = (nb + 15) / 16;
   for (int bi = 0; bi < nblk16; ++bi) {
-    const int rb = UPPER ? (nblk16 - 1 - bi) : bi;
-    const int rlo = rb * 16, rhi = min(rlo + 16, nb), nr = rhi - rlo;
+    const int rlo = bi * 16, nr = min(16, nb - rlo);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nr * nb; idx += 256) { int i = idx / nb, c = idx - i * nb; sT[i][c] = Tm[(size_t)(rlo + i) * ldt + c]; }
+    { const int i = tid >> 4, p = tid & 15; Ds[tid] = (i < nr && p < nr) ? T[(size_t)(rlo + i) * ldt + rlo + p] : dc_make(0.0, 0.0); }
     __syncthreads();
-    if (!act) continue;
     dc x[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = (i < nr) ? Xj[(size_t)(rlo + i) * ldx] : dc_make(0.0, 0.0);
-    if (!UPPER) {
-      for (int p = 0; p < rlo; ++p) {
-        const dc xp = Xj[(size_t)p * ldx];
+    for (int i = 0; i < 16; ++i) x[i] = (i < nr) ? Xs[(rlo + i) * 64 + cg] : dc_make(0.0, 0.0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const dc t = sT[i][p]; x[i].re -= t.re * xp.re - t.im * xp.im; x[i].im -= t.re * xp.im + t.im * xp.re; }
-      }
+    for (int i = 1; i < 16; ++i) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i < nr) {
+      for (int p = 0; p < i; ++p) { const dc t = Ds[i * 16 + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
+    }
+    if (rg == 0) {
 #pragma unroll
-          for (int p = 0; p < i; ++p) { const dc t = sT[i][rlo + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
-        }
-      }
-    } else {
-      for (int p = rhi; p < nb; ++p) {
-        const dc xp = Xj[(size_t)p * ldx];
+      for (int i = 0; i < 16; ++i) if (i < nr) Xs[(rlo + i) * 64 + cg] = x[i];
+    }
+    for (int r = rlo + 16 + rg; r < nb; r += 4) {
+      const dc* __restrict__ Lr = T + (size_t)r * ldt + rlo;      // wave-uniform address -> scalar loads
+      dc acc = Xs[r * 64 + cg];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const dc t = sT[i][p]; x[i].re -= t.re * xp.re - t.im * xp.im; x[i].im -= t.re * xp.im + t.im * xp.re; }
-      }
+      for (int i = 0; i < 16; ++i) { const dc t = Lr[i]; acc.re -= t.re * x[i].re - t.im * x[i].im; acc.im -= t.re * x[i].im + t.im * x[i].re; }
+      Xs[r * 64 + cg] = acc;
+    }
+  }
+  __syncthreads();
+  if (act) for (int r = rg; r < nb; r += 4) X[(size_t)r * ldx + c0 + cg] = Xs[r * 64 + cg];
+}
+
+// ------------------------------------------------------------------ triangular solves for the right-hand sides
+// x <- T^-1 x for one vector of nb <= 128 entries; one wavefront per right-hand side, lane l owns
+// rows l and l + 64 and streams its own rows of T (row-major: contiguous per lane); the solved
+// entry is broadcast with a cross-lane read. UPPER=false: unit lower; UPPER=true: non-unit upper.
+template <bool UPPER>
+__global__ __launch_bounds__(64) void lu_trsv_kernel(const dc* __restrict__ T, int ldt, int nb, dc* __restrict__ B, size_t ldb) {
+  const int lane = threadIdx.x;
+  dc* b = B + (size_t)blockIdx.x * ldb;
+  const int r0 = lane, r1 = lane + 64;
+  dc v0 = r0 < nb ? b[r0] : dc_make(0.0, 0.0);
+  dc v1 = r1 < nb ? b[r1] : dc_make(0.0, 0.0);
+  const dc* T0 = T + (size_t)(r0 < nb ? r0 : 0) * ldt;
+  const dc* T1 = T + (size_t)(r1 < nb ? r1 : 0) * ldt;
+  if (!UPPER) {
+    for (int p0 = 0; p0 < nb; p0 += 8) {
+      dc t0[8], t1[8];
 #pragma unroll
-      for (int i = 15; i >= 0; --i) {
-        if (i < nr) {
+      for (int q = 0; q < 8; ++q) { const int p = min(p0 + q, nb - 1); t0[q] = T0[p]; t1[q] = T1[p]; }   // 16 loads in flight
 #pragma unroll
-          for (int p = 15; p > i; --p) if (p < nr) { const dc t = sT[i][rlo + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
-          x[i] = x[i] * crecip(sT[i][rlo + i]);
+      for (int q = 0; q < 8; ++q) {
+        const int p = p0 + q;
+        if (p < nb) {
+          const int src = p & 63;
+          const double xr = __shfl(p < 64 ? v0.re : v1.re, src, 64), xi = __shfl(p < 64 ? v0.im : v1.im, src, 64);
+          if (r0 > p && r0 < nb) { v0.re -= t0[q].re * xr - t0[q].im * xi; v0.im -= t0[q].re * xi + t0[q].im * xr; }
+          if (r1 > p && r1 < nb) { v1.re -= t1[q].re * xr - t1[q].im * xi; v1.im -= t1[q].re * xi + t1[q].im * xr; }
         }
       }
     }
+  } else {
+    for (int p0 = nb - 1; p0 >= 0; p0 -= 8) {
+      dc t0[8], t1[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) if (i < nr) Xj[(size_t)(rlo + i) * ldx] = x[i];
+      for (int q = 0; q < 8; ++q) { const int p = max(p0 - q, 0); t0[q] = T0[p]; t1[q] = T1[p]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int p = p0 - q;
+        if (p >= 0) {
+          const int src = p & 63;
+          if (r0 == p) v0 = v0 * crecip(t0[q]);               // the owner divides by the diagonal entry first
+          if (r1 == p) v1 = v1 * crecip(t1[q]);
+          const double xr = __shfl(p < 64 ? v0.re : v1.re, src, 64), xi = __shfl(p < 64 ? v0.im : v1.im, src, 64);
+          if (r0 < p) { v0.re -= t0[q].re * xr - t0[q].im * xi; v0.im -= t0[q].re * xi + t0[q].im * xr; }
+          if (r1 < p && r1 < nb) { v1.re -= t1[q].re * xr - t1[q].im * xi; v1.im -= t1[q].re * xi + t1[q].im * xr; }
+        }
+      }
+    }
   }
+  if (r0 < nb) b[r0] = v0;
+  if (r1 < nb) b[r1] = v1;
 }
 
 // ------------------------------------------------------------------ C -= A * B on the f64 matrix cores
@@ -484,11 +572,25 @@ int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, 
   return MA_OK;
 }
 
-int lu_launch_trsm(bool upper, const c64* T, int ldt, int nb, c64* X, size_t ldx, size_t incx, int ncols, hipStream_t st) {
+int lu_trsm_configure() {
+  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return MA_OK;
+}
+
+// X (nb x ncols at X, row stride ldx) <- L11^-1 X with the unit-lower nb x nb triangle at T
+int lu_launch_trsm_strip(const c64* T, int ldt, int nb, c64* X, size_t ldx, int ncols, hipStream_t st) {
   if (ncols <= 0 || nb <= 0) return MA_OK;
-  dim3 grid((ncols + 255) / 256), block(256);
-  if (upper) hipLaunchKernelGGL(lu_trsm_kernel<true>, grid, block, 0, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, incx, ncols);
-  else hipLaunchKernelGGL(lu_trsm_kernel<false>, grid, block, 0, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, incx, ncols);
+  const size_t lds = ((size_t)nb * 64 + 256) * sizeof(dc);
+  hipLaunchKernelGGL(lu_trsm_strip_kernel, dim3((ncols + 63) / 64), dim3(256), lds, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, ncols);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// nrhs vectors b_r = B + r*ldb (nb entries each): b_r <- T^-1 b_r
+int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st) {
+  if (nrhs <= 0 || nb <= 0) return MA_OK;
+  if (upper) hipLaunchKernelGGL(lu_trsv_kernel<true>, dim3(nrhs), dim3(64), 0, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(B), ldb);
+  else hipLaunchKernelGGL(lu_trsv_kernel<false>, dim3(nrhs), dim3(64), 0, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(B), ldb);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -23,7 +23,9 @@ size_t lu_panel_lds_bytes(int nb, int rpb);
 int lu_panel_configure();
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, hipStream_t st);
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, hipStream_t st);
-int lu_launch_trsm(bool upper, const c64* T, int ldt, int nb, c64* X, size_t ldx, size_t incx, int ncols, hipStream_t st);
+int lu_trsm_configure();
+int lu_launch_trsm_strip(const c64* T, int ldt, int nb, c64* X, size_t ldx, int ncols, hipStream_t st);
+int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st);
 int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st);
 int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st);
 int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st);

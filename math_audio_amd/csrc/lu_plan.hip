@@ -86,6 +86,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   P->d_lists = (int*)(base + o_lists);
   P->d_ipiv = (int*)(base + o_ipiv);
   rc = lu_panel_configure();
+  if (!rc) rc = lu_trsm_configure();
   if (rc) { (void)hipFree(P->ws_block); (void)hipFree(P->d_tmp); delete P; return rc; }
   *out = P;
   return MA_OK;
@@ -141,11 +142,11 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrh
     const int nright = n - k0 - nb;
     if ((rc = mark(P, &cur, 2, st))) return rc;
     const c64* T = A + (size_t)k0 * n + k0;
-    if (nright > 0 && (rc = lu_launch_trsm(false, T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, 1, nright, st))) return rc;
+    if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
     if ((rc = mark(P, &cur, 4, st))) return rc;
     // forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b, b[below] -= L21 b[k0:k0+nb]
     if (nrhs > 0) {
-      if ((rc = lu_launch_trsm(false, T, n, nb, B + k0, 1, (size_t)n, nrhs, st))) return rc;
+      if ((rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
       for (int r = 0; r < nrhs && nright > 0; ++r)
         if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
     }
@@ -163,7 +164,7 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrh
   if (nrhs > 0) {
     for (int q = (int)k0s.size() - 1; q >= 0; --q) {
       const int k0 = k0s[q], nb = nbs[q];
-      if ((rc = lu_launch_trsm(true, A + (size_t)k0 * n + k0, n, nb, B + k0, 1, (size_t)n, nrhs, st))) return rc;
+      if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
       for (int r = 0; r < nrhs && k0 > 0; ++r)
         if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
     }
