@@ -158,9 +158,10 @@ int ma_bem_plan_set_timing(ma_bem_plan_t* plan, int enable);
 /* out[0]=far kernel, out[1]=near kernel, out[2]=self kernel ms of the last assemble */
 int ma_bem_plan_last_timing(ma_bem_plan_t* plan, double* out3);
 int ma_lu_plan_set_timing(ma_lu_plan_t* plan, int enable);
-/* out[0]=panel, out[1]=row swaps, out[2]=trsm, out[3]=trailing zgemm, out[4]=triangular solves (ms);
- * out[5]=number of zgemm launches */
-int ma_lu_plan_last_timing(ma_lu_plan_t* plan, double* out6);
+/* out[0]=panel (on the look-ahead stream, overlaps out[3]), out[1]=row swaps, out[2]=trsm, out[3]=trailing
+ * zgemm, out[4]=right-hand-side and triangular solves (ms); out[5]=number of zgemm launches; out[6]=whole
+ * factor+solve on the caller's stream (ms); out[7] reserved */
+int ma_lu_plan_last_timing(ma_lu_plan_t* plan, double* out8);
 
 #ifdef __cplusplus
 }

@@ -257,7 +257,7 @@ class LuPlan:
         check(lib().ma_lu_plan_set_timing(self.h, 1 if on else 0))
 
     def last_timing(self):
-        out = np.zeros(6)
+        out = np.zeros(8)
         check(lib().ma_lu_plan_last_timing(self.h, _vp(out)))
         return out
 

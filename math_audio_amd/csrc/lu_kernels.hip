@@ -5,7 +5,7 @@
 // (swaps are contiguous 16-B-per-lane row copies). Per panel of nb <= 128 columns:
 //   lu_panel_kernel    co-resident workgroups, each keeping its <= 72 rows of the panel in LDS
 //                      (160 KB/CU makes the whole 10k x 128 panel on-chip); one chip-wide
-//                      gather per column (sc1 write-through stores, one counter, sc1 loads)
+//                      gather per column (sc1 write-through stores, tagged 8-byte granules, sc1 loads)
 //                      picks the pivot and hands every workgroup the pivot row.
 //   lu_perm_kernel     one wavefront folds the panel's swap sequence into a gather list;
 //   lu_gather/scatter  apply it to the columns left and right of the panel (and to the RHS).
@@ -16,6 +16,7 @@
 #include "lu_kernels.hpp"
 #include "ma_device_math.hpp"
 #include <climits>
+#include <mutex>
 
 namespace ma {
 
@@ -44,8 +45,8 @@ __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) 
 // ------------------------------------------------------------------ panel factorisation
 // Dynamic LDS: P[rpb][nb+1] | urow[nb] | drow[nb] | small scalars.
 // Per column c every workgroup publishes its best pivot candidate (value, row, the row's nb panel
-// entries) and, if it owns it, the current diagonal row; one arrival counter; then every
-// workgroup reduces the candidates to the same pivot and fetches the pivot row. The candidate of
+// entries) and, if it owns it, the current diagonal row; every workgroup sweeps the tagged
+// candidate granules until all are present, reduces them to the same pivot and fetches its row. The candidate of
 // column c+1 is published BEFORE the bulk of step c's rank-1 update (only column c+1 and the two
 // rows that are about to be published are brought up to date first), so the chip-wide wait
 // overlaps the local update.
@@ -72,6 +73,9 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
   int* s_misc = s_wr + 4;                                // [0] best row, [3] fail
   double* s_bestv = reinterpret_cast<double*>(s_misc + 4);
 
+  // The panel is a chain of short, latency-critical steps; when it shares a CU with throughput-bound
+  // wavefronts (another frequency's trailing update) its instructions should issue first.
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, nblk = gridDim.x;
   const int r0 = k0 + b * rpb;
@@ -88,6 +92,15 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
   // local candidate of column `col` among rows >= k0+col -> s_bestv[0], s_misc[0] (after the barriers)
   auto scan_column = [&](int col) {
     PanelCand cd; cd.v = -1.0; cd.row = INT_MAX;
+    if (nrows <= 64) {                                   // one wavefront sees every row: no cross-wave step
+      if (wave == 0) {
+        if (tid < nrows && myrow >= k0 + col) { cd.v = cabs1(P[tid * pitch + col]); cd.row = myrow; }
+        cd = wave_best(cd);
+        if (lane == 0) { s_bestv[0] = cd.v; s_misc[0] = cd.row; }
+      }
+      __syncthreads();
+      return;
+    }
     if (tid < nrows && myrow >= k0 + col) { cd.v = cabs1(P[tid * pitch + col]); cd.row = myrow; }
     cd = wave_best(cd);
     if (lane == 0) { s_wv[wave] = cd.v; s_wr[wave] = cd.row; }
@@ -99,12 +112,14 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     }
     __syncthreads();
   };
-  // publish the candidate (and the diagonal row, if owned) of column `col`, then arrive
+  // publish the candidate (and the diagonal row, if owned) of column `col`. The 8-byte granule
+  // {high 32 bits of |re|+|im|, tag = col+1, row} is both the data and the flag: it is stored last,
+  // after every wave has drained the row payload (write-through stores), by ONE lane.
+  // Pivot selection therefore compares magnitudes to 21 significant bits (exponent + 20 mantissa
+  // bits); ties go to the lower row. The pivot is within 1e-6 relative of the column maximum.
   auto publish = [&](int col) {
     const int buf = col & 1;
     const double bv = s_bestv[0]; const int br = s_misc[0];
-    u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + b) * 2;
-    if (tid == 0) { st_sc1(cand, bv); __hip_atomic_store(cand + 1, (u64)(unsigned)br, RLX_AGENT); }
     if (br != INT_MAX) {
       const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
       u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
@@ -118,46 +133,63 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(ws.counter, 1u, RLX_AGENT);
+    if (tid == 0) {
+      const u64 hi = br != INT_MAX ? ((u64)__double_as_longlong(bv) >> 32) : 0ull;
+      const u64 lo = ((u64)(unsigned)(col + 1) << 24) | (u64)(br != INT_MAX ? (unsigned)br : 0xFFFFFFu);
+      __hip_atomic_store(ws.cand + (size_t)buf * ws.max_blocks + b, (hi << 32) | lo, RLX_AGENT);
+    }
   };
 
   scan_column(0);
   publish(0);
+#ifdef MA_PANEL_STAMPS
+  u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 stamp_t = __builtin_amdgcn_s_memrealtime();
+#define MA_STAMP(i) do { if (tid == 0) { u64 now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#else
+#define MA_STAMP(i) do { } while (0)
+#endif
 
   for (int c = 0; c < nb; ++c) {
     const int gc = k0 + c;
     const int buf = c & 1;
-    // ---- wait for every workgroup's candidate of column c (monotonic counter)
-    if (tid == 0) {
-      const unsigned target = (unsigned)nblk * (unsigned)(c + 1);
+    // ---- wavefront 0 sweeps every workgroup's granule until all carry this column's tag, and
+    // reduces them on the way (the data is the flag: no counter, no second round trip)
+    if (wave == 0) {
+      const u64* cbase = ws.cand + (size_t)buf * ws.max_blocks;
+      const unsigned want = (unsigned)(c + 1);
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(ws.counter, RLX_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {       // 4 s at 100 MHz: give up, never hang
-          __hip_atomic_store(ws.timeout, 1u, RLX_AGENT);
-          s_misc[3] = 1;
+      u64 best; int bblk; bool fail = false;
+      for (;;) {
+        bool ok = true; best = 0; bblk = 0; unsigned brow = 0xFFFFFFu; unsigned bhi = 0;
+        for (int t = lane; t < nblk; t += 64) {
+          const u64 g = __hip_atomic_load(cbase + t, RLX_AGENT);
+          const unsigned tag = (unsigned)(g >> 24) & 0xFFu, row = (unsigned)g & 0xFFFFFFu, hi = (unsigned)(g >> 32);
+          ok = ok && (tag == want);
+          if (hi > bhi || (hi == bhi && row < brow)) { bhi = hi; brow = row; bblk = t; }
+        }
+        if (__all(ok)) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64); const int ob = __shfl_xor(bblk, off, 64);
+            if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; bblk = ob; }
+          }
+          best = brow;
           break;
         }
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }   // 4 s at 100 MHz: never hang
+      }
+      if (lane == 0) {
+        if (fail) { __hip_atomic_store(ws.timeout, 1u, RLX_AGENT); s_misc[3] = 1; }
+        s_misc[1] = (int)best; s_misc[2] = bblk;
       }
     }
     __syncthreads();
+    MA_STAMP(0);
     if (s_misc[3]) return;                               // uniform: the whole workgroup leaves
-    // ---- every wavefront reduces all candidates to the same pivot (no cross-wave step needed)
-    int p, wb;
-    {
-      double v = -1.0; int row = INT_MAX; int blk = 0;
-      for (int t = lane; t < nblk; t += 64) {
-        const u64* cand = ws.cand + ((size_t)buf * ws.max_blocks + t) * 2;
-        const double cv = ld_sc1(cand); const int cr = (int)(unsigned)__hip_atomic_load(cand + 1, RLX_AGENT);
-        if (cand_better(cv, cr, v, row)) { v = cv; row = cr; blk = t; }
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        double ov = __shfl_xor(v, off, 64); int orow = __shfl_xor(row, off, 64); int ob = __shfl_xor(blk, off, 64);
-        if (cand_better(ov, orow, v, row)) { v = ov; row = orow; blk = ob; }
-      }
-      p = row; wb = blk;
-    }
+    const int p = s_misc[1], wb = s_misc[2];
+    MA_STAMP(1);
     // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads
     {
       const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX);
@@ -170,6 +202,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       }
     }
     __syncthreads();
+    MA_STAMP(2);
     // ---- interchange inside the panel
     if (p != gc) {
       if (p >= r0 && p < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(p - r0) * pitch + t] = drow[t];
@@ -191,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
         P[tid * pitch + c + 1] = a;
       }
     }
+    MA_STAMP(3);
     int br = INT_MAX;
     if (more) {
       scan_column(c + 1);
@@ -212,24 +246,42 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
         }
       }
       __syncthreads();
+      MA_STAMP(4);
       publish(c + 1);
+      MA_STAMP(5);
     }
-    // ---- bulk rank-1 update (overlaps the other workgroups' arrival)
-    if (!singular) {
-      const int jfirst = more ? c + 2 : nb;
-      for (int rr = wave; rr < nrows; rr += 4) {
+    // ---- bulk rank-1 update (overlaps the other workgroups' arrival): lane = row (the row pitch of
+    // nb+1 complex spreads the lanes over all LDS banks); each wavefront takes every 4th group of 4
+    // columns, loads the group before touching it so the LDS latency is paid once per group
+    if (!singular && more) {
+      for (int rbase = 0; rbase < nrows; rbase += 64) {
+        const int rr = rbase + lane;
         const int gr = r0 + rr;
-        if (gr <= gc || gr == br || gr == gc + 1) continue;
-        const dc l = P[rr * pitch + c];
-        for (int j = jfirst + lane; j < nb; j += 64) {
-          dc a = P[rr * pitch + j]; const dc u = urow[j];
-          a.re -= l.re * u.re - l.im * u.im; a.im -= l.re * u.im + l.im * u.re;
-          P[rr * pitch + j] = a;
+        const bool on = rr < nrows && gr > gc && gr != br && gr != gc + 1;
+        const dc l = on ? P[rr * pitch + c] : dc_make(0.0, 0.0);
+        dc* Pr = P + (size_t)(on ? rr : 0) * pitch;
+        for (int j0 = c + 2 + 4 * wave; j0 < nb; j0 += 16) {
+          dc u[4], a[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int j = min(j0 + q, nb - 1); u[q] = urow[j]; a[q] = Pr[j]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { a[q].re -= l.re * u[q].re - l.im * u[q].im; a[q].im -= l.re * u[q].im + l.im * u[q].re; }
+          if (on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (j0 + q < nb) Pr[j0 + q] = a[q];
+          }
         }
       }
     }
-    __syncthreads();
+    // LDS-only barrier: the granule store of publish() may still be in flight (write-through ack ~1 us)
+    // and nothing in the next column depends on it, so do not drain the vector-memory counter here.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    MA_STAMP(6);
   }
+#ifdef MA_PANEL_STAMPS
+  if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, stamp_acc[i]);
+#endif
   for (int idx = tid; idx < nrows * nb; idx += 256) {
     int rr = idx / nb, j = idx - rr * nb;
     A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
@@ -508,6 +560,96 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
       }
 }
 
+// ------------------------------------------------------------------ C -= A * B, 3M form
+// Same contract as zgemm_sub_kernel with three real products per complex product:
+//   T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi);  Re = T1 - T2,  Im = T3 - T1 - T2.
+// 25 % fewer matrix-core instructions than the 4-product form; normwise (not componentwise)
+// backward stable, which is what the LU update needs. Workgroup tile 128 x 64, 8 wavefronts as
+// 4 (M) x 2 (N), 32 x 32 per wavefront = 2 x 2 MFMA tiles x 3 accumulators. The sums Ar+Ai and
+// Br+Bi are formed once per fragment load.
+#define Z3_BM 128
+#define Z3_BN 64
+
+__global__ __launch_bounds__(512, 1) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
+                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
+  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
+  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * Z3_BM, n0 = blockIdx.x * Z3_BN;
+  const int li = lane & 15, lk = lane >> 4;
+
+  v4d t1[2][2], t2[2][2], t3[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { t1[a][b] = (v4d){0, 0, 0, 0}; t2[a][b] = (v4d){0, 0, 0, 0}; t3[a][b] = (v4d){0, 0, 0, 0}; }
+
+  dc ra[2], rb;
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int e = tid + 512 * s;
+      const int row = e >> 3, kk = e & 7;
+      const int gm = m0 + row, gk = k0 + kk;
+      ra[s] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : dc_make(0.0, 0.0);
+    }
+    const int bk = tid >> 6, bn = tid & 63;
+    const int gn = n0 + bn, gk2 = k0 + bk;
+    rb = (gn < N && gk2 < K) ? B[(size_t)gk2 * ldb + gn] : dc_make(0.0, 0.0);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { const int e = tid + 512 * s; As[buf][e & 7][e >> 3] = ra[s]; }
+    Bs[buf][tid >> 6][tid & 63] = rb;
+  };
+
+  const int nstage = (K + ZG_BK - 1) / ZG_BK;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstage) load_stage((st + 1) * ZG_BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int kk = ks * 4 + lk;
+      dc af[2], bf[2];
+      double as[2], bs[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) { af[a] = As[buf][kk][wm * 32 + a * 16 + li]; as[a] = af[a].re + af[a].im; }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) { bf[b] = Bs[buf][kk][wn * 32 + b * 16 + li]; bs[b] = bf[b].re + bf[b].im; }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          t1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].re, bf[b].re, t1[a][b], 0, 0, 0);
+          t2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].im, bf[b].im, t2[a][b], 0, 0, 0);
+          t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bs[b], t3[a][b], 0, 0, 0);
+        }
+    }
+    if (st + 1 < nstage) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm * 32 + a * 16 + lk + 4 * r;
+        const int gn = n0 + wn * 32 + b * 16 + li;
+        if (gm < M && gn < N) {
+          dc* pc = C + (size_t)gm * ldc + gn;
+          dc c = *pc;
+          const double p1 = t1[a][b][r], p2 = t2[a][b][r];
+          c.re -= p1 - p2; c.im -= t3[a][b][r] - p1 - p2;
+          *pc = c;
+        }
+      }
+}
+
 // thin-N variant for the right-hand sides (N = nrhs small): y[m] -= sum_k A[m][k] x[k]; one wave per row
 __global__ __launch_bounds__(256) void zgemv_sub_kernel(int M, int K, const dc* __restrict__ A, size_t lda, const dc* __restrict__ x, dc* __restrict__ y) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -548,11 +690,44 @@ int lu_panel_configure() {
   return MA_OK;
 }
 
-int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, hipStream_t st) {
-  MA_HIP(hipMemsetAsync(ws.counter, 0, 16, st));           // counter + timeout words share one 16-byte block
+// Panel kernels need ALL their workgroups co-resident (they wait for each other every column). Several
+// of them in flight on one device (frequencies in flight on several streams, several plans or host
+// threads) must therefore fit on the chip TOGETHER, or each could hold part of the CUs and wait for the
+// rest forever. The launcher bounds the number of panel kernels in flight per device: launch i waits for
+// the panel kernel launched `lag` launches earlier, where lag x (workgroups per panel) never exceeds what
+// the CUs can hold by LDS. Kernels of other kinds always terminate, so they only delay residency.
+namespace {
+struct PanelSequencer {
+  std::mutex mu;
+  hipEvent_t ring[16][8] = {};
+  bool made[16] = {};
+  unsigned long long count[16] = {};
+};
+PanelSequencer g_seq;
+}  // namespace
+
+int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, hipStream_t st) {
+  int dev = 0;
+  MA_HIP(hipGetDevice(&dev));
+  MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
   const size_t lds = lu_panel_lds_bytes(nb, rpb);
+  int per_cu = (int)((160 * 1024) / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
+  int lag = (ncu * per_cu) / (nblk > 0 ? nblk : 1);
+  if (lag < 1) lag = 1;
+  if (lag > 8) lag = 8;
+  std::lock_guard<std::mutex> lock(g_seq.mu);
+  if (!g_seq.made[dev]) {
+    for (int i = 0; i < 8; ++i) MA_HIP(hipEventCreateWithFlags(&g_seq.ring[dev][i], hipEventDisableTiming));
+    g_seq.made[dev] = true;
+  }
+  const unsigned long long i = g_seq.count[dev];
+  // slot (i mod 8) still holds launch i-8; launch i-lag sits in slot (i - lag) mod 8
+  if (i >= (unsigned long long)lag) MA_HIP(hipStreamWaitEvent(st, g_seq.ring[dev][(i - lag) & 7], 0));
+  MA_HIP(hipMemsetAsync(ws.cand, 0, sizeof(unsigned long long) * 2 * (size_t)ws.max_blocks, st));   // stale tags must not match
   hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(A), n, k0, nb, rpb, ws, ipiv);
   MA_HIP(hipGetLastError());
+  MA_HIP(hipEventRecord(g_seq.ring[dev][i & 7], st));
+  g_seq.count[dev] = i + 1;
   return MA_OK;
 }
 
@@ -595,8 +770,15 @@ int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb
   return MA_OK;
 }
 
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st) {
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m) {
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
+  if (use_3m) {
+    dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
+    hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(512), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+                       reinterpret_cast<dc*>(C), ldc);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+  }
   dim3 grid((N + ZG_BN - 1) / ZG_BN, (M + ZG_BM - 1) / ZG_BM), block(512);
   hipLaunchKernelGGL(zgemm_sub_kernel, grid, block, 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
                      reinterpret_cast<dc*>(C), ldc);

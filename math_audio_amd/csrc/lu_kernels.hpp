@@ -6,11 +6,11 @@
 
 namespace ma {
 
-// Global scratch shared by the co-resident workgroups of lu_panel_kernel. `counter` and `timeout`
-// live in one 16-byte block that is zeroed before every launch (arrival counter is monotonic
-// within a launch); `info` persists over a factorisation (first zero pivot, 1-based; 0 = none).
+// Global scratch shared by the co-resident workgroups of lu_panel_kernel. `counter` lives in a
+// 16-byte block that is zeroed before every launch (the arrival counter is monotonic within a
+// launch); `info` (first zero pivot, 1-based; 0 = none) and `timeout` persist over a factorisation.
 struct LuPanelWs {
-  unsigned* counter;            // [0] arrivals, [1] timeout flag (same 16-byte block)
+  unsigned* counter;            // arrivals
   unsigned* timeout;
   int* info;
   unsigned long long* cand;     // [2][max_blocks][2]   {|re|+|im| bits, row}
@@ -21,12 +21,12 @@ struct LuPanelWs {
 
 size_t lu_panel_lds_bytes(int nb, int rpb);
 int lu_panel_configure();
-int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, hipStream_t st);
+int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, hipStream_t st);
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, hipStream_t st);
 int lu_trsm_configure();
 int lu_launch_trsm_strip(const c64* T, int ldt, int nb, c64* X, size_t ldx, int ncols, hipStream_t st);
 int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st);
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st);
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m);
 int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st);
 int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st);
 

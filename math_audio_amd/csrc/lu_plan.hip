@@ -2,6 +2,7 @@
 // (replaces lu_solve, math-solvers/src/direct/lu.rs:142-153).
 #include "lu_kernels.hpp"
 #include <vector>
+#include <algorithm>
 #include <new>
 
 using namespace ma;
@@ -18,15 +19,24 @@ struct ma_lu_plan {
   int nrhs_max = 4;
   bool timing = false;
   std::vector<hipEvent_t> ev;     // event pool for per-phase timing
-  std::vector<int> ev_phase;      // phase id of interval i (between ev[i] and ev[i+1])
+  size_t ev_used = 0;
+  struct Iv { int a, b, phase; };
+  std::vector<Iv> iv;             // timed intervals of the last call
+  int ev_last = -1;
   int n_gemm_launch = 0;
   bool ev_valid = false;
+  hipStream_t panel_stream = nullptr;   // high-priority stream for the look-ahead panel
+  hipEvent_t sync_ev[3] = {nullptr, nullptr, nullptr};
+  bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
+  int want_nb = LU_NB_MAX;
+  bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
+  int rpb_cap = 44;               // rows per panel workgroup: 44 x 129 x 16 B = 91 KB leaves room for a zgemm workgroup on the CU
 };
 
 namespace {
 
 // Panel geometry: widest panel (128/64/32/16) whose rows fit the co-resident workgroups' LDS.
-void panel_shape(int R, int ncu, int want_nb, int* nb_out, int* rpb_out, int* nblk_out) {
+void panel_shape(int R, int ncu, int want_nb, int rpb_cap, int* nb_out, int* rpb_out, int* nblk_out) {
   const int widths[4] = {128, 64, 32, 16};
   for (int w = 0; w < 4; ++w) {
     int nb = widths[w];
@@ -34,7 +44,7 @@ void panel_shape(int R, int ncu, int want_nb, int* nb_out, int* rpb_out, int* nb
     if (rpb_max > 256) rpb_max = 256;
     long long cap = (long long)rpb_max * ncu;
     if (cap >= R || w == 3) {
-      int rpb = rpb_max < 64 ? rpb_max : 64;          // prefer <= 64 rows per workgroup, more workgroups
+      int rpb = rpb_max < rpb_cap ? rpb_max : rpb_cap; // few rows per workgroup: small LDS footprint, short local update
       int nblk = (R + rpb - 1) / rpb;
       if (nblk > ncu) { rpb = (R + ncu - 1) / ncu; nblk = (R + rpb - 1) / rpb; }
       if (nb > want_nb) nb = want_nb;
@@ -65,7 +75,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_sync = take(16), o_info = take(16), o_cand = take(sizeof(unsigned long long) * 2 * mb * 2),
-               o_crow = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX), o_drow = take(sizeof(unsigned long long) * 2 * 2 * LU_NB_MAX),
+               o_crow = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX), o_drow = take(sizeof(unsigned long long) * (2 * 2 * LU_NB_MAX + 16)),
                o_lists = take(sizeof(int) * (1 + 4 * LU_NB_MAX)), o_ipiv = take(sizeof(int) * (size_t)n);
   hipError_t e = hipMalloc(&P->ws_block, off);
   if (e == hipSuccess) e = hipMalloc(&P->d_tmp, sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + P->nrhs_max));
@@ -77,8 +87,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   }
   char* base = (char*)P->ws_block;
   P->pws.counter = (unsigned*)(base + o_sync);
-  P->pws.timeout = P->pws.counter + 1;
   P->pws.info = (int*)(base + o_info);
+  P->pws.timeout = (unsigned*)(P->pws.info + 1);     // persists over the factorisation, like info
   P->pws.cand = (unsigned long long*)(base + o_cand);
   P->pws.candrow = (unsigned long long*)(base + o_crow);
   P->pws.diagrow = (unsigned long long*)(base + o_drow);
@@ -87,6 +97,17 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   P->d_ipiv = (int*)(base + o_ipiv);
   rc = lu_panel_configure();
   if (!rc) rc = lu_trsm_configure();
+  if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v == 16 || v == 32 || v == 64 || v == 128) P->want_nb = v; }
+  if (const char* e0 = getenv("MA_ZGEMM_3M")) P->use_3m = atoi(e0) != 0;
+  if (const char* e2 = getenv("MA_LU_LOOKAHEAD")) P->lookahead = atoi(e2) != 0;
+  if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) P->rpb_cap = v; }
+  if (!rc) {
+    int lo = 0, hi = 0;
+    hipError_t e4 = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e4 == hipSuccess) e4 = hipStreamCreateWithPriority(&P->panel_stream, hipStreamNonBlocking, hi);
+    for (int i = 0; i < 3 && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->sync_ev[i], hipEventDisableTiming);
+    if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
+  }
   if (rc) { (void)hipFree(P->ws_block); (void)hipFree(P->d_tmp); delete P; return rc; }
   *out = P;
   return MA_OK;
@@ -96,6 +117,8 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (!P) return MA_OK;
   (void)hipSetDevice(P->device);
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
+  for (int i = 0; i < 3; ++i) if (P->sync_ev[i]) (void)hipEventDestroy(P->sync_ev[i]);
+  if (P->panel_stream) (void)hipStreamDestroy(P->panel_stream);
   if (P->d_tmp) (void)hipFree(P->d_tmp);
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
@@ -109,68 +132,118 @@ int ma_lu_plan_set_timing(ma_lu_plan_t* P, int enable) {
   return MA_OK;
 }
 
-static int mark(ma_lu_plan* P, size_t* cursor, int phase, hipStream_t st) {
+// timing bookkeeping: events are taken from a pool; an interval is (begin event, end event, phase)
+static int mark(ma_lu_plan* P, hipStream_t st, int* idx_out) {
+  *idx_out = -1;
   if (!P->timing) return MA_OK;
-  if (*cursor >= P->ev.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); P->ev.push_back(e); }
-  MA_HIP(hipEventRecord(P->ev[*cursor], st));
-  if (*cursor >= P->ev_phase.size()) P->ev_phase.push_back(phase); else P->ev_phase[*cursor] = phase;
-  ++*cursor;
+  if (P->ev_used >= P->ev.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); P->ev.push_back(e); }
+  MA_HIP(hipEventRecord(P->ev[P->ev_used], st));
+  *idx_out = (int)P->ev_used++;
   return MA_OK;
 }
+static void interval(ma_lu_plan* P, int a, int b, int phase) {
+  if (a >= 0 && b >= 0) P->iv.push_back({a, b, phase});
+}
+#define MA_MARK(var, stream) int var; if ((rc = mark(P, (stream), &var))) return rc
 
 // Factor d_A in place and solve for nrhs right-hand sides (d_B[nrhs][n]); everything asynchronous.
+//
+// Right-looking blocked LU with one panel of look-ahead: as soon as the columns of panel q+1 have
+// received panel q's update (a narrow zgemm), panel q+1 is factored on the plan's own high-priority
+// stream while the rest of panel q's trailing update runs on the caller's stream. The panel
+// workgroups are latency-bound (one chip-wide gather per column) and sized to share a CU with a
+// zgemm workgroup (LDS 95 KB + 64 KB), so the matrix cores stay busy underneath them.
 int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrhs, void* stream) {
   MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
   MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
   MA_REQUIRE(nrhs == 0 || dB, MA_ERR_INVALID, "d_B is NULL");
   MA_HIP(hipSetDevice(P->device));
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sp = P->lookahead ? P->panel_stream : st;
   const int n = P->n;
   c64* A = (c64*)dA; c64* B = (c64*)dB;
   int rc;
+  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->ev_valid = false;
   MA_HIP(hipMemsetAsync(P->pws.info, 0, 16, st));
-  size_t cur = 0; P->n_gemm_launch = 0;
-  // phases: 0 panel, 1 swaps, 2 trsm, 3 zgemm, 4 rhs/triangular solves, 5 end marker
-  std::vector<int> k0s, nbs;
+  MA_MARK(e_begin, st);
+
+  // panel schedule
+  std::vector<int> k0s, nbs, rpbs, nblks;
   for (int k0 = 0; k0 < n;) {
     int nb, rpb, nblk;
-    panel_shape(n - k0, P->ncu, n - k0 < LU_NB_MAX ? n - k0 : LU_NB_MAX, &nb, &rpb, &nblk);
-    if ((rc = mark(P, &cur, 0, st))) return rc;
-    if ((rc = lu_launch_panel(A, n, k0, nb, rpb, nblk, P->pws, P->d_ipiv, st))) return rc;
-    if ((rc = mark(P, &cur, 1, st))) return rc;
-    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv, P->d_lists, P->d_tmp, B, nrhs, st))) return rc;
+    panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), P->rpb_cap, &nb, &rpb, &nblk);
+    k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
+    k0 += nb;
+  }
+  const int Q = (int)k0s.size();
+  auto panel = [&](int q) -> int {
+    MA_MARK(a, sp);
+    if ((rc = lu_launch_panel(A, n, k0s[q], nbs[q], rpbs[q], nblks[q], P->ncu, P->pws, P->d_ipiv, sp))) return rc;
+    MA_MARK(b, sp);
+    interval(P, a, b, 0);
+    return MA_OK;
+  };
+  if (sp != st) { MA_HIP(hipEventRecord(P->sync_ev[0], st)); MA_HIP(hipStreamWaitEvent(sp, P->sync_ev[0], 0)); }
+  if ((rc = panel(0))) return rc;
+  for (int q = 0; q < Q; ++q) {
+    const int k0 = k0s[q], nb = nbs[q];
     const int nright = n - k0 - nb;
-    if ((rc = mark(P, &cur, 2, st))) return rc;
+    if (sp != st) { MA_HIP(hipEventRecord(P->sync_ev[1], sp)); MA_HIP(hipStreamWaitEvent(st, P->sync_ev[1], 0)); }
+    MA_MARK(t0, st);
+    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv, P->d_lists, P->d_tmp, B, nrhs, st))) return rc;
+    MA_MARK(t1, st);
+    interval(P, t0, t1, 1);
     const c64* T = A + (size_t)k0 * n + k0;
     if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
-    if ((rc = mark(P, &cur, 4, st))) return rc;
+    MA_MARK(t2, st);
+    interval(P, t1, t2, 2);
     // forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b, b[below] -= L21 b[k0:k0+nb]
     if (nrhs > 0) {
       if ((rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
       for (int r = 0; r < nrhs && nright > 0; ++r)
         if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
     }
-    if ((rc = mark(P, &cur, 3, st))) return rc;
+    MA_MARK(t3, st);
+    interval(P, t2, t3, 4);
     if (nright > 0) {
-      if ((rc = lu_launch_zgemm_sub(nright, nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, A + (size_t)k0 * n + k0 + nb, (size_t)n,
-                                    A + (size_t)(k0 + nb) * n + k0 + nb, (size_t)n, st))) return rc;
-      P->n_gemm_launch++;
+      const c64* L21 = A + (size_t)(k0 + nb) * n + k0;
+      const c64* U12 = A + (size_t)k0 * n + k0 + nb;
+      c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
+      const int nnext = (q + 1 < Q) ? nbs[q + 1] : 0;
+      if (sp != st && nnext > 0) {
+        // narrow update of the next panel's columns first, then factor it concurrently with the rest
+        if ((rc = lu_launch_zgemm_sub(nright, nnext, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
+        P->n_gemm_launch++;
+        MA_HIP(hipEventRecord(P->sync_ev[2], st)); MA_HIP(hipStreamWaitEvent(sp, P->sync_ev[2], 0));
+        if ((rc = panel(q + 1))) return rc;
+        if (nright - nnext > 0) {
+          if ((rc = lu_launch_zgemm_sub(nright, nright - nnext, nb, L21, (size_t)n, U12 + nnext, (size_t)n, A22 + nnext, (size_t)n, st, P->use_3m))) return rc;
+          P->n_gemm_launch++;
+        }
+      } else {
+        if ((rc = lu_launch_zgemm_sub(nright, nright, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
+        P->n_gemm_launch++;
+        if (q + 1 < Q && (rc = panel(q + 1))) return rc;
+      }
     }
-    k0s.push_back(k0); nbs.push_back(nb);
-    k0 += nb;
+    MA_MARK(t4, st);
+    interval(P, t3, t4, 3);
   }
   // backward substitution U x = y, block rows from the bottom
-  if ((rc = mark(P, &cur, 4, st))) return rc;
+  MA_MARK(t5, st);
   if (nrhs > 0) {
-    for (int q = (int)k0s.size() - 1; q >= 0; --q) {
+    for (int q = Q - 1; q >= 0; --q) {
       const int k0 = k0s[q], nb = nbs[q];
       if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
       for (int r = 0; r < nrhs && k0 > 0; ++r)
         if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
     }
   }
-  if ((rc = mark(P, &cur, 5, st))) return rc;
-  if (P->timing) { P->ev.resize(P->ev.size()); P->ev_phase.resize(cur); P->ev_valid = true; }
+  MA_MARK(e_end, st);
+  interval(P, t5, e_end, 4);
+  interval(P, e_begin, e_end, 6);
+  P->ev_last = e_end;
+  if (P->timing) P->ev_valid = true;
   return MA_OK;
 }
 
@@ -178,28 +251,28 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipStreamSynchronize((hipStream_t)stream));
-  int info = 0; unsigned sync[2] = {0, 0};
-  MA_HIP(hipMemcpy(&info, P->pws.info, sizeof(int), hipMemcpyDeviceToHost));
-  MA_HIP(hipMemcpy(sync, P->pws.counter, sizeof(sync), hipMemcpyDeviceToHost));
-  MA_REQUIRE(sync[1] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
-  MA_REQUIRE(info == 0, MA_ERR_SINGULAR, "matrix is singular: zero pivot at column %d", info - 1);
+  if (P->panel_stream) MA_HIP(hipStreamSynchronize(P->panel_stream));
+  int info[2] = {0, 0};
+  MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
+  MA_REQUIRE(info[1] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
+  MA_REQUIRE(info[0] == 0, MA_ERR_SINGULAR, "matrix is singular: zero pivot at column %d", info[0] - 1);
   return MA_OK;
 }
 
-int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out6) {
-  MA_REQUIRE(P && out6, MA_ERR_INVALID, "NULL argument");
-  MA_REQUIRE(P->ev_valid && P->ev_phase.size() >= 2, MA_ERR_INVALID, "no timed factorisation has run on this plan");
+int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
+  MA_REQUIRE(P && out8, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(P->ev_valid && P->ev_last >= 0, MA_ERR_INVALID, "no timed factorisation has run on this plan");
   MA_HIP(hipSetDevice(P->device));
-  const size_t m = P->ev_phase.size();
-  MA_HIP(hipEventSynchronize(P->ev[m - 1]));
-  for (int i = 0; i < 6; ++i) out6[i] = 0.0;
-  for (size_t i = 0; i + 1 < m; ++i) {
+  MA_HIP(hipEventSynchronize(P->ev[P->ev_last]));
+  if (P->panel_stream) MA_HIP(hipStreamSynchronize(P->panel_stream));
+  for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+  for (const auto& v : P->iv) {
     float ms = 0.f;
-    MA_HIP(hipEventElapsedTime(&ms, P->ev[i], P->ev[i + 1]));
-    int ph = P->ev_phase[i];
-    if (ph >= 0 && ph < 5) out6[ph] += ms;
+    MA_HIP(hipEventElapsedTime(&ms, P->ev[v.a], P->ev[v.b]));
+    if (v.phase >= 0 && v.phase < 5) out8[v.phase] += ms;
+    else if (v.phase == 6) out8[6] = ms;
   }
-  out6[5] = P->n_gemm_launch;
+  out8[5] = P->n_gemm_launch;
   return MA_OK;
 }
 
@@ -253,10 +326,21 @@ int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma
   MA_HIP(hipMemcpy(dA, A, sizeof(c64) * (size_t)M * K, hipMemcpyHostToDevice));
   MA_HIP(hipMemcpy(dB, B, sizeof(c64) * (size_t)K * N, hipMemcpyHostToDevice));
   MA_HIP(hipMemcpy(dC, C, sizeof(c64) * (size_t)M * N, hipMemcpyHostToDevice));
-  rc = lu_launch_zgemm_sub(M, N, K, dA, (size_t)K, dB, (size_t)N, dC, (size_t)N, nullptr);
+  { bool m3 = true; if (const char* e0 = getenv("MA_ZGEMM_3M")) m3 = atoi(e0) != 0; rc = lu_launch_zgemm_sub(M, N, K, dA, (size_t)K, dB, (size_t)N, dC, (size_t)N, nullptr, m3); }
   if (!rc) { hipError_t e = hipMemcpy(C, dC, sizeof(c64) * (size_t)M * N, hipMemcpyDeviceToHost); if (e != hipSuccess) { set_error("copy back: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; } }
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
   return rc;
+}
+
+// Diagnostic build only (-DMA_PANEL_STAMPS): per-phase 100 MHz tick totals of workgroup 0 of every panel kernel
+int ma_lu_plan_panel_stamps(ma_lu_plan_t* P, unsigned long long* out8, int reset) {
+  MA_REQUIRE(P && out8, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(P->device));
+  MA_HIP(hipDeviceSynchronize());
+  unsigned long long* d = P->pws.diagrow + 2 * 2 * LU_NB_MAX;
+  MA_HIP(hipMemcpy(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) MA_HIP(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
+  return MA_OK;
 }
 
 // MFMA f64 issue-rate probe (bench.py uses it to state the measured matrix-core peak next to the
