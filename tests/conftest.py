@@ -8,16 +8,25 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-def pytest_configure(config):
-    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
-
-
 def _gpu_count():
+    # PyTorch-ROCm bundles its own HIP runtime; when a test uses torch tensors as device buffers, torch has
+    # to initialise the GPU BEFORE libmathaudio_hip.so pulls in a runtime of the same soname (the loader then
+    # shares torch's copy). bench.py has the same order.
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     try:
         import math_audio_amd as ma
         return ma.device_count()
     except Exception:
         return 0
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    config._ma_gpu_count = _gpu_count()      # also fixes the HIP runtime load order (see _gpu_count)
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,339 @@
+"""The CPU oracle pinned against the reference's own known answers for this path
+and against independent libraries (NumPy/SciPy LAPACK, scipy.special). No GPU needed."""
+import os
+import numpy as np
+import pytest
+import scipy.linalg as sl
+import scipy.special as sp
+import oracle_lib as O
+from helpers import k_from_ka, RADIUS, rel_l2
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "bem_golden.npz"))
+
+
+# ---------------------------------------------------------------- quadrature (gauss.rs:415-442)
+@pytest.mark.parametrize("n", [2, 4, 6, 8, 10, 12, 16, 20])
+def test_gauss_weights_sum_to_two(n):
+    x, w = O.gauss_legendre(n)
+    assert len(x) == n and abs(w.sum() - 2.0) < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20])
+def test_gauss_tables_are_gauss_legendre(n):
+    x, w = O.gauss_legendre(n)
+    xr, wr = np.polynomial.legendre.leggauss(n)
+    assert np.abs(x - xr).max() < 2e-15 and np.abs(w - wr).max() < 2e-15
+
+
+def test_gauss_fallback_to_next_table():          # gauss.rs:41-58
+    assert len(O.gauss_legendre(9)[0]) == 12 and len(O.gauss_legendre(11)[0]) == 12
+    assert len(O.gauss_legendre(13)[0]) == 16 and len(O.gauss_legendre(17)[0]) == 20 and len(O.gauss_legendre(33)[0]) == 20
+
+
+def test_triangle_rules():                          # gauss.rs:424-432: weights sum to 0.5
+    for order, npts in ((1, 1), (2, 4), (3, 7), (4, 13), (7, 13)):
+        q = O.triangle_quadrature(order)
+        assert q.shape == (npts, 3) and abs(q[:, 2].sum() - 0.5) < 1e-10
+    q = O.triangle_quadrature(4)                    # degree-7 rule integrates x^3 y^2 over the unit triangle: 3!2!/7! = 1/420
+    assert abs((q[:, 0] ** 3 * q[:, 1] ** 2 * q[:, 2]).sum() - 1.0 / 420.0) < 1e-12
+
+
+def test_quad_rule():                               # gauss.rs:434-442
+    q = O.quad_quadrature(2)
+    assert q.shape == (4, 3) and abs(q[:, 2].sum() - 4.0) < 1e-10
+
+
+# ---------------------------------------------------------------- panel integrals
+TRI = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+
+
+def test_planar_self_term_invariants():             # singular.rs:779-815
+    k = O.wave_number(10.0, 343.0)
+    x = TRI.mean(axis=0); n = np.array([0.0, 0.0, 1.0])
+    r = O.singular_integration(x, n, TRI, k)
+    assert r[0].real > 0.0                           # Re G > 0
+    assert abs(r[1]) < 1e-10 and abs(r[2]) < 1e-10   # |H|, |H^T| vanish in the panel's own plane
+    assert np.all(np.isfinite(r.view(np.float64)))
+
+
+def test_far_field_g_is_small_and_matches_point_kernel():   # regular.rs:537-559 (|G| < 0.1) + closed form
+    k = 2.0
+    x = np.array([0.3, 0.2, 40.0]); n = np.array([0.0, 0.0, 1.0])
+    r = O.regular_integration(x, n, TRI, 0.5, k)
+    assert abs(r[0]) < 0.1
+    d = np.linalg.norm(TRI.mean(axis=0) - x)
+    g = 0.5 * np.exp(1j * k * d) / (4 * np.pi * d)   # area x G(centroid): exact to O((h/d)^2)
+    assert abs(r[0] - g) / abs(g) < 5e-3
+
+
+def test_green_kernel_unit_value():                  # math-wave helmholtz.rs:28-31: |G(r=1,k=2)| = 1/4pi
+    tiny = TRI * 1e-4
+    x = np.array([0.0, 0.0, 1.0])
+    r = O.regular_integration(x, np.array([0.0, 0.0, 1.0]), tiny, 0.5e-8, 2.0)
+    assert abs(abs(r[0]) / 0.5e-8 - 1.0 / (4 * np.pi)) < 1e-7
+
+
+def _leaf_area(subs):
+    area = 0.0
+    for s in subs:
+        t = np.array(list(s.tri)).reshape(3, 2)
+        area += 0.5 * abs((t[1, 0] - t[0, 0]) * (t[2, 1] - t[0, 1]) - (t[2, 0] - t[0, 0]) * (t[1, 1] - t[0, 1]))
+    return area
+
+
+def test_subelements_unsplit_when_far_and_split_when_near():    # singular.rs:497-660
+    far = O.generate_subelements([0.3, 0.3, 10.0], TRI, 0.5)
+    assert len(far) == 1 and far[0].factor == 1.0 and far[0].gauss_order == 4
+    near = O.generate_subelements([0.3, 0.3, 0.8], TRI, 0.5)       # two levels, every level fully kept
+    assert len(near) == 16 and all(s.factor == 0.25 for s in near)
+    assert abs(_leaf_area(near) - 0.5) < 1e-12                     # leaves tile the parent exactly
+
+
+def test_subelements_level_overflow_quirk():
+    """`ndie > 15 => break` (singular.rs:556-562) abandons the rest of a level: for a very near point the
+    stored leaves do NOT cover the panel. The restatement (and the device kernel) must reproduce that."""
+    very = O.generate_subelements([0.3, 0.3, 0.05], TRI, 0.5)
+    assert len(very) == 109
+    assert abs(_leaf_area(very) - 0.40625) < 1e-12
+    capped = O.generate_subelements([0.33, 0.33, 1e-4], TRI, 0.5)
+    assert len(capped) <= 110
+
+
+def test_subdivided_integral_converges_to_fine_quadrature():
+    """A near-singular integral from the adaptive path agrees with brute-force tensor quadrature."""
+    k = 5.0
+    x = np.array([0.3, 0.25, 0.8]); nx = np.array([0.0, 0.0, 1.0])     # two full levels of subdivision, no level overflow
+    got = O.regular_integration(x, nx, TRI, 0.5, k)[0]
+    xs, ws = np.polynomial.legendre.leggauss(200)
+    u = 0.5 * (xs + 1); wu = 0.5 * ws
+    U, V = np.meshgrid(u, u, indexing="ij"); W = np.outer(wu, wu)
+    s = U; t = V * (1 - U); jac = (1 - U)              # Duffy map of the unit square onto the triangle
+    y = np.stack([s, t, np.zeros_like(s)], axis=-1)
+    r = np.linalg.norm(y - x, axis=-1)
+    ref = (W * jac * np.exp(1j * k * r) / (4 * np.pi * r)).sum()
+    assert abs(got - ref) / abs(ref) < 5e-4           # GAU_ACCU = 5e-4 is the reference's own accuracy target
+
+
+# ---------------------------------------------------------------- meshes (generators.rs tests)
+def test_icosphere_counts_and_radius():
+    for sub, (nn, ne) in enumerate([(12, 20), (42, 80), (162, 320), (642, 1280)]):
+        m = O.icosphere(RADIUS, sub)
+        assert m.nodes.shape[0] == nn and m.n_elem == ne
+        assert np.abs(np.linalg.norm(m.nodes, axis=1) - RADIUS).max() < 1e-12
+        assert np.all((m.normal * m.center).sum(axis=1) > 0)         # outward
+        assert abs(m.area.sum() - 4 * np.pi * RADIUS ** 2) / (4 * np.pi * RADIUS ** 2) < (0.35 if sub == 0 else 0.1)
+
+
+def test_uv_sphere_counts():
+    m = O.uv_sphere(RADIUS, 51, 100)
+    assert m.n_elem == 10000 and m.nodes.shape[0] == 5002
+    cs = GOLD["s10_checksums"]
+    got = np.array([m.nodes.sum(), np.abs(m.nodes).sum(), m.area.sum(), m.center[:, 2].sum(), float(m.conn[:, :3].astype(np.int64).sum()), 10000.0])
+    assert np.allclose(got, cs, rtol=1e-13, atol=1e-13)
+
+
+# ---------------------------------------------------------------- Mie oracle (solutions_3d.rs)
+@pytest.mark.parametrize("x", [0.2, 1.0, 3.0, 14.7])
+def test_spherical_bessel_against_scipy(x):
+    for n in range(0, 40):
+        j = O.lib().mao_spherical_bessel_j(n, x); jr = sp.spherical_jn(n, x)
+        assert abs(j - jr) <= 1e-12 * max(abs(jr), 1e-300) + 1e-300
+        y = O.lib().mao_spherical_bessel_y(n, x); yr = sp.spherical_yn(n, x)
+        assert abs(y - yr) <= 1e-10 * abs(yr)
+    assert abs(O.lib().mao_legendre_p(7, 0.3) - sp.eval_legendre(7, 0.3)) < 1e-14
+
+
+def _mie_scipy(k, a, r, theta, terms=50, reference_quirk=True):
+    """Rigid-sphere series with scipy.special. reference_quirk=True reproduces solutions_3d.rs:167-173,
+    which uses y_{-1}(x) = -sin(x)/x for the n = 0 derivative (the identity is +sin(x)/x), so the
+    reference's a_0 is slightly off; the restatement follows the reference, not the textbook."""
+    ka = k * a
+    n = np.arange(terms)
+    jp = sp.spherical_jn(n, ka, derivative=True)
+    yp = sp.spherical_yn(n, ka, derivative=True)
+    if reference_quirk:
+        yp = yp.copy(); yp[0] = -np.sin(ka) / ka - (1.0 / ka) * sp.spherical_yn(0, ka)
+    an = jp / (jp + 1j * yp)
+    hn = sp.spherical_jn(n, k * r) + 1j * sp.spherical_yn(n, k * r)
+    t = (2 * n + 1) * (1j ** n) * (sp.spherical_jn(n, k * r) - an * hn) * sp.eval_legendre(n, np.cos(theta))
+    return t[np.isfinite(t)].sum()
+
+
+@pytest.mark.parametrize("ka", [0.2, 1.0, 3.0])
+def test_mie_series_against_scipy(ka):
+    k = ka / RADIUS
+    theta = np.linspace(0, np.pi, 9)
+    got = O.sphere_scattering_3d(k, RADIUS, 50, [RADIUS, 2 * RADIUS], theta)
+    for ir, r in enumerate([RADIUS, 2 * RADIUS]):
+        for it, th in enumerate(theta):
+            ref = _mie_scipy(k, RADIUS, r, th)
+            assert abs(got[ir, it] - ref) <= 1e-12 * max(1.0, abs(ref))
+
+
+def test_mie_reference_quirk_is_small():
+    """How far the reference's series is from the textbook one (only the n = 0 term differs)."""
+    for ka, bound in ((0.2, 2e-3), (1.0, 1.0), (3.0, 1.0)):     # ~1e-3 at ka=0.2, 0.84 at ka=1: the reference "analytical" series is off in a_0
+        k = ka / RADIUS
+        d = abs(_mie_scipy(k, RADIUS, RADIUS, 0.7) - _mie_scipy(k, RADIUS, RADIUS, 0.7, reference_quirk=False))
+        assert 0.0 < d < bound
+
+
+def test_textbook_series_has_zero_radial_velocity():
+    """Sanity of the scipy comparison series itself (rigid wall: dp/dr = 0 on the surface)."""
+    ka = 1.0; k = ka / RADIUS; h = 1e-6
+    for th in (0.3, 1.2, 2.5):
+        p1 = _mie_scipy(k, RADIUS, RADIUS * (1 + h), th, reference_quirk=False)
+        p0 = _mie_scipy(k, RADIUS, RADIUS, th, reference_quirk=False)
+        assert abs((p1 - p0) / (RADIUS * h)) < 1e-3 * k
+
+
+# ---------------------------------------------------------------- QA-suite acceptance (bin/qa_suite.rs:175-179, 199-326)
+@pytest.mark.parametrize("ka,sub,tol", [(0.2, 2, 0.05), (1.0, 3, 0.30), (3.0, 3, 0.30)])
+def test_qa_suite_scattering_thresholds(ka, sub, tol):
+    om = O.icosphere(RADIUS, sub)
+    k = k_from_ka(ka)
+    beta, _ = O.beta_adaptive(k, RADIUS)
+    A, rhs0 = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    rhs = rhs0 + O.compute_rhs_with_beta(om.center, om.normal, k, beta)
+    x, _, rc = O.zgesv(A, rhs, nthreads=8)
+    assert rc == 0
+    r = np.linalg.norm(om.center, axis=1); theta = np.arccos(om.center[:, 2] / r)
+    mie = np.array([O.sphere_scattering_3d(k, RADIUS, 50, [r[i]], [theta[i]])[0, 0] for i in range(om.n_elem)])
+    assert rel_l2(x, mie) < tol
+    assert np.all(np.abs(np.diag(A)) > 1e-15)           # tbem.rs:585-598
+
+
+def test_threaded_assembly_is_bitwise_sequential():
+    om = O.icosphere(RADIUS, 1)
+    k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+    A1, _ = O.build_tbem_system_with_beta(om, k, beta, nthreads=1)
+    A8, _ = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    assert np.array_equal(A1, A8)
+
+
+def test_golden_system_regression():
+    om = O.icosphere(RADIUS, 1)
+    assert np.array_equal(om.nodes, GOLD["ico1_nodes"]) and np.array_equal(om.conn, GOLD["ico1_conn"])
+    for tag in ("ka1", "ka02"):
+        k = float(GOLD["ico1_%s_k" % tag][0]); beta = complex(GOLD["ico1_%s_beta" % tag][0])
+        A, rhs0 = O.build_tbem_system_with_beta(om, k, beta)
+        rhs = rhs0 + O.compute_rhs_with_beta(om.center, om.normal, k, beta)
+        assert np.allclose(A, GOLD["ico1_%s_A" % tag], rtol=1e-13, atol=1e-15)
+        assert np.allclose(rhs, GOLD["ico1_%s_rhs" % tag], rtol=1e-13, atol=1e-15)
+        x, _, rc = O.zgesv(A, rhs)
+        assert rc == 0 and rel_l2(x, GOLD["ico1_%s_x" % tag]) < 1e-12
+
+
+def test_sign_switch_and_beta_tiers():                  # tbem.rs:108-123, types.rs:173-195
+    assert O.beta_adaptive(2.0, 0.1)[1] == 1.0 and O.beta_adaptive(10.0, 0.1)[1] == 4.0
+    assert O.beta_adaptive(15.0, 0.1)[1] == 8.0 and O.beta_adaptive(30.0, 0.1)[1] == 16.0
+    om = O.icosphere(RADIUS, 1)
+    i, j = 0, 40                                               # a far pair: coefficient = sign*K' + beta*E
+    r1 = O.regular_integration(om.center[i], om.normal[i], om.coords(j), om.area[j], 4.9)
+    r2 = O.regular_integration(om.center[i], om.normal[i], om.coords(j), om.area[j], 5.5)
+    lo, _ = O.build_tbem_system_with_beta(om, 4.9, 0.2j)      # k * mean|c| < 0.5 -> +K'
+    hi, _ = O.build_tbem_system_with_beta(om, 5.5, 0.2j)      # k * mean|c| = 0.518 >= 0.5 -> -K
+    assert abs(lo[i, j] - (r1[1] + 0.2j * r1[3])) < 1e-15 * abs(lo[i, j]) + 1e-18
+    assert abs(hi[i, j] - (-r2[1] + 0.2j * r2[3])) < 1e-15 * abs(hi[i, j]) + 1e-18
+
+
+# ---------------------------------------------------------------- dense solve (lu.rs:163-240)
+def test_lu_known_answers():
+    x, _, rc = O.zgesv(np.array([[4.0, 1.0], [1.0, 3.0]]), np.array([1.0, 2.0]))
+    assert rc == 0 and np.abs(np.array([[4.0, 1.0], [1.0, 3.0]]) @ x - [1.0, 2.0]).max() < 1e-10
+    Ac = np.array([[4 + 1j, 1], [1, 3 - 1j]]); bc = np.array([1 + 1j, 2 - 1j])
+    x, _, rc = O.zgesv(Ac, bc)
+    assert rc == 0 and np.abs(Ac @ x - bc).max() < 1e-10
+    x, _, rc = O.zgesv(np.eye(5), np.arange(1.0, 6.0))
+    assert rc == 0 and np.abs(x - np.arange(1.0, 6.0)).max() < 1e-10
+    _, _, rc = O.zgesv(np.array([[1.0, 2.0], [2.0, 4.0]]), np.array([1.0, 2.0]))
+    assert rc == 1                                       # singular -> LuError::SingularMatrix
+    A3 = np.array([[4.0, 1.0, 0.0], [1.0, 3.0, 1.0], [0.0, 1.0, 2.0]])
+    for b in ([1.0, 2.0, 3.0], [4.0, 5.0, 6.0]):
+        x, _, rc = O.zgesv(A3, np.array(b))
+        assert rc == 0 and np.abs(A3 @ x - b).max() < 1e-10
+        xf, rcf = O.lu_solve_fallback(A3, np.array(b, dtype=complex))
+        assert rcf == 0 and np.abs(A3 @ xf - b).max() < 1e-10
+
+
+def test_zgesv_is_lapack_on_the_transposed_view():
+    """lu_solve hands the C-order buffer to LAPACK as column-major (= A^T) and solves with trans='T'."""
+    rng = np.random.default_rng(3)
+    n = 60
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)); b = rng.standard_normal(n) + 0j
+    x, ipiv, rc = O.zgesv(A, b)
+    lu, piv = sl.lu_factor(A.T, check_finite=False)
+    assert rc == 0 and np.array_equal(ipiv[:n], piv)
+    xr = sl.lu_solve((lu, piv), b, trans=1, check_finite=False)
+    assert rel_l2(x, xr) < 1e-13 and rel_l2(x, np.linalg.solve(A, b)) < 1e-12
+
+
+# ---------------------------------------------------------------- CSR / smoothers / GMRES
+def _lap1d(n, shift=0.0):
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for j, v in ((i - 1, -1.0), (i, 2.0 + shift), (i + 1, -1.0)):
+            if 0 <= j < n:
+                rows.append(i); cols.append(j); vals.append(v)
+    import scipy.sparse as ss
+    M = ss.csr_matrix((np.array(vals, dtype=complex), (rows, cols)), shape=(n, n))
+    return M
+
+
+def test_csr_matvec_known_answers():                     # csr.rs tests :659-736
+    y = O.csr_matvec([0, 2, 4], [0, 1, 0, 1], [1, 2, 3, 4], [1, 2])
+    assert np.allclose(y, [5, 11])
+    y = O.csr_matvec([0, 2, 3, 5], [0, 2, 1, 0, 2], [1, 2, 3, 4, 5], [1, 1, 1])
+    assert np.allclose(y, [3, 3, 9])
+    M = _lap1d(300, 0.1 + 0.05j)
+    x = np.sin(0.1 * np.arange(300)) + 1j * np.cos(0.2 * np.arange(300))
+    assert np.allclose(O.csr_matvec(M.indptr, M.indices, M.data, x, nthreads=4), M @ x, rtol=1e-14)
+
+
+def test_helmholtz_values_k0_is_stiffness():             # math-fem helmholtz.rs:354-390
+    K = np.array([2.0, -1.0, 3.0]); Mv = np.array([0.5, 0.25, 1.0])
+    assert np.allclose(O.helmholtz_values(K, Mv, 0.0), K)
+    assert np.allclose(O.helmholtz_values(K, Mv, 2.0 + 0.1j), K - (2.0 + 0.1j) ** 2 * Mv)
+
+
+def test_smoothers_reduce_the_residual():                # smoother.rs:192-237, amg.rs tests
+    M = _lap1d(64, 0.05)
+    b = np.ones(64, dtype=complex); x0 = np.zeros(64, dtype=complex)
+    r0 = np.linalg.norm(b - M @ x0)
+    for x in (O.amg_jacobi(M.indptr, M.indices, M.data, x0, b, 2.0 / 3.0, 5),
+              O.amg_l1_jacobi(M.indptr, M.indices, M.data, x0, b, 5),
+              O.amg_sym_gauss_seidel(M.indptr, M.indices, M.data, x0, b, 3)):
+        assert np.linalg.norm(b - M @ x) < r0
+    coo = M.tocoo()
+    for kind in (0, 1, 2):
+        x = O.fem_smooth(64, coo.row, coo.col, coo.data, x0, b, kind=kind, iterations=4)
+        assert np.linalg.norm(O.fem_residual(64, coo.row, coo.col, coo.data, x, b)) < r0
+    # one Jacobi sweep is x + omega D^-1 (b - A x)
+    x1 = O.amg_jacobi(M.indptr, M.indices, M.data, x0 + 1.0, b, 0.8, 1)
+    assert np.allclose(x1, (x0 + 1.0) + 0.8 * (b - M @ (x0 + 1.0)) / M.diagonal(), rtol=1e-14)
+
+
+def test_gmres_solves_dense_and_csr():                   # gmres.rs:632-705
+    rng = np.random.default_rng(1)
+    n = 40
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) + 8 * np.eye(n)
+    b = rng.standard_normal(n) + 0j
+    x, info = O.gmres(b, dense=A, restart=30, max_iterations=50, tol=1e-10)
+    assert info.converged == 1 and np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-8
+    M = _lap1d(50, 0.5)
+    bb = np.ones(50, dtype=complex)
+    x, info = O.gmres(bb, csr=(M.indptr, M.indices, M.data), restart=50, max_iterations=10, tol=1e-10)
+    assert info.converged == 1 and np.linalg.norm(M @ x - bb) / np.linalg.norm(bb) < 1e-8
+    x, info = O.gmres(np.zeros(5, dtype=complex), dense=np.eye(5))
+    assert info.converged == 1 and info.iterations == 0
+
+
+def test_room_collocation_matrix_formula():              # room_acoustics/solver.rs:448-493
+    om = O.icosphere(1.0, 1)
+    k = 2.0
+    A = O.room_build_matrix(om.center, om.normal, om.area, k, nthreads=2)
+    i, j = 3, 40
+    d = om.center[i] - om.center[j]; r = np.linalg.norm(d)
+    ref = (1j * k * r - 1) * np.exp(1j * k * r) / (4 * np.pi * r * r) * (d @ om.normal[i]) / r * om.area[j]
+    assert abs(A[i, j] - ref) <= 1e-14 * abs(ref)
+    assert abs(A[5, 5] - (-1j * k / (2 * np.pi)) * om.area[5]) < 1e-16

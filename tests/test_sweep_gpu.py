@@ -1,0 +1,149 @@
+"""GPU tests of the device-resident path (plan -> assemble -> incident RHS -> LU) at the reference's
+QA configurations, against the committed golden vectors, and at BASELINE.json's full size (10 000
+panels) through size-independent properties."""
+import os
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from math_audio_amd import mesh as mm
+from helpers import to_ma_mesh, k_from_ka, RADIUS, rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "bem_golden.npz"))
+
+
+def _device_solve(mesh, k, beta):
+    import torch
+    n = mesh.n_elem
+    dev = torch.device("cuda", 0)
+    plan = ma.BemPlan(mesh); lu = ma.LuPlan(n)
+    A = torch.empty(n * n, dtype=torch.complex128, device=dev); x = torch.empty(n, dtype=torch.complex128, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.assemble_dev(k, beta, A.data_ptr(), x.data_ptr(), stream=st)
+    plan.incident_rhs_dev(k, beta, x.data_ptr(), accumulate=True, stream=st)
+    Acopy = A.clone(); b = x.clone()
+    lu.factor_solve_dev(A.data_ptr(), x.data_ptr(), 1, stream=st)
+    assert lu.status(st) == ma.MA_OK
+    plan.close(); lu.close()
+    return Acopy.view(n, n), b, x
+
+
+@pytest.mark.parametrize("ka,sub,tol", [(0.2, 2, 0.05), (1.0, 3, 0.30), (3.0, 3, 0.30)])
+def test_qa_suite_on_device(gpu, ka, sub, tol):
+    """bin/qa_suite.rs:199-326 end to end on the GPU: L2 vs the reference's Mie series below its threshold,
+    and the solution within 1e-8 of the CPU restatement's (config #2)."""
+    om = O.icosphere(RADIUS, sub)
+    k = k_from_ka(ka)
+    beta, _ = O.beta_adaptive(k, RADIUS)
+    A, b, x = _device_solve(to_ma_mesh(om), k, beta)
+    x = x.cpu().numpy()
+    A_ref, r0 = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    rhs_ref = r0 + O.compute_rhs_with_beta(om.center, om.normal, k, beta)
+    x_ref, _, rc = O.zgesv(A_ref, rhs_ref, nthreads=8)
+    assert rc == 0
+    assert rel_l2(x, x_ref) <= 1e-8
+    r = np.linalg.norm(om.center, axis=1); theta = np.arccos(om.center[:, 2] / r)
+    mie = np.array([O.sphere_scattering_3d(k, RADIUS, 50, [r[i]], [theta[i]])[0, 0] for i in range(om.n_elem)])
+    assert rel_l2(x, mie) < tol
+
+
+def test_golden_vectors_on_device(gpu):
+    om = O.Mesh(GOLD["ico1_nodes"], GOLD["ico1_conn"])
+    for tag in ("ka1", "ka02"):
+        k = float(GOLD["ico1_%s_k" % tag][0]); beta = complex(GOLD["ico1_%s_beta" % tag][0])
+        A, rhs0 = ma.assemble_tbem(to_ma_mesh(om), k, beta)
+        Ag = GOLD["ico1_%s_A" % tag]
+        assert (np.abs(A - Ag) / np.abs(Ag).max(axis=1, keepdims=True)).max() <= 1e-9
+        rhs = rhs0 + ma.incident_rhs(om.center, om.normal, k, beta)
+        assert np.abs(rhs - GOLD["ico1_%s_rhs" % tag]).max() <= 1e-13 * np.abs(rhs).max()
+        x = ma.zgesv(A, rhs)
+        assert rel_l2(x, GOLD["ico1_%s_x" % tag]) <= 1e-9
+    om2 = O.icosphere(RADIUS, 2)
+    plan = ma.BemPlan(to_ma_mesh(om2))
+    pairs = GOLD["ico2_pairs"]
+    off = pairs[pairs[:, 0] != pairs[:, 1]]
+    for tag in ("ka1", "ka3"):
+        k = float(GOLD["ico2_%s_k" % tag][0])
+        got = plan.probe_pairs(k, off)
+        selfs = plan.probe_self(k)
+        qo = 0
+        for q, (i, j) in enumerate(pairs):
+            ref = GOLD["ico2_%s_integrals" % tag][q][:4]
+            if i == j:
+                g = selfs[i, 1:5]
+            else:
+                g = got[qo, 1:5]
+                assert int(round(got[qo, 0].real)) == int(GOLD["ico2_%s_nsub" % tag][q]); qo += 1
+            assert np.all(np.abs(g - ref) <= 1e-10 * np.abs(ref).max()), (tag, i, j)
+    plan.close()
+
+
+def test_level_overflow_quirk_on_device(gpu):
+    """Two parallel unit triangles 0.05 apart: the collocation point of one sits so close to the other that
+    a subdivision level wants more than 15 splits; the reference abandons the rest of that level
+    (singular.rs:556-562) and the device kernel must integrate exactly the same 109 leaves."""
+    nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0.05], [1, 0, 0.05], [0, 1, 0.05],
+                      [0.02, 0.01, 0.8], [1.02, 0.01, 0.8], [0.02, 1.01, 0.8]], dtype=float)
+    conn = np.array([[0, 1, 2, -1], [3, 4, 5, -1], [6, 7, 8, -1]], dtype=np.int32)
+    om = O.Mesh(nodes, conn)
+    # collocation points are the stored centres; override them so that panel 1 sees panel 0 from (0.3, 0.3, 0.05)
+    om.center[1] = [0.3, 0.3, 0.05]
+    plan = ma.BemPlan(to_ma_mesh(om))
+    k = 5.0
+    got = plan.probe_pairs(k, np.array([[1, 0], [2, 0], [0, 2]], dtype=np.int32))
+    for q, (i, j) in enumerate([(1, 0), (2, 0), (0, 2)]):
+        ref = O.regular_integration(om.center[i], om.normal[i], om.coords(j), om.area[j], k)[:4]
+        nsub = len(O.generate_subelements(om.center[i], om.coords(j), om.area[j]))
+        assert int(round(got[q, 0].real)) == nsub
+        assert np.all(np.abs(got[q, 1:5] - ref) <= 1e-10 * np.abs(ref).max())
+    assert int(round(got[0, 0].real)) == 109          # the truncated level
+    assert int(round(got[1, 0].real)) == 16           # two complete levels
+    plan.close()
+
+
+def test_full_size_sphere_properties(gpu):
+    """S10 (10 000 panels, BASELINE.json configs[2]) at 926 Hz: sampled rows against the CPU restatement,
+    residual and linearity of the device solve."""
+    import torch
+    mesh = mm.generate_sphere_mesh(RADIUS, 51, 100)
+    n = mesh.n_elem
+    f = mm.log_space(100.0, 8000.0, 64)[32]
+    k = mm.wave_number(f); beta = mm.burton_miller_beta_scaled(k, 4.0)
+    A, b, x = _device_solve(mesh, k, beta)
+    # (1) sampled rows vs the oracle (first, last, and three interior rows incl. polar caps)
+    om = O.uv_sphere(RADIUS, 51, 100)
+    assert np.abs(om.nodes - mesh.nodes).max() <= 2e-17
+    om.nodes[:] = mesh.nodes; om.center[:] = mesh.center; om.normal[:] = mesh.normal; om.area[:] = mesh.area
+    Aref = np.zeros((n, n), dtype=np.complex128); rref = np.zeros(n, dtype=np.complex128)
+    for r0 in (0, 137, 5000, 9999):
+        O.build_tbem_system_with_beta(om, k, beta, nthreads=8, rows=(r0, r0 + 1), A=Aref, rhs=rref)
+        row = A[r0].cpu().numpy()
+        assert np.abs(row - Aref[r0]).max() <= 1e-9 * np.abs(Aref[r0]).max()
+    # (2) residual of the solve, computed on the device with the saved copy of A
+    res = torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)
+    assert float(res) <= 1e-10
+    # (3) linearity: solving for 2b - i b gives (2 - i) x
+    lu = ma.LuPlan(n)
+    A2 = A.clone().reshape(-1); b2 = ((2 - 1j) * b).clone()
+    st = torch.cuda.current_stream().cuda_stream
+    lu.factor_solve_dev(A2.data_ptr(), b2.data_ptr(), 1, stream=st)
+    assert lu.status(st) == ma.MA_OK
+    assert float(torch.linalg.norm(b2 - (2 - 1j) * x) / torch.linalg.norm(x)) <= 1e-10
+    lu.close()
+
+
+def test_lookahead_and_plain_schedules_agree(gpu):
+    """The look-ahead schedule only reorders independent kernels: same pivots, same factors."""
+    import subprocess, sys, json
+    code = ("import sys,numpy as np;sys.path.insert(0,'.');import math_audio_amd as ma;"
+            "rng=np.random.default_rng(0);n=700;A=rng.standard_normal((n,n))+1j*rng.standard_normal((n,n));b=rng.standard_normal(n)+0j;"
+            "x=ma.zgesv(A,b);print(repr(float(np.abs(x).sum())),repr(float(np.abs(A@x-b).max())))")
+    outs = []
+    for la in ("0", "1"):
+        env = dict(os.environ, MA_LU_LOOKAHEAD=la)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip().split())
+    assert outs[0][0] == outs[1][0]                       # bitwise-identical solution checksum
+    assert float(outs[0][1]) < 1e-10
