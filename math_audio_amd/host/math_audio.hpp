@@ -1,0 +1,245 @@
+// math_audio.hpp — C++ host mirror of the reference's Rust API for the hot path, on top of the C-ABI.
+//
+// The reference is compiled code (Rust); this image has no Rust toolchain, so the host side above
+// include/mathaudio_hip.h is C++ with the reference's names, argument meaning and error behaviour:
+//   math_bem::PhysicsParams / Element / Mesh / generate_icosphere_mesh / build_tbem_system_with_beta /
+//            IncidentField::compute_rhs_with_beta        (math-bem/src/core/{types,mesh/generators,assembly/tbem,incident}.rs)
+//   math_solvers::lu_solve -> Result (LuError)            (math-solvers/src/direct/lu.rs)
+// Header-only; links against libmathaudio_hip.so. No CPU fallback: errors come back as exceptions or
+// Result values carrying the C status code.
+#pragma once
+#include <array>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/mathaudio_hip.h"
+
+namespace math_bem {
+
+using Complex64 = std::complex<double>;
+static_assert(sizeof(Complex64) == sizeof(ma_c64), "Complex64 layout");
+
+struct BemError : std::runtime_error {
+  int status;
+  BemError(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+// types.rs:16-219
+struct PhysicsParams {
+  double speed_of_sound, density, frequency, wave_number, omega, wave_length, harmonic_factor, pressure_factor, tau;
+  PhysicsParams(double f, double c, double rho, bool is_internal) {
+    const double PI = 3.14159265358979323846;
+    omega = 2.0 * PI * f; wave_number = omega / c; wave_length = c / f; harmonic_factor = 1.0;
+    tau = is_internal ? -1.0 : 1.0; speed_of_sound = c; density = rho; frequency = f; pressure_factor = rho * omega * harmonic_factor;
+  }
+  double gamma() const { return 1.0; }
+  Complex64 burton_miller_beta() const { return tau > 0.0 ? Complex64(0.0, harmonic_factor / wave_number) : Complex64(0.0, 0.0); }
+  Complex64 burton_miller_beta_scaled(double s) const { return tau > 0.0 ? Complex64(0.0, harmonic_factor * s / wave_number) : Complex64(0.0, 0.0); }
+  std::pair<Complex64, double> burton_miller_beta_adaptive(double radius) const {
+    if (tau <= 0.0) return {Complex64(0.0, 0.0), 1.0};
+    const double ka = wave_number * radius;
+    const double scale = ka < 0.5 ? 1.0 : (ka < 1.2 ? 4.0 : (ka < 1.8 ? 8.0 : 16.0));
+    return {Complex64(0.0, harmonic_factor * scale / wave_number), scale};
+  }
+};
+
+enum class ElementType { Tri3, Quad4 };
+enum class ElementProperty { Surface = 0, MidFace = 1, Evaluation = 2 };
+struct BoundaryCondition {
+  enum Kind { Velocity, Pressure, Other } kind = Velocity;
+  std::vector<Complex64> values{Complex64(0.0, 0.0)};
+};
+
+// types.rs:330-351
+struct Element {
+  std::vector<size_t> connectivity;
+  ElementType element_type = ElementType::Tri3;
+  ElementProperty property = ElementProperty::Surface;
+  double normal[3] = {0, 0, 0};
+  double center[3] = {0, 0, 0};
+  double area = 0.0;
+  BoundaryCondition boundary_condition;
+  std::vector<size_t> dof_addresses;
+};
+
+struct Mesh {
+  std::vector<double> nodes;          // n_nodes x 3 row-major (Array2<f64>)
+  std::vector<Element> elements;
+  size_t num_nodes() const { return nodes.size() / 3; }
+};
+
+// generators.rs:513-602
+inline void compute_element_geometry(Element& e, const std::vector<double>& nodes) {
+  const size_t n = e.connectivity.size();
+  double c[3] = {0, 0, 0};
+  for (size_t a = 0; a < n; ++a) for (int d = 0; d < 3; ++d) c[d] += nodes[3 * e.connectivity[a] + d];
+  for (int d = 0; d < 3; ++d) c[d] /= (double)n;
+  double v1[3], v2[3];
+  if (n == 3) { for (int d = 0; d < 3; ++d) { v1[d] = nodes[3 * e.connectivity[1] + d] - nodes[3 * e.connectivity[0] + d]; v2[d] = nodes[3 * e.connectivity[2] + d] - nodes[3 * e.connectivity[0] + d]; } }
+  else { for (int d = 0; d < 3; ++d) { v1[d] = nodes[3 * e.connectivity[2] + d] - nodes[3 * e.connectivity[0] + d]; v2[d] = nodes[3 * e.connectivity[3] + d] - nodes[3 * e.connectivity[1] + d]; } }
+  const double cr[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+  const double len = std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+  e.area = len / 2.0;
+  if (len > 1e-15) for (int d = 0; d < 3; ++d) e.normal[d] = cr[d] / len;
+  if (e.normal[0] * c[0] + e.normal[1] * c[1] + e.normal[2] * c[2] < 0.0) for (int d = 0; d < 3; ++d) e.normal[d] = -e.normal[d];
+  for (int d = 0; d < 3; ++d) e.center[d] = c[d];
+}
+
+// generators.rs:110-228
+inline Mesh generate_icosphere_mesh(double radius, size_t subdivisions) {
+  const double phi = (1.0 + std::sqrt(5.0)) / 2.0;
+  std::vector<std::array<double, 3>> v = {{-1, phi, 0}, {1, phi, 0}, {-1, -phi, 0}, {1, -phi, 0}, {0, -1, phi}, {0, 1, phi},
+                                          {0, -1, -phi}, {0, 1, -phi}, {phi, 0, -1}, {phi, 0, 1}, {-phi, 0, -1}, {-phi, 0, 1}};
+  for (auto& p : v) { const double l = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); p[0] /= l; p[1] /= l; p[2] /= l; }
+  std::vector<std::array<size_t, 3>> f = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4}, {11, 10, 2}, {10, 7, 6}, {7, 1, 8},
+                                          {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8}, {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1}};
+  for (size_t s = 0; s < subdivisions; ++s) {
+    std::map<std::pair<size_t, size_t>, size_t> cache;
+    auto mid = [&](size_t a, size_t b) {
+      auto key = a < b ? std::make_pair(a, b) : std::make_pair(b, a);
+      auto it = cache.find(key);
+      if (it != cache.end()) return it->second;
+      std::array<double, 3> m = {(v[a][0] + v[b][0]) / 2.0, (v[a][1] + v[b][1]) / 2.0, (v[a][2] + v[b][2]) / 2.0};
+      const double l = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+      v.push_back({m[0] / l, m[1] / l, m[2] / l});
+      return cache[key] = v.size() - 1;
+    };
+    std::vector<std::array<size_t, 3>> nf;
+    for (auto& t : f) {
+      const size_t m01 = mid(t[0], t[1]), m12 = mid(t[1], t[2]), m20 = mid(t[2], t[0]);
+      nf.push_back({t[0], m01, m20}); nf.push_back({t[1], m12, m01}); nf.push_back({t[2], m20, m12}); nf.push_back({m01, m12, m20});
+    }
+    f.swap(nf);
+  }
+  Mesh m;
+  for (auto& p : v) { m.nodes.push_back(p[0] * radius); m.nodes.push_back(p[1] * radius); m.nodes.push_back(p[2] * radius); }
+  for (size_t i = 0; i < f.size(); ++i) {
+    Element e; e.connectivity = {f[i][0], f[i][1], f[i][2]}; e.dof_addresses = {i};
+    compute_element_geometry(e, m.nodes);
+    m.elements.push_back(e);
+  }
+  return m;
+}
+
+// tbem.rs:13-20
+struct TbemSystem {
+  std::vector<Complex64> matrix;      // num_dofs x num_dofs row-major
+  std::vector<Complex64> rhs;
+  size_t num_dofs = 0;
+  Complex64& at(size_t i, size_t j) { return matrix[i * num_dofs + j]; }
+};
+
+namespace detail {
+struct Flat {
+  std::vector<int32_t> conn, dof, bclen;
+  std::vector<double> center, normal, area;
+  std::vector<uint8_t> bct, eval;
+  std::vector<Complex64> bcv;
+  ma_mesh_t c{};
+};
+inline void flatten(const std::vector<Element>& el, const std::vector<double>& nodes, Flat& F) {
+  const size_t n = el.size();
+  F.conn.assign(4 * n, -1); F.dof.resize(n); F.bclen.assign(n, 1); F.center.resize(3 * n); F.normal.resize(3 * n); F.area.resize(n);
+  F.bct.assign(n, 0); F.eval.assign(n, 0); F.bcv.assign(4 * n, Complex64(0.0, 0.0));
+  for (size_t e = 0; e < n; ++e) {
+    for (size_t a = 0; a < el[e].connectivity.size() && a < 4; ++a) F.conn[4 * e + a] = (int32_t)el[e].connectivity[a];
+    for (int d = 0; d < 3; ++d) { F.center[3 * e + d] = el[e].center[d]; F.normal[3 * e + d] = el[e].normal[d]; }
+    F.area[e] = el[e].area; F.dof[e] = (int32_t)el[e].dof_addresses.at(0);
+    F.eval[e] = el[e].property == ElementProperty::Evaluation;
+    const auto& bc = el[e].boundary_condition;
+    F.bct[e] = bc.kind == BoundaryCondition::Velocity ? 0 : (bc.kind == BoundaryCondition::Pressure ? 1 : 2);
+    F.bclen[e] = (int32_t)(bc.values.empty() ? 1 : bc.values.size());
+    for (size_t a = 0; a < bc.values.size() && a < 4; ++a) F.bcv[4 * e + a] = bc.values[a];
+  }
+  F.c.n_nodes = (int32_t)(nodes.size() / 3); F.c.nodes = nodes.data(); F.c.n_elem = (int32_t)n; F.c.conn = F.conn.data();
+  F.c.center = F.center.data(); F.c.normal = F.normal.data(); F.c.area = F.area.data(); F.c.dof = F.dof.data();
+  F.c.bc_type = F.bct.data(); F.c.bc_values = reinterpret_cast<const ma_c64*>(F.bcv.data()); F.c.bc_len = F.bclen.data(); F.c.is_eval = F.eval.data();
+}
+inline ma_physics_t phys(const PhysicsParams& p) { return ma_physics_t{p.wave_number, p.harmonic_factor, p.tau, p.gamma()}; }
+}  // namespace detail
+
+// tbem.rs:96-101 — same arguments, same result; throws BemError with the C status on failure
+inline TbemSystem build_tbem_system_with_beta(const std::vector<Element>& elements, const std::vector<double>& nodes,
+                                              const PhysicsParams& physics, Complex64 beta) {
+  detail::Flat F; detail::flatten(elements, nodes, F);
+  size_t nd = 0; for (auto& e : elements) nd += e.property != ElementProperty::Evaluation;
+  TbemSystem s; s.num_dofs = nd; s.matrix.assign(nd * nd, Complex64(0.0, 0.0)); s.rhs.assign(nd, Complex64(0.0, 0.0));
+  const ma_physics_t ph = detail::phys(physics);
+  const int rc = ma_bem_assemble_tbem(&F.c, &ph, beta.real(), beta.imag(), reinterpret_cast<ma_c64*>(s.matrix.data()), reinterpret_cast<ma_c64*>(s.rhs.data()));
+  if (rc != MA_OK) throw BemError(rc, ma_last_error_string());
+  return s;
+}
+inline TbemSystem build_tbem_system(const std::vector<Element>& el, const std::vector<double>& nodes, const PhysicsParams& p) {
+  return build_tbem_system_with_beta(el, nodes, p, p.burton_miller_beta());                    // tbem.rs:45-51
+}
+inline TbemSystem build_tbem_system_scaled(const std::vector<Element>& el, const std::vector<double>& nodes, const PhysicsParams& p, double scale) {
+  return build_tbem_system_with_beta(el, nodes, p, p.burton_miller_beta_scaled(scale));        // tbem.rs:85-93
+}
+
+// incident.rs:17-39, 317-342
+struct IncidentField {
+  int kind = 0; double v[3] = {0, 0, 1}; Complex64 amp{1.0, 0.0};
+  static IncidentField plane_wave_z() { return IncidentField{}; }
+  static IncidentField plane_wave(const double d[3], double a) {
+    IncidentField f; const double l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (l > 1e-10) { f.v[0] = d[0] / l; f.v[1] = d[1] / l; f.v[2] = d[2] / l; } else { f.v[0] = 0; f.v[1] = 0; f.v[2] = -1; }
+    f.amp = Complex64(a, 0.0); return f;
+  }
+  static IncidentField point_source(const double p[3], double s) { IncidentField f; f.kind = 1; f.v[0] = p[0]; f.v[1] = p[1]; f.v[2] = p[2]; f.amp = Complex64(s, 0.0); return f; }
+  std::vector<Complex64> compute_rhs_with_beta(const std::vector<double>& centers, const std::vector<double>& normals,
+                                               const PhysicsParams& physics, Complex64 beta) const {
+    const int n = (int)(centers.size() / 3);
+    std::vector<Complex64> rhs(n);
+    const ma_physics_t ph = detail::phys(physics);
+    const int rc = ma_bem_incident_rhs(n, centers.data(), normals.data(), &ph, beta.real(), beta.imag(), kind, v, amp.real(), amp.imag(),
+                                       reinterpret_cast<ma_c64*>(rhs.data()));
+    if (rc != MA_OK) throw BemError(rc, ma_last_error_string());
+    return rhs;
+  }
+};
+
+}  // namespace math_bem
+
+namespace math_solvers {
+
+using Complex64 = std::complex<double>;
+
+// lu.rs:16-21
+struct LuError {
+  enum Kind { SingularMatrix, DimensionMismatch, Backend } kind;
+  size_t expected = 0, got = 0;
+  std::string text;
+};
+
+template <class T>
+struct Result {
+  bool ok; T value; LuError err;
+  bool is_ok() const { return ok; }
+  bool is_err() const { return !ok; }
+  const T& expect(const char* msg) const { if (!ok) throw std::runtime_error(std::string(msg) + ": " + err.text); return value; }
+};
+
+// lu.rs:142-153: a is n x n row-major (ndarray C order), b has n entries
+inline Result<std::vector<Complex64>> lu_solve(const std::vector<Complex64>& a, size_t nrows, size_t ncols, const std::vector<Complex64>& b) {
+  Result<std::vector<Complex64>> r{false, {}, {}};
+  if (nrows != ncols || a.size() != nrows * ncols) { r.err = {LuError::DimensionMismatch, nrows, ncols, "Matrix dimensions mismatch"}; return r; }
+  if (b.size() != nrows) { r.err = {LuError::DimensionMismatch, nrows, b.size(), "Matrix dimensions mismatch"}; return r; }
+  std::vector<Complex64> lu(a), x(b);
+  const int rc = ma_zgesv((int32_t)nrows, reinterpret_cast<ma_c64*>(lu.data()), reinterpret_cast<ma_c64*>(x.data()), nullptr);
+  if (rc == MA_OK) { r.ok = true; r.value.swap(x); return r; }
+  if (rc == MA_ERR_SINGULAR) r.err = {LuError::SingularMatrix, 0, 0, "Matrix is singular or nearly singular"};
+  else if (rc == MA_ERR_DIM) r.err = {LuError::DimensionMismatch, nrows, b.size(), ma_last_error_string()};
+  else r.err = {LuError::Backend, 0, 0, ma_last_error_string()};
+  return r;
+}
+inline Result<std::vector<Complex64>> lu_solve(const std::vector<double>& a, size_t n, size_t m, const std::vector<double>& b) {
+  std::vector<Complex64> ac(a.begin(), a.end()), bc(b.begin(), b.end());
+  return lu_solve(ac, n, m, bc);
+}
+
+}  // namespace math_solvers

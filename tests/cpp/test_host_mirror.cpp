@@ -1,0 +1,77 @@
+// test_host_mirror.cpp — the reference's own unit tests for the seam functions, restated against
+// the C++ host mirror (math-solvers/src/direct/lu.rs:163-240; math-bem/src/core/assembly/tbem.rs:545-598;
+// math-bem/bin/qa_suite.rs:199-326 at ka = 0.2). Exit code 0 = all passed. Needs an MI355X.
+#include <array>
+#include <cstdio>
+#include "../../math_audio_amd/host/math_audio.hpp"
+
+using math_solvers::Complex64;
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+static void test_lu_solve_real() {                      // lu.rs:163-175
+  std::vector<double> a = {4.0, 1.0, 1.0, 3.0}, b = {1.0, 2.0};
+  auto x = math_solvers::lu_solve(a, 2, 2, b).expect("LU solve should succeed");
+  for (int i = 0; i < 2; ++i) { Complex64 ax = a[2 * i] * x[0] + a[2 * i + 1] * x[1]; CHECK(std::abs(ax - b[i]) < 1e-10); }
+}
+static void test_lu_solve_complex() {                   // lu.rs:177-193
+  std::vector<Complex64> a = {{4, 1}, {1, 0}, {1, 0}, {3, -1}}, b = {{1, 1}, {2, -1}};
+  auto x = math_solvers::lu_solve(a, 2, 2, b).expect("LU solve should succeed");
+  for (int i = 0; i < 2; ++i) CHECK(std::abs(a[2 * i] * x[0] + a[2 * i + 1] * x[1] - b[i]) < 1e-10);
+}
+static void test_lu_identity() {                        // lu.rs:195-206
+  const int n = 5; std::vector<double> a(n * n, 0.0), b(n);
+  for (int i = 0; i < n; ++i) { a[i * n + i] = 1.0; b[i] = i + 1.0; }
+  auto x = math_solvers::lu_solve(a, n, n, b).expect("LU solve should succeed");
+  for (int i = 0; i < n; ++i) CHECK(std::abs(x[i] - b[i]) < 1e-10);
+}
+static void test_lu_singular() {                        // lu.rs:208-216
+  std::vector<double> a = {1.0, 2.0, 2.0, 4.0}, b = {1.0, 2.0};
+  auto r = math_solvers::lu_solve(a, 2, 2, b);
+  CHECK(r.is_err()); CHECK(r.err.kind == math_solvers::LuError::SingularMatrix);
+}
+static void test_lu_dimension_mismatch() {
+  std::vector<double> a = {1.0, 0.0, 0.0, 1.0}, b = {1.0, 2.0, 3.0};
+  auto r = math_solvers::lu_solve(a, 2, 2, b);
+  CHECK(r.is_err()); CHECK(r.err.kind == math_solvers::LuError::DimensionMismatch);
+}
+static void test_tbem_diagonal_nonzero_and_qa() {       // tbem.rs:585-598 + qa_suite.rs:199-326 (Rayleigh, ka = 0.2)
+  using namespace math_bem;
+  const double radius = 0.1, c = 343.0, rho = 1.21, ka = 0.2;
+  const double k = ka / radius, freq = k * c / (2.0 * 3.14159265358979323846);
+  PhysicsParams physics(freq, c, rho, false);
+  Mesh mesh = generate_icosphere_mesh(radius, 2);
+  CHECK(mesh.elements.size() == 320); CHECK(mesh.num_nodes() == 162);
+  auto beta = physics.burton_miller_beta_adaptive(radius).first;
+  TbemSystem sys = build_tbem_system_with_beta(mesh.elements, mesh.nodes, physics, beta);
+  CHECK(sys.num_dofs == 320);
+  for (size_t i = 0; i < sys.num_dofs; ++i) CHECK(std::abs(sys.at(i, i)) > 1e-15);
+  std::vector<double> centers, normals;
+  for (auto& e : mesh.elements) for (int d = 0; d < 3; ++d) { centers.push_back(e.center[d]); normals.push_back(e.normal[d]); }
+  auto rhs = IncidentField::plane_wave_z().compute_rhs_with_beta(centers, normals, physics, beta);
+  for (size_t i = 0; i < rhs.size(); ++i) rhs[i] += sys.rhs[i];
+  auto p = math_solvers::lu_solve(sys.matrix, sys.num_dofs, sys.num_dofs, rhs).expect("LU solve should succeed");
+  // Rayleigh regime: the total surface pressure of a small rigid sphere is close to the incident plane wave
+  // (first-order: p = p_inc (1 + 1.5 i k a cos(theta)) ), well inside the QA suite's 5 % L2 threshold.
+  double num = 0.0, den = 0.0;
+  for (size_t i = 0; i < p.size(); ++i) {
+    const double z = mesh.elements[i].center[2], r = std::sqrt(centers[3 * i] * centers[3 * i] + centers[3 * i + 1] * centers[3 * i + 1] + z * z);
+    const Complex64 approx = Complex64(1.0, 1.5 * physics.wave_number * r * (z / r));
+    num += std::norm(p[i] - approx); den += std::norm(approx);
+  }
+  CHECK(std::sqrt(num / den) < 0.05);
+  // error behaviour: a Quad4 element is refused loudly, never silently computed on the CPU
+  Mesh bad = mesh; bad.elements[0].connectivity.push_back(3);
+  bool threw = false;
+  try { build_tbem_system_with_beta(bad.elements, bad.nodes, physics, beta); } catch (const BemError& e) { threw = e.status == MA_ERR_UNSUPPORTED; }
+  CHECK(threw);
+}
+
+int main() {
+  int n = 0;
+  if (ma_device_count(&n) != MA_OK || n <= 0) { std::printf("no HIP device: the host mirror has no CPU fallback\n"); return 77; }
+  test_lu_solve_real(); test_lu_solve_complex(); test_lu_identity(); test_lu_singular(); test_lu_dimension_mismatch();
+  test_tbem_diagonal_nonzero_and_qa();
+  std::printf(failures ? "%d check(s) failed\n" : "host mirror: all checks passed\n", failures);
+  return failures ? 1 : 0;
+}
