@@ -131,6 +131,37 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sparse FEM side: complex CSR operator, SpMV, residual, Jacobi-type smoother sweeps.
+ * Replaces: CsrMatrix<Complex64>{num_rows, values, col_indices: Vec<usize>, row_ptrs: Vec<usize>} and
+ *           CsrMatrix::matvec(&x) -> y                 math-solvers/src/sparse/csr.rs:21-33, 240-292
+ *           HelmholtzAssembler::assemble(k, ..)        math-fem/src/assembly/assembler.rs:216-257
+ *             (ma_csr_create_helmholtz keeps the real K and M values of the shared pattern resident and
+ *              forms a_ij = K_ij - k^2 M_ij inside the kernels; ma_csr_set_wavenumber replaces the
+ *              per-frequency value rewrite)
+ *           AmgPreconditioner::smooth_jacobi / smooth_l1_jacobi / compute_diag_inv
+ *                                                     math-solvers/src/preconditioners/amg.rs:855-929, 400-413
+ *           the residual r = b - A x of the V-cycle    amg.rs:1028
+ * Indices are the Rust side's usize widened to int64 (they are range-checked and narrowed to 32 bits
+ * on the device). Column indices of a row must be unique (CSR from from_triplets / the assembler).
+ * The *_dev forms take device pointers to n complex128 values each and a hipStream_t.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ma_csr ma_csr_t;
+int ma_csr_create(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr_t** out);
+int ma_csr_create_helmholtz(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const double* K, const double* M,
+                            int device, ma_csr_t** out);
+int ma_csr_destroy(ma_csr_t* h);
+int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz);
+int ma_csr_set_wavenumber(ma_csr_t* h, double k_re, double k_im);
+int ma_csr_spmv(ma_csr_t* h, const ma_c64* x, ma_c64* y);
+int ma_csr_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r);
+int ma_csr_jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, double omega, int sweeps);
+int ma_csr_l1jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps);
+int ma_csr_spmv_dev(ma_csr_t* h, const void* d_x, void* d_y, void* stream);
+int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r, void* stream);
+int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
+int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Parity-test hooks (no counterpart in the reference API): raw panel integrals computed by the
  * device kernels, comparable to IntegrationResult of regular_integration / singular_integration
  * (math-bem/src/core/integration/regular.rs:33, singular.rs:123; types.rs:722-734).

@@ -79,6 +79,19 @@ def lib():
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],
+            "ma_csr_create": [i64, vp, vp, vp, C.c_int, P(vp)],
+            "ma_csr_create_helmholtz": [i64, vp, vp, vp, vp, C.c_int, P(vp)],
+            "ma_csr_destroy": [vp],
+            "ma_csr_num_rows": [vp, P(i64), P(i64)],
+            "ma_csr_set_wavenumber": [vp, dbl, dbl],
+            "ma_csr_spmv": [vp, vp, vp],
+            "ma_csr_residual": [vp, vp, vp, vp],
+            "ma_csr_jacobi": [vp, vp, vp, dbl, C.c_int],
+            "ma_csr_l1jacobi": [vp, vp, vp, C.c_int],
+            "ma_csr_spmv_dev": [vp, vp, vp, vp],
+            "ma_csr_residual_dev": [vp, vp, vp, vp, vp],
+            "ma_csr_jacobi_dev": [vp, vp, vp, dbl, C.c_int, vp, vp],
+            "ma_csr_l1jacobi_dev": [vp, vp, vp, C.c_int, vp, vp],
             "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
             "ma_probe_mfma_f64": [C.c_int, P(dbl)],
         }
@@ -274,3 +287,67 @@ def probe_mfma_f64(device=0):
     t = C.c_double(0)
     check(lib().ma_probe_mfma_f64(device, C.byref(t)))
     return t.value
+
+
+class CsrOperator:
+    """ma_csr_t: CsrMatrix<Complex64> (values=...) or the Helmholtz K/M pair of one pattern (K=..., M=...)."""
+
+    def __init__(self, row_ptrs, col_indices, values=None, K=None, M=None, device=0):
+        self.rp = np.ascontiguousarray(row_ptrs, dtype=np.int64)
+        self.ci = np.ascontiguousarray(col_indices, dtype=np.int64)
+        self.n = len(self.rp) - 1
+        self.h = C.c_void_p()
+        if values is not None:
+            v = np.ascontiguousarray(values, dtype=np.complex128)
+            check(lib().ma_csr_create(self.n, _vp(self.rp), _vp(self.ci), _vp(v), device, C.byref(self.h)))
+        else:
+            k = np.ascontiguousarray(K, dtype=np.float64); m = np.ascontiguousarray(M, dtype=np.float64)
+            check(lib().ma_csr_create_helmholtz(self.n, _vp(self.rp), _vp(self.ci), _vp(k), _vp(m), device, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ma_csr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_wavenumber(self, k):
+        k = complex(k)
+        check(lib().ma_csr_set_wavenumber(self.h, k.real, k.imag))
+
+    def matvec(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128); y = np.empty(self.n, dtype=np.complex128)
+        check(lib().ma_csr_spmv(self.h, _vp(x), _vp(y)))
+        return y
+
+    def residual(self, x, b):
+        x = np.ascontiguousarray(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+        r = np.empty(self.n, dtype=np.complex128)
+        check(lib().ma_csr_residual(self.h, _vp(x), _vp(b), _vp(r)))
+        return r
+
+    def jacobi(self, x, b, omega, sweeps):
+        x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+        check(lib().ma_csr_jacobi(self.h, _vp(x), _vp(b), float(omega), int(sweeps)))
+        return x
+
+    def l1_jacobi(self, x, b, sweeps):
+        x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+        check(lib().ma_csr_l1jacobi(self.h, _vp(x), _vp(b), int(sweeps)))
+        return x
+
+    def spmv_dev(self, d_x, d_y, stream=0):
+        check(lib().ma_csr_spmv_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream)))
+
+    def residual_dev(self, d_x, d_b, d_r, stream=0):
+        check(lib().ma_csr_residual_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_b), C.c_void_p(d_r), C.c_void_p(stream)))
+
+    def jacobi_dev(self, d_x, d_b, omega, sweeps, d_tmp, stream=0):
+        check(lib().ma_csr_jacobi_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_b), float(omega), int(sweeps), C.c_void_p(d_tmp), C.c_void_p(stream)))
+
+    def l1_jacobi_dev(self, d_x, d_b, sweeps, d_tmp, stream=0):
+        check(lib().ma_csr_l1jacobi_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_b), int(sweeps), C.c_void_p(d_tmp), C.c_void_p(stream)))

@@ -1,0 +1,25 @@
+// csr_kernels.hpp — device view and launchers of the CSR SpMV / smoother kernels.
+#pragma once
+#include "ma_common.hpp"
+
+namespace ma {
+
+struct dc;
+
+struct CsrView {
+  long long n;                 // rows (square operators on this path)
+  long long nnz;
+  const long long* row_ptr;    // n + 1
+  const int* col;              // nnz (usize on the Rust side; narrowed after a range check)
+  const ::ma::dc* val;         // complex values, or nullptr in K/M mode
+  const double* K;             // stiffness values (K/M mode)
+  const double* M;             // mass values (K/M mode)
+  double k2_re, k2_im;         // k^2 of the current frequency (K/M mode)
+  const ::ma::dc* dinv;        // 1 / a_ii for the current values
+  const double* l1;            // sum_j |a_ij|
+};
+
+int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st);
+int csr_launch_diag(const CsrView& A, bool km, c64* dinv, double* l1, hipStream_t st);
+
+}  // namespace ma

@@ -1,0 +1,203 @@
+// csr_plan.hip — C-ABI of the sparse FEM side: CSR operator handles, SpMV, residual, Jacobi sweeps.
+#include "csr_kernels.hpp"
+#include "ma_device_math.hpp"
+#include <vector>
+#include <new>
+#include <cmath>
+
+using namespace ma;
+
+struct ma_csr {
+  int device = 0;
+  long long n = 0, nnz = 0;
+  bool km = false;
+  int group = 16;
+  long long* d_rowptr = nullptr; int* d_col = nullptr;
+  c64* d_val = nullptr; double* d_K = nullptr; double* d_M = nullptr;
+  c64* d_dinv = nullptr; double* d_l1 = nullptr;
+  c64* d_x = nullptr; c64* d_y = nullptr; c64* d_b = nullptr;   // staging for the host-buffer entry points and ping-pong
+  double k2_re = 0.0, k2_im = 0.0;
+  bool diag_valid = false;
+  CsrView view() const {
+    CsrView v{};
+    v.n = n; v.nnz = nnz; v.row_ptr = d_rowptr; v.col = d_col; v.val = reinterpret_cast<const dc*>(d_val); v.K = d_K; v.M = d_M;
+    v.k2_re = k2_re; v.k2_im = k2_im; v.dinv = reinterpret_cast<const dc*>(d_dinv); v.l1 = d_l1;
+    return v;
+  }
+};
+
+namespace {
+int pick_group(long long n, long long nnz) {
+  const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
+  int g = 4;
+  while (g < 64 && g < mean) g <<= 1;
+  return g;
+}
+void free_all(ma_csr* h) {
+  void* p[] = {h->d_rowptr, h->d_col, h->d_val, h->d_K, h->d_M, h->d_dinv, h->d_l1, h->d_x, h->d_y, h->d_b};
+  for (void* q : p) if (q) (void)hipFree(q);
+}
+int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  MA_REQUIRE(n > 0 && rowptr && col, MA_ERR_INVALID, "bad CSR arguments");
+  MA_REQUIRE(rowptr[0] == 0, MA_ERR_INVALID, "row_ptrs[0] must be 0");
+  const int64_t nnz = rowptr[n];
+  MA_REQUIRE(nnz >= 0, MA_ERR_INVALID, "row_ptrs[n] is negative");
+  for (int64_t i = 0; i < n; ++i) MA_REQUIRE(rowptr[i + 1] >= rowptr[i], MA_ERR_INVALID, "row_ptrs must be non-decreasing (row %lld)", (long long)i);
+  MA_REQUIRE(n < 2147483647LL, MA_ERR_UNSUPPORTED, "more than 2^31-1 columns");
+  std::vector<int> c32((size_t)nnz);
+  for (int64_t i = 0; i < nnz; ++i) { MA_REQUIRE(col[i] >= 0 && col[i] < n, MA_ERR_INVALID, "column index %lld out of range at %lld", (long long)col[i], (long long)i); c32[(size_t)i] = (int)col[i]; }
+  int rc = use_device(device);
+  if (rc) return rc;
+  ma_csr* h = new (std::nothrow) ma_csr();
+  MA_REQUIRE(h, MA_ERR_NOMEM, "host allocation failed");
+  h->device = device; h->n = n; h->nnz = nnz; h->group = pick_group(n, nnz);
+  hipError_t e = hipMalloc(&h->d_rowptr, sizeof(long long) * (size_t)(n + 1));
+  if (e == hipSuccess) e = hipMalloc(&h->d_col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  if (e == hipSuccess) e = hipMalloc(&h->d_dinv, sizeof(c64) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&h->d_l1, sizeof(double) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&h->d_x, sizeof(c64) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&h->d_y, sizeof(c64) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&h->d_b, sizeof(c64) * (size_t)n);
+  if (e == hipSuccess) e = hipMemcpy(h->d_rowptr, rowptr, sizeof(long long) * (size_t)(n + 1), hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpy(h->d_col, c32.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("CSR upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; return e == hipErrorOutOfMemory ? MA_ERR_NOMEM : MA_ERR_HIP; }
+  *out = h;
+  return MA_OK;
+}
+int ensure_diag(ma_csr* h, hipStream_t st) {
+  if (h->diag_valid) return MA_OK;
+  int rc = csr_launch_diag(h->view(), h->km, h->d_dinv, h->d_l1, st);
+  if (!rc) h->diag_valid = true;
+  return rc;
+}
+}  // namespace
+
+extern "C" {
+
+// CsrMatrix<Complex64>::from_raw_parts (csr.rs:69-99): complex values
+int ma_csr_create(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr_t** out) {
+  MA_REQUIRE(values, MA_ERR_INVALID, "values is NULL");
+  int rc = create_common(n, row_ptrs, col_indices, device, out);
+  if (rc) return rc;
+  ma_csr* h = *out;
+  hipError_t e = hipMalloc(&h->d_val, sizeof(c64) * (size_t)(h->nnz > 0 ? h->nnz : 1));
+  if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_val, values, sizeof(c64) * (size_t)h->nnz, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("CSR value upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; *out = nullptr; return MA_ERR_HIP; }
+  return MA_OK;
+}
+
+// HelmholtzAssembler (assembler.rs:19-32): one pattern, real K and M values; a_ij = K_ij - k^2 M_ij per frequency
+int ma_csr_create_helmholtz(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const double* K, const double* M, int device, ma_csr_t** out) {
+  MA_REQUIRE(K && M, MA_ERR_INVALID, "K or M is NULL");
+  int rc = create_common(n, row_ptrs, col_indices, device, out);
+  if (rc) return rc;
+  ma_csr* h = *out;
+  h->km = true;
+  const size_t nz = (size_t)(h->nnz > 0 ? h->nnz : 1);
+  hipError_t e = hipMalloc(&h->d_K, sizeof(double) * nz);
+  if (e == hipSuccess) e = hipMalloc(&h->d_M, sizeof(double) * nz);
+  if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_K, K, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice);
+  if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_M, M, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("K/M upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; *out = nullptr; return MA_ERR_HIP; }
+  return MA_OK;
+}
+
+int ma_csr_destroy(ma_csr_t* h) {
+  if (!h) return MA_OK;
+  (void)hipSetDevice(h->device);
+  free_all(h);
+  delete h;
+  return MA_OK;
+}
+
+// HelmholtzAssembler::assemble(k, ..) (assembler.rs:216): here only k^2 changes; no values are rewritten
+int ma_csr_set_wavenumber(ma_csr_t* h, double k_re, double k_im) {
+  MA_REQUIRE(h, MA_ERR_INVALID, "NULL handle");
+  MA_REQUIRE(h->km, MA_ERR_INVALID, "handle holds complex values, not K/M");
+  h->k2_re = k_re * k_re - k_im * k_im; h->k2_im = 2.0 * k_re * k_im;
+  h->diag_valid = false;
+  return MA_OK;
+}
+
+int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz) {
+  MA_REQUIRE(h && n && nnz, MA_ERR_INVALID, "NULL argument");
+  *n = h->n; *nnz = h->nnz;
+  return MA_OK;
+}
+
+// device-pointer forms (x, y, b, r: n complex128 each; distinct buffers)
+int ma_csr_spmv_dev(ma_csr_t* h, const void* d_x, void* d_y, void* stream) {
+  MA_REQUIRE(h && d_x && d_y, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  return csr_launch_rows(h->view(), h->km, h->group, 0, (const c64*)d_x, nullptr, (c64*)d_y, 0.0, (hipStream_t)stream);
+}
+int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r, void* stream) {
+  MA_REQUIRE(h && d_x && d_b && d_r, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  return csr_launch_rows(h->view(), h->km, h->group, 1, (const c64*)d_x, (const c64*)d_b, (c64*)d_r, 0.0, (hipStream_t)stream);
+}
+// `sweeps` Jacobi sweeps on d_x (in place from the caller's view; d_tmp is a scratch vector of n entries)
+int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream) {
+  MA_REQUIRE(h && d_x && d_b && d_tmp && sweeps >= 0, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ensure_diag(h, st);
+  c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
+  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->km, h->group, 2, cur, (const c64*)d_b, nxt, omega, st); std::swap(cur, nxt); }
+  if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
+  return rc;
+}
+int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream) {
+  MA_REQUIRE(h && d_x && d_b && d_tmp && sweeps >= 0, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ensure_diag(h, st);
+  c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
+  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->km, h->group, 3, cur, (const c64*)d_b, nxt, 0.0, st); std::swap(cur, nxt); }
+  if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
+  return rc;
+}
+
+// host-buffer forms: CsrMatrix::matvec(&x) -> y (csr.rs:240), smooth_jacobi / smooth_l1_jacobi (amg.rs:855-929)
+static int up(ma_csr* h, c64* d, const ma_c64* s) { MA_HIP(hipMemcpy(d, s, sizeof(c64) * (size_t)h->n, hipMemcpyHostToDevice)); return MA_OK; }
+static int down(ma_csr* h, ma_c64* d, const c64* s) { MA_HIP(hipMemcpy(d, s, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToHost)); return MA_OK; }
+
+int ma_csr_spmv(ma_csr_t* h, const ma_c64* x, ma_c64* y) {
+  MA_REQUIRE(h && x && y, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = up(h, h->d_x, x);
+  if (!rc) rc = ma_csr_spmv_dev(h, h->d_x, h->d_y, nullptr);
+  if (!rc) rc = down(h, y, h->d_y);
+  return rc;
+}
+int ma_csr_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r) {
+  MA_REQUIRE(h && x && b && r, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = up(h, h->d_x, x);
+  if (!rc) rc = up(h, h->d_b, b);
+  if (!rc) rc = ma_csr_residual_dev(h, h->d_x, h->d_b, h->d_y, nullptr);
+  if (!rc) rc = down(h, r, h->d_y);
+  return rc;
+}
+int ma_csr_jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, double omega, int sweeps) {
+  MA_REQUIRE(h && x_inout && b, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = up(h, h->d_x, x_inout);
+  if (!rc) rc = up(h, h->d_b, b);
+  if (!rc) rc = ma_csr_jacobi_dev(h, h->d_x, h->d_b, omega, sweeps, h->d_y, nullptr);
+  if (!rc) rc = down(h, x_inout, h->d_x);
+  return rc;
+}
+int ma_csr_l1jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps) {
+  MA_REQUIRE(h && x_inout && b, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = up(h, h->d_x, x_inout);
+  if (!rc) rc = up(h, h->d_b, b);
+  if (!rc) rc = ma_csr_l1jacobi_dev(h, h->d_x, h->d_b, sweeps, h->d_y, nullptr);
+  if (!rc) rc = down(h, x_inout, h->d_x);
+  return rc;
+}
+
+}  // extern "C"

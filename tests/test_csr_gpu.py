@@ -1,0 +1,102 @@
+"""GPU parity of the sparse FEM side: CSR SpMV, residual, Jacobi / l1-Jacobi sweeps vs the CPU oracle.
+
+Known answers from math-solvers/src/sparse/csr.rs:659-736 and math-fem/src/assembly/helmholtz.rs:354-390;
+P1-tet Helmholtz matrices of the F1M family at a test size. Tolerance: 1e-13 relative
+to the row scale (same products, different summation order inside a row)."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from math_audio_amd import fem
+
+pytestmark = pytest.mark.gpu
+
+
+def _x0(n):
+    i = np.arange(n)
+    return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)       # the deterministic pattern of tests/test_fmm_validation.rs:121
+
+
+def test_csr_known_answers(gpu):
+    A = ma.CsrOperator([0, 2, 4], [0, 1, 0, 1], values=[1, 2, 3, 4])
+    assert np.allclose(A.matvec([1, 2]), [5, 11])
+    B = ma.CsrOperator([0, 2, 3, 5], [0, 2, 1, 0, 2], values=[1, 2, 3, 4, 5])
+    assert np.allclose(B.matvec([1, 1, 1]), [3, 3, 9])
+    A.close(); B.close()
+
+
+@pytest.mark.parametrize("nxyz", [(6, 5, 4), (21, 17, 13)])
+def test_helmholtz_spmv_and_smoothers_match_oracle(gpu, nxyz):
+    nodes, rp, ci, K, M = fem.helmholtz_box(*nxyz)
+    n = len(rp) - 1
+    assert n == (nxyz[0] + 1) * (nxyz[1] + 1) * (nxyz[2] + 1)
+    op = ma.CsrOperator(rp, ci, K=K, M=M)
+    x = _x0(n); b = np.cos(0.3 * np.arange(n)) + 0.5j
+    for k in (0.0, 2 * np.pi * 100.0 / 343.0, 1.832 + 0.01j):
+        op.set_wavenumber(k)
+        vals = O.helmholtz_values(K, M, k)
+        if k == 0.0:
+            assert np.array_equal(vals, K.astype(complex))            # helmholtz.rs:354-390
+        y_ref = O.csr_matvec(rp, ci, vals, x, nthreads=4)
+        scale = np.abs(y_ref).max()
+        assert np.abs(op.matvec(x) - y_ref).max() <= 1e-13 * scale
+        assert np.abs(op.residual(x, b) - (b - y_ref)).max() <= 1e-13 * max(scale, 1.0)
+        xj_ref = O.amg_jacobi(rp, ci, vals, x, b, 0.8, 2, nthreads=4)   # AmgConfig::for_parallel: omega 0.8, 2 sweeps
+        assert np.abs(op.jacobi(x, b, 0.8, 2) - xj_ref).max() <= 1e-12 * np.abs(xj_ref).max()
+        xl_ref = O.amg_l1_jacobi(rp, ci, vals, x, b, 2, nthreads=4)
+        assert np.abs(op.l1_jacobi(x, b, 2) - xl_ref).max() <= 1e-12 * np.abs(xl_ref).max()
+    op.close()
+
+
+def test_generic_complex_csr_with_ragged_rows(gpu):
+    """Empty rows, a dense row, long and short rows: every group width path."""
+    rng = np.random.default_rng(4)
+    n = 500
+    rows = []
+    for i in range(n):
+        m = [0, 1, 3, 17, 70, 300][i % 6]
+        rows.append(np.sort(rng.choice(n, size=m, replace=False)))
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    ci = np.concatenate(rows).astype(np.int64)
+    vals = rng.standard_normal(len(ci)) + 1j * rng.standard_normal(len(ci))
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    op = ma.CsrOperator(rp, ci, values=vals)
+    y_ref = O.csr_matvec(rp, ci, vals, x)
+    assert np.abs(op.matvec(x) - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    op.close()
+
+
+def test_jacobi_sweeps_on_device_buffers(gpu):
+    """Device-resident ping-pong form: equals the oracle sweep for sweep and, as in smoother.rs:192-237 /
+    the amg.rs tests, drives the residual down (K + 0.25 M is positive definite)."""
+    import torch
+    nodes, rp, ci, K, M = fem.helmholtz_box(12, 10, 8)
+    n = len(rp) - 1
+    op = ma.CsrOperator(rp, ci, K=K, M=M)
+    op.set_wavenumber(0.5j)
+    vals = O.helmholtz_values(K, M, 0.5j)
+    dev = torch.device("cuda", 0)
+    bh = np.ones(n, dtype=complex)
+    b = torch.tensor(bh, device=dev); x = torch.zeros_like(b); tmp = torch.empty_like(b); r = torch.empty_like(b)
+    st = torch.cuda.current_stream().cuda_stream
+    op.residual_dev(x.data_ptr(), b.data_ptr(), r.data_ptr(), st); r0 = float(torch.linalg.norm(r))
+    op.jacobi_dev(x.data_ptr(), b.data_ptr(), 2.0 / 3.0, 5, tmp.data_ptr(), st)           # odd count: result copied back
+    x_ref = O.amg_jacobi(rp, ci, vals, np.zeros(n, dtype=complex), bh, 2.0 / 3.0, 5)
+    assert np.abs(x.cpu().numpy() - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+    op.l1_jacobi_dev(x.data_ptr(), b.data_ptr(), 4, tmp.data_ptr(), st)
+    x_ref = O.amg_l1_jacobi(rp, ci, vals, x_ref, bh, 4)
+    assert np.abs(x.cpu().numpy() - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+    op.l1_jacobi_dev(x.data_ptr(), b.data_ptr(), 200, tmp.data_ptr(), st)
+    op.residual_dev(x.data_ptr(), b.data_ptr(), r.data_ptr(), st); r1 = float(torch.linalg.norm(r))
+    assert r1 < 0.7 * r0                                   # Jacobi is a smoother, not a solver
+    op.close()
+
+
+def test_csr_argument_errors(gpu):
+    with pytest.raises(ma.MaError) as e:
+        ma.CsrOperator([0, 1, 2], [0, 5], values=[1, 1])          # column out of range
+    assert e.value.status == ma.MA_ERR_INVALID
+    A = ma.CsrOperator([0, 1, 2], [0, 1], values=[1, 1])
+    with pytest.raises(ma.MaError):
+        A.set_wavenumber(1.0)                                      # complex-valued handle has no K/M
+    A.close()
