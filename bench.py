@@ -99,8 +99,71 @@ def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
     }
 
 
+def fem_workload(args):
+    """BASELINE.json configs[3]: F1M = box 5 x 4 x 2.5 m, n^3 nodes P1 Kuhn tets,
+    k = 2 pi 100 / 343: `--steps` CSR SpMVs, Jacobi (omega 0.8) and l1-Jacobi sweeps, device-resident.
+    HBM-bound: achieved = algorithmic bytes (nnz 20 B + N 36 B per SpMV, + N 64 B per smoother update) / time."""
+    import torch
+    import math_audio_amd as ma
+    from math_audio_amd import fem
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    dev = torch.device("cuda", 0)
+    m = args.fem_n - 1
+    t0 = time.perf_counter()
+    nodes, rp, ci, K, M = fem.helmholtz_box(m, m, m)
+    n, nnz = len(rp) - 1, len(ci)
+    t_gen = time.perf_counter() - t0
+    op = ma.CsrOperator(rp, ci, K=K, M=M)
+    k = 2.0 * math.pi * 100.0 / C_SOUND
+    op.set_wavenumber(complex(k, 0.01))
+    i = torch.arange(n, dtype=torch.float64, device=dev)
+    x = torch.complex(torch.sin(0.1 * i), torch.cos(0.2 * i)); b = torch.ones(n, dtype=torch.complex128, device=dev)
+    y = torch.empty_like(x); tmp = torch.empty_like(x)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    byts = {"spmv": nnz * 20.0 + n * 36.0, "jacobi": nnz * 20.0 + n * 100.0, "l1_jacobi": nnz * 20.0 + n * 92.0}
+    for name in ("spmv", "jacobi", "l1_jacobi"):
+        def run(reps):
+            if name == "spmv":
+                for _ in range(reps):
+                    op.spmv_dev(x.data_ptr(), y.data_ptr(), st)
+            elif name == "jacobi":
+                op.jacobi_dev(y.data_ptr(), b.data_ptr(), 0.8, reps, tmp.data_ptr(), st)
+            else:
+                op.l1_jacobi_dev(y.data_ptr(), b.data_ptr(), reps, tmp.data_ptr(), st)
+        y.copy_(x); run(max(2, args.warmup * 2)); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        reps = args.steps * 10
+        e0.record(); run(reps); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        res[name] = {"ms": ms, "GB/s": byts[name] / (ms * 1e-3) / 1e9, "frac_of_8TBs": byts[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out = {"metric": "fem_csr_spmv_gbs", "value": res["spmv"]["GB/s"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps * 10, "warmup": args.warmup,
+           "ms_per_step": res["spmv"]["ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128 x, real K/M)",
+           "data": "synthetic", "config": {"workload": "F1M-family box 5x4x2.5 m, %d^3 nodes, P1 Kuhn tets: N=%d, nnz=%d; A = K - k^2 M fused; k = 2 pi 100/343 + 0.01i" % (args.fem_n, n, nnz),
+                                           "host_generation_s": t_gen},
+           "kernels": res,
+           "roofline": {"kernel": "csr_rows_kernel (SpMV)", "bound": "hbm", "achieved": res["spmv"]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": res["spmv"]["frac_of_8TBs"], "traffic": None}}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cores = os.cpu_count() or 1
+        vals = O.helmholtz_values(K, M, complex(k, 0.01)); xh = x.cpu().numpy()
+        O.csr_matvec(rp, ci, vals, xh, nthreads=cores)
+        t0 = time.perf_counter(); reps = 5
+        for _ in range(reps):
+            O.csr_matvec(rp, ci, vals, xh, nthreads=cores)
+        tc = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": byts["spmv"] / tc / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+                               "sample": "oracle row-parallel CSR matvec (csr.rs:273-292), %d threads, %d reps of the same matrix" % (cores, reps)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["bem", "fem"], default="bem", help="bem = the headline sweep (default); fem = CSR SpMV / smoother bandwidth")
+    ap.add_argument("--fem-n", type=int, default=100, help="nodes per box edge for --workload fem")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
@@ -111,6 +174,8 @@ def main():
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "1")),
                     help="frequencies in flight per GPU (each slot owns a matrix, an LU workspace and a stream)")
     args = ap.parse_args()
+    if args.workload == "fem":
+        return fem_workload(args)
 
     import torch
     import torch.distributed as dist

@@ -162,6 +162,32 @@ int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int
 int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Operator boundary and GMRES.
+ * Replaces: trait LinearOperator<Complex64> { num_rows, apply(&x) -> y }   math-solvers/src/traits.rs:316-327
+ *           DenseOperator (matrix.dot(x))                               math-bem/src/core/solver/fmm_interface.rs:25-53
+ *           impl LinearOperator for CsrMatrix                           math-solvers/src/sparse/csr.rs:420-440
+ *           gmres / gmres_with_guess(operator, b, x0, config)            math-solvers/src/iterative/gmres.rs:96-277
+ * ma_op_create_tbem is the matrix-free TBEM operator of BASELINE.json configs[4] (new; it must equal A x of
+ * the dense matrix): rows [row0, row1) of y are produced; the plan is borrowed and must outlive the operator.
+ * A Rust struct holding the handle implements the trait; Drop calls ma_op_destroy.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ma_op ma_op_t;
+typedef struct { int32_t iterations, restarts, converged; double residual; } ma_gmres_info_t;   /* GmresSolution, gmres.rs:72-85 */
+int ma_op_create_dense(int64_t n, const ma_c64* A_rowmajor, int device, ma_op_t** out);
+int ma_op_create_dense_dev(int64_t n, const void* d_A, int device, ma_op_t** out);
+int ma_op_create_csr(ma_csr_t* csr, ma_op_t** out);
+int ma_op_create_tbem(ma_bem_plan_t* plan, const ma_physics_t* physics, double beta_re, double beta_im,
+                      int32_t row0, int32_t row1, ma_op_t** out);
+int ma_op_destroy(ma_op_t* op);
+int ma_op_num_rows(const ma_op_t* op, int64_t* n);
+int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);
+int ma_op_apply_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
+/* Restarted GMRES(m), relative tolerance on ||b||; defaults of GmresConfig: restart 30, tol 1e-6, 100 restarts
+ * (gmres.rs:27-35). x0 may be NULL. Non-convergence is reported in info->converged, not as an error. */
+int ma_gmres(ma_op_t* op, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol,
+             ma_c64* x_out, ma_gmres_info_t* info);
+
+/* ------------------------------------------------------------------------------------------
  * Parity-test hooks (no counterpart in the reference API): raw panel integrals computed by the
  * device kernels, comparable to IntegrationResult of regular_integration / singular_integration
  * (math-bem/src/core/integration/regular.rs:33, singular.rs:123; types.rs:722-734).

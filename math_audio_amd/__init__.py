@@ -92,6 +92,15 @@ def lib():
             "ma_csr_residual_dev": [vp, vp, vp, vp, vp],
             "ma_csr_jacobi_dev": [vp, vp, vp, dbl, C.c_int, vp, vp],
             "ma_csr_l1jacobi_dev": [vp, vp, vp, C.c_int, vp, vp],
+            "ma_op_create_dense": [i64, vp, C.c_int, P(vp)],
+            "ma_op_create_dense_dev": [i64, vp, C.c_int, P(vp)],
+            "ma_op_create_csr": [vp, P(vp)],
+            "ma_op_create_tbem": [vp, P(ma_physics_t), dbl, dbl, i32, i32, P(vp)],
+            "ma_op_destroy": [vp],
+            "ma_op_num_rows": [vp, P(i64)],
+            "ma_op_apply": [vp, vp, vp],
+            "ma_op_apply_dev": [vp, vp, vp, vp],
+            "ma_gmres": [vp, vp, vp, i32, i32, dbl, vp, vp],
             "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
             "ma_probe_mfma_f64": [C.c_int, P(dbl)],
         }
@@ -351,3 +360,74 @@ class CsrOperator:
 
     def l1_jacobi_dev(self, d_x, d_b, sweeps, d_tmp, stream=0):
         check(lib().ma_csr_l1jacobi_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_b), int(sweeps), C.c_void_p(d_tmp), C.c_void_p(stream)))
+
+
+class GmresInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("restarts", C.c_int32), ("converged", C.c_int32), ("residual", C.c_double)]
+
+
+class LinearOperator:
+    """ma_op_t: the LinearOperator<Complex64> boundary (traits.rs:316-327). Build with dense(), csr() or tbem()."""
+
+    def __init__(self, handle, keep=None):
+        self.h = handle
+        self._keep = keep           # borrowed objects (plan / CSR handle) must outlive the operator
+        n = C.c_int64()
+        check(lib().ma_op_num_rows(self.h, C.byref(n)))
+        self.n = n.value
+
+    @staticmethod
+    def dense(A, device=0):
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        h = C.c_void_p()
+        check(lib().ma_op_create_dense(A.shape[0], _vp(A), device, C.byref(h)))
+        return LinearOperator(h)
+
+    @staticmethod
+    def dense_dev(n, d_A, device=0, keep=None):
+        h = C.c_void_p()
+        check(lib().ma_op_create_dense_dev(n, C.c_void_p(d_A), device, C.byref(h)))
+        return LinearOperator(h, keep)
+
+    @staticmethod
+    def csr(csr_operator):
+        h = C.c_void_p()
+        check(lib().ma_op_create_csr(csr_operator.h, C.byref(h)))
+        return LinearOperator(h, csr_operator)
+
+    @staticmethod
+    def tbem(plan, k, beta, rows=None, harmonic=1.0, tau=1.0):
+        ph = physics(k, harmonic, tau); beta = complex(beta)
+        r0, r1 = (0, plan.num_dofs) if rows is None else rows
+        h = C.c_void_p()
+        check(lib().ma_op_create_tbem(plan.h, C.byref(ph), beta.real, beta.imag, r0, r1, C.byref(h)))
+        return LinearOperator(h, plan)
+
+    def close(self):
+        if self.h:
+            lib().ma_op_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def apply(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128); y = np.empty(self.n, dtype=np.complex128)
+        check(lib().ma_op_apply(self.h, _vp(x), _vp(y)))
+        return y
+
+    def apply_dev(self, d_x, d_y, stream=0):
+        check(lib().ma_op_apply_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream)))
+
+
+def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
+    """gmres / gmres_with_guess (gmres.rs:96-277) on the device: returns (x, GmresInfo)."""
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    x = np.empty(op.n, dtype=np.complex128)
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    info = GmresInfo()
+    check(lib().ma_gmres(op.h, _vp(b), _vp(x0a), restart, max_iterations, float(tol), _vp(x), C.byref(info)))
+    return x, info

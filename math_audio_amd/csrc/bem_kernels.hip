@@ -186,7 +186,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // PROBE = true: instead of the matrix entry, write the leaf count and the four raw integrals
 // (G, H, H^T, E) of pair pid to out[5*pid..] — used by the parity tests on arbitrary (i != j) pairs.
-template <bool PROBE>
+template <int MODE>   // 0: write A[i][j]; 1: probe {leaves, G, H, H^T, E} to out[5 pid]; 2: coefficient to out[pid]
 __global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs,
                                                         long long npairs, dc* __restrict__ A) {
   __shared__ double s_leaf[4][MA_MAX_LEAVES][6];
@@ -289,9 +289,11 @@ __global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, c
   s.ht.re = wave_sum(s.ht.re); s.ht.im = wave_sum(s.ht.im);
   s.e.re = wave_sum(s.e.re); s.e.im = wave_sum(s.e.im);
   if (lane == 0) {
-    if (PROBE) {
+    if (MODE == 1) {
       dc* o = A + 5 * pid;
       o[0] = dc_make((double)nleaf, 0.0); o[1] = s.g; o[2] = s.h; o[3] = s.ht; o[4] = s.e;
+    } else if (MODE == 2) {
+      A[pid] = bm_coeff(s, g.bc_type[j], ph);
     } else {
       A[(long long)g.dof[i] * g.nd + g.dof[j]] = bm_coeff(s, g.bc_type[j], ph);
     }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, c
 __device__ __constant__ double c_csi6[6] = {0.0, 1.0, 0.0, 0.5, 0.5, 0.0};
 __device__ __constant__ double c_eta6[6] = {0.0, 0.0, 1.0, 0.0, 0.5, 0.5};
 
-template <bool PROBE>
+template <int MODE>   // 0: write A[i][i]; 1: probe to out[5 e]; 2: diagonal entry (with free term) to out[e]
 __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + wave;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
   s.h = dc_make(wave_sum(sh.re), wave_sum(sh.im));
   s.ht = dc_make(wave_sum(sht.re), wave_sum(sht.im));
   s.e = dc_make(wave_sum(se.re), wave_sum(se.im));
-  if (PROBE) {
+  if (MODE == 1) {
     if (lane == 0) {
       dc* o = A + 5 * (long long)e;
       o[0] = dc_make((double)ntask, 0.0); o[1] = s.g; o[2] = s.h; o[3] = s.ht; o[4] = s.e;
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
     if (bc == 0) fr = dc_make(-(ph.gamma * 0.5), 0.0);
     else if (bc == 1) fr = dc_make(-(ph.beta_re * ph.tau * 0.5), -(ph.beta_im * ph.tau * 0.5));
     const long long d = g.dof[e];
-    A[d * g.nd + d] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
+    if (MODE == 2) A[e] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
+    else A[d * g.nd + d] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
   }
 }
 
@@ -491,7 +494,7 @@ int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) 
 int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st) {
   if (npairs <= 0) return MA_OK;
   dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
-  hipLaunchKernelGGL(tbem_near_kernel<false>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
+  hipLaunchKernelGGL(tbem_near_kernel<0>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -499,21 +502,36 @@ int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long
 int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st) {
   if (npairs <= 0) return MA_OK;
   dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
-  hipLaunchKernelGGL(tbem_near_kernel<true>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out5));
+  hipLaunchKernelGGL(tbem_near_kernel<1>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out5));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
 
 int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st) {
   dim3 grid((g.np + 3) / 4), block(256);
-  hipLaunchKernelGGL(tbem_self_kernel<true>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out5));
+  hipLaunchKernelGGL(tbem_self_kernel<1>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out5));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
 
 int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) {
   dim3 grid((g.np + 3) / 4), block(256);
-  hipLaunchKernelGGL(tbem_self_kernel<false>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
+  hipLaunchKernelGGL(tbem_self_kernel<0>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// list forms for the on-the-fly operator: coefficient of every listed near pair / of every diagonal entry
+int bem_launch_near_list_values(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st) {
+  if (npairs <= 0) return MA_OK;
+  dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
+  hipLaunchKernelGGL(tbem_near_kernel<2>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int bem_launch_self_list_values(const BemGeom& g, const BemPhys& ph, c64* out, hipStream_t st) {
+  dim3 grid((g.np + 3) / 4), block(256);
+  hipLaunchKernelGGL(tbem_self_kernel<2>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -39,8 +39,27 @@ int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long
 int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
 int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st);
 int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st);
+int bem_launch_near_list_values(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st);
+int bem_launch_self_list_values(const BemGeom& g, const BemPhys& ph, c64* out, hipStream_t st);
 int bem_launch_zero(c64* v, int n, hipStream_t st);
 int bem_launch_incident(const BemGeom& g, const BemPhys& ph, int kind, const double* v, double are, double aim,
                         int accumulate, c64* rhs, hipStream_t st);
 
 }  // namespace ma
+
+// the plan object behind ma_bem_plan_t (shared by bem_plan.hip and op_plan.hip)
+struct ma_bem_plan {
+  int device = 0;
+  int np = 0, nd = 0;
+  double avg_radius = 0.0;         // tbem.rs:108-117
+  void* pool = nullptr;            // one HBM allocation holding every SoA array
+  ma::BemGeom geom{};
+  int2* d_pairs = nullptr;         // near pairs, sorted by collocation row i then j
+  long long* d_pair_off = nullptr; // np + 1 row offsets into d_pairs
+  long long npairs = 0;
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double last_ms[3] = {0, 0, 0};
+  bool ev_valid = false;
+};
+int ma_bem_make_phys(const ma_bem_plan* P, const ma_physics_t* ph, double bre, double bim, ma::BemPhys* o);

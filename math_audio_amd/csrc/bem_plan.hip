@@ -41,20 +41,6 @@ int use_device(int device) {
 
 using namespace ma;
 
-struct ma_bem_plan {
-  int device = 0;
-  int np = 0, nd = 0;
-  double avg_radius = 0.0;         // tbem.rs:108-117
-  void* pool = nullptr;            // one HBM allocation holding every SoA array
-  BemGeom geom{};
-  int2* d_pairs = nullptr;
-  long long npairs = 0;
-  bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  double last_ms[3] = {0, 0, 0};
-  bool ev_valid = false;
-};
-
 namespace {
 
 // Host geometry exactly as the reference's per-point code evaluates it for a flat Tri3
@@ -209,23 +195,25 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   // near-pair list: count, scan on host, fill (one-off per mesh; creation is synchronous)
   int* d_counts = nullptr; long long* d_offsets = nullptr;
   MA_TRY(hipMalloc(&d_counts, sizeof(int) * (size_t)np));
-  MA_TRY(hipMalloc(&d_offsets, sizeof(long long) * (size_t)np));
+  MA_TRY(hipMalloc(&d_offsets, sizeof(long long) * (size_t)(np + 1)));
   rc = bem_launch_near_list(g, 0, d_counts, nullptr, nullptr, nullptr);
   if (rc) { (void)hipFree(d_counts); (void)hipFree(d_offsets); return fail(rc); }
   std::vector<int> hc((size_t)np);
   MA_TRY(hipMemcpy(hc.data(), d_counts, sizeof(int) * (size_t)np, hipMemcpyDeviceToHost));
-  std::vector<long long> ho((size_t)np);
+  std::vector<long long> ho((size_t)np + 1);
   long long tot = 0;
   for (int i = 0; i < np; ++i) { ho[i] = tot; tot += hc[i]; }
+  ho[np] = tot;
   P->npairs = tot;
+  MA_TRY(hipMemcpy(d_offsets, ho.data(), sizeof(long long) * (size_t)(np + 1), hipMemcpyHostToDevice));
   if (tot > 0) {
     MA_TRY(hipMalloc(&P->d_pairs, sizeof(int2) * (size_t)tot));
-    MA_TRY(hipMemcpy(d_offsets, ho.data(), sizeof(long long) * (size_t)np, hipMemcpyHostToDevice));
     rc = bem_launch_near_list(g, 1, d_counts, d_offsets, P->d_pairs, nullptr);
     if (rc) { (void)hipFree(d_counts); (void)hipFree(d_offsets); return fail(rc); }
   }
   MA_TRY(hipDeviceSynchronize());
-  (void)hipFree(d_counts); (void)hipFree(d_offsets);
+  (void)hipFree(d_counts);
+  P->d_pair_off = d_offsets;
   for (int i = 0; i < 4; ++i) MA_TRY(hipEventCreate(&P->ev[i]));
 #undef MA_TRY
   *out = P;
@@ -237,6 +225,7 @@ int ma_bem_plan_destroy(ma_bem_plan_t* P) {
   (void)hipSetDevice(P->device);
   for (int i = 0; i < 4; ++i) if (P->ev[i]) (void)hipEventDestroy(P->ev[i]);
   if (P->d_pairs) (void)hipFree(P->d_pairs);
+  if (P->d_pair_off) (void)hipFree(P->d_pair_off);
   if (P->pool) (void)hipFree(P->pool);
   delete P;
   return MA_OK;
@@ -254,7 +243,8 @@ int ma_bem_plan_num_near_pairs(const ma_bem_plan_t* P, int64_t* n) {
   return MA_OK;
 }
 
-static int make_phys(const ma_bem_plan* P, const ma_physics_t* ph, double bre, double bim, BemPhys* o) {
+extern "C++" {
+int ma_bem_make_phys(const ma_bem_plan* P, const ma_physics_t* ph, double bre, double bim, ma::BemPhys* o) {
   MA_REQUIRE(ph, MA_ERR_INVALID, "physics is NULL");
   MA_REQUIRE(std::isfinite(ph->wave_number) && ph->wave_number > 0.0, MA_ERR_INVALID, "wave_number must be finite and > 0");
   o->k = ph->wave_number; o->harmonic = ph->harmonic_factor; o->tau = ph->tau; o->gamma = ph->gamma;
@@ -263,11 +253,12 @@ static int make_phys(const ma_bem_plan* P, const ma_physics_t* ph, double bre, d
   o->sign = ka < 0.5 ? 1.0 : -1.0;
   return MA_OK;
 }
+}  // extern "C++"
 
 int ma_bem_plan_assemble_dev(ma_bem_plan_t* P, const ma_physics_t* ph, double bre, double bim, void* dA, void* drhs, void* stream) {
   MA_REQUIRE(P && dA && drhs, MA_ERR_INVALID, "NULL argument");
   BemPhys bp;
-  int rc = make_phys(P, ph, bre, bim, &bp);
+  int rc = ma_bem_make_phys(P, ph, bre, bim, &bp);
   if (rc) return rc;
   MA_HIP(hipSetDevice(P->device));
   hipStream_t st = (hipStream_t)stream;
@@ -308,7 +299,7 @@ int ma_bem_plan_incident_rhs_dev(ma_bem_plan_t* P, const ma_physics_t* ph, doubl
   MA_REQUIRE(P && vec3 && drhs, MA_ERR_INVALID, "NULL argument");
   MA_REQUIRE(kind == 0 || kind == 1, MA_ERR_INVALID, "kind must be 0 (plane wave) or 1 (point source)");
   BemPhys bp;
-  int rc = make_phys(P, ph, bre, bim, &bp);
+  int rc = ma_bem_make_phys(P, ph, bre, bim, &bp);
   if (rc) return rc;
   MA_HIP(hipSetDevice(P->device));
   return bem_launch_incident(P->geom, bp, kind, vec3, are, aim, accumulate, (c64*)drhs, (hipStream_t)stream);
@@ -320,7 +311,7 @@ int ma_bem_plan_incident_rhs_dev(ma_bem_plan_t* P, const ma_physics_t* ph, doubl
 int ma_bem_plan_probe_pairs(ma_bem_plan_t* P, const ma_physics_t* ph, int64_t npairs, const int32_t* pairs, ma_c64* out5) {
   MA_REQUIRE(P && pairs && out5 && npairs >= 0, MA_ERR_INVALID, "bad argument");
   BemPhys bp;
-  int rc = make_phys(P, ph, 0.0, 0.0, &bp);
+  int rc = ma_bem_make_phys(P, ph, 0.0, 0.0, &bp);
   if (rc) return rc;
   for (int64_t q = 0; q < npairs; ++q) {
     int i = pairs[2 * q], j = pairs[2 * q + 1];
@@ -345,7 +336,7 @@ int ma_bem_plan_probe_pairs(ma_bem_plan_t* P, const ma_physics_t* ph, int64_t np
 int ma_bem_plan_probe_self(ma_bem_plan_t* P, const ma_physics_t* ph, ma_c64* out5) {
   MA_REQUIRE(P && out5, MA_ERR_INVALID, "bad argument");
   BemPhys bp;
-  int rc = make_phys(P, ph, 0.0, 0.0, &bp);
+  int rc = ma_bem_make_phys(P, ph, 0.0, 0.0, &bp);
   if (rc) return rc;
   MA_HIP(hipSetDevice(P->device));
   c64* dout = nullptr;

@@ -368,14 +368,16 @@ __global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A
 // ------------------------------------------------------------------ U12 = L11^-1 A12 (strip kernel)
 // One workgroup owns a strip of 64 columns of A12 and keeps the whole nb x 64 strip in LDS
 // (128 KB at nb = 128: the strip never leaves the CU during the solve). Lane = column, the 4
-// wavefronts split the rows. Per 16-row block: every thread solves the 16 x 16 unit-lower diagonal
-// block for its own column in registers (the small triangle sits in LDS, read as broadcasts), then
-// the rows below are updated with the 16 multipliers of their row fetched on the scalar path
-// (the row index is wave-uniform, so L[r][rlo..rlo+16) arrives in SGPRs).
+// wavefronts split the rows. Per 16-row block: wavefront 0 solves the 16 x 16 unit-lower diagonal
+// block for its 64 columns in registers (the small triangle sits in LDS, read as broadcasts) and
+// writes the solved rows back; then every wavefront updates its share of the rows below with the
+// block's 16 multipliers per row, staged through LDS 64 rows at a time (wave-uniform row ->
+// broadcast reads).
 __global__ __launch_bounds__(256, 1) void lu_trsm_strip_kernel(const dc* __restrict__ T, int ldt, int nb, dc* __restrict__ X, size_t ldx, int ncols) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   dc* Xs = reinterpret_cast<dc*>(smem);                 // [nb][64]
   dc* Ds = Xs + (size_t)nb * 64;                        // [16][16] diagonal block
+  dc* Ls = Ds + 256;                                    // [64][16] multipliers of up to 64 rows below
   const int tid = threadIdx.x, cg = tid & 63;
   const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0 = blockIdx.x * 64;
@@ -387,24 +389,35 @@ __global__ __launch_bounds__(256, 1) void lu_trsm_strip_kernel(const dc* __restr
     __syncthreads();
     { const int i = tid >> 4, p = tid & 15; Ds[tid] = (i < nr && p < nr) ? T[(size_t)(rlo + i) * ldt + rlo + p] : dc_make(0.0, 0.0); }
     __syncthreads();
-    dc x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = (i < nr) ? Xs[(rlo + i) * 64 + cg] : dc_make(0.0, 0.0);
-#pragma unroll
-    for (int i = 1; i < 16; ++i) {
-#pragma unroll
-      for (int p = 0; p < i; ++p) { const dc t = Ds[i * 16 + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
-    }
     if (rg == 0) {
+      dc x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = (i < nr) ? Xs[(rlo + i) * 64 + cg] : dc_make(0.0, 0.0);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) {
+#pragma unroll
+        for (int p = 0; p < i; ++p) { const dc t = Ds[i * 16 + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) if (i < nr) Xs[(rlo + i) * 64 + cg] = x[i];
     }
-    for (int r = rlo + 16 + rg; r < nb; r += 4) {
-      const dc* __restrict__ Lr = T + (size_t)r * ldt + rlo;      // wave-uniform address -> scalar loads
-      dc acc = Xs[r * 64 + cg];
+    const int below = nb - (rlo + 16);
+    for (int base = 0; base < below; base += 64) {
+      const int cnt = min(64, below - base);
+      __syncthreads();                                   // solved rows visible; previous Ls chunk consumed
+      for (int idx = tid; idx < cnt * 16; idx += 256) { const int r = idx >> 4, i = idx & 15; Ls[idx] = T[(size_t)(rlo + 16 + base + r) * ldt + rlo + i]; }
+      __syncthreads();
+      dc x[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const dc t = Lr[i]; acc.re -= t.re * x[i].re - t.im * x[i].im; acc.im -= t.re * x[i].im + t.im * x[i].re; }
-      Xs[r * 64 + cg] = acc;
+      for (int i = 0; i < 16; ++i) x[i] = Xs[(rlo + i) * 64 + cg];
+      for (int r = rg; r < cnt; r += 4) {
+        const int gr = rlo + 16 + base + r;
+        dc acc = Xs[gr * 64 + cg];
+        const dc* Lr = Ls + r * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const dc t = Lr[i]; acc.re -= t.re * x[i].re - t.im * x[i].im; acc.im -= t.re * x[i].im + t.im * x[i].re; }
+        Xs[gr * 64 + cg] = acc;
+      }
     }
   }
   __syncthreads();
@@ -755,7 +768,7 @@ int lu_trsm_configure() {
 // X (nb x ncols at X, row stride ldx) <- L11^-1 X with the unit-lower nb x nb triangle at T
 int lu_launch_trsm_strip(const c64* T, int ldt, int nb, c64* X, size_t ldx, int ncols, hipStream_t st) {
   if (ncols <= 0 || nb <= 0) return MA_OK;
-  const size_t lds = ((size_t)nb * 64 + 256) * sizeof(dc);
+  const size_t lds = ((size_t)nb * 64 + 256 + 64 * 16) * sizeof(dc);
   hipLaunchKernelGGL(lu_trsm_strip_kernel, dim3((ncols + 63) / 64), dim3(256), lds, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, ncols);
   MA_HIP(hipGetLastError());
   return MA_OK;

@@ -1,0 +1,258 @@
+// op_kernels.hip — operator applies and the BLAS-1 pieces of device GMRES for gfx950.
+//
+//   zgemv_kernel        dense y = A x (DenseOperator::apply = matrix.dot(x), fmm_interface.rs:46-48); HBM-bound.
+//   tbem_matvec_kernel  on-the-fly y = A x of the TBEM operator without storing A: lane = collocation
+//                       row (its point and normal live in VGPRs), the field panels stream past as
+//                       wave-uniform data on the scalar path; each pair is integrated with the same
+//                       13-point routine as tbem_far_kernel and immediately multiplied by x_j. Column
+//                       chunks go to blockIdx.y and are summed by a second deterministic pass.
+//   tbem_corr_*         sparse corrections (near pairs and the diagonal): A_true - A_13pt, computed once
+//                       per frequency with the K2/K3 kernels, applied as a small CSR product.
+//   dot / axpy / scale  inner_product (conj(x).y), axpy and vector_norm of blas_helpers.rs:21-73 with the
+//                       scalar kept on the device between the dot and the axpy of modified Gram-Schmidt.
+#include "op_kernels.hpp"
+#include "ma_device_math.hpp"
+
+namespace ma {
+
+// ------------------------------------------------------------------ dense y = A x (one wavefront per row)
+__global__ __launch_bounds__(256) void zgemv_kernel(long long n, const dc* __restrict__ A, const dc* __restrict__ x, dc* __restrict__ y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= n) return;
+  const dc* Ar = A + row * n;
+  double sr = 0.0, si = 0.0;
+  for (long long j = lane; j < n; j += 64) {
+    const dc a = Ar[j], v = x[j];
+    sr += a.re * v.re - a.im * v.im; si += a.re * v.im + a.im * v.re;
+  }
+  sr = wave_sum(sr); si = wave_sum(si);
+  if (lane == 0) y[row] = dc_make(sr, si);
+}
+
+// ------------------------------------------------------------------ BLAS-1 with device-resident scalars
+#define RED_BLOCKS 256
+// partial[b] = sum over the block's slice of conj(x) * y   (mode 0) or |x|^2 (mode 1, y unused)
+__global__ __launch_bounds__(256) void dot_partial_kernel(long long n, const dc* __restrict__ x, const dc* __restrict__ y, int mode, dc* __restrict__ partial) {
+  __shared__ double sr[4], si[4];
+  double ar = 0.0, ai = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const dc a = x[i];
+    if (mode == 0) { const dc b = y[i]; ar += a.re * b.re + a.im * b.im; ai += a.re * b.im - a.im * b.re; }
+    else ar += a.re * a.re + a.im * a.im;
+  }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sr[wave] = ar; si[wave] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = dc_make((sr[0] + sr[1]) + (sr[2] + sr[3]), (si[0] + si[1]) + (si[2] + si[3]));
+}
+// out = sum(partial[0..nb)) (mode 0), or sqrt of its real part (mode 1)
+__global__ __launch_bounds__(256) void dot_final_kernel(int nb, const dc* __restrict__ partial, int mode, dc* __restrict__ out) {
+  __shared__ double sr[4], si[4];
+  double ar = 0.0, ai = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) { ar += partial[i].re; ai += partial[i].im; }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sr[wave] = ar; si[wave] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double r = (sr[0] + sr[1]) + (sr[2] + sr[3]), i2 = (si[0] + si[1]) + (si[2] + si[3]);
+    *out = mode == 0 ? dc_make(r, i2) : dc_make(__builtin_sqrt(r), 0.0);
+  }
+}
+// y += s * alpha * x with alpha read from device memory (s = +1 / -1), or with a host scalar when alpha == nullptr
+__global__ __launch_bounds__(256) void axpy_kernel(long long n, const dc* __restrict__ alpha, double sgn, double hre, double him,
+                                                   const dc* __restrict__ x, dc* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double are = hre, aim = him;
+  if (alpha) { are = sgn * alpha->re; aim = sgn * alpha->im; }
+  const dc xv = x[i]; dc yv = y[i];
+  yv.re += are * xv.re - aim * xv.im; yv.im += are * xv.im + aim * xv.re;
+  y[i] = yv;
+}
+// out = a * x + b * y (host scalars; y may be nullptr when b == 0)
+__global__ __launch_bounds__(256) void axpby_kernel(long long n, double are, double aim, const dc* __restrict__ x, double bre, double bim,
+                                                    const dc* __restrict__ y, dc* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const dc xv = x[i];
+  dc o = dc_make(are * xv.re - aim * xv.im, are * xv.im + aim * xv.re);
+  if (y) { const dc yv = y[i]; o.re += bre * yv.re - bim * yv.im; o.im += bre * yv.im + bim * yv.re; }
+  out[i] = o;
+}
+
+// ------------------------------------------------------------------ on-the-fly TBEM matvec, 13-point part
+__constant__ double c_op_tri13[13][3];
+int op_upload_tables(const double tri13_scaled[13][3]) {
+  MA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_op_tri13), tri13_scaled, sizeof(double) * 39));
+  return MA_OK;
+}
+
+#define MA_INV4PI 0.07957747154594767280
+
+// One (i, j) pair with the un-subdivided 13-point rule: returns the Burton–Miller coefficient exactly as
+// tbem_far_kernel forms it (same operation order), so that "dense A x" and "on-the-fly A x" differ by
+// summation order only.
+__device__ __forceinline__ dc pair_coeff_13(double d0x, double d0y, double d0z, double e1x, double e1y, double e1z, double e2x, double e2y,
+                                            double e2z, double nyx, double nyy, double nyz, double nxx, double nxy, double nxz, double jw,
+                                            int fbc, const BemPhys& ph, double k, double k2) {
+  const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+  double g_re = 0, g_im = 0, h_re = 0, h_im = 0, t_re = 0, t_im = 0, e_re = 0, e_im = 0;
+#pragma unroll
+  for (int q = 0; q < 13; ++q) {
+    const double xi = c_op_tri13[q][0], eta = c_op_tri13[q][1], w4pi = c_op_tri13[q][2] * jw;
+    const double dx = __builtin_fma(eta, e2x, __builtin_fma(xi, e1x, d0x));
+    const double dy = __builtin_fma(eta, e2y, __builtin_fma(xi, e1y, d0y));
+    const double dz = __builtin_fma(eta, e2z, __builtin_fma(xi, e1z, d0z));
+    const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+    if (!(r2 >= 1e-30)) continue;
+    double r, ri; sqrt_rsqrt(r2, r, ri);
+    double sn, cs; sincos_fast(k * r, sn, cs);
+    const double gsc = w4pi * ri;
+    const double gre = cs * gsc, gim = sn * gsc;
+    const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
+    const double a = (dx * nyx + dy * nyy + dz * nyz) * ri;
+    const double b = -((dx * nxx + dy * nxy + dz * nxz) * ri);
+    const double rq = a * b, ri2 = ri * ri;
+    const double fr = (3.0 * ri2 - k2) * rq + m * ri2;
+    const double fi = -(k * ri) * (3.0 * rq + m);
+    g_re += gre; g_im += gim;
+    h_re = __builtin_fma(bre, a, h_re); h_im = __builtin_fma(bim, a, h_im);
+    t_re = __builtin_fma(bre, b, t_re); t_im = __builtin_fma(bim, b, t_im);
+    e_re += gre * fr - gim * fi; e_im += gre * fi + gim * fr;
+  }
+  const double gt = ph.gamma * ph.tau;
+  if (fbc == 0) {
+    const double hr = h_re * ph.sign, hi = h_im * ph.sign;
+    return dc_make(hr * gt + (e_re * ph.beta_re - e_im * ph.beta_im), hi * gt + (e_re * ph.beta_im + e_im * ph.beta_re));
+  } else if (fbc == 1) {
+    return dc_make(-(g_re * gt + (t_re * ph.beta_re - t_im * ph.beta_im)), -(g_im * gt + (t_re * ph.beta_im + t_im * ph.beta_re)));
+  }
+  return dc_make(0.0, 0.0);
+}
+
+// grid.x: strips of 256 rows in [row0, row1); grid.y: column chunks. partial[chunk][i - row0] = sum_j A13_ij x_j
+__global__ __launch_bounds__(256) void tbem_matvec_kernel(BemGeom g, BemPhys ph, int row0, int row1, int chunk_cols, const dc* __restrict__ x,
+                                                          dc* __restrict__ partial) {
+  const int i = row0 + blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < row1;
+  const int ii = valid ? i : row1 - 1;
+  const double cx = g.c[0][ii], cy = g.c[1][ii], cz = g.c[2][ii];
+  const double nxx = g.nx[0][ii], nxy = g.nx[1][ii], nxz = g.nx[2][ii];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  const int j0 = blockIdx.y * chunk_cols, j1 = min(j0 + chunk_cols, g.np);
+  double yr = 0.0, yi = 0.0;
+  for (int j = j0; j < j1; ++j) {
+    // wave-uniform field panel (scalar loads) and its x entry; x is indexed by the panel's dof
+    const double p0x = g.p0[0][j], p0y = g.p0[1][j], p0z = g.p0[2][j];
+    const dc xj = x[g.dof[j]];
+    const dc a = pair_coeff_13(p0x - cx, p0y - cy, p0z - cz, g.e1[0][j], g.e1[1][j], g.e1[2][j], g.e2[0][j], g.e2[1][j], g.e2[2][j],
+                               g.ny[0][j], g.ny[1][j], g.ny[2][j], nxx, nxy, nxz, g.jac[j] * MA_INV4PI, g.bc_type[j], ph, k, k2);
+    yr += a.re * xj.re - a.im * xj.im; yi += a.re * xj.im + a.im * xj.re;
+  }
+  if (valid) partial[(size_t)blockIdx.y * (row1 - row0) + (i - row0)] = dc_make(yr, yi);
+}
+
+// 13-point coefficient of listed pairs (to form corrections A_true - A_13): out[q] for pairs[q] = (i, j)
+__global__ __launch_bounds__(256) void tbem_pairs13_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs, long long npairs, dc* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npairs) return;
+  const int i = pairs[q].x, j = pairs[q].y;
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  out[q] = pair_coeff_13(g.p0[0][j] - g.c[0][i], g.p0[1][j] - g.c[1][i], g.p0[2][j] - g.c[2][i], g.e1[0][j], g.e1[1][j], g.e1[2][j],
+                         g.e2[0][j], g.e2[1][j], g.e2[2][j], g.ny[0][j], g.ny[1][j], g.ny[2][j], g.nx[0][i], g.nx[1][i], g.nx[2][i],
+                         g.jac[j] * MA_INV4PI, g.bc_type[j], ph, k, k2);
+}
+
+// y[dof_i] = sum_chunks partial[c][i] + diag_corr[i] x[dof_i] + sum_{near pairs of row i} corr[q] x[dof_j]
+// pair_off[i]..pair_off[i+1] delimit row i's pairs (the plan's list is sorted by row).
+__global__ __launch_bounds__(256) void tbem_matvec_finish_kernel(BemGeom g, int row0, int row1, int nchunks, const dc* __restrict__ partial,
+                                                                const long long* __restrict__ pair_off, const int2* __restrict__ pairs,
+                                                                const dc* __restrict__ corr, const dc* __restrict__ diag_corr,
+                                                                const dc* __restrict__ x, dc* __restrict__ y) {
+  const int i = row0 + blockIdx.x * 256 + threadIdx.x;
+  if (i >= row1) return;
+  const int nr = row1 - row0;
+  double yr = 0.0, yi = 0.0;
+  for (int c = 0; c < nchunks; ++c) { const dc p = partial[(size_t)c * nr + (i - row0)]; yr += p.re; yi += p.im; }
+  { const dc d = diag_corr[i], xv = x[g.dof[i]]; yr += d.re * xv.re - d.im * xv.im; yi += d.re * xv.im + d.im * xv.re; }
+  for (long long q = pair_off[i]; q < pair_off[i + 1]; ++q) {
+    const dc a = corr[q], xv = x[g.dof[pairs[q].y]];
+    yr += a.re * xv.re - a.im * xv.im; yi += a.re * xv.im + a.im * xv.re;
+  }
+  y[g.dof[i]] = dc_make(yr, yi);
+}
+
+// corr[q] = A_true[q] - A_13[q] in place (A_true arrives in `corr`, A_13 in `a13`)
+__global__ __launch_bounds__(256) void sub_inplace_kernel(long long n, dc* __restrict__ corr, const dc* __restrict__ a13) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  corr[q] = dc_make(corr[q].re - a13[q].re, corr[q].im - a13[q].im);
+}
+
+// ------------------------------------------------------------------ launchers
+int op_launch_zgemv(long long n, const c64* A, const c64* x, c64* y, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(zgemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(A), reinterpret_cast<const dc*>(x),
+                     reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st) {
+  int nb = (int)((n + 255) / 256); if (nb > RED_BLOCKS) nb = RED_BLOCKS; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, n, reinterpret_cast<const dc*>(x), reinterpret_cast<const dc*>(y), mode,
+                     reinterpret_cast<dc*>(partial));
+  hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, nb, reinterpret_cast<const dc*>(partial), mode, reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_axpy_dev(long long n, const c64* alpha_dev, double sgn, const c64* x, c64* y, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(alpha_dev), sgn, 0.0, 0.0,
+                     reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_axpy_host(long long n, double are, double aim, const c64* x, c64* y, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const dc*)nullptr, 1.0, are, aim,
+                     reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_axpby(long long n, double are, double aim, const c64* x, double bre, double bim, const c64* y, c64* out, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, are, aim, reinterpret_cast<const dc*>(x), bre, bim,
+                     reinterpret_cast<const dc*>(y), reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_tbem_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,
+                          const long long* pair_off, const int2* pairs, const c64* corr, const c64* diag_corr, c64* y, hipStream_t st) {
+  const int nr = row1 - row0;
+  if (nr <= 0) return MA_OK;
+  const int chunk_cols = (g.np + nchunks - 1) / nchunks;
+  dim3 grid((nr + 255) / 256, nchunks), block(256);
+  hipLaunchKernelGGL(tbem_matvec_kernel, grid, block, 0, st, g, ph, row0, row1, chunk_cols, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
+  hipLaunchKernelGGL(tbem_matvec_finish_kernel, dim3((nr + 255) / 256), block, 0, st, g, row0, row1, nchunks, reinterpret_cast<const dc*>(partial),
+                     pair_off, pairs, reinterpret_cast<const dc*>(corr), reinterpret_cast<const dc*>(diag_corr), reinterpret_cast<const dc*>(x),
+                     reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_pairs13(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st) {
+  if (npairs <= 0) return MA_OK;
+  hipLaunchKernelGGL(tbem_pairs13_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_sub_inplace(long long n, c64* corr, const c64* a13, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(sub_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<dc*>(corr), reinterpret_cast<const dc*>(a13));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+}  // namespace ma

@@ -1,0 +1,19 @@
+// op_kernels.hpp — launchers of the operator-apply and BLAS-1 kernels.
+#pragma once
+#include "bem_kernels.hpp"
+
+namespace ma {
+
+int op_upload_tables(const double tri13_scaled[13][3]);
+int op_launch_zgemv(long long n, const c64* A, const c64* x, c64* y, hipStream_t st);
+// mode 0: out = conj(x).y ; mode 1: out = ||x||_2 (real part)
+int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st);
+int op_launch_axpy_dev(long long n, const c64* alpha_dev, double sgn, const c64* x, c64* y, hipStream_t st);
+int op_launch_axpy_host(long long n, double are, double aim, const c64* x, c64* y, hipStream_t st);
+int op_launch_axpby(long long n, double are, double aim, const c64* x, double bre, double bim, const c64* y, c64* out, hipStream_t st);
+int op_launch_tbem_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,
+                          const long long* pair_off, const int2* pairs, const c64* corr, const c64* diag_corr, c64* y, hipStream_t st);
+int op_launch_pairs13(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st);
+int op_launch_sub_inplace(long long n, c64* corr, const c64* a13, hipStream_t st);
+
+}  // namespace ma

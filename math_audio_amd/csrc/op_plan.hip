@@ -1,0 +1,275 @@
+// op_plan.hip — the operator boundary (LinearOperator<Complex64>, math-solvers/src/traits.rs:316-327) and
+// restarted GMRES (math-solvers/src/iterative/gmres.rs:105-277) on the device.
+#include "op_kernels.hpp"
+#include "ma_tables.h"
+#include <vector>
+#include <complex>
+#include <new>
+#include <cmath>
+
+using namespace ma;
+typedef std::complex<double> cplx;
+
+struct ma_csr;   // csr_plan.hip
+extern "C" int ma_csr_spmv_dev(ma_csr* h, const void* d_x, void* d_y, void* stream);
+extern "C" int ma_csr_num_rows(const ma_csr* h, int64_t* n, int64_t* nnz);
+
+struct ma_op {
+  int kind = 0;                 // 0 dense, 1 csr, 2 on-the-fly TBEM
+  int device = 0;
+  long long n = 0;
+  c64* dA = nullptr; bool own_A = false;
+  ma_csr* csr = nullptr;
+  // TBEM
+  ma_bem_plan* plan = nullptr; BemPhys ph{}; int row0 = 0, row1 = 0, nchunks = 1;
+  c64* d_corr = nullptr; c64* d_diag = nullptr; c64* d_partial = nullptr;
+  // staging for the host-buffer entry points
+  c64* d_x = nullptr; c64* d_y = nullptr;
+};
+
+namespace {
+void op_free(ma_op* o) {
+  if (o->own_A && o->dA) (void)hipFree(o->dA);
+  void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y};
+  for (void* q : p) if (q) (void)hipFree(q);
+}
+int op_stage(ma_op* o) {
+  MA_HIP(hipMalloc(&o->d_x, sizeof(c64) * (size_t)o->n));
+  MA_HIP(hipMalloc(&o->d_y, sizeof(c64) * (size_t)o->n));
+  return MA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// DenseOperator::new(matrix) (math-bem/src/core/solver/fmm_interface.rs:25-53): A is n x n row-major on the host
+int ma_op_create_dense(int64_t n, const ma_c64* A, int device, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(n > 0 && A, MA_ERR_INVALID, "bad argument");
+  int rc = use_device(device); if (rc) return rc;
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 0; o->device = device; o->n = n; o->own_A = true;
+  hipError_t e = hipMalloc(&o->dA, sizeof(c64) * (size_t)n * (size_t)n);
+  if (e == hipSuccess) e = hipMemcpy(o->dA, A, sizeof(c64) * (size_t)n * (size_t)n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("dense operator upload failed: %s", hipGetErrorString(e)); op_free(o); delete o; return MA_ERR_NOMEM; }
+  rc = op_stage(o); if (rc) { op_free(o); delete o; return rc; }
+  *out = o; return MA_OK;
+}
+// dense operator over a matrix that already lives in HBM (borrowed; e.g. the output of ma_bem_plan_assemble_dev)
+int ma_op_create_dense_dev(int64_t n, const void* d_A, int device, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(n > 0 && d_A, MA_ERR_INVALID, "bad argument");
+  int rc = use_device(device); if (rc) return rc;
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 0; o->device = device; o->n = n; o->dA = (c64*)d_A; o->own_A = false;
+  rc = op_stage(o); if (rc) { op_free(o); delete o; return rc; }
+  *out = o; return MA_OK;
+}
+// impl LinearOperator for CsrMatrix (csr.rs:420-440); the CSR handle is borrowed
+int ma_op_create_csr(ma_csr_t* csr, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(csr, MA_ERR_INVALID, "csr is NULL");
+  int64_t n = 0, nnz = 0;
+  int rc = ma_csr_num_rows(csr, &n, &nnz); if (rc) return rc;
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 1; o->n = n; o->csr = csr;
+  int dev = 0; MA_HIP(hipGetDevice(&dev)); o->device = dev;
+  rc = op_stage(o); if (rc) { op_free(o); delete o; return rc; }
+  *out = o; return MA_OK;
+}
+// Matrix-free TBEM operator (new, must equal A x of the dense TBEM matrix): rows [row0, row1) of
+// y = A x are produced (the whole operator for row0 = 0, row1 = num_dofs; a row block per GPU when sharded).
+// The plan is borrowed and must outlive the operator.
+int ma_op_create_tbem(ma_bem_plan_t* P, const ma_physics_t* physics, double beta_re, double beta_im, int32_t row0, int32_t row1, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(P, MA_ERR_INVALID, "plan is NULL");
+  MA_REQUIRE(row0 >= 0 && row1 <= P->np && row0 < row1, MA_ERR_INVALID, "row range [%d,%d) outside 0..%d", row0, row1, P->np);
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  int rc = ma_bem_make_phys(P, physics, beta_re, beta_im, &o->ph);
+  if (rc) { delete o; return rc; }
+  o->kind = 2; o->device = P->device; o->n = P->nd; o->plan = P; o->row0 = row0; o->row1 = row1;
+  MA_HIP(hipSetDevice(P->device));
+  // enough (row strip, column chunk) workgroups to fill 256 CUs several times over
+  const int strips = (row1 - row0 + 255) / 256;
+  int nch = (2048 + strips - 1) / strips; if (nch < 1) nch = 1; if (nch > 64) nch = 64; if (nch > P->np) nch = P->np;
+  o->nchunks = nch;
+  hipError_t e = hipMalloc(&o->d_corr, sizeof(c64) * (size_t)(P->npairs > 0 ? P->npairs : 1));
+  if (e == hipSuccess) e = hipMalloc(&o->d_diag, sizeof(c64) * (size_t)P->np);
+  if (e == hipSuccess) e = hipMalloc(&o->d_partial, sizeof(c64) * (size_t)nch * (size_t)(row1 - row0));
+  c64* tmp = nullptr;
+  if (e == hipSuccess) e = hipMalloc(&tmp, sizeof(c64) * (size_t)((P->npairs > P->np ? P->npairs : P->np) + 1));
+  int2* dpairs_diag = nullptr;
+  if (e == hipSuccess) e = hipMalloc(&dpairs_diag, sizeof(int2) * (size_t)P->np);
+  if (e != hipSuccess) { set_error("operator workspace allocation failed: %s", hipGetErrorString(e)); if (tmp) (void)hipFree(tmp); if (dpairs_diag) (void)hipFree(dpairs_diag); op_free(o); delete o; return MA_ERR_NOMEM; }
+  double t13[13][3];
+  for (int q = 0; q < 13; ++q) { t13[q][0] = mat_tri13[q][0]; t13[q][1] = mat_tri13[q][1]; t13[q][2] = mat_tri13[q][2] * 0.5; }
+  rc = op_upload_tables(t13);
+  // corrections: true coefficient (K2 / K3 kernels) minus the 13-point coefficient the streaming kernel will add
+  if (!rc) rc = bem_launch_near_list_values(P->geom, o->ph, P->d_pairs, P->npairs, o->d_corr, nullptr);
+  if (!rc) rc = op_launch_pairs13(P->geom, o->ph, P->d_pairs, P->npairs, tmp, nullptr);
+  if (!rc) rc = op_launch_sub_inplace(P->npairs, o->d_corr, tmp, nullptr);
+  if (!rc) rc = bem_launch_self_list_values(P->geom, o->ph, o->d_diag, nullptr);
+  if (!rc) {
+    std::vector<int2> hp((size_t)P->np);
+    for (int i = 0; i < P->np; ++i) hp[i] = make_int2(i, i);
+    e = hipMemcpy(dpairs_diag, hp.data(), sizeof(int2) * (size_t)P->np, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; }
+  }
+  if (!rc) rc = op_launch_pairs13(P->geom, o->ph, dpairs_diag, P->np, tmp, nullptr);
+  if (!rc) rc = op_launch_sub_inplace(P->np, o->d_diag, tmp, nullptr);
+  if (!rc) { e = hipDeviceSynchronize(); if (e != hipSuccess) { set_error("correction kernels failed: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; } }
+  (void)hipFree(tmp); (void)hipFree(dpairs_diag);
+  if (!rc) rc = op_stage(o);
+  if (rc) { op_free(o); delete o; return rc; }
+  *out = o; return MA_OK;
+}
+
+int ma_op_destroy(ma_op_t* o) {
+  if (!o) return MA_OK;
+  (void)hipSetDevice(o->device);
+  op_free(o);
+  delete o;
+  return MA_OK;
+}
+int ma_op_num_rows(const ma_op_t* o, int64_t* n) {
+  MA_REQUIRE(o && n, MA_ERR_INVALID, "NULL argument");
+  *n = o->n; return MA_OK;
+}
+
+// LinearOperator::apply: y = A x, device pointers
+int ma_op_apply_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) {
+  MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(o->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (o->kind == 0) return op_launch_zgemv(o->n, o->dA, (const c64*)d_x, (c64*)d_y, st);
+  if (o->kind == 1) return ma_csr_spmv_dev(o->csr, d_x, d_y, stream);
+  return op_launch_tbem_matvec(o->plan->geom, o->ph, o->row0, o->row1, o->nchunks, (const c64*)d_x, o->d_partial, o->plan->d_pair_off,
+                               o->plan->d_pairs, o->d_corr, o->d_diag, (c64*)d_y, st);
+}
+// host buffers (apply(&self, x: &Array1<T>) -> Array1<T>, traits.rs:324)
+int ma_op_apply(ma_op_t* o, const ma_c64* x, ma_c64* y) {
+  MA_REQUIRE(o && x && y, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(o->device));
+  MA_HIP(hipMemcpy(o->d_x, x, sizeof(c64) * (size_t)o->n, hipMemcpyHostToDevice));
+  if (o->kind == 2 && (o->row0 != 0 || o->row1 != o->plan->np)) MA_HIP(hipMemset(o->d_y, 0, sizeof(c64) * (size_t)o->n));
+  int rc = ma_op_apply_dev(o, o->d_x, o->d_y, nullptr);
+  if (rc) return rc;
+  MA_HIP(hipMemcpy(y, o->d_y, sizeof(c64) * (size_t)o->n, hipMemcpyDeviceToHost));
+  return MA_OK;
+}
+
+// ------------------------------------------------------------------ GMRES(m), gmres.rs:105-277
+// b, x0 (may be NULL), x_out: host vectors of n entries. info = {iterations, restarts, converged, residual}.
+// Non-convergence is not an error (gmres.rs:270-276): the flag is returned with MA_OK.
+int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t restart, int32_t max_iterations, double tol,
+             ma_c64* x_out, ma_gmres_info_t* info) {
+  MA_REQUIRE(o && b_host && x_out && info, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(restart >= 1 && max_iterations >= 0, MA_ERR_INVALID, "restart must be >= 1");
+  MA_HIP(hipSetDevice(o->device));
+  const long long n = o->n; const int m = restart;
+  hipStream_t st = nullptr;
+  c64 *V = nullptr, *w = nullptr, *x = nullptr, *b = nullptr, *scal = nullptr, *partial = nullptr;
+  auto cleanup = [&]() { void* p[] = {V, w, x, b, scal, partial}; for (void* q : p) if (q) (void)hipFree(q); };
+#define GM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return MA_ERR_HIP; } } while (0)
+#define GM_RC(call) do { int rc_ = (call); if (rc_) { cleanup(); return rc_; } } while (0)
+  GM_HIP(hipMalloc(&V, sizeof(c64) * (size_t)n * (size_t)(m + 1)));
+  GM_HIP(hipMalloc(&w, sizeof(c64) * (size_t)n));
+  GM_HIP(hipMalloc(&x, sizeof(c64) * (size_t)n));
+  GM_HIP(hipMalloc(&b, sizeof(c64) * (size_t)n));
+  GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 4)));
+  GM_HIP(hipMalloc(&partial, sizeof(c64) * 256));
+  GM_HIP(hipMemcpy(b, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
+  if (x0_host) GM_HIP(hipMemcpy(x, x0_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
+  else GM_HIP(hipMemset(x, 0, sizeof(c64) * (size_t)n));
+  auto norm_of = [&](const c64* v, double* out) -> int {
+    int rc = op_launch_dot(n, v, nullptr, 1, partial, scal, st); if (rc) return rc;
+    c64 h; MA_HIP(hipMemcpy(&h, scal, sizeof(c64), hipMemcpyDeviceToHost)); *out = h.re; return MA_OK;
+  };
+  double b_norm = 0.0;
+  GM_RC(norm_of(b, &b_norm));
+  info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
+  if (b_norm < 1e-15) { GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost)); cleanup(); return MA_OK; }
+
+  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2);
+  auto Hh = [&](int i, int j) -> cplx& { return H[(size_t)i * m + j]; };
+  auto givens = [](cplx a, cplx bb, cplx* c, cplx* s) {
+    if (std::abs(bb) < 1e-30) { *c = 1.0; *s = 0.0; return; }
+    if (std::abs(a) < 1e-30) { *c = 0.0; *s = 1.0; return; }
+    const double r = std::sqrt(std::norm(a) + std::norm(bb));
+    *c = a * (1.0 / r); *s = bb * (1.0 / r);
+  };
+  auto solve_upper = [&](int k) {
+    for (int i = k - 1; i >= 0; --i) {
+      cplx sum = g[i];
+      for (int q = i + 1; q < k; ++q) sum -= Hh(i, q) * y[q];
+      y[i] = std::abs(Hh(i, i)) > 1e-30 ? sum * (1.0 / Hh(i, i)) : cplx(0.0, 0.0);
+    }
+  };
+  auto update_x = [&](int k) -> int {
+    for (int i = 0; i < k; ++i) { int rc = op_launch_axpy_host(n, y[i].real(), y[i].imag(), V + (size_t)i * n, x, st); if (rc) return rc; }
+    return MA_OK;
+  };
+  int total = 0, restarts = 0; bool done = false;
+  for (int outer = 0; outer < max_iterations && !done; ++outer) {
+    GM_RC(ma_op_apply_dev(o, x, w, st));
+    GM_RC(op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, w, V, st));          // r = b - A x into v[0]
+    double beta = 0.0; GM_RC(norm_of(V, &beta));
+    double rel = beta / b_norm;
+    if (rel < tol) { info->iterations = total; info->restarts = restarts; info->residual = rel; info->converged = 1; done = true; break; }
+    GM_RC(op_launch_axpby(n, 1.0 / beta, 0.0, V, 0.0, 0.0, nullptr, V, st));
+    std::fill(H.begin(), H.end(), cplx(0.0, 0.0)); std::fill(g.begin(), g.end(), cplx(0.0, 0.0));
+    g[0] = beta;
+    bool inner_conv = false, finished = false;
+    for (int j = 0; j < m; ++j) {
+      total += 1;
+      GM_RC(ma_op_apply_dev(o, V + (size_t)j * n, w, st));
+      for (int i = 0; i <= j; ++i) {                                        // modified Gram-Schmidt, scalars stay on the device
+        GM_RC(op_launch_dot(n, V + (size_t)i * n, w, 0, partial, scal + 1 + i, st));
+        GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, V + (size_t)i * n, w, st));
+      }
+      GM_RC(op_launch_dot(n, w, nullptr, 1, partial, scal + 2 + j, st));
+      GM_HIP(hipMemcpy(hcol.data(), scal + 1, sizeof(c64) * (size_t)(j + 2), hipMemcpyDeviceToHost));   // one sync per inner step
+      for (int i = 0; i <= j; ++i) Hh(i, j) = hcol[i];
+      const double wn = hcol[j + 1].real();
+      Hh(j + 1, j) = wn;
+      if (wn < 1e-14) inner_conv = true;
+      else GM_RC(op_launch_axpby(n, 1.0 + (1.0 / wn - 1.0), 0.0, w, 0.0, 0.0, nullptr, V + (size_t)(j + 1) * n, st));   // w + (1/|w| - 1) w
+      for (int i = 0; i < j; ++i) {
+        const cplx t = std::conj(cs[i]) * Hh(i, j) + std::conj(sn[i]) * Hh(i + 1, j);
+        Hh(i + 1, j) = cplx(0.0, 0.0) - sn[i] * Hh(i, j) + cs[i] * Hh(i + 1, j);
+        Hh(i, j) = t;
+      }
+      cplx c, s; givens(Hh(j, j), Hh(j + 1, j), &c, &s);
+      cs[j] = c; sn[j] = s;
+      Hh(j, j) = std::conj(c) * Hh(j, j) + std::conj(s) * Hh(j + 1, j);
+      Hh(j + 1, j) = 0.0;
+      const cplx t = std::conj(c) * g[j] + std::conj(s) * g[j + 1];
+      g[j + 1] = cplx(0.0, 0.0) - s * g[j] + c * g[j + 1];
+      g[j] = t;
+      rel = std::abs(g[j + 1]) / b_norm;
+      if (rel < tol || inner_conv) {
+        solve_upper(j + 1);
+        GM_RC(update_x(j + 1));
+        info->iterations = total; info->restarts = restarts; info->residual = rel; info->converged = 1;
+        finished = true; done = true; break;
+      }
+    }
+    if (finished) break;
+    solve_upper(m);
+    GM_RC(update_x(m));
+    restarts += 1;
+  }
+  if (!done) {
+    GM_RC(ma_op_apply_dev(o, x, w, st));
+    GM_RC(op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, w, w, st));
+    double rn = 0.0; GM_RC(norm_of(w, &rn));
+    info->iterations = total; info->restarts = restarts; info->residual = rn / b_norm; info->converged = 0;
+  }
+  GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost));
+  cleanup();
+#undef GM_HIP
+#undef GM_RC
+  return MA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""GPU parity of the operator boundary (dense, CSR, matrix-free TBEM) and of device GMRES(m) against the
+CPU oracle. gmres.rs:632-705 known answers; the matrix-free operator must equal A x of the dense TBEM
+matrix."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from math_audio_amd import fem
+from helpers import to_ma_mesh, k_from_ka, RADIUS, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dense_and_csr_operators_apply(gpu):
+    rng = np.random.default_rng(2)
+    n = 333
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)); x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    op = ma.LinearOperator.dense(A)
+    assert np.abs(op.apply(x) - A @ x).max() <= 1e-13 * np.abs(A @ x).max()
+    op.close()
+    nodes, rp, ci, K, M = fem.helmholtz_box(7, 6, 5)
+    c = ma.CsrOperator(rp, ci, K=K, M=M); c.set_wavenumber(1.8 + 0.01j)
+    op = ma.LinearOperator.csr(c)
+    xx = np.sin(0.1 * np.arange(op.n)) + 1j * np.cos(0.2 * np.arange(op.n))
+    ref = O.csr_matvec(rp, ci, O.helmholtz_values(K, M, 1.8 + 0.01j), xx)
+    assert np.abs(op.apply(xx) - ref).max() <= 1e-13 * np.abs(ref).max()
+    op.close(); c.close()
+
+
+@pytest.mark.parametrize("sub,ka", [(1, 0.2), (2, 1.0), (2, 3.0)])
+def test_matrix_free_tbem_equals_dense_matvec(gpu, sub, ka):
+    om = O.icosphere(RADIUS, sub)
+    k = k_from_ka(ka); beta, _ = O.beta_adaptive(k, RADIUS)
+    mesh = to_ma_mesh(om)
+    A, _ = ma.assemble_tbem(mesh, k, beta)
+    A_ref, _ = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    plan = ma.BemPlan(mesh)
+    op = ma.LinearOperator.tbem(plan, k, beta)
+    i = np.arange(om.n_elem)
+    x = np.sin(0.1 * i) + 1j * np.cos(0.2 * i)                     # tests/test_fmm_validation.rs:121
+    y = op.apply(x)
+    assert np.abs(y - A @ x).max() <= 1e-12 * np.abs(A @ x).max()   # same entries, different summation order
+    assert np.abs(y - A_ref @ x).max() <= 1e-9 * np.abs(A_ref @ x).max()
+    # row-block form (one block per GPU when sharded): the blocks tile the product
+    n = om.n_elem; h = n // 3
+    parts = np.zeros(n, dtype=complex)
+    for r0, r1 in ((0, h), (h, 2 * h), (2 * h, n)):
+        blk = ma.LinearOperator.tbem(plan, k, beta, rows=(r0, r1))
+        parts[r0:r1] = blk.apply(x)[r0:r1]
+        blk.close()
+    assert np.array_equal(parts, y)
+    op.close(); plan.close()
+
+
+def test_gmres_known_answers(gpu):                                  # gmres.rs:632-705
+    A = np.array([[4.0, 1.0], [1.0, 3.0]], dtype=complex); b = np.array([1.0, 2.0], dtype=complex)
+    op = ma.LinearOperator.dense(A)
+    x, info = ma.gmres(op, b, restart=10, max_iterations=10, tol=1e-10)
+    assert info.converged == 1 and np.abs(A @ x - b).max() < 1e-8
+    x, info = ma.gmres(op, np.zeros(2, dtype=complex))
+    assert info.converged == 1 and info.iterations == 0 and np.all(x == 0)
+    x, info = ma.gmres(op, b, x0=np.linalg.solve(A, b), tol=1e-8)
+    assert info.converged == 1 and info.iterations == 0            # the guess already satisfies the tolerance
+    op.close()
+    I = ma.LinearOperator.dense(np.eye(5, dtype=complex))
+    x, info = ma.gmres(I, np.arange(1, 6).astype(complex), tol=1e-12)
+    assert info.converged == 1 and np.abs(x - np.arange(1, 6)).max() < 1e-10
+    I.close()
+
+
+def test_gmres_matches_oracle_on_bem_system(gpu):
+    """qa_suite-style system (icosphere 2, ka = 1): same iteration count and solution as the CPU restatement,
+    with the dense, and with the matrix-free operator; GMRES and LU agree."""
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+    A, r0 = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    b = r0 + O.compute_rhs_with_beta(om.center, om.normal, k, beta)
+    x_ref, info_ref = O.gmres(b, dense=A, restart=50, max_iterations=20, tol=1e-6)
+    assert info_ref.converged == 1
+    op = ma.LinearOperator.dense(A)
+    x, info = ma.gmres(op, b, restart=50, max_iterations=20, tol=1e-6)
+    assert info.converged == 1 and info.iterations == info_ref.iterations and info.restarts == info_ref.restarts
+    assert rel_l2(x, x_ref) <= 1e-9
+    op.close()
+    plan = ma.BemPlan(to_ma_mesh(om))
+    mf = ma.LinearOperator.tbem(plan, k, beta)
+    x2, info2 = ma.gmres(mf, b, restart=50, max_iterations=20, tol=1e-6)
+    assert info2.converged == 1 and info2.iterations == info_ref.iterations
+    assert rel_l2(x2, x_ref) <= 1e-7
+    x_lu, _, rc = O.zgesv(A, b)
+    assert rc == 0 and rel_l2(x2, x_lu) <= 1e-4                     # GMRES tolerance 1e-6 on the residual
+    mf.close(); plan.close()
+
+
+def test_gmres_restarts_and_nonconvergence_flag(gpu):
+    rng = np.random.default_rng(9)
+    n = 120
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) + 3.0 * np.eye(n); b = rng.standard_normal(n) + 0j
+    op = ma.LinearOperator.dense(A)
+    x_ref, info_ref = O.gmres(b, dense=A, restart=10, max_iterations=3, tol=1e-12)
+    x, info = ma.gmres(op, b, restart=10, max_iterations=3, tol=1e-12)
+    assert info.converged == info_ref.converged == 0                # not an error, a flag (gmres.rs:270-276)
+    assert info.iterations == info_ref.iterations == 30 and info.restarts == info_ref.restarts == 3
+    assert rel_l2(x, x_ref) <= 1e-8 and abs(info.residual - info_ref.residual) <= 1e-8 * info_ref.residual
+    op.close()
