@@ -188,6 +188,19 @@ int ma_gmres(ma_op_t* op, const ma_c64* b, const ma_c64* x0, int32_t restart, in
              ma_c64* x_out, ma_gmres_info_t* info);
 
 /* ------------------------------------------------------------------------------------------
+ * Field evaluation and the room-acoustics collocation matrix (the O(M N) / O(N^2) loops either side of the solve).
+ * Replaces: compute_scattered_field(eval_points, elements, nodes, surface_pressure, surface_velocity, physics)
+ *           math-bem/src/core/postprocess/pressure.rs:81-137 (7-point rule per element, :154-258); surface values are
+ *           one per boundary element in plan order; surface_velocity may be NULL.
+ *           build_bem_matrix_parallel(mesh, k)   math-bem/src/room_acoustics/solver.rs:448-493, from the element
+ *           centres, normals and areas of element_center_and_normal / element_area (:38-122).
+ * ------------------------------------------------------------------------------------------ */
+int ma_bem_plan_scattered_field(ma_bem_plan_t* plan, const ma_physics_t* physics, int32_t n_eval, const double* eval_points,
+                                const ma_c64* surface_pressure, const ma_c64* surface_velocity, ma_c64* out);
+int ma_room_build_matrix(int32_t n, const double* center, const double* normal, const double* area, double k, ma_c64* A_rowmajor);
+int ma_room_build_matrix_dev(int32_t n, const void* d_center, const void* d_normal, const void* d_area, double k, void* d_A, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Parity-test hooks (no counterpart in the reference API): raw panel integrals computed by the
  * device kernels, comparable to IntegrationResult of regular_integration / singular_integration
  * (math-bem/src/core/integration/regular.rs:33, singular.rs:123; types.rs:722-734).

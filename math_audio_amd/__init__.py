@@ -101,6 +101,9 @@ def lib():
             "ma_op_apply": [vp, vp, vp],
             "ma_op_apply_dev": [vp, vp, vp, vp],
             "ma_gmres": [vp, vp, vp, i32, i32, dbl, vp, vp],
+            "ma_bem_plan_scattered_field": [vp, P(ma_physics_t), i32, vp, vp, vp, vp],
+            "ma_room_build_matrix": [i32, vp, vp, vp, dbl, vp],
+            "ma_room_build_matrix_dev": [i32, vp, vp, vp, dbl, vp, vp],
             "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
             "ma_probe_mfma_f64": [C.c_int, P(dbl)],
         }
@@ -431,3 +434,24 @@ def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
     info = GmresInfo()
     check(lib().ma_gmres(op.h, _vp(b), _vp(x0a), restart, max_iterations, float(tol), _vp(x), C.byref(info)))
     return x, info
+
+
+def scattered_field(plan, k, eval_points, surface_pressure, surface_velocity=None, harmonic=1.0, tau=1.0):
+    """compute_scattered_field (postprocess/pressure.rs:81-137) on the device."""
+    ep = np.ascontiguousarray(eval_points, dtype=np.float64)
+    ps = np.ascontiguousarray(surface_pressure, dtype=np.complex128)
+    vs = None if surface_velocity is None else np.ascontiguousarray(surface_velocity, dtype=np.complex128)
+    out = np.empty(ep.shape[0], dtype=np.complex128)
+    ph = physics(k, harmonic, tau)
+    check(lib().ma_bem_plan_scattered_field(plan.h, C.byref(ph), ep.shape[0], _vp(ep), _vp(ps), _vp(vs), _vp(out)))
+    return out
+
+
+def room_build_matrix(center, normal, area, k):
+    """build_bem_matrix_parallel (room_acoustics/solver.rs:448-493) on the device."""
+    c = np.ascontiguousarray(center, dtype=np.float64); nr = np.ascontiguousarray(normal, dtype=np.float64)
+    a = np.ascontiguousarray(area, dtype=np.float64)
+    n = len(a)
+    A = np.empty((n, n), dtype=np.complex128)
+    check(lib().ma_room_build_matrix(n, _vp(c), _vp(nr), _vp(a), float(k), _vp(A)))
+    return A

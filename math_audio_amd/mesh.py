@@ -112,6 +112,40 @@ def generate_icosphere_mesh(radius, subdivisions):
     return _finish(nodes, conn)
 
 
+def generate_box_mesh(lx, ly, lz, nx, ny, nz):
+    """Closed box centred at the origin, faces gridded nx x ny x nz cells, every quad split into two Tri3 with
+    outward winding (the synthetic cabinet of BASELINE.json configs[4]; face gridding as RectangularRoom::
+    generate_mesh, math-xem-common/src/geometry.rs:107-183): 4 (nx ny + nx nz + ny nz) panels."""
+    xs = [-lx / 2.0 + lx * float(i) / float(nx) for i in range(nx + 1)]
+    ys = [-ly / 2.0 + ly * float(j) / float(ny) for j in range(ny + 1)]
+    zs = [-lz / 2.0 + lz * float(k) / float(nz) for k in range(nz + 1)]
+    index = {}
+    nodes = []
+
+    def nid(i, j, k):
+        key = (i, j, k)
+        if key not in index:
+            index[key] = len(nodes); nodes.append([xs[i], ys[j], zs[k]])
+        return index[key]
+    conn = []
+
+    def quad(a, b, c, d):          # a-b-c-d counter-clockwise seen from outside
+        conn.append([a, b, c, -1]); conn.append([a, c, d, -1])
+    for i in range(nx):
+        for j in range(ny):
+            quad(nid(i, j, 0), nid(i, j + 1, 0), nid(i + 1, j + 1, 0), nid(i + 1, j, 0))                      # z = -lz/2 (normal -z)
+            quad(nid(i, j, nz), nid(i + 1, j, nz), nid(i + 1, j + 1, nz), nid(i, j + 1, nz))                  # z = +lz/2
+    for i in range(nx):
+        for k in range(nz):
+            quad(nid(i, 0, k), nid(i + 1, 0, k), nid(i + 1, 0, k + 1), nid(i, 0, k + 1))                      # y = -ly/2
+            quad(nid(i, ny, k), nid(i, ny, k + 1), nid(i + 1, ny, k + 1), nid(i + 1, ny, k))                  # y = +ly/2
+    for j in range(ny):
+        for k in range(nz):
+            quad(nid(0, j, k), nid(0, j, k + 1), nid(0, j + 1, k + 1), nid(0, j + 1, k))                      # x = -lx/2
+            quad(nid(nx, j, k), nid(nx, j + 1, k), nid(nx, j + 1, k + 1), nid(nx, j, k + 1))                  # x = +lx/2
+    return _finish(nodes, conn)
+
+
 # ---------------------------------------------------------------- physics (types.rs:39-219)
 def wave_number(frequency, speed_of_sound=343.0):
     omega = 2.0 * math.pi * frequency
