@@ -171,8 +171,8 @@ def main():
     ap.add_argument("--n-phi", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "1")),
-                    help="frequencies in flight per GPU (each slot owns a matrix, an LU workspace and a stream)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "2")),
+                    help="frequencies in flight per GPU (systems factored as one interleaved batch, 1..4)")
     args = ap.parse_args()
     if args.workload == "fem":
         return fem_workload(args)
@@ -198,63 +198,51 @@ def main():
     mesh = mm.generate_sphere_mesh(RADIUS, args.n_theta, args.n_phi)
     n = mesh.n_elem
     freqs = mm.log_space(100.0, 8000.0, 64)
-    # Frequencies are independent, and 288 GB of HBM holds many 1.6 GB systems: S slots keep S
-    # frequencies in flight on S streams, so one frequency's latency-bound panel factorisation
-    # (one chip-wide gather per column) runs underneath another's MFMA-bound trailing update.
-    S = max(1, min(args.slots, args.steps))
-
-    class Slot:
-        def __init__(self):
-            self.plan = ma.BemPlan(mesh, device=local_rank)
-            self.lu = ma.LuPlan(n, device=local_rank)
-            self.A = torch.empty(n * n, dtype=torch.complex128, device=dev)
-            self.x = torch.empty(n, dtype=torch.complex128, device=dev)
-            self.tstream = torch.cuda.Stream(device=dev)
-            self.stream = self.tstream.cuda_stream
-            self.busy = False
-
-    slots = [Slot() for _ in range(S)]
+    # Frequencies are independent, and 288 GB of HBM holds many 1.6 GB systems: S systems are kept in flight and
+    # factored as ONE interleaved batch, so one frequency's latency-bound panel factorisation (one chip-wide
+    # gather per column) runs underneath another's MFMA-bound trailing update. A step is still one frequency.
+    S = max(1, min(args.slots, args.steps, 4))
+    plan = ma.BemPlan(mesh, device=local_rank)
+    lu = ma.LuPlan(n, device=local_rank)
+    As = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
+    xs_ = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
+    stream = torch.cuda.current_stream().cuda_stream
     asm_ms = np.zeros(3); lu_ms = np.zeros(8)
     timing = False
 
-    def retire(sl):
-        """Wait for the slot's frequency and collect its per-kernel HIP-event timings."""
-        if not sl.busy:
-            return
+    def batch(first_step, count):
+        """`count` (<= S) consecutive frequencies: assemble each, then one interleaved factor+solve."""
+        for i in range(count):
+            f = freqs[(rank + (first_step + i) * world) % len(freqs)]
+            k = mm.wave_number(f, C_SOUND)
+            beta = mm.burton_miller_beta_scaled(k, 4.0)
+            plan.assemble_dev(k, beta, As[i].data_ptr(), xs_[i].data_ptr(), stream=stream)
+            plan.incident_rhs_dev(k, beta, xs_[i].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
+            if timing:
+                asm_ms[:] += plan.last_timing()
+        lu.factor_solve_batch_dev([a.data_ptr() for a in As[:count]], [v.data_ptr() for v in xs_[:count]], 1, stream=stream)
         if timing:
-            asm_ms[:] += sl.plan.last_timing(); lu_ms[:] += sl.lu.last_timing()
-        sl.busy = False
+            lu_ms[:] += lu.last_timing()
 
-    def step(s):
-        sl = slots[s % S]
-        retire(sl)
-        f = freqs[(rank + s * world) % len(freqs)]
-        k = mm.wave_number(f, C_SOUND)
-        beta = mm.burton_miller_beta_scaled(k, 4.0)
-        sl.plan.assemble_dev(k, beta, sl.A.data_ptr(), sl.x.data_ptr(), stream=sl.stream)
-        sl.plan.incident_rhs_dev(k, beta, sl.x.data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=sl.stream)
-        sl.lu.factor_solve_dev(sl.A.data_ptr(), sl.x.data_ptr(), 1, stream=sl.stream)
-        sl.busy = True
+    def run(first, nsteps):
+        s = 0
+        while s < nsteps:
+            c = min(S, nsteps - s)
+            batch(first + s, c)
+            s += c
 
-    for s in range(args.warmup):
-        step(s)
+    run(0, args.warmup)
     torch.cuda.synchronize()
-    for sl in slots:
-        sl.busy = False
-        if sl.lu.status(sl.stream) != ma.MA_OK:
-            raise SystemExit("warm-up solve failed: %s" % ma.lib().ma_last_error_string().decode())
+    if lu.status(stream) != ma.MA_OK:
+        raise SystemExit("warm-up solve failed: %s" % ma.lib().ma_last_error_string().decode())
 
     timing = not args.no_timing
-    for sl in slots:
-        sl.plan.set_timing(timing); sl.lu.set_timing(timing)
+    plan.set_timing(timing); lu.set_timing(timing)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(args.warmup + s)
-    for sl in slots:
-        retire(sl)
+    run(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -264,11 +252,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    for sl in slots:
-        if sl.lu.status(sl.stream) != ma.MA_OK:
-            raise SystemExit("solve failed: %s" % ma.lib().ma_last_error_string().decode())
-        xs = sl.x.cpu().numpy()
-        if not np.all(np.isfinite(xs.view(np.float64))):
+    if lu.status(stream) != ma.MA_OK:
+        raise SystemExit("solve failed: %s" % ma.lib().ma_last_error_string().decode())
+    for v in xs_:
+        if not np.all(np.isfinite(v.cpu().numpy().view(np.float64))):
             raise SystemExit("non-finite solution")
 
     if rank == 0:

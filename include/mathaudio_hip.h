@@ -128,6 +128,11 @@ int ma_lu_plan_destroy(ma_lu_plan_t* plan);
  * d_B[nrhs][n] (each contiguous). Asynchronous on `stream`; the singularity flag is reported by
  * ma_lu_plan_status(), which synchronises the stream. */
 int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_t nrhs, void* stream);
+/* The same for nmat (1..4) independent systems of size n kept in flight together (d_As[m], d_Bs[m] device
+ * pointers): the panels of the systems are interleaved on the plan's panel stream so that one system's
+ * latency-bound panel chain runs underneath another's trailing updates. Results per system are
+ * bit-identical to separate ma_lu_plan_factor_solve_dev calls. */
+int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* const* d_As, void* const* d_Bs, int32_t nrhs, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
 
 /* ------------------------------------------------------------------------------------------

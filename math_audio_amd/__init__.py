@@ -76,6 +76,7 @@ def lib():
             "ma_lu_plan_create": [i32, C.c_int, P(vp)],
             "ma_lu_plan_destroy": [vp],
             "ma_lu_plan_factor_solve_dev": [vp, vp, vp, i32, vp],
+            "ma_lu_plan_factor_solve_batch_dev": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],
@@ -274,6 +275,12 @@ class LuPlan:
 
     def factor_solve_dev(self, d_A, d_B, nrhs=1, stream=0):
         check(lib().ma_lu_plan_factor_solve_dev(self.h, C.c_void_p(d_A), C.c_void_p(d_B), nrhs, C.c_void_p(stream)))
+
+    def factor_solve_batch_dev(self, d_As, d_Bs, nrhs=1, stream=0):
+        """Interleaved factor+solve of len(d_As) independent systems (device pointers)."""
+        m = len(d_As)
+        pa = (C.c_void_p * m)(*[C.c_void_p(p) for p in d_As]); pb = (C.c_void_p * m)(*[C.c_void_p(p) for p in d_Bs])
+        check(lib().ma_lu_plan_factor_solve_batch_dev(self.h, m, pa, pb, nrhs, C.c_void_p(stream)))
 
     def status(self, stream=0):
         return lib().ma_lu_plan_status(self.h, C.c_void_p(stream))

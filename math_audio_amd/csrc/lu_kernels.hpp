@@ -3,6 +3,7 @@
 #include "ma_common.hpp"
 
 #define LU_NB_MAX 128
+#define LU_BATCH_MAX 4
 
 namespace ma {
 

@@ -13,9 +13,13 @@ struct ma_lu_plan {
   int ncu = 256;
   void* ws_block = nullptr;       // one allocation: sync words | info | cand | candrow | diagrow | lists | ipiv
   LuPanelWs pws{};
-  int* d_lists = nullptr;
-  int* d_ipiv = nullptr;
-  c64* d_tmp = nullptr;           // 2*NB rows x (n + nrhs_max) for the row interchanges
+  // per system of a batch: pivots, the folded interchange lists, and 2*NB rows x (n + nrhs_max) staging for the interchanges
+  int* d_lists[LU_BATCH_MAX] = {};
+  int* d_ipiv[LU_BATCH_MAX] = {};
+  c64* d_tmp[LU_BATCH_MAX] = {};
+  int last_batch = 1;
+  hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {};
+  int ensure_batch(int nmat);
   int nrhs_max = 4;
   bool timing = false;
   std::vector<hipEvent_t> ev;     // event pool for per-phase timing
@@ -26,7 +30,6 @@ struct ma_lu_plan {
   int n_gemm_launch = 0;
   bool ev_valid = false;
   hipStream_t panel_stream = nullptr;   // high-priority stream for the look-ahead panel
-  hipEvent_t sync_ev[3] = {nullptr, nullptr, nullptr};
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
   int want_nb = LU_NB_MAX;
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
@@ -56,6 +59,16 @@ void panel_shape(int R, int ncu, int want_nb, int rpb_cap, int* nb_out, int* rpb
 
 }  // namespace
 
+int ma_lu_plan::ensure_batch(int nmat) {
+  for (int m = 0; m < nmat; ++m) {
+    if (d_tmp[m]) continue;
+    MA_HIP(hipMalloc(&d_tmp[m], sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + nrhs_max)));
+    MA_HIP(hipMalloc(&d_ipiv[m], sizeof(int) * (size_t)n));
+    MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * (1 + 4 * LU_NB_MAX)));
+  }
+  return MA_OK;
+}
+
 extern "C" {
 
 int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
@@ -74,27 +87,26 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   const int mb = ncu;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_sync = take(16), o_info = take(16), o_cand = take(sizeof(unsigned long long) * 2 * mb * 2),
+  const size_t o_sync = take(16), o_info = take(64), o_cand = take(sizeof(unsigned long long) * 2 * mb * 2),
                o_crow = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX), o_drow = take(sizeof(unsigned long long) * (2 * 2 * LU_NB_MAX + 16)),
                o_lists = take(sizeof(int) * (1 + 4 * LU_NB_MAX)), o_ipiv = take(sizeof(int) * (size_t)n);
+  (void)o_lists; (void)o_ipiv;
   hipError_t e = hipMalloc(&P->ws_block, off);
-  if (e == hipSuccess) e = hipMalloc(&P->d_tmp, sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + P->nrhs_max));
   if (e != hipSuccess) {
     set_error("hipMalloc of the LU workspace failed: %s", hipGetErrorString(e));
     if (P->ws_block) (void)hipFree(P->ws_block);
     delete P;
     return MA_ERR_NOMEM;
   }
+  if ((rc = P->ensure_batch(1))) { (void)hipFree(P->ws_block); delete P; return rc; }
   char* base = (char*)P->ws_block;
   P->pws.counter = (unsigned*)(base + o_sync);
   P->pws.info = (int*)(base + o_info);
-  P->pws.timeout = (unsigned*)(P->pws.info + 1);     // persists over the factorisation, like info
+  P->pws.timeout = (unsigned*)(P->pws.info + LU_BATCH_MAX);   // persists over the factorisation, like info
   P->pws.cand = (unsigned long long*)(base + o_cand);
   P->pws.candrow = (unsigned long long*)(base + o_crow);
   P->pws.diagrow = (unsigned long long*)(base + o_drow);
   P->pws.max_blocks = mb;
-  P->d_lists = (int*)(base + o_lists);
-  P->d_ipiv = (int*)(base + o_ipiv);
   rc = lu_panel_configure();
   if (!rc) rc = lu_trsm_configure();
   if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v == 16 || v == 32 || v == 64 || v == 128) P->want_nb = v; }
@@ -105,10 +117,12 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     int lo = 0, hi = 0;
     hipError_t e4 = hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (e4 == hipSuccess) e4 = hipStreamCreateWithPriority(&P->panel_stream, hipStreamNonBlocking, hi);
-    for (int i = 0; i < 3 && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->sync_ev[i], hipEventDisableTiming);
+    if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&P->ev_start, hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_panel[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_narrow[i], hipEventDisableTiming);
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
   }
-  if (rc) { (void)hipFree(P->ws_block); (void)hipFree(P->d_tmp); delete P; return rc; }
+  if (rc) { ma_lu_plan_destroy(P); return rc; }
   *out = P;
   return MA_OK;
 }
@@ -117,9 +131,10 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (!P) return MA_OK;
   (void)hipSetDevice(P->device);
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
-  for (int i = 0; i < 3; ++i) if (P->sync_ev[i]) (void)hipEventDestroy(P->sync_ev[i]);
+  if (P->ev_start) (void)hipEventDestroy(P->ev_start);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]); }
   if (P->panel_stream) (void)hipStreamDestroy(P->panel_stream);
-  if (P->d_tmp) (void)hipFree(P->d_tmp);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
   return MA_OK;
@@ -146,28 +161,26 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 }
 #define MA_MARK(var, stream) int var; if ((rc = mark(P, (stream), &var))) return rc
 
-// Factor d_A in place and solve for nrhs right-hand sides (d_B[nrhs][n]); everything asynchronous.
+// Factor the matrices in place and solve for nrhs right-hand sides each (d_B[nrhs][n]); everything asynchronous.
 //
 // Right-looking blocked LU with one panel of look-ahead: as soon as the columns of panel q+1 have
 // received panel q's update (a narrow zgemm), panel q+1 is factored on the plan's own high-priority
 // stream while the rest of panel q's trailing update runs on the caller's stream. The panel
 // workgroups are latency-bound (one chip-wide gather per column) and sized to share a CU with a
-// zgemm workgroup (LDS 95 KB + 64 KB), so the matrix cores stay busy underneath them.
-int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrhs, void* stream) {
-  MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
-  MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
-  MA_REQUIRE(nrhs == 0 || dB, MA_ERR_INVALID, "d_B is NULL");
-  MA_HIP(hipSetDevice(P->device));
-  hipStream_t st = (hipStream_t)stream;
+// zgemm workgroup (LDS 91 KB + 48 KB), so the matrix cores stay busy underneath them.
+//
+// A batch of independent systems of the same size (frequencies of a sweep) is interleaved panel by
+// panel: the panel stream runs P(A,q+1), P(B,q+1) back to back (never two panel kernels at once)
+// while the caller's stream runs the trailing updates of A and B, so each system's latency-bound
+// chain hides under the other's throughput-bound work.
+static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* const* Bs, int32_t nrhs, hipStream_t st) {
   hipStream_t sp = P->lookahead ? P->panel_stream : st;
   const int n = P->n;
-  c64* A = (c64*)dA; c64* B = (c64*)dB;
   int rc;
-  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->ev_valid = false;
-  MA_HIP(hipMemsetAsync(P->pws.info, 0, 16, st));
+  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->ev_valid = false; P->last_batch = nmat;
+  MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
   MA_MARK(e_begin, st);
 
-  // panel schedule
   std::vector<int> k0s, nbs, rpbs, nblks;
   for (int k0 = 0; k0 < n;) {
     int nb, rpb, nblk;
@@ -176,46 +189,63 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrh
     k0 += nb;
   }
   const int Q = (int)k0s.size();
-  auto panel = [&](int q) -> int {
+  auto panel = [&](int m, int q) -> int {
+    LuPanelWs ws = P->pws;
+    ws.info = P->pws.info + m;                                // per-system first-zero-pivot word
     MA_MARK(a, sp);
-    if ((rc = lu_launch_panel(A, n, k0s[q], nbs[q], rpbs[q], nblks[q], P->ncu, P->pws, P->d_ipiv, sp))) return rc;
+    if ((rc = lu_launch_panel(As[m], n, k0s[q], nbs[q], rpbs[q], nblks[q], P->ncu, ws, P->d_ipiv[m], sp))) return rc;
     MA_MARK(b, sp);
     interval(P, a, b, 0);
+    if (sp != st) MA_HIP(hipEventRecord(P->ev_panel[m], sp));
     return MA_OK;
   };
-  if (sp != st) { MA_HIP(hipEventRecord(P->sync_ev[0], st)); MA_HIP(hipStreamWaitEvent(sp, P->sync_ev[0], 0)); }
-  if ((rc = panel(0))) return rc;
+  if (sp != st) { MA_HIP(hipEventRecord(P->ev_start, st)); MA_HIP(hipStreamWaitEvent(sp, P->ev_start, 0)); }
+  for (int m = 0; m < nmat; ++m) if ((rc = panel(m, 0))) return rc;
   for (int q = 0; q < Q; ++q) {
     const int k0 = k0s[q], nb = nbs[q];
     const int nright = n - k0 - nb;
-    if (sp != st) { MA_HIP(hipEventRecord(P->sync_ev[1], sp)); MA_HIP(hipStreamWaitEvent(st, P->sync_ev[1], 0)); }
-    MA_MARK(t0, st);
-    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv, P->d_lists, P->d_tmp, B, nrhs, st))) return rc;
-    MA_MARK(t1, st);
-    interval(P, t0, t1, 1);
-    const c64* T = A + (size_t)k0 * n + k0;
-    if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
-    MA_MARK(t2, st);
-    interval(P, t1, t2, 2);
-    // forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b, b[below] -= L21 b[k0:k0+nb]
-    if (nrhs > 0) {
-      if ((rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
-      for (int r = 0; r < nrhs && nright > 0; ++r)
-        if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
+    const int nnext = (q + 1 < Q) ? nbs[q + 1] : 0;
+    for (int m = 0; m < nmat; ++m) {
+      c64* A = As[m]; c64* B = Bs ? Bs[m] : nullptr;
+      if (sp != st) MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
+      MA_MARK(t0, st);
+      if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists[m], P->d_tmp[m], B, nrhs, st))) return rc;
+      MA_MARK(t1, st);
+      interval(P, t0, t1, 1);
+      const c64* T = A + (size_t)k0 * n + k0;
+      if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
+      MA_MARK(t2, st);
+      interval(P, t1, t2, 2);
+      // forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b, b[below] -= L21 b[k0:k0+nb]
+      if (nrhs > 0) {
+        if ((rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
+        for (int r = 0; r < nrhs && nright > 0; ++r)
+          if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
+      }
+      MA_MARK(t3, st);
+      interval(P, t2, t3, 4);
+      if (nright > 0 && nnext > 0) {
+        const c64* L21 = A + (size_t)(k0 + nb) * n + k0;
+        const c64* U12 = A + (size_t)k0 * n + k0 + nb;
+        c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
+        if (sp != st) {
+          // narrow update of the next panel's columns first, then factor it concurrently with the rest
+          if ((rc = lu_launch_zgemm_sub(nright, nnext, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
+          P->n_gemm_launch++;
+          MA_HIP(hipEventRecord(P->ev_narrow[m], st)); MA_HIP(hipStreamWaitEvent(sp, P->ev_narrow[m], 0));
+          if ((rc = panel(m, q + 1))) return rc;
+        }
+      }
+      MA_MARK(t4, st);
+      interval(P, t3, t4, 3);
     }
-    MA_MARK(t3, st);
-    interval(P, t2, t3, 4);
-    if (nright > 0) {
+    for (int m = 0; m < nmat && nright > 0; ++m) {
+      c64* A = As[m];
       const c64* L21 = A + (size_t)(k0 + nb) * n + k0;
       const c64* U12 = A + (size_t)k0 * n + k0 + nb;
       c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
-      const int nnext = (q + 1 < Q) ? nbs[q + 1] : 0;
-      if (sp != st && nnext > 0) {
-        // narrow update of the next panel's columns first, then factor it concurrently with the rest
-        if ((rc = lu_launch_zgemm_sub(nright, nnext, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
-        P->n_gemm_launch++;
-        MA_HIP(hipEventRecord(P->sync_ev[2], st)); MA_HIP(hipStreamWaitEvent(sp, P->sync_ev[2], 0));
-        if ((rc = panel(q + 1))) return rc;
+      MA_MARK(t5, st);
+      if (sp != st) {
         if (nright - nnext > 0) {
           if ((rc = lu_launch_zgemm_sub(nright, nright - nnext, nb, L21, (size_t)n, U12 + nnext, (size_t)n, A22 + nnext, (size_t)n, st, P->use_3m))) return rc;
           P->n_gemm_launch++;
@@ -223,28 +253,58 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrh
       } else {
         if ((rc = lu_launch_zgemm_sub(nright, nright, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
         P->n_gemm_launch++;
-        if (q + 1 < Q && (rc = panel(q + 1))) return rc;
+        if (q + 1 < Q && (rc = panel(m, q + 1))) return rc;
       }
+      MA_MARK(t6, st);
+      interval(P, t5, t6, 3);
     }
-    MA_MARK(t4, st);
-    interval(P, t3, t4, 3);
   }
   // backward substitution U x = y, block rows from the bottom
-  MA_MARK(t5, st);
+  MA_MARK(t7, st);
   if (nrhs > 0) {
-    for (int q = Q - 1; q >= 0; --q) {
-      const int k0 = k0s[q], nb = nbs[q];
-      if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
-      for (int r = 0; r < nrhs && k0 > 0; ++r)
-        if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
+    for (int m = 0; m < nmat; ++m) {
+      c64* A = As[m]; c64* B = Bs[m];
+      for (int q = Q - 1; q >= 0; --q) {
+        const int k0 = k0s[q], nb = nbs[q];
+        if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
+        for (int r = 0; r < nrhs && k0 > 0; ++r)
+          if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
+      }
     }
   }
   MA_MARK(e_end, st);
-  interval(P, t5, e_end, 4);
+  interval(P, t7, e_end, 4);
   interval(P, e_begin, e_end, 6);
   P->ev_last = e_end;
   if (P->timing) P->ev_valid = true;
   return MA_OK;
+}
+
+int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrhs, void* stream) {
+  MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
+  MA_REQUIRE(nrhs == 0 || dB, MA_ERR_INVALID, "d_B is NULL");
+  MA_HIP(hipSetDevice(P->device));
+  c64* A = (c64*)dA; c64* B = (c64*)dB;
+  return factor_solve_batch(P, 1, &A, &B, nrhs, (hipStream_t)stream);
+}
+
+// nmat (1..MA_LU_BATCH_MAX) independent n x n systems, e.g. the frequencies of a sweep kept in flight together.
+int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* P, int32_t nmat, void* const* dAs, void* const* dBs, int32_t nrhs, void* stream) {
+  MA_REQUIRE(P && dAs, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(nmat >= 1 && nmat <= LU_BATCH_MAX, MA_ERR_INVALID, "batch must be 1..%d systems", LU_BATCH_MAX);
+  MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
+  MA_REQUIRE(nrhs == 0 || dBs, MA_ERR_INVALID, "d_Bs is NULL");
+  c64* As[LU_BATCH_MAX]; c64* Bs[LU_BATCH_MAX];
+  for (int m = 0; m < nmat; ++m) {
+    MA_REQUIRE(dAs[m] && (nrhs == 0 || dBs[m]), MA_ERR_INVALID, "system %d has a NULL pointer", m);
+    As[m] = (c64*)dAs[m]; Bs[m] = nrhs ? (c64*)dBs[m] : nullptr;
+    for (int o = 0; o < m; ++o) MA_REQUIRE(As[o] != As[m], MA_ERR_INVALID, "systems %d and %d alias", o, m);
+  }
+  MA_HIP(hipSetDevice(P->device));
+  int rc = P->ensure_batch(nmat);
+  if (rc) return rc;
+  return factor_solve_batch(P, nmat, As, Bs, nrhs, (hipStream_t)stream);
 }
 
 int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
@@ -252,10 +312,11 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (P->panel_stream) MA_HIP(hipStreamSynchronize(P->panel_stream));
-  int info[2] = {0, 0};
+  int info[16];
   MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
-  MA_REQUIRE(info[1] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
-  MA_REQUIRE(info[0] == 0, MA_ERR_SINGULAR, "matrix is singular: zero pivot at column %d", info[0] - 1);
+  MA_REQUIRE(info[LU_BATCH_MAX] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
+  for (int m = 0; m < P->last_batch; ++m)
+    MA_REQUIRE(info[m] == 0, MA_ERR_SINGULAR, "system %d is singular: zero pivot at column %d", m, info[m] - 1);
   return MA_OK;
 }
 
@@ -304,7 +365,7 @@ int ma_zgesv(int32_t n, ma_c64* A, ma_c64* b, int32_t* ipiv) {
     // the factors are returned in either case (LAPACK leaves them in A); x only when non-singular
     hipError_t e2 = hipMemcpy(A, dA, nn * nn * sizeof(c64), hipMemcpyDeviceToHost);
     if (e2 == hipSuccess && !rc) e2 = hipMemcpy(b, db, nn * sizeof(c64), hipMemcpyDeviceToHost);
-    if (e2 == hipSuccess && ipiv) e2 = hipMemcpy(ipiv, P->d_ipiv, nn * sizeof(int), hipMemcpyDeviceToHost);
+    if (e2 == hipSuccess && ipiv) e2 = hipMemcpy(ipiv, P->d_ipiv[0], nn * sizeof(int), hipMemcpyDeviceToHost);
     if (e2 != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e2)); rc = MA_ERR_HIP; }
   }
   (void)hipFree(dA); (void)hipFree(db);
