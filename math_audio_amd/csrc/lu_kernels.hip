@@ -577,13 +577,14 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
 // Same contract as zgemm_sub_kernel with three real products per complex product:
 //   T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi);  Re = T1 - T2,  Im = T3 - T1 - T2.
 // 25 % fewer matrix-core instructions than the 4-product form; normwise (not componentwise)
-// backward stable, which is what the LU update needs. Workgroup tile 128 x 64, 8 wavefronts as
-// 4 (M) x 2 (N), 32 x 32 per wavefront = 2 x 2 MFMA tiles x 3 accumulators. The sums Ar+Ai and
-// Br+Bi are formed once per fragment load.
-#define Z3_BM 128
+// backward stable, which is what the LU update needs. Workgroup tile 64 x 64, 4 wavefronts as
+// 2 (M) x 2 (N), 32 x 32 per wavefront = 2 x 2 MFMA tiles x 3 accumulators. Two or three such workgroups
+// share a CU (165 VGPRs, 32 KB LDS each), so that one's C read-modify-write epilogue runs under the
+// others' MFMA loops (with one 128 x 64 workgroup per CU the epilogue cost 22 % of the kernel); the sums Ar+Ai and Br+Bi are formed once per fragment load.
+#define Z3_BM 64
 #define Z3_BN 64
 
-__global__ __launch_bounds__(512, 1) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
+__global__ __launch_bounds__(256, 2) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
                                                              const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
   __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
   __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
@@ -598,23 +599,26 @@ __global__ __launch_bounds__(512, 1) void zgemm3m_sub_kernel(int M, int N, int K
 #pragma unroll
     for (int b = 0; b < 2; ++b) { t1[a][b] = (v4d){0, 0, 0, 0}; t2[a][b] = (v4d){0, 0, 0, 0}; t3[a][b] = (v4d){0, 0, 0, 0}; }
 
-  dc ra[2], rb;
+  dc ra[2], rb[2];
   auto load_stage = [&](int k0) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int e = tid + 512 * s;
-      const int row = e >> 3, kk = e & 7;
+      const int e = tid + 256 * s;
+      const int row = e >> 3, kk = e & 7;                       // A: 8 consecutive k of one row = 128 B
       const int gm = m0 + row, gk = k0 + kk;
       ra[s] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : dc_make(0.0, 0.0);
+      const int bk = e >> 6, bn = e & 63;                       // B: 64 consecutive n of one k-row
+      const int gn = n0 + bn, gk2 = k0 + bk;
+      rb[s] = (gn < N && gk2 < K) ? B[(size_t)gk2 * ldb + gn] : dc_make(0.0, 0.0);
     }
-    const int bk = tid >> 6, bn = tid & 63;
-    const int gn = n0 + bn, gk2 = k0 + bk;
-    rb = (gn < N && gk2 < K) ? B[(size_t)gk2 * ldb + gn] : dc_make(0.0, 0.0);
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { const int e = tid + 512 * s; As[buf][e & 7][e >> 3] = ra[s]; }
-    Bs[buf][tid >> 6][tid & 63] = rb;
+    for (int s = 0; s < 2; ++s) {
+      const int e = tid + 256 * s;
+      As[buf][e & 7][e >> 3] = ra[s];
+      Bs[buf][e >> 6][e & 63] = rb[s];
+    }
   };
 
   const int nstage = (K + ZG_BK - 1) / ZG_BK;
@@ -787,7 +791,7 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
   if (use_3m) {
     dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
-    hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(512), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+    hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
                        reinterpret_cast<dc*>(C), ldc);
     MA_HIP(hipGetLastError());
     return MA_OK;

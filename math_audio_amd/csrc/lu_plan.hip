@@ -33,6 +33,7 @@ struct ma_lu_plan {
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
   int want_nb = LU_NB_MAX;
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
+  bool rpb_env = false;           // MA_LU_RPB given
   int rpb_cap = 44;               // rows per panel workgroup: 44 x 129 x 16 B = 91 KB leaves room for a zgemm workgroup on the CU
 };
 
@@ -112,7 +113,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v == 16 || v == 32 || v == 64 || v == 128) P->want_nb = v; }
   if (const char* e0 = getenv("MA_ZGEMM_3M")) P->use_3m = atoi(e0) != 0;
   if (const char* e2 = getenv("MA_LU_LOOKAHEAD")) P->lookahead = atoi(e2) != 0;
-  if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) P->rpb_cap = v; }
+  if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
   if (!rc) {
     int lo = 0, hi = 0;
     hipError_t e4 = hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -184,7 +185,10 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   std::vector<int> k0s, nbs, rpbs, nblks;
   for (int k0 = 0; k0 < n;) {
     int nb, rpb, nblk;
-    panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), P->rpb_cap, &nb, &rpb, &nblk);
+    // a lone system shares its CUs with its own trailing update (44 rows = 91 KB of LDS next to the zgemm
+    // workgroups); in a batch the panel workgroups take whole CUs (64 rows = 132 KB): measured faster
+    const int cap = P->rpb_env ? P->rpb_cap : (nmat >= 2 ? 64 : 44);
+    panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), cap, &nb, &rpb, &nblk);
     k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
     k0 += nb;
   }
