@@ -33,6 +33,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet FP64 matrix (= FP64 vector) peak, dense
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH doubled as the gfx950 guide prescribes). PMC
+    counters cannot be read from inside the timed run; null if no profile has been committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+            if k:
+                best = k["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+    return best
+
+
 def lu_flops(n):
     return (8.0 / 3.0) * n ** 3 + 8.0 * n ** 2          # SURVEY §8(a9): zgetrf + zgetrs, real flops
 
@@ -285,12 +301,13 @@ def main():
                                         "note": "lu_panel runs on the look-ahead stream concurrently with lu_zgemm; lu_zgemm intervals include waiting for it"}
             ach = gf / gemm_t / 1e12
             out["roofline"] = {"kernel": "zgemm_sub_kernel (LU trailing update, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": ach,
-                               "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+                               "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic("ma::zgemm3m_sub_kernel"),
+                               "traffic_note": "bytes per launch from a separate rocprofv3 --pmc pass (profiles/); algorithmic C read+write = %.3g B per launch" % (2.0 * 16.0 * sum((n - k0 - 128) ** 2 for k0 in range(0, n - 128, 128)) / n_gemm * (n_gemm / max(1.0, (n // 128)))),
                                "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
                                "algorithmic_flops_per_step": gf}
             far_t = asm_ms[0] / K * 1e-3
             out["roofline_assembly"] = {"kernel": "tbem_far_kernel", "bound": "hbm", "achieved": 16.0 * n * n / far_t / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                        "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("ma::tbem_far_kernel"),
                                         "note": "16 B written per pair; the kernel is FP64-VALU/transcendental bound (SURVEY §8d): ~1.2 kflop per pair",
                                         "fp64_valu_tflops_equiv": 1.2e3 * n * n / far_t / 1e12}
             try:
