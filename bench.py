@@ -302,7 +302,8 @@ def main():
             ach = gf / gemm_t / 1e12
             out["roofline"] = {"kernel": "zgemm_sub_kernel (LU trailing update, v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": ach,
                                "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic("ma::zgemm3m_sub_kernel"),
-                               "traffic_note": "bytes per launch from a separate rocprofv3 --pmc pass (profiles/); algorithmic C read+write = %.3g B per launch" % (2.0 * 16.0 * sum((n - k0 - 128) ** 2 for k0 in range(0, n - 128, 128)) / n_gemm * (n_gemm / max(1.0, (n // 128)))),
+                               "traffic_note": "HBM-side bytes per launch from a separate rocprofv3 --pmc pass (profiles/); the algorithmic C read+write "
+                                               "is %.3g B per launch on average" % (32.0 * sum((n - k0 - 128) ** 2 for k0 in range(0, n - 128, 128)) / n_gemm),
                                "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
                                "algorithmic_flops_per_step": gf}
             far_t = asm_ms[0] / K * 1e-3
