@@ -454,6 +454,9 @@ __global__ __launch_bounds__(64) void lu_trsv_kernel(const dc* __restrict__ T, i
       }
     }
   } else {
+    // reciprocals of this lane's two diagonal entries up front: the division leaves the dependent chain
+    const dc rd0 = r0 < nb ? crecip(T0[r0]) : dc_make(0.0, 0.0);
+    const dc rd1 = r1 < nb ? crecip(T1[r1]) : dc_make(0.0, 0.0);
     for (int p0 = nb - 1; p0 >= 0; p0 -= 8) {
       dc t0[8], t1[8];
 #pragma unroll
@@ -463,8 +466,8 @@ __global__ __launch_bounds__(64) void lu_trsv_kernel(const dc* __restrict__ T, i
         const int p = p0 - q;
         if (p >= 0) {
           const int src = p & 63;
-          if (r0 == p) v0 = v0 * crecip(t0[q]);               // the owner divides by the diagonal entry first
-          if (r1 == p) v1 = v1 * crecip(t1[q]);
+          if (r0 == p) v0 = v0 * rd0;                         // the owner scales by 1 / u_pp first
+          if (r1 == p) v1 = v1 * rd1;
           const double xr = __shfl(p < 64 ? v0.re : v1.re, src, 64), xi = __shfl(p < 64 ? v0.im : v1.im, src, 64);
           if (r0 < p) { v0.re -= t0[q].re * xr - t0[q].im * xi; v0.im -= t0[q].re * xi + t0[q].im * xr; }
           if (r1 < p && r1 < nb) { v1.re -= t1[q].re * xr - t1[q].im * xi; v1.im -= t1[q].re * xi + t1[q].im * xr; }
