@@ -187,6 +187,21 @@ int ma_op_destroy(ma_op_t* op);
 int ma_op_num_rows(const ma_op_t* op, int64_t* n);
 int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);
 int ma_op_apply_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
+/* Preconditioner boundary: trait Preconditioner<T> { apply(&r) -> z }   math-solvers/src/traits.rs:370-375.
+ * The device preconditioners are the AMG smoothers applied from z = 0 (one level of
+ * AmgPreconditioner::apply, amg.rs:981-1005, 1068-1087): Jacobi(omega, sweeps) or l1-Jacobi(sweeps) on the CSR
+ * handle's current values (after ma_csr_set_wavenumber). The CSR handle is borrowed. */
+typedef struct ma_precond ma_precond_t;
+int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out);
+int ma_precond_create_l1jacobi(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
+int ma_precond_destroy(ma_precond_t* M);
+int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
+int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */
+/* DiagonalPreconditioner::from_csr (preconditioners/diagonal.rs:27-37, 57-75) is jacobi(omega = 1, sweeps = 1). */
+/* gmres_preconditioned(_with_guess)(operator, precond, b, x0, config): left preconditioning, tolerance relative to
+ * ||M^-1 b||   math-solvers/src/iterative/gmres.rs:282-585 */
+int ma_gmres_preconditioned(ma_op_t* op, ma_precond_t* M, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations,
+                            double tol, ma_c64* x_out, ma_gmres_info_t* info);
 /* Restarted GMRES(m), relative tolerance on ||b||; defaults of GmresConfig: restart 30, tol 1e-6, 100 restarts
  * (gmres.rs:27-35). x0 may be NULL. Non-convergence is reported in info->converged, not as an error. */
 int ma_gmres(ma_op_t* op, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol,

@@ -102,6 +102,12 @@ def lib():
             "ma_op_apply": [vp, vp, vp],
             "ma_op_apply_dev": [vp, vp, vp, vp],
             "ma_gmres": [vp, vp, vp, i32, i32, dbl, vp, vp],
+            "ma_precond_create_jacobi": [vp, dbl, i32, P(vp)],
+            "ma_precond_create_l1jacobi": [vp, i32, P(vp)],
+            "ma_precond_destroy": [vp],
+            "ma_precond_apply_dev": [vp, vp, vp, vp],
+            "ma_precond_apply": [vp, vp, vp],
+            "ma_gmres_preconditioned": [vp, vp, vp, vp, i32, i32, dbl, vp, vp],
             "ma_bem_plan_scattered_field": [vp, P(ma_physics_t), i32, vp, vp, vp, vp],
             "ma_room_build_matrix": [i32, vp, vp, vp, dbl, vp],
             "ma_room_build_matrix_dev": [i32, vp, vp, vp, dbl, vp, vp],
@@ -440,6 +446,44 @@ def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
     x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
     info = GmresInfo()
     check(lib().ma_gmres(op.h, _vp(b), _vp(x0a), restart, max_iterations, float(tol), _vp(x), C.byref(info)))
+    return x, info
+
+
+class Preconditioner:
+    """ma_precond_t: the Preconditioner<Complex64> boundary (traits.rs:370-375); Jacobi / l1-Jacobi sweeps from zero."""
+
+    def __init__(self, csr_operator, kind="jacobi", omega=2.0 / 3.0, sweeps=2):
+        self.h = C.c_void_p()
+        self._keep = csr_operator
+        if kind == "jacobi":
+            check(lib().ma_precond_create_jacobi(csr_operator.h, float(omega), int(sweeps), C.byref(self.h)))
+        else:
+            check(lib().ma_precond_create_l1jacobi(csr_operator.h, int(sweeps), C.byref(self.h)))
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.complex128); z = np.empty_like(r)
+        check(lib().ma_precond_apply(self.h, _vp(r), _vp(z)))
+        return z
+
+    def close(self):
+        if self.h:
+            lib().ma_precond_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gmres_preconditioned(op, precond, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
+    """gmres_preconditioned(_with_guess) (gmres.rs:282-585) on the device: returns (x, GmresInfo)."""
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    x = np.empty(op.n, dtype=np.complex128)
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    info = GmresInfo()
+    check(lib().ma_gmres_preconditioned(op.h, precond.h, _vp(b), _vp(x0a), restart, max_iterations, float(tol), _vp(x), C.byref(info)))
     return x, info
 
 

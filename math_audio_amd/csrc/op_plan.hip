@@ -158,18 +158,75 @@ int ma_op_apply(ma_op_t* o, const ma_c64* x, ma_c64* y) {
   return MA_OK;
 }
 
-// ------------------------------------------------------------------ GMRES(m), gmres.rs:105-277
+// ------------------------------------------------------------------ Preconditioner boundary (traits.rs:370-375)
+// apply(r) -> z. The device preconditioners are the one-level smoothers of the AMG V-cycle applied from z = 0
+// (what AmgPreconditioner::apply does on its coarsest level, amg.rs:981-1005): `sweeps` Jacobi (kind 1) or
+// l1-Jacobi (kind 2) sweeps on A z = r with the CSR handle's current values. kind 0 is the identity.
+struct ma_precond {
+  int kind = 0; ma_csr* csr = nullptr; double omega = 2.0 / 3.0; int sweeps = 2; long long n = 0; int device = 0;
+  c64* d_tmp = nullptr;
+};
+
+extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
+extern "C" int ma_csr_l1jacobi_dev(ma_csr* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
+
+int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(csr && sweeps >= 0, MA_ERR_INVALID, "bad argument");
+  int64_t n = 0, nnz = 0; int rc = ma_csr_num_rows(csr, &n, &nnz); if (rc) return rc;
+  ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
+  M->kind = 1; M->csr = csr; M->omega = omega; M->sweeps = sweeps; M->n = n;
+  MA_HIP(hipGetDevice(&M->device));
+  hipError_t e = hipMalloc(&M->d_tmp, sizeof(c64) * (size_t)n);
+  if (e != hipSuccess) { set_error("preconditioner workspace: %s", hipGetErrorString(e)); delete M; return MA_ERR_NOMEM; }
+  *out = M; return MA_OK;
+}
+int ma_precond_create_l1jacobi(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out) {
+  int rc = ma_precond_create_jacobi(csr, 1.0, sweeps, out);
+  if (!rc) (*out)->kind = 2;
+  return rc;
+}
+int ma_precond_destroy(ma_precond_t* M) {
+  if (!M) return MA_OK;
+  if (M->d_tmp) (void)hipFree(M->d_tmp);
+  delete M; return MA_OK;
+}
+// z = M^-1 r on device vectors (z and r distinct)
+int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream) {
+  MA_REQUIRE(M && d_r && d_z, MA_ERR_INVALID, "NULL argument");
+  if (M->kind == 0) { MA_HIP(hipMemcpyAsync(d_z, d_r, sizeof(c64) * (size_t)M->n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return MA_OK; }
+  MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
+  if (M->kind == 1) return ma_csr_jacobi_dev(M->csr, d_z, d_r, M->omega, M->sweeps, M->d_tmp, stream);
+  return ma_csr_l1jacobi_dev(M->csr, d_z, d_r, M->sweeps, M->d_tmp, stream);
+}
+
+// host-buffer convenience form of apply (tests, small systems)
+int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host) {
+  MA_REQUIRE(M && r_host && z_host, MA_ERR_INVALID, "NULL argument");
+  int rc = use_device(M->device); if (rc) return rc;
+  c64 *d_r = nullptr, *d_z = nullptr; size_t bytes = sizeof(c64) * (size_t)M->n;
+  if (hipMalloc(&d_r, bytes) != hipSuccess || hipMalloc(&d_z, bytes) != hipSuccess) { if (d_r) (void)hipFree(d_r); set_error("preconditioner vectors: out of device memory"); return MA_ERR_NOMEM; }
+  rc = MA_OK;
+  if (hipMemcpy(d_r, r_host, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = MA_ERR_HIP;
+  if (!rc) rc = ma_precond_apply_dev(M, d_r, d_z, nullptr);
+  if (!rc && hipMemcpy(z_host, d_z, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = MA_ERR_HIP;
+  (void)hipFree(d_r); (void)hipFree(d_z);
+  return rc;
+}
+
+// ------------------------------------------------------------------ GMRES(m), gmres.rs:105-277 (and :282-585 with a preconditioner)
 // b, x0 (may be NULL), x_out: host vectors of n entries. info = {iterations, restarts, converged, residual}.
 // Non-convergence is not an error (gmres.rs:270-276): the flag is returned with MA_OK.
-int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t restart, int32_t max_iterations, double tol,
-             ma_c64* x_out, ma_gmres_info_t* info) {
+static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const ma_c64* x0_host, int32_t restart, int32_t max_iterations, double tol,
+                      ma_c64* x_out, ma_gmres_info_t* info) {
   MA_REQUIRE(o && b_host && x_out && info, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(!Mp || Mp->n == o->n, MA_ERR_DIM, "preconditioner and operator sizes differ");
   MA_REQUIRE(restart >= 1 && max_iterations >= 0, MA_ERR_INVALID, "restart must be >= 1");
   MA_HIP(hipSetDevice(o->device));
   const long long n = o->n; const int m = restart;
   hipStream_t st = nullptr;
-  c64 *V = nullptr, *w = nullptr, *x = nullptr, *b = nullptr, *scal = nullptr, *partial = nullptr;
-  auto cleanup = [&]() { void* p[] = {V, w, x, b, scal, partial}; for (void* q : p) if (q) (void)hipFree(q); };
+  c64 *V = nullptr, *w = nullptr, *x = nullptr, *b = nullptr, *scal = nullptr, *partial = nullptr, *t = nullptr;
+  auto cleanup = [&]() { void* p[] = {V, w, x, b, scal, partial, t}; for (void* q : p) if (q) (void)hipFree(q); };
 #define GM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return MA_ERR_HIP; } } while (0)
 #define GM_RC(call) do { int rc_ = (call); if (rc_) { cleanup(); return rc_; } } while (0)
   GM_HIP(hipMalloc(&V, sizeof(c64) * (size_t)n * (size_t)(m + 1)));
@@ -178,6 +235,7 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
   GM_HIP(hipMalloc(&b, sizeof(c64) * (size_t)n));
   GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 4)));
   GM_HIP(hipMalloc(&partial, sizeof(c64) * 256));
+  GM_HIP(hipMalloc(&t, sizeof(c64) * (size_t)n));
   GM_HIP(hipMemcpy(b, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
   if (x0_host) GM_HIP(hipMemcpy(x, x0_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
   else GM_HIP(hipMemset(x, 0, sizeof(c64) * (size_t)n));
@@ -185,8 +243,10 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
     int rc = op_launch_dot(n, v, nullptr, 1, partial, scal, st); if (rc) return rc;
     c64 h; MA_HIP(hipMemcpy(&h, scal, sizeof(c64), hipMemcpyDeviceToHost)); *out = h.re; return MA_OK;
   };
+  // left preconditioning measures everything in the M^-1 norm: b_norm = ||M^-1 b|| (gmres.rs:299-300)
   double b_norm = 0.0;
-  GM_RC(norm_of(b, &b_norm));
+  if (Mp) { GM_RC(ma_precond_apply_dev(Mp, b, w, st)); GM_RC(norm_of(w, &b_norm)); }
+  else GM_RC(norm_of(b, &b_norm));
   info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
   if (b_norm < 1e-15) { GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost)); cleanup(); return MA_OK; }
 
@@ -212,7 +272,8 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
   int total = 0, restarts = 0; bool done = false;
   for (int outer = 0; outer < max_iterations && !done; ++outer) {
     GM_RC(ma_op_apply_dev(o, x, w, st));
-    GM_RC(op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, w, V, st));          // r = b - A x into v[0]
+    if (Mp) { GM_RC(op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, w, t, st)); GM_RC(ma_precond_apply_dev(Mp, t, V, st)); }   // r = M^-1 (b - A x)
+    else GM_RC(op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, w, V, st));     // r = b - A x into v[0]
     double beta = 0.0; GM_RC(norm_of(V, &beta));
     double rel = beta / b_norm;
     if (rel < tol) { info->iterations = total; info->restarts = restarts; info->residual = rel; info->converged = 1; done = true; break; }
@@ -222,7 +283,8 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
     bool inner_conv = false, finished = false;
     for (int j = 0; j < m; ++j) {
       total += 1;
-      GM_RC(ma_op_apply_dev(o, V + (size_t)j * n, w, st));
+      if (Mp) { GM_RC(ma_op_apply_dev(o, V + (size_t)j * n, t, st)); GM_RC(ma_precond_apply_dev(Mp, t, w, st)); }   // w = M^-1 A v_j
+      else GM_RC(ma_op_apply_dev(o, V + (size_t)j * n, w, st));
       for (int i = 0; i <= j; ++i) {                                        // modified Gram-Schmidt, scalars stay on the device
         GM_RC(op_launch_dot(n, V + (size_t)i * n, w, 0, partial, scal + 1 + i, st));
         GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, V + (size_t)i * n, w, st));
@@ -233,7 +295,7 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
       const double wn = hcol[j + 1].real();
       Hh(j + 1, j) = wn;
       if (wn < 1e-14) inner_conv = true;
-      else GM_RC(op_launch_axpby(n, 1.0 + (1.0 / wn - 1.0), 0.0, w, 0.0, 0.0, nullptr, V + (size_t)(j + 1) * n, st));   // w + (1/|w| - 1) w
+      else GM_RC(op_launch_axpby(n, Mp ? 1.0 / wn : 1.0 + (1.0 / wn - 1.0), 0.0, w, 0.0, 0.0, nullptr, V + (size_t)(j + 1) * n, st));   // w/|w| (:366) or w + (1/|w| - 1) w (:198-201)
       for (int i = 0; i < j; ++i) {
         const cplx t = std::conj(cs[i]) * Hh(i, j) + std::conj(sn[i]) * Hh(i + 1, j);
         Hh(i + 1, j) = cplx(0.0, 0.0) - sn[i] * Hh(i, j) + cs[i] * Hh(i + 1, j);
@@ -262,6 +324,7 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
   if (!done) {
     GM_RC(ma_op_apply_dev(o, x, w, st));
     GM_RC(op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, w, w, st));
+    if (Mp) { GM_RC(ma_precond_apply_dev(Mp, w, t, st)); GM_HIP(hipMemcpyAsync(w, t, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice, st)); }
     double rn = 0.0; GM_RC(norm_of(w, &rn));
     info->iterations = total; info->restarts = restarts; info->residual = rn / b_norm; info->converged = 0;
   }
@@ -270,6 +333,16 @@ int ma_gmres(ma_op_t* o, const ma_c64* b_host, const ma_c64* x0_host, int32_t re
 #undef GM_HIP
 #undef GM_RC
   return MA_OK;
+}
+
+int ma_gmres(ma_op_t* o, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info) {
+  return gmres_impl(o, nullptr, b, x0, restart, max_iterations, tol, x_out, info);
+}
+// gmres_preconditioned / gmres_preconditioned_with_guess (gmres.rs:282-585)
+int ma_gmres_preconditioned(ma_op_t* o, ma_precond_t* M, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol,
+                            ma_c64* x_out, ma_gmres_info_t* info) {
+  MA_REQUIRE(M, MA_ERR_INVALID, "preconditioner is NULL");
+  return gmres_impl(o, M, b, x0, restart, max_iterations, tol, x_out, info);
 }
 
 }  // extern "C"

@@ -141,6 +141,11 @@ void mao_gmres(int n, int op_kind, const mao_c64* dense, const long long* row_pt
                const mao_c64* val, const mao_c64* b, const mao_c64* x0 /*NULL ok*/, int restart, int max_iterations,
                double tol, mao_c64* x, mao_gmres_info* info);
 
+/* gmres_preconditioned(_with_guess) (gmres.rs:282-585) on a CSR operator with a one-level smoother as the
+ * Preconditioner: pkind 0 identity, 1 Jacobi(omega, sweeps), 2 l1-Jacobi(sweeps), each applied from z = 0. */
+void mao_gmres_preconditioned(int n, const long long* row_ptr, const long long* col, const mao_c64* val, int pkind, double omega, int sweeps,
+                              const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol, mao_c64* x, mao_gmres_info* info);
+
 /* ---- room-acoustics collocation assembly (room_acoustics/solver.rs:448-493) ---- */
 void mao_room_build_matrix(int n_elem, const double* center, const double* normal, const double* area,
                            double k, mao_c64* A, int nthreads);

@@ -416,3 +416,105 @@ void mao_gmres(int n, int kind, const mao_c64* dense, const long long* rp, const
 #undef HH
   free(V); free(H); free(cs); free(sn); free(g); free(w); free(y);
 }
+
+/* ======================================================================
+ * gmres_preconditioned(_with_guess) — iterative/gmres.rs:282-585, left preconditioning, with the
+ * Preconditioner::apply (traits.rs:370-375) of a one-level smoother: z = 0, then `sweeps` Jacobi
+ * (kind 1, amg.rs:855-884) or l1-Jacobi (kind 2, amg.rs:887-929) sweeps on A z = r, i.e. what
+ * AmgPreconditioner::apply does on its coarsest level (amg.rs:981-1005, 1068-1087).
+ * ====================================================================== */
+static void precond_apply(int n, const long long* rp, const long long* col, const mao_c64* val, int kind, double omega, int sweeps,
+                          const mao_c64* r, mao_c64* z) {
+  if (kind == 0) { memcpy(z, r, sizeof(mao_c64) * (size_t)n); return; }
+  memset(z, 0, sizeof(mao_c64) * (size_t)n);
+  if (kind == 1) mao_amg_jacobi(n, rp, col, val, z, r, omega, sweeps, 1);
+  else mao_amg_l1_jacobi(n, rp, col, val, z, r, sweeps, 1);
+}
+
+void mao_gmres_preconditioned(int n, const long long* rp, const long long* col, const mao_c64* val, int pkind, double omega, int sweeps,
+                              const mao_c64* b, const mao_c64* x0, int m, int max_it, double tol, mao_c64* x, mao_gmres_info* info) {
+  if (x0) memcpy(x, x0, sizeof(mao_c64) * (size_t)n); else memset(x, 0, sizeof(mao_c64) * (size_t)n);
+  mao_c64* V = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n * (size_t)(m + 1));
+  mao_c64* H = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)(m + 1) * (size_t)m);
+  mao_c64* cs = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)m);
+  mao_c64* sn = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)m);
+  mao_c64* g = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)(m + 1));
+  mao_c64* w = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+  mao_c64* t = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+  mao_c64* y = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)m);
+  precond_apply(n, rp, col, val, pkind, omega, sweeps, b, w);
+  double bnorm = vnorm(n, w);
+  info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
+  int total = 0, restarts = 0, done = 0;
+  if (bnorm < 1e-15) done = 2;
+#define HH(i, j) H[(size_t)(i) * (size_t)m + (size_t)(j)]
+  for (int outer = 0; outer < max_it && !done; ++outer) {
+    mao_csr_matvec(n, rp, col, val, x, t, 1);
+    for (int i = 0; i < n; ++i) t[i] = csub(b[i], t[i]);
+    mao_c64* r = V;
+    precond_apply(n, rp, col, val, pkind, omega, sweeps, t, r);
+    double beta = vnorm(n, r);
+    double rel = beta / bnorm;
+    if (rel < tol) { info->iterations = total; info->restarts = restarts; info->residual = rel; done = 1; break; }
+    mao_c64 ib = C(1.0 / beta, 0.0);
+    for (int i = 0; i < n; ++i) r[i] = cmul(r[i], ib);
+    memset(H, 0, sizeof(mao_c64) * (size_t)(m + 1) * (size_t)m);
+    memset(g, 0, sizeof(mao_c64) * (size_t)(m + 1));
+    g[0] = C(beta, 0.0);
+    int nv = 1, inner_conv = 0, finished = 0;
+    for (int j = 0; j < m; ++j) {
+      total += 1;
+      mao_csr_matvec(n, rp, col, val, V + (size_t)j * n, t, 1);
+      precond_apply(n, rp, col, val, pkind, omega, sweeps, t, w);
+      for (int i = 0; i <= j; ++i) {
+        HH(i, j) = inner(n, V + (size_t)i * n, w);
+        mao_c64 h = HH(i, j);
+        const mao_c64* vi = V + (size_t)i * n;
+        for (int q = 0; q < n; ++q) w[q] = csub(w[q], cmul(vi[q], h));
+      }
+      double wn = vnorm(n, w);
+      HH(j + 1, j) = C(wn, 0.0);
+      if (wn < 1e-14) inner_conv = 1;
+      else { mao_c64 iw = C(1.0 / wn, 0.0); mao_c64* nvp = V + (size_t)nv * n; for (int q = 0; q < n; ++q) nvp[q] = cmul(w[q], iw); nv += 1; }
+      for (int i = 0; i < j; ++i) {
+        mao_c64 tt = cadd(cmul(cconj(cs[i]), HH(i, j)), cmul(cconj(sn[i]), HH(i + 1, j)));
+        HH(i + 1, j) = cadd(csub(C(0.0, 0.0), cmul(sn[i], HH(i, j))), cmul(cs[i], HH(i + 1, j)));
+        HH(i, j) = tt;
+      }
+      mao_c64 c, s2; givens(HH(j, j), HH(j + 1, j), &c, &s2);
+      cs[j] = c; sn[j] = s2;
+      HH(j, j) = cadd(cmul(cconj(c), HH(j, j)), cmul(cconj(s2), HH(j + 1, j)));
+      HH(j + 1, j) = C(0.0, 0.0);
+      mao_c64 tt = cadd(cmul(cconj(c), g[j]), cmul(cconj(s2), g[j + 1]));
+      g[j + 1] = cadd(csub(C(0.0, 0.0), cmul(s2, g[j])), cmul(c, g[j + 1]));
+      g[j] = tt;
+      rel = cnorm(g[j + 1]) / bnorm;
+      if (rel < tol || inner_conv) {
+        int kk = j + 1;
+        for (int i = kk - 1; i >= 0; --i) {
+          mao_c64 sum = g[i];
+          for (int q = i + 1; q < kk; ++q) sum = csub(sum, cmul(HH(i, q), y[q]));
+          y[i] = cnorm(HH(i, i)) > 1e-30 ? cmul(sum, cinv(HH(i, i))) : C(0.0, 0.0);
+        }
+        for (int i = 0; i < kk; ++i) { const mao_c64* vi = V + (size_t)i * n; for (int q = 0; q < n; ++q) x[q] = cadd(x[q], cmul(vi[q], y[i])); }
+        info->iterations = total; info->restarts = restarts; info->residual = rel; finished = 1; done = 1; break;
+      }
+    }
+    if (finished) break;
+    for (int i = m - 1; i >= 0; --i) {
+      mao_c64 sum = g[i];
+      for (int q = i + 1; q < m; ++q) sum = csub(sum, cmul(HH(i, q), y[q]));
+      y[i] = cnorm(HH(i, i)) > 1e-30 ? cmul(sum, cinv(HH(i, i))) : C(0.0, 0.0);
+    }
+    for (int i = 0; i < m; ++i) { const mao_c64* vi = V + (size_t)i * n; for (int q = 0; q < n; ++q) x[q] = cadd(x[q], cmul(vi[q], y[i])); }
+    restarts += 1;
+  }
+  if (!done) {
+    mao_csr_matvec(n, rp, col, val, x, t, 1);
+    for (int i = 0; i < n; ++i) t[i] = csub(b[i], t[i]);
+    precond_apply(n, rp, col, val, pkind, omega, sweeps, t, w);
+    info->iterations = total; info->restarts = restarts; info->residual = vnorm(n, w) / bnorm; info->converged = 0;
+  }
+#undef HH
+  free(V); free(H); free(cs); free(sn); free(g); free(w); free(t); free(y);
+}

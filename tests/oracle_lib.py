@@ -336,6 +336,18 @@ def gmres(b, dense=None, csr=None, x0=None, restart=30, max_iterations=100, tol=
     return x, info
 
 
+def gmres_preconditioned(b, csr, pkind=1, omega=2.0 / 3.0, sweeps=2, x0=None, restart=30, max_iterations=100, tol=1e-6):
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    n = len(b)
+    x = np.zeros(n, dtype=np.complex128)
+    info = GmresInfo()
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    rp, col, val = _csr_args(*csr)
+    lib().mao_gmres_preconditioned(n, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), pkind, C.c_double(omega), sweeps, _vp(b), _vp(x0a),
+                                   restart, max_iterations, C.c_double(tol), _vp(x), C.byref(info))
+    return x, info
+
+
 def room_build_matrix(center, normal, area, k, nthreads=1):
     center = np.ascontiguousarray(center, dtype=np.float64); normal = np.ascontiguousarray(normal, dtype=np.float64)
     area = np.ascontiguousarray(area, dtype=np.float64)

@@ -103,3 +103,40 @@ def test_gmres_restarts_and_nonconvergence_flag(gpu):
     assert info.iterations == info_ref.iterations == 30 and info.restarts == info_ref.restarts == 3
     assert rel_l2(x, x_ref) <= 1e-8 and abs(info.residual - info_ref.residual) <= 1e-8 * info_ref.residual
     op.close()
+
+
+def test_preconditioned_gmres_matches_oracle_on_fem_system(gpu):
+    """P1 Helmholtz box system with a damped wavenumber: GMRES through the Preconditioner boundary (Jacobi and
+    l1-Jacobi sweeps from zero) vs the CPU restatement of gmres_preconditioned (gmres.rs:282-428)."""
+    nodes, rp, ci, K, M = fem.helmholtz_box(9, 8, 7)
+    n = len(rp) - 1
+    k = 0.3 + 1.5j
+    c = ma.CsrOperator(rp, ci, K=K, M=M); c.set_wavenumber(k)
+    vals = O.helmholtz_values(K, M, k)
+    b = np.cos(0.3 * np.arange(n)) + 0.5j
+    op = ma.LinearOperator.csr(c)
+    its = {}
+    for kind, pk in (("jacobi", 1), ("l1", 2)):
+        pre = ma.Preconditioner(c, kind=kind, omega=0.8, sweeps=2)
+        x_ref, info_ref = O.gmres_preconditioned(b, (rp, ci, vals), pkind=pk, omega=0.8, sweeps=2, restart=30, max_iterations=20, tol=1e-8)
+        x, info = ma.gmres_preconditioned(op, pre, b, restart=30, max_iterations=20, tol=1e-8)
+        assert info_ref.converged == 1 and info.converged == 1
+        assert info.iterations == info_ref.iterations and info.restarts == info_ref.restarts
+        assert rel_l2(x, x_ref) <= 1e-9
+        assert np.linalg.norm(O.csr_matvec(rp, ci, vals, x) - b) / np.linalg.norm(b) < 1e-6
+        its[kind] = info.iterations
+        pre.close()
+    _, info_plain = ma.gmres(op, b, restart=30, max_iterations=20, tol=1e-8)
+    assert its["jacobi"] < info_plain.iterations          # the preconditioner pays on this system
+    op.close(); c.close()
+
+
+def test_diagonal_preconditioner_known_answers(gpu):               # preconditioners/diagonal.rs:106-145
+    d = ma.CsrOperator([0, 1, 2, 3], [0, 1, 2], values=[2, 4, 1])
+    pre = ma.Preconditioner(d, kind="jacobi", omega=1.0, sweeps=1)
+    assert np.allclose(pre.apply([2, 8, 3]), [1, 2, 3], atol=1e-10)
+    pre.close(); d.close()
+    a = ma.CsrOperator([0, 2, 4], [0, 1, 0, 1], values=[4, 1, 1, 2])
+    pre = ma.Preconditioner(a, kind="jacobi", omega=1.0, sweeps=1)
+    assert np.allclose(pre.apply([4, 4]), [1, 2], atol=1e-10)
+    pre.close(); a.close()

@@ -337,3 +337,21 @@ def test_room_collocation_matrix_formula():              # room_acoustics/solver
     ref = (1j * k * r - 1) * np.exp(1j * k * r) / (4 * np.pi * r * r) * (d @ om.normal[i]) / r * om.area[j]
     assert abs(A[i, j] - ref) <= 1e-14 * abs(ref)
     assert abs(A[5, 5] - (-1j * k / (2 * np.pi)) * om.area[5]) < 1e-16
+
+
+def test_gmres_preconditioned_restatement():
+    """gmres.rs:282-428: with the identity preconditioner the iteration is gmres itself; with Jacobi sweeps the
+    tolerance is relative to ||M^-1 b|| and the true residual still falls."""
+    rng = np.random.default_rng(21)
+    n = 60
+    dense = np.diag(4.0 + rng.random(n)) + 0.3 * rng.standard_normal((n, n)) + 0.1j * rng.standard_normal((n, n))
+    rp = np.arange(0, n * n + 1, n); ci = np.tile(np.arange(n), n); vals = dense.reshape(-1)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    x0, i0 = O.gmres(b, csr=(rp, ci, vals), restart=20, max_iterations=10, tol=1e-10)
+    x1, i1 = O.gmres_preconditioned(b, (rp, ci, vals), pkind=0, restart=20, max_iterations=10, tol=1e-10)
+    assert i0.converged == i1.converged == 1 and i0.iterations == i1.iterations
+    assert np.abs(x0 - x1).max() <= 1e-12
+    for pk in (1, 2):
+        x2, i2 = O.gmres_preconditioned(b, (rp, ci, vals), pkind=pk, omega=1.0, sweeps=1, restart=20, max_iterations=10, tol=1e-10)
+        assert i2.converged == 1 and i2.iterations <= i0.iterations
+        assert np.linalg.norm(dense @ x2 - b) / np.linalg.norm(b) < 1e-8
