@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       }
     }
     __syncthreads();
+#ifdef MA_PANEL_STAMPS
+    if (c == 0 && tid == 0) stamp_acc[7] += __builtin_amdgcn_s_memrealtime() - stamp_t;   // residency wait: first column only
+#endif
     MA_STAMP(0);
     if (s_misc[3]) return;                               // uniform: the whole workgroup leaves
     const int p = s_misc[1], wb = s_misc[2];
@@ -291,7 +294,36 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
 // ------------------------------------------------------------------ row interchanges outside the panel
 // One wavefront replays the panel's nb interchanges on an index map and emits (dst,src) row lists:
 // after the sequence, row dst holds what row src held before it. m <= 2 nb entries.
-__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */) {
+//
+// Blocks 1.. of the same launch invert the 32 x 32 unit-lower diagonal blocks of the panel's L11 (they are final once
+// the panel kernel has ended): invd[d*32 + i][j] = (L_dd^-1)[i][j], padded with the identity beyond nb. Lane j carries
+// column j of the inverse through the forward substitution; the multipliers are LDS broadcasts.
+__device__ void lu_invert_diag32(const dc* __restrict__ T, int ldt, int nb, int d, dc* __restrict__ invd) {
+  __shared__ dc Ls[32 * 33];
+  const int lane = threadIdx.x, base = d * 32;
+  const int m = min(32, nb - base);
+  for (int idx = lane; idx < 1024; idx += 64) {
+    const int i = idx >> 5, k = idx & 31;
+    Ls[i * 33 + k] = (i < m && k < i) ? T[(size_t)(base + i) * ldt + base + k] : dc_make(0.0, 0.0);
+  }
+  __syncthreads();
+  if (lane < 32) {
+    dc x[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      dc acc = dc_make(i == lane ? 1.0 : 0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < i; ++k) { const dc t = Ls[i * 33 + k]; acc.re -= t.re * x[k].re - t.im * x[k].im; acc.im -= t.re * x[k].im + t.im * x[k].re; }
+      x[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) invd[((size_t)base + i) * 32 + lane] = x[i];
+  }
+}
+
+__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
+                                                     const dc* __restrict__ T, int ldt, dc* __restrict__ invd) {
+  if (blockIdx.x > 0) { lu_invert_diag32(T, ldt, nb, blockIdx.x - 1, invd); return; }
   __shared__ int top[LU_NB_MAX];       // content of row k0+c
   __shared__ int ext_row[LU_NB_MAX];   // rows >= k0+nb that were touched
   __shared__ int ext_src[LU_NB_MAX];
@@ -422,6 +454,111 @@ __global__ __launch_bounds__(256, 1) void lu_trsm_strip_kernel(const dc* __restr
   }
   __syncthreads();
   if (act) for (int r = rg; r < nb; r += 4) X[(size_t)r * ldx + c0 + cg] = Xs[r * 64 + cg];
+}
+
+// ------------------------------------------------------------------ U12 = L11^-1 A12 on the f64 matrix cores
+// Blocked forward substitution with inverted 32 x 32 diagonal blocks (lu_invert_diag32): per 32-row block
+//   X_b = D_b^-1 B_b,   B_below -= L_(below,b) X_b,
+// everything a 16x16x4 MFMA. One wavefront owns 16 columns and keeps its whole nb x 16 block of A12 in
+// accumulator registers (8 tiles x re/im); a result tile's register r holds rows 4r..4r+3 in exactly the layout
+// of the MFMA B operand for that k-slice, so solved rows feed the next products without leaving the registers.
+// The A operands (L11's current 32-column slab with D_b^-1 in place of its diagonal block) are staged through
+// LDS as separate re/im planes (pitch 34: conflict-free 8-byte reads). In place: a workgroup reads and writes
+// its own columns only. The last workgroup of the launch (if nc2 > 0) does the same for the right-hand sides,
+// addressed with their own strides (row stride 1, column stride ldb): the forward substitution rides along.
+#define TM_PITCH 34
+__global__ __launch_bounds__(128) void lu_trsm_mfma_kernel(const dc* __restrict__ T, int ldt, int nb, const dc* __restrict__ invd,
+                                                           dc* __restrict__ X, size_t xrs, size_t xcs, int nc, int nmain,
+                                                           dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* Lre = reinterpret_cast<double*>(smem);
+  double* Lim = Lre + 128 * TM_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const bool extra = (int)blockIdx.x >= nmain;
+  dc* Xp = extra ? X2 : X;
+  const size_t rs = extra ? x2rs : xrs, cs = extra ? x2cs : xcs;
+  const int ncols = extra ? nc2 : nc;
+  const int c0 = extra ? wave * 16 : ((int)blockIdx.x * 2 + wave) * 16;
+  const bool active = c0 < ncols;
+  const int col = c0 + li;
+  const int NT = (nb + 15) >> 4;
+
+  v4d bre[8], bim[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    bre[t] = (v4d){0, 0, 0, 0}; bim[t] = (v4d){0, 0, 0, 0};
+    if (t < NT && active) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + lk + 4 * r;
+        if (row < nb && col < ncols) { const dc v = Xp[(size_t)row * rs + (size_t)col * cs]; bre[t][r] = v.re; bim[t][r] = v.im; }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    if (blk * 32 >= nb) break;
+    const int rows = nb - blk * 32;                      // slab rows: the diagonal block and everything below it
+    __syncthreads();
+    for (int idx = tid; idx < rows * 32; idx += 128) {
+      const int rr = idx >> 5, c = idx & 31;
+      dc v;
+      if (rr < 32) v = invd[((size_t)blk * 32 + rr) * 32 + c];
+      else v = (blk * 32 + c < nb) ? T[(size_t)(blk * 32 + rr) * ldt + blk * 32 + c] : dc_make(0.0, 0.0);
+      Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int t0 = 2 * blk, t1 = 2 * blk + 1;
+    v4d x0r = (v4d){0, 0, 0, 0}, x0i = x0r, x1r = x0r, x1i = x0r;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {                     // X1 = D[16:32, 0:32] (B_t0; B_t1)
+      const double ar = Lre[(16 + li) * TM_PITCH + ks * 4 + lk], ai = Lim[(16 + li) * TM_PITCH + ks * 4 + lk];
+      const double br = bre[t0 + (ks >> 2)][ks & 3], bi = bim[t0 + (ks >> 2)][ks & 3];
+      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x1r, 0, 0, 0);
+      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x1i, 0, 0, 0);
+      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x1r, 0, 0, 0);
+      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x1i, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                     // X0 = D[0:16, 0:16] B_t0
+      const double ar = Lre[li * TM_PITCH + ks * 4 + lk], ai = Lim[li * TM_PITCH + ks * 4 + lk];
+      const double br = bre[t0][ks], bi = bim[t0][ks];
+      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x0r, 0, 0, 0);
+      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x0i, 0, 0, 0);
+      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x0r, 0, 0, 0);
+      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x0i, 0, 0, 0);
+    }
+    bre[t0] = x0r; bim[t0] = x0i;
+    if (t1 < 8) { bre[t1 < 8 ? t1 : 7] = x1r; bim[t1 < 8 ? t1 : 7] = x1i; }
+#pragma unroll
+    for (int tj = t1 + 1; tj < 8; ++tj) {                // B_tj -= L[tj rows, slab] (X0; X1)
+      if (tj >= NT) break;
+      const int lr = tj * 16 - blk * 32 + li;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const double ar = Lre[lr * TM_PITCH + ks * 4 + lk], ai = Lim[lr * TM_PITCH + ks * 4 + lk];
+        const double xr = (ks < 4) ? x0r[ks & 3] : x1r[ks & 3], xi = (ks < 4) ? x0i[ks & 3] : x1i[ks & 3];
+        bre[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xr, bre[tj], 0, 0, 0);
+        bim[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xi, bim[tj], 0, 0, 0);
+        bre[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, xi, bre[tj], 0, 0, 0);
+        bim[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, xr, bim[tj], 0, 0, 0);
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t >= NT) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + lk + 4 * r;
+        if (row < nb && col < ncols) Xp[(size_t)row * rs + (size_t)col * cs] = dc_make(bre[t][r], bim[t][r]);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ triangular solves for the right-hand sides
@@ -751,8 +888,10 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   return MA_OK;
 }
 
-int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, hipStream_t st) {
-  hipLaunchKernelGGL(lu_perm_kernel, dim3(1), dim3(64), 0, st, ipiv, k0, nb, lists);
+int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, c64* invd, hipStream_t st) {
+  // block 0 folds the interchanges; blocks 1.. invert L11's 32 x 32 diagonal blocks for lu_trsm_mfma_kernel
+  hipLaunchKernelGGL(lu_perm_kernel, dim3(invd ? 1 + (nb + 31) / 32 : 1), dim3(64), 0, st, ipiv, k0, nb, lists,
+                     reinterpret_cast<const dc*>(A + (size_t)k0 * n + k0), n, reinterpret_cast<dc*>(invd));
   MA_HIP(hipGetLastError());
   const int ncol = n - nb + nrhs;
   if (ncol <= 0) return MA_OK;
@@ -769,6 +908,19 @@ int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, 
 
 int lu_trsm_configure() {
   MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TM_PITCH * 8));
+  return MA_OK;
+}
+
+// X (nb x ncols, row stride ldx) <- L11^-1 X and the nrhs right-hand sides b_r = B + r*ldb (nb entries each) <- L11^-1 b_r,
+// with the inverted diagonal blocks `invd` of lu_launch_swaps
+int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st) {
+  if (nb <= 0 || (ncols <= 0 && nrhs <= 0)) return MA_OK;
+  MA_REQUIRE(nb <= LU_NB_MAX && nrhs <= 32, MA_ERR_DIM, "trsm: nb %d / nrhs %d beyond the kernel's tiles", nb, nrhs);
+  const int nmain = ncols > 0 ? (ncols + 31) / 32 : 0;
+  hipLaunchKernelGGL(lu_trsm_mfma_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), 2 * 128 * TM_PITCH * 8, st, reinterpret_cast<const dc*>(T), ldt, nb,
+                     reinterpret_cast<const dc*>(invd), reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
+  MA_HIP(hipGetLastError());
   return MA_OK;
 }
 

@@ -2,6 +2,7 @@
 // (replaces lu_solve, math-solvers/src/direct/lu.rs:142-153).
 #include "lu_kernels.hpp"
 #include <vector>
+#include <cstring>
 #include <algorithm>
 #include <new>
 
@@ -12,11 +13,14 @@ struct ma_lu_plan {
   int n = 0;
   int ncu = 256;
   void* ws_block = nullptr;       // one allocation: sync words | info | cand | candrow | diagrow | lists | ipiv
-  LuPanelWs pws{};
+  LuPanelWs pws{};                // system 0's panel workspace; pws_m[m] for the other systems of a batch (own gather buffers,
+  LuPanelWs pws_m[LU_BATCH_MAX]{};  // so that two systems' panel kernels may be in flight together when the chip holds both)
   // per system of a batch: pivots, the folded interchange lists, and 2*NB rows x (n + nrhs_max) staging for the interchanges
   int* d_lists[LU_BATCH_MAX] = {};
   int* d_ipiv[LU_BATCH_MAX] = {};
   c64* d_tmp[LU_BATCH_MAX] = {};
+  c64* d_invd[LU_BATCH_MAX] = {};  // inverted 32 x 32 diagonal blocks of the current panel's L11 (LU_NB_MAX x 32)
+  bool trsm_mfma = true;          // MA_LU_TRSM=strip selects the LDS strip kernel + separate RHS trsv
   int last_batch = 1;
   hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {};
   int ensure_batch(int nmat);
@@ -29,7 +33,9 @@ struct ma_lu_plan {
   int ev_last = -1;
   int n_gemm_launch = 0;
   bool ev_valid = false;
-  hipStream_t panel_stream = nullptr;   // high-priority stream for the look-ahead panel
+  hipStream_t panel_stream = nullptr;   // high-priority stream for the look-ahead panel (system 0)
+  hipStream_t panel_streams[LU_BATCH_MAX] = {};   // [0] aliases panel_stream; one per system of a batch
+  bool panel_overlap = true;      // MA_LU_PANEL_OVERLAP=0: all systems' panels on one stream (strictly serial)
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
   int want_nb = LU_NB_MAX;
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
@@ -66,6 +72,7 @@ int ma_lu_plan::ensure_batch(int nmat) {
     MA_HIP(hipMalloc(&d_tmp[m], sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + nrhs_max)));
     MA_HIP(hipMalloc(&d_ipiv[m], sizeof(int) * (size_t)n));
     MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * (1 + 4 * LU_NB_MAX)));
+    MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * LU_NB_MAX * 32));
   }
   return MA_OK;
 }
@@ -88,10 +95,13 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   const int mb = ncu;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t o_sync = take(16), o_info = take(64), o_cand = take(sizeof(unsigned long long) * 2 * mb * 2),
-               o_crow = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX), o_drow = take(sizeof(unsigned long long) * (2 * 2 * LU_NB_MAX + 16)),
-               o_lists = take(sizeof(int) * (1 + 4 * LU_NB_MAX)), o_ipiv = take(sizeof(int) * (size_t)n);
-  (void)o_lists; (void)o_ipiv;
+  const size_t o_sync = take(16), o_info = take(64);
+  size_t o_cand[LU_BATCH_MAX], o_crow[LU_BATCH_MAX], o_drow[LU_BATCH_MAX];
+  for (int m = 0; m < LU_BATCH_MAX; ++m) {
+    o_cand[m] = take(sizeof(unsigned long long) * 2 * mb * 2);
+    o_crow[m] = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX);
+    o_drow[m] = take(sizeof(unsigned long long) * (2 * 2 * LU_NB_MAX + 16));
+  }
   hipError_t e = hipMalloc(&P->ws_block, off);
   if (e != hipSuccess) {
     set_error("hipMalloc of the LU workspace failed: %s", hipGetErrorString(e));
@@ -104,20 +114,29 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   P->pws.counter = (unsigned*)(base + o_sync);
   P->pws.info = (int*)(base + o_info);
   P->pws.timeout = (unsigned*)(P->pws.info + LU_BATCH_MAX);   // persists over the factorisation, like info
-  P->pws.cand = (unsigned long long*)(base + o_cand);
-  P->pws.candrow = (unsigned long long*)(base + o_crow);
-  P->pws.diagrow = (unsigned long long*)(base + o_drow);
   P->pws.max_blocks = mb;
+  for (int m = 0; m < LU_BATCH_MAX; ++m) {
+    P->pws_m[m] = P->pws;
+    P->pws_m[m].info = P->pws.info + m;                       // per-system first-zero-pivot word
+    P->pws_m[m].cand = (unsigned long long*)(base + o_cand[m]);
+    P->pws_m[m].candrow = (unsigned long long*)(base + o_crow[m]);
+    P->pws_m[m].diagrow = (unsigned long long*)(base + o_drow[m]);
+  }
+  P->pws = P->pws_m[0];
   rc = lu_panel_configure();
   if (!rc) rc = lu_trsm_configure();
   if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v == 16 || v == 32 || v == 64 || v == 128) P->want_nb = v; }
   if (const char* e0 = getenv("MA_ZGEMM_3M")) P->use_3m = atoi(e0) != 0;
   if (const char* e2 = getenv("MA_LU_LOOKAHEAD")) P->lookahead = atoi(e2) != 0;
+  if (const char* e6 = getenv("MA_LU_TRSM")) P->trsm_mfma = strcmp(e6, "strip") != 0;
+  if (const char* e5 = getenv("MA_LU_PANEL_OVERLAP")) P->panel_overlap = atoi(e5) != 0;
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
   if (!rc) {
     int lo = 0, hi = 0;
     hipError_t e4 = hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (e4 == hipSuccess) e4 = hipStreamCreateWithPriority(&P->panel_stream, hipStreamNonBlocking, hi);
+    P->panel_streams[0] = P->panel_stream;
+    for (int i = 1; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipStreamCreateWithPriority(&P->panel_streams[i], hipStreamNonBlocking, hi);
     if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&P->ev_start, hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_panel[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_narrow[i], hipEventDisableTiming);
@@ -134,8 +153,8 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]); }
-  if (P->panel_stream) (void)hipStreamDestroy(P->panel_stream);
-  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
   return MA_OK;
@@ -175,7 +194,9 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 // while the caller's stream runs the trailing updates of A and B, so each system's latency-bound
 // chain hides under the other's throughput-bound work.
 static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* const* Bs, int32_t nrhs, hipStream_t st) {
-  hipStream_t sp = P->lookahead ? P->panel_stream : st;
+  hipStream_t sps[LU_BATCH_MAX];
+  for (int m = 0; m < LU_BATCH_MAX; ++m) sps[m] = !P->lookahead ? st : (P->panel_overlap ? P->panel_streams[m] : P->panel_stream);
+  const bool la = P->lookahead;
   const int n = P->n;
   int rc;
   P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->ev_valid = false; P->last_batch = nmat;
@@ -187,23 +208,29 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     int nb, rpb, nblk;
     // a lone system shares its CUs with its own trailing update (44 rows = 91 KB of LDS next to the zgemm
     // workgroups); in a batch the panel workgroups take whole CUs (64 rows = 132 KB): measured faster
-    const int cap = P->rpb_env ? P->rpb_cap : (nmat >= 2 ? 64 : 44);
+    // ... until two systems' panels fit on the chip together at 44 rows: from there on they run concurrently
+    // (own streams, the launcher's sequencer admits as many panel kernels as the CUs hold), next to the zgemm workgroups
+    const bool pair_fits = P->lookahead && P->panel_overlap && nmat >= 2 && (n - k0) <= 44 * (P->ncu / 2);
+    const int cap = P->rpb_env ? P->rpb_cap : (nmat >= 2 && !pair_fits ? 64 : 44);
     panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), cap, &nb, &rpb, &nblk);
     k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
     k0 += nb;
   }
   const int Q = (int)k0s.size();
   auto panel = [&](int m, int q) -> int {
-    LuPanelWs ws = P->pws;
-    ws.info = P->pws.info + m;                                // per-system first-zero-pivot word
+    const LuPanelWs& ws = P->pws_m[m];
+    hipStream_t sp = sps[m];
     MA_MARK(a, sp);
     if ((rc = lu_launch_panel(As[m], n, k0s[q], nbs[q], rpbs[q], nblks[q], P->ncu, ws, P->d_ipiv[m], sp))) return rc;
     MA_MARK(b, sp);
     interval(P, a, b, 0);
-    if (sp != st) MA_HIP(hipEventRecord(P->ev_panel[m], sp));
+    if (la) MA_HIP(hipEventRecord(P->ev_panel[m], sp));
     return MA_OK;
   };
-  if (sp != st) { MA_HIP(hipEventRecord(P->ev_start, st)); MA_HIP(hipStreamWaitEvent(sp, P->ev_start, 0)); }
+  if (la) {
+    MA_HIP(hipEventRecord(P->ev_start, st));
+    for (int m = 0; m < nmat; ++m) if (m == 0 || sps[m] != sps[0]) MA_HIP(hipStreamWaitEvent(sps[m], P->ev_start, 0));
+  }
   for (int m = 0; m < nmat; ++m) if ((rc = panel(m, 0))) return rc;
   for (int q = 0; q < Q; ++q) {
     const int k0 = k0s[q], nb = nbs[q];
@@ -211,18 +238,21 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     const int nnext = (q + 1 < Q) ? nbs[q + 1] : 0;
     for (int m = 0; m < nmat; ++m) {
       c64* A = As[m]; c64* B = Bs ? Bs[m] : nullptr;
-      if (sp != st) MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
+      if (la) MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
       MA_MARK(t0, st);
-      if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists[m], P->d_tmp[m], B, nrhs, st))) return rc;
+      if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists[m], P->d_tmp[m], B, nrhs, P->trsm_mfma ? P->d_invd[m] : nullptr, st))) return rc;
       MA_MARK(t1, st);
       interval(P, t0, t1, 1);
       const c64* T = A + (size_t)k0 * n + k0;
-      if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
+      // U12 = L11^-1 A12; the forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b
+      if (P->trsm_mfma) {
+        if ((rc = lu_launch_trsm_mfma(T, n, nb, P->d_invd[m], A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, st))) return rc;
+      } else if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
       MA_MARK(t2, st);
       interval(P, t1, t2, 2);
-      // forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b, b[below] -= L21 b[k0:k0+nb]
+      // ... b[below] -= L21 b[k0:k0+nb]
       if (nrhs > 0) {
-        if ((rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
+        if (!P->trsm_mfma && (rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
         for (int r = 0; r < nrhs && nright > 0; ++r)
           if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
       }
@@ -232,11 +262,11 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
         const c64* L21 = A + (size_t)(k0 + nb) * n + k0;
         const c64* U12 = A + (size_t)k0 * n + k0 + nb;
         c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
-        if (sp != st) {
+        if (la) {
           // narrow update of the next panel's columns first, then factor it concurrently with the rest
           if ((rc = lu_launch_zgemm_sub(nright, nnext, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
           P->n_gemm_launch++;
-          MA_HIP(hipEventRecord(P->ev_narrow[m], st)); MA_HIP(hipStreamWaitEvent(sp, P->ev_narrow[m], 0));
+          MA_HIP(hipEventRecord(P->ev_narrow[m], st)); MA_HIP(hipStreamWaitEvent(sps[m], P->ev_narrow[m], 0));
           if ((rc = panel(m, q + 1))) return rc;
         }
       }
@@ -249,7 +279,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       const c64* U12 = A + (size_t)k0 * n + k0 + nb;
       c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
       MA_MARK(t5, st);
-      if (sp != st) {
+      if (la) {
         if (nright - nnext > 0) {
           if ((rc = lu_launch_zgemm_sub(nright, nright - nnext, nb, L21, (size_t)n, U12 + nnext, (size_t)n, A22 + nnext, (size_t)n, st, P->use_3m))) return rc;
           P->n_gemm_launch++;
@@ -315,7 +345,7 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (P->panel_stream) MA_HIP(hipStreamSynchronize(P->panel_stream));
+  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i]));
   int info[16];
   MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
   MA_REQUIRE(info[LU_BATCH_MAX] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
@@ -329,7 +359,7 @@ int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
   MA_REQUIRE(P->ev_valid && P->ev_last >= 0, MA_ERR_INVALID, "no timed factorisation has run on this plan");
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipEventSynchronize(P->ev[P->ev_last]));
-  if (P->panel_stream) MA_HIP(hipStreamSynchronize(P->panel_stream));
+  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i]));
   for (int i = 0; i < 8; ++i) out8[i] = 0.0;
   for (const auto& v : P->iv) {
     float ms = 0.f;

@@ -1,0 +1,33 @@
+"""Diagnostic: per-phase time of the LU panel kernel inside a 2-system batch (needs a -DMA_PANEL_STAMPS build).
+Slot 7 is the wait of the first column of every panel = time until all of the panel's workgroups are resident."""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import math_audio_amd as ma
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+nmat = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dev = torch.device("cuda", 0)
+g = torch.Generator(device="cpu").manual_seed(0)
+A0 = [(torch.randn(n, n, dtype=torch.float64, generator=g) + 1j * torch.randn(n, n, dtype=torch.float64, generator=g)).to(dev) for _ in range(nmat)]
+b0 = torch.ones(n, dtype=torch.complex128, device=dev)
+lu = ma.LuPlan(n)
+L = ma.lib()
+L.ma_lu_plan_panel_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+out = np.zeros(8, dtype=np.uint64)
+st = torch.cuda.current_stream().cuda_stream
+for it in range(2):
+    A = [a.clone() for a in A0]; b = [b0.clone() for _ in range(nmat)]
+    L.ma_lu_plan_panel_stamps(lu.h, out.ctypes.data_as(C.c_void_p), 1)
+    lu.set_timing(True)
+    lu.factor_solve_batch_dev([a.data_ptr() for a in A], [x.data_ptr() for x in b], 1, st)
+    assert lu.status(st) == 0
+    t = lu.last_timing()
+    L.ma_lu_plan_panel_stamps(lu.h, out.ctypes.data_as(C.c_void_p), 0)
+names = ["wait(poll)+barrier", "reduce candidates", "fetch rows+barrier", "swap+multipliers+col c+1", "scan+priority rows", "publish+drain+arrive", "bulk update+barrier", "(first-column wait, inside slot 0)"]
+tot = out[:7].sum() / 100.0
+print("system 0 panel phase totals for workgroup 0 (us), n=%d, batch=%d" % (n, nmat))
+for nm, v in zip(names, out):
+    print("  %-36s %10.1f us  %6.2f us/col" % (nm, v / 100.0, v / 100.0 / n))
+print("  total %.1f us = %.2f us/col; event-timed: panel %.1f ms (all systems), total %.1f ms" % (tot, tot / n, t[0], t[6]))
+print("res", float(torch.linalg.norm(A0[0] @ b[0] - b0) / torch.linalg.norm(b0)))
