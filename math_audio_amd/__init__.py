@@ -80,6 +80,7 @@ def lib():
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],
+            "ma_lu_plan_last_update_stats": [vp, P(dbl), P(dbl), P(dbl)],
             "ma_csr_create": [i64, vp, vp, vp, C.c_int, P(vp)],
             "ma_csr_create_helmholtz": [i64, vp, vp, vp, vp, C.c_int, P(vp)],
             "ma_csr_destroy": [vp],
@@ -298,6 +299,12 @@ class LuPlan:
         out = np.zeros(8)
         check(lib().ma_lu_plan_last_timing(self.h, _vp(out)))
         return out
+
+    def last_update_stats(self):
+        """(launches, algorithmic flops, algorithmic C bytes) of the caller-stream trailing updates of the last call."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(lib().ma_lu_plan_last_update_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
 
 def test_zgemm_sub(A, B, Cm):

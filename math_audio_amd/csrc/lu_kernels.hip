@@ -9,10 +9,10 @@
 //                      picks the pivot and hands every workgroup the pivot row.
 //   lu_perm_kernel     one wavefront folds the panel's swap sequence into a gather list;
 //   lu_gather/scatter  apply it to the columns left and right of the panel (and to the RHS).
-//   lu_trsm_strip      U12 = L11^-1 A12, a 64-column strip resident in LDS per workgroup;
-//   lu_trsv_kernel     the nb x nb triangular solves of the right-hand sides, one wavefront each.
-//   zgemm_sub_kernel   A22 -= L21 U12 on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex tile
-//                      product), 128x128 tiles staged through LDS, 8 wavefronts per workgroup.
+//   lu_trsm_mfma       U12 = L11^-1 A12 as MFMA products with inverted 32 x 32 diagonal blocks (the RHS rides along);
+//   lu_trsv_kernel     the nb x nb triangular solves of the backward substitution, one wavefront each.
+//   zgemm3m_sub_kernel A22 -= L21 U12 on v_mfma_f64_16x16x4_f64, 3 real products per complex product, 64 x 64 tiles
+//                      (zgemm_sub_kernel: the 4-product form, 128 x 128 tiles).
 #include "lu_kernels.hpp"
 #include "ma_device_math.hpp"
 #include <climits>
@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       }
       if (lane == 0) {
         if (fail) { __hip_atomic_store(ws.timeout, 1u, RLX_AGENT); s_misc[3] = 1; }
+        // no workgroup offered a row (a column of NaNs compares false everywhere): keep the diagonal row and report
+        // the column as a failed pivot, so that no out-of-range row index ever reaches the interchange kernels
+        if (!fail && best >= (u64)n) { best = (u64)gc; bblk = -1; if (b == 0) atomicCAS(ws.info, 0, gc + 1); }
         s_misc[1] = (int)best; s_misc[2] = bblk;
       }
     }
@@ -195,7 +198,8 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     MA_STAMP(1);
     // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads
     {
-      const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX);
+      // wb < 0 (no candidate anywhere): the diagonal row stands in as the pivot row
+      const u64* src = wb >= 0 ? ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX) : ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
       double* dst = reinterpret_cast<double*>(urow);
       for (int t = tid; t < 2 * nb; t += 256) dst[t] = ld_sc1(src + t);
       if (p != gc) {
@@ -321,7 +325,7 @@ __device__ void lu_invert_diag32(const dc* __restrict__ T, int ldt, int nb, int 
   }
 }
 
-__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
+__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
                                                      const dc* __restrict__ T, int ldt, dc* __restrict__ invd) {
   if (blockIdx.x > 0) { lu_invert_diag32(T, ldt, nb, blockIdx.x - 1, invd); return; }
   __shared__ int top[LU_NB_MAX];       // content of row k0+c
@@ -332,7 +336,8 @@ __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipi
   int next = 0;
   __builtin_amdgcn_wave_barrier();
   for (int c = 0; c < nb; ++c) {
-    const int p = ipiv[k0 + c];
+    int p = ipiv[k0 + c];
+    if (p < k0 + c || p >= n) p = k0 + c;                // never act on an out-of-range pivot (stale or failed panel)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (p == k0 + c) continue;
     if (p < k0 + nb) {
@@ -367,93 +372,34 @@ __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipi
   if (lane == 0) lists[0] = m;
 }
 
-// tmp[idx][col] = M[src[idx]][col] for the columns outside [k0, k0+nb) plus the nrhs RHS "columns"
-__global__ __launch_bounds__(256) void lu_gather_rows_kernel(const dc* __restrict__ A, int n, int k0, int nb, const int* __restrict__ lists,
-                                                             dc* __restrict__ tmp, const dc* __restrict__ B, int nrhs) {
+// tmp[idx][q] = A[src[idx]][col(q)] over the column set [x0, x1) U [y0, y1) plus the nrhs RHS "columns"
+__global__ __launch_bounds__(256) void lu_gather_rows_kernel(const dc* __restrict__ A, int n, const int* __restrict__ lists, dc* __restrict__ tmp, int tstride,
+                                                             int x0, int x1, int y0, int y1, const dc* __restrict__ B, int nrhs) {
   const int m = lists[0];
   const int idx = blockIdx.y;
   if (idx >= m) return;
   const int s = lists[1 + 2 * LU_NB_MAX + idx];
-  const int ncol = n - nb + nrhs;
+  const int nx = x1 - x0, nxy = nx + (y1 - y0), ncol = nxy + nrhs;
   for (int q = blockIdx.x * 256 + threadIdx.x; q < ncol; q += gridDim.x * 256) {
     dc v;
-    if (q < n - nb) { int col = q < k0 ? q : q + nb; v = A[(size_t)s * n + col]; }
-    else v = B[(size_t)(q - (n - nb)) * n + s];
-    tmp[(size_t)idx * (n + nrhs) + q] = v;
+    if (q < nxy) { const int col = q < nx ? x0 + q : y0 + (q - nx); v = A[(size_t)s * n + col]; }
+    else v = B[(size_t)(q - nxy) * n + s];
+    tmp[(size_t)idx * tstride + q] = v;
   }
 }
 
-__global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A, int n, int k0, int nb, const int* __restrict__ lists,
-                                                              const dc* __restrict__ tmp, dc* __restrict__ B, int nrhs) {
+__global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A, int n, const int* __restrict__ lists, const dc* __restrict__ tmp, int tstride,
+                                                              int x0, int x1, int y0, int y1, dc* __restrict__ B, int nrhs) {
   const int m = lists[0];
   const int idx = blockIdx.y;
   if (idx >= m) return;
   const int d = lists[1 + idx];
-  const int ncol = n - nb + nrhs;
+  const int nx = x1 - x0, nxy = nx + (y1 - y0), ncol = nxy + nrhs;
   for (int q = blockIdx.x * 256 + threadIdx.x; q < ncol; q += gridDim.x * 256) {
-    dc v = tmp[(size_t)idx * (n + nrhs) + q];
-    if (q < n - nb) { int col = q < k0 ? q : q + nb; A[(size_t)d * n + col] = v; }
-    else B[(size_t)(q - (n - nb)) * n + d] = v;
+    const dc v = tmp[(size_t)idx * tstride + q];
+    if (q < nxy) { const int col = q < nx ? x0 + q : y0 + (q - nx); A[(size_t)d * n + col] = v; }
+    else B[(size_t)(q - nxy) * n + d] = v;
   }
-}
-
-// ------------------------------------------------------------------ U12 = L11^-1 A12 (strip kernel)
-// One workgroup owns a strip of 64 columns of A12 and keeps the whole nb x 64 strip in LDS
-// (128 KB at nb = 128: the strip never leaves the CU during the solve). Lane = column, the 4
-// wavefronts split the rows. Per 16-row block: wavefront 0 solves the 16 x 16 unit-lower diagonal
-// block for its 64 columns in registers (the small triangle sits in LDS, read as broadcasts) and
-// writes the solved rows back; then every wavefront updates its share of the rows below with the
-// block's 16 multipliers per row, staged through LDS 64 rows at a time (wave-uniform row ->
-// broadcast reads).
-__global__ __launch_bounds__(256, 1) void lu_trsm_strip_kernel(const dc* __restrict__ T, int ldt, int nb, dc* __restrict__ X, size_t ldx, int ncols) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  dc* Xs = reinterpret_cast<dc*>(smem);                 // [nb][64]
-  dc* Ds = Xs + (size_t)nb * 64;                        // [16][16] diagonal block
-  dc* Ls = Ds + 256;                                    // [64][16] multipliers of up to 64 rows below
-  const int tid = threadIdx.x, cg = tid & 63;
-  const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c0 = blockIdx.x * 64;
-  const bool act = c0 + cg < ncols;
-  for (int r = rg; r < nb; r += 4) Xs[r * 64 + cg] = act ? X[(size_t)r * ldx + c0 + cg] : dc_make(0.0, 0.0);
-  const int nblk16 = (nb + 15) / 16;
-  for (int bi = 0; bi < nblk16; ++bi) {
-    const int rlo = bi * 16, nr = min(16, nb - rlo);
-    __syncthreads();
-    { const int i = tid >> 4, p = tid & 15; Ds[tid] = (i < nr && p < nr) ? T[(size_t)(rlo + i) * ldt + rlo + p] : dc_make(0.0, 0.0); }
-    __syncthreads();
-    if (rg == 0) {
-      dc x[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = (i < nr) ? Xs[(rlo + i) * 64 + cg] : dc_make(0.0, 0.0);
-#pragma unroll
-      for (int i = 1; i < 16; ++i) {
-#pragma unroll
-        for (int p = 0; p < i; ++p) { const dc t = Ds[i * 16 + p]; x[i].re -= t.re * x[p].re - t.im * x[p].im; x[i].im -= t.re * x[p].im + t.im * x[p].re; }
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) if (i < nr) Xs[(rlo + i) * 64 + cg] = x[i];
-    }
-    const int below = nb - (rlo + 16);
-    for (int base = 0; base < below; base += 64) {
-      const int cnt = min(64, below - base);
-      __syncthreads();                                   // solved rows visible; previous Ls chunk consumed
-      for (int idx = tid; idx < cnt * 16; idx += 256) { const int r = idx >> 4, i = idx & 15; Ls[idx] = T[(size_t)(rlo + 16 + base + r) * ldt + rlo + i]; }
-      __syncthreads();
-      dc x[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = Xs[(rlo + i) * 64 + cg];
-      for (int r = rg; r < cnt; r += 4) {
-        const int gr = rlo + 16 + base + r;
-        dc acc = Xs[gr * 64 + cg];
-        const dc* Lr = Ls + r * 16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const dc t = Lr[i]; acc.re -= t.re * x[i].re - t.im * x[i].im; acc.im -= t.re * x[i].im + t.im * x[i].re; }
-        Xs[gr * 64 + cg] = acc;
-      }
-    }
-  }
-  __syncthreads();
-  if (act) for (int r = rg; r < nb; r += 4) X[(size_t)r * ldx + c0 + cg] = Xs[r * 64 + cg];
 }
 
 // ------------------------------------------------------------------ U12 = L11^-1 A12 on the f64 matrix cores
@@ -500,13 +446,15 @@ __global__ __launch_bounds__(128) void lu_trsm_mfma_kernel(const dc* __restrict_
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     if (blk * 32 >= nb) break;
-    const int rows = nb - blk * 32;                      // slab rows: the diagonal block and everything below it
+    // slab rows: the (identity-padded) inverted diagonal block and everything below it, zero beyond nb up to the
+    // tile boundary: padded rows of a tile feed later products as k-slices and must stay exactly zero
+    const int rows = max(32, NT * 16 - blk * 32);
     __syncthreads();
     for (int idx = tid; idx < rows * 32; idx += 128) {
       const int rr = idx >> 5, c = idx & 31;
       dc v;
       if (rr < 32) v = invd[((size_t)blk * 32 + rr) * 32 + c];
-      else v = (blk * 32 + c < nb) ? T[(size_t)(blk * 32 + rr) * ldt + blk * 32 + c] : dc_make(0.0, 0.0);
+      else v = (blk * 32 + rr < nb && blk * 32 + c < nb) ? T[(size_t)(blk * 32 + rr) * ldt + blk * 32 + c] : dc_make(0.0, 0.0);
       Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
     }
     __syncthreads();
@@ -724,7 +672,10 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
 #define Z3_BM 64
 #define Z3_BN 64
 
-__global__ __launch_bounds__(256, 2) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
+#ifndef MA_ZGEMM_MAXWAVES
+#define MA_ZGEMM_MAXWAVES 2
+#endif
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
                                                              const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
   __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
   __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
@@ -867,8 +818,12 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
+  // Admission: the panel kernels in flight may hold at most 96 KB of a CU's LDS between them, i.e. two trailing-update
+  // workgroups (2 x 32 KB) still fit beside them on every CU. Then every admitted workgroup finds room as soon as kernels
+  // that always terminate have drained. (Packing the LDS full with spinning panel workgroups -- 2 x 68 KB per CU, three
+  // kernels in flight -- timed out on the chip: partially resident panel kernels and the other kernels blocked each other.)
   const size_t lds = lu_panel_lds_bytes(nb, rpb);
-  int per_cu = (int)((160 * 1024) / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8;
+  int per_cu = (int)((96 * 1024) / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 4) per_cu = 4;
   int lag = (ncu * per_cu) / (nblk > 0 ? nblk : 1);
   if (lag < 1) lag = 1;
   if (lag > 8) lag = 8;
@@ -888,26 +843,29 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   return MA_OK;
 }
 
-int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, c64* B, int nrhs, c64* invd, hipStream_t st) {
-  // block 0 folds the interchanges; blocks 1.. invert L11's 32 x 32 diagonal blocks for lu_trsm_mfma_kernel
-  hipLaunchKernelGGL(lu_perm_kernel, dim3(invd ? 1 + (nb + 31) / 32 : 1), dim3(64), 0, st, ipiv, k0, nb, lists,
+// Apply panel (k0, nb)'s interchanges to the columns [x0, x1) U [y0, y1) of A and to the nrhs right-hand sides.
+// `tmp` holds 2 nb rows of `tstride` >= (x1-x0)+(y1-y0)+nrhs entries. With `invd`, blocks 1.. of the first launch
+// also invert the 32 x 32 diagonal blocks of the panel's L11 for lu_trsm_mfma_kernel.
+int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
+                    c64* invd, hipStream_t st) {
+  hipLaunchKernelGGL(lu_perm_kernel, dim3(invd ? 1 + (nb + 31) / 32 : 1), dim3(64), 0, st, ipiv, n, k0, nb, lists,
                      reinterpret_cast<const dc*>(A + (size_t)k0 * n + k0), n, reinterpret_cast<dc*>(invd));
   MA_HIP(hipGetLastError());
-  const int ncol = n - nb + nrhs;
+  const int ncol = (x1 - x0) + (y1 - y0) + nrhs;
   if (ncol <= 0) return MA_OK;
+  MA_REQUIRE(ncol <= tstride, MA_ERR_INVALID, "interchange staging rows too short (%d > %d)", ncol, tstride);
   int gx = (ncol + 255) / 256; if (gx > 64) gx = 64;
   dim3 grid(gx, 2 * nb);
-  hipLaunchKernelGGL(lu_gather_rows_kernel, grid, dim3(256), 0, st, reinterpret_cast<const dc*>(A), n, k0, nb, lists, reinterpret_cast<dc*>(tmp),
+  hipLaunchKernelGGL(lu_gather_rows_kernel, grid, dim3(256), 0, st, reinterpret_cast<const dc*>(A), n, lists, reinterpret_cast<dc*>(tmp), tstride, x0, x1, y0, y1,
                      reinterpret_cast<const dc*>(B), nrhs);
   MA_HIP(hipGetLastError());
-  hipLaunchKernelGGL(lu_scatter_rows_kernel, grid, dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, lists, reinterpret_cast<const dc*>(tmp),
+  hipLaunchKernelGGL(lu_scatter_rows_kernel, grid, dim3(256), 0, st, reinterpret_cast<dc*>(A), n, lists, reinterpret_cast<const dc*>(tmp), tstride, x0, x1, y0, y1,
                      reinterpret_cast<dc*>(B), nrhs);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
 
 int lu_trsm_configure() {
-  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TM_PITCH * 8));
   return MA_OK;
 }
@@ -920,15 +878,6 @@ int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, 
   const int nmain = ncols > 0 ? (ncols + 31) / 32 : 0;
   hipLaunchKernelGGL(lu_trsm_mfma_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), 2 * 128 * TM_PITCH * 8, st, reinterpret_cast<const dc*>(T), ldt, nb,
                      reinterpret_cast<const dc*>(invd), reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
-  MA_HIP(hipGetLastError());
-  return MA_OK;
-}
-
-// X (nb x ncols at X, row stride ldx) <- L11^-1 X with the unit-lower nb x nb triangle at T
-int lu_launch_trsm_strip(const c64* T, int ldt, int nb, c64* X, size_t ldx, int ncols, hipStream_t st) {
-  if (ncols <= 0 || nb <= 0) return MA_OK;
-  const size_t lds = ((size_t)nb * 64 + 256 + 64 * 16) * sizeof(dc);
-  hipLaunchKernelGGL(lu_trsm_strip_kernel, dim3((ncols + 63) / 64), dim3(256), lds, st, reinterpret_cast<const dc*>(T), ldt, nb, reinterpret_cast<dc*>(X), ldx, ncols);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -8,6 +8,10 @@
 
 using namespace ma;
 
+#define LU_LISTS_LEN (1 + 4 * LU_NB_MAX)
+#define LU_KB_MAX 8                         // panels per trailing update
+#define LU_LANE_TSTRIDE (3 * LU_NB_MAX)      // the lane's interchanges touch at most (kb-1) panels' columns
+
 struct ma_lu_plan {
   int device = 0;
   int n = 0;
@@ -19,8 +23,14 @@ struct ma_lu_plan {
   int* d_lists[LU_BATCH_MAX] = {};
   int* d_ipiv[LU_BATCH_MAX] = {};
   c64* d_tmp[LU_BATCH_MAX] = {};
-  c64* d_invd[LU_BATCH_MAX] = {};  // inverted 32 x 32 diagonal blocks of the current panel's L11 (LU_NB_MAX x 32)
-  bool trsm_mfma = true;          // MA_LU_TRSM=strip selects the LDS strip kernel + separate RHS trsv
+  c64* d_invd[LU_BATCH_MAX] = {};  // inverted 32 x 32 diagonal blocks of L11 of each panel of the current block (4 x LU_NB_MAX x 32)
+  // the look-ahead lane's own copies (it works on block g+1 while the main lane works on block g)
+  int* d_lists_l[LU_BATCH_MAX] = {};
+  c64* d_tmp_l[LU_BATCH_MAX] = {};
+  c64* d_invd_l[LU_BATCH_MAX] = {};
+  int kb = 4;                     // panels per trailing update (MA_LU_KB=1..4): K = kb * nb = 256
+  double gemm_flops = 0.0;        // algorithmic flops of the caller-stream update launches of the last call
+  double gemm_cbytes = 0.0;       // and their algorithmic C read + write bytes
   int last_batch = 1;
   hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {};
   int ensure_batch(int nmat);
@@ -37,10 +47,10 @@ struct ma_lu_plan {
   hipStream_t panel_streams[LU_BATCH_MAX] = {};   // [0] aliases panel_stream; one per system of a batch
   bool panel_overlap = true;      // MA_LU_PANEL_OVERLAP=0: all systems' panels on one stream (strictly serial)
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
-  int want_nb = LU_NB_MAX;
+  int want_nb = 64;               // panel width (MA_LU_NB): 64 columns keep two systems' panels co-resident from the first column of a 10k system
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
   bool rpb_env = false;           // MA_LU_RPB given
-  int rpb_cap = 44;               // rows per panel workgroup: 44 x 129 x 16 B = 91 KB leaves room for a zgemm workgroup on the CU
+  int rpb_cap = 44;               // rows per panel workgroup when MA_LU_RPB is given
 };
 
 namespace {
@@ -71,8 +81,12 @@ int ma_lu_plan::ensure_batch(int nmat) {
     if (d_tmp[m]) continue;
     MA_HIP(hipMalloc(&d_tmp[m], sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + nrhs_max)));
     MA_HIP(hipMalloc(&d_ipiv[m], sizeof(int) * (size_t)n));
-    MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * (1 + 4 * LU_NB_MAX)));
-    MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * LU_NB_MAX * 32));
+    MA_HIP(hipMemset(d_ipiv[m], 0, sizeof(int) * (size_t)n));
+    MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * LU_KB_MAX * LU_LISTS_LEN));
+    MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * LU_KB_MAX * LU_NB_MAX * 32));
+    MA_HIP(hipMalloc(&d_lists_l[m], sizeof(int) * LU_LISTS_LEN));
+    MA_HIP(hipMalloc(&d_invd_l[m], sizeof(c64) * LU_NB_MAX * 32));
+    MA_HIP(hipMalloc(&d_tmp_l[m], sizeof(c64) * 2 * LU_NB_MAX * LU_LANE_TSTRIDE));
   }
   return MA_OK;
 }
@@ -125,10 +139,10 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   P->pws = P->pws_m[0];
   rc = lu_panel_configure();
   if (!rc) rc = lu_trsm_configure();
-  if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v == 16 || v == 32 || v == 64 || v == 128) P->want_nb = v; }
+  if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v >= 16 && v <= LU_NB_MAX && v % 16 == 0) P->want_nb = v; }
   if (const char* e0 = getenv("MA_ZGEMM_3M")) P->use_3m = atoi(e0) != 0;
   if (const char* e2 = getenv("MA_LU_LOOKAHEAD")) P->lookahead = atoi(e2) != 0;
-  if (const char* e6 = getenv("MA_LU_TRSM")) P->trsm_mfma = strcmp(e6, "strip") != 0;
+  if (const char* e6 = getenv("MA_LU_KB")) { int v = atoi(e6); if (v >= 1 && v <= LU_KB_MAX) P->kb = v; }
   if (const char* e5 = getenv("MA_LU_PANEL_OVERLAP")) P->panel_overlap = atoi(e5) != 0;
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
   if (!rc) {
@@ -154,7 +168,8 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]); }
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
-  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
+    if (P->d_lists_l[i]) (void)hipFree(P->d_lists_l[i]); if (P->d_invd_l[i]) (void)hipFree(P->d_invd_l[i]); if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
   return MA_OK;
@@ -183,91 +198,128 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 
 // Factor the matrices in place and solve for nrhs right-hand sides each (d_B[nrhs][n]); everything asynchronous.
 //
-// Right-looking blocked LU with one panel of look-ahead: as soon as the columns of panel q+1 have
-// received panel q's update (a narrow zgemm), panel q+1 is factored on the plan's own high-priority
-// stream while the rest of panel q's trailing update runs on the caller's stream. The panel
-// workgroups are latency-bound (one chip-wide gather per column) and sized to share a CU with a
-// zgemm workgroup (LDS 91 KB + 48 KB), so the matrix cores stay busy underneath them.
+// Right-looking blocked LU on two levels. Pivoting works on panels of <= 128 columns (lu_panel_kernel: the width whose
+// rows fit the LDS of the co-resident workgroups); the trailing matrix is updated once per BLOCK of `kb` panels (default
+// 2 => K = 256), because the update kernel's cost per launch is the read-modify-write of C: at K = 128 it runs at 61
+// TFLOP/s, at K = 256 at 71 (tools/zgemm_bench.hip).
 //
-// A batch of independent systems of the same size (frequencies of a sweep) is interleaved panel by
-// panel: the panel stream runs P(A,q+1), P(B,q+1) back to back (never two panel kernels at once)
-// while the caller's stream runs the trailing updates of A and B, so each system's latency-bound
-// chain hides under the other's throughput-bound work.
+//   look-ahead lane (own high-priority stream per system), block g+1 = panels p_0..p_{kb-1}, columns [a_0, e):
+//     for j: panel(p_j);  if j < kb-1: interchanges of p_j -> columns [a_{j+1}, e);  U = L_jj^-1 A[p_j rows, a_{j+1}:e);
+//            A[a_{j+1}:n, a_{j+1}:e) -= L[a_{j+1}:n, p_j] U          (a small right-looking LU of the block column)
+//   main lane (caller's stream), block g, once its panels are done:
+//     interchanges of every p_j -> columns [0, a_j) U [e, n) and the right-hand sides
+//     for j: U_j = L_jj^-1 A[p_j rows, e:n)  (+ forward substitution of b's rows, riding in the same launch);
+//            b[a_{j+1}:n) -= L b_j;   A[a_{j+1}:e, e:n) -= L[a_{j+1}:e, p_j] U_j
+//     A[e:n, e:n) -= A[e:n, a_0:e) A[a_0:e, e:n): first the columns of block g+1 (then the look-ahead lane starts on
+//     them, concurrently with ...) then the rest.
+//
+// The panel workgroups are latency-bound (one chip-wide gather per column) and sized to share a CU with update
+// workgroups, so the matrix cores stay busy underneath them. A batch of independent systems of the same size
+// (frequencies of a sweep) is interleaved block by block on the caller's stream, each system with its own look-ahead
+// lane: one system's latency-bound chain hides under the others' throughput-bound work. Two systems' panel kernels
+// run at the same time only when the chip holds both (the launcher's sequencer).
 static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* const* Bs, int32_t nrhs, hipStream_t st) {
   hipStream_t sps[LU_BATCH_MAX];
   for (int m = 0; m < LU_BATCH_MAX; ++m) sps[m] = !P->lookahead ? st : (P->panel_overlap ? P->panel_streams[m] : P->panel_stream);
   const bool la = P->lookahead;
   const int n = P->n;
+  const int tstride = n + P->nrhs_max;
   int rc;
-  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->ev_valid = false; P->last_batch = nmat;
+  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->ev_valid = false; P->last_batch = nmat;
   MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
   MA_MARK(e_begin, st);
 
   std::vector<int> k0s, nbs, rpbs, nblks;
   for (int k0 = 0; k0 < n;) {
     int nb, rpb, nblk;
-    // a lone system shares its CUs with its own trailing update (44 rows = 91 KB of LDS next to the zgemm
-    // workgroups); in a batch the panel workgroups take whole CUs (64 rows = 132 KB): measured faster
-    // ... until two systems' panels fit on the chip together at 44 rows: from there on they run concurrently
-    // (own streams, the launcher's sequencer admits as many panel kernels as the CUs hold), next to the zgemm workgroups
-    const bool pair_fits = P->lookahead && P->panel_overlap && nmat >= 2 && (n - k0) <= 44 * (P->ncu / 2);
-    const int cap = P->rpb_env ? P->rpb_cap : (nmat >= 2 && !pair_fits ? 64 : 44);
+    // rows per panel workgroup: at most 47.5 KB of LDS, so that two systems' panel workgroups AND two trailing-update
+    // workgroups fit on a CU together (the launcher admits panel kernels up to 96 KB per CU): 44 rows at nb = 64.
+    // Few rows per workgroup also keep the per-column local work -- which a co-tenant update slows down -- short.
+    const int wnb = std::min(n - k0, P->want_nb);
+    const int cap = P->rpb_env ? P->rpb_cap : std::max(8, (int)((48640 - 2 * wnb * 16 - 256) / ((wnb + 1) * 16)));
     panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), cap, &nb, &rpb, &nblk);
     k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
     k0 += nb;
   }
   const int Q = (int)k0s.size();
-  auto panel = [&](int m, int q) -> int {
-    const LuPanelWs& ws = P->pws_m[m];
+  // the lane's interchange staging holds (kb-1) panels' columns
+  int kb = std::max(1, std::min(P->kb, LU_KB_MAX));
+  while (kb > 1 && (kb - 1) * P->want_nb > LU_LANE_TSTRIDE) --kb;
+  const int G = (Q + kb - 1) / kb;
+  auto blk_first = [&](int g) { return g * kb; };
+  auto blk_last = [&](int g) { return std::min(Q, (g + 1) * kb); };           // one past
+  auto blk_end = [&](int g) { int q = blk_last(g) - 1; return k0s[q] + nbs[q]; };   // first column right of block g
+  auto gemm = [&](int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_) -> int {
+    if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
+    if (s_ == st) { P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_; }   // the timed (phase 3) launches
+    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m);
+  };
+
+  // the look-ahead lane: factor the block column of block g of system m
+  auto lane = [&](int m, int g) -> int {
+    c64* A = As[m];
     hipStream_t sp = sps[m];
-    MA_MARK(a, sp);
-    if ((rc = lu_launch_panel(As[m], n, k0s[q], nbs[q], rpbs[q], nblks[q], P->ncu, ws, P->d_ipiv[m], sp))) return rc;
-    MA_MARK(b, sp);
-    interval(P, a, b, 0);
+    const int e = blk_end(g);
+    for (int q = blk_first(g); q < blk_last(g); ++q) {
+      const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+      MA_MARK(t0, sp);
+      if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], sp))) return rc;
+      MA_MARK(t1, sp);
+      interval(P, t0, t1, 0);
+      if (a1 < e) {
+        if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists_l[m], P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, P->d_invd_l[m], sp))) return rc;
+        const c64* T = A + (size_t)k0 * n + k0;
+        if ((rc = lu_launch_trsm_mfma(T, n, nb, P->d_invd_l[m], A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
+        MA_MARK(t2, sp);
+        interval(P, t1, t2, 5);
+      }
+    }
     if (la) MA_HIP(hipEventRecord(P->ev_panel[m], sp));
     return MA_OK;
   };
+
   if (la) {
     MA_HIP(hipEventRecord(P->ev_start, st));
     for (int m = 0; m < nmat; ++m) if (m == 0 || sps[m] != sps[0]) MA_HIP(hipStreamWaitEvent(sps[m], P->ev_start, 0));
   }
-  for (int m = 0; m < nmat; ++m) if ((rc = panel(m, 0))) return rc;
-  for (int q = 0; q < Q; ++q) {
-    const int k0 = k0s[q], nb = nbs[q];
-    const int nright = n - k0 - nb;
-    const int nnext = (q + 1 < Q) ? nbs[q + 1] : 0;
+  for (int m = 0; m < nmat; ++m) if ((rc = lane(m, 0))) return rc;
+  for (int g = 0; g < G; ++g) {
+    const int a0 = k0s[blk_first(g)], e = blk_end(g);
+    const int nright = n - e;
+    const int enext = (g + 1 < G) ? blk_end(g + 1) : e;      // block g+1 occupies columns [e, enext)
     for (int m = 0; m < nmat; ++m) {
       c64* A = As[m]; c64* B = Bs ? Bs[m] : nullptr;
       if (la) MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
       MA_MARK(t0, st);
-      if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists[m], P->d_tmp[m], B, nrhs, P->trsm_mfma ? P->d_invd[m] : nullptr, st))) return rc;
+      for (int q = blk_first(g); q < blk_last(g); ++q)
+        if ((rc = lu_launch_swaps(A, n, k0s[q], nbs[q], P->d_ipiv[m], P->d_lists[m] + (q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs,
+                                  P->d_invd[m] + (size_t)(q - blk_first(g)) * LU_NB_MAX * 32, st))) return rc;
       MA_MARK(t1, st);
       interval(P, t0, t1, 1);
-      const c64* T = A + (size_t)k0 * n + k0;
-      // U12 = L11^-1 A12; the forward substitution on the right-hand sides rides along: b[k0:k0+nb] <- L11^-1 b
-      if (P->trsm_mfma) {
-        if ((rc = lu_launch_trsm_mfma(T, n, nb, P->d_invd[m], A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, st))) return rc;
-      } else if (nright > 0 && (rc = lu_launch_trsm_strip(T, n, nb, A + (size_t)k0 * n + k0 + nb, (size_t)n, nright, st))) return rc;
-      MA_MARK(t2, st);
-      interval(P, t1, t2, 2);
-      // ... b[below] -= L21 b[k0:k0+nb]
-      if (nrhs > 0) {
-        if (!P->trsm_mfma && (rc = lu_launch_trsv(false, T, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
-        for (int r = 0; r < nrhs && nright > 0; ++r)
-          if ((rc = lu_launch_zgemv_sub(nright, nb, A + (size_t)(k0 + nb) * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + k0 + nb, st))) return rc;
+      for (int q = blk_first(g); q < blk_last(g); ++q) {
+        const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+        const c64* T = A + (size_t)k0 * n + k0;
+        const c64* invd = P->d_invd[m] + (size_t)(q - blk_first(g)) * LU_NB_MAX * 32;
+        MA_MARK(u0, st);
+        if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + e, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, st))) return rc;
+        MA_MARK(u1, st);
+        interval(P, u0, u1, 2);
+        for (int r = 0; r < nrhs && a1 < n; ++r)
+          if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, st))) return rc;
+        MA_MARK(u2, st);
+        interval(P, u1, u2, 4);
+        if (a1 < e && (rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, st))) return rc;
+        MA_MARK(u3, st);
+        interval(P, u2, u3, 3);
       }
       MA_MARK(t3, st);
-      interval(P, t2, t3, 4);
-      if (nright > 0 && nnext > 0) {
-        const c64* L21 = A + (size_t)(k0 + nb) * n + k0;
-        const c64* U12 = A + (size_t)k0 * n + k0 + nb;
-        c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
+      if (nright > 0 && g + 1 < G) {
         if (la) {
-          // narrow update of the next panel's columns first, then factor it concurrently with the rest
-          if ((rc = lu_launch_zgemm_sub(nright, nnext, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
-          P->n_gemm_launch++;
+          // narrow update of the next block's columns first, then factor them concurrently with the rest
+          if ((rc = gemm(nright, enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, st))) return rc;
           MA_HIP(hipEventRecord(P->ev_narrow[m], st)); MA_HIP(hipStreamWaitEvent(sps[m], P->ev_narrow[m], 0));
-          if ((rc = panel(m, q + 1))) return rc;
+          if ((rc = lane(m, g + 1))) return rc;
         }
       }
       MA_MARK(t4, st);
@@ -275,19 +327,12 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     }
     for (int m = 0; m < nmat && nright > 0; ++m) {
       c64* A = As[m];
-      const c64* L21 = A + (size_t)(k0 + nb) * n + k0;
-      const c64* U12 = A + (size_t)k0 * n + k0 + nb;
-      c64* A22 = A + (size_t)(k0 + nb) * n + k0 + nb;
       MA_MARK(t5, st);
       if (la) {
-        if (nright - nnext > 0) {
-          if ((rc = lu_launch_zgemm_sub(nright, nright - nnext, nb, L21, (size_t)n, U12 + nnext, (size_t)n, A22 + nnext, (size_t)n, st, P->use_3m))) return rc;
-          P->n_gemm_launch++;
-        }
+        if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, st))) return rc;
       } else {
-        if ((rc = lu_launch_zgemm_sub(nright, nright, nb, L21, (size_t)n, U12, (size_t)n, A22, (size_t)n, st, P->use_3m))) return rc;
-        P->n_gemm_launch++;
-        if (q + 1 < Q && (rc = panel(m, q + 1))) return rc;
+        if ((rc = gemm(nright, nright, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, st))) return rc;
+        if (g + 1 < G && (rc = lane(m, g + 1))) return rc;
       }
       MA_MARK(t6, st);
       interval(P, t5, t6, 3);
@@ -368,6 +413,15 @@ int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
     else if (v.phase == 6) out8[6] = ms;
   }
   out8[5] = P->n_gemm_launch;
+  out8[7] = P->gemm_flops;
+  return MA_OK;
+}
+
+// Trailing-update launches on the caller's stream in the last call (all systems of the batch): count, algorithmic
+// flops (8 M N K each) and algorithmic C bytes (32 M N each). They are the launches the phase-3 time covers.
+int ma_lu_plan_last_update_stats(ma_lu_plan_t* P, double* launches, double* flops, double* c_bytes) {
+  MA_REQUIRE(P && launches && flops && c_bytes, MA_ERR_INVALID, "NULL argument");
+  *launches = P->n_gemm_launch; *flops = P->gemm_flops; *c_bytes = P->gemm_cbytes;
   return MA_OK;
 }
 
