@@ -303,26 +303,55 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
 // the panel kernel has ended): invd[d*32 + i][j] = (L_dd^-1)[i][j], padded with the identity beyond nb. Lane j carries
 // column j of the inverse through the forward substitution; the multipliers are LDS broadcasts.
 __device__ void lu_invert_diag32(const dc* __restrict__ T, int ldt, int nb, int d, dc* __restrict__ invd) {
+  // L = [A 0; C B] in 16 x 16 blocks:  L^-1 = [A^-1 0; -B^-1 C A^-1  B^-1].  Lanes 0-15 / 16-31 carry the columns of
+  // A^-1 / B^-1 through a 16-row forward substitution (a quarter of the 32-row dependent chain); then lane (j, q)
+  // forms column j of W = C A^-1 and rows 4q..4q+3 of -B^-1 W: products with 16 independent accumulators.
   __shared__ dc Ls[32 * 33];
+  __shared__ dc Xs[32 * 33];
   const int lane = threadIdx.x, base = d * 32;
   const int m = min(32, nb - base);
   for (int idx = lane; idx < 1024; idx += 64) {
     const int i = idx >> 5, k = idx & 31;
     Ls[i * 33 + k] = (i < m && k < i) ? T[(size_t)(base + i) * ldt + base + k] : dc_make(0.0, 0.0);
+    Xs[i * 33 + k] = dc_make(0.0, 0.0);
   }
   __syncthreads();
   if (lane < 32) {
-    dc x[32];
+    const int off = lane & 16, j = lane & 15;
+    dc x[16];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      dc acc = dc_make(i == lane ? 1.0 : 0.0, 0.0);
+    for (int i = 0; i < 16; ++i) {
+      dc acc = dc_make(i == j ? 1.0 : 0.0, 0.0);
 #pragma unroll
-      for (int k = 0; k < i; ++k) { const dc t = Ls[i * 33 + k]; acc.re -= t.re * x[k].re - t.im * x[k].im; acc.im -= t.re * x[k].im + t.im * x[k].re; }
+      for (int k = 0; k < i; ++k) { const dc t = Ls[(off + i) * 33 + off + k]; acc.re -= t.re * x[k].re - t.im * x[k].im; acc.im -= t.re * x[k].im + t.im * x[k].re; }
       x[i] = acc;
     }
 #pragma unroll
-    for (int i = 0; i < 32; ++i) invd[((size_t)base + i) * 32 + lane] = x[i];
+    for (int i = 0; i < 16; ++i) Xs[(off + i) * 33 + off + j] = x[i];
   }
+  __syncthreads();
+  {
+    const int j = lane & 15, q = lane >> 4;
+    dc w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = dc_make(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const dc a = Xs[k * 33 + j];                        // A^-1[k][j]
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const dc c = Ls[(16 + i) * 33 + k]; w[i].re += c.re * a.re - c.im * a.im; w[i].im += c.re * a.im + c.im * a.re; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * q + r;
+      dc acc = dc_make(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const dc bi = Xs[(16 + i) * 33 + 16 + k]; acc.re -= bi.re * w[k].re - bi.im * w[k].im; acc.im -= bi.re * w[k].im + bi.im * w[k].re; }
+      Xs[(16 + i) * 33 + j] = acc;
+    }
+  }
+  __syncthreads();
+  for (int idx = lane; idx < 1024; idx += 64) invd[(size_t)base * 32 + idx] = Xs[(idx >> 5) * 33 + (idx & 31)];
 }
 
 __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
