@@ -248,11 +248,11 @@ int ma_bem_plan_set_timing(ma_bem_plan_t* plan, int enable);
 /* out[0]=far kernel, out[1]=near kernel, out[2]=self kernel ms of the last assemble */
 int ma_bem_plan_last_timing(ma_bem_plan_t* plan, double* out3);
 int ma_lu_plan_set_timing(ma_lu_plan_t* plan, int enable);
-/* out[0]=panel (on the look-ahead stream, overlaps out[3]), out[1]=row swaps, out[2]=trsm, out[3]=trailing
- * zgemm, out[4]=right-hand-side and triangular solves (ms); out[5]=number of zgemm launches; out[6]=whole
- * factor+solve on the caller's stream (ms); out[7]=algorithmic flops of those zgemm launches */
+/* out[0]=panel kernels (on the look-ahead streams, overlap out[3]), out[1]=row swaps, out[2]=trsm, out[3]=zgemm launches
+ * of the main lane, out[4]=right-hand-side and triangular solves (ms); out[5]=number of zgemm launches (all lanes);
+ * out[6]=whole factor+solve on the caller's stream (ms); out[7]=zgemm launches of the look-ahead lanes (ms) */
 int ma_lu_plan_last_timing(ma_lu_plan_t* plan, double* out8);
-/* the trailing-update launches out[3] covers: count, algorithmic flops (8 M N K) and C read+write bytes (32 M N) */
+/* the update (zgemm) launches out[3]+out[7] cover: count, algorithmic flops (8 M N K) and C read+write bytes (32 M N) */
 int ma_lu_plan_last_update_stats(ma_lu_plan_t* plan, double* launches, double* flops, double* c_bytes);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ struct ma_lu_plan {
   c64* d_tmp_l[LU_BATCH_MAX] = {};
   c64* d_invd_l[LU_BATCH_MAX] = {};
   int kb = 4;                     // panels per trailing update (MA_LU_KB=1..4): K = kb * nb = 256
-  double gemm_flops = 0.0;        // algorithmic flops of the caller-stream update launches of the last call
+  double gemm_flops = 0.0;        // algorithmic flops of the update launches of the last call
   double gemm_cbytes = 0.0;       // and their algorithmic C read + write bytes
   int last_batch = 1;
   hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {};
@@ -251,7 +251,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   auto blk_end = [&](int g) { int q = blk_last(g) - 1; return k0s[q] + nbs[q]; };   // first column right of block g
   auto gemm = [&](int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_) -> int {
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
-    if (s_ == st) { P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_; }   // the timed (phase 3) launches
+    P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;   // every launch is timed: phase 3 (main lane) or 5 (look-ahead lanes)
     return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m);
   };
 
@@ -270,9 +270,10 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
         if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists_l[m], P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, P->d_invd_l[m], sp))) return rc;
         const c64* T = A + (size_t)k0 * n + k0;
         if ((rc = lu_launch_trsm_mfma(T, n, nb, P->d_invd_l[m], A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
-        if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
         MA_MARK(t2, sp);
-        interval(P, t1, t2, 5);
+        if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
+        MA_MARK(t3, sp);
+        interval(P, t2, t3, 5);
       }
     }
     if (la) MA_HIP(hipEventRecord(P->ev_panel[m], sp));
@@ -410,15 +411,15 @@ int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
     float ms = 0.f;
     MA_HIP(hipEventElapsedTime(&ms, P->ev[v.a], P->ev[v.b]));
     if (v.phase >= 0 && v.phase < 5) out8[v.phase] += ms;
+    else if (v.phase == 5) out8[7] += ms;
     else if (v.phase == 6) out8[6] = ms;
   }
   out8[5] = P->n_gemm_launch;
-  out8[7] = P->gemm_flops;
   return MA_OK;
 }
 
-// Trailing-update launches on the caller's stream in the last call (all systems of the batch): count, algorithmic
-// flops (8 M N K each) and algorithmic C bytes (32 M N each). They are the launches the phase-3 time covers.
+// Update (zgemm) launches of the last call, main lane and look-ahead lanes, all systems of the batch: count, algorithmic
+// flops (8 M N K each) and algorithmic C bytes (32 M N each). Their time is out8[3] + out8[7] of ma_lu_plan_last_timing.
 int ma_lu_plan_last_update_stats(ma_lu_plan_t* P, double* launches, double* flops, double* c_bytes) {
   MA_REQUIRE(P && launches && flops && c_bytes, MA_ERR_INVALID, "NULL argument");
   *launches = P->n_gemm_launch; *flops = P->gemm_flops; *c_bytes = P->gemm_cbytes;
