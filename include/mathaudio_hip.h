@@ -166,6 +166,17 @@ int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r
 int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
 int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
 
+/* math-fem geometric-multigrid smoothers on the COO HelmholtzMatrix (math-fem/src/assembly/helmholtz.rs:22-33,
+ * multigrid/smoother.rs:44-68, 120-160, 163-176). The triplets are summed once into a CSR operator (an ma_csr_t: all
+ * ma_csr_* calls work on it); rows with |a_ii| < 1e-15 are skipped by the sweeps as in the reference.
+ * kind: 0 Gauss-Seidel, 1 Jacobi, 2 symmetric GS -- only Jacobi runs on the device (the GS family is a sequential
+ * recurrence: MA_ERR_UNSUPPORTED). */
+/* the transposed operator as a new handle (apply_transpose of CsrMatrix, csr.rs:420-440) */
+int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out);
+int ma_fem_matrix_create(int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const ma_c64* values, int device, ma_csr_t** out);
+int ma_fem_smooth(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int kind, int iterations, double omega);
+int ma_fem_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r);
+
 /* ------------------------------------------------------------------------------------------
  * Operator boundary and GMRES.
  * Replaces: trait LinearOperator<Complex64> { num_rows, apply(&x) -> y }   math-solvers/src/traits.rs:316-327
@@ -187,6 +198,12 @@ int ma_op_destroy(ma_op_t* op);
 int ma_op_num_rows(const ma_op_t* op, int64_t* n);
 int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);
 int ma_op_apply_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
+/* apply_transpose (y = A^T x) and apply_hermitian (y = A^H x), traits.rs:326-358; dense and CSR operators
+ * (the matrix-free TBEM operator returns MA_ERR_UNSUPPORTED) */
+int ma_op_apply_transpose(ma_op_t* op, const ma_c64* x, ma_c64* y);
+int ma_op_apply_hermitian(ma_op_t* op, const ma_c64* x, ma_c64* y);
+int ma_op_apply_transpose_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
+int ma_op_apply_hermitian_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
 /* Preconditioner boundary: trait Preconditioner<T> { apply(&r) -> z }   math-solvers/src/traits.rs:370-375.
  * The device preconditioners are the AMG smoothers applied from z = 0 (one level of
  * AmgPreconditioner::apply, amg.rs:981-1005, 1068-1087): Jacobi(omega, sweeps) or l1-Jacobi(sweeps) on the CSR

@@ -94,6 +94,9 @@ def lib():
             "ma_csr_residual_dev": [vp, vp, vp, vp, vp],
             "ma_csr_jacobi_dev": [vp, vp, vp, dbl, C.c_int, vp, vp],
             "ma_csr_l1jacobi_dev": [vp, vp, vp, C.c_int, vp, vp],
+            "ma_fem_matrix_create": [i64, i64, vp, vp, vp, C.c_int, P(vp)],
+            "ma_fem_smooth": [vp, vp, vp, C.c_int, C.c_int, dbl],
+            "ma_fem_residual": [vp, vp, vp, vp],
             "ma_op_create_dense": [i64, vp, C.c_int, P(vp)],
             "ma_op_create_dense_dev": [i64, vp, C.c_int, P(vp)],
             "ma_op_create_csr": [vp, P(vp)],
@@ -102,6 +105,11 @@ def lib():
             "ma_op_num_rows": [vp, P(i64)],
             "ma_op_apply": [vp, vp, vp],
             "ma_op_apply_dev": [vp, vp, vp, vp],
+            "ma_op_apply_transpose": [vp, vp, vp],
+            "ma_op_apply_hermitian": [vp, vp, vp],
+            "ma_op_apply_transpose_dev": [vp, vp, vp, vp],
+            "ma_op_apply_hermitian_dev": [vp, vp, vp, vp],
+            "ma_csr_transpose": [vp, P(vp)],
             "ma_gmres": [vp, vp, vp, i32, i32, dbl, vp, vp],
             "ma_precond_create_jacobi": [vp, dbl, i32, P(vp)],
             "ma_precond_create_l1jacobi": [vp, i32, P(vp)],
@@ -336,6 +344,29 @@ class CsrOperator:
             k = np.ascontiguousarray(K, dtype=np.float64); m = np.ascontiguousarray(M, dtype=np.float64)
             check(lib().ma_csr_create_helmholtz(self.n, _vp(self.rp), _vp(self.ci), _vp(k), _vp(m), device, C.byref(self.h)))
 
+    @staticmethod
+    def from_coo(n, rows, cols, values, device=0):
+        """HelmholtzMatrix triplets (helmholtz.rs:22-33) -> operator; duplicates are summed, zero-diagonal rows are skipped by sweeps."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64); cols = np.ascontiguousarray(cols, dtype=np.int64)
+        values = np.ascontiguousarray(values, dtype=np.complex128)
+        self = CsrOperator.__new__(CsrOperator)
+        self.n = int(n); self.rp = None; self.ci = None
+        self.h = C.c_void_p()
+        check(lib().ma_fem_matrix_create(self.n, len(rows), _vp(rows), _vp(cols), _vp(values), device, C.byref(self.h)))
+        return self
+
+    def fem_smooth(self, x, b, kind=1, iterations=2, omega=2.0 / 3.0):
+        """smooth() of math-fem/src/multigrid/smoother.rs:44-68 (Jacobi on the device)."""
+        x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+        check(lib().ma_fem_smooth(self.h, _vp(x), _vp(b), int(kind), int(iterations), float(omega)))
+        return x
+
+    def fem_residual(self, x, b):
+        x = np.ascontiguousarray(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+        r = np.empty(self.n, dtype=np.complex128)
+        check(lib().ma_fem_residual(self.h, _vp(x), _vp(b), _vp(r)))
+        return r
+
     def close(self):
         if self.h:
             lib().ma_csr_destroy(self.h)
@@ -444,6 +475,16 @@ class LinearOperator:
 
     def apply_dev(self, d_x, d_y, stream=0):
         check(lib().ma_op_apply_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream)))
+
+    def apply_transpose(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128); y = np.empty(self.n, dtype=np.complex128)
+        check(lib().ma_op_apply_transpose(self.h, _vp(x), _vp(y)))
+        return y
+
+    def apply_hermitian(self, x):
+        x = np.ascontiguousarray(x, dtype=np.complex128); y = np.empty(self.n, dtype=np.complex128)
+        check(lib().ma_op_apply_hermitian(self.h, _vp(x), _vp(y)))
+        return y
 
 
 def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void csr_diag_kernel(CsrView A, dc* __restrict
   }
   const double nd = hypot(d.re, d.im);
   if (nd > 1e-15) { const double ns = d.re * d.re + d.im * d.im; dinv[row] = dc_make(d.re / ns, -d.im / ns); }   // Complex::inv()
-  else dinv[row] = dc_make(1.0, 0.0);
+  else dinv[row] = dc_make(A.zero_diag_dinv, 0.0);
   l1[row] = sum > 1e-15 ? sum : 1.0;
 }
 

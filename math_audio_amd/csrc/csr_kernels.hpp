@@ -17,6 +17,7 @@ struct CsrView {
   double k2_re, k2_im;         // k^2 of the current frequency (K/M mode)
   const ::ma::dc* dinv;        // 1 / a_ii for the current values
   const double* l1;            // sum_j |a_ij|
+  double zero_diag_dinv;       // 1/a_ii stand-in for |a_ii| <= 1e-15: 1 (amg.rs:400-413) or 0 = leave the row alone (smoother.rs:143-146)
 };
 
 int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st);

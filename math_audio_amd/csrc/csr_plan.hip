@@ -2,6 +2,7 @@
 #include "csr_kernels.hpp"
 #include "ma_device_math.hpp"
 #include <vector>
+#include <algorithm>
 #include <new>
 #include <cmath>
 
@@ -18,10 +19,12 @@ struct ma_csr {
   c64* d_x = nullptr; c64* d_y = nullptr; c64* d_b = nullptr;   // staging for the host-buffer entry points and ping-pong
   double k2_re = 0.0, k2_im = 0.0;
   bool diag_valid = false;
+  double zero_diag_dinv = 1.0;
   CsrView view() const {
     CsrView v{};
     v.n = n; v.nnz = nnz; v.row_ptr = d_rowptr; v.col = d_col; v.val = reinterpret_cast<const dc*>(d_val); v.K = d_K; v.M = d_M;
     v.k2_re = k2_re; v.k2_im = k2_im; v.dinv = reinterpret_cast<const dc*>(d_dinv); v.l1 = d_l1;
+    v.zero_diag_dinv = zero_diag_dinv;
     return v;
   }
 };
@@ -199,5 +202,87 @@ int ma_csr_l1jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps) {
   if (!rc) rc = down(h, x_inout, h->d_x);
   return rc;
 }
+
+// The transposed operator as its own handle (same value mode, same k^2 and zero-diagonal policy): built once on the host
+// by a counting sort of the downloaded pattern. CsrMatrix's LinearOperator::apply_transpose (csr.rs:420-440) is then an
+// SpMV on it -- a scatter with atomics would not be reproducible.
+int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out) {
+  MA_REQUIRE(h && out, MA_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  MA_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)h->n, nnz = (size_t)h->nnz;
+  std::vector<long long> rp(n + 1); std::vector<int> ci(nnz ? nnz : 1);
+  MA_HIP(hipMemcpy(rp.data(), h->d_rowptr, sizeof(long long) * (n + 1), hipMemcpyDeviceToHost));
+  if (nnz) MA_HIP(hipMemcpy(ci.data(), h->d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+  std::vector<c64> val; std::vector<double> K, M;
+  if (h->km) { K.resize(nnz ? nnz : 1); M.resize(nnz ? nnz : 1); if (nnz) { MA_HIP(hipMemcpy(K.data(), h->d_K, sizeof(double) * nnz, hipMemcpyDeviceToHost)); MA_HIP(hipMemcpy(M.data(), h->d_M, sizeof(double) * nnz, hipMemcpyDeviceToHost)); } }
+  else { val.resize(nnz ? nnz : 1); if (nnz) MA_HIP(hipMemcpy(val.data(), h->d_val, sizeof(c64) * nnz, hipMemcpyDeviceToHost)); }
+  std::vector<int64_t> trp(n + 1, 0), tci(nnz ? nnz : 1);
+  for (size_t t = 0; t < nnz; ++t) trp[(size_t)ci[t] + 1]++;
+  for (size_t i = 0; i < n; ++i) trp[i + 1] += trp[i];
+  std::vector<int64_t> pos(trp.begin(), trp.end() - 1);
+  std::vector<c64> tval(val.size()); std::vector<double> tK(K.size()), tM(M.size());
+  for (size_t i = 0; i < n; ++i)
+    for (long long t = rp[i]; t < rp[i + 1]; ++t) {       // rows ascending: the transposed rows come out with sorted columns
+      const size_t q = (size_t)pos[(size_t)ci[(size_t)t]]++;
+      tci[q] = (int64_t)i;
+      if (h->km) { tK[q] = K[(size_t)t]; tM[q] = M[(size_t)t]; } else tval[q] = val[(size_t)t];
+    }
+  int rc = h->km ? ma_csr_create_helmholtz((int64_t)n, trp.data(), tci.data(), tK.data(), tM.data(), h->device, out)
+                 : ma_csr_create((int64_t)n, trp.data(), tci.data(), reinterpret_cast<const ma_c64*>(tval.data()), h->device, out);
+  if (rc) return rc;
+  (*out)->k2_re = h->k2_re; (*out)->k2_im = h->k2_im; (*out)->zero_diag_dinv = h->zero_diag_dinv; (*out)->diag_valid = false;
+  return MA_OK;
+}
+
+// ------------------------------------------------------------------ math-fem HelmholtzMatrix (COO) and its smoothers
+// HelmholtzMatrix { rows, cols, values, dim } (math-fem/src/assembly/helmholtz.rs:22-33) holds unsummed triplets;
+// the reference's sweeps sum duplicates on the fly (smoother.rs:78-92, 124-137). Here they are summed once, in
+// triplet order, into a CSR operator; rows whose diagonal is < 1e-15 are left untouched by the sweeps
+// (smoother.rs:94-96, 143-146).
+int ma_fem_matrix_create(int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const ma_c64* values, int device, ma_csr_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  MA_REQUIRE(n > 0 && nnz >= 0 && (nnz == 0 || (rows && cols && values)), MA_ERR_INVALID, "bad COO arguments");
+  std::vector<int64_t> cnt((size_t)n + 1, 0);
+  for (int64_t t = 0; t < nnz; ++t) {
+    MA_REQUIRE(rows[t] >= 0 && rows[t] < n && cols[t] >= 0 && cols[t] < n, MA_ERR_INVALID, "triplet %lld is out of range", (long long)t);
+    cnt[(size_t)rows[t] + 1]++;
+  }
+  for (int64_t i = 0; i < n; ++i) cnt[(size_t)i + 1] += cnt[(size_t)i];
+  // bucket by row (stable), then sort each row by column (stable) and merge equal columns in triplet order
+  std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1), order((size_t)nnz);
+  for (int64_t t = 0; t < nnz; ++t) order[(size_t)pos[(size_t)rows[t]]++] = t;
+  std::vector<int64_t> rp((size_t)n + 1, 0), ci; std::vector<ma_c64> vv;
+  ci.reserve((size_t)nnz); vv.reserve((size_t)nnz);
+  for (int64_t i = 0; i < n; ++i) {
+    auto b = order.begin() + cnt[(size_t)i], e = order.begin() + cnt[(size_t)i + 1];
+    std::stable_sort(b, e, [&](int64_t a, int64_t c) { return cols[a] < cols[c]; });
+    for (auto it = b; it != e; ++it) {
+      const int64_t t = *it;
+      if (it != b && cols[t] == ci.back()) { vv.back().re += values[t].re; vv.back().im += values[t].im; }
+      else { ci.push_back(cols[t]); vv.push_back(values[t]); }
+    }
+    rp[(size_t)i + 1] = (int64_t)ci.size();
+  }
+  if (ci.empty()) { ci.push_back(0); vv.push_back(ma_c64{0.0, 0.0}); for (int64_t i = 1; i <= n; ++i) rp[(size_t)i] = 1; }   // an all-zero operator still needs storage
+  int rc = ma_csr_create(n, rp.data(), ci.data(), vv.data(), device, out);
+  if (rc) return rc;
+  (*out)->zero_diag_dinv = 0.0;
+  (*out)->diag_valid = false;
+  return MA_OK;
+}
+
+// smooth(matrix, x, b, config) (smoother.rs:44-68). kind 1 = Jacobi: x <- omega (b - sigma)/a_ii + (1 - omega) x, `iterations`
+// times. kind 0 (Gauss-Seidel, the reference's default) and 2 (symmetric GS) are sequential recurrences over the rows
+// in index order: they are not offered on the device (MA_ERR_UNSUPPORTED), use Jacobi or keep the CPU path.
+int ma_fem_smooth(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int kind, int iterations, double omega) {
+  MA_REQUIRE(h && x_inout && b, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(kind == 1, MA_ERR_UNSUPPORTED, "smoother kind %d (Gauss-Seidel family) is a sequential sweep; the device offers Jacobi (kind 1)", kind);
+  return ma_csr_jacobi(h, x_inout, b, omega, iterations);
+}
+
+// compute_residual (smoother.rs:163-176): r = b - A x
+int ma_fem_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r) { return ma_csr_residual(h, x, b, r); }
 
 }  // extern "C"

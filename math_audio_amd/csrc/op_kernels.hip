@@ -192,7 +192,62 @@ __global__ __launch_bounds__(256) void sub_inplace_kernel(long long n, dc* __res
   corr[q] = dc_make(corr[q].re - a13[q].re, corr[q].im - a13[q].im);
 }
 
+// y = A^T x (CONJ: A^H x) for a dense row-major A: lane = column (coalesced along the rows of A), the 4 wavefronts of a
+// workgroup take every 4th row of the workgroup's row chunk, partials[chunk][col] are summed by zgemv_t_finish in chunk
+// order -- reproducible, unlike a scatter with atomics.
+#define ZT_CHUNKS 16
+template <bool CONJ>
+__global__ __launch_bounds__(256) void zgemv_t_kernel(long long n, const dc* __restrict__ A, const dc* __restrict__ x, dc* __restrict__ partial) {
+  __shared__ dc red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long col = (long long)blockIdx.x * 64 + lane;
+  const long long rpc = (n + ZT_CHUNKS - 1) / ZT_CHUNKS;
+  const long long r0 = (long long)blockIdx.y * rpc, r1 = min(n, r0 + rpc);
+  double sr = 0.0, si = 0.0;
+  if (col < n)
+    for (long long r = r0 + wave; r < r1; r += 4) {
+      const dc a = A[r * n + col]; const dc v = x[r];
+      const double ai = CONJ ? -a.im : a.im;
+      sr += a.re * v.re - ai * v.im; si += a.re * v.im + ai * v.re;
+    }
+  red[wave][lane] = dc_make(sr, si);
+  __syncthreads();
+  if (wave == 0 && col < n) {
+    dc t = red[0][lane];
+    for (int w = 1; w < 4; ++w) { t.re += red[w][lane].re; t.im += red[w][lane].im; }
+    partial[(long long)blockIdx.y * n + col] = t;
+  }
+}
+__global__ __launch_bounds__(256) void zgemv_t_finish_kernel(long long n, const dc* __restrict__ partial, dc* __restrict__ y) {
+  const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (col >= n) return;
+  dc t = partial[col];
+  for (int c = 1; c < ZT_CHUNKS; ++c) { const dc p = partial[(long long)c * n + col]; t.re += p.re; t.im += p.im; }
+  y[col] = t;
+}
+__global__ __launch_bounds__(256) void conj_kernel(long long n, const dc* in, dc* out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const dc v = in[i]; out[i] = dc_make(v.re, -v.im); }
+}
+
 // ------------------------------------------------------------------ launchers
+// partial: ZT_CHUNKS * n entries
+int op_launch_zgemv_t(long long n, const c64* A, const c64* x, c64* partial, c64* y, bool conj, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  dim3 grid((unsigned)((n + 63) / 64), ZT_CHUNKS);
+  if (conj) hipLaunchKernelGGL(zgemv_t_kernel<true>, grid, dim3(256), 0, st, n, reinterpret_cast<const dc*>(A), reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
+  else hipLaunchKernelGGL(zgemv_t_kernel<false>, grid, dim3(256), 0, st, n, reinterpret_cast<const dc*>(A), reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
+  hipLaunchKernelGGL(zgemv_t_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(partial), reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_zgemv_t_chunks() { return ZT_CHUNKS; }
+int op_launch_conj(long long n, const c64* in, c64* out, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(in), reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
 int op_launch_zgemv(long long n, const c64* A, const c64* x, c64* y, hipStream_t st) {
   if (n <= 0) return MA_OK;
   hipLaunchKernelGGL(zgemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(A), reinterpret_cast<const dc*>(x),

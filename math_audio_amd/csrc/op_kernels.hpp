@@ -6,6 +6,10 @@ namespace ma {
 
 int op_upload_tables(const double tri13_scaled[13][3]);
 int op_launch_zgemv(long long n, const c64* A, const c64* x, c64* y, hipStream_t st);
+// y = A^T x or A^H x; partial holds op_zgemv_t_chunks() * n entries
+int op_launch_zgemv_t(long long n, const c64* A, const c64* x, c64* partial, c64* y, bool conj, hipStream_t st);
+int op_zgemv_t_chunks();
+int op_launch_conj(long long n, const c64* in, c64* out, hipStream_t st);
 // mode 0: out = conj(x).y ; mode 1: out = ||x||_2 (real part)
 int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st);
 int op_launch_axpy_dev(long long n, const c64* alpha_dev, double sgn, const c64* x, c64* y, hipStream_t st);

@@ -13,6 +13,8 @@ typedef std::complex<double> cplx;
 struct ma_csr;   // csr_plan.hip
 extern "C" int ma_csr_spmv_dev(ma_csr* h, const void* d_x, void* d_y, void* stream);
 extern "C" int ma_csr_num_rows(const ma_csr* h, int64_t* n, int64_t* nnz);
+extern "C" int ma_csr_transpose(ma_csr* h, ma_csr** out);
+extern "C" int ma_csr_destroy(ma_csr* h);
 
 struct ma_op {
   int kind = 0;                 // 0 dense, 1 csr, 2 on-the-fly TBEM
@@ -20,6 +22,9 @@ struct ma_op {
   long long n = 0;
   c64* dA = nullptr; bool own_A = false;
   ma_csr* csr = nullptr;
+  ma_csr* csr_t = nullptr;      // transposed CSR operator, built at the first apply_transpose (owned)
+  c64* d_tpart = nullptr;       // dense A^T x: per-row-chunk partial sums
+  c64* d_cx = nullptr;          // conj(x) / pre-conjugation result of the hermitian CSR apply
   // TBEM
   ma_bem_plan* plan = nullptr; BemPhys ph{}; int row0 = 0, row1 = 0, nchunks = 1;
   c64* d_corr = nullptr; c64* d_diag = nullptr; c64* d_partial = nullptr;
@@ -30,8 +35,9 @@ struct ma_op {
 namespace {
 void op_free(ma_op* o) {
   if (o->own_A && o->dA) (void)hipFree(o->dA);
-  void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y};
+  void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y, o->d_tpart, o->d_cx};
   for (void* q : p) if (q) (void)hipFree(q);
+  if (o->csr_t) (void)ma_csr_destroy(o->csr_t);
 }
 int op_stage(ma_op* o) {
   MA_HIP(hipMalloc(&o->d_x, sizeof(c64) * (size_t)o->n));
@@ -157,6 +163,40 @@ int ma_op_apply(ma_op_t* o, const ma_c64* x, ma_c64* y) {
   MA_HIP(hipMemcpy(y, o->d_y, sizeof(c64) * (size_t)o->n, hipMemcpyDeviceToHost));
   return MA_OK;
 }
+
+// LinearOperator::apply_transpose (y = A^T x) and apply_hermitian (y = A^H x = conj(A^T conj(x)), traits.rs:326-358),
+// device pointers (x and y distinct). Dense: DenseOperator's matrix.t().dot(x) (fmm_interface.rs:40-48); CSR: an SpMV on
+// the transposed operator, built once. The matrix-free TBEM operator has no transpose on the device (the reference's
+// GMRES path never asks for one): MA_ERR_UNSUPPORTED.
+static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStream_t st) {
+  MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(o->kind != 2, MA_ERR_UNSUPPORTED, "the matrix-free TBEM operator has no transpose on the device");
+  MA_HIP(hipSetDevice(o->device));
+  if (o->kind == 0) {
+    if (!o->d_tpart) MA_HIP(hipMalloc(&o->d_tpart, sizeof(c64) * (size_t)op_zgemv_t_chunks() * (size_t)o->n));
+    return op_launch_zgemv_t(o->n, o->dA, (const c64*)d_x, o->d_tpart, (c64*)d_y, herm, st);
+  }
+  if (!o->csr_t) { int rc = ma_csr_transpose(o->csr, &o->csr_t); if (rc) return rc; }
+  if (!herm) return ma_csr_spmv_dev(o->csr_t, d_x, d_y, st);
+  if (!o->d_cx) MA_HIP(hipMalloc(&o->d_cx, sizeof(c64) * (size_t)o->n));
+  int rc = op_launch_conj(o->n, (const c64*)d_x, o->d_cx, st);
+  if (!rc) rc = ma_csr_spmv_dev(o->csr_t, o->d_cx, d_y, st);
+  if (!rc) rc = op_launch_conj(o->n, (const c64*)d_y, (c64*)d_y, st);
+  return rc;
+}
+int ma_op_apply_transpose_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) { return op_apply_t(o, d_x, d_y, false, (hipStream_t)stream); }
+int ma_op_apply_hermitian_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) { return op_apply_t(o, d_x, d_y, true, (hipStream_t)stream); }
+static int op_apply_t_host(ma_op_t* o, const ma_c64* x, ma_c64* y, bool herm) {
+  MA_REQUIRE(o && x && y, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(o->device));
+  MA_HIP(hipMemcpy(o->d_x, x, sizeof(c64) * (size_t)o->n, hipMemcpyHostToDevice));
+  int rc = op_apply_t(o, o->d_x, o->d_y, herm, nullptr);
+  if (rc) return rc;
+  MA_HIP(hipMemcpy(y, o->d_y, sizeof(c64) * (size_t)o->n, hipMemcpyDeviceToHost));
+  return MA_OK;
+}
+int ma_op_apply_transpose(ma_op_t* o, const ma_c64* x, ma_c64* y) { return op_apply_t_host(o, x, y, false); }
+int ma_op_apply_hermitian(ma_op_t* o, const ma_c64* x, ma_c64* y) { return op_apply_t_host(o, x, y, true); }
 
 // ------------------------------------------------------------------ Preconditioner boundary (traits.rs:370-375)
 // apply(r) -> z. The device preconditioners are the one-level smoothers of the AMG V-cycle applied from z = 0

@@ -100,3 +100,34 @@ def test_csr_argument_errors(gpu):
     with pytest.raises(ma.MaError):
         A.set_wavenumber(1.0)                                      # complex-valued handle has no K/M
     A.close()
+
+
+def test_fem_coo_smoother_matches_oracle(gpu):
+    """math-fem's HelmholtzMatrix is COO with unsummed duplicates (helmholtz.rs:22-33); Jacobi sweep and residual of
+    multigrid/smoother.rs:120-176 vs the CPU restatement, including a zero-diagonal row (left untouched, :143-146)."""
+    rng = np.random.default_rng(12)
+    n = 400
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        if i != 7:                                        # row 7 has no diagonal entry at all
+            for part in (2.0 + 0.3j, 1.5 - 0.1j):         # the diagonal arrives as two triplets
+                rows.append(i); cols.append(i); vals.append(part)
+        for j in rng.choice(n, size=5, replace=False):
+            if j != i:
+                for _ in range(2):                        # duplicated off-diagonals
+                    rows.append(i); cols.append(int(j)); vals.append(0.1 * (rng.standard_normal() + 1j * rng.standard_normal()))
+    perm = rng.permutation(len(rows))                     # triplet order is arbitrary
+    rows = np.array(rows)[perm]; cols = np.array(cols)[perm]; vals = np.array(vals)[perm]
+    x = _x0(n); b = np.cos(0.3 * np.arange(n)) + 0.5j
+    A = ma.CsrOperator.from_coo(n, rows, cols, vals)
+    r_ref = O.fem_residual(n, rows, cols, vals, x, b)
+    assert np.abs(A.fem_residual(x, b) - r_ref).max() <= 1e-13 * np.abs(r_ref).max()
+    for omega, its in ((2.0 / 3.0, 2), (0.8, 3)):
+        x_ref = O.fem_smooth(n, rows, cols, vals, x, b, kind=1, iterations=its, omega=omega)
+        x_dev = A.fem_smooth(x, b, kind=1, iterations=its, omega=omega)
+        assert np.abs(x_dev - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+        assert x_dev[7] == x[7]                           # zero diagonal: skipped
+    with pytest.raises(ma.MaError) as ei:                 # Gauss-Seidel is a sequential sweep: refused, never emulated
+        A.fem_smooth(x, b, kind=0)
+    assert ei.value.status == ma.MA_ERR_UNSUPPORTED
+    A.close()

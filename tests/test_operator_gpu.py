@@ -140,3 +140,41 @@ def test_diagonal_preconditioner_known_answers(gpu):               # preconditio
     pre = ma.Preconditioner(a, kind="jacobi", omega=1.0, sweeps=1)
     assert np.allclose(pre.apply([4, 4]), [1, 2], atol=1e-10)
     pre.close(); a.close()
+
+
+def test_apply_transpose_and_hermitian(gpu):
+    """LinearOperator::apply_transpose / apply_hermitian (traits.rs:326-358) for the dense and the CSR operator;
+    hermitian == conj(A^T conj(x)) exactly as the trait's default implementation states it."""
+    rng = np.random.default_rng(31)
+    n = 777
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    op = ma.LinearOperator.dense(A)
+    scale = np.abs(A.T @ x).max()
+    assert np.abs(op.apply_transpose(x) - A.T @ x).max() <= 1e-12 * scale
+    assert np.abs(op.apply_hermitian(x) - A.conj().T @ x).max() <= 1e-12 * scale
+    op.close()
+    # unsymmetric sparse operator with empty rows and columns
+    dens = 0.02
+    S = np.where(rng.random((n, n)) < dens, A, 0.0); S[5, :] = 0.0; S[:, 9] = 0.0
+    rp = np.concatenate(([0], np.cumsum((S != 0).sum(axis=1)))); ci = np.nonzero(S)[1]; vals = S[S != 0]
+    c = ma.CsrOperator(rp, ci, values=vals)
+    ops = ma.LinearOperator.csr(c)
+    assert np.abs(ops.apply(x) - S @ x).max() <= 1e-12 * np.abs(S @ x).max()
+    assert np.abs(ops.apply_transpose(x) - S.T @ x).max() <= 1e-12 * np.abs(S.T @ x).max()
+    assert np.abs(ops.apply_hermitian(x) - S.conj().T @ x).max() <= 1e-12 * np.abs(S.T @ x).max()
+    assert np.array_equal(ops.apply_hermitian(x), np.conj(ops.apply_transpose(np.conj(x))))
+    ops.close(); c.close()
+    # K/M mode keeps its wavenumber through the transpose
+    nodes, rp2, ci2, K, M = fem.helmholtz_box(5, 4, 3)
+    h = ma.CsrOperator(rp2, ci2, K=K, M=M); h.set_wavenumber(1.3 + 0.2j)
+    oph = ma.LinearOperator.csr(h)
+    x2 = _xvec(len(rp2) - 1)
+    ref = O.csr_matvec(rp2, ci2, O.helmholtz_values(K, M, 1.3 + 0.2j), x2)     # K, M symmetric: A^T = A
+    assert np.abs(oph.apply_transpose(x2) - ref).max() <= 1e-12 * np.abs(ref).max()
+    oph.close(); h.close()
+
+
+def _xvec(n):
+    i = np.arange(n)
+    return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
