@@ -82,8 +82,9 @@ typedef struct {
  * (and through it build_tbem_system :45, _bounded :64, _scaled :85; callers bem_solver.rs:367,
  *  bin/qa_suite.rs:228,355).
  * A: num_dofs*num_dofs row-major [[source_dof, field_dof]] (tbem.rs:340), overwritten.
- * rhs: num_dofs, overwritten (TbemSystem.rhs: BC contributions; zero for rigid scatterers).
- * MA_ERR_UNSUPPORTED: Quad4 elements; non-zero BC values (the rhs_contribution path).
+ * rhs: num_dofs, overwritten (TbemSystem.rhs: free-term shares and rhs_contributions of the elements that carry
+ *      non-zero boundary values, tbem.rs:273-304, regular.rs:157-177, singular.rs:360-392; zero for rigid scatterers).
+ * MA_ERR_UNSUPPORTED: Quad4 elements.
  * ------------------------------------------------------------------------------------------ */
 int ma_bem_assemble_tbem(const ma_mesh_t* mesh, const ma_physics_t* physics,
                          double beta_re, double beta_im, ma_c64* A, ma_c64* rhs);

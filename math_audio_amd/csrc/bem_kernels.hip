@@ -184,24 +184,10 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// PROBE = true: instead of the matrix entry, write the leaf count and the four raw integrals
-// (G, H, H^T, E) of pair pid to out[5*pid..] — used by the parity tests on arbitrary (i != j) pairs.
-template <int MODE>   // 0: write A[i][j]; 1: probe {leaves, G, H, H^T, E} to out[5 pid]; 2: coefficient to out[pid]
-__global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs,
-                                                        long long npairs, dc* __restrict__ A) {
-  __shared__ double s_leaf[4][MA_MAX_LEAVES][6];
-  __shared__ double s_next[4][MA_MAX_NSE][6];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long pid = (long long)blockIdx.x * 4 + wave;
-  if (pid >= npairs) return;                         // whole wave leaves; no block barrier below
-  const int2 pr = pairs[pid];
-  const int i = pr.x, j = pr.y;
-  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
-  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
-  double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
-  const double area = g.area[j];
-
-  // ---- generate_subelements (singular.rs:497-660), one lane per sub-triangle of the level
+// generate_subelements (singular.rs:497-660) for the Tri3 panel with vertices v seen from (cx, cy, cz): one lane per
+// sub-triangle of the level; the leaves (local vertex coordinates) land in s_leaf[wave][0..nleaf). Returns nleaf.
+__device__ __forceinline__ int near_build_leaves(const double* v, double area, double cx, double cy, double cz, int wave, int lane,
+                                                 double (*s_leaf)[MA_MAX_LEAVES][6], double (*s_next)[MA_MAX_NSE][6]) {
   double s0 = 0.0, t0 = 0.0, s1 = 1.0, t1 = 0.0, s2 = 0.0, t2 = 1.0;
   int nsel = 1, nleaf = 0;
   double faclin = 2.0;
@@ -257,6 +243,28 @@ __global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, c
     wave_lds_sync();
   }
   wave_lds_sync();
+
+  return nleaf;
+}
+
+// PROBE = true: instead of the matrix entry, write the leaf count and the four raw integrals
+// (G, H, H^T, E) of pair pid to out[5*pid..] — used by the parity tests on arbitrary (i != j) pairs.
+template <int MODE>   // 0: write A[i][j]; 1: probe {leaves, G, H, H^T, E} to out[5 pid]; 2: coefficient to out[pid]
+__global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs,
+                                                        long long npairs, dc* __restrict__ A) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][6];
+  __shared__ double s_next[4][MA_MAX_NSE][6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;                         // whole wave leaves; no block barrier below
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
+  const double area = g.area[j];
+
+  const int nleaf = near_build_leaves(v, area, cx, cy, cz, wave, lane, s_leaf, s_next);
 
   // ---- integrate: tasks = (leaf, point); affine map of the 13-point rule into each leaf
   // (regular.rs:76-96), shape functions of the parent triangle (regular.rs:193-260).
@@ -432,6 +440,222 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
   }
 }
 
+// ------------------------------------------------------------------ boundary values on the right-hand side
+// rhs_contribution of regular.rs:157-177 / singular.rs:360-392 and the free-term share of add_free_terms
+// (tbem.rs:273-304), for panels that carry non-zero boundary values (radiation problems). Per quadrature point the
+// reference adds  K(point) * zb(point),  K = gamma tau G + beta_p dG/dn_x  (velocity) or -(gamma tau dG/dn_y + beta_p E)
+// (pressure),  zb = sum_{a < min(3, len)} bc[a] N_a(point)  -- with a single value only N_0 weighs it -- and
+// beta_p = i h / k, the PhysicsParams' own coupling, not the beta the system was built with (regular.rs:168).
+// Three passes mirror the matrix kernels (far 13-point rule, subdivided near pairs, singular self term), each leaves a
+// deterministic per-row / per-pair partial, and tbem_rhs_finish_kernel adds them up in a fixed order.
+__device__ __forceinline__ dc green_point_k(double dx, double dy, double dz, double w4pi, double k, double k2,
+                                            double nyx, double nyy, double nyz, double nxx, double nxy, double nxz,
+                                            double m, int fbc, double gt, double bp) {
+  const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+  if (!(r2 >= 1e-30)) return dc_make(0.0, 0.0);
+  double r, ri; sqrt_rsqrt(r2, r, ri);
+  double sn, cs; sincos_fast(k * r, sn, cs);
+  const double gsc = w4pi * ri;
+  const double gre = cs * gsc, gim = sn * gsc;
+  const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
+  const double a = (dx * nyx + dy * nyy + dz * nyz) * ri;
+  const double b = -((dx * nxx + dy * nxy + dz * nxz) * ri);
+  if (fbc == 0) {                                       // gamma tau zg + (i bp) zht
+    const double htre = bre * b, htim = bim * b;
+    return dc_make(gt * gre - bp * htim, gt * gim + bp * htre);
+  }
+  const double rq = a * b, ri2 = ri * ri;               // -(gamma tau zhh + (i bp) ze)
+  const double fr = (3.0 * ri2 - k2) * rq + m * ri2, fi = -(k * ri) * (3.0 * rq + m);
+  const double ere = gre * fr - gim * fi, eim = gre * fi + gim * fr;
+  const double hre = bre * a, him = bim * a;
+  return dc_make(-(gt * hre - bp * eim), -(gt * him + bp * ere));
+}
+__device__ __forceinline__ dc bc_combine(const BemBc& bc, int j, const dc acc[3]) {
+  const int len = min(bc.len[j], 3);
+  dc t = dc_make(0.0, 0.0);
+  for (int a = 0; a < len; ++a) { const dc v = bc.val[4 * j + a]; t.re += v.re * acc[a].re - v.im * acc[a].im; t.im += v.re * acc[a].im + v.im * acc[a].re; }
+  return t;
+}
+
+// far pairs: one wavefront per collocation row, lanes stride over the field panels that carry values
+__global__ __launch_bounds__(256) void tbem_rhs_far_kernel(BemGeom g, BemPhys ph, BemBc bc, dc* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= g.np) return;
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+  double sre = 0.0, sim = 0.0;
+  for (int j = lane; j < g.np; j += 64) {
+    if (!bc.nz[j] || j == i || pair_is_near(g, i, j)) continue;
+    const int fbc = g.bc_type[j];
+    const double nyx = g.ny[0][j], nyy = g.ny[1][j], nyz = g.ny[2][j];
+    const double e1x = g.e1[0][j], e1y = g.e1[1][j], e1z = g.e1[2][j];
+    const double e2x = g.e2[0][j], e2y = g.e2[1][j], e2z = g.e2[2][j];
+    const double d0x = g.p0[0][j] - cx, d0y = g.p0[1][j] - cy, d0z = g.p0[2][j] - cz;
+    const double jw = g.jac[j] * MA_INV4PI;
+    const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+    dc acc[3] = {dc_make(0, 0), dc_make(0, 0), dc_make(0, 0)};
+    for (int q = 0; q < 13; ++q) {
+      const double xi = c_tri13[q][0], eta = c_tri13[q][1], w = c_tri13[q][2];
+      const double dx = __builtin_fma(eta, e2x, __builtin_fma(xi, e1x, d0x));
+      const double dy = __builtin_fma(eta, e2y, __builtin_fma(xi, e1y, d0y));
+      const double dz = __builtin_fma(eta, e2z, __builtin_fma(xi, e1z, d0z));
+      const dc kv = green_point_k(dx, dy, dz, w * jw, k, k2, nyx, nyy, nyz, nxx, nxy, nxz, m, fbc, gt, bp);
+      const double n0 = 1.0 - xi - eta;
+      acc[0].re += n0 * kv.re; acc[0].im += n0 * kv.im;
+      acc[1].re += xi * kv.re; acc[1].im += xi * kv.im;
+      acc[2].re += eta * kv.re; acc[2].im += eta * kv.im;
+    }
+    const dc t = bc_combine(bc, j, acc);
+    sre += t.re; sim += t.im;
+  }
+  sre = wave_sum(sre); sim = wave_sum(sim);
+  if (lane == 0) out[i] = dc_make(sre, sim);
+}
+
+// near pairs: the leaves of tbem_near_kernel, weighted
+__global__ __launch_bounds__(256) void tbem_rhs_near_kernel(BemGeom g, BemPhys ph, BemBc bc, const int2* __restrict__ pairs, long long npairs,
+                                                            dc* __restrict__ out) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][6];
+  __shared__ double s_next[4][MA_MAX_NSE][6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  if (!bc.nz[j]) { if (lane == 0) out[pid] = dc_make(0.0, 0.0); return; }
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
+  const int nleaf = near_build_leaves(v, g.area[j], cx, cy, cz, wave, lane, s_leaf, s_next);
+  const double e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
+  const double e2x = v[6] - v[0], e2y = v[7] - v[1], e2z = v[8] - v[2];
+  const double nyx = g.ny[0][j], nyy = g.ny[1][j], nyz = g.ny[2][j];
+  const double jw = g.jac[j] * MA_INV4PI;
+  const double d0x = v[0] - cx, d0y = v[1] - cy, d0z = v[2] - cz;
+  const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+  const int fbc = g.bc_type[j];
+  dc acc[3] = {dc_make(0, 0), dc_make(0, 0), dc_make(0, 0)};
+  const int ntask = nleaf * 13;
+  for (int t = lane; t < ntask; t += 64) {
+    const int lf = t / 13, q = t - lf * 13;
+    const double* L = s_leaf[wave][lf];
+    const double a0 = L[0], b0 = L[1], a1 = L[2], b1 = L[3], a2 = L[4], b2 = L[5];
+    const double xi = c_tri13[q][0], eta = c_tri13[q][1], w = c_tri13[q][2];
+    const double l0 = 1.0 - xi - eta;
+    const double xio = a0 * l0 + a1 * xi + a2 * eta;
+    const double eto = b0 * l0 + b1 * xi + b2 * eta;
+    const double det = __builtin_fabs((a1 - a0) * (b2 - b0) - (a2 - a0) * (b1 - b0));
+    const double dx = __builtin_fma(eto, e2x, __builtin_fma(xio, e1x, d0x));
+    const double dy = __builtin_fma(eto, e2y, __builtin_fma(xio, e1y, d0y));
+    const double dz = __builtin_fma(eto, e2z, __builtin_fma(xio, e1z, d0z));
+    const dc kv = green_point_k(dx, dy, dz, w * det * jw, k, k2, nyx, nyy, nyz, nxx, nxy, nxz, m, fbc, gt, bp);
+    const double n0 = 1.0 - xio - eto;
+    acc[0].re += n0 * kv.re; acc[0].im += n0 * kv.im;
+    acc[1].re += xio * kv.re; acc[1].im += xio * kv.im;
+    acc[2].re += eto * kv.re; acc[2].im += eto * kv.im;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { acc[a].re = wave_sum(acc[a].re); acc[a].im = wave_sum(acc[a].im); }
+  if (lane == 0) out[pid] = bc_combine(bc, j, acc);
+}
+
+// self term, velocity values: the collapsed-square sub-triangle points of singular.rs:257-357, weighted (the edge line
+// integral carries no boundary value). Pressure values use the finished integrals (singular.rs:380-392): finish kernel.
+__global__ __launch_bounds__(256) void tbem_rhs_self_kernel(BemGeom g, BemPhys ph, BemBc bc, dc* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + wave;
+  if (e >= g.np) return;
+  if (!bc.nz[e] || g.bc_type[e] != 0) { if (lane == 0) out[e] = dc_make(0.0, 0.0); return; }
+  const double cx = g.c[0][e], cy = g.c[1][e], cz = g.c[2][e];
+  const double nxx = g.nx[0][e], nxy = g.nx[1][e], nxz = g.nx[2][e];
+  const double P[3][3] = {{g.p0[0][e], g.p0[1][e], g.p0[2][e]}, {g.p1[0][e], g.p1[1][e], g.p1[2][e]}, {g.p2[0][e], g.p2[1][e], g.p2[2][e]}};
+  const double nyx = g.ny[0][e], nyy = g.ny[1][e], nyz = g.ny[2][e];
+  const double jac = g.jac[e];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+  double el = 0.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int b = (a + 1) % 3;
+    double ddx = P[b][0] - P[a][0], ddy = P[b][1] - P[a][1], ddz = P[b][2] - P[a][2];
+    el += __builtin_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+  }
+  const double ka = ph.k * (el / 3.0);
+  int ngausin, nsec2;
+  if (ka < 0.3)      { ngausin = 4; nsec2 = 2; }
+  else if (ka < 1.0) { ngausin = 5; nsec2 = 2; }
+  else if (ka < 2.0) { ngausin = 6; nsec2 = 3; }
+  else               { ngausin = 7; nsec2 = 4; }
+  const int so = c_gl_index[ngausin][0], ns = c_gl_index[ngausin][1];
+  const int per_edge = nsec2 * ns * ns;
+  const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+  dc acc[3] = {dc_make(0, 0), dc_make(0, 0), dc_make(0, 0)};
+  for (int t = lane; t < 3 * per_edge; t += 64) {
+    const int ieg = t / per_edge, v2 = t - ieg * per_edge;
+    const int ig1 = (ieg + 1) % 3, ig2 = ieg + 3;
+    const int isec = v2 / (ns * ns);
+    const int ij = v2 - isec * ns * ns;
+    const int ii = ij / ns, jj = ij - ii * ns;
+    const double aresub = 1.0 / 24.0 / (double)nsec2;
+    const double ss0 = 1.0 / 3.0, ts0 = 1.0 / 3.0;
+    double ss1, ss2, ts1, ts2;
+    if (isec == 0) { ss1 = c_csi6[ieg]; ss2 = c_csi6[ig2]; ts1 = c_eta6[ieg]; ts2 = c_eta6[ig2]; }
+    else           { ss1 = c_csi6[ig2]; ss2 = c_csi6[ig1]; ts1 = c_eta6[ig2]; ts2 = c_eta6[ig1]; }
+    const double sga = c_gl_x[so + ii], tga = c_gl_x[so + jj];
+    const double wei = c_gl_w[so + ii] * c_gl_w[so + jj];
+    const double sgg = 0.5 * (1.0 - sga) * ss0 + 0.25 * (1.0 + sga) * ((1.0 - tga) * ss1 + (1.0 + tga) * ss2);
+    const double tgg = 0.5 * (1.0 - sga) * ts0 + 0.25 * (1.0 + sga) * ((1.0 - tga) * ts1 + (1.0 + tga) * ts2);
+    const double n0 = 1.0 - sgg - tgg;
+    const double dx = (n0 * P[0][0] + sgg * P[1][0] + tgg * P[2][0]) - cx;
+    const double dy = (n0 * P[0][1] + sgg * P[1][1] + tgg * P[2][1]) - cy;
+    const double dz = (n0 * P[0][2] + sgg * P[1][2] + tgg * P[2][2]) - cz;
+    const double wga = wei * (1.0 + sga) * aresub * jac;
+    const dc kv = green_point_k(dx, dy, dz, wga * MA_INV4PI, k, k2, nyx, nyy, nyz, nxx, nxy, nxz, m, 0, gt, bp);
+    acc[0].re += n0 * kv.re; acc[0].im += n0 * kv.im;
+    acc[1].re += sgg * kv.re; acc[1].im += sgg * kv.im;
+    acc[2].re += tgg * kv.re; acc[2].im += tgg * kv.im;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { acc[a].re = wave_sum(acc[a].re); acc[a].im = wave_sum(acc[a].im); }
+  if (lane == 0) out[e] = bc_combine(bc, e, acc);
+}
+
+// rhs[dof_i] = free-term share + far[i] + sum of the row's near pairs (in list order) + self[i]; `self5` holds the raw
+// self integrals {count, G, H, H^T, E} of every panel (tbem_self_kernel<1>) for the pressure-value self term.
+__global__ __launch_bounds__(256) void tbem_rhs_finish_kernel(BemGeom g, BemPhys ph, BemBc bc, const dc* __restrict__ far, const dc* __restrict__ near,
+                                                              const long long* __restrict__ pair_off, const dc* __restrict__ selfv,
+                                                              const dc* __restrict__ self5, dc* __restrict__ rhs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.np) return;
+  const int bt = g.bc_type[i];
+  dc avg = dc_make(0.0, 0.0);
+  if (bt <= 1) {
+    const int len = bc.len[i];
+    for (int a = 0; a < len; ++a) { avg.re += bc.val[4 * i + a].re; avg.im += bc.val[4 * i + a].im; }
+    avg.re /= (double)len; avg.im /= (double)len;
+  }
+  dc t = dc_make(0.0, 0.0);
+  if (bt == 0) {                                          // avg * beta * tau / 2 (tbem.rs:288)
+    const dc ab = avg * dc_make(ph.beta_re, ph.beta_im);
+    t = dc_make(ab.re * ph.tau * 0.5, ab.im * ph.tau * 0.5);
+  } else if (bt == 1) t = dc_make(avg.re * ph.tau * 0.5, avg.im * ph.tau * 0.5);   // avg * tau / 2 (tbem.rs:297)
+  t.re += far[i].re; t.im += far[i].im;
+  for (long long p = pair_off[i]; p < pair_off[i + 1]; ++p) { t.re += near[p].re; t.im += near[p].im; }
+  if (bc.nz[i]) {
+    if (bt == 0) { t.re += selfv[i].re; t.im += selfv[i].im; }
+    else if (bt == 1) {                                   // -(gamma tau dG/dn_y + beta_p E) * avg with the finished integrals
+      const double gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+      const dc h = self5[5 * (long long)i + 2], ee = self5[5 * (long long)i + 4];
+      const dc kk = dc_make(-(gt * h.re - bp * ee.im), -(gt * h.im + bp * ee.re));
+      const dc c = kk * avg;
+      t.re += c.re; t.im += c.im;
+    }
+  }
+  rhs[g.dof[i]] = t;
+}
+
 // ------------------------------------------------------------------ right-hand sides
 __global__ void fill_zero_kernel(dc* __restrict__ v, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,6 +756,20 @@ int bem_launch_near_list_values(const BemGeom& g, const BemPhys& ph, const int2*
 int bem_launch_self_list_values(const BemGeom& g, const BemPhys& ph, c64* out, hipStream_t st) {
   dim3 grid((g.np + 3) / 4), block(256);
   hipLaunchKernelGGL(tbem_self_kernel<2>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// right-hand side from the panels' boundary values: scratch = far[np] | self[np] | self5[5 np] | near[npairs]
+int bem_launch_rhs_bc(const BemGeom& g, const BemPhys& ph, const BemBc& bc, const int2* pairs, const long long* pair_off, long long npairs,
+                      c64* scratch, c64* rhs, hipStream_t st) {
+  dc* far = reinterpret_cast<dc*>(scratch); dc* selfv = far + g.np; dc* self5 = selfv + g.np; dc* near = self5 + 5 * (size_t)g.np;
+  dim3 rows((g.np + 3) / 4), block(256);
+  hipLaunchKernelGGL(tbem_rhs_far_kernel, rows, block, 0, st, g, ph, bc, far);
+  if (npairs > 0) hipLaunchKernelGGL(tbem_rhs_near_kernel, dim3((unsigned)((npairs + 3) / 4)), block, 0, st, g, ph, bc, pairs, npairs, near);
+  hipLaunchKernelGGL(tbem_rhs_self_kernel, rows, block, 0, st, g, ph, bc, selfv);
+  hipLaunchKernelGGL(tbem_self_kernel<1>, rows, block, 0, st, g, ph, self5);
+  hipLaunchKernelGGL(tbem_rhs_finish_kernel, dim3((g.np + 255) / 256), block, 0, st, g, ph, bc, far, near, pair_off, selfv, self5, reinterpret_cast<dc*>(rhs));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -9,6 +9,7 @@ namespace ma {
 // e1 = p1-p0, e2 = p2-p0, n_y = (e1 x e2)/|e1 x e2| (NOT flipped, regular.rs:249-257),
 // jac = |e1 x e2|. Collocation side (row i): stored centre c and stored outward-flipped
 // normal nx (generators.rs:590-600), stored area (subdivision criterion, singular.rs:535).
+struct dc;
 struct BemGeom {
   int np;                 // panels
   int nd;                 // num_dofs (== np) = leading dimension of A
@@ -24,6 +25,13 @@ struct BemGeom {
   const double* area;
   const int* dof;
   const unsigned char* bc_type;
+};
+
+// boundary values of the panels (BoundaryCondition::{Velocity,Pressure} payloads, types.rs:330-351): 4 slots per panel
+struct BemBc {
+  const ::ma::dc* val;          // [4 np]
+  const int* len;               // values present (1..4)
+  const unsigned char* nz;      // has_nonzero_bc (tbem.rs:247-249)
 };
 
 struct BemPhys {
@@ -42,6 +50,8 @@ int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStr
 int bem_launch_near_list_values(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st);
 int bem_launch_self_list_values(const BemGeom& g, const BemPhys& ph, c64* out, hipStream_t st);
 int bem_launch_zero(c64* v, int n, hipStream_t st);
+int bem_launch_rhs_bc(const BemGeom& g, const BemPhys& ph, const BemBc& bc, const int2* pairs, const long long* pair_off, long long npairs,
+                      c64* scratch, c64* rhs, hipStream_t st);
 int bem_launch_incident(const BemGeom& g, const BemPhys& ph, int kind, const double* v, double are, double aim,
                         int accumulate, c64* rhs, hipStream_t st);
 
@@ -57,6 +67,10 @@ struct ma_bem_plan {
   int2* d_pairs = nullptr;         // near pairs, sorted by collocation row i then j
   long long* d_pair_off = nullptr; // np + 1 row offsets into d_pairs
   long long npairs = 0;
+  bool has_bc = false;             // some panel carries a non-zero boundary value
+  ma::BemBc bc{};                  // device arrays (inside `bcpool`)
+  void* bcpool = nullptr;
+  ma::c64* d_rhs_scratch = nullptr;  // far[np] | self[np] | self5[5 np] | near[npairs]
   bool timing = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   double last_ms[3] = {0, 0, 0};

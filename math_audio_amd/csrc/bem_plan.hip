@@ -81,11 +81,6 @@ int validate_mesh(const ma_mesh_t* m) {
     if (m->bc_values) {
       int len = m->bc_len ? m->bc_len[e] : 1;
       MA_REQUIRE(len >= 1 && len <= 4, MA_ERR_INVALID, "element %d: bc_len %d outside 1..4", e, len);
-      for (int a = 0; a < len; ++a) {
-        const ma_c64 v = m->bc_values[4 * e + a];
-        MA_REQUIRE(std::hypot(v.re, v.im) <= 1e-15, MA_ERR_UNSUPPORTED,
-                   "element %d has a non-zero boundary value; the rhs_contribution path (regular.rs:157-177) is not on the device yet", e);
-      }
     }
   }
   return MA_OK;
@@ -214,6 +209,38 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   MA_TRY(hipDeviceSynchronize());
   (void)hipFree(d_counts);
   P->d_pair_off = d_offsets;
+
+  // boundary values (get_bc_type_and_value, tbem.rs:234-244: transfer admittances carry a single zero)
+  if (m->bc_values) {
+    std::vector<c64> hv((size_t)4 * np); std::vector<int> hl((size_t)np, 1); std::vector<unsigned char> hz((size_t)np, 0);
+    bool any = false;
+    for (int p = 0; p < np; ++p) {
+      const int e = elems[p];
+      const int len = m->bc_len ? m->bc_len[e] : 1;
+      hl[p] = len;
+      for (int a = 0; a < 4; ++a) { hv[4 * (size_t)p + a].re = 0.0; hv[4 * (size_t)p + a].im = 0.0; }
+      if (hbc[p] <= 1)
+        for (int a = 0; a < len; ++a) {
+          const ma_c64 v = m->bc_values[4 * e + a];
+          hv[4 * (size_t)p + a].re = v.re; hv[4 * (size_t)p + a].im = v.im;
+          if (std::hypot(v.re, v.im) > 1e-15) hz[p] = 1;                   // has_nonzero_bc, tbem.rs:247-249
+        }
+      any = any || hz[p];
+    }
+    if (any) {
+      const size_t b_val = sizeof(c64) * 4 * (size_t)np, b_len = (sizeof(int) * (size_t)np + 15) & ~(size_t)15;
+      auto fail2 = [&](int code) { if (P->bcpool) (void)hipFree(P->bcpool); if (P->d_rhs_scratch) (void)hipFree(P->d_rhs_scratch); (void)hipFree(P->d_pair_off); return fail(code); };
+      hipError_t e2 = hipMalloc(&P->bcpool, b_val + b_len + (size_t)np);
+      if (e2 == hipSuccess) e2 = hipMalloc(&P->d_rhs_scratch, sizeof(c64) * (7 * (size_t)np + (size_t)tot + 1));
+      char* bb = (char*)P->bcpool;
+      if (e2 == hipSuccess) e2 = hipMemcpy(bb, hv.data(), b_val, hipMemcpyHostToDevice);
+      if (e2 == hipSuccess) e2 = hipMemcpy(bb + b_val, hl.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice);
+      if (e2 == hipSuccess) e2 = hipMemcpy(bb + b_val + b_len, hz.data(), (size_t)np, hipMemcpyHostToDevice);
+      if (e2 != hipSuccess) { set_error("boundary-value upload failed: %s", hipGetErrorString(e2)); return fail2(MA_ERR_HIP); }
+      P->bc.val = reinterpret_cast<const dc*>(bb); P->bc.len = (const int*)(bb + b_val); P->bc.nz = (const unsigned char*)(bb + b_val + b_len);
+      P->has_bc = true;
+    }
+  }
   for (int i = 0; i < 4; ++i) MA_TRY(hipEventCreate(&P->ev[i]));
 #undef MA_TRY
   *out = P;
@@ -227,6 +254,8 @@ int ma_bem_plan_destroy(ma_bem_plan_t* P) {
   if (P->d_pairs) (void)hipFree(P->d_pairs);
   if (P->d_pair_off) (void)hipFree(P->d_pair_off);
   if (P->pool) (void)hipFree(P->pool);
+  if (P->bcpool) (void)hipFree(P->bcpool);
+  if (P->d_rhs_scratch) (void)hipFree(P->d_rhs_scratch);
   delete P;
   return MA_OK;
 }
@@ -263,7 +292,9 @@ int ma_bem_plan_assemble_dev(ma_bem_plan_t* P, const ma_physics_t* ph, double br
   MA_HIP(hipSetDevice(P->device));
   hipStream_t st = (hipStream_t)stream;
   c64* A = (c64*)dA;
-  if ((rc = bem_launch_zero((c64*)drhs, P->nd, st))) return rc;         // TbemSystem.rhs: zero for zero BC values
+  // TbemSystem.rhs: zero for zero BC values, else the free-term shares and rhs_contributions of the panels that carry values
+  if (P->has_bc) { if ((rc = bem_launch_rhs_bc(P->geom, bp, P->bc, P->d_pairs, P->d_pair_off, P->npairs, P->d_rhs_scratch, (c64*)drhs, st))) return rc; }
+  else if ((rc = bem_launch_zero((c64*)drhs, P->nd, st))) return rc;
   if (P->timing) MA_HIP(hipEventRecord(P->ev[0], st));
   if ((rc = bem_launch_far(P->geom, bp, A, st))) return rc;
   if (P->timing) MA_HIP(hipEventRecord(P->ev[1], st));

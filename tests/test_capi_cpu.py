@@ -50,10 +50,10 @@ def test_argument_validation_precedes_the_device():
         ma.BemPlan(to_ma_mesh(om))
     assert e.value.status == ma.MA_ERR_UNSUPPORTED and "Quad4" in str(e.value)
     om = O.icosphere(RADIUS, 0)
-    om.bc_values[1, 0] = 0.5j
+    om.bc_len[1] = 7                                               # more boundary values than a panel has slots
     with pytest.raises(ma.MaError) as e:
         ma.BemPlan(to_ma_mesh(om))
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    assert e.value.status == ma.MA_ERR_INVALID
     om = O.icosphere(RADIUS, 0)
     om.conn[0, 0] = 999
     with pytest.raises(ma.MaError) as e:
