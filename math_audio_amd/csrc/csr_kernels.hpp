@@ -17,6 +17,12 @@ struct CsrView {
   double k2_re, k2_im;         // k^2 of the current frequency (K/M mode)
   const ::ma::dc* dinv;        // 1 / a_ii for the current values
   const double* l1;            // sum_j |a_ij|
+  // sliced ELLPACK copy (slices of 64 rows = one wavefront, entries column-major inside a slice), or null
+  const long long* sell_ptr;   // n_slices + 1 entry offsets
+  const int* sell_col;
+  const ::ma::dc* sell_val;
+  const double* sell_K;
+  const double* sell_M;
   double zero_diag_dinv;       // 1/a_ii stand-in for |a_ii| <= 1e-15: 1 (amg.rs:400-413) or 0 = leave the row alone (smoother.rs:143-146)
 };
 

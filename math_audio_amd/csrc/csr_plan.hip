@@ -2,6 +2,7 @@
 #include "csr_kernels.hpp"
 #include "ma_device_math.hpp"
 #include <vector>
+#include <cstdlib>
 #include <algorithm>
 #include <new>
 #include <cmath>
@@ -20,11 +21,14 @@ struct ma_csr {
   double k2_re = 0.0, k2_im = 0.0;
   bool diag_valid = false;
   double zero_diag_dinv = 1.0;
+  // sliced-ELLPACK copy (null when the padding would cost too much or MA_CSR_SELL=0)
+  long long* d_sell_ptr = nullptr; int* d_sell_col = nullptr; c64* d_sell_val = nullptr; double* d_sell_K = nullptr; double* d_sell_M = nullptr;
   CsrView view() const {
     CsrView v{};
     v.n = n; v.nnz = nnz; v.row_ptr = d_rowptr; v.col = d_col; v.val = reinterpret_cast<const dc*>(d_val); v.K = d_K; v.M = d_M;
     v.k2_re = k2_re; v.k2_im = k2_im; v.dinv = reinterpret_cast<const dc*>(d_dinv); v.l1 = d_l1;
     v.zero_diag_dinv = zero_diag_dinv;
+    v.sell_ptr = d_sell_ptr; v.sell_col = d_sell_col; v.sell_val = reinterpret_cast<const dc*>(d_sell_val); v.sell_K = d_sell_K; v.sell_M = d_sell_M;
     return v;
   }
 };
@@ -37,7 +41,8 @@ int pick_group(long long n, long long nnz) {
   return g;
 }
 void free_all(ma_csr* h) {
-  void* p[] = {h->d_rowptr, h->d_col, h->d_val, h->d_K, h->d_M, h->d_dinv, h->d_l1, h->d_x, h->d_y, h->d_b};
+  void* p[] = {h->d_rowptr, h->d_col, h->d_val, h->d_K, h->d_M, h->d_dinv, h->d_l1, h->d_x, h->d_y, h->d_b,
+               h->d_sell_ptr, h->d_sell_col, h->d_sell_val, h->d_sell_K, h->d_sell_M};
   for (void* q : p) if (q) (void)hipFree(q);
 }
 int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out) {
@@ -69,6 +74,50 @@ int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int devi
   *out = h;
   return MA_OK;
 }
+// Sliced-ELLPACK copy of the operator (csr_kernels.hip: sell_rows_kernel). Skipped, leaving the CSR-vector kernel in
+// charge, when padding every slice to its longest row would add more than 30 % of entries.
+int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c64* vals, const double* K, const double* M) {
+  if (const char* e = getenv("MA_CSR_SELL")) if (atoi(e) == 0) return MA_OK;
+  const int64_t n = h->n, nnz = h->nnz;
+  if (nnz <= 0) return MA_OK;
+  const int64_t ns = (n + 63) / 64;
+  std::vector<long long> sp((size_t)ns + 1, 0);
+  for (int64_t s = 0; s < ns; ++s) {
+    int64_t w = 0;
+    for (int64_t r = s * 64; r < std::min<int64_t>(n, s * 64 + 64); ++r) w = std::max<int64_t>(w, rowptr[r + 1] - rowptr[r]);
+    sp[(size_t)s + 1] = sp[(size_t)s] + w * 64;
+  }
+  const long long tot = sp[(size_t)ns];
+  if ((double)tot > 1.3 * (double)nnz + 64.0 * 64.0) return MA_OK;
+  std::vector<int> sc((size_t)tot, 0); std::vector<c64> sv; std::vector<double> sk, sm;
+  if (vals) sv.assign((size_t)tot, c64{0.0, 0.0}); else { sk.assign((size_t)tot, 0.0); sm.assign((size_t)tot, 0.0); }
+  for (int64_t s = 0; s < ns; ++s)
+    for (int l = 0; l < 64; ++l) {
+      const int64_t r = s * 64 + l;
+      const long long w = (sp[(size_t)s + 1] - sp[(size_t)s]) / 64;
+      const int64_t len = r < n ? rowptr[r + 1] - rowptr[r] : 0;
+      for (long long kk = 0; kk < w; ++kk) {
+        const size_t q = (size_t)(sp[(size_t)s] + kk * 64 + l);
+        if (kk < len) {
+          const int64_t t = rowptr[r] + kk;
+          sc[q] = (int)col[t];
+          if (vals) { sv[q].re = vals[t].re; sv[q].im = vals[t].im; } else { sk[q] = K[t]; sm[q] = M[t]; }
+        } else sc[q] = (int)(r < n ? r : 0);             // padding: zero coefficient, a column that is in cache anyway
+      }
+    }
+  hipError_t e = hipMalloc(&h->d_sell_ptr, sizeof(long long) * ((size_t)ns + 1));
+  if (e == hipSuccess) e = hipMalloc(&h->d_sell_col, sizeof(int) * (size_t)tot);
+  if (e == hipSuccess && vals) e = hipMalloc(&h->d_sell_val, sizeof(c64) * (size_t)tot);
+  if (e == hipSuccess && !vals) e = hipMalloc(&h->d_sell_K, sizeof(double) * (size_t)tot);
+  if (e == hipSuccess && !vals) e = hipMalloc(&h->d_sell_M, sizeof(double) * (size_t)tot);
+  if (e == hipSuccess) e = hipMemcpy(h->d_sell_ptr, sp.data(), sizeof(long long) * ((size_t)ns + 1), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_sell_col, sc.data(), sizeof(int) * (size_t)tot, hipMemcpyHostToDevice);
+  if (e == hipSuccess && vals) e = hipMemcpy(h->d_sell_val, sv.data(), sizeof(c64) * (size_t)tot, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !vals) e = hipMemcpy(h->d_sell_K, sk.data(), sizeof(double) * (size_t)tot, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !vals) e = hipMemcpy(h->d_sell_M, sm.data(), sizeof(double) * (size_t)tot, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("sliced-ELLPACK upload failed: %s", hipGetErrorString(e)); return MA_ERR_HIP; }
+  return MA_OK;
+}
 int ensure_diag(ma_csr* h, hipStream_t st) {
   if (h->diag_valid) return MA_OK;
   int rc = csr_launch_diag(h->view(), h->km, h->d_dinv, h->d_l1, st);
@@ -88,6 +137,7 @@ int ma_csr_create(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices
   hipError_t e = hipMalloc(&h->d_val, sizeof(c64) * (size_t)(h->nnz > 0 ? h->nnz : 1));
   if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_val, values, sizeof(c64) * (size_t)h->nnz, hipMemcpyHostToDevice);
   if (e != hipSuccess) { set_error("CSR value upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; *out = nullptr; return MA_ERR_HIP; }
+  if ((rc = build_sell(h, row_ptrs, col_indices, values, nullptr, nullptr))) { free_all(h); delete h; *out = nullptr; return rc; }
   return MA_OK;
 }
 
@@ -104,6 +154,7 @@ int ma_csr_create_helmholtz(int64_t n, const int64_t* row_ptrs, const int64_t* c
   if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_K, K, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice);
   if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_M, M, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice);
   if (e != hipSuccess) { set_error("K/M upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; *out = nullptr; return MA_ERR_HIP; }
+  if ((rc = build_sell(h, row_ptrs, col_indices, nullptr, K, M))) { free_all(h); delete h; *out = nullptr; return rc; }
   return MA_OK;
 }
 

@@ -25,8 +25,11 @@ def test_csr_known_answers(gpu):
     A.close(); B.close()
 
 
+@pytest.mark.parametrize("layout", ["sell", "csr"])
 @pytest.mark.parametrize("nxyz", [(6, 5, 4), (21, 17, 13)])
-def test_helmholtz_spmv_and_smoothers_match_oracle(gpu, nxyz):
+def test_helmholtz_spmv_and_smoothers_match_oracle(gpu, nxyz, layout, monkeypatch):
+    """Both device layouts of the same operator: sliced ELLPACK (the default for near-uniform rows) and CSR-vector."""
+    monkeypatch.setenv("MA_CSR_SELL", "1" if layout == "sell" else "0")
     nodes, rp, ci, K, M = fem.helmholtz_box(*nxyz)
     n = len(rp) - 1
     assert n == (nxyz[0] + 1) * (nxyz[1] + 1) * (nxyz[2] + 1)
