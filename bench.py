@@ -160,7 +160,8 @@ def fem_workload(args):
                                            "host_generation_s": t_gen},
            "kernels": res,
            "roofline": {"kernel": "sell_rows_kernel (SpMV, sliced-ELLPACK copy of the CSR operator)", "bound": "hbm", "achieved": res["spmv"]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": res["spmv"]["frac_of_8TBs"], "traffic": None}}
+                        "frac": res["spmv"]["frac_of_8TBs"], "traffic": pmc_traffic("ma::sell_rows_kernel<true, 0>"),
+                        "algorithmic_bytes_per_launch": byts["spmv"]}}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
