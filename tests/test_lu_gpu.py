@@ -129,3 +129,28 @@ def test_batched_factor_solve_is_bitwise_the_single_one(gpu):
     lu.factor_solve_batch_dev([dA0.data_ptr(), dS.data_ptr()], [db0.data_ptr(), ds.data_ptr()], 1, st)
     assert lu.status(st) == ma.MA_ERR_SINGULAR
     lu.close()
+
+
+@pytest.mark.parametrize("n,nrhs,nsys", [(333, 3, 1), (1100, 4, 2), (520, 2, 4)])
+def test_several_right_hand_sides_and_systems(gpu, n, nrhs, nsys):
+    """nrhs right-hand sides per system (d_B is [nrhs][n]) ride through interchanges, forward and backward substitution;
+    up to 4 systems per batch."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(n)
+    lu = ma.LuPlan(n)
+    st = torch.cuda.current_stream().cuda_stream
+    As = [rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) for _ in range(nsys)]
+    Bs = [rng.standard_normal((nrhs, n)) + 1j * rng.standard_normal((nrhs, n)) for _ in range(nsys)]
+    dAs = [torch.tensor(A, device=dev).reshape(-1) for A in As]; dBs = [torch.tensor(B, device=dev).reshape(-1) for B in Bs]
+    if nsys == 1:
+        lu.factor_solve_dev(dAs[0].data_ptr(), dBs[0].data_ptr(), nrhs, st)
+    else:
+        lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dBs], nrhs, st)
+    assert lu.status(st) == ma.MA_OK
+    for A, B, dB in zip(As, Bs, dBs):
+        X = dB.cpu().numpy().reshape(nrhs, n)
+        for r in range(nrhs):
+            assert np.linalg.norm(A @ X[r] - B[r]) / (np.linalg.norm(A) * np.linalg.norm(X[r])) <= 1e-14 * n
+            assert np.linalg.norm(X[r] - np.linalg.solve(A, B[r])) / np.linalg.norm(X[r]) <= 1e-9
+    lu.close()
