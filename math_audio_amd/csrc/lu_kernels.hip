@@ -360,12 +360,14 @@ __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipi
   __shared__ int top[LU_NB_MAX];       // content of row k0+c
   __shared__ int ext_row[LU_NB_MAX];   // rows >= k0+nb that were touched
   __shared__ int ext_src[LU_NB_MAX];
+  __shared__ int piv[LU_NB_MAX];       // the panel's pivots, fetched in one coalesced load (not one dependent load per column)
   const int lane = threadIdx.x;
-  for (int c = lane; c < nb; c += 64) top[c] = k0 + c;
+  for (int c = lane; c < nb; c += 64) { top[c] = k0 + c; piv[c] = ipiv[k0 + c]; }
   int next = 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int c = 0; c < nb; ++c) {
-    int p = ipiv[k0 + c];
+    int p = piv[c];
     if (p < k0 + c || p >= n) p = k0 + c;                // never act on an out-of-range pivot (stale or failed panel)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (p == k0 + c) continue;
