@@ -5,9 +5,12 @@
 //   math_bem::PhysicsParams / Element / Mesh / generate_icosphere_mesh / build_tbem_system_with_beta /
 //            IncidentField::compute_rhs_with_beta        (math-bem/src/core/{types,mesh/generators,assembly/tbem,incident}.rs)
 //   math_solvers::lu_solve -> Result (LuError)            (math-solvers/src/direct/lu.rs)
+//   math_solvers::CsrMatrix / LinearOperator / DenseOperator / DiagonalPreconditioner / GmresConfig / GmresSolution /
+//            gmres / gmres_with_guess / gmres_preconditioned   (math-solvers/src/{sparse/csr,traits,iterative/gmres,preconditioners/diagonal}.rs)
 // Header-only; links against libmathaudio_hip.so. No CPU fallback: errors come back as exceptions or
 // Result values carrying the C status code.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <complex>
@@ -15,6 +18,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 #include "../../include/mathaudio_hip.h"
@@ -240,6 +244,181 @@ inline Result<std::vector<Complex64>> lu_solve(const std::vector<Complex64>& a, 
 inline Result<std::vector<Complex64>> lu_solve(const std::vector<double>& a, size_t n, size_t m, const std::vector<double>& b) {
   std::vector<Complex64> ac(a.begin(), a.end()), bc(b.begin(), b.end());
   return lu_solve(ac, n, m, bc);
+}
+
+// ---------------------------------------------------------------- sparse/csr.rs, traits.rs, iterative/gmres.rs
+struct SolverError : std::runtime_error {
+  int status;
+  SolverError(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+inline void solver_check(int rc) { if (rc != MA_OK) throw SolverError(rc, ma_last_error_string()); }
+
+// traits.rs:316-364: the operator boundary. `handle()` is the device operator GMRES iterates on.
+struct LinearOperator {
+  virtual ~LinearOperator() = default;
+  virtual size_t num_rows() const = 0;
+  virtual size_t num_cols() const = 0;
+  virtual ma_op_t* handle() const = 0;
+  std::vector<Complex64> apply(const std::vector<Complex64>& x) const {
+    std::vector<Complex64> y(num_rows());
+    solver_check(ma_op_apply(handle(), reinterpret_cast<const ma_c64*>(x.data()), reinterpret_cast<ma_c64*>(y.data())));
+    return y;
+  }
+  std::vector<Complex64> apply_transpose(const std::vector<Complex64>& x) const {
+    std::vector<Complex64> y(num_cols());
+    solver_check(ma_op_apply_transpose(handle(), reinterpret_cast<const ma_c64*>(x.data()), reinterpret_cast<ma_c64*>(y.data())));
+    return y;
+  }
+  std::vector<Complex64> apply_hermitian(const std::vector<Complex64>& x) const {
+    std::vector<Complex64> y(num_cols());
+    solver_check(ma_op_apply_hermitian(handle(), reinterpret_cast<const ma_c64*>(x.data()), reinterpret_cast<ma_c64*>(y.data())));
+    return y;
+  }
+};
+
+// csr.rs:21-33. Square operators only on the device path (what the FEM and BEM callers build).
+class CsrMatrix : public LinearOperator {
+ public:
+  size_t num_rows_ = 0, num_cols_ = 0;
+  std::vector<int64_t> row_ptrs, col_indices;
+  std::vector<Complex64> values;
+
+  // csr.rs:69-99
+  static CsrMatrix from_raw_parts(size_t nr, size_t nc, std::vector<int64_t> rp, std::vector<int64_t> ci, std::vector<Complex64> v) {
+    CsrMatrix m; m.num_rows_ = nr; m.num_cols_ = nc; m.row_ptrs = std::move(rp); m.col_indices = std::move(ci); m.values = std::move(v);
+    return m;
+  }
+  // csr.rs:135-205: sorted by (row, col), duplicates summed, zeros kept
+  static CsrMatrix from_triplets(size_t nr, size_t nc, std::vector<std::tuple<size_t, size_t, Complex64>> t) {
+    std::stable_sort(t.begin(), t.end(), [](const auto& a, const auto& b) { return std::get<0>(a) != std::get<0>(b) ? std::get<0>(a) < std::get<0>(b) : std::get<1>(a) < std::get<1>(b); });
+    CsrMatrix m; m.num_rows_ = nr; m.num_cols_ = nc; m.row_ptrs.assign(nr + 1, 0);
+    for (size_t i = 0; i < t.size(); ++i) {
+      const size_t r = std::get<0>(t[i]), c = std::get<1>(t[i]);
+      if (i > 0 && std::get<0>(t[i - 1]) == r && std::get<1>(t[i - 1]) == c) { m.values.back() += std::get<2>(t[i]); continue; }
+      m.col_indices.push_back((int64_t)c); m.values.push_back(std::get<2>(t[i])); m.row_ptrs[r + 1]++;
+    }
+    for (size_t r = 0; r < nr; ++r) m.row_ptrs[r + 1] += m.row_ptrs[r];
+    return m;
+  }
+  // csr.rs:101-133: entries with |a| > threshold
+  static CsrMatrix from_dense(const std::vector<Complex64>& a, size_t nr, size_t nc, double threshold) {
+    CsrMatrix m; m.num_rows_ = nr; m.num_cols_ = nc; m.row_ptrs.assign(nr + 1, 0);
+    for (size_t r = 0; r < nr; ++r) {
+      for (size_t c = 0; c < nc; ++c) if (std::abs(a[r * nc + c]) > threshold) { m.col_indices.push_back((int64_t)c); m.values.push_back(a[r * nc + c]); }
+      m.row_ptrs[r + 1] = (int64_t)m.values.size();
+    }
+    return m;
+  }
+  static CsrMatrix identity(size_t n) {
+    CsrMatrix m; m.num_rows_ = m.num_cols_ = n; m.row_ptrs.resize(n + 1);
+    for (size_t i = 0; i <= n; ++i) m.row_ptrs[i] = (int64_t)i;
+    for (size_t i = 0; i < n; ++i) { m.col_indices.push_back((int64_t)i); m.values.push_back(Complex64(1.0, 0.0)); }
+    return m;
+  }
+  size_t nnz() const { return values.size(); }
+  Complex64 get(size_t i, size_t j) const {                       // csr.rs:207-220
+    for (int64_t t = row_ptrs[i]; t < row_ptrs[i + 1]; ++t) if ((size_t)col_indices[(size_t)t] == j) return values[(size_t)t];
+    return Complex64(0.0, 0.0);
+  }
+  std::vector<Complex64> matvec(const std::vector<Complex64>& x) const { return apply(x); }   // csr.rs:240-292, on the device
+  size_t num_rows() const override { return num_rows_; }
+  size_t num_cols() const override { return num_cols_; }
+  ma_csr_t* csr_handle() const { ensure(); return csr_; }
+  ma_op_t* handle() const override { ensure(); return op_; }
+  CsrMatrix() = default;
+  CsrMatrix(CsrMatrix&& o) noexcept { *this = std::move(o); }
+  CsrMatrix& operator=(CsrMatrix&& o) noexcept {
+    release(); num_rows_ = o.num_rows_; num_cols_ = o.num_cols_; row_ptrs = std::move(o.row_ptrs); col_indices = std::move(o.col_indices);
+    values = std::move(o.values); csr_ = o.csr_; op_ = o.op_; o.csr_ = nullptr; o.op_ = nullptr; return *this;
+  }
+  CsrMatrix(const CsrMatrix&) = delete;
+  CsrMatrix& operator=(const CsrMatrix&) = delete;
+  ~CsrMatrix() override { release(); }
+
+ private:
+  mutable ma_csr_t* csr_ = nullptr;
+  mutable ma_op_t* op_ = nullptr;
+  void ensure() const {
+    if (op_) return;
+    if (num_rows_ != num_cols_) throw SolverError(MA_ERR_UNSUPPORTED, "the device path takes square operators");
+    solver_check(ma_csr_create((int64_t)num_rows_, row_ptrs.data(), col_indices.data(), reinterpret_cast<const ma_c64*>(values.data()), 0, &csr_));
+    solver_check(ma_op_create_csr(csr_, &op_));
+  }
+  void release() { if (op_) ma_op_destroy(op_); if (csr_) ma_csr_destroy(csr_); op_ = nullptr; csr_ = nullptr; }
+};
+
+// math-bem/src/core/solver/fmm_interface.rs:25-53
+class DenseOperator : public LinearOperator {
+ public:
+  DenseOperator(const std::vector<Complex64>& a, size_t n) : n_(n) {
+    if (a.size() != n * n) throw SolverError(MA_ERR_DIM, "DenseOperator: matrix is not n x n");
+    solver_check(ma_op_create_dense((int64_t)n, reinterpret_cast<const ma_c64*>(a.data()), 0, &op_));
+  }
+  ~DenseOperator() override { if (op_) ma_op_destroy(op_); }
+  DenseOperator(const DenseOperator&) = delete;
+  DenseOperator& operator=(const DenseOperator&) = delete;
+  size_t num_rows() const override { return n_; }
+  size_t num_cols() const override { return n_; }
+  ma_op_t* handle() const override { return op_; }
+ private:
+  size_t n_; ma_op_t* op_ = nullptr;
+};
+
+// traits.rs:370-375 and preconditioners/diagonal.rs:20-75
+struct Preconditioner {
+  virtual ~Preconditioner() = default;
+  virtual ma_precond_t* handle() const = 0;
+  std::vector<Complex64> apply(const std::vector<Complex64>& r) const {
+    std::vector<Complex64> z(r.size());
+    solver_check(ma_precond_apply(handle(), reinterpret_cast<const ma_c64*>(r.data()), reinterpret_cast<ma_c64*>(z.data())));
+    return z;
+  }
+};
+class DiagonalPreconditioner : public Preconditioner {
+ public:
+  static DiagonalPreconditioner from_csr(const CsrMatrix& m) { DiagonalPreconditioner p; solver_check(ma_precond_create_jacobi(m.csr_handle(), 1.0, 1, &p.h_)); return p; }
+  DiagonalPreconditioner(DiagonalPreconditioner&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  ~DiagonalPreconditioner() override { if (h_) ma_precond_destroy(h_); }
+  ma_precond_t* handle() const override { return h_; }
+ private:
+  DiagonalPreconditioner() = default;
+  ma_precond_t* h_ = nullptr;
+};
+
+// gmres.rs:14-85
+struct GmresConfig {
+  size_t max_iterations = 100, restart = 30;
+  double tolerance = 1e-6;
+  size_t print_interval = 0;
+  static GmresConfig for_small_problems() { return GmresConfig{50, 50, 1e-8, 0}; }
+  static GmresConfig with_restart(size_t r) { GmresConfig c; c.restart = r; return c; }
+};
+struct GmresSolution {
+  std::vector<Complex64> x;
+  size_t iterations = 0, restarts = 0;
+  double residual = 0.0;
+  bool converged = false;
+};
+namespace detail {
+inline GmresSolution run_gmres(const LinearOperator& op, const Preconditioner* m, const std::vector<Complex64>& b, const std::vector<Complex64>* x0, const GmresConfig& c) {
+  GmresSolution s; s.x.resize(b.size());
+  ma_gmres_info_t info{};
+  const ma_c64* g = x0 ? reinterpret_cast<const ma_c64*>(x0->data()) : nullptr;
+  const int rc = m ? ma_gmres_preconditioned(op.handle(), m->handle(), reinterpret_cast<const ma_c64*>(b.data()), g, (int32_t)c.restart, (int32_t)c.max_iterations, c.tolerance,
+                                             reinterpret_cast<ma_c64*>(s.x.data()), &info)
+                   : ma_gmres(op.handle(), reinterpret_cast<const ma_c64*>(b.data()), g, (int32_t)c.restart, (int32_t)c.max_iterations, c.tolerance,
+                              reinterpret_cast<ma_c64*>(s.x.data()), &info);
+  solver_check(rc);
+  s.iterations = (size_t)info.iterations; s.restarts = (size_t)info.restarts; s.residual = info.residual; s.converged = info.converged != 0;
+  return s;
+}
+}  // namespace detail
+// gmres.rs:96-103, 105-277, 282-292, 434-585
+inline GmresSolution gmres(const LinearOperator& a, const std::vector<Complex64>& b, const GmresConfig& c) { return detail::run_gmres(a, nullptr, b, nullptr, c); }
+inline GmresSolution gmres_with_guess(const LinearOperator& a, const std::vector<Complex64>& b, const std::vector<Complex64>* x0, const GmresConfig& c) { return detail::run_gmres(a, nullptr, b, x0, c); }
+inline GmresSolution gmres_preconditioned(const LinearOperator& a, const Preconditioner& m, const std::vector<Complex64>& b, const GmresConfig& c) { return detail::run_gmres(a, &m, b, nullptr, c); }
+inline GmresSolution gmres_preconditioned_with_guess(const LinearOperator& a, const Preconditioner& m, const std::vector<Complex64>& b, const std::vector<Complex64>* x0, const GmresConfig& c) {
+  return detail::run_gmres(a, &m, b, x0, c);
 }
 
 }  // namespace math_solvers

@@ -67,11 +67,62 @@ static void test_tbem_diagonal_nonzero_and_qa() {       // tbem.rs:585-598 + qa_
   CHECK(threw);
 }
 
+// ---- math-solvers/src/sparse/csr.rs:659-760, preconditioners/diagonal.rs:106-145, iterative/gmres.rs:632-705
+static void test_csr_from_dense_matvec_triplets() {
+  using namespace math_solvers;
+  std::vector<Complex64> d = {1, 0, 2, 0, 3, 0, 4, 0, 5};
+  CsrMatrix csr = CsrMatrix::from_dense(d, 3, 3, 1e-15);
+  CHECK(csr.num_rows() == 3 && csr.num_cols() == 3 && csr.nnz() == 5);
+  CHECK(csr.get(0, 0).real() == 1.0 && csr.get(0, 2).real() == 2.0 && csr.get(1, 1).real() == 3.0 && csr.get(2, 0).real() == 4.0 && csr.get(2, 2).real() == 5.0);
+  CsrMatrix m2 = CsrMatrix::from_dense({1, 2, 3, 4}, 2, 2, 1e-15);
+  auto y = m2.matvec({Complex64(1, 0), Complex64(2, 0)});                    // [1 2; 3 4] [1 2]^T = [5 11]^T
+  CHECK(std::abs(y[0] - Complex64(5, 0)) < 1e-10 && std::abs(y[1] - Complex64(11, 0)) < 1e-10);
+  CsrMatrix t = CsrMatrix::from_triplets(3, 3, {{0, 0, {1, 0}}, {0, 2, {2, 0}}, {1, 1, {3, 0}}, {2, 0, {4, 0}}, {2, 2, {5, 0}}});
+  CHECK(t.nnz() == 5 && t.get(0, 0).real() == 1.0 && t.get(1, 1).real() == 3.0);
+  CsrMatrix dup = CsrMatrix::from_triplets(2, 2, {{0, 0, {1, 0}}, {0, 0, {2, 0}}, {1, 1, {3, 0}}});
+  CHECK(dup.get(0, 0).real() == 3.0);                                        // 1 + 2 = 3
+  auto yt = m2.apply_transpose({Complex64(1, 0), Complex64(2, 0)});          // [1 3; 2 4] [1 2]^T = [7 10]^T
+  CHECK(std::abs(yt[0] - Complex64(7, 0)) < 1e-10 && std::abs(yt[1] - Complex64(10, 0)) < 1e-10);
+}
+static void test_diagonal_preconditioner() {
+  using namespace math_solvers;
+  CsrMatrix m = CsrMatrix::from_dense({4, 1, 1, 2}, 2, 2, 1e-15);
+  auto p = DiagonalPreconditioner::from_csr(m);
+  auto z = p.apply({Complex64(4, 0), Complex64(4, 0)});
+  CHECK(std::abs(z[0] - Complex64(1, 0)) < 1e-10 && std::abs(z[1] - Complex64(2, 0)) < 1e-10);
+}
+static void test_gmres_simple_identity_preconditioned() {
+  using namespace math_solvers;
+  CsrMatrix a = CsrMatrix::from_dense({4, 1, 1, 3}, 2, 2, 1e-15);
+  std::vector<Complex64> b = {{1, 0}, {2, 0}};
+  GmresConfig config{100, 10, 1e-10, 0};
+  auto sol = gmres(a, b, config);
+  CHECK(sol.converged);
+  auto ax = a.matvec(sol.x);
+  CHECK(std::sqrt(std::norm(ax[0] - b[0]) + std::norm(ax[1] - b[1])) < 1e-8);
+  const size_t n = 5;
+  CsrMatrix id = CsrMatrix::identity(n);
+  std::vector<Complex64> bi; for (size_t i = 1; i <= n; ++i) bi.push_back(Complex64((double)i, 0.0));
+  auto s2 = gmres(id, bi, GmresConfig{10, 10, 1e-12, 0});
+  CHECK(s2.converged && s2.iterations <= 2);
+  double e = 0.0; for (size_t i = 0; i < n; ++i) e += std::norm(s2.x[i] - bi[i]);
+  CHECK(std::sqrt(e) < 1e-10);
+  auto p = DiagonalPreconditioner::from_csr(a);
+  auto s3 = gmres_preconditioned(a, p, b, config);
+  CHECK(s3.converged);
+  auto ax3 = a.matvec(s3.x);
+  CHECK(std::sqrt(std::norm(ax3[0] - b[0]) + std::norm(ax3[1] - b[1])) < 1e-8);
+  DenseOperator dn({4, 1, 1, 3}, 2);                                         // DenseOperator, fmm_interface.rs:25-53
+  auto s4 = gmres_with_guess(dn, b, &sol.x, config);
+  CHECK(s4.converged && s4.iterations <= 1);
+}
+
 int main() {
   int n = 0;
   if (ma_device_count(&n) != MA_OK || n <= 0) { std::printf("no HIP device: the host mirror has no CPU fallback\n"); return 77; }
   test_lu_solve_real(); test_lu_solve_complex(); test_lu_identity(); test_lu_singular(); test_lu_dimension_mismatch();
   test_tbem_diagonal_nonzero_and_qa();
+  test_csr_from_dense_matvec_triplets(); test_diagonal_preconditioner(); test_gmres_simple_identity_preconditioned();
   std::printf(failures ? "%d check(s) failed\n" : "host mirror: all checks passed\n", failures);
   return failures ? 1 : 0;
 }
