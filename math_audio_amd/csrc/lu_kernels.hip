@@ -845,7 +845,7 @@ struct PanelSequencer {
 PanelSequencer g_seq;
 }  // namespace
 
-int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, hipStream_t st) {
+int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
@@ -866,7 +866,11 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   const unsigned long long i = g_seq.count[dev];
   // slot (i mod 8) still holds launch i-8; launch i-lag sits in slot (i - lag) mod 8
   if (i >= (unsigned long long)lag) MA_HIP(hipStreamWaitEvent(st, g_seq.ring[dev][(i - lag) & 7], 0));
-  MA_HIP(hipMemsetAsync(ws.cand, 0, sizeof(unsigned long long) * 2 * (size_t)ws.max_blocks, st));   // stale tags must not match
+  // Stale tags must not match. A workgroup rewrites its granule every column, so only columns 0 and 1 of a launch can
+  // see the previous launch's granules, which carry that launch's last two tags (nb and nb - 1): they differ from the
+  // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
+  // factorisation, whose predecessor may have been aborted) the granules are cleared.
+  if (clear_tags) MA_HIP(hipMemsetAsync(ws.cand, 0, sizeof(unsigned long long) * 2 * (size_t)ws.max_blocks, st));
   hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(A), n, k0, nb, rpb, ws, ipiv);
   MA_HIP(hipGetLastError());
   MA_HIP(hipEventRecord(g_seq.ring[dev][i & 7], st));

@@ -263,7 +263,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     for (int q = blk_first(g); q < blk_last(g); ++q) {
       const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
       MA_MARK(t0, sp);
-      if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], sp))) return rc;
+      if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp))) return rc;
       MA_MARK(t1, sp);
       interval(P, t0, t1, 0);
       if (a1 < e) {
