@@ -16,6 +16,7 @@
 #include "lu_kernels.hpp"
 #include "ma_device_math.hpp"
 #include <climits>
+#include <algorithm>
 #include <mutex>
 
 namespace ma {
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(128) void lu_trsm_mfma_kernel(const dc* __restrict_
                                                            dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* Lre = reinterpret_cast<double*>(smem);
-  double* Lim = Lre + 128 * TM_PITCH;
+  double* Lim = Lre + (size_t)max(32, ((nb + 15) >> 4) * 16) * TM_PITCH;   // the launch sizes the two planes for this nb
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const bool extra = (int)blockIdx.x >= nmain;
@@ -911,7 +912,10 @@ int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, 
   if (nb <= 0 || (ncols <= 0 && nrhs <= 0)) return MA_OK;
   MA_REQUIRE(nb <= LU_NB_MAX && nrhs <= 32, MA_ERR_DIM, "trsm: nb %d / nrhs %d beyond the kernel's tiles", nb, nrhs);
   const int nmain = ncols > 0 ? (ncols + 31) / 32 : 0;
-  hipLaunchKernelGGL(lu_trsm_mfma_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), 2 * 128 * TM_PITCH * 8, st, reinterpret_cast<const dc*>(T), ldt, nb,
+  // LDS for the slab of this nb only (34.8 KB at nb = 64): the launch then fits on a CU that already holds two panel
+  // workgroups (with the full 128-row 69.6 KB it never did, and queued behind them)
+  const size_t lds = 2 * (size_t)std::max(32, ((nb + 15) / 16) * 16) * TM_PITCH * 8;
+  hipLaunchKernelGGL(lu_trsm_mfma_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
                      reinterpret_cast<const dc*>(invd), reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
   MA_HIP(hipGetLastError());
   return MA_OK;
