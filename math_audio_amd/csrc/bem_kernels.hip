@@ -89,8 +89,8 @@ __device__ __forceinline__ dc bm_coeff(const Acc4& s, int field_bc, const BemPhy
 __global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block) {
   const int np = g.np;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = j < np;
-  const int jj = valid ? j : np - 1;
+  const int jj = j < np ? j : np - 1;
+  const bool valid = j < np && !(g.nquad > 0 && g.ptype[jj] == 4);     // Quad4 columns belong to tbem_far_quad_kernel
   const double p0x = g.p0[0][jj], p0y = g.p0[1][jj], p0z = g.p0[2][jj];
   const double e1x = g.e1[0][jj], e1y = g.e1[1][jj], e1z = g.e1[2][jj];
   const double e2x = g.e2[0][jj], e2y = g.e2[1][jj], e2z = g.e2[2][jj];
@@ -142,7 +142,46 @@ __device__ __forceinline__ double tri_ratio(double s0, double t0, double s1, dou
   return dist / sq_arels;
 }
 
+// Quad4: bilinear shape functions on [-1,1]^2 (regular.rs:211-234) and the same level-0 / level-L criterion on the mean of
+// the sub-element's four local vertices (singular.rs:542-556), rounded as the CPU restatement rounds it.
+__device__ __forceinline__ double quad_ratio(const double* s, const double* t, const double* v /* 4 vertices x 3 */, double cx, double cy, double cz,
+                                             double sq_arels) {
+  double scent = ((((0.0 + s[0]) + s[1]) + s[2]) + s[3]) / 4.0;
+  double tcent = ((((0.0 + t[0]) + t[1]) + t[2]) + t[3]) / 4.0;
+  double s1 = 0.25 * (scent + 1.0), s2 = 0.25 * (scent - 1.0), t1 = tcent + 1.0, t2 = tcent - 1.0;
+  double n0 = s1 * t1, n1 = -s2 * t1, n2 = s2 * t2, n3 = -s1 * t2;
+  double px = (((0.0 + n0 * v[0]) + n1 * v[3]) + n2 * v[6]) + n3 * v[9];
+  double py = (((0.0 + n0 * v[1]) + n1 * v[4]) + n2 * v[7]) + n3 * v[10];
+  double pz = (((0.0 + n0 * v[2]) + n1 * v[5]) + n2 * v[8]) + n3 * v[11];
+  double dx = px - cx, dy = py - cy, dz = pz - cz;
+  double dist = __builtin_sqrt(((0.0 + dx * dx) + dy * dy) + dz * dz);
+  return dist / sq_arels;
+}
+// compute_gauss_order (singular.rs:663-693): smallest order in [4, 7] whose three error estimates fall below 5e-4
+__device__ __forceinline__ int quad_gauss_order(double ratdis) {
+  const double disfac = 0.5 / ratdis;
+  for (int order = 4; order <= 7; ++order) {
+    const double base = disfac / (2.0 * (double)order + 1.0);
+    double eg = 1.0;
+    for (int e = 0; e < 2 * order + 1; ++e) eg *= base;
+    const double eh = eg * base, ee = eh * base;
+    if (eg < 0.0005 && eh < 0.0005 && ee < 0.0005) return order;
+  }
+  return 7;
+}
+__device__ __forceinline__ void quad_load(const BemGeom& g, int j, double* v) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { v[d] = g.p0[d][j]; v[3 + d] = g.p1[d][j]; v[6 + d] = g.p2[d][j]; v[9 + d] = g.p3[d][j]; }
+}
+
 __device__ __forceinline__ bool pair_is_near(const BemGeom& g, int i, int j) {
+  if (g.nquad > 0 && g.ptype[j] == 4) {
+    double v4[12]; quad_load(g, j, v4);
+    const double cs[4] = {1.0, -1.0, -1.0, 1.0}, ct[4] = {1.0, 1.0, -1.0, -1.0};
+    double faclin = 2.0 * 0.5;
+    double arels = g.area[j] * faclin * faclin;
+    return quad_ratio(cs, ct, v4, g.c[0][i], g.c[1][i], g.c[2][i], __builtin_sqrt(arels)) < 3.0;
+  }
   double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
   double faclin = 2.0 * 0.5;
   double arels = g.area[j] * faclin * faclin;
@@ -259,6 +298,7 @@ __global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, c
   if (pid >= npairs) return;                         // whole wave leaves; no block barrier below
   const int2 pr = pairs[pid];
   const int i = pr.x, j = pr.y;
+  if (g.nquad > 0 && g.ptype[j] == 4) return;        // Quad4 field panel: tbem_near_quad_kernel
   const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
   const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
   double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
@@ -320,6 +360,7 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + wave;
   if (e >= g.np) return;
+  if (g.nquad > 0 && g.ptype[e] == 4) return;        // Quad4 panel: tbem_self_quad_kernel
   const double cx = g.c[0][e], cy = g.c[1][e], cz = g.c[2][e];
   const double nxx = g.nx[0][e], nxy = g.nx[1][e], nxz = g.nx[2][e];
   const double P[3][3] = {{g.p0[0][e], g.p0[1][e], g.p0[2][e]}, {g.p1[0][e], g.p1[1][e], g.p1[2][e]}, {g.p2[0][e], g.p2[1][e], g.p2[2][e]}};
@@ -438,6 +479,300 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
     if (MODE == 2) A[e] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
     else A[d * g.nd + d] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
   }
+}
+
+// ------------------------------------------------------------------ Quad4 panels
+// The same three regimes for bilinear quadrilaterals (ElementType::Quad4): the position, the unit normal and the
+// Jacobian vary over the panel (compute_parameters, regular.rs:211-260), the rule of an (un)subdivided piece is the
+// n x n Gauss-Legendre tensor rule with n in [4, 7] from the distance criterion (gauss.rs:94-105, singular.rs:663-693),
+// pieces are axis-aligned squares (centre, half-width) in the reference square (regular.rs:96-103).
+__device__ __constant__ double c_csi8[8] = {1.0, -1.0, -1.0, 1.0, 0.0, -1.0, 0.0, 1.0};
+__device__ __constant__ double c_eta8[8] = {1.0, 1.0, -1.0, -1.0, 1.0, 0.0, -1.0, 0.0};
+
+struct QuadPoint { double dx, dy, dz, nyx, nyy, nyz, jac; };
+// point (s, t) of the panel with vertices v, relative to the collocation point c
+__device__ __forceinline__ QuadPoint quad_point(const double* v, double s, double t, double cx, double cy, double cz) {
+  const double s1 = 0.25 * (s + 1.0), s2 = 0.25 * (s - 1.0), t1 = t + 1.0, t2 = t - 1.0;
+  const double n0 = s1 * t1, n1 = -s2 * t1, n2 = s2 * t2, n3 = -s1 * t2;
+  const double a0 = 0.25 * (t + 1.0), a1 = -0.25 * (t + 1.0), a2 = 0.25 * (t - 1.0), a3 = -0.25 * (t - 1.0);     // dN/ds
+  const double b0 = 0.25 * (s + 1.0), b1 = 0.25 * (1.0 - s), b2 = 0.25 * (s - 1.0), b3 = -0.25 * (s + 1.0);      // dN/dt
+  double p[3], ds[3], dt[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    p[d] = n0 * v[d] + n1 * v[3 + d] + n2 * v[6 + d] + n3 * v[9 + d];
+    ds[d] = a0 * v[d] + a1 * v[3 + d] + a2 * v[6 + d] + a3 * v[9 + d];
+    dt[d] = b0 * v[d] + b1 * v[3 + d] + b2 * v[6 + d] + b3 * v[9 + d];
+  }
+  const double nx = ds[1] * dt[2] - ds[2] * dt[1], ny = ds[2] * dt[0] - ds[0] * dt[2], nz = ds[0] * dt[1] - ds[1] * dt[0];
+  const double jac = __builtin_sqrt(nx * nx + ny * ny + nz * nz);
+  const double ij = jac > 1e-15 ? 1.0 / jac : 0.0;
+  QuadPoint q;
+  q.dx = p[0] - cx; q.dy = p[1] - cy; q.dz = p[2] - cz;
+  q.nyx = nx * ij; q.nyy = ny * ij; q.nyz = nz * ij; q.jac = jac;
+  return q;
+}
+__device__ __forceinline__ void quad_green(const double* v, double s, double t, double w, double cx, double cy, double cz,
+                                           double nxx, double nxy, double nxz, double k, double k2, Acc4& acc) {
+  const QuadPoint q = quad_point(v, s, t, cx, cy, cz);
+  const double m = nxx * q.nyx + nxy * q.nyy + nxz * q.nyz;
+  green_point(q.dx, q.dy, q.dz, w * q.jac * MA_INV4PI, k, k2, q.nyx, q.nyy, q.nyz, nxx, nxy, nxz, m, acc);
+}
+
+// K1q: every pair whose field panel is a quad, un-subdivided rule of the order the distance asks for.
+// grid.x: strips of 256 quad panels (lane = panel), grid.y: strips of collocation rows.
+__global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = q < g.nquad;
+  const int j = g.quad_ids[valid ? q : 0];
+  double v[12]; quad_load(g, j, v);
+  const int fbc = g.bc_type[j];
+  const long long col = g.dof[j];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  double sq;
+  {
+#pragma clang fp contract(off)
+    double arels = g.area[j] * 1.0 * 1.0;
+    sq = __builtin_sqrt(arels);
+  }
+  const double cs[4] = {1.0, -1.0, -1.0, 1.0}, ct[4] = {1.0, 1.0, -1.0, -1.0};
+  const int i0 = blockIdx.y * rows_per_block, i1 = min(i0 + rows_per_block, g.np);
+  for (int i = i0; i < i1; ++i) {
+    const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+    const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+    const int order = quad_gauss_order(quad_ratio(cs, ct, v, cx, cy, cz, sq));
+    const int off = c_gl_index[order][0], n = c_gl_index[order][1];
+    Acc4 s;
+    s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b)
+        quad_green(v, c_gl_x[off + a], c_gl_x[off + b], c_gl_w[off + a] * c_gl_w[off + b], cx, cy, cz, nxx, nxy, nxz, k, k2, s);
+    if (valid) A[(long long)g.dof[i] * g.nd + col] = bm_coeff(s, fbc, ph);
+  }
+}
+
+// K2q: near pairs with a quad field panel. generate_subelements for nv = 4 (singular.rs:497-660): a split yields the
+// children [v_j, mid(v_j, v_j+1), centre, mid(v_j-1, v_j)], j = 0..3, each with its own vertex order (which decides the
+// order of ITS children, hence which pieces the 15-splits-per-level limit drops); leaves keep centre, half-width and order.
+template <int MODE>   // 0: write A[i][j]; 1: probe {leaves, G, H, H^T, E}; 2: coefficient to out[pid]
+__global__ __launch_bounds__(256) void tbem_near_quad_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs, long long npairs, dc* __restrict__ A) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][4];
+  __shared__ double s_next[4][MA_MAX_NSE][8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  if (g.ptype[j] != 4) return;
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[12]; quad_load(g, j, v);
+  const double area = g.area[j];
+  double sv[4] = {1.0, -1.0, -1.0, 1.0}, tv[4] = {1.0, 1.0, -1.0, -1.0};
+  int nsel = 1, nleaf = 0;
+  double faclin = 2.0;
+  for (;;) {
+    faclin *= 0.5;
+    double sq;
+    {
+#pragma clang fp contract(off)
+      double arels = area * faclin * faclin;
+      sq = __builtin_sqrt(arels);
+    }
+    const bool active = lane < nsel;
+    const double ratio = active ? quad_ratio(sv, tv, v, cx, cy, cz, sq) : 1e300;
+    const bool split = active && (ratio < 3.0);
+    const unsigned long long smask = __ballot(split);
+    const int nsplit = __popcll(smask);
+    const int rank = __popcll(smask & lanemask_lt());
+    int cut = 64;
+    if (nsplit > 15) {
+      unsigned long long mm = smask;
+      for (int q = 0; q < 15; ++q) mm &= mm - 1;
+      cut = __builtin_ctzll(mm);
+    }
+    const bool isleaf = active && !split && lane < cut;
+    const unsigned long long lmask = __ballot(isleaf);
+    const int lrank = nleaf + __popcll(lmask & lanemask_lt());
+    if (isleaf && lrank < MA_MAX_LEAVES) {
+      double* L = s_leaf[wave][lrank];
+      double xc, ec;
+      {
+#pragma clang fp contract(off)
+        xc = (((sv[0] + sv[1]) + sv[2]) + sv[3]) / 4.0;
+        ec = (((tv[0] + tv[1]) + tv[2]) + tv[3]) / 4.0;
+      }
+      L[0] = xc; L[1] = ec; L[2] = faclin; L[3] = (double)quad_gauss_order(ratio);
+    }
+    nleaf += __popcll(lmask);
+    if (nleaf >= MA_MAX_LEAVES) { nleaf = MA_MAX_LEAVES; break; }
+    if (nsplit == 0) break;
+    if (split && rank < 15) {
+      double scent, tcent, ms[4], mt[4];
+      {
+#pragma clang fp contract(off)
+        scent = ((((0.0 + sv[0]) + sv[1]) + sv[2]) + sv[3]) / 4.0;
+        tcent = ((((0.0 + tv[0]) + tv[1]) + tv[2]) + tv[3]) / 4.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { ms[a] = (sv[a] + sv[(a + 1) & 3]) / 2.0; mt[a] = (tv[a] + tv[(a + 1) & 3]) / 2.0; }
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {                      // child a: v_a, mid(a, a+1), centre, mid(a-1, a)
+        double* Cn = s_next[wave][rank * 4 + a];
+        const int am = (a + 3) & 3;
+        Cn[0] = sv[a]; Cn[1] = ms[a]; Cn[2] = scent; Cn[3] = ms[am];
+        Cn[4] = tv[a]; Cn[5] = mt[a]; Cn[6] = tcent; Cn[7] = mt[am];
+      }
+    }
+    wave_lds_sync();
+    nsel = (nsplit > 15 ? 15 : nsplit) * 4;
+    if (lane < nsel) {
+      const double* Cn = s_next[wave][lane];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { sv[a] = Cn[a]; tv[a] = Cn[4 + a]; }
+    }
+    wave_lds_sync();
+  }
+  wave_lds_sync();
+
+  // ---- integrate leaf by leaf: lane = point of the leaf's n x n rule (n <= 7)
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  Acc4 s;
+  s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+  for (int lf = 0; lf < nleaf; ++lf) {
+    const double* L = s_leaf[wave][lf];
+    const double xice = L[0], etce = L[1], fase = L[2];
+    const int order = (int)L[3];
+    const int off = c_gl_index[order][0], n = c_gl_index[order][1];
+    if (lane < n * n) {
+      const int a = lane / n, b = lane - a * n;
+      const double xio = xice + c_gl_x[off + a] * fase, eto = etce + c_gl_x[off + b] * fase;
+      quad_green(v, xio, eto, c_gl_w[off + a] * c_gl_w[off + b] * (fase * fase), cx, cy, cz, nxx, nxy, nxz, k, k2, s);
+    }
+  }
+  s.g.re = wave_sum(s.g.re); s.g.im = wave_sum(s.g.im);
+  s.h.re = wave_sum(s.h.re); s.h.im = wave_sum(s.h.im);
+  s.ht.re = wave_sum(s.ht.re); s.ht.im = wave_sum(s.ht.im);
+  s.e.re = wave_sum(s.e.re); s.e.im = wave_sum(s.e.im);
+  if (lane == 0) {
+    if (MODE == 1) {
+      dc* o = A + 5 * pid;
+      o[0] = dc_make((double)nleaf, 0.0); o[1] = s.g; o[2] = s.h; o[3] = s.ht; o[4] = s.e;
+    } else if (MODE == 2) A[pid] = bm_coeff(s, g.bc_type[j], ph);
+    else A[(long long)g.dof[i] * g.nd + g.dof[j]] = bm_coeff(s, g.bc_type[j], ph);
+  }
+}
+
+// K3q: singular self term of a quad panel (singular.rs:154-394 with num_nodes = 4): four edges, per edge the line integral
+// of the hypersingular part and nsec2 collapsed-square sub-triangles (centre (0,0), edge vertex, edge mid-point; area 1/4 each).
+template <int MODE>   // 0: write A[i][i]; 1: probe to out[5 e]; 2: diagonal entry (with free term) to out[e]
+__global__ __launch_bounds__(256) void tbem_self_quad_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + wave;
+  if (e >= g.np) return;
+  if (g.ptype[e] != 4) return;
+  const double cx = g.c[0][e], cy = g.c[1][e], cz = g.c[2][e];
+  const double nxx = g.nx[0][e], nxy = g.nx[1][e], nxz = g.nx[2][e];
+  double v[12]; quad_load(g, e, v);
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  double el = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int b = (a + 1) & 3;
+    const double ddx = v[3 * b] - v[3 * a], ddy = v[3 * b + 1] - v[3 * a + 1], ddz = v[3 * b + 2] - v[3 * a + 2];
+    el += __builtin_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+  }
+  const double ka = ph.k * (el / 4.0);
+  int ngpo1, ngausin, nsec1, nsec2;
+  if (ka < 0.3)      { ngpo1 = 3; ngausin = 4; nsec1 = 4;  nsec2 = 2; }
+  else if (ka < 1.0) { ngpo1 = 4; ngausin = 5; nsec1 = 6;  nsec2 = 2; }
+  else if (ka < 2.0) { ngpo1 = 5; ngausin = 6; nsec1 = 8;  nsec2 = 3; }
+  else               { ngpo1 = 6; ngausin = 7; nsec1 = 10; nsec2 = 4; }
+  const int eo = c_gl_index[ngpo1][0], so = c_gl_index[ngausin][0];
+  const int ne = c_gl_index[ngpo1][1], ns = c_gl_index[ngausin][1];
+  const int n_edge_pts = nsec1 * ne;
+  const int per_edge = n_edge_pts + nsec2 * ns * ns;
+  const int ntask = 4 * per_edge;
+  Acc4 s;
+  s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+  for (int t = lane; t < ntask; t += 64) {
+    const int ieg = t / per_edge;
+    const int u = t - ieg * per_edge;
+    const int ig1 = (ieg + 1) & 3, ig2 = ieg + 4;
+    if (u < n_edge_pts) {
+      const int isec = u / ne, ig = u - isec * ne;
+      const double dpx = v[3 * ig1] - v[3 * ieg], dpy = v[3 * ig1 + 1] - v[3 * ieg + 1], dpz = v[3 * ig1 + 2] - v[3 * ieg + 2];
+      const double len = __builtin_sqrt(dpx * dpx + dpy * dpy + dpz * dpz);
+      const double ox = dpx / len, oy = dpy / len, oz = dpz / len;
+      const double lens = len / (2.0 * (double)nsec1);
+      const double delsec = 2.0 / (double)nsec1;
+      double secmid = -1.0 - delsec / 2.0;
+      for (int q = 0; q <= isec; ++q) secmid += delsec;
+      const double sga = secmid + c_gl_x[eo + ig] / (double)nsec1;
+      const double wga = c_gl_w[eo + ig] * lens;
+      const double f = (sga + 1.0) / 2.0;
+      const double dx = (v[3 * ieg] + dpx * f) - cx, dy = (v[3 * ieg + 1] + dpy * f) - cy, dz = (v[3 * ieg + 2] + dpz * f) - cz;
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 >= 1e-30) {
+        double r, ri; sqrt_rsqrt(r2, r, ri);
+        double sn, cs; sincos_fast(k * r, sn, cs);
+        const double gs = MA_INV4PI * ri;
+        const double gre = cs * gs, gim = sn * gs;
+        const double fre = -(gre * ri) - gim * k, fim = gre * k - gim * ri;
+        const double ux = dx * ri, uy = dy * ri, uz = dz * ri;
+        const double wx = uy * oz - uz * oy, wy = uz * ox - ux * oz, wz = ux * oy - uy * ox;
+        const double sc = (wx * nxx + wy * nxy + wz * nxz) * wga;
+        s.e.re += fre * sc; s.e.im += fim * sc;
+      }
+    } else {
+      const int v2 = u - n_edge_pts;
+      const int isec = v2 / (ns * ns);
+      const int ij = v2 - isec * ns * ns;
+      const int ii = ij / ns, jj = ij - ii * ns;
+      const double aresub = 0.25 / (double)nsec2;
+      double ss1, ss2, ts1, ts2;
+      if (isec == 0) { ss1 = c_csi8[ieg]; ss2 = c_csi8[ig2]; ts1 = c_eta8[ieg]; ts2 = c_eta8[ig2]; }
+      else           { ss1 = c_csi8[ig2]; ss2 = c_csi8[ig1]; ts1 = c_eta8[ig2]; ts2 = c_eta8[ig1]; }
+      const double sga = c_gl_x[so + ii], tga = c_gl_x[so + jj];
+      const double wei = c_gl_w[so + ii] * c_gl_w[so + jj];
+      const double sgg = 0.25 * (1.0 + sga) * ((1.0 - tga) * ss1 + (1.0 + tga) * ss2);       // centre (0, 0) drops out
+      const double tgg = 0.25 * (1.0 + sga) * ((1.0 - tga) * ts1 + (1.0 + tga) * ts2);
+      const QuadPoint q = quad_point(v, sgg, tgg, cx, cy, cz);
+      const double wga = wei * (1.0 + sga) * aresub * q.jac;
+      const double r2 = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
+      if (r2 >= 1e-30) {
+        double r, ri; sqrt_rsqrt(r2, r, ri);
+        double sn, cs; sincos_fast(k * r, sn, cs);
+        const double gs = wga * MA_INV4PI * ri;
+        const double gre = cs * gs, gim = sn * gs;
+        const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
+        const double a = (q.dx * q.nyx + q.dy * q.nyy + q.dz * q.nyz) * ri;
+        const double b = -((q.dx * nxx + q.dy * nxy + q.dz * nxz) * ri);
+        const double m = nxx * q.nyx + nxy * q.nyy + nxz * q.nyz;
+        s.g.re += gre; s.g.im += gim;
+        s.h.re += bre * a; s.h.im += bim * a;
+        s.ht.re += bre * b; s.ht.im += bim * b;
+        s.e.re += gre * k2 * m; s.e.im += gim * k2 * m;
+      }
+    }
+  }
+  s.g = dc_make(wave_sum(s.g.re), wave_sum(s.g.im));
+  s.h = dc_make(wave_sum(s.h.re), wave_sum(s.h.im));
+  s.ht = dc_make(wave_sum(s.ht.re), wave_sum(s.ht.im));
+  s.e = dc_make(wave_sum(s.e.re), wave_sum(s.e.im));
+  if (lane != 0) return;
+  if (MODE == 1) {
+    dc* o = A + 5 * (long long)e;
+    o[0] = dc_make((double)ntask, 0.0); o[1] = s.g; o[2] = s.h; o[3] = s.ht; o[4] = s.e;
+    return;
+  }
+  const int bc = g.bc_type[e];
+  const dc coeff = bm_coeff(s, bc, ph);
+  dc fr = dc_make(0.0, 0.0);
+  if (bc == 0) fr = dc_make(-(ph.gamma * 0.5), 0.0);
+  else if (bc == 1) fr = dc_make(-(ph.beta_re * ph.tau * 0.5), -(ph.beta_im * ph.tau * 0.5));
+  const long long d = g.dof[e];
+  if (MODE == 2) A[e] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
+  else A[d * g.nd + d] = dc_make(fr.re + coeff.re, fr.im + coeff.im);
 }
 
 // ------------------------------------------------------------------ boundary values on the right-hand side
@@ -711,6 +1046,7 @@ int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) 
   const int rpb = 32;
   dim3 grid((g.np + 255) / 256, (g.np + rpb - 1) / rpb), block(256);
   hipLaunchKernelGGL(tbem_far_kernel, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A), rpb);
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_far_quad_kernel, dim3((g.nquad + 255) / 256, (g.np + rpb - 1) / rpb), block, 0, st, g, ph, reinterpret_cast<dc*>(A), rpb);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -719,6 +1055,7 @@ int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long
   if (npairs <= 0) return MA_OK;
   dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
   hipLaunchKernelGGL(tbem_near_kernel<0>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_near_quad_kernel<0>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -727,6 +1064,7 @@ int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pair
   if (npairs <= 0) return MA_OK;
   dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
   hipLaunchKernelGGL(tbem_near_kernel<1>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out5));
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_near_quad_kernel<1>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out5));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -734,6 +1072,7 @@ int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pair
 int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st) {
   dim3 grid((g.np + 3) / 4), block(256);
   hipLaunchKernelGGL(tbem_self_kernel<1>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out5));
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_self_quad_kernel<1>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out5));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -741,6 +1080,7 @@ int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStr
 int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) {
   dim3 grid((g.np + 3) / 4), block(256);
   hipLaunchKernelGGL(tbem_self_kernel<0>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_self_quad_kernel<0>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -750,12 +1090,14 @@ int bem_launch_near_list_values(const BemGeom& g, const BemPhys& ph, const int2*
   if (npairs <= 0) return MA_OK;
   dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
   hipLaunchKernelGGL(tbem_near_kernel<2>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out));
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_near_quad_kernel<2>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
 int bem_launch_self_list_values(const BemGeom& g, const BemPhys& ph, c64* out, hipStream_t st) {
   dim3 grid((g.np + 3) / 4), block(256);
   hipLaunchKernelGGL(tbem_self_kernel<2>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out));
+  if (g.nquad > 0) hipLaunchKernelGGL(tbem_self_quad_kernel<2>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(out));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

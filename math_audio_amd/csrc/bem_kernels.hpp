@@ -25,6 +25,12 @@ struct BemGeom {
   const double* area;
   const int* dof;
   const unsigned char* bc_type;
+  // Quad4 panels (mixed meshes): 4th vertex, per-panel node count (3 / 4), and the list of the quad panels.
+  // nquad == 0 (the sphere configurations) leaves every Tri3 kernel on its original path.
+  const double* p3[3];
+  const unsigned char* ptype;
+  const int* quad_ids;
+  int nquad;
 };
 
 // boundary values of the panels (BoundaryCondition::{Velocity,Pressure} payloads, types.rs:330-351): 4 slots per panel

@@ -75,8 +75,8 @@ int validate_mesh(const ma_mesh_t* m) {
              "mesh has a NULL required array");
   for (int e = 0; e < m->n_elem; ++e) {
     const int32_t* c = m->conn + 4 * e;
-    MA_REQUIRE(c[3] < 0, MA_ERR_UNSUPPORTED, "element %d is Quad4; the device path handles Tri3 panels only", e);
-    for (int a = 0; a < 3; ++a)
+    const int nn = c[3] < 0 ? 3 : 4;                    // Tri3 rows carry -1 in the fourth slot
+    for (int a = 0; a < nn; ++a)
       MA_REQUIRE(c[a] >= 0 && c[a] < m->n_nodes, MA_ERR_INVALID, "element %d references node %d (n_nodes=%d)", e, c[a], m->n_nodes);
     if (m->bc_values) {
       int len = m->bc_len ? m->bc_len[e] : 1;
@@ -126,11 +126,12 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   }
 
   // host SoA: 25 double arrays of np + dof(int) + bc(uchar)
-  const int ND = 25;
+  const int ND = 28;                                     // 25 Tri3 arrays + the fourth vertex of Quad4 panels
   const size_t stride = ((size_t)np + 63) & ~(size_t)63;   // keep every array 512-B aligned
   std::vector<double> h((size_t)ND * stride, 0.0);
   std::vector<int> hdof(stride, 0);
-  std::vector<unsigned char> hbc(stride, 0);
+  std::vector<unsigned char> hbc(stride, 0), hpt(stride, 3);
+  std::vector<int> hquads;
   auto arr = [&](int a) { return h.data() + (size_t)a * stride; };
   for (int p = 0; p < np; ++p) {
     const int e = elems[p];
@@ -146,6 +147,11 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
       arr(19 + d)[p] = m->center[3 * e + d]; arr(22 + d)[p] = m->normal[3 * e + d];
     }
     arr(18)[p] = jac;
+    if (c[3] >= 0) {
+      const double* q3 = m->nodes + 3 * c[3];
+      for (int d = 0; d < 3; ++d) arr(25 + d)[p] = q3[d];
+      hpt[p] = 4; hquads.push_back(p);
+    }
     hdof[p] = m->dof[e];
     hbc[p] = m->bc_type[e] > 1 ? 2 : m->bc_type[e];
   }
@@ -158,7 +164,8 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   P->avg_radius = avg_center_radius(m);
 
   const size_t bytes_d = (size_t)(ND + 1) * stride * sizeof(double);
-  const size_t bytes = bytes_d + stride * sizeof(int) + stride;
+  const size_t nq_pad = (hquads.size() + 63) & ~(size_t)63;
+  const size_t bytes = bytes_d + stride * sizeof(int) + stride + stride + (nq_pad + 64) * sizeof(int);
   hipError_t he = hipMalloc(&P->pool, bytes);
   if (he != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(he)); delete P; return MA_ERR_NOMEM; }
   char* base = (char*)P->pool;
@@ -168,6 +175,8 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   MA_TRY(hipMemcpy(base + (size_t)ND * stride * sizeof(double), harea.data(), stride * sizeof(double), hipMemcpyHostToDevice));
   MA_TRY(hipMemcpy(base + bytes_d, hdof.data(), stride * sizeof(int), hipMemcpyHostToDevice));
   MA_TRY(hipMemcpy(base + bytes_d + stride * sizeof(int), hbc.data(), stride, hipMemcpyHostToDevice));
+  MA_TRY(hipMemcpy(base + bytes_d + stride * sizeof(int) + stride, hpt.data(), stride, hipMemcpyHostToDevice));
+  if (!hquads.empty()) MA_TRY(hipMemcpy(base + bytes_d + stride * sizeof(int) + 2 * stride, hquads.data(), hquads.size() * sizeof(int), hipMemcpyHostToDevice));
   BemGeom& g = P->geom;
   g.np = np; g.nd = np;
   const double* dd = (const double*)base;
@@ -180,6 +189,10 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   g.area = dd + (size_t)ND * stride;
   g.dof = (const int*)(base + bytes_d);
   g.bc_type = (const unsigned char*)(base + bytes_d + stride * sizeof(int));
+  for (int d = 0; d < 3; ++d) g.p3[d] = dd + (size_t)(25 + d) * stride;
+  g.ptype = (const unsigned char*)(base + bytes_d + stride * sizeof(int) + stride);
+  g.quad_ids = (const int*)(base + bytes_d + stride * sizeof(int) + 2 * stride);
+  g.nquad = (int)hquads.size();
 
   // constant tables (13-point rule scaled by 0.5 as triangle_quadrature does, gauss.rs:70)
   double t13[13][3];
@@ -224,6 +237,10 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
           const ma_c64 v = m->bc_values[4 * e + a];
           hv[4 * (size_t)p + a].re = v.re; hv[4 * (size_t)p + a].im = v.im;
           if (std::hypot(v.re, v.im) > 1e-15) hz[p] = 1;                   // has_nonzero_bc, tbem.rs:247-249
+          if (hz[p] && hpt[p] == 4) {
+            set_error("element %d: non-zero boundary values on Quad4 panels are not on the device yet", e);
+            (void)hipFree(P->d_pair_off); return fail(MA_ERR_UNSUPPORTED);
+          }
         }
       any = any || hz[p];
     }

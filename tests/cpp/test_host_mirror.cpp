@@ -60,10 +60,10 @@ static void test_tbem_diagonal_nonzero_and_qa() {       // tbem.rs:585-598 + qa_
     num += std::norm(p[i] - approx); den += std::norm(approx);
   }
   CHECK(std::sqrt(num / den) < 0.05);
-  // error behaviour: a Quad4 element is refused loudly, never silently computed on the CPU
-  Mesh bad = mesh; bad.elements[0].connectivity.push_back(3);
+  // error behaviour: an element that references a node outside the mesh is refused before anything is computed
+  Mesh bad = mesh; bad.elements[0].connectivity[1] = 100000;
   bool threw = false;
-  try { build_tbem_system_with_beta(bad.elements, bad.nodes, physics, beta); } catch (const BemError& e) { threw = e.status == MA_ERR_UNSUPPORTED; }
+  try { build_tbem_system_with_beta(bad.elements, bad.nodes, physics, beta); } catch (const BemError& e) { threw = e.status == MA_ERR_INVALID; }
   CHECK(threw);
 }
 

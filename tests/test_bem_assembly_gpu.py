@@ -100,14 +100,6 @@ def test_incident_rhs_matches_oracle(gpu):
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
-def test_unsupported_inputs_fail_loudly(gpu):
-    om = O.icosphere(RADIUS, 1)
-    om.conn[0, 3] = 2
-    with pytest.raises(ma.MaError) as e:
-        ma.assemble_tbem(to_ma_mesh(om), 10.0, 0.4j)
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED
-
-
 @pytest.mark.parametrize("case", ["velocity_const", "velocity_nodal", "pressure", "mixed_patch"])
 def test_boundary_values_reach_the_rhs(gpu, case):
     """Non-zero boundary values: free-term share (tbem.rs:273-304) + rhs_contribution of every pair

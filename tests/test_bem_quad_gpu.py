@@ -1,0 +1,116 @@
+"""GPU parity of the Quad4 path (ElementType::Quad4): bilinear panels, n x n Gauss rules by distance, quad-tree
+subdivision, 4-edge singular term -- against the CPU restatement of regular.rs / singular.rs, on meshes of warped
+(non-planar) quads and on a mixed Tri3 + Quad4 mesh."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from helpers import to_ma_mesh, k_from_ka, RADIUS
+
+pytestmark = pytest.mark.gpu
+
+
+def cube_sphere(radius, m, split_some=False):
+    """Closed surface of 6 m^2 quads: a cube's face grids projected onto the sphere (warped bilinear quads).
+    split_some: every third quad becomes two triangles (mixed mesh)."""
+    idx = {}
+    nodes = []
+
+    def nid(p):
+        key = tuple(np.round(p, 12))
+        if key not in idx:
+            idx[key] = len(nodes); nodes.append(p)
+        return idx[key]
+    conn = []
+    g = np.linspace(-1.0, 1.0, m + 1)
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            for a in range(m):
+                for b in range(m):
+                    quad = []
+                    for (u, v) in ((g[a], g[b]), (g[a + 1], g[b]), (g[a + 1], g[b + 1]), (g[a], g[b + 1])):
+                        p = np.zeros(3); p[axis] = sign; p[(axis + 1) % 3] = u; p[(axis + 2) % 3] = v
+                        quad.append(nid(radius * p / np.linalg.norm(p)))
+                    if sign < 0:
+                        quad = quad[::-1]
+                    if split_some and (len(conn) % 3 == 0):
+                        conn.append([quad[0], quad[1], quad[2], -1]); conn.append([quad[0], quad[2], quad[3], -1])
+                    else:
+                        conn.append(quad)
+    return O.Mesh(np.array(nodes), np.array(conn, dtype=np.int32))
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("ka", [0.2, 2.5])
+def test_quad_assembly_matches_oracle(gpu, mixed, ka):
+    om = cube_sphere(RADIUS, 5, split_some=mixed)
+    assert (om.conn[:, 3] >= 0).sum() > 0
+    k = k_from_ka(ka)
+    beta = complex(0.0, 4.0 / k)
+    A_ref, rhs_ref = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    A, rhs = ma.assemble_tbem(to_ma_mesh(om), k, beta)
+    assert np.all(np.isfinite(A.view(np.float64)))
+    scale = np.abs(A_ref).max(axis=1, keepdims=True)
+    err = np.abs(A - A_ref) / scale
+    assert err.max() <= 1e-9, np.unravel_index(err.argmax(), err.shape)
+    assert np.abs(rhs).max() == 0.0
+
+
+def test_quad_near_list_leaf_counts_and_raw_integrals(gpu):
+    om = cube_sphere(RADIUS, 6)
+    n = om.n_elem
+    k = k_from_ka(1.0)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    near = plan.near_pairs()
+    ref = set()
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                subs = O.generate_subelements(om.center[i], om.coords(j), om.area[j])
+                if not (len(subs) == 1 and abs(subs[0].factor - 1.0) < 1e-10):
+                    ref.add((i, j))
+    assert set(map(tuple, near.tolist())) == ref
+    rng = np.random.default_rng(3)
+    pick = near[rng.choice(len(near), min(300, len(near)), replace=False)]
+    out = plan.probe_pairs(k, pick.astype(np.int32))
+    for q, (i, j) in enumerate(pick):
+        r = O.regular_integration(om.center[i], om.normal[i], om.coords(j), om.area[j], k)[:4]
+        assert int(round(out[q, 0].real)) == len(O.generate_subelements(om.center[i], om.coords(j), om.area[j]))
+        assert np.all(np.abs(out[q, 1:5] - r) <= 1e-10 * np.abs(r).max()), (i, j)
+    selfs = plan.probe_self(k)
+    for e in range(0, n, 5):
+        r = O.singular_integration(om.center[e], om.normal[e], om.coords(e), k)[:4]
+        assert np.all(np.abs(selfs[e, 1:5] - r) <= 1e-10 * np.abs(r).max()), e
+    plan.close()
+
+
+def test_quad_very_near_point_hits_the_split_limit(gpu):
+    """A collocation point hovering just above a big quad: the 15-splits-per-level limit of generate_subelements
+    (singular.rs:556-562) drops pieces; the device must drop the same ones."""
+    h = 0.02
+    nodes = np.array([[1, 1, 0], [-1, 1, 0], [-1, -1, 0], [1, -1, 0],          # the big quad
+                      [0.30, 0.20, h], [0.34, 0.20, h], [0.34, 0.24, h], [0.30, 0.24, h]], dtype=float)   # a tiny one above it
+    om = O.Mesh(nodes, np.array([[0, 1, 2, 3], [4, 5, 6, 7]], dtype=np.int32))
+    subs = O.generate_subelements(om.center[1], om.coords(0), om.area[0])
+    assert len(subs) > 40
+    plan = ma.BemPlan(to_ma_mesh(om))
+    k = 3.0
+    out = plan.probe_pairs(k, np.array([[1, 0]], dtype=np.int32))
+    r = O.regular_integration(om.center[1], om.normal[1], om.coords(0), om.area[0], k)[:4]
+    assert int(round(out[0, 0].real)) == len(subs)
+    assert np.all(np.abs(out[0, 1:5] - r) <= 1e-10 * np.abs(r).max())
+    plan.close()
+
+
+def test_quad_unsupported_corners_fail_loudly(gpu):
+    om = cube_sphere(RADIUS, 3)
+    om.bc_values[2, 0] = 1.0                              # boundary values on a quad: not on the device yet
+    with pytest.raises(ma.MaError) as e:
+        ma.BemPlan(to_ma_mesh(om))
+    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    om = cube_sphere(RADIUS, 3)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    with pytest.raises(ma.MaError) as e:
+        ma.LinearOperator.tbem(plan, 10.0, 0.4j)
+    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    plan.close()

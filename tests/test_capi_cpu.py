@@ -45,11 +45,6 @@ def test_argument_validation_precedes_the_device():
     assert L.ma_bem_plan_create(None, 0, C.byref(h)) == ma.MA_ERR_INVALID
     assert b"NULL" in L.ma_last_error_string()
     om = O.icosphere(RADIUS, 0)
-    om.conn[2, 3] = 1                                              # a Quad4 element
-    with pytest.raises(ma.MaError) as e:
-        ma.BemPlan(to_ma_mesh(om))
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED and "Quad4" in str(e.value)
-    om = O.icosphere(RADIUS, 0)
     om.bc_len[1] = 7                                               # more boundary values than a panel has slots
     with pytest.raises(ma.MaError) as e:
         ma.BemPlan(to_ma_mesh(om))
