@@ -85,7 +85,6 @@ typedef struct {
  * rhs: num_dofs, overwritten (TbemSystem.rhs: free-term shares and rhs_contributions of the elements that carry
  *      non-zero boundary values, tbem.rs:273-304, regular.rs:157-177, singular.rs:360-392; zero for rigid scatterers).
  * Tri3 and Quad4 elements (conn row = 3 node ids and -1, or 4 node ids), also mixed.
- * MA_ERR_UNSUPPORTED: non-zero boundary values on Quad4 elements.
  * ------------------------------------------------------------------------------------------ */
 int ma_bem_assemble_tbem(const ma_mesh_t* mesh, const ma_physics_t* physics,
                          double beta_re, double beta_im, ma_c64* A, ma_c64* rhs);

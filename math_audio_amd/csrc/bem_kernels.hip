@@ -550,23 +550,9 @@ __global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys p
   }
 }
 
-// K2q: near pairs with a quad field panel. generate_subelements for nv = 4 (singular.rs:497-660): a split yields the
-// children [v_j, mid(v_j, v_j+1), centre, mid(v_j-1, v_j)], j = 0..3, each with its own vertex order (which decides the
-// order of ITS children, hence which pieces the 15-splits-per-level limit drops); leaves keep centre, half-width and order.
-template <int MODE>   // 0: write A[i][j]; 1: probe {leaves, G, H, H^T, E}; 2: coefficient to out[pid]
-__global__ __launch_bounds__(256) void tbem_near_quad_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs, long long npairs, dc* __restrict__ A) {
-  __shared__ double s_leaf[4][MA_MAX_LEAVES][4];
-  __shared__ double s_next[4][MA_MAX_NSE][8];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long pid = (long long)blockIdx.x * 4 + wave;
-  if (pid >= npairs) return;
-  const int2 pr = pairs[pid];
-  const int i = pr.x, j = pr.y;
-  if (g.ptype[j] != 4) return;
-  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
-  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
-  double v[12]; quad_load(g, j, v);
-  const double area = g.area[j];
+// generate_subelements for nv = 4: leaves {xi centre, eta centre, half-width, Gauss order} in s_leaf[wave][0..nleaf)
+__device__ __forceinline__ int quad_build_leaves(const double* v, double area, double cx, double cy, double cz, int wave, int lane,
+                                                 double (*s_leaf)[MA_MAX_LEAVES][4], double (*s_next)[MA_MAX_NSE][8]) {
   double sv[4] = {1.0, -1.0, -1.0, 1.0}, tv[4] = {1.0, 1.0, -1.0, -1.0};
   int nsel = 1, nleaf = 0;
   double faclin = 2.0;
@@ -633,6 +619,28 @@ __global__ __launch_bounds__(256) void tbem_near_quad_kernel(BemGeom g, BemPhys 
     wave_lds_sync();
   }
   wave_lds_sync();
+
+  return nleaf;
+}
+
+// K2q: near pairs with a quad field panel. generate_subelements for nv = 4 (singular.rs:497-660): a split yields the
+// children [v_j, mid(v_j, v_j+1), centre, mid(v_j-1, v_j)], j = 0..3, each with its own vertex order (which decides the
+// order of ITS children, hence which pieces the 15-splits-per-level limit drops); leaves keep centre, half-width and order.
+template <int MODE>   // 0: write A[i][j]; 1: probe {leaves, G, H, H^T, E}; 2: coefficient to out[pid]
+__global__ __launch_bounds__(256) void tbem_near_quad_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs, long long npairs, dc* __restrict__ A) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][4];
+  __shared__ double s_next[4][MA_MAX_NSE][8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  if (g.ptype[j] != 4) return;
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[12]; quad_load(g, j, v);
+  const double area = g.area[j];
+  const int nleaf = quad_build_leaves(v, area, cx, cy, cz, wave, lane, s_leaf, s_next);
 
   // ---- integrate leaf by leaf: lane = point of the leaf's n x n rule (n <= 7)
   const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
@@ -805,8 +813,8 @@ __device__ __forceinline__ dc green_point_k(double dx, double dy, double dz, dou
   const double hre = bre * a, him = bim * a;
   return dc_make(-(gt * hre - bp * eim), -(gt * him + bp * ere));
 }
-__device__ __forceinline__ dc bc_combine(const BemBc& bc, int j, const dc acc[3]) {
-  const int len = min(bc.len[j], 3);
+__device__ __forceinline__ dc bc_combine(const BemBc& bc, int j, const dc* acc, int nn = 3) {
+  const int len = min(bc.len[j], nn);
   dc t = dc_make(0.0, 0.0);
   for (int a = 0; a < len; ++a) { const dc v = bc.val[4 * j + a]; t.re += v.re * acc[a].re - v.im * acc[a].im; t.im += v.re * acc[a].im + v.im * acc[a].re; }
   return t;
@@ -822,7 +830,7 @@ __global__ __launch_bounds__(256) void tbem_rhs_far_kernel(BemGeom g, BemPhys ph
   const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
   double sre = 0.0, sim = 0.0;
   for (int j = lane; j < g.np; j += 64) {
-    if (!bc.nz[j] || j == i || pair_is_near(g, i, j)) continue;
+    if (!bc.nz[j] || j == i || (g.nquad > 0 && g.ptype[j] == 4) || pair_is_near(g, i, j)) continue;
     const int fbc = g.bc_type[j];
     const double nyx = g.ny[0][j], nyy = g.ny[1][j], nyz = g.ny[2][j];
     const double e1x = g.e1[0][j], e1y = g.e1[1][j], e1z = g.e1[2][j];
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(256) void tbem_rhs_near_kernel(BemGeom g, BemPhys p
   if (pid >= npairs) return;
   const int2 pr = pairs[pid];
   const int i = pr.x, j = pr.y;
-  if (!bc.nz[j]) { if (lane == 0) out[pid] = dc_make(0.0, 0.0); return; }
+  if (!bc.nz[j] || (g.nquad > 0 && g.ptype[j] == 4)) { if (lane == 0) out[pid] = dc_make(0.0, 0.0); return; }   // quad pairs: tbem_rhs_near_quad_kernel overwrites
   const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
   const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
   double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(256) void tbem_rhs_self_kernel(BemGeom g, BemPhys p
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + wave;
   if (e >= g.np) return;
-  if (!bc.nz[e] || g.bc_type[e] != 0) { if (lane == 0) out[e] = dc_make(0.0, 0.0); return; }
+  if (!bc.nz[e] || g.bc_type[e] != 0 || (g.nquad > 0 && g.ptype[e] == 4)) { if (lane == 0) out[e] = dc_make(0.0, 0.0); return; }   // quads: tbem_rhs_self_quad_kernel overwrites
   const double cx = g.c[0][e], cy = g.c[1][e], cz = g.c[2][e];
   const double nxx = g.nx[0][e], nxy = g.nx[1][e], nxz = g.nx[2][e];
   const double P[3][3] = {{g.p0[0][e], g.p0[1][e], g.p0[2][e]}, {g.p1[0][e], g.p1[1][e], g.p1[2][e]}, {g.p2[0][e], g.p2[1][e], g.p2[2][e]}};
@@ -955,6 +963,136 @@ __global__ __launch_bounds__(256) void tbem_rhs_self_kernel(BemGeom g, BemPhys p
 #pragma unroll
   for (int a = 0; a < 3; ++a) { acc[a].re = wave_sum(acc[a].re); acc[a].im = wave_sum(acc[a].im); }
   if (lane == 0) out[e] = bc_combine(bc, e, acc);
+}
+
+// ---- the same three passes for Quad4 field panels that carry values (bilinear N_0..N_3, up to 4 values)
+__device__ __forceinline__ void quad_weights(double s, double t, double* n) {
+  const double s1 = 0.25 * (s + 1.0), s2 = 0.25 * (s - 1.0), t1 = t + 1.0, t2 = t - 1.0;
+  n[0] = s1 * t1; n[1] = -s2 * t1; n[2] = s2 * t2; n[3] = -s1 * t2;
+}
+__device__ __forceinline__ void quad_point_k(const double* v, double s, double t, double w, double cx, double cy, double cz, double nxx, double nxy,
+                                             double nxz, double k, double k2, int fbc, double gt, double bp, dc* acc) {
+  const QuadPoint q = quad_point(v, s, t, cx, cy, cz);
+  const double m = nxx * q.nyx + nxy * q.nyy + nxz * q.nyz;
+  const dc kv = green_point_k(q.dx, q.dy, q.dz, w * q.jac * MA_INV4PI, k, k2, q.nyx, q.nyy, q.nyz, nxx, nxy, nxz, m, fbc, gt, bp);
+  double n[4]; quad_weights(s, t, n);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a].re += n[a] * kv.re; acc[a].im += n[a] * kv.im; }
+}
+
+// far quad pairs: one wavefront per row, lanes stride over the quad panels; ADDS to out[i] (after tbem_rhs_far_kernel)
+__global__ __launch_bounds__(256) void tbem_rhs_far_quad_kernel(BemGeom g, BemPhys ph, BemBc bc, dc* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= g.np) return;
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+  const double cs[4] = {1.0, -1.0, -1.0, 1.0}, ct[4] = {1.0, 1.0, -1.0, -1.0};
+  double sre = 0.0, sim = 0.0;
+  for (int q = lane; q < g.nquad; q += 64) {
+    const int j = g.quad_ids[q];
+    if (!bc.nz[j] || j == i) continue;
+    double v[12]; quad_load(g, j, v);
+    double sq;
+    {
+#pragma clang fp contract(off)
+      double arels = g.area[j] * 1.0 * 1.0;
+      sq = __builtin_sqrt(arels);
+    }
+    const double ratio = quad_ratio(cs, ct, v, cx, cy, cz, sq);
+    if (ratio < 3.0) continue;                            // near pair: tbem_rhs_near_quad_kernel
+    const int order = quad_gauss_order(ratio);
+    const int off = c_gl_index[order][0], n = c_gl_index[order][1];
+    dc acc[4] = {dc_make(0, 0), dc_make(0, 0), dc_make(0, 0), dc_make(0, 0)};
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b)
+        quad_point_k(v, c_gl_x[off + a], c_gl_x[off + b], c_gl_w[off + a] * c_gl_w[off + b], cx, cy, cz, nxx, nxy, nxz, k, k2, g.bc_type[j], gt, bp, acc);
+    const dc t = bc_combine(bc, j, acc, 4);
+    sre += t.re; sim += t.im;
+  }
+  sre = wave_sum(sre); sim = wave_sum(sim);
+  if (lane == 0) { out[i].re += sre; out[i].im += sim; }
+}
+
+__global__ __launch_bounds__(256) void tbem_rhs_near_quad_kernel(BemGeom g, BemPhys ph, BemBc bc, const int2* __restrict__ pairs, long long npairs,
+                                                                 dc* __restrict__ out) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][4];
+  __shared__ double s_next[4][MA_MAX_NSE][8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  if (g.ptype[j] != 4 || !bc.nz[j]) return;               // tri pairs / value-free pairs were written by tbem_rhs_near_kernel
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[12]; quad_load(g, j, v);
+  const int nleaf = quad_build_leaves(v, g.area[j], cx, cy, cz, wave, lane, s_leaf, s_next);
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+  const int fbc = g.bc_type[j];
+  dc acc[4] = {dc_make(0, 0), dc_make(0, 0), dc_make(0, 0), dc_make(0, 0)};
+  for (int lf = 0; lf < nleaf; ++lf) {
+    const double* L = s_leaf[wave][lf];
+    const double xice = L[0], etce = L[1], fase = L[2];
+    const int order = (int)L[3];
+    const int off = c_gl_index[order][0], n = c_gl_index[order][1];
+    if (lane < n * n) {
+      const int a = lane / n, b = lane - a * n;
+      quad_point_k(v, xice + c_gl_x[off + a] * fase, etce + c_gl_x[off + b] * fase, c_gl_w[off + a] * c_gl_w[off + b] * (fase * fase), cx, cy, cz,
+                   nxx, nxy, nxz, k, k2, fbc, gt, bp, acc);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a].re = wave_sum(acc[a].re); acc[a].im = wave_sum(acc[a].im); }
+  if (lane == 0) out[pid] = bc_combine(bc, j, acc, 4);
+}
+
+// self term of a quad with velocity values: the weighted collapsed-square points of tbem_self_quad_kernel
+__global__ __launch_bounds__(256) void tbem_rhs_self_quad_kernel(BemGeom g, BemPhys ph, BemBc bc, dc* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + wave;
+  if (e >= g.np) return;
+  if (g.ptype[e] != 4 || !bc.nz[e] || g.bc_type[e] != 0) return;      // others: tbem_rhs_self_kernel wrote the slot
+  const double cx = g.c[0][e], cy = g.c[1][e], cz = g.c[2][e];
+  const double nxx = g.nx[0][e], nxy = g.nx[1][e], nxz = g.nx[2][e];
+  double v[12]; quad_load(g, e, v);
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k, gt = ph.gamma * ph.tau, bp = ph.tau > 0.0 ? ph.harmonic / ph.k : 0.0;
+  double el = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int b = (a + 1) & 3;
+    const double ddx = v[3 * b] - v[3 * a], ddy = v[3 * b + 1] - v[3 * a + 1], ddz = v[3 * b + 2] - v[3 * a + 2];
+    el += __builtin_sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+  }
+  const double ka = ph.k * (el / 4.0);
+  int ngausin, nsec2;
+  if (ka < 0.3)      { ngausin = 4; nsec2 = 2; }
+  else if (ka < 1.0) { ngausin = 5; nsec2 = 2; }
+  else if (ka < 2.0) { ngausin = 6; nsec2 = 3; }
+  else               { ngausin = 7; nsec2 = 4; }
+  const int so = c_gl_index[ngausin][0], ns = c_gl_index[ngausin][1];
+  const int per_edge = nsec2 * ns * ns;
+  dc acc[4] = {dc_make(0, 0), dc_make(0, 0), dc_make(0, 0), dc_make(0, 0)};
+  for (int t = lane; t < 4 * per_edge; t += 64) {
+    const int ieg = t / per_edge, v2 = t - ieg * per_edge;
+    const int ig1 = (ieg + 1) & 3, ig2 = ieg + 4;
+    const int isec = v2 / (ns * ns);
+    const int ij = v2 - isec * ns * ns;
+    const int ii = ij / ns, jj = ij - ii * ns;
+    const double aresub = 0.25 / (double)nsec2;
+    double ss1, ss2, ts1, ts2;
+    if (isec == 0) { ss1 = c_csi8[ieg]; ss2 = c_csi8[ig2]; ts1 = c_eta8[ieg]; ts2 = c_eta8[ig2]; }
+    else           { ss1 = c_csi8[ig2]; ss2 = c_csi8[ig1]; ts1 = c_eta8[ig2]; ts2 = c_eta8[ig1]; }
+    const double sga = c_gl_x[so + ii], tga = c_gl_x[so + jj];
+    const double wei = c_gl_w[so + ii] * c_gl_w[so + jj];
+    const double sgg = 0.25 * (1.0 + sga) * ((1.0 - tga) * ss1 + (1.0 + tga) * ss2);
+    const double tgg = 0.25 * (1.0 + sga) * ((1.0 - tga) * ts1 + (1.0 + tga) * ts2);
+    quad_point_k(v, sgg, tgg, wei * (1.0 + sga) * aresub, cx, cy, cz, nxx, nxy, nxz, k, k2, 0, gt, bp, acc);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { acc[a].re = wave_sum(acc[a].re); acc[a].im = wave_sum(acc[a].im); }
+  if (lane == 0) out[e] = bc_combine(bc, e, acc, 4);
 }
 
 // rhs[dof_i] = free-term share + far[i] + sum of the row's near pairs (in list order) + self[i]; `self5` holds the raw
@@ -1111,6 +1249,12 @@ int bem_launch_rhs_bc(const BemGeom& g, const BemPhys& ph, const BemBc& bc, cons
   if (npairs > 0) hipLaunchKernelGGL(tbem_rhs_near_kernel, dim3((unsigned)((npairs + 3) / 4)), block, 0, st, g, ph, bc, pairs, npairs, near);
   hipLaunchKernelGGL(tbem_rhs_self_kernel, rows, block, 0, st, g, ph, bc, selfv);
   hipLaunchKernelGGL(tbem_self_kernel<1>, rows, block, 0, st, g, ph, self5);
+  if (g.nquad > 0) {
+    hipLaunchKernelGGL(tbem_rhs_far_quad_kernel, rows, block, 0, st, g, ph, bc, far);
+    if (npairs > 0) hipLaunchKernelGGL(tbem_rhs_near_quad_kernel, dim3((unsigned)((npairs + 3) / 4)), block, 0, st, g, ph, bc, pairs, npairs, near);
+    hipLaunchKernelGGL(tbem_rhs_self_quad_kernel, rows, block, 0, st, g, ph, bc, selfv);
+    hipLaunchKernelGGL(tbem_self_quad_kernel<1>, rows, block, 0, st, g, ph, self5);
+  }
   hipLaunchKernelGGL(tbem_rhs_finish_kernel, dim3((g.np + 255) / 256), block, 0, st, g, ph, bc, far, near, pair_off, selfv, self5, reinterpret_cast<dc*>(rhs));
   MA_HIP(hipGetLastError());
   return MA_OK;

@@ -237,10 +237,6 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
           const ma_c64 v = m->bc_values[4 * e + a];
           hv[4 * (size_t)p + a].re = v.re; hv[4 * (size_t)p + a].im = v.im;
           if (std::hypot(v.re, v.im) > 1e-15) hz[p] = 1;                   // has_nonzero_bc, tbem.rs:247-249
-          if (hz[p] && hpt[p] == 4) {
-            set_error("element %d: non-zero boundary values on Quad4 panels are not on the device yet", e);
-            (void)hipFree(P->d_pair_off); return fail(MA_ERR_UNSUPPORTED);
-          }
         }
       any = any || hz[p];
     }

@@ -135,7 +135,8 @@ int ma_room_build_matrix(int32_t n, const double* center, const double* normal, 
 int ma_bem_plan_scattered_field(ma_bem_plan_t* P, const ma_physics_t* physics, int32_t n_eval, const double* eval_points,
                                 const ma_c64* surface_pressure, const ma_c64* surface_velocity, ma_c64* out) {
   MA_REQUIRE(P && physics && n_eval > 0 && eval_points && surface_pressure && out, MA_ERR_INVALID, "bad argument");
-  MA_REQUIRE(P->geom.nquad == 0, MA_ERR_UNSUPPORTED, "field evaluation over Quad4 panels is not on the device (the reference itself integrates only their first three nodes, pressure.rs:166-198)");
+  // Quad4 panels: the reference integrates the triangle of their first three nodes with the 7-point rule
+  // (pressure.rs:166-198); the plan's Tri3 arrays (p0, e1, e2, n_y, jac) of a quad are exactly that triangle.
   MA_HIP(hipSetDevice(P->device));
   double t7[7][3];
   for (int q = 0; q < 7; ++q) { t7[q][0] = mat_tri7[q][0]; t7[q][1] = mat_tri7[q][1]; t7[q][2] = mat_tri7[q][2] * 0.5; }

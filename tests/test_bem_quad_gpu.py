@@ -102,15 +102,51 @@ def test_quad_very_near_point_hits_the_split_limit(gpu):
     plan.close()
 
 
-def test_quad_unsupported_corners_fail_loudly(gpu):
-    om = cube_sphere(RADIUS, 3)
-    om.bc_values[2, 0] = 1.0                              # boundary values on a quad: not on the device yet
-    with pytest.raises(ma.MaError) as e:
-        ma.BemPlan(to_ma_mesh(om))
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+def test_quad_matrix_free_operator_is_refused(gpu):
     om = cube_sphere(RADIUS, 3)
     plan = ma.BemPlan(to_ma_mesh(om))
-    with pytest.raises(ma.MaError) as e:
+    with pytest.raises(ma.MaError) as e:                  # the streaming operator is the Tri3 13-point rule
         ma.LinearOperator.tbem(plan, 10.0, 0.4j)
     assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    plan.close()
+
+
+@pytest.mark.parametrize("case", ["velocity_const", "nodal", "pressure_patch"])
+def test_quad_boundary_values_reach_the_rhs(gpu, case):
+    """rhs_contribution and free-term shares with Quad4 (and mixed) field panels: bilinear N_0..N_3, up to 4 values."""
+    om = cube_sphere(RADIUS, 4, split_some=(case != "velocity_const"))
+    n = om.n_elem
+    nn = np.where(om.conn[:, 3] >= 0, 4, 3)
+    rng = np.random.default_rng(8)
+    if case == "velocity_const":
+        om.bc_values[:, 0] = 1e-3 * (1.0 - 0.4j)
+    elif case == "nodal":
+        om.bc_len[:] = nn
+        vals = 1e-3 * (rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4)))
+        om.bc_values[:] = np.where(np.arange(4)[None, :] < nn[:, None], vals, 0.0)
+    else:
+        om.bc_type[10:40] = 1; om.bc_len[10:40] = nn[10:40]
+        om.bc_values[10:40, :] = np.where(np.arange(4)[None, :] < nn[10:40, None], rng.standard_normal((30, 4)) + 0.2j, 0.0)
+        om.bc_values[60:70, 0] = 2e-3
+    for ka in (0.3, 2.2):
+        k = k_from_ka(ka)
+        beta = complex(0.0, 4.0 / k)
+        A_ref, rhs_ref = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+        A, rhs = ma.assemble_tbem(to_ma_mesh(om), k, beta)
+        assert np.abs(rhs_ref).max() > 0
+        assert np.abs(rhs - rhs_ref).max() <= 1e-10 * np.abs(rhs_ref).max()
+        assert (np.abs(A - A_ref) / np.abs(A_ref).max(axis=1, keepdims=True)).max() <= 1e-9
+
+
+def test_quad_field_evaluation_follows_the_reference_quirk(gpu):
+    """integrate_element_field (pressure.rs:154-258) uses the triangle of a quad's first three nodes."""
+    om = cube_sphere(RADIUS, 4, split_some=True)
+    k = k_from_ka(1.0)
+    rng = np.random.default_rng(2)
+    ps = rng.standard_normal(om.n_elem) + 1j * rng.standard_normal(om.n_elem)
+    ep = 2.5 * RADIUS * np.array([[0, 0, 1.0], [1.0, 0, 0], [0.6, -0.8, 0], [0.0, 0.6, 0.8]])
+    plan = ma.BemPlan(to_ma_mesh(om))
+    ref = O.compute_scattered_field(ep, om, ps, k)
+    got = ma.scattered_field(plan, k, ep, ps)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
     plan.close()
