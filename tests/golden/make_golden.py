@@ -23,6 +23,33 @@ def k_from_ka(ka):
     return O.wave_number(k * C / (2.0 * np.pi), C)
 
 
+def mixed_cube_sphere(radius, m):
+    """6 m^2 quads of a cube's face grids projected onto the sphere; every third quad split into two triangles."""
+    idx, nodes, conn = {}, [], []
+    g = np.linspace(-1.0, 1.0, m + 1)
+
+    def nid(p):
+        key = tuple(np.round(p, 12))
+        if key not in idx:
+            idx[key] = len(nodes); nodes.append(p)
+        return idx[key]
+    for axis in range(3):
+        for sign in (-1.0, 1.0):
+            for a in range(m):
+                for b in range(m):
+                    quad = []
+                    for (u, v) in ((g[a], g[b]), (g[a + 1], g[b]), (g[a + 1], g[b + 1]), (g[a], g[b + 1])):
+                        p = np.zeros(3); p[axis] = sign; p[(axis + 1) % 3] = u; p[(axis + 2) % 3] = v
+                        quad.append(nid(radius * p / np.linalg.norm(p)))
+                    if sign < 0:
+                        quad = quad[::-1]
+                    if len(conn) % 3 == 0:
+                        conn.append([quad[0], quad[1], quad[2], -1]); conn.append([quad[0], quad[2], quad[3], -1])
+                    else:
+                        conn.append(quad)
+    return np.array(nodes), np.array(conn, dtype=np.int32)
+
+
 def main():
     out = {}
     # --- 80-panel icosphere system at ka = 1 (sign -1, beta = 4i/k) and ka = 0.2 (sign +1, beta = i/k)
@@ -62,6 +89,19 @@ def main():
     s10 = O.uv_sphere(RADIUS, 51, 100)
     out["s10_checksums"] = np.array([s10.nodes.sum(), np.abs(s10.nodes).sum(), s10.area.sum(), s10.center[:, 2].sum(),
                                      float(s10.conn[:, :3].astype(np.int64).sum()), float(s10.n_elem)])
+    # --- a mixed Tri3 + Quad4 mesh (cube-sphere, 2 x 2 faces, every third quad split) with nodal boundary values:
+    #     matrix and boundary-value right-hand side at ka = 1, beta = 4i/k
+    nodes, conn = mixed_cube_sphere(RADIUS, 2)
+    mq = O.Mesh(nodes, conn)
+    nn = np.where(mq.conn[:, 3] >= 0, 4, 3)
+    mq.bc_len[:] = nn
+    t = np.arange(mq.n_elem)[:, None] * 4 + np.arange(4)[None, :]
+    mq.bc_values[:] = np.where(np.arange(4)[None, :] < nn[:, None], 1e-3 * (np.cos(0.7 * t) + 1j * np.sin(0.3 * t)), 0.0)
+    mq.bc_type[5:9] = 1
+    k = k_from_ka(1.0); beta = complex(0.0, 4.0 / k)
+    Aq, rq = O.build_tbem_system_with_beta(mq, k, beta)
+    out["mixq_nodes"] = mq.nodes; out["mixq_conn"] = mq.conn; out["mixq_bc_type"] = mq.bc_type; out["mixq_bc_len"] = mq.bc_len
+    out["mixq_bc_values"] = mq.bc_values; out["mixq_k"] = np.array([k]); out["mixq_beta"] = np.array([beta]); out["mixq_A"] = Aq; out["mixq_rhs"] = rq
     np.savez_compressed(os.path.join(HERE, "bem_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "bem_golden.npz"), {k: v.shape for k, v in out.items()})
 

@@ -150,3 +150,15 @@ def test_quad_field_evaluation_follows_the_reference_quirk(gpu):
     got = ma.scattered_field(plan, k, ep, ps)
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
     plan.close()
+
+
+def test_golden_mixed_mesh_fixture(gpu):
+    """Device vs the committed fixture (tests/golden/bem_golden.npz: mixq_*)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bem_golden.npz"))
+    om = O.Mesh(G["mixq_nodes"], G["mixq_conn"])
+    om.bc_type = G["mixq_bc_type"].copy(); om.bc_len = G["mixq_bc_len"].copy(); om.bc_values = G["mixq_bc_values"].copy()
+    A, rhs = ma.assemble_tbem(to_ma_mesh(om), float(G["mixq_k"][0]), complex(G["mixq_beta"][0]))
+    Ag = G["mixq_A"]
+    assert (np.abs(A - Ag) / np.abs(Ag).max(axis=1, keepdims=True)).max() <= 1e-9
+    assert np.abs(rhs - G["mixq_rhs"]).max() <= 1e-10 * np.abs(G["mixq_rhs"]).max()

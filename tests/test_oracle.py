@@ -355,3 +355,62 @@ def test_gmres_preconditioned_restatement():
         x2, i2 = O.gmres_preconditioned(b, (rp, ci, vals), pkind=pk, omega=1.0, sweeps=1, restart=20, max_iterations=10, tol=1e-10)
         assert i2.converged == 1 and i2.iterations <= i0.iterations
         assert np.linalg.norm(dense @ x2 - b) / np.linalg.norm(b) < 1e-8
+
+
+# ---------------------------------------------------------------- Quad4 restatement (regular.rs:211-260, singular.rs:257-357)
+def _quad_brute(x, nx, coords, k, n=160):
+    """G and dG/dn_y over a bilinear quad by an n x n mid-point... Gauss rule on [-1,1]^2 (independent of the restatement)."""
+    g, w = np.polynomial.legendre.leggauss(n)
+    S, T = np.meshgrid(g, g, indexing="ij"); W = np.outer(w, w)
+    N = np.stack([0.25 * (S + 1) * (T + 1), 0.25 * (1 - S) * (T + 1), 0.25 * (1 - S) * (1 - T), 0.25 * (S + 1) * (1 - T)])
+    dS = np.stack([0.25 * (T + 1), -0.25 * (T + 1), 0.25 * (T - 1), -0.25 * (T - 1)])
+    dT = np.stack([0.25 * (S + 1), 0.25 * (1 - S), 0.25 * (S - 1), -0.25 * (S + 1)])
+    P = np.einsum("aij,ad->ijd", N, coords); A = np.einsum("aij,ad->ijd", dS, coords); B = np.einsum("aij,ad->ijd", dT, coords)
+    nrm = np.cross(A, B); J = np.linalg.norm(nrm, axis=2); ny = nrm / J[..., None]
+    d = P - x; r = np.linalg.norm(d, axis=2)
+    G = np.exp(1j * k * r) / (4 * np.pi * r)
+    H = G * (-1.0 / r + 1j * k) * (np.einsum("ijd,ijd->ij", d, ny) / r)
+    return (G * W * J).sum(), (H * W * J).sum()
+
+
+def test_quad4_regular_integration_against_brute_force():
+    """The restated Quad4 path (bilinear geometry, n x n rules by distance, quad-tree subdivision) against a 160 x 160
+    Gauss rule on a warped quad: far point (4 x 4 rule) to 1e-6, near points to the GAU_ACCU level 5e-4 (singular.rs:507-512)."""
+    coords = np.array([[1.0, 1.0, 0.1], [-1.0, 1.1, -0.05], [-0.9, -1.0, 0.0], [1.1, -0.9, 0.15]])
+    area = 4.0
+    k = 1.7
+    nx = np.array([0.0, 0.0, 1.0])
+    for x, tol in ((np.array([0.3, -0.2, 9.0]), 1e-6), (np.array([0.3, -0.2, 0.7]), 5e-4), (np.array([1.5, 0.4, 0.3]), 5e-4)):
+        res = O.regular_integration(x, nx, coords, area, k)
+        G, H = _quad_brute(x, nx, coords, k)
+        assert abs(res[0] - G) <= tol * abs(G) and abs(res[1] - H) <= tol * max(abs(H), abs(G))
+    # far away the quad and its two triangles integrate the same function
+    x = np.array([0.5, 0.2, 12.0])
+    flat = np.array([[1.0, 1.0, 0.0], [-1.0, 1.0, 0.0], [-1.0, -1.0, 0.0], [1.0, -1.0, 0.0]])
+    q = O.regular_integration(x, nx, flat, 4.0, k)
+    t = O.regular_integration(x, nx, flat[[0, 1, 2]], 2.0, k) + O.regular_integration(x, nx, flat[[0, 2, 3]], 2.0, k)
+    assert np.all(np.abs(q[:4] - t[:4]) <= 1e-7 * np.abs(t[:4]).max())
+
+
+def test_quad4_subelements_tile_the_square_and_self_term_is_planar():
+    """Leaves of the quad-tree tile [-1,1]^2 (area 4) when no level overflows; the planar self term has Re G > 0 and
+    vanishing H (the triangle's known answer, singular.rs:779-815, applied to a square)."""
+    flat = np.array([[1.0, 1.0, 0.0], [-1.0, 1.0, 0.0], [-1.0, -1.0, 0.0], [1.0, -1.0, 0.0]])
+    subs = O.generate_subelements(np.array([0.2, -0.1, 1.2]), flat, 4.0)
+    assert len(subs) > 1
+    assert abs(sum((2.0 * s.factor) ** 2 for s in subs) - 4.0) < 1e-12
+    assert all(4 <= s.gauss_order <= 7 for s in subs)
+    res = O.singular_integration(np.zeros(3), np.array([0.0, 0.0, 1.0]), flat, 1.0)
+    assert res[0].real > 0 and abs(res[1]) < 1e-10 and abs(res[2]) < 1e-10
+    # static limit of the planar self term: integral of 1/(4 pi r) over the square [-1,1]^2 from its centre = 2 ln(1+sqrt 2) * 4 / (4 pi) ...
+    exact = (8.0 * np.log(1.0 + np.sqrt(2.0))) / (4.0 * np.pi)
+    res0 = O.singular_integration(np.zeros(3), np.array([0.0, 0.0, 1.0]), flat, 1e-6)
+    assert abs(res0[0].real - exact) <= 2e-3 * exact
+
+
+def test_golden_mixed_quad_mesh_with_boundary_values():
+    """Committed fixture: mixed Tri3 + Quad4 mesh with nodal velocity / pressure values (matrix and rhs)."""
+    om = O.Mesh(GOLD["mixq_nodes"], GOLD["mixq_conn"])
+    om.bc_type = GOLD["mixq_bc_type"].copy(); om.bc_len = GOLD["mixq_bc_len"].copy(); om.bc_values = GOLD["mixq_bc_values"].copy()
+    A, rhs = O.build_tbem_system_with_beta(om, float(GOLD["mixq_k"][0]), complex(GOLD["mixq_beta"][0]), nthreads=4)
+    assert np.allclose(A, GOLD["mixq_A"], rtol=1e-13, atol=1e-15) and np.allclose(rhs, GOLD["mixq_rhs"], rtol=1e-13, atol=1e-18)
