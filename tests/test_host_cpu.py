@@ -80,3 +80,65 @@ def test_two_process_gloo_sweep_gather():
     for rank, table, tmax in res:
         assert np.array_equal(table, expect)
         assert tmax == 1.25
+
+
+# ---------------------------------------------------------------- row-sharded operator + replicated GMRES (config #5, C2)
+def _sharded_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from math_audio_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(17)                       # same matrix on every rank
+    n = 91                                                # not a multiple of the world size: the last block is short
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) + 40.0 * np.eye(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    r0, r1 = sharded.row_block(n, rank, world)
+    At = torch.tensor(A[r0:r1])
+
+    def local_apply(x, y_block):                          # stands in for the HIP row-block operator on the CPU test
+        y_block.copy_(At @ x)
+    op = sharded.ShardedOperator(n, local_apply, dist=dist)
+    y = op.apply(torch.tensor(b)).numpy()
+    x, info = sharded.gmres(op, torch.tensor(b), restart=20, max_iterations=10, tol=1e-10)
+    dist.destroy_process_group()
+    q.put((rank, (r0, r1), y, x.numpy(), info))
+
+
+def test_two_process_gloo_row_sharded_gmres():
+    """world_size = 2 on CPU: the all-gathered product equals A x, and the replicated GMRES follows the restatement of
+    gmres.rs iteration for iteration on both ranks."""
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(17)
+    n = 91
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) + 40.0 * np.eye(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    x_ref, info_ref = O.gmres(b, dense=A, restart=20, max_iterations=10, tol=1e-10)
+    blocks = sorted(r[1] for r in res)
+    assert blocks == [(0, 46), (46, 91)]
+    for rank, _, y, x, info in res:
+        assert np.abs(y - A @ b).max() <= 1e-12 * np.abs(A @ b).max()
+        assert info["converged"] and info_ref.converged == 1
+        assert info["iterations"] == info_ref.iterations and info["restarts"] == info_ref.restarts
+        assert np.abs(x - x_ref).max() <= 1e-10 * np.abs(x_ref).max()
+    assert np.array_equal(res[0][3], res[1][3])           # replicated Krylov vectors: the ranks agree bit for bit
+
+
+def test_row_block_partition():
+    from math_audio_amd import sharded
+    for n, w in ((50172, 8), (10, 4), (3, 8), (64, 1)):
+        blocks = [sharded.row_block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+        assert max(b1 - b0 for b0, b1 in blocks) == (n + w - 1) // w

@@ -178,3 +178,29 @@ def test_apply_transpose_and_hermitian(gpu):
 def _xvec(n):
     i = np.arange(n)
     return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
+
+
+def test_row_sharded_operator_and_gmres_on_one_gpu(gpu):
+    """math_audio_amd.sharded at world size 1 (the all-gather degenerates; the 2-rank path is covered with gloo on the CPU):
+    the row-block operator equals the dense product and the replicated GMRES equals the single-GPU ma_gmres."""
+    import torch
+    from math_audio_amd import sharded
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+    mesh = to_ma_mesh(om)
+    plan = ma.BemPlan(mesh)
+    A, _ = ma.assemble_tbem(mesh, k, beta)
+    dev = torch.device("cuda", 0)
+    so = sharded.tbem_sharded_operator(plan, k, beta, dist=None, device=dev)
+    x = np.cos(0.37 * np.arange(plan.num_dofs)) + 1j * np.sin(0.11 * np.arange(plan.num_dofs))
+    y = so.apply(torch.tensor(x, device=dev)).cpu().numpy()
+    assert np.abs(y - A @ x).max() <= 1e-10 * np.abs(A @ x).max()
+    b = ma.incident_rhs(om.center, om.normal, k, beta)
+    xs, info = sharded.gmres(so, torch.tensor(b, device=dev), restart=30, max_iterations=10, tol=1e-8)
+    op = ma.LinearOperator.tbem(plan, k, beta)
+    xr, info_r = ma.gmres(op, b, restart=30, max_iterations=10, tol=1e-8)
+    assert info["converged"] and info_r.converged == 1
+    assert info["iterations"] == info_r.iterations and info["restarts"] == info_r.restarts
+    assert rel_l2(xs.cpu().numpy(), xr) <= 1e-9
+    assert np.linalg.norm(A @ xs.cpu().numpy() - b) / np.linalg.norm(b) < 1e-7
+    op.close(); plan.close()
