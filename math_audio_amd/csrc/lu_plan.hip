@@ -43,7 +43,7 @@ struct ma_lu_plan {
   int ev_last = -1;
   int n_gemm_launch = 0;
   bool ev_valid = false;
-  hipStream_t panel_stream = nullptr;   // high-priority stream for the look-ahead panel (system 0)
+  hipStream_t panel_stream = nullptr;   // stream of the look-ahead lane (system 0)
   hipStream_t panel_streams[LU_BATCH_MAX] = {};   // [0] aliases panel_stream; one per system of a batch
   bool panel_overlap = true;      // MA_LU_PANEL_OVERLAP=0: all systems' panels on one stream (strictly serial)
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
@@ -148,6 +148,10 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (!rc) {
     int lo = 0, hi = 0;
     hipError_t e4 = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // The look-ahead lanes run at the caller's (normal) priority: measured equal to the highest priority with up to three
+    // systems in flight, and with four the high-priority lanes starved the main lane's small launches, on which every
+    // lane waits (MA_LU_LANE_PRIO=1 selects the highest priority, -1 the lowest).
+    { int v = 0; if (const char* e8 = getenv("MA_LU_LANE_PRIO")) v = atoi(e8); if (v == 0) hi = 0; else if (v < 0) hi = lo; }
     if (e4 == hipSuccess) e4 = hipStreamCreateWithPriority(&P->panel_stream, hipStreamNonBlocking, hi);
     P->panel_streams[0] = P->panel_stream;
     for (int i = 1; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipStreamCreateWithPriority(&P->panel_streams[i], hipStreamNonBlocking, hi);
@@ -203,7 +207,7 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 // 2 => K = 256), because the update kernel's cost per launch is the read-modify-write of C: at K = 128 it runs at 61
 // TFLOP/s, at K = 256 at 71 (tools/zgemm_bench.hip).
 //
-//   look-ahead lane (own high-priority stream per system), block g+1 = panels p_0..p_{kb-1}, columns [a_0, e):
+//   look-ahead lane (own stream per system), block g+1 = panels p_0..p_{kb-1}, columns [a_0, e):
 //     for j: panel(p_j);  if j < kb-1: interchanges of p_j -> columns [a_{j+1}, e);  U = L_jj^-1 A[p_j rows, a_{j+1}:e);
 //            A[a_{j+1}:n, a_{j+1}:e) -= L[a_{j+1}:n, p_j] U          (a small right-looking LU of the block column)
 //   main lane (caller's stream), block g, once its panels are done:
