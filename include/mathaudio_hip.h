@@ -237,6 +237,19 @@ int ma_bem_plan_scattered_field(ma_bem_plan_t* plan, const ma_physics_t* physics
                                 const ma_c64* surface_pressure, const ma_c64* surface_velocity, ma_c64* out);
 int ma_room_build_matrix(int32_t n, const double* center, const double* normal, const double* area, double k, ma_c64* A_rowmajor);
 int ma_room_build_matrix_dev(int32_t n, const void* d_center, const void* d_normal, const void* d_area, double k, void* d_A, void* stream);
+/* The rest of math-bem/src/room_acoustics/solver.rs around the collocation matrix:
+ * element_center_and_normal :38-67, element_area :70-122, element_characteristic_length :600-611 (host arithmetic,
+ *   conn = 4 node ids per element, -1 in the fourth slot of a triangle);
+ * build_bem_matrix_adaptive(mesh, k, use_adaptive) :500-597;
+ * calculate_incident_field_derivative_parallel :638-678 and calculate_field_pressure_bem_parallel :687-748, where
+ *   amp is [nsrc] (the same amplitude towards every point) or, with per_point != 0, [nsrc][n points] as
+ *   Source::amplitude_towards (math-xem-common/src/source.rs:203-219) gives it. */
+int ma_room_element_data(int32_t n_elem, const double* nodes, const int32_t* conn, double* center, double* normal, double* area, double* charlen);
+int ma_room_build_matrix_adaptive(int32_t n_nodes, const double* nodes, int32_t n_elem, const int32_t* conn, double k, int use_adaptive, ma_c64* A_rowmajor);
+int ma_room_incident_derivative(int32_t n, const double* center, const double* normal, int32_t nsrc, const double* src_pos, const double* amp, int per_point,
+                                double k, ma_c64* out);
+int ma_room_field_pressure(int32_t n, const double* center, const double* normal, const double* area, const ma_c64* surface_pressure, int32_t nsrc,
+                           const double* src_pos, const double* amp, int per_point, int32_t npts, const double* pts, double k, ma_c64* out);
 
 /* ------------------------------------------------------------------------------------------
  * Parity-test hooks (no counterpart in the reference API): raw panel integrals computed by the

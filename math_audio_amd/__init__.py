@@ -120,6 +120,10 @@ def lib():
             "ma_bem_plan_scattered_field": [vp, P(ma_physics_t), i32, vp, vp, vp, vp],
             "ma_room_build_matrix": [i32, vp, vp, vp, dbl, vp],
             "ma_room_build_matrix_dev": [i32, vp, vp, vp, dbl, vp, vp],
+            "ma_room_element_data": [i32, vp, vp, vp, vp, vp, vp],
+            "ma_room_build_matrix_adaptive": [i32, vp, i32, vp, dbl, C.c_int, vp],
+            "ma_room_incident_derivative": [i32, vp, vp, i32, vp, vp, C.c_int, dbl, vp],
+            "ma_room_field_pressure": [i32, vp, vp, vp, vp, i32, vp, vp, C.c_int, i32, vp, dbl, vp],
             "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
             "ma_probe_mfma_f64": [C.c_int, P(dbl)],
         }
@@ -554,3 +558,58 @@ def room_build_matrix(center, normal, area, k):
     A = np.empty((n, n), dtype=np.complex128)
     check(lib().ma_room_build_matrix(n, _vp(c), _vp(nr), _vp(a), float(k), _vp(A)))
     return A
+
+
+def _conn4(conn):
+    conn = np.asarray(conn, dtype=np.int32)
+    if conn.ndim == 2 and conn.shape[1] == 3:
+        conn = np.concatenate([conn, -np.ones((conn.shape[0], 1), dtype=np.int32)], axis=1)
+    return np.ascontiguousarray(conn, dtype=np.int32)
+
+
+def room_element_data(nodes, conn):
+    """element_center_and_normal, element_area, element_characteristic_length (room_acoustics/solver.rs:38-122, 600-611):
+    returns (center, normal, area, char_length). Host arithmetic inside the library; needs no device."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64); conn = _conn4(conn)
+    n = conn.shape[0]
+    c = np.empty((n, 3)); nr = np.empty((n, 3)); a = np.empty(n); cl = np.empty(n)
+    check(lib().ma_room_element_data(n, _vp(nodes), _vp(conn), _vp(c), _vp(nr), _vp(a), _vp(cl)))
+    return c, nr, a, cl
+
+
+def room_build_matrix_adaptive(nodes, conn, k, use_adaptive=True):
+    """build_bem_matrix_adaptive (room_acoustics/solver.rs:500-597) on the device."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64); conn = _conn4(conn)
+    n = conn.shape[0]
+    A = np.empty((n, n), dtype=np.complex128)
+    check(lib().ma_room_build_matrix_adaptive(nodes.shape[0], _vp(nodes), n, _vp(conn), float(k), 1 if use_adaptive else 0, _vp(A)))
+    return A
+
+
+def _amp(amp, nsrc, npts):
+    amp = np.ascontiguousarray(amp, dtype=np.float64)
+    per_point = 1 if amp.ndim == 2 else 0
+    if per_point and amp.shape != (nsrc, npts):
+        raise ValueError("per-point amplitudes must be (n_sources, n_points)")
+    return amp, per_point
+
+
+def room_incident_derivative(center, normal, src_pos, amp, k):
+    """calculate_incident_field_derivative_parallel (solver.rs:638-678): -sum_s dG/dn amp."""
+    c = np.ascontiguousarray(center, dtype=np.float64); nr = np.ascontiguousarray(normal, dtype=np.float64)
+    sp = np.ascontiguousarray(src_pos, dtype=np.float64).reshape(-1, 3)
+    amp, pp = _amp(amp, sp.shape[0], c.shape[0])
+    out = np.empty(c.shape[0], dtype=np.complex128)
+    check(lib().ma_room_incident_derivative(c.shape[0], _vp(c), _vp(nr), sp.shape[0], _vp(sp), _vp(amp), pp, float(k), _vp(out)))
+    return out
+
+
+def room_field_pressure(center, normal, area, surface_pressure, src_pos, amp, points, k):
+    """calculate_field_pressure_bem_parallel (solver.rs:687-748)."""
+    c = np.ascontiguousarray(center, dtype=np.float64); nr = np.ascontiguousarray(normal, dtype=np.float64); a = np.ascontiguousarray(area, dtype=np.float64)
+    ps = np.ascontiguousarray(surface_pressure, dtype=np.complex128)
+    sp = np.ascontiguousarray(src_pos, dtype=np.float64).reshape(-1, 3); pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    amp, pp = _amp(amp, sp.shape[0], pts.shape[0])
+    out = np.empty(pts.shape[0], dtype=np.complex128)
+    check(lib().ma_room_field_pressure(len(a), _vp(c), _vp(nr), _vp(a), _vp(ps), sp.shape[0], _vp(sp), _vp(amp), pp, pts.shape[0], _vp(pts), float(k), _vp(out)))
+    return out

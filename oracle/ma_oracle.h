@@ -149,6 +149,14 @@ void mao_gmres_preconditioned(int n, const long long* row_ptr, const long long* 
 /* ---- room-acoustics collocation assembly (room_acoustics/solver.rs:448-493) ---- */
 void mao_room_build_matrix(int n_elem, const double* center, const double* normal, const double* area,
                            double k, mao_c64* A, int nthreads);
+/* the rest of the room path: element data (solver.rs:38-122, 600-611), adaptive assembly (:500-597), incident
+ * derivative (:638-678), field pressure (:687-748) */
+void mao_room_element_data(int n_elem, const double* nodes, const int* conn, double* center, double* normal, double* area, double* charlen);
+void mao_room_build_matrix_adaptive(int n_elem, const double* nodes, const int* conn, double k, int use_adaptive, mao_c64* A);
+void mao_room_incident_derivative(int n, const double* center, const double* normal, int nsrc, const double* src_pos, const double* amp,
+                                  int per_point, double k, mao_c64* out);
+void mao_room_field_pressure(int n, const double* center, const double* normal, const double* area, const mao_c64* surface_pressure,
+                             int nsrc, const double* src_pos, const double* amp, int per_point, int npts, const double* pts, double k, mao_c64* out);
 
 #ifdef __cplusplus
 }

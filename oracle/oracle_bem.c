@@ -841,3 +841,127 @@ void mao_room_build_matrix(int n, const double* center, const double* normal, co
   else room_rows(&jobs[0]);
   free(jobs); free(th);
 }
+
+/* ======================================================================
+ * Rest of the room-acoustics path — room_acoustics/solver.rs:38-122 (element data), 500-597 (adaptive assembly),
+ * 600-611 (characteristic length), 638-678 (incident derivative), 687-748 (field pressure)
+ * ====================================================================== */
+/* element_center_and_normal :38-67, element_area :70-122, element_characteristic_length :600-611; conn rows hold 3 or 4
+ * node ids (-1 in the fourth slot for triangles) */
+void mao_room_element_data(int n_elem, const double* nodes, const int* conn, double* center, double* normal, double* area, double* charlen) {
+  for (int e = 0; e < n_elem; ++e) {
+    const int* cn = conn + 4*e;
+    int nn = cn[3] < 0 ? 3 : 4;
+    const double* p[4];
+    for (int a = 0; a < nn; ++a) p[a] = nodes + 3*cn[a];
+    for (int d = 0; d < 3; ++d) {
+      double s = 0.0;
+      for (int a = 0; a < nn; ++a) s += p[a][d];
+      center[3*e+d] = s / (double)nn;
+    }
+    double v1[3], v2[3];
+    for (int d = 0; d < 3; ++d) { v1[d] = p[1][d] - p[0][d]; v2[d] = p[2][d] - p[0][d]; }
+    double nx = v1[1]*v2[2] - v1[2]*v2[1], ny = v1[2]*v2[0] - v1[0]*v2[2], nz = v1[0]*v2[1] - v1[1]*v2[0];
+    double nrm = sqrt(nx*nx + ny*ny + nz*nz);
+    normal[3*e] = nx / nrm; normal[3*e+1] = ny / nrm; normal[3*e+2] = nz / nrm;
+    double a1 = 0.5 * sqrt(nx*nx + ny*ny + nz*nz);
+    if (nn == 4) {
+      double v3[3];
+      for (int d = 0; d < 3; ++d) v3[d] = p[3][d] - p[0][d];
+      double cx = v2[1]*v3[2] - v2[2]*v3[1], cy = v2[2]*v3[0] - v2[0]*v3[2], cz = v2[0]*v3[1] - v2[1]*v3[0];
+      a1 += 0.5 * sqrt(cx*cx + cy*cy + cz*cz);
+    }
+    area[e] = a1;
+    double d01 = 0.0, d12 = 0.0, d20 = 0.0;
+    for (int d = 0; d < 3; ++d) {
+      d01 += (p[0][d] - p[1][d]) * (p[0][d] - p[1][d]); d12 += (p[1][d] - p[2][d]) * (p[1][d] - p[2][d]); d20 += (p[2][d] - p[0][d]) * (p[2][d] - p[0][d]);
+    }
+    charlen[e] = (sqrt(d01) + sqrt(d12) + sqrt(d20)) / 3.0;
+  }
+}
+
+static mao_c64 room_dgdn(double r, double k, double cosang) {      /* greens_function_derivative :28-35 */
+  if (r < 1e-10) return C(0.0, 0.0);
+  mao_c64 e = C(cos(k * r), sin(k * r));
+  mao_c64 f = cdivr(cmul(C(-1.0, k * r), e), 4.0 * PI * r * r);
+  return cscale(f, cosang);
+}
+
+/* build_bem_matrix_adaptive :500-597. Near pairs (r < 2 (l_i + l_j) or i == j) take dg_dn_integral of
+ * singular_integration_with_params on the FIRST THREE nodes of element j (ElementType::Tri3 whatever the element is, :556),
+ * with QuadratureParams::for_ka(k l_j); the rest is the point collocation of build_bem_matrix_parallel. */
+void mao_room_build_matrix_adaptive(int n_elem, const double* nodes, const int* conn, double k, int use_adaptive, mao_c64* A) {
+  double* c = (double*)malloc(sizeof(double) * 3 * (size_t)n_elem); double* nr = (double*)malloc(sizeof(double) * 3 * (size_t)n_elem);
+  double* ar = (double*)malloc(sizeof(double) * (size_t)n_elem); double* cl = (double*)malloc(sizeof(double) * (size_t)n_elem);
+  mao_room_element_data(n_elem, nodes, conn, c, nr, ar, cl);
+  for (int i = 0; i < n_elem; ++i)
+    for (int j = 0; j < n_elem; ++j) {
+      double dx = c[3*i] - c[3*j], dy = c[3*i+1] - c[3*j+1], dz = c[3*i+2] - c[3*j+2];
+      double r = sqrt(dx*dx + dy*dy + dz*dz);
+      int is_near = r < 2.0 * (cl[i] + cl[j]) || i == j;
+      mao_c64 v;
+      if (use_adaptive && is_near) {
+        double coords[9];
+        for (int a = 0; a < 3; ++a) for (int d = 0; d < 3; ++d) coords[3*a+d] = nodes[3*conn[4*j+a]+d];
+        double ka = k * cl[j];
+        int p[4];
+        if (ka < 0.3)      { p[0] = 3; p[1] = 4; p[2] = 4;  p[3] = 2; }
+        else if (ka < 1.0) { p[0] = 4; p[1] = 5; p[2] = 6;  p[3] = 2; }
+        else if (ka < 2.0) { p[0] = 5; p[1] = 6; p[2] = 8;  p[3] = 3; }
+        else               { p[0] = 6; p[1] = 7; p[2] = 10; p[3] = 4; }
+        mao_integration_result res;
+        mao_singular_integration_with_params(c + 3*i, nr + 3*i, coords, 3, k, 1.0, -1.0, NULL, 0, 0, 0, p[0], p[1], p[2], p[3], &res);
+        v = res.dg_dn;
+      } else if (i == j) v = cscale(C(0.0, -k / (2.0 * PI)), ar[j]);
+      else {
+        double cosang = (dx * nr[3*i] + dy * nr[3*i+1] + dz * nr[3*i+2]) / r;
+        v = cscale(room_dgdn(r, k, cosang), ar[j]);
+      }
+      A[(size_t)i * (size_t)n_elem + (size_t)j] = v;
+    }
+  free(c); free(nr); free(ar); free(cl);
+}
+
+/* calculate_incident_field_derivative_parallel :638-678: rhs_i = - sum_s dG/dn(r_is) amp_is; amp is [nsrc] (the same
+ * towards every element: an omnidirectional source) or [nsrc][n] when per_point != 0 (Source::amplitude_towards evaluated
+ * by the caller, math-xem-common/src/source.rs:203-219) */
+void mao_room_incident_derivative(int n, const double* center, const double* normal, int nsrc, const double* src_pos, const double* amp,
+                                  int per_point, double k, mao_c64* out) {
+  for (int i = 0; i < n; ++i) {
+    mao_c64 s = C(0.0, 0.0);
+    for (int q = 0; q < nsrc; ++q) {
+      double dx = center[3*i] - src_pos[3*q], dy = center[3*i+1] - src_pos[3*q+1], dz = center[3*i+2] - src_pos[3*q+2];
+      double r = sqrt(dx*dx + dy*dy + dz*dz);
+      if (r < 1e-10) continue;
+      double cosang = (dx * normal[3*i] + dy * normal[3*i+1] + dz * normal[3*i+2]) / r;
+      double a = per_point ? amp[(size_t)q * (size_t)n + (size_t)i] : amp[q];
+      s = cadd(s, cscale(room_dgdn(r, k, cosang), a));
+    }
+    out[i] = cneg(s);
+  }
+}
+
+/* calculate_field_pressure_bem_parallel :687-748: p(x) = sum_s G(|x - s|) amp + sum_j dG/dn_j(x - c_j) p_j A_j */
+void mao_room_field_pressure(int n, const double* center, const double* normal, const double* area, const mao_c64* surface_pressure,
+                             int nsrc, const double* src_pos, const double* amp, int per_point, int npts, const double* pts, double k, mao_c64* out) {
+  for (int m = 0; m < npts; ++m) {
+    const double* x = pts + 3*m;
+    mao_c64 p = C(0.0, 0.0);
+    for (int q = 0; q < nsrc; ++q) {
+      double dx = x[0] - src_pos[3*q], dy = x[1] - src_pos[3*q+1], dz = x[2] - src_pos[3*q+2];
+      double r = sqrt(dx*dx + dy*dy + dz*dz);
+      if (r < 1e-10) continue;
+      double a = per_point ? amp[(size_t)q * (size_t)npts + (size_t)m] : amp[q];
+      mao_c64 g = cdivr(C(cos(k * r), sin(k * r)), 4.0 * PI * r);        /* greens_function_3d :18-24 */
+      p = cadd(p, cscale(g, a));
+    }
+    for (int j = 0; j < n; ++j) {
+      double dx = x[0] - center[3*j], dy = x[1] - center[3*j+1], dz = x[2] - center[3*j+2];
+      double r = sqrt(dx*dx + dy*dy + dz*dz);
+      if (r < 1e-10) continue;
+      double cosang = (dx * normal[3*j] + dy * normal[3*j+1] + dz * normal[3*j+2]) / r;
+      p = cadd(p, cscale(cmul(room_dgdn(r, k, cosang), surface_pressure[j]), area[j]));
+    }
+    out[m] = p;
+  }
+}

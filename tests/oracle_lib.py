@@ -355,3 +355,39 @@ def room_build_matrix(center, normal, area, k, nthreads=1):
     A = np.zeros((n, n), dtype=np.complex128)
     lib().mao_room_build_matrix(n, _p(center), _p(normal), _p(area), C.c_double(k), _vp(A), nthreads)
     return A
+
+
+# ---------------------------------------------------------------- rest of the room path (room_acoustics/solver.rs)
+def room_element_data(nodes, conn):
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64); conn = np.ascontiguousarray(conn, dtype=np.int32)
+    n = conn.shape[0]
+    c = np.zeros((n, 3)); nr = np.zeros((n, 3)); a = np.zeros(n); cl = np.zeros(n)
+    lib().mao_room_element_data(n, _p(nodes), _p(conn, C.c_int), _p(c), _p(nr), _p(a), _p(cl))
+    return c, nr, a, cl
+
+
+def room_build_matrix_adaptive(nodes, conn, k, use_adaptive=True):
+    nodes = np.ascontiguousarray(nodes, dtype=np.float64); conn = np.ascontiguousarray(conn, dtype=np.int32)
+    n = conn.shape[0]
+    A = np.zeros((n, n), dtype=np.complex128)
+    lib().mao_room_build_matrix_adaptive(n, _p(nodes), _p(conn, C.c_int), C.c_double(k), 1 if use_adaptive else 0, _vp(A))
+    return A
+
+
+def room_incident_derivative(center, normal, src_pos, amp, k):
+    c = np.ascontiguousarray(center, dtype=np.float64); nr = np.ascontiguousarray(normal, dtype=np.float64)
+    sp = np.ascontiguousarray(src_pos, dtype=np.float64).reshape(-1, 3); amp = np.ascontiguousarray(amp, dtype=np.float64)
+    out = np.zeros(c.shape[0], dtype=np.complex128)
+    lib().mao_room_incident_derivative(c.shape[0], _p(c), _p(nr), sp.shape[0], _p(sp), _p(amp), 1 if amp.ndim == 2 else 0, C.c_double(k), _vp(out))
+    return out
+
+
+def room_field_pressure(center, normal, area, surface_pressure, src_pos, amp, points, k):
+    c = np.ascontiguousarray(center, dtype=np.float64); nr = np.ascontiguousarray(normal, dtype=np.float64); a = np.ascontiguousarray(area, dtype=np.float64)
+    ps = np.ascontiguousarray(surface_pressure, dtype=np.complex128)
+    sp = np.ascontiguousarray(src_pos, dtype=np.float64).reshape(-1, 3); pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    amp = np.ascontiguousarray(amp, dtype=np.float64)
+    out = np.zeros(pts.shape[0], dtype=np.complex128)
+    lib().mao_room_field_pressure(len(a), _p(c), _p(nr), _p(a), _vp(ps), sp.shape[0], _p(sp), _p(amp), 1 if amp.ndim == 2 else 0, pts.shape[0], _p(pts),
+                                  C.c_double(k), _vp(out))
+    return out

@@ -47,3 +47,73 @@ def test_room_collocation_matrix_matches_oracle(gpu, sub, k):
     got = ma.room_build_matrix(om.center, om.normal, om.area, k)
     assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
     assert np.array_equal(np.diag(got), np.diag(ref))
+
+
+def _room_box(nx=6, ny=5, nz=4, lx=5.0, ly=4.0, lz=2.5, tri_every=4):
+    """Room interior surface: box faces gridded into quads (RectangularRoom::generate_mesh, math-xem-common/src/geometry.rs:107-183),
+    every `tri_every`-th quad split into two triangles; element normals as the node order gives them."""
+    idx = {}; nodes = []; conn = []
+
+    def nid(p):
+        key = tuple(np.round(p, 12))
+        if key not in idx:
+            idx[key] = len(nodes); nodes.append(p)
+        return idx[key]
+    xs = np.linspace(0, lx, nx + 1); ys = np.linspace(0, ly, ny + 1); zs = np.linspace(0, lz, nz + 1)
+    faces = []
+    for i in range(nx):
+        for j in range(ny):
+            faces.append([(xs[i], ys[j], 0), (xs[i + 1], ys[j], 0), (xs[i + 1], ys[j + 1], 0), (xs[i], ys[j + 1], 0)])
+            faces.append([(xs[i], ys[j], lz), (xs[i], ys[j + 1], lz), (xs[i + 1], ys[j + 1], lz), (xs[i + 1], ys[j], lz)])
+    for i in range(nx):
+        for k in range(nz):
+            faces.append([(xs[i], 0, zs[k]), (xs[i], 0, zs[k + 1]), (xs[i + 1], 0, zs[k + 1]), (xs[i + 1], 0, zs[k])])
+            faces.append([(xs[i], ly, zs[k]), (xs[i + 1], ly, zs[k]), (xs[i + 1], ly, zs[k + 1]), (xs[i], ly, zs[k + 1])])
+    for j in range(ny):
+        for k in range(nz):
+            faces.append([(0, ys[j], zs[k]), (0, ys[j + 1], zs[k]), (0, ys[j + 1], zs[k + 1]), (0, ys[j], zs[k + 1])])
+            faces.append([(lx, ys[j], zs[k]), (lx, ys[j], zs[k + 1]), (lx, ys[j + 1], zs[k + 1]), (lx, ys[j + 1], zs[k])])
+    for q, f in enumerate(faces):
+        ids = [nid(np.array(p, dtype=float)) for p in f]
+        if q % tri_every == 0:
+            conn.append([ids[0], ids[1], ids[2], -1]); conn.append([ids[0], ids[2], ids[3], -1])
+        else:
+            conn.append(ids)
+    return np.array(nodes), np.array(conn, dtype=np.int32)
+
+
+def test_room_element_data_and_adaptive_matrix_match_oracle(gpu):
+    """element_center_and_normal / element_area / characteristic length (solver.rs:38-122, 600-611) and
+    build_bem_matrix_adaptive (:500-597): collocation for far pairs, the double-layer part of the singular routine on
+    the first three nodes for near pairs (also for quads -- the reference's ElementType::Tri3 quirk, :556)."""
+    nodes, conn = _room_box()
+    c, nr, a, cl = ma.room_element_data(nodes, conn)
+    c0, n0, a0, l0 = O.room_element_data(nodes, conn)
+    assert np.array_equal(c, c0) and np.array_equal(a, a0) and np.array_equal(cl, l0) and np.abs(nr - n0).max() <= 1e-15
+    assert abs(a.sum() - 2 * (5 * 4 + 5 * 2.5 + 4 * 2.5)) < 1e-9
+    for k in (0.7, 6.0):
+        for adaptive in (True, False):
+            ref = O.room_build_matrix_adaptive(nodes, conn, k, adaptive)
+            got = ma.room_build_matrix_adaptive(nodes, conn, k, adaptive)
+            assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+        plain = ma.room_build_matrix(c, nr, a, k)
+        assert np.abs(ma.room_build_matrix_adaptive(nodes, conn, k, False) - plain).max() <= 1e-12 * np.abs(plain).max()
+
+
+def test_room_incident_derivative_and_field_pressure_match_oracle(gpu):
+    nodes, conn = _room_box()
+    c, nr, a, cl = ma.room_element_data(nodes, conn)
+    n = len(a)
+    k = 2 * np.pi * 250.0 / 343.0
+    src = np.array([[1.2, 0.9, 1.1], [3.8, 3.1, 0.6]])
+    rng = np.random.default_rng(4)
+    for amp in (np.array([1.0, 0.35]), 0.5 + rng.random((2, n))):            # omnidirectional, or per-point (directivity x crossover)
+        ref = O.room_incident_derivative(c, nr, src, amp, k)
+        got = ma.room_incident_derivative(c, nr, src, amp, k)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    ps = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    pts = np.array([[2.5, 2.0, 1.25], [0.4, 3.5, 2.0], [4.6, 0.3, 0.2], [1.2, 0.9, 1.1]])     # the last one sits on a source: skipped term
+    for amp in (np.array([1.0, 0.35]), 0.5 + rng.random((2, len(pts)))):
+        ref = O.room_field_pressure(c, nr, a, ps, src, amp, pts, k)
+        got = ma.room_field_pressure(c, nr, a, ps, src, amp, pts, k)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()

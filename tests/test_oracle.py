@@ -414,3 +414,28 @@ def test_golden_mixed_quad_mesh_with_boundary_values():
     om.bc_type = GOLD["mixq_bc_type"].copy(); om.bc_len = GOLD["mixq_bc_len"].copy(); om.bc_values = GOLD["mixq_bc_values"].copy()
     A, rhs = O.build_tbem_system_with_beta(om, float(GOLD["mixq_k"][0]), complex(GOLD["mixq_beta"][0]), nthreads=4)
     assert np.allclose(A, GOLD["mixq_A"], rtol=1e-13, atol=1e-15) and np.allclose(rhs, GOLD["mixq_rhs"], rtol=1e-13, atol=1e-18)
+
+
+def test_room_path_restatement_consistency():
+    """room_acoustics/solver.rs: element data of a unit square quad and of its two triangles, adaptive assembly switched
+    off equals build_bem_matrix_parallel, the incident derivative is -dG/dn of a monopole, the field pressure of a zero
+    surface pressure is the incident field."""
+    nodes = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.2, 0.3, 1.0], [0.9, 0.3, 1.0], [0.9, 0.8, 1.2]], dtype=float)
+    conn = np.array([[0, 1, 2, 3], [0, 1, 2, -1], [4, 5, 6, -1]], dtype=np.int32)
+    c, nr, a, cl = O.room_element_data(nodes, conn)
+    assert np.allclose(c[0], [0.5, 0.5, 0.0]) and np.allclose(nr[0], [0, 0, 1]) and abs(a[0] - 1.0) < 1e-15 and abs(a[1] - 0.5) < 1e-15
+    assert abs(cl[0] - (1 + 1 + np.sqrt(2)) / 3) < 1e-15                    # the quad's length uses its first three nodes
+    k = 3.0
+    A0 = O.room_build_matrix_adaptive(nodes, conn, k, use_adaptive=False)
+    assert np.abs(A0 - O.room_build_matrix(c, nr, a, k)).max() <= 1e-15
+    A1 = O.room_build_matrix_adaptive(nodes, conn, k, use_adaptive=True)
+    assert np.all(np.isfinite(A1.view(float))) and abs(A1[2, 2]) < 1e-10     # planar self term: vanishing double layer
+    src = np.array([[0.5, 0.5, 2.0]])
+    rhs = O.room_incident_derivative(c, nr, src, np.array([2.0]), k)
+    d = c[0] - src[0]; r = np.linalg.norm(d)
+    expect = -2.0 * (1j * k * r - 1) * np.exp(1j * k * r) / (4 * np.pi * r * r) * (d @ nr[0]) / r
+    assert abs(rhs[0] - expect) < 1e-15
+    pts = np.array([[0.1, 0.2, 0.7]])
+    p = O.room_field_pressure(c, nr, a, np.zeros(3, dtype=complex), src, np.array([2.0]), pts, k)
+    rr = np.linalg.norm(pts[0] - src[0])
+    assert abs(p[0] - 2.0 * np.exp(1j * k * rr) / (4 * np.pi * rr)) < 1e-15
