@@ -158,6 +158,11 @@ int ma_csr_create_helmholtz(int64_t n, const int64_t* row_ptrs, const int64_t* c
 int ma_csr_destroy(ma_csr_t* h);
 int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz);
 int ma_csr_set_wavenumber(ma_csr_t* h, double k_re, double k_im);
+/* HelmholtzAssembler with boundary matrices (math-fem/src/assembly/assembler.rs:19-32, 216-257): boundary_values[tag] are
+ * real values on the operator's pattern; assemble(wavenumber, boundary_coeffs) forms A = K - k^2 M + sum_t c_t B_t over the
+ * tags present in both. Without matching tags it equals ma_csr_set_wavenumber. */
+int ma_csr_add_boundary(ma_csr_t* h, int32_t tag, const double* values_nnz);
+int ma_csr_assemble(ma_csr_t* h, double k_re, double k_im, int32_t ncoef, const int32_t* tags, const ma_c64* coeffs, void* stream);
 int ma_csr_spmv(ma_csr_t* h, const ma_c64* x, ma_c64* y);
 int ma_csr_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r);
 int ma_csr_jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, double omega, int sweeps);
@@ -174,6 +179,10 @@ int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, voi
  * recurrence: MA_ERR_UNSUPPORTED). */
 /* the transposed operator as a new handle (apply_transpose of CsrMatrix, csr.rs:420-440) */
 int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out);
+/* value epoch of a handle (bumped by set_wavenumber / assemble) and the cheap re-sync of a transposed copy after the
+ * source changed frequency (*rebuild = 1: the copy has to be built again with ma_csr_transpose) */
+unsigned long long ma_csr_epoch(const ma_csr_t* h);
+int ma_csr_refresh_transpose(const ma_csr_t* src, ma_csr_t* dst, int* rebuild);
 int ma_fem_matrix_create(int64_t n, int64_t nnz, const int64_t* rows, const int64_t* cols, const ma_c64* values, int device, ma_csr_t** out);
 int ma_fem_smooth(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int kind, int iterations, double omega);
 int ma_fem_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r);

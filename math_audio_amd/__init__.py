@@ -86,6 +86,8 @@ def lib():
             "ma_csr_destroy": [vp],
             "ma_csr_num_rows": [vp, P(i64), P(i64)],
             "ma_csr_set_wavenumber": [vp, dbl, dbl],
+            "ma_csr_add_boundary": [vp, i32, vp],
+            "ma_csr_assemble": [vp, dbl, dbl, i32, vp, vp, vp],
             "ma_csr_spmv": [vp, vp, vp],
             "ma_csr_residual": [vp, vp, vp, vp],
             "ma_csr_jacobi": [vp, vp, vp, dbl, C.c_int],
@@ -385,6 +387,18 @@ class CsrOperator:
     def set_wavenumber(self, k):
         k = complex(k)
         check(lib().ma_csr_set_wavenumber(self.h, k.real, k.imag))
+
+    def add_boundary(self, tag, values):
+        """HelmholtzAssembler.boundary_values[tag] (assembler.rs:19-32)."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        check(lib().ma_csr_add_boundary(self.h, int(tag), _vp(v)))
+
+    def assemble(self, k, boundary_coeffs=None, stream=0):
+        """HelmholtzAssembler::assemble(wavenumber, boundary_coeffs) (assembler.rs:216-257)."""
+        k = complex(k)
+        bc = boundary_coeffs or {}
+        tags = np.ascontiguousarray(list(bc.keys()), dtype=np.int32); co = np.ascontiguousarray([complex(v) for v in bc.values()], dtype=np.complex128)
+        check(lib().ma_csr_assemble(self.h, k.real, k.imag, len(tags), _vp(tags) if len(tags) else None, _vp(co) if len(tags) else None, C.c_void_p(stream)))
 
     def matvec(self, x):
         x = np.ascontiguousarray(x, dtype=np.complex128); y = np.empty(self.n, dtype=np.complex128)

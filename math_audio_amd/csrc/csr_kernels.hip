@@ -168,6 +168,36 @@ int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x,
   return km ? launch_km<true>(A, group, epi, x, b, out, omega, st) : launch_km<false>(A, group, epi, x, b, out, omega, st);
 }
 
+// HelmholtzAssembler::assemble with boundary terms (assembler.rs:216-257): val[i] = K[i] - k^2 M[i] + sum_t c_t B_t[i],
+// a term only where B_t[i] != 0
+struct CsrBoundary { int nb; const double* B[8]; double cre[8], cim[8]; };
+__global__ __launch_bounds__(256) void csr_assemble_kernel(long long nnz, const double* __restrict__ K, const double* __restrict__ M, double k2re, double k2im,
+                                                           CsrBoundary bd, dc* __restrict__ val) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nnz) return;
+  const double mv = M[i];
+  double vr = K[i] - k2re * mv, vi = -(k2im * mv);
+  for (int t = 0; t < bd.nb; ++t) { const double b = bd.B[t][i]; if (b != 0.0) { vr += bd.cre[t] * b; vi += bd.cim[t] * b; } }
+  val[i] = dc_make(vr, vi);
+}
+__global__ __launch_bounds__(256) void sell_gather_kernel(long long tot, const int* __restrict__ src, const dc* __restrict__ val, dc* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= tot) return;
+  const int s = src[q];
+  out[q] = s >= 0 ? val[s] : dc_make(0.0, 0.0);
+}
+int csr_launch_assemble(long long nnz, const double* K, const double* M, double k2re, double k2im, int nb, const double* const* B, const double* cre, const double* cim,
+                        c64* val, long long sell_tot, const int* sell_src, c64* sell_val, hipStream_t st) {
+  if (nnz <= 0) return MA_OK;
+  CsrBoundary bd{}; bd.nb = nb;
+  for (int t = 0; t < nb; ++t) { bd.B[t] = B[t]; bd.cre[t] = cre[t]; bd.cim[t] = cim[t]; }
+  hipLaunchKernelGGL(csr_assemble_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, K, M, k2re, k2im, bd, reinterpret_cast<dc*>(val));
+  if (sell_src && sell_val && sell_tot > 0)
+    hipLaunchKernelGGL(sell_gather_kernel, dim3((unsigned)((sell_tot + 255) / 256)), dim3(256), 0, st, sell_tot, sell_src, reinterpret_cast<const dc*>(val), reinterpret_cast<dc*>(sell_val));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 int csr_launch_diag(const CsrView& A, bool km, c64* dinv, double* l1, hipStream_t st) {
   if (A.n <= 0) return MA_OK;
   dim3 grid((unsigned)((A.n + 255) / 256)), block(256);

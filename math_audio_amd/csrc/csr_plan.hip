@@ -23,14 +23,23 @@ struct ma_csr {
   double zero_diag_dinv = 1.0;
   // sliced-ELLPACK copy (null when the padding would cost too much or MA_CSR_SELL=0)
   long long* d_sell_ptr = nullptr; int* d_sell_col = nullptr; c64* d_sell_val = nullptr; double* d_sell_K = nullptr; double* d_sell_M = nullptr;
+  int* d_sell_src = nullptr; long long sell_tot = 0;      // CSR index behind every sliced-ELLPACK slot (-1 = padding)
+  // boundary matrices of the HelmholtzAssembler (tag -> real values on the shared pattern); with a non-empty coefficient
+  // set the complex values are materialised (assemble) and the kernels run in complex-value mode
+  std::vector<int> btags; std::vector<double*> d_B;
+  bool materialised = false;
+  unsigned long long epoch = 0;   // bumped whenever the operator's values change (set_wavenumber / assemble)
   CsrView view() const {
     CsrView v{};
     v.n = n; v.nnz = nnz; v.row_ptr = d_rowptr; v.col = d_col; v.val = reinterpret_cast<const dc*>(d_val); v.K = d_K; v.M = d_M;
+    if (km && materialised) { v.K = nullptr; v.M = nullptr; }
     v.k2_re = k2_re; v.k2_im = k2_im; v.dinv = reinterpret_cast<const dc*>(d_dinv); v.l1 = d_l1;
     v.zero_diag_dinv = zero_diag_dinv;
     v.sell_ptr = d_sell_ptr; v.sell_col = d_sell_col; v.sell_val = reinterpret_cast<const dc*>(d_sell_val); v.sell_K = d_sell_K; v.sell_M = d_sell_M;
+    if (km && materialised && !d_sell_val) v.sell_ptr = nullptr;      // no complex sliced copy: the CSR-vector kernel serves it
     return v;
   }
+  bool fused_km() const { return km && !materialised; }   // kernels form K - k^2 M in registers
 };
 
 namespace {
@@ -42,7 +51,8 @@ int pick_group(long long n, long long nnz) {
 }
 void free_all(ma_csr* h) {
   void* p[] = {h->d_rowptr, h->d_col, h->d_val, h->d_K, h->d_M, h->d_dinv, h->d_l1, h->d_x, h->d_y, h->d_b,
-               h->d_sell_ptr, h->d_sell_col, h->d_sell_val, h->d_sell_K, h->d_sell_M};
+               h->d_sell_ptr, h->d_sell_col, h->d_sell_val, h->d_sell_K, h->d_sell_M, h->d_sell_src};
+  for (double* b : h->d_B) if (b) (void)hipFree(b);
   for (void* q : p) if (q) (void)hipFree(q);
 }
 int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out) {
@@ -89,7 +99,7 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
   }
   const long long tot = sp[(size_t)ns];
   if ((double)tot > 1.3 * (double)nnz + 64.0 * 64.0) return MA_OK;
-  std::vector<int> sc((size_t)tot, 0); std::vector<c64> sv; std::vector<double> sk, sm;
+  std::vector<int> sc((size_t)tot, 0), ssrc((size_t)tot, -1); std::vector<c64> sv; std::vector<double> sk, sm;
   if (vals) sv.assign((size_t)tot, c64{0.0, 0.0}); else { sk.assign((size_t)tot, 0.0); sm.assign((size_t)tot, 0.0); }
   for (int64_t s = 0; s < ns; ++s)
     for (int l = 0; l < 64; ++l) {
@@ -100,7 +110,7 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
         const size_t q = (size_t)(sp[(size_t)s] + kk * 64 + l);
         if (kk < len) {
           const int64_t t = rowptr[r] + kk;
-          sc[q] = (int)col[t];
+          sc[q] = (int)col[t]; ssrc[q] = (int)t;
           if (vals) { sv[q].re = vals[t].re; sv[q].im = vals[t].im; } else { sk[q] = K[t]; sm[q] = M[t]; }
         } else sc[q] = (int)(r < n ? r : 0);             // padding: zero coefficient, a column that is in cache anyway
       }
@@ -110,6 +120,9 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
   if (e == hipSuccess && vals) e = hipMalloc(&h->d_sell_val, sizeof(c64) * (size_t)tot);
   if (e == hipSuccess && !vals) e = hipMalloc(&h->d_sell_K, sizeof(double) * (size_t)tot);
   if (e == hipSuccess && !vals) e = hipMalloc(&h->d_sell_M, sizeof(double) * (size_t)tot);
+  if (e == hipSuccess && !vals && nnz < 2147483647LL) e = hipMalloc(&h->d_sell_src, sizeof(int) * (size_t)tot);
+  if (e == hipSuccess && h->d_sell_src) e = hipMemcpy(h->d_sell_src, ssrc.data(), sizeof(int) * (size_t)tot, hipMemcpyHostToDevice);
+  h->sell_tot = tot;
   if (e == hipSuccess) e = hipMemcpy(h->d_sell_ptr, sp.data(), sizeof(long long) * ((size_t)ns + 1), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_sell_col, sc.data(), sizeof(int) * (size_t)tot, hipMemcpyHostToDevice);
   if (e == hipSuccess && vals) e = hipMemcpy(h->d_sell_val, sv.data(), sizeof(c64) * (size_t)tot, hipMemcpyHostToDevice);
@@ -120,7 +133,7 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
 }
 int ensure_diag(ma_csr* h, hipStream_t st) {
   if (h->diag_valid) return MA_OK;
-  int rc = csr_launch_diag(h->view(), h->km, h->d_dinv, h->d_l1, st);
+  int rc = csr_launch_diag(h->view(), h->fused_km(), h->d_dinv, h->d_l1, st);
   if (!rc) h->diag_valid = true;
   return rc;
 }
@@ -172,6 +185,48 @@ int ma_csr_set_wavenumber(ma_csr_t* h, double k_re, double k_im) {
   MA_REQUIRE(h->km, MA_ERR_INVALID, "handle holds complex values, not K/M");
   h->k2_re = k_re * k_re - k_im * k_im; h->k2_im = 2.0 * k_re * k_im;
   h->diag_valid = false;
+  h->materialised = false;
+  h->epoch++;
+  return MA_OK;
+}
+
+// HelmholtzAssembler.boundary_values[tag] (assembler.rs:19-32): real values on the operator's pattern (nnz entries)
+int ma_csr_add_boundary(ma_csr_t* h, int32_t tag, const double* values) {
+  MA_REQUIRE(h && values, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(h->km, MA_ERR_INVALID, "boundary matrices belong to a K/M handle");
+  MA_REQUIRE(h->btags.size() < 8, MA_ERR_UNSUPPORTED, "at most 8 boundary matrices per handle");
+  for (int t : h->btags) MA_REQUIRE(t != tag, MA_ERR_INVALID, "boundary tag %d is already present", tag);
+  MA_HIP(hipSetDevice(h->device));
+  double* d = nullptr;
+  const size_t nz = (size_t)(h->nnz > 0 ? h->nnz : 1);
+  if (hipMalloc(&d, sizeof(double) * nz) != hipSuccess) { set_error("boundary matrix allocation failed"); return MA_ERR_NOMEM; }
+  if (h->nnz > 0 && hipMemcpy(d, values, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); set_error("boundary matrix upload failed"); return MA_ERR_HIP; }
+  h->btags.push_back(tag); h->d_B.push_back(d);
+  return MA_OK;
+}
+
+// HelmholtzAssembler::assemble(wavenumber, boundary_coeffs) (assembler.rs:216-257): A = K - k^2 M + sum_t c_t B_t over the
+// tags present in both maps. Without boundary terms this is ma_csr_set_wavenumber (values formed in registers); with
+// them the complex values are written once per call by a device kernel and the SpMV reads them (28 instead of 20 B/nnz).
+int ma_csr_assemble(ma_csr_t* h, double k_re, double k_im, int32_t ncoef, const int32_t* tags, const ma_c64* coeffs, void* stream) {
+  MA_REQUIRE(h, MA_ERR_INVALID, "NULL handle");
+  MA_REQUIRE(h->km, MA_ERR_INVALID, "handle holds complex values, not K/M");
+  MA_REQUIRE(ncoef >= 0 && (ncoef == 0 || (tags && coeffs)), MA_ERR_INVALID, "bad coefficient list");
+  h->k2_re = k_re * k_re - k_im * k_im; h->k2_im = 2.0 * k_re * k_im;
+  h->diag_valid = false;
+  h->epoch++;
+  const double* B[8]; double cre[8], cim[8]; int nb = 0;
+  for (size_t t = 0; t < h->btags.size(); ++t)
+    for (int c = 0; c < ncoef; ++c) if (tags[c] == h->btags[t]) { B[nb] = h->d_B[t]; cre[nb] = coeffs[c].re; cim[nb] = coeffs[c].im; ++nb; break; }
+  if (nb == 0) { h->materialised = false; return MA_OK; }
+  MA_HIP(hipSetDevice(h->device));
+  const size_t nz = (size_t)(h->nnz > 0 ? h->nnz : 1);
+  if (!h->d_val) MA_HIP(hipMalloc(&h->d_val, sizeof(c64) * nz));
+  if (h->d_sell_ptr && h->d_sell_src && !h->d_sell_val) MA_HIP(hipMalloc(&h->d_sell_val, sizeof(c64) * (size_t)h->sell_tot));
+  int rc = csr_launch_assemble(h->nnz, h->d_K, h->d_M, h->k2_re, h->k2_im, nb, B, cre, cim, h->d_val, h->sell_tot, h->d_sell_src,
+                               (h->d_sell_ptr && h->d_sell_src) ? h->d_sell_val : nullptr, (hipStream_t)stream);
+  if (rc) return rc;
+  h->materialised = true;
   return MA_OK;
 }
 
@@ -185,12 +240,12 @@ int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz) {
 int ma_csr_spmv_dev(ma_csr_t* h, const void* d_x, void* d_y, void* stream) {
   MA_REQUIRE(h && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(h->device));
-  return csr_launch_rows(h->view(), h->km, h->group, 0, (const c64*)d_x, nullptr, (c64*)d_y, 0.0, (hipStream_t)stream);
+  return csr_launch_rows(h->view(), h->fused_km(), h->group, 0, (const c64*)d_x, nullptr, (c64*)d_y, 0.0, (hipStream_t)stream);
 }
 int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r, void* stream) {
   MA_REQUIRE(h && d_x && d_b && d_r, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(h->device));
-  return csr_launch_rows(h->view(), h->km, h->group, 1, (const c64*)d_x, (const c64*)d_b, (c64*)d_r, 0.0, (hipStream_t)stream);
+  return csr_launch_rows(h->view(), h->fused_km(), h->group, 1, (const c64*)d_x, (const c64*)d_b, (c64*)d_r, 0.0, (hipStream_t)stream);
 }
 // `sweeps` Jacobi sweeps on d_x (in place from the caller's view; d_tmp is a scratch vector of n entries)
 int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream) {
@@ -199,7 +254,7 @@ int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int
   hipStream_t st = (hipStream_t)stream;
   int rc = ensure_diag(h, st);
   c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
-  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->km, h->group, 2, cur, (const c64*)d_b, nxt, omega, st); std::swap(cur, nxt); }
+  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->fused_km(), h->group, 2, cur, (const c64*)d_b, nxt, omega, st); std::swap(cur, nxt); }
   if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
   return rc;
 }
@@ -209,7 +264,7 @@ int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, voi
   hipStream_t st = (hipStream_t)stream;
   int rc = ensure_diag(h, st);
   c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
-  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->km, h->group, 3, cur, (const c64*)d_b, nxt, 0.0, st); std::swap(cur, nxt); }
+  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->fused_km(), h->group, 3, cur, (const c64*)d_b, nxt, 0.0, st); std::swap(cur, nxt); }
   if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
   return rc;
 }
@@ -266,7 +321,8 @@ int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out) {
   MA_HIP(hipMemcpy(rp.data(), h->d_rowptr, sizeof(long long) * (n + 1), hipMemcpyDeviceToHost));
   if (nnz) MA_HIP(hipMemcpy(ci.data(), h->d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
   std::vector<c64> val; std::vector<double> K, M;
-  if (h->km) { K.resize(nnz ? nnz : 1); M.resize(nnz ? nnz : 1); if (nnz) { MA_HIP(hipMemcpy(K.data(), h->d_K, sizeof(double) * nnz, hipMemcpyDeviceToHost)); MA_HIP(hipMemcpy(M.data(), h->d_M, sizeof(double) * nnz, hipMemcpyDeviceToHost)); } }
+  const bool km = h->km && !h->materialised;            // a handle assembled with boundary terms transposes its complex values
+  if (km) { K.resize(nnz ? nnz : 1); M.resize(nnz ? nnz : 1); if (nnz) { MA_HIP(hipMemcpy(K.data(), h->d_K, sizeof(double) * nnz, hipMemcpyDeviceToHost)); MA_HIP(hipMemcpy(M.data(), h->d_M, sizeof(double) * nnz, hipMemcpyDeviceToHost)); } }
   else { val.resize(nnz ? nnz : 1); if (nnz) MA_HIP(hipMemcpy(val.data(), h->d_val, sizeof(c64) * nnz, hipMemcpyDeviceToHost)); }
   std::vector<int64_t> trp(n + 1, 0), tci(nnz ? nnz : 1);
   for (size_t t = 0; t < nnz; ++t) trp[(size_t)ci[t] + 1]++;
@@ -277,12 +333,25 @@ int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out) {
     for (long long t = rp[i]; t < rp[i + 1]; ++t) {       // rows ascending: the transposed rows come out with sorted columns
       const size_t q = (size_t)pos[(size_t)ci[(size_t)t]]++;
       tci[q] = (int64_t)i;
-      if (h->km) { tK[q] = K[(size_t)t]; tM[q] = M[(size_t)t]; } else tval[q] = val[(size_t)t];
+      if (km) { tK[q] = K[(size_t)t]; tM[q] = M[(size_t)t]; } else tval[q] = val[(size_t)t];
     }
-  int rc = h->km ? ma_csr_create_helmholtz((int64_t)n, trp.data(), tci.data(), tK.data(), tM.data(), h->device, out)
+  int rc = km ? ma_csr_create_helmholtz((int64_t)n, trp.data(), tci.data(), tK.data(), tM.data(), h->device, out)
                  : ma_csr_create((int64_t)n, trp.data(), tci.data(), reinterpret_cast<const ma_c64*>(tval.data()), h->device, out);
   if (rc) return rc;
   (*out)->k2_re = h->k2_re; (*out)->k2_im = h->k2_im; (*out)->zero_diag_dinv = h->zero_diag_dinv; (*out)->diag_valid = false;
+  return MA_OK;
+}
+
+// Keep a transposed handle in step with its source after the source's values changed: a fused K/M pair only needs the new
+// k^2; anything else (boundary terms materialised, or a change of mode) asks for a rebuild (*rebuild = 1).
+unsigned long long ma_csr_epoch(const ma_csr_t* h) { return h ? h->epoch : 0; }
+int ma_csr_refresh_transpose(const ma_csr_t* src, ma_csr_t* dst, int* rebuild) {
+  MA_REQUIRE(src && dst && rebuild, MA_ERR_INVALID, "NULL argument");
+  *rebuild = 1;
+  if (src->fused_km() && dst->km) {
+    dst->k2_re = src->k2_re; dst->k2_im = src->k2_im; dst->materialised = false; dst->diag_valid = false; dst->epoch++;
+    *rebuild = 0;
+  }
   return MA_OK;
 }
 

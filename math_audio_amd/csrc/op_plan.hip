@@ -15,6 +15,8 @@ extern "C" int ma_csr_spmv_dev(ma_csr* h, const void* d_x, void* d_y, void* stre
 extern "C" int ma_csr_num_rows(const ma_csr* h, int64_t* n, int64_t* nnz);
 extern "C" int ma_csr_transpose(ma_csr* h, ma_csr** out);
 extern "C" int ma_csr_destroy(ma_csr* h);
+extern "C" unsigned long long ma_csr_epoch(const ma_csr* h);
+extern "C" int ma_csr_refresh_transpose(const ma_csr* src, ma_csr* dst, int* rebuild);
 
 struct ma_op {
   int kind = 0;                 // 0 dense, 1 csr, 2 on-the-fly TBEM
@@ -23,6 +25,7 @@ struct ma_op {
   c64* dA = nullptr; bool own_A = false;
   ma_csr* csr = nullptr;
   ma_csr* csr_t = nullptr;      // transposed CSR operator, built at the first apply_transpose (owned)
+  unsigned long long csr_t_epoch = 0;   // value epoch of `csr` the transposed copy corresponds to
   c64* d_tpart = nullptr;       // dense A^T x: per-row-chunk partial sums
   c64* d_cx = nullptr;          // conj(x) / pre-conjugation result of the hermitian CSR apply
   // TBEM
@@ -177,7 +180,13 @@ static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStre
     if (!o->d_tpart) MA_HIP(hipMalloc(&o->d_tpart, sizeof(c64) * (size_t)op_zgemv_t_chunks() * (size_t)o->n));
     return op_launch_zgemv_t(o->n, o->dA, (const c64*)d_x, o->d_tpart, (c64*)d_y, herm, st);
   }
-  if (!o->csr_t) { int rc = ma_csr_transpose(o->csr, &o->csr_t); if (rc) return rc; }
+  if (o->csr_t && o->csr_t_epoch != ma_csr_epoch(o->csr)) {          // the source was re-assembled for another frequency
+    int rebuild = 1;
+    int rc = ma_csr_refresh_transpose(o->csr, o->csr_t, &rebuild); if (rc) return rc;
+    if (rebuild) { (void)ma_csr_destroy(o->csr_t); o->csr_t = nullptr; }
+    o->csr_t_epoch = ma_csr_epoch(o->csr);
+  }
+  if (!o->csr_t) { int rc = ma_csr_transpose(o->csr, &o->csr_t); if (rc) return rc; o->csr_t_epoch = ma_csr_epoch(o->csr); }
   if (!herm) return ma_csr_spmv_dev(o->csr_t, d_x, d_y, st);
   if (!o->d_cx) MA_HIP(hipMalloc(&o->d_cx, sizeof(c64) * (size_t)o->n));
   int rc = op_launch_conj(o->n, (const c64*)d_x, o->d_cx, st);

@@ -134,3 +134,45 @@ def test_fem_coo_smoother_matches_oracle(gpu):
         A.fem_smooth(x, b, kind=0)
     assert ei.value.status == ma.MA_ERR_UNSUPPORTED
     A.close()
+
+
+@pytest.mark.parametrize("layout", ["sell", "csr"])
+def test_helmholtz_assemble_with_boundary_terms(gpu, layout, monkeypatch):
+    """HelmholtzAssembler::assemble (assembler.rs:216-257): A = K - k^2 M + sum_t c_t B_t with two boundary matrices (an
+    impedance wall and a second tag that gets no coefficient), SpMV, smoothers and transpose on the assembled operator."""
+    monkeypatch.setenv("MA_CSR_SELL", "1" if layout == "sell" else "0")
+    nodes, rp, ci, K, M = fem.helmholtz_box(7, 6, 5)
+    n = len(rp) - 1
+    rng = np.random.default_rng(6)
+    wall = nodes[:, 0] < 1e-12                                       # entries coupling two nodes of the x = 0 wall
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    B1 = np.where(wall[rows] & wall[ci], 0.01 * (1.0 + rng.random(len(ci))), 0.0)
+    B2 = np.where(nodes[rows, 2] > 2.4, 0.02, 0.0) * (nodes[ci, 2] > 2.4)
+    op = ma.CsrOperator(rp, ci, K=K, M=M)
+    op.add_boundary(3, B1); op.add_boundary(9, B2)
+    k = 1.9 + 0.05j
+    x = _x0(n); b = np.cos(0.3 * np.arange(n)) + 0.5j
+    for coeffs in ({3: 1j * k * 0.7}, {3: 1j * k * 0.7, 9: -0.3 + 0.1j}, {}, {5: 2.0}):
+        op.assemble(k, coeffs)
+        vals = O.helmholtz_values(K, M, k)
+        if 3 in coeffs: vals = vals + coeffs[3] * B1
+        if 9 in coeffs: vals = vals + coeffs[9] * B2
+        y_ref = O.csr_matvec(rp, ci, vals, x, nthreads=4)
+        assert np.abs(op.matvec(x) - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+        xj = O.amg_jacobi(rp, ci, vals, x, b, 0.8, 2, nthreads=4)
+        assert np.abs(op.jacobi(x, b, 0.8, 2) - xj).max() <= 1e-12 * np.abs(xj).max()
+        xl = O.amg_l1_jacobi(rp, ci, vals, x, b, 2, nthreads=4)
+        assert np.abs(op.l1_jacobi(x, b, 2) - xl).max() <= 1e-12 * np.abs(xl).max()
+    op.assemble(k, {3: 1j * k * 0.7})
+    lo = ma.LinearOperator.csr(op)
+    vals = O.helmholtz_values(K, M, k) + 1j * k * 0.7 * B1
+    dense = np.zeros((n, n), dtype=complex); dense[rows, ci] = vals
+    assert np.abs(lo.apply_transpose(x) - dense.T @ x).max() <= 1e-12 * np.abs(dense.T @ x).max()
+    op.set_wavenumber(k)                                             # back to the fused K - k^2 M path
+    y0 = O.csr_matvec(rp, ci, O.helmholtz_values(K, M, k), x, nthreads=4)
+    assert np.abs(op.matvec(x) - y0).max() <= 1e-13 * np.abs(y0).max()
+    assert np.abs(lo.apply_transpose(x) - y0).max() <= 1e-12 * np.abs(y0).max()     # the cached transpose follows (K, M symmetric)
+    op.set_wavenumber(0.5 * k)
+    y1 = O.csr_matvec(rp, ci, O.helmholtz_values(K, M, 0.5 * k), x, nthreads=4)
+    assert np.abs(lo.apply_transpose(x) - y1).max() <= 1e-12 * np.abs(y1).max()
+    lo.close(); op.close()
