@@ -112,6 +112,11 @@ int ma_bem_plan_incident_rhs_dev(ma_bem_plan_t* plan, const ma_physics_t* physic
 int ma_bem_incident_rhs(int n, const double* centers, const double* normals, const ma_physics_t* physics,
                         double beta_re, double beta_im, int kind, const double* vec3,
                         double amp_re, double amp_im, ma_c64* rhs);
+/* IncidentField::evaluate_pressure (incident.rs:93-166) / ::evaluate_normal_derivative (:177-280) at n points; either
+ * output may be NULL (normals may be NULL when dpdn_out is). compute_total_field (postprocess/pressure.rs:273-311) is
+ * this p plus ma_bem_plan_scattered_field. */
+int ma_bem_incident_evaluate(int n, const double* points, const double* normals, const ma_physics_t* physics, int kind, const double* vec3,
+                             double amp_re, double amp_im, ma_c64* p_out, ma_c64* dpdn_out);
 
 /* ------------------------------------------------------------------------------------------
  * Dense complex solve.

@@ -122,6 +122,7 @@ def lib():
             "ma_bem_plan_scattered_field": [vp, P(ma_physics_t), i32, vp, vp, vp, vp],
             "ma_room_build_matrix": [i32, vp, vp, vp, dbl, vp],
             "ma_room_build_matrix_dev": [i32, vp, vp, vp, dbl, vp, vp],
+            "ma_bem_incident_evaluate": [C.c_int, vp, vp, P(ma_physics_t), C.c_int, vp, dbl, dbl, vp, vp],
             "ma_room_element_data": [i32, vp, vp, vp, vp, vp, vp],
             "ma_room_build_matrix_adaptive": [i32, vp, i32, vp, dbl, C.c_int, vp],
             "ma_room_incident_derivative": [i32, vp, vp, i32, vp, vp, C.c_int, dbl, vp],
@@ -627,3 +628,23 @@ def room_field_pressure(center, normal, area, surface_pressure, src_pos, amp, po
     out = np.empty(pts.shape[0], dtype=np.complex128)
     check(lib().ma_room_field_pressure(len(a), _vp(c), _vp(nr), _vp(a), _vp(ps), sp.shape[0], _vp(sp), _vp(amp), pp, pts.shape[0], _vp(pts), float(k), _vp(out)))
     return out
+
+
+def incident_evaluate(points, k, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, normals=None, harmonic=1.0):
+    """IncidentField::evaluate_pressure (and ::evaluate_normal_derivative when normals are given): returns p or (p, dp/dn)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)
+    ph = physics(k, harmonic)
+    p = np.empty(pts.shape[0], dtype=np.complex128)
+    if normals is None:
+        check(lib().ma_bem_incident_evaluate(pts.shape[0], _vp(pts), None, C.byref(ph), kind, _vp(v), amp.real, amp.imag, _vp(p), None))
+        return p
+    nr = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+    d = np.empty(pts.shape[0], dtype=np.complex128)
+    check(lib().ma_bem_incident_evaluate(pts.shape[0], _vp(pts), _vp(nr), C.byref(ph), kind, _vp(v), amp.real, amp.imag, _vp(p), _vp(d)))
+    return p, d
+
+
+def total_field(plan, k, eval_points, surface_pressure, surface_velocity=None, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0):
+    """compute_total_field (postprocess/pressure.rs:273-311): (p_incident, p_scattered) at the evaluation points."""
+    return incident_evaluate(eval_points, k, kind, vec, amp), scattered_field(plan, k, eval_points, surface_pressure, surface_velocity)

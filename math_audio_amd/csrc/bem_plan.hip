@@ -467,4 +467,28 @@ int ma_bem_incident_rhs(int n, const double* centers, const double* normals, con
   return rc;
 }
 
+// IncidentField::evaluate_pressure (incident.rs:93-166) and ::evaluate_normal_derivative (:177-280) at arbitrary points:
+// p and/or dp/dn (either output may be NULL; normals may be NULL when dp/dn is not asked for). They are the two terms of
+// compute_rhs_with_beta = -(gamma p + beta tau dp/dn), read off with (gamma, beta) = (1, 0) and (0, 1).
+int ma_bem_incident_evaluate(int n, const double* points, const double* normals, const ma_physics_t* ph, int kind, const double* vec3, double are, double aim,
+                             ma_c64* p_out, ma_c64* dpdn_out) {
+  MA_REQUIRE(n > 0 && points && ph && vec3 && (p_out || dpdn_out), MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(!dpdn_out || normals, MA_ERR_INVALID, "normals are needed for dp/dn");
+  std::vector<double> zero;
+  if (!normals) { zero.assign(3 * (size_t)n, 0.0); normals = zero.data(); }
+  ma_physics_t q = *ph;
+  int rc = MA_OK;
+  if (p_out) {
+    q.gamma = 1.0; q.tau = 1.0;
+    rc = ma_bem_incident_rhs(n, points, normals, &q, 0.0, 0.0, kind, vec3, are, aim, p_out);
+    for (int i = 0; i < n && !rc; ++i) { p_out[i].re = -p_out[i].re; p_out[i].im = -p_out[i].im; }
+  }
+  if (dpdn_out && !rc) {
+    q.gamma = 0.0; q.tau = 1.0;
+    rc = ma_bem_incident_rhs(n, points, normals, &q, 1.0, 0.0, kind, vec3, are, aim, dpdn_out);
+    for (int i = 0; i < n && !rc; ++i) { dpdn_out[i].re = -dpdn_out[i].re; dpdn_out[i].im = -dpdn_out[i].im; }
+  }
+  return rc;
+}
+
 }  // extern "C"

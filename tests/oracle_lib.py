@@ -222,6 +222,14 @@ def incident_pressure(points, k, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0):
     return out
 
 
+def incident_normal_derivative(points, normals, k, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0):
+    points = np.ascontiguousarray(points, dtype=np.float64); normals = np.ascontiguousarray(normals, dtype=np.float64)
+    v = np.ascontiguousarray(vec, dtype=np.float64)
+    out = np.zeros(points.shape[0], dtype=np.complex128)
+    lib().mao_incident_normal_derivative(kind, _p(v), _cz(amp), points.shape[0], _p(points), _p(normals), C.c_double(k), _vp(out))
+    return out
+
+
 # ---------------------------------------------------------------- dense solve
 def zgesv(A, b, nthreads=1):
     """Returns (x, ipiv, status); A is copied."""

@@ -117,3 +117,23 @@ def test_room_incident_derivative_and_field_pressure_match_oracle(gpu):
         ref = O.room_field_pressure(c, nr, a, ps, src, amp, pts, k)
         got = ma.room_field_pressure(c, nr, a, ps, src, amp, pts, k)
         assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_incident_evaluate_and_total_field(gpu):
+    """IncidentField::evaluate_pressure / evaluate_normal_derivative (incident.rs:93-280) and compute_total_field."""
+    om = O.icosphere(RADIUS, 1)
+    k = k_from_ka(1.3)
+    rng = np.random.default_rng(1)
+    pts = rng.standard_normal((50, 3)); nrm = rng.standard_normal((50, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    for kind, vec, amp in ((0, (0.6, 0.0, 0.8), 1.5 - 0.5j), (1, (0.2, -0.4, 3.0), 2.0 + 0j)):
+        p, d = ma.incident_evaluate(pts, k, kind, vec, amp, normals=nrm)
+        assert np.abs(p - O.incident_pressure(pts, k, kind, vec, amp)).max() <= 1e-13 * np.abs(p).max()
+        assert np.abs(d - O.incident_normal_derivative(pts, nrm, k, kind, vec, amp)).max() <= 1e-13 * np.abs(d).max()
+        assert np.array_equal(ma.incident_evaluate(pts, k, kind, vec, amp), p)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    ps = rng.standard_normal(om.n_elem) + 0j
+    ep = 3 * RADIUS * pts[:5] / np.linalg.norm(pts[:5], axis=1, keepdims=True)
+    pi, psc = ma.total_field(plan, k, ep, ps)
+    assert np.abs(pi - np.exp(1j * k * ep[:, 2])).max() <= 1e-13
+    assert np.abs(psc - O.compute_scattered_field(ep, om, ps, k)).max() <= 1e-12 * np.abs(psc).max()
+    plan.close()
