@@ -127,6 +127,14 @@ int ma_bem_incident_evaluate(int n, const double* points, const double* normals,
  * ------------------------------------------------------------------------------------------ */
 int ma_zgesv(int32_t n, ma_c64* A_rowmajor, ma_c64* b_inout, int32_t* ipiv_or_null);
 
+/* The same solve with the reference's own signature, lu_solve(&a, &b) -> x: inputs untouched, factors not copied back. */
+int ma_lu_solve(int32_t n, const ma_c64* A_rowmajor, const ma_c64* b, ma_c64* x);
+/* lu_factorize(&a) -> LuFactorization (lu.rs:83-137) and LuFactorization::solve(&b) (lu.rs:38-78): the factors stay in HBM. */
+typedef struct ma_lu_factorization ma_lu_factorization_t;
+int ma_lu_factorize(int32_t n, const ma_c64* A_rowmajor, ma_lu_factorization_t** out);
+int ma_lu_factorization_solve(ma_lu_factorization_t* f, const ma_c64* b, ma_c64* x);
+int ma_lu_factorization_destroy(ma_lu_factorization_t* f);
+
 typedef struct ma_lu_plan ma_lu_plan_t;           /* workspace for device-resident solves of size n */
 int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out);
 int ma_lu_plan_destroy(ma_lu_plan_t* plan);
@@ -138,6 +146,8 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_
  * pointers): the panels of the systems are interleaved on the plan's panel stream so that one system's
  * latency-bound panel chain runs underneath another's trailing updates. Results per system are
  * bit-identical to separate ma_lu_plan_factor_solve_dev calls. */
+/* solve further right-hand sides with the factors a previous ma_lu_plan_factor_solve_dev call on this plan left in d_A */
+int ma_lu_plan_solve_dev(ma_lu_plan_t* plan, void* d_A_factored, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* const* d_As, void* const* d_Bs, int32_t nrhs, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
 

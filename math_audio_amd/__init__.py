@@ -76,6 +76,11 @@ def lib():
             "ma_lu_plan_create": [i32, C.c_int, P(vp)],
             "ma_lu_plan_destroy": [vp],
             "ma_lu_plan_factor_solve_dev": [vp, vp, vp, i32, vp],
+            "ma_lu_plan_solve_dev": [vp, vp, vp, i32, vp],
+            "ma_lu_solve": [i32, vp, vp, vp],
+            "ma_lu_factorize": [i32, vp, P(vp)],
+            "ma_lu_factorization_solve": [vp, vp, vp],
+            "ma_lu_factorization_destroy": [vp],
             "ma_lu_plan_factor_solve_batch_dev": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
@@ -648,3 +653,44 @@ def incident_evaluate(points, k, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, normals=N
 def total_field(plan, k, eval_points, surface_pressure, surface_velocity=None, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0):
     """compute_total_field (postprocess/pressure.rs:273-311): (p_incident, p_scattered) at the evaluation points."""
     return incident_evaluate(eval_points, k, kind, vec, amp), scattered_field(plan, k, eval_points, surface_pressure, surface_velocity)
+
+
+def lu_solve(A, b):
+    """lu_solve(&a, &b) -> x (math-solvers/src/direct/lu.rs:142-153): inputs untouched, factors stay on the device."""
+    A = np.ascontiguousarray(A, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+    if A.ndim != 2 or A.shape[0] != A.shape[1] or b.shape != (A.shape[0],):
+        raise MaError(MA_ERR_DIM, "lu_solve: A must be n x n and b of length n")
+    x = np.empty_like(b)
+    check(lib().ma_lu_solve(A.shape[0], _vp(A), _vp(b), _vp(x)))
+    return x
+
+
+class LuFactorization:
+    """lu_factorize(&a) (lu.rs:83-137) / LuFactorization::solve(&b) (lu.rs:38-78): the factors live in HBM."""
+
+    def __init__(self, A):
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise MaError(MA_ERR_DIM, "lu_factorize: A must be square")
+        self.n = A.shape[0]
+        self.h = C.c_void_p()
+        check(lib().ma_lu_factorize(self.n, _vp(A), C.byref(self.h)))
+
+    def solve(self, b):
+        b = np.ascontiguousarray(b, dtype=np.complex128)
+        if b.shape != (self.n,):
+            raise MaError(MA_ERR_DIM, "solve: b must have n entries")
+        x = np.empty_like(b)
+        check(lib().ma_lu_factorization_solve(self.h, _vp(b), _vp(x)))
+        return x
+
+    def close(self):
+        if self.h:
+            lib().ma_lu_factorization_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

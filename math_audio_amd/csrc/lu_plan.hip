@@ -200,6 +200,22 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 }
 #define MA_MARK(var, stream) int var; if ((rc = mark(P, (stream), &var))) return rc
 
+// panels of the factorisation: first column, width, rows per panel workgroup, workgroups
+static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks) {
+  const int n = P->n;
+  for (int k0 = 0; k0 < n;) {
+    int nb, rpb, nblk;
+    // rows per panel workgroup: at most 47.5 KB of LDS, so that two systems' panel workgroups AND two trailing-update
+    // workgroups fit on a CU together (the launcher admits panel kernels up to 96 KB per CU): 44 rows at nb = 64.
+    // Few rows per workgroup also keep the per-column local work -- which a co-tenant update slows down -- short.
+    const int wnb = std::min(n - k0, P->want_nb);
+    const int cap = P->rpb_env ? P->rpb_cap : std::max(8, (int)((48640 - 2 * wnb * 16 - 256) / ((wnb + 1) * 16)));
+    panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), cap, &nb, &rpb, &nblk);
+    k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
+    k0 += nb;
+  }
+}
+
 // Factor the matrices in place and solve for nrhs right-hand sides each (d_B[nrhs][n]); everything asynchronous.
 //
 // Right-looking blocked LU on two levels. Pivoting works on panels of <= 128 columns (lu_panel_kernel: the width whose
@@ -234,17 +250,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   MA_MARK(e_begin, st);
 
   std::vector<int> k0s, nbs, rpbs, nblks;
-  for (int k0 = 0; k0 < n;) {
-    int nb, rpb, nblk;
-    // rows per panel workgroup: at most 47.5 KB of LDS, so that two systems' panel workgroups AND two trailing-update
-    // workgroups fit on a CU together (the launcher admits panel kernels up to 96 KB per CU): 44 rows at nb = 64.
-    // Few rows per workgroup also keep the per-column local work -- which a co-tenant update slows down -- short.
-    const int wnb = std::min(n - k0, P->want_nb);
-    const int cap = P->rpb_env ? P->rpb_cap : std::max(8, (int)((48640 - 2 * wnb * 16 - 256) / ((wnb + 1) * 16)));
-    panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), cap, &nb, &rpb, &nblk);
-    k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
-    k0 += nb;
-  }
+  panel_schedule(P, k0s, nbs, rpbs, nblks);
   const int Q = (int)k0s.size();
   // the lane's interchange staging holds (kb-1) panels' columns
   int kb = std::max(1, std::min(P->kb, LU_KB_MAX));
@@ -364,6 +370,43 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   return MA_OK;
 }
 
+// Solve with factors that an earlier ma_lu_plan_factor_solve_dev call on THIS plan left in d_A (the plan still holds
+// the pivots): b <- P b panel by panel, forward substitution with the unit-lower factor, backward with the upper one.
+// LuFactorization::solve (lu.rs:38-78).
+static int solve_only(ma_lu_plan* P, c64* A, c64* B, int32_t nrhs, hipStream_t st) {
+  const int n = P->n;
+  const int tstride = n + P->nrhs_max;
+  std::vector<int> k0s, nbs, rpbs, nblks;
+  panel_schedule(P, k0s, nbs, rpbs, nblks);
+  const int Q = (int)k0s.size();
+  int rc;
+  // the stored factors are in their final row order (later interchanges were applied to the earlier L columns), so every
+  // interchange goes onto b first (zgetrs: laswp, then the triangular solves)
+  for (int q = 0; q < Q; ++q)
+    if ((rc = lu_launch_swaps(A, n, k0s[q], nbs[q], P->d_ipiv[0], P->d_lists[0], P->d_tmp[0], tstride, 0, 0, 0, 0, B, nrhs, nullptr, st))) return rc;
+  for (int q = 0; q < Q; ++q) {
+    const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[0], P->d_lists[0], P->d_tmp[0], tstride, 0, 0, 0, 0, nullptr, 0, P->d_invd[0], st))) return rc;   // inverted diagonal blocks only
+    if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, P->d_invd[0], A, (size_t)n, 0, B + k0, (size_t)n, nrhs, st))) return rc;
+    for (int r = 0; r < nrhs && a1 < n; ++r)
+      if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, st))) return rc;
+  }
+  for (int q = Q - 1; q >= 0; --q) {
+    const int k0 = k0s[q], nb = nbs[q];
+    if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
+    for (int r = 0; r < nrhs && k0 > 0; ++r)
+      if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
+  }
+  return MA_OK;
+}
+
+int ma_lu_plan_solve_dev(ma_lu_plan_t* P, void* dA_factored, void* dB, int32_t nrhs, void* stream) {
+  MA_REQUIRE(P && dA_factored && dB, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(nrhs >= 1 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 1..%d", P->nrhs_max);
+  MA_HIP(hipSetDevice(P->device));
+  return solve_only(P, (c64*)dA_factored, (c64*)dB, nrhs, (hipStream_t)stream);
+}
+
 int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrhs, void* stream) {
   MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
   MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
@@ -464,6 +507,68 @@ int ma_zgesv(int32_t n, ma_c64* A, ma_c64* b, int32_t* ipiv) {
   (void)hipFree(dA); (void)hipFree(db);
   ma_lu_plan_destroy(P);
   return rc;
+}
+
+// lu_solve(&a, &b) -> x (lu.rs:142-153) with the reference's own signature: A and b are not modified and the factors are
+// not brought back (half the PCIe traffic of ma_zgesv).
+int ma_lu_solve(int32_t n, const ma_c64* A, const ma_c64* b, ma_c64* x) {
+  MA_REQUIRE(n >= 0, MA_ERR_DIM, "n is negative");
+  if (n == 0) return MA_OK;
+  MA_REQUIRE(A && b && x, MA_ERR_INVALID, "NULL argument");
+  ma_lu_factorization_t* F = nullptr;
+  int rc = ma_lu_factorize(n, A, &F);
+  if (!rc) rc = ma_lu_factorization_solve(F, b, x);
+  ma_lu_factorization_destroy(F);
+  return rc;
+}
+
+// lu_factorize (lu.rs:83-137): the factors stay in HBM behind the handle
+struct ma_lu_factorization { ma_lu_plan* plan = nullptr; c64* dA = nullptr; c64* db = nullptr; int n = 0; };
+
+int ma_lu_factorize(int32_t n, const ma_c64* A, ma_lu_factorization_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  MA_REQUIRE(n > 0, MA_ERR_DIM, "n must be positive");
+  MA_REQUIRE(A, MA_ERR_INVALID, "A is NULL");
+  int dev = 0;
+  if (const char* s = getenv("MA_DEVICE")) dev = atoi(s);
+  ma_lu_factorization* F = new (std::nothrow) ma_lu_factorization();
+  MA_REQUIRE(F, MA_ERR_NOMEM, "host allocation failed");
+  F->n = n;
+  int rc = ma_lu_plan_create(n, dev, &F->plan);
+  const size_t nn = (size_t)n;
+  if (!rc) {
+    hipError_t e = hipMalloc(&F->dA, nn * nn * sizeof(c64));
+    if (e == hipSuccess) e = hipMalloc(&F->db, nn * sizeof(c64));
+    if (e == hipSuccess) e = hipMemcpy(F->dA, A, nn * nn * sizeof(c64), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error("factorisation buffers for n = %d: %s", n, hipGetErrorString(e)); rc = MA_ERR_NOMEM; }
+  }
+  if (!rc) rc = ma_lu_plan_factor_solve_dev(F->plan, F->dA, nullptr, 0, nullptr);
+  if (!rc) rc = ma_lu_plan_status(F->plan, nullptr);
+  if (rc) { ma_lu_factorization_destroy(F); return rc; }
+  *out = F;
+  return MA_OK;
+}
+
+// LuFactorization::solve (lu.rs:38-78)
+int ma_lu_factorization_solve(ma_lu_factorization_t* F, const ma_c64* b, ma_c64* x) {
+  MA_REQUIRE(F && b && x, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(F->plan->device));
+  const size_t nn = (size_t)F->n;
+  MA_HIP(hipMemcpy(F->db, b, nn * sizeof(c64), hipMemcpyHostToDevice));
+  int rc = ma_lu_plan_solve_dev(F->plan, F->dA, F->db, 1, nullptr);
+  if (rc) return rc;
+  MA_HIP(hipMemcpy(x, F->db, nn * sizeof(c64), hipMemcpyDeviceToHost));
+  return MA_OK;
+}
+
+int ma_lu_factorization_destroy(ma_lu_factorization_t* F) {
+  if (!F) return MA_OK;
+  if (F->dA) (void)hipFree(F->dA);
+  if (F->db) (void)hipFree(F->db);
+  if (F->plan) ma_lu_plan_destroy(F->plan);
+  delete F;
+  return MA_OK;
 }
 
 // Test hook: C <- C - A B with the MFMA kernel on host buffers (row-major, tight leading dimensions).

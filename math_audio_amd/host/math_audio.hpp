@@ -16,6 +16,7 @@
 #include <complex>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -233,8 +234,8 @@ inline Result<std::vector<Complex64>> lu_solve(const std::vector<Complex64>& a, 
   Result<std::vector<Complex64>> r{false, {}, {}};
   if (nrows != ncols || a.size() != nrows * ncols) { r.err = {LuError::DimensionMismatch, nrows, ncols, "Matrix dimensions mismatch"}; return r; }
   if (b.size() != nrows) { r.err = {LuError::DimensionMismatch, nrows, b.size(), "Matrix dimensions mismatch"}; return r; }
-  std::vector<Complex64> lu(a), x(b);
-  const int rc = ma_zgesv((int32_t)nrows, reinterpret_cast<ma_c64*>(lu.data()), reinterpret_cast<ma_c64*>(x.data()), nullptr);
+  std::vector<Complex64> x(b.size());
+  const int rc = ma_lu_solve((int32_t)nrows, reinterpret_cast<const ma_c64*>(a.data()), reinterpret_cast<const ma_c64*>(b.data()), reinterpret_cast<ma_c64*>(x.data()));
   if (rc == MA_OK) { r.ok = true; r.value.swap(x); return r; }
   if (rc == MA_ERR_SINGULAR) r.err = {LuError::SingularMatrix, 0, 0, "Matrix is singular or nearly singular"};
   else if (rc == MA_ERR_DIM) r.err = {LuError::DimensionMismatch, nrows, b.size(), ma_last_error_string()};
@@ -244,6 +245,44 @@ inline Result<std::vector<Complex64>> lu_solve(const std::vector<Complex64>& a, 
 inline Result<std::vector<Complex64>> lu_solve(const std::vector<double>& a, size_t n, size_t m, const std::vector<double>& b) {
   std::vector<Complex64> ac(a.begin(), a.end()), bc(b.begin(), b.end());
   return lu_solve(ac, n, m, bc);
+}
+
+// lu.rs:25-78, 83-137: the factors stay on the device behind the object
+class LuFactorization {
+ public:
+  size_t n = 0;
+  LuFactorization(LuFactorization&& o) noexcept : n(o.n), h_(o.h_) { o.h_ = nullptr; }
+  LuFactorization(const LuFactorization&) = delete;
+  ~LuFactorization() { if (h_) ma_lu_factorization_destroy(h_); }
+  Result<std::vector<Complex64>> solve(const std::vector<Complex64>& b) const {
+    Result<std::vector<Complex64>> r{false, {}, {}};
+    if (b.size() != n) { r.err = {LuError::DimensionMismatch, n, b.size(), "Matrix dimensions mismatch"}; return r; }
+    std::vector<Complex64> x(n);
+    const int rc = ma_lu_factorization_solve(h_, reinterpret_cast<const ma_c64*>(b.data()), reinterpret_cast<ma_c64*>(x.data()));
+    if (rc == MA_OK) { r.ok = true; r.value.swap(x); } else r.err = {LuError::Backend, 0, 0, ma_last_error_string()};
+    return r;
+  }
+  friend Result<LuFactorization> lu_factorize(const std::vector<Complex64>& a, size_t nrows, size_t ncols);
+ private:
+  LuFactorization() = default;
+  ma_lu_factorization_t* h_ = nullptr;
+};
+template <>
+struct Result<LuFactorization> {
+  bool ok = false; std::unique_ptr<LuFactorization> value; LuError err{};
+  bool is_ok() const { return ok; }
+  bool is_err() const { return !ok; }
+  LuFactorization& expect(const char* msg) { if (!ok) throw std::runtime_error(std::string(msg) + ": " + err.text); return *value; }
+};
+inline Result<LuFactorization> lu_factorize(const std::vector<Complex64>& a, size_t nrows, size_t ncols) {
+  Result<LuFactorization> r;
+  if (nrows != ncols || a.size() != nrows * ncols) { r.err = {LuError::DimensionMismatch, nrows, ncols, "Matrix dimensions mismatch"}; return r; }
+  ma_lu_factorization_t* h = nullptr;
+  const int rc = ma_lu_factorize((int32_t)nrows, reinterpret_cast<const ma_c64*>(a.data()), &h);
+  if (rc == MA_ERR_SINGULAR) { r.err = {LuError::SingularMatrix, 0, 0, "Matrix is singular or nearly singular"}; return r; }
+  if (rc != MA_OK) { r.err = {LuError::Backend, 0, 0, ma_last_error_string()}; return r; }
+  r.value.reset(new LuFactorization()); r.value->n = nrows; r.value->h_ = h; r.ok = true;
+  return r;
 }
 
 // ---------------------------------------------------------------- sparse/csr.rs, traits.rs, iterative/gmres.rs

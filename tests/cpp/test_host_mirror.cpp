@@ -35,6 +35,17 @@ static void test_lu_dimension_mismatch() {
   auto r = math_solvers::lu_solve(a, 2, 2, b);
   CHECK(r.is_err()); CHECK(r.err.kind == math_solvers::LuError::DimensionMismatch);
 }
+static void test_lu_factorize_then_solve() {             // lu.rs:218-240 (factorize once, solve)
+  std::vector<Complex64> a = {{4, 1}, {1, 0}, {2, 0}, {1, 0}, {3, -1}, {0, 1}, {2, 0}, {0, 1}, {5, 0}};
+  auto f = math_solvers::lu_factorize(a, 3, 3);
+  CHECK(f.is_ok());
+  for (int t = 0; t < 2; ++t) {
+    std::vector<Complex64> b = {{1.0 + t, 1}, {2, -1.0 * t}, {0.5, 0.25}};
+    auto x = f.expect("factorization").solve(b).expect("solve");
+    for (int i = 0; i < 3; ++i) CHECK(std::abs(a[3 * i] * x[0] + a[3 * i + 1] * x[1] + a[3 * i + 2] * x[2] - b[i]) < 1e-10);
+  }
+  CHECK(math_solvers::lu_factorize({1, 2, 2, 4}, 2, 2).err.kind == math_solvers::LuError::SingularMatrix);
+}
 static void test_tbem_diagonal_nonzero_and_qa() {       // tbem.rs:585-598 + qa_suite.rs:199-326 (Rayleigh, ka = 0.2)
   using namespace math_bem;
   const double radius = 0.1, c = 343.0, rho = 1.21, ka = 0.2;
@@ -120,7 +131,7 @@ static void test_gmres_simple_identity_preconditioned() {
 int main() {
   int n = 0;
   if (ma_device_count(&n) != MA_OK || n <= 0) { std::printf("no HIP device: the host mirror has no CPU fallback\n"); return 77; }
-  test_lu_solve_real(); test_lu_solve_complex(); test_lu_identity(); test_lu_singular(); test_lu_dimension_mismatch();
+  test_lu_solve_real(); test_lu_solve_complex(); test_lu_identity(); test_lu_singular(); test_lu_dimension_mismatch(); test_lu_factorize_then_solve();
   test_tbem_diagonal_nonzero_and_qa();
   test_csr_from_dense_matvec_triplets(); test_diagonal_preconditioner(); test_gmres_simple_identity_preconditioned();
   std::printf(failures ? "%d check(s) failed\n" : "host mirror: all checks passed\n", failures);

@@ -154,3 +154,25 @@ def test_several_right_hand_sides_and_systems(gpu, n, nrhs, nsys):
             assert np.linalg.norm(A @ X[r] - B[r]) / (np.linalg.norm(A) * np.linalg.norm(X[r])) <= 1e-14 * n
             assert np.linalg.norm(X[r] - np.linalg.solve(A, B[r])) / np.linalg.norm(X[r]) <= 1e-9
     lu.close()
+
+
+@pytest.mark.parametrize("n", [5, 130, 1000])
+def test_lu_factorize_then_solve_and_lu_solve(gpu, n):
+    """lu_factorize + LuFactorization::solve (lu.rs:38-137) and lu_solve with untouched inputs (lu.rs:142-153)."""
+    A, b = _rand(n, 3 * n)
+    A0 = A.copy(); b0 = b.copy()
+    x = ma.lu_solve(A, b)
+    assert np.array_equal(A, A0) and np.array_equal(b, b0)
+    assert np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * max(n, 10)
+    assert np.linalg.norm(x - ma.zgesv(A.copy(), b.copy())) <= 1e-12 * np.linalg.norm(x)
+    F = ma.LuFactorization(A)
+    rng = np.random.default_rng(n)
+    for _ in range(3):
+        c = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        y = F.solve(c)
+        assert np.linalg.norm(A @ y - c) / (np.linalg.norm(A) * np.linalg.norm(y)) <= 1e-14 * max(n, 10)
+    assert np.linalg.norm(F.solve(b) - x) <= 1e-12 * np.linalg.norm(x)
+    F.close()
+    with pytest.raises(ma.MaError) as e:
+        ma.LuFactorization(np.ones((4, 4)))
+    assert e.value.status == ma.MA_ERR_SINGULAR
