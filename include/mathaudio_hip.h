@@ -127,6 +127,15 @@ int ma_bem_incident_evaluate(int n, const double* points, const double* normals,
  * ------------------------------------------------------------------------------------------ */
 int ma_zgesv(int32_t n, ma_c64* A_rowmajor, ma_c64* b_inout, int32_t* ipiv_or_null);
 
+/* The frequency loop of the BEM drivers (math-bem/bin/room_simulator_bem.rs:329-360; BemSolver::solve, bem_solver.rs:355-480)
+ * as one device-resident call: per frequency k = 2 pi f / c, beta = i h scale / k (burton_miller_beta_scaled), TBEM assembly,
+ * incident right-hand side (kind 0 plane wave: vec3 = direction; 1 point source: vec3 = position), dense solve. `slots`
+ * systems (1..4, 0 = default 3) are kept in HBM and factored as one interleaved batch; only the n_freq x num_dofs
+ * solutions come back. status_or_null[f]: MA_OK or MA_ERR_SINGULAR per frequency. */
+int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
+                       double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, int32_t slots,
+                       ma_c64* X_out, int32_t* status_or_null);
+
 /* The same solve with the reference's own signature, lu_solve(&a, &b) -> x: inputs untouched, factors not copied back. */
 int ma_lu_solve(int32_t n, const ma_c64* A_rowmajor, const ma_c64* b, ma_c64* x);
 /* lu_factorize(&a) -> LuFactorization (lu.rs:83-137) and LuFactorization::solve(&b) (lu.rs:38-78): the factors stay in HBM. */

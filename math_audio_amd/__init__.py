@@ -78,6 +78,7 @@ def lib():
             "ma_lu_plan_factor_solve_dev": [vp, vp, vp, i32, vp],
             "ma_lu_plan_solve_dev": [vp, vp, vp, i32, vp],
             "ma_lu_solve": [i32, vp, vp, vp],
+            "ma_bem_solve_sweep": [vp, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
             "ma_lu_factorize": [i32, vp, P(vp)],
             "ma_lu_factorization_solve": [vp, vp, vp],
             "ma_lu_factorization_destroy": [vp],
@@ -694,3 +695,14 @@ class LuFactorization:
             self.close()
         except Exception:
             pass
+
+
+def solve_sweep(plan, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, slots=3, harmonic=1.0, tau=1.0):
+    """The BEM drivers' frequency loop as one device-resident call (ma_bem_solve_sweep): returns (X[n_freq, n], status[n_freq])."""
+    f = np.ascontiguousarray(frequencies_hz, dtype=np.float64); v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)
+    X = np.empty((len(f), plan.num_dofs), dtype=np.complex128); st = np.zeros(len(f), dtype=np.int32)
+    rc = lib().ma_bem_solve_sweep(plan.h, len(f), _vp(f), float(speed_of_sound), float(harmonic), float(tau), float(beta_scale), int(kind), _vp(v),
+                                  amp.real, amp.imag, int(slots), _vp(X), _vp(st))
+    if rc not in (MA_OK, MA_ERR_SINGULAR):
+        check(rc)
+    return X, st

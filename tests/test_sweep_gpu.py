@@ -147,3 +147,24 @@ def test_lookahead_and_plain_schedules_agree(gpu):
         outs.append(r.stdout.strip().split())
     assert outs[0][0] == outs[1][0]                       # bitwise-identical solution checksum
     assert float(outs[0][1]) < 1e-10
+
+
+def test_solve_sweep_driver_matches_per_frequency_path(gpu):
+    """ma_bem_solve_sweep = the drivers' loop (room_simulator_bem.rs:329-360): per frequency assembly + incident RHS + solve,
+    several systems per interleaved batch, against the one-shot path and the CPU restatement."""
+    om = O.icosphere(RADIUS, 2)
+    mesh = to_ma_mesh(om)
+    plan = ma.BemPlan(mesh)
+    freqs = [150.0, 545.9, 900.0, 1400.0, 2100.0]
+    X, st = ma.solve_sweep(plan, freqs, speed_of_sound=343.0, beta_scale=4.0, slots=2)
+    assert np.all(st == ma.MA_OK)
+    for fi, f in enumerate(freqs):
+        k = O.wave_number(f, 343.0); beta = complex(0.0, 4.0 / k)
+        A, r0 = ma.assemble_tbem(mesh, k, beta)
+        x1 = ma.zgesv(A, r0 + ma.incident_rhs(om.center, om.normal, k, beta))
+        assert rel_l2(X[fi], x1) <= 1e-10
+    k = O.wave_number(freqs[1], 343.0); beta = complex(0.0, 4.0 / k)
+    A_ref, rhs_ref = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+    x_ref, _, rc = O.zgesv(A_ref, rhs_ref + O.compute_rhs_with_beta(om.center, om.normal, k, beta), nthreads=8)
+    assert rc == 0 and rel_l2(X[1], x_ref) <= 1e-8
+    plan.close()
