@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int e = tid + 512 * s;
-      As[buf][e & 7][e >> 3] = ra[s];
+      As[buf][e & 7][(e >> 3) ^ (e & 7)] = ra[s];   // XOR swizzle: the 8 lanes of one row (k = 0..7, 1 KB apart) hit 8 different bank groups
       Bs[buf][e >> 7][e & 127] = rb[s];
     }
   };
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
       const int kk = ks * 4 + lk;
       dc af[2], bf[4];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = As[buf][kk][wm * 32 + a * 16 + li];
+      for (int a = 0; a < 2; ++a) af[a] = As[buf][kk][(wm * 32 + a * 16 + li) ^ kk];
 #pragma unroll
       for (int b = 0; b < 4; ++b) bf[b] = Bs[buf][kk][wn * 64 + b * 16 + li];
 #pragma unroll
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZG
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int e = tid + 256 * s;
-      As[buf][e & 7][e >> 3] = ra[s];
+      As[buf][e & 7][(e >> 3) ^ (e & 7)] = ra[s];   // XOR swizzle (see zgemm_sub_kernel): conflict-free transposed store
       Bs[buf][e >> 6][e & 63] = rb[s];
     }
   };
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZG
       dc af[2], bf[2];
       double as[2], bs[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) { af[a] = As[buf][kk][wm * 32 + a * 16 + li]; as[a] = af[a].re + af[a].im; }
+      for (int a = 0; a < 2; ++a) { af[a] = As[buf][kk][(wm * 32 + a * 16 + li) ^ kk]; as[a] = af[a].re + af[a].im; }
 #pragma unroll
       for (int b = 0; b < 2; ++b) { bf[b] = Bs[buf][kk][wn * 32 + b * 16 + li]; bs[b] = bf[b].re + bf[b].im; }
 #pragma unroll
