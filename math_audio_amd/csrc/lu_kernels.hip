@@ -882,11 +882,16 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
 // Apply panel (k0, nb)'s interchanges to the columns [x0, x1) U [y0, y1) of A and to the nrhs right-hand sides.
 // `tmp` holds 2 nb rows of `tstride` >= (x1-x0)+(y1-y0)+nrhs entries. With `invd`, blocks 1.. of the first launch
 // also invert the 32 x 32 diagonal blocks of the panel's L11 for lu_trsm_mfma_kernel.
-int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
-                    c64* invd, hipStream_t st) {
+// fold the panel's interchange sequence into its gather lists and invert the 32 x 32 diagonal blocks of L11
+int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, hipStream_t st) {
   hipLaunchKernelGGL(lu_perm_kernel, dim3(invd ? 1 + (nb + 31) / 32 : 1), dim3(64), 0, st, ipiv, n, k0, nb, lists,
                      reinterpret_cast<const dc*>(A + (size_t)k0 * n + k0), n, reinterpret_cast<dc*>(invd));
   MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// apply the lists of lu_launch_perm to the columns [x0, x1) U [y0, y1) and to the right-hand sides
+int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs, hipStream_t st) {
   const int ncol = (x1 - x0) + (y1 - y0) + nrhs;
   if (ncol <= 0) return MA_OK;
   MA_REQUIRE(ncol <= tstride, MA_ERR_INVALID, "interchange staging rows too short (%d > %d)", ncol, tstride);
@@ -899,6 +904,13 @@ int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, 
                      reinterpret_cast<dc*>(B), nrhs);
   MA_HIP(hipGetLastError());
   return MA_OK;
+}
+
+int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
+                    c64* invd, hipStream_t st) {
+  int rc = lu_launch_perm(A, n, k0, nb, ipiv, lists, invd, st);
+  if (rc) return rc;
+  return lu_launch_row_moves(A, n, nb, lists, tmp, tstride, x0, x1, y0, y1, B, nrhs, st);
 }
 
 int lu_trsm_configure() {

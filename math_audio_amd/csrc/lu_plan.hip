@@ -23,16 +23,15 @@ struct ma_lu_plan {
   int* d_lists[LU_BATCH_MAX] = {};
   int* d_ipiv[LU_BATCH_MAX] = {};
   c64* d_tmp[LU_BATCH_MAX] = {};
-  c64* d_invd[LU_BATCH_MAX] = {};  // inverted 32 x 32 diagonal blocks of L11 of each panel of the current block (4 x LU_NB_MAX x 32)
-  // the look-ahead lane's own copies (it works on block g+1 while the main lane works on block g)
-  int* d_lists_l[LU_BATCH_MAX] = {};
+  c64* d_invd[LU_BATCH_MAX] = {};  // inverted 32 x 32 diagonal blocks of L11, one slot per panel of a block; lists and these are written by the
+                                   // look-ahead lane (block g+1 -> slots of parity (g+1)&1) and read by the main lane (block g)
+  // the look-ahead lane's own interchange staging (it works on block g+1 while the main lane works on block g)
   c64* d_tmp_l[LU_BATCH_MAX] = {};
-  c64* d_invd_l[LU_BATCH_MAX] = {};
   int kb = 4;                     // panels per trailing update (MA_LU_KB=1..4): K = kb * nb = 256
   double gemm_flops = 0.0;        // algorithmic flops of the update launches of the last call
   double gemm_cbytes = 0.0;       // and their algorithmic C read + write bytes
   int last_batch = 1;
-  hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {};
+  hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {}, ev_mid[LU_BATCH_MAX] = {}, ev_big[LU_BATCH_MAX] = {};
   int ensure_batch(int nmat);
   int nrhs_max = 4;
   bool timing = false;
@@ -46,6 +45,8 @@ struct ma_lu_plan {
   hipStream_t panel_stream = nullptr;   // stream of the look-ahead lane (system 0)
   hipStream_t panel_streams[LU_BATCH_MAX] = {};   // [0] aliases panel_stream; one per system of a batch
   bool panel_overlap = true;      // MA_LU_PANEL_OVERLAP=0: all systems' panels on one stream (strictly serial)
+  hipStream_t mid_streams[LU_BATCH_MAX] = {};     // per system: the small per-panel work of the current block (MA_LU_MIDLANE=0: on the caller's stream)
+  int midlane = 1;                // 1: on the system's look-ahead stream, 2: on a third stream per system, 0: on the caller's stream
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
   int want_nb = 64;               // panel width (MA_LU_NB): 64 columns keep two systems' panels co-resident from the first column of a 10k system
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
@@ -82,10 +83,8 @@ int ma_lu_plan::ensure_batch(int nmat) {
     MA_HIP(hipMalloc(&d_tmp[m], sizeof(c64) * 2 * LU_NB_MAX * ((size_t)n + nrhs_max)));
     MA_HIP(hipMalloc(&d_ipiv[m], sizeof(int) * (size_t)n));
     MA_HIP(hipMemset(d_ipiv[m], 0, sizeof(int) * (size_t)n));
-    MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * LU_KB_MAX * LU_LISTS_LEN));
-    MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * LU_KB_MAX * LU_NB_MAX * 32));
-    MA_HIP(hipMalloc(&d_lists_l[m], sizeof(int) * LU_LISTS_LEN));
-    MA_HIP(hipMalloc(&d_invd_l[m], sizeof(c64) * LU_NB_MAX * 32));
+    MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * 2 * LU_KB_MAX * LU_LISTS_LEN));
+    MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * 2 * LU_KB_MAX * LU_NB_MAX * 32));
     MA_HIP(hipMalloc(&d_tmp_l[m], sizeof(c64) * 2 * LU_NB_MAX * LU_LANE_TSTRIDE));
   }
   return MA_OK;
@@ -144,6 +143,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (const char* e2 = getenv("MA_LU_LOOKAHEAD")) P->lookahead = atoi(e2) != 0;
   if (const char* e6 = getenv("MA_LU_KB")) { int v = atoi(e6); if (v >= 1 && v <= LU_KB_MAX) P->kb = v; }
   if (const char* e5 = getenv("MA_LU_PANEL_OVERLAP")) P->panel_overlap = atoi(e5) != 0;
+  if (const char* e7 = getenv("MA_LU_MIDLANE")) P->midlane = atoi(e7);
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
   if (!rc) {
     int lo = 0, hi = 0;
@@ -158,6 +158,9 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&P->ev_start, hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_panel[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_narrow[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipStreamCreateWithPriority(&P->mid_streams[i], hipStreamNonBlocking, hi);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_mid[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_big[i], hipEventDisableTiming);
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
   }
   if (rc) { ma_lu_plan_destroy(P); return rc; }
@@ -170,10 +173,11 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   (void)hipSetDevice(P->device);
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
-  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]);
+    if (P->ev_mid[i]) (void)hipEventDestroy(P->ev_mid[i]); if (P->ev_big[i]) (void)hipEventDestroy(P->ev_big[i]); if (P->mid_streams[i]) (void)hipStreamDestroy(P->mid_streams[i]); }
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
-    if (P->d_lists_l[i]) (void)hipFree(P->d_lists_l[i]); if (P->d_invd_l[i]) (void)hipFree(P->d_invd_l[i]); if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); }
+    if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
   return MA_OK;
@@ -276,10 +280,15 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp))) return rc;
       MA_MARK(t1, sp);
       interval(P, t0, t1, 0);
+      // the panel's gather lists and inverted diagonal blocks: once, here; the main lane reuses them
+      const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
+      int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
+      c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
+      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, sp))) return rc;
       if (a1 < e) {
-        if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[m], P->d_lists_l[m], P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, P->d_invd_l[m], sp))) return rc;
+        if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
         const c64* T = A + (size_t)k0 * n + k0;
-        if ((rc = lu_launch_trsm_mfma(T, n, nb, P->d_invd_l[m], A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
         MA_MARK(t2, sp);
         if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
         MA_MARK(t3, sp);
@@ -295,49 +304,58 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     for (int m = 0; m < nmat; ++m) if (m == 0 || sps[m] != sps[0]) MA_HIP(hipStreamWaitEvent(sps[m], P->ev_start, 0));
   }
   for (int m = 0; m < nmat; ++m) if ((rc = lane(m, 0))) return rc;
+  // With several systems in flight the per-panel work of the current block (interchanges, U12 = L11^-1 A12, the updates
+  // inside the block and of the next block's columns: short, latency-bound launches) runs on a stream of its own per
+  // system; the caller's stream carries only the big updates, back to back over the systems.
+  const bool split = la && nmat > 1 && P->panel_overlap && P->midlane;
+  hipStream_t sms[LU_BATCH_MAX];
+  for (int m = 0; m < LU_BATCH_MAX; ++m) sms[m] = split ? (P->midlane == 2 ? P->mid_streams[m] : sps[m]) : st;
+  if (split) for (int m = 0; m < nmat; ++m) MA_HIP(hipStreamWaitEvent(sms[m], P->ev_start, 0));
   for (int g = 0; g < G; ++g) {
     const int a0 = k0s[blk_first(g)], e = blk_end(g);
     const int nright = n - e;
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;      // block g+1 occupies columns [e, enext)
     for (int m = 0; m < nmat; ++m) {
       c64* A = As[m]; c64* B = Bs ? Bs[m] : nullptr;
-      if (la) MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
-      MA_MARK(t0, st);
+      hipStream_t sm = sms[m];
+      if (la) MA_HIP(hipStreamWaitEvent(sm, P->ev_panel[m], 0));
+      if (split && g > 0) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));     // block g-1's big update of this system
+      MA_MARK(t0, sm);
       for (int q = blk_first(g); q < blk_last(g); ++q)
-        if ((rc = lu_launch_swaps(A, n, k0s[q], nbs[q], P->d_ipiv[m], P->d_lists[m] + (q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs,
-                                  P->d_invd[m] + (size_t)(q - blk_first(g)) * LU_NB_MAX * 32, st))) return rc;
-      MA_MARK(t1, st);
+        if ((rc = lu_launch_row_moves(A, n, nbs[q], P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs, sm))) return rc;
+      MA_MARK(t1, sm);
       interval(P, t0, t1, 1);
       for (int q = blk_first(g); q < blk_last(g); ++q) {
         const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
         const c64* T = A + (size_t)k0 * n + k0;
-        const c64* invd = P->d_invd[m] + (size_t)(q - blk_first(g)) * LU_NB_MAX * 32;
-        MA_MARK(u0, st);
-        if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + e, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, st))) return rc;
-        MA_MARK(u1, st);
+        const c64* invd = P->d_invd[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_NB_MAX * 32;
+        MA_MARK(u0, sm);
+        if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + e, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, sm))) return rc;
+        MA_MARK(u1, sm);
         interval(P, u0, u1, 2);
         for (int r = 0; r < nrhs && a1 < n; ++r)
-          if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, st))) return rc;
-        MA_MARK(u2, st);
+          if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, sm))) return rc;
+        MA_MARK(u2, sm);
         interval(P, u1, u2, 4);
-        if (a1 < e && (rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, st))) return rc;
-        MA_MARK(u3, st);
-        interval(P, u2, u3, 3);
+        if (a1 < e && (rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, sm))) return rc;
+        MA_MARK(u3, sm);
+        interval(P, u2, u3, split ? 5 : 3);
       }
-      MA_MARK(t3, st);
-      if (nright > 0 && g + 1 < G) {
-        if (la) {
-          // narrow update of the next block's columns first, then factor them concurrently with the rest
-          if ((rc = gemm(nright, enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, st))) return rc;
-          MA_HIP(hipEventRecord(P->ev_narrow[m], st)); MA_HIP(hipStreamWaitEvent(sps[m], P->ev_narrow[m], 0));
-          if ((rc = lane(m, g + 1))) return rc;
-        }
+      MA_MARK(t3, sm);
+      const bool narrow = la && nright > 0 && g + 1 < G;
+      // narrow update of the next block's columns first, then factor them concurrently with the rest
+      if (narrow && (rc = gemm(nright, enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, sm))) return rc;
+      MA_MARK(t4, sm);
+      interval(P, t3, t4, split ? 5 : 3);
+      if (split) MA_HIP(hipEventRecord(P->ev_mid[m], sm));
+      if (narrow) {
+        if (sm != sps[m]) { MA_HIP(hipEventRecord(P->ev_narrow[m], sm)); MA_HIP(hipStreamWaitEvent(sps[m], P->ev_narrow[m], 0)); }
+        if ((rc = lane(m, g + 1))) return rc;
       }
-      MA_MARK(t4, st);
-      interval(P, t3, t4, 3);
     }
     for (int m = 0; m < nmat && nright > 0; ++m) {
       c64* A = As[m];
+      if (split) MA_HIP(hipStreamWaitEvent(st, P->ev_mid[m], 0));
       MA_MARK(t5, st);
       if (la) {
         if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, st))) return rc;
@@ -347,20 +365,30 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       }
       MA_MARK(t6, st);
       interval(P, t5, t6, 3);
+      if (split) MA_HIP(hipEventRecord(P->ev_big[m], st));
     }
   }
   // backward substitution U x = y, block rows from the bottom
   MA_MARK(t7, st);
   if (nrhs > 0) {
+    // a chain of 2 Q short launches per system: the systems of a batch run theirs side by side on their own streams
+    const bool side = la && nmat > 1 && P->panel_overlap;
+    if (side && !split) MA_HIP(hipEventRecord(P->ev_start, st));
     for (int m = 0; m < nmat; ++m) {
       c64* A = As[m]; c64* B = Bs[m];
+      hipStream_t sb = split ? sms[m] : (side ? sps[m] : st);
+      if (side && !split) MA_HIP(hipStreamWaitEvent(sb, P->ev_start, 0));
       for (int q = Q - 1; q >= 0; --q) {
         const int k0 = k0s[q], nb = nbs[q];
-        if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, st))) return rc;
+        if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, sb))) return rc;
         for (int r = 0; r < nrhs && k0 > 0; ++r)
-          if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, st))) return rc;
+          if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, sb))) return rc;
       }
+      if (side) { MA_HIP(hipEventRecord(P->ev_panel[m], sb)); }
     }
+    if (side) for (int m = 0; m < nmat; ++m) MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
+  } else if (split) {
+    for (int m = 0; m < nmat; ++m) { MA_HIP(hipEventRecord(P->ev_mid[m], sms[m])); MA_HIP(hipStreamWaitEvent(st, P->ev_mid[m], 0)); }
   }
   MA_MARK(e_end, st);
   interval(P, t7, e_end, 4);
@@ -438,7 +466,7 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipStreamSynchronize((hipStream_t)stream));
-  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i]));
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i])); if (P->mid_streams[i]) MA_HIP(hipStreamSynchronize(P->mid_streams[i])); }
   int info[16];
   MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
   MA_REQUIRE(info[LU_BATCH_MAX] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
@@ -452,7 +480,7 @@ int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
   MA_REQUIRE(P->ev_valid && P->ev_last >= 0, MA_ERR_INVALID, "no timed factorisation has run on this plan");
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipEventSynchronize(P->ev[P->ev_last]));
-  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i]));
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i])); if (P->mid_streams[i]) MA_HIP(hipStreamSynchronize(P->mid_streams[i])); }
   for (int i = 0; i < 8; ++i) out8[i] = 0.0;
   for (const auto& v : P->iv) {
     float ms = 0.f;
