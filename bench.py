@@ -154,6 +154,13 @@ def fem_workload(args):
         e0.record(); run(reps); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         res[name] = {"ms": ms, "GB/s": byts[name] / (ms * 1e-3) / 1e9, "frac_of_8TBs": byts[name] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # symmetric Gauss-Seidel (amg.rs:932-978; the FEM smoother's default family): one launch per dependency level, latency-bound
+    y.copy_(x); op.sym_gauss_seidel_dev(y.data_ptr(), b.data_ptr(), 1, st); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); op.sym_gauss_seidel_dev(y.data_ptr(), b.data_ptr(), 2, st); e1.record(); torch.cuda.synchronize()
+    lev = op.gauss_seidel_levels()
+    res["sym_gauss_seidel"] = {"ms": e0.elapsed_time(e1) / 2, "levels_forward_backward": list(lev),
+                               "GB/s": 2 * (nnz * 20.0 + n * 68.0) / (e0.elapsed_time(e1) / 2 * 1e-3) / 1e9}
     out = {"metric": "fem_csr_spmv_gbs", "value": res["spmv"]["GB/s"], "unit": "GB/s", "n_gpus": 1, "steps": args.steps * 10, "warmup": args.warmup,
            "ms_per_step": res["spmv"]["ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128 x, real K/M)",
            "data": "synthetic", "config": {"workload": "F1M-family box 5x4x2.5 m, %d^3 nodes, P1 Kuhn tets: N=%d, nnz=%d; A = K - k^2 M fused; k = 2 pi 100/343 + 0.01i" % (args.fem_n, n, nnz),

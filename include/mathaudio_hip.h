@@ -195,12 +195,22 @@ int ma_csr_spmv_dev(ma_csr_t* h, const void* d_x, void* d_y, void* stream);
 int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r, void* stream);
 int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
 int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
+/* AmgPreconditioner::smooth_sym_gauss_seidel(matrix, x, b, num_sweeps)   math-solvers/src/preconditioners/amg.rs:932-978:
+ * forward then backward Gauss-Seidel sweep over the rows, num_sweeps times (a row without a stored diagonal uses 1, rows
+ * with |a_ii| <= 1e-15 are left alone). The sweeps run level by level over the dependency levels of the sparsity pattern
+ * (built on first use), which reproduces the sequential sweep in index order; one launch per level.
+ * ma_csr_gauss_seidel_sweep_dev is one sweep: mode 0 = math-fem smoother.rs:71-117 (x_i = (b_i - sigma)/a_ii, rows with
+ * |a_ii| < 1e-15 skipped), mode 1 = the amg.rs form; backward = 0 ascending rows, 1 descending rows. */
+int ma_csr_sym_gauss_seidel(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps);
+int ma_csr_sym_gauss_seidel_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* stream);
+int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int mode, int backward, void* stream);
+int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward);   /* launches per sweep (diagnostic) */
 
 /* math-fem geometric-multigrid smoothers on the COO HelmholtzMatrix (math-fem/src/assembly/helmholtz.rs:22-33,
  * multigrid/smoother.rs:44-68, 120-160, 163-176). The triplets are summed once into a CSR operator (an ma_csr_t: all
  * ma_csr_* calls work on it); rows with |a_ii| < 1e-15 are skipped by the sweeps as in the reference.
- * kind: 0 Gauss-Seidel, 1 Jacobi, 2 symmetric GS -- only Jacobi runs on the device (the GS family is a sequential
- * recurrence: MA_ERR_UNSUPPORTED). */
+ * kind: 0 Gauss-Seidel (SmootherConfig's default, smoother.rs:31-39, 71-117), 1 Jacobi, 2 symmetric Gauss-Seidel (forward
+ * then backward sweep per iteration); the Gauss-Seidel sweeps are level-scheduled (see ma_csr_sym_gauss_seidel). */
 /* the transposed operator as a new handle (apply_transpose of CsrMatrix, csr.rs:420-440) */
 int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out);
 /* value epoch of a handle (bumped by set_wavenumber / assemble) and the cheap re-sync of a transposed copy after the
@@ -240,11 +250,12 @@ int ma_op_apply_transpose_dev(ma_op_t* op, const void* d_x, void* d_y, void* str
 int ma_op_apply_hermitian_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
 /* Preconditioner boundary: trait Preconditioner<T> { apply(&r) -> z }   math-solvers/src/traits.rs:370-375.
  * The device preconditioners are the AMG smoothers applied from z = 0 (one level of
- * AmgPreconditioner::apply, amg.rs:981-1005, 1068-1087): Jacobi(omega, sweeps) or l1-Jacobi(sweeps) on the CSR
- * handle's current values (after ma_csr_set_wavenumber). The CSR handle is borrowed. */
+ * AmgPreconditioner::apply, amg.rs:981-1005, 1068-1087): Jacobi(omega, sweeps), l1-Jacobi(sweeps) or symmetric
+ * Gauss-Seidel(sweeps) on the CSR handle's current values (after ma_csr_set_wavenumber). The CSR handle is borrowed. */
 typedef struct ma_precond ma_precond_t;
 int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out);
 int ma_precond_create_l1jacobi(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
+int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
 int ma_precond_destroy(ma_precond_t* M);
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
 int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */

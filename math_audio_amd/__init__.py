@@ -102,6 +102,10 @@ def lib():
             "ma_csr_residual_dev": [vp, vp, vp, vp, vp],
             "ma_csr_jacobi_dev": [vp, vp, vp, dbl, C.c_int, vp, vp],
             "ma_csr_l1jacobi_dev": [vp, vp, vp, C.c_int, vp, vp],
+            "ma_csr_sym_gauss_seidel": [vp, vp, vp, C.c_int],
+            "ma_csr_sym_gauss_seidel_dev": [vp, vp, vp, C.c_int, vp],
+            "ma_csr_gauss_seidel_sweep_dev": [vp, vp, vp, C.c_int, C.c_int, vp],
+            "ma_csr_gauss_seidel_levels": [vp, P(C.c_int64), P(C.c_int64)],
             "ma_fem_matrix_create": [i64, i64, vp, vp, vp, C.c_int, P(vp)],
             "ma_fem_smooth": [vp, vp, vp, C.c_int, C.c_int, dbl],
             "ma_fem_residual": [vp, vp, vp, vp],
@@ -121,6 +125,7 @@ def lib():
             "ma_gmres": [vp, vp, vp, i32, i32, dbl, vp, vp],
             "ma_precond_create_jacobi": [vp, dbl, i32, P(vp)],
             "ma_precond_create_l1jacobi": [vp, i32, P(vp)],
+            "ma_precond_create_sym_gauss_seidel": [vp, i32, P(vp)],
             "ma_precond_destroy": [vp],
             "ma_precond_apply_dev": [vp, vp, vp, vp],
             "ma_precond_apply": [vp, vp, vp],
@@ -368,8 +373,8 @@ class CsrOperator:
         check(lib().ma_fem_matrix_create(self.n, len(rows), _vp(rows), _vp(cols), _vp(values), device, C.byref(self.h)))
         return self
 
-    def fem_smooth(self, x, b, kind=1, iterations=2, omega=2.0 / 3.0):
-        """smooth() of math-fem/src/multigrid/smoother.rs:44-68 (Jacobi on the device)."""
+    def fem_smooth(self, x, b, kind=0, iterations=2, omega=2.0 / 3.0):
+        """smooth() of math-fem/src/multigrid/smoother.rs:44-68: kind 0 Gauss-Seidel (default), 1 Jacobi, 2 symmetric GS."""
         x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
         check(lib().ma_fem_smooth(self.h, _vp(x), _vp(b), int(kind), int(iterations), float(omega)))
         return x
@@ -427,6 +432,20 @@ class CsrOperator:
         x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
         check(lib().ma_csr_l1jacobi(self.h, _vp(x), _vp(b), int(sweeps)))
         return x
+
+    def sym_gauss_seidel(self, x, b, sweeps):
+        """smooth_sym_gauss_seidel (amg.rs:932-978), level-scheduled on the device."""
+        x = np.array(x, dtype=np.complex128); b = np.ascontiguousarray(b, dtype=np.complex128)
+        check(lib().ma_csr_sym_gauss_seidel(self.h, _vp(x), _vp(b), int(sweeps)))
+        return x
+
+    def gauss_seidel_levels(self):
+        f = C.c_int64(); bk = C.c_int64()
+        check(lib().ma_csr_gauss_seidel_levels(self.h, C.byref(f), C.byref(bk)))
+        return f.value, bk.value
+
+    def sym_gauss_seidel_dev(self, d_x, d_b, sweeps, stream=0):
+        check(lib().ma_csr_sym_gauss_seidel_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_b), int(sweeps), C.c_void_p(stream)))
 
     def spmv_dev(self, d_x, d_y, stream=0):
         check(lib().ma_csr_spmv_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream)))
@@ -523,13 +542,15 @@ def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
 
 
 class Preconditioner:
-    """ma_precond_t: the Preconditioner<Complex64> boundary (traits.rs:370-375); Jacobi / l1-Jacobi sweeps from zero."""
+    """ma_precond_t: the Preconditioner<Complex64> boundary (traits.rs:370-375); Jacobi / l1-Jacobi / symmetric GS sweeps from zero."""
 
     def __init__(self, csr_operator, kind="jacobi", omega=2.0 / 3.0, sweeps=2):
         self.h = C.c_void_p()
         self._keep = csr_operator
         if kind == "jacobi":
             check(lib().ma_precond_create_jacobi(csr_operator.h, float(omega), int(sweeps), C.byref(self.h)))
+        elif kind in ("sgs", "sym_gauss_seidel"):
+            check(lib().ma_precond_create_sym_gauss_seidel(csr_operator.h, int(sweeps), C.byref(self.h)))
         else:
             check(lib().ma_precond_create_l1jacobi(csr_operator.h, int(sweeps), C.byref(self.h)))
 

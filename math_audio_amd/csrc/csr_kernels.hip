@@ -207,4 +207,56 @@ int csr_launch_diag(const CsrView& A, bool km, c64* dinv, double* l1, hipStream_
   return MA_OK;
 }
 
+// One Gauss-Seidel step for the rows of one dependency level. Level scheduling (csr_plan.hip: build_levels): a row's
+// level is one more than the highest level among the earlier rows it shares an entry with (in either direction), so the
+// rows of a level neither read nor write each other and everything a row reads from earlier rows is final: the sweep
+// equals the reference's sequential loop over the rows in index order. 16 lanes per row (the launches are latency-bound:
+// two dependent loads per entry); the row's products are summed by a lane tree, i.e. in a different association than the
+// reference's running sum (rounding-level difference only).
+// MODE 0 (smoother.rs:71-117): sigma = sum_{j != i} a_ij x_j, x_i = (b_i - sigma) / a_ii, rows with |a_ii| < 1e-15 skipped
+// MODE 1 (amg.rs:932-978):     x_i = (b_i - sum_{j != i} a_ij x_j) * a_ii.inv(), a_ii = 1 when the row stores none,
+//                              rows with |a_ii| <= 1e-15 skipped
+template <bool KM, int MODE>
+__global__ __launch_bounds__(256) void csr_gs_level_kernel(CsrView A, const int* __restrict__ rows, int count, dc* x, const dc* __restrict__ b) {
+  constexpr int G = 16;
+  const int t = (blockIdx.x * 256 + threadIdx.x) / G, lg = threadIdx.x & (G - 1);
+  if (t >= count) return;                               // whole groups leave together
+  const int i = rows[t];
+  const long long beg = A.row_ptr[i], end = A.row_ptr[i + 1];
+  double sr = 0.0, si = 0.0, dr = 0.0, di = 0.0, have = 0.0;
+  for (long long idx = beg + lg; idx < end; idx += G) {
+    double ar, ai;
+    if (KM) { const double kv = A.K[idx], mv = A.M[idx]; ar = kv - A.k2_re * mv; ai = -(A.k2_im * mv); }
+    else { const dc v = A.val[idx]; ar = v.re; ai = v.im; }
+    const int j = A.col[idx];
+    if (j == i) { dr += ar; di += ai; have = 1.0; }       // one stored diagonal per row on this path (duplicates are pre-summed)
+    else { const dc xv = x[j]; sr += ar * xv.re - ai * xv.im; si += ar * xv.im + ai * xv.re; }
+  }
+  sr = group_sum<G>(sr); si = group_sum<G>(si); dr = group_sum<G>(dr); di = group_sum<G>(di); have = group_sum<G>(have);
+  if (lg != 0) return;
+  if (MODE == 1 && have == 0.0) { dr = 1.0; di = 0.0; }
+  const double nd = hypot(dr, di);
+  if (MODE == 1 ? !(nd > 1e-15) : (nd < 1e-15)) return;
+  const dc bb = b[i];
+  const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
+  if (MODE == 1) {          // sum * diag.inv(): inv = conj / norm_sqr
+    const double ir = dr / ns, ii = -di / ns;
+    x[i] = dc_make(nr * ir - ni * ii, nr * ii + ni * ir);
+  } else {                  // (b - sigma) / diag
+    x[i] = dc_make((nr * dr + ni * di) / ns, (ni * dr - nr * di) / ns);
+  }
+}
+
+int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, int count, c64* x, const c64* b, hipStream_t st) {
+  if (count <= 0) return MA_OK;
+  dim3 grid((unsigned)(((long long)count * 16 + 255) / 256)), block(256);
+  dc* xx = reinterpret_cast<dc*>(x); const dc* bb = reinterpret_cast<const dc*>(b);
+  if (km) { if (mode) hipLaunchKernelGGL((csr_gs_level_kernel<true, 1>), grid, block, 0, st, A, rows, count, xx, bb);
+            else hipLaunchKernelGGL((csr_gs_level_kernel<true, 0>), grid, block, 0, st, A, rows, count, xx, bb); }
+  else { if (mode) hipLaunchKernelGGL((csr_gs_level_kernel<false, 1>), grid, block, 0, st, A, rows, count, xx, bb);
+         else hipLaunchKernelGGL((csr_gs_level_kernel<false, 0>), grid, block, 0, st, A, rows, count, xx, bb); }
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 }  // namespace ma

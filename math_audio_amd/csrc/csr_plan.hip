@@ -29,6 +29,9 @@ struct ma_csr {
   std::vector<int> btags; std::vector<double*> d_B;
   bool materialised = false;
   unsigned long long epoch = 0;   // bumped whenever the operator's values change (set_wavenumber / assemble)
+  // Gauss-Seidel level schedules (pattern only, built on first use): [0] forward sweep, [1] backward sweep
+  int* d_lev_rows[2] = {nullptr, nullptr};
+  std::vector<long long> lev_ptr[2];
   CsrView view() const {
     CsrView v{};
     v.n = n; v.nnz = nnz; v.row_ptr = d_rowptr; v.col = d_col; v.val = reinterpret_cast<const dc*>(d_val); v.K = d_K; v.M = d_M;
@@ -53,6 +56,7 @@ void free_all(ma_csr* h) {
   void* p[] = {h->d_rowptr, h->d_col, h->d_val, h->d_K, h->d_M, h->d_dinv, h->d_l1, h->d_x, h->d_y, h->d_b,
                h->d_sell_ptr, h->d_sell_col, h->d_sell_val, h->d_sell_K, h->d_sell_M, h->d_sell_src};
   for (double* b : h->d_B) if (b) (void)hipFree(b);
+  for (int* r : h->d_lev_rows) if (r) (void)hipFree(r);
   for (void* q : p) if (q) (void)hipFree(q);
 }
 int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out) {
@@ -393,13 +397,112 @@ int ma_fem_matrix_create(int64_t n, int64_t nnz, const int64_t* rows, const int6
   return MA_OK;
 }
 
-// smooth(matrix, x, b, config) (smoother.rs:44-68). kind 1 = Jacobi: x <- omega (b - sigma)/a_ii + (1 - omega) x, `iterations`
-// times. kind 0 (Gauss-Seidel, the reference's default) and 2 (symmetric GS) are sequential recurrences over the rows
-// in index order: they are not offered on the device (MA_ERR_UNSUPPORTED), use Jacobi or keep the CPU path.
+// ---- Gauss-Seidel by level scheduling
+// level_fwd(i) = 1 + max{ level_fwd(j) : j < i, a_ij or a_ji stored }; the backward schedule mirrors it from the last row.
+// Rows of one level are independent, and ascending levels reproduce the sequential sweep exactly.
+static int build_levels(ma_csr* h) {
+  if (h->d_lev_rows[0]) return MA_OK;
+  const long long n = h->n, nnz = h->nnz;
+  std::vector<long long> rp((size_t)n + 1); std::vector<int> col((size_t)std::max<long long>(nnz, 1));
+  MA_HIP(hipMemcpy(rp.data(), h->d_rowptr, sizeof(long long) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+  if (nnz > 0) MA_HIP(hipMemcpy(col.data(), h->d_col, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+  for (int dir = 0; dir < 2; ++dir) {
+    std::vector<int> lvl((size_t)n, 0), pend((size_t)n, 0);
+    int nlev = 0;
+    for (long long ii = 0; ii < n; ++ii) {
+      const long long i = dir == 0 ? ii : n - 1 - ii;
+      int m = pend[(size_t)i];
+      for (long long idx = rp[(size_t)i]; idx < rp[(size_t)i + 1]; ++idx) {
+        const long long j = col[(size_t)idx];
+        if (j < 0 || j >= n || j == i) continue;
+        const bool earlier = dir == 0 ? j < i : j > i;
+        if (earlier) m = std::max(m, lvl[(size_t)j]);
+      }
+      const int L = m + 1;
+      lvl[(size_t)i] = L; nlev = std::max(nlev, L);
+      for (long long idx = rp[(size_t)i]; idx < rp[(size_t)i + 1]; ++idx) {
+        const long long j = col[(size_t)idx];
+        if (j < 0 || j >= n || j == i) continue;
+        const bool later = dir == 0 ? j > i : j < i;
+        if (later) pend[(size_t)j] = std::max(pend[(size_t)j], L);
+      }
+    }
+    std::vector<long long>& lp = h->lev_ptr[dir];
+    lp.assign((size_t)nlev + 1, 0);
+    for (long long i = 0; i < n; ++i) lp[(size_t)lvl[(size_t)i]]++;           // level L counted at slot L (levels are 1-based)
+    for (int L = 1; L <= nlev; ++L) lp[(size_t)L] += lp[(size_t)L - 1];        // lp[L] = one past the last row of level L
+    std::vector<long long> cur(lp.begin(), lp.end() - 1);                    // cur[L-1] = first slot of level L
+    std::vector<int> rows((size_t)n);
+    for (long long ii = 0; ii < n; ++ii) {                                    // sweep order inside a level, for locality
+      const long long i = dir == 0 ? ii : n - 1 - ii;
+      rows[(size_t)cur[(size_t)lvl[(size_t)i] - 1]++] = (int)i;
+    }
+    MA_HIP(hipMalloc(&h->d_lev_rows[dir], sizeof(int) * (size_t)n));
+    MA_HIP(hipMemcpy(h->d_lev_rows[dir], rows.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  }
+  return MA_OK;
+}
+
+// one sweep over all rows in index order (backward = 0) or reverse order (1); mode 0 = smoother.rs:71-117, 1 = amg.rs:932-978
+int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int mode, int backward, void* stream) {
+  MA_REQUIRE(h && d_x && d_b && (mode == 0 || mode == 1), MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = build_levels(h);
+  if (rc) return rc;
+  const int dir = backward ? 1 : 0;
+  const std::vector<long long>& lp = h->lev_ptr[dir];
+  const CsrView v = h->view();
+  for (size_t L = 0; L + 1 < lp.size() && !rc; ++L)
+    rc = csr_launch_gs_level(v, h->fused_km(), mode, h->d_lev_rows[dir] + lp[L], (int)(lp[L + 1] - lp[L]), (c64*)d_x, (const c64*)d_b, (hipStream_t)stream);
+  return rc;
+}
+
+// smooth_sym_gauss_seidel(matrix, x, b, num_sweeps) (amg.rs:932-978): forward then backward sweep, num_sweeps times
+int ma_csr_sym_gauss_seidel_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* stream) {
+  MA_REQUIRE(sweeps >= 0, MA_ERR_INVALID, "negative sweep count");
+  int rc = MA_OK;
+  for (int s = 0; s < sweeps && !rc; ++s) {
+    rc = ma_csr_gauss_seidel_sweep_dev(h, d_x, d_b, 1, 0, stream);
+    if (!rc) rc = ma_csr_gauss_seidel_sweep_dev(h, d_x, d_b, 1, 1, stream);
+  }
+  return rc;
+}
+int ma_csr_sym_gauss_seidel(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps) {
+  MA_REQUIRE(h && x_inout && b, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = up(h, h->d_x, x_inout);
+  if (!rc) rc = up(h, h->d_b, b);
+  if (!rc) rc = ma_csr_sym_gauss_seidel_dev(h, h->d_x, h->d_b, sweeps, nullptr);
+  if (!rc) rc = down(h, x_inout, h->d_x);
+  return rc;
+}
+// number of dependency levels of the forward / backward Gauss-Seidel schedule (diagnostics: launches per sweep)
+int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward) {
+  MA_REQUIRE(h, MA_ERR_INVALID, "NULL handle");
+  MA_HIP(hipSetDevice(h->device));
+  int rc = build_levels(h);
+  if (rc) return rc;
+  if (forward) *forward = (int64_t)h->lev_ptr[0].size() - 1;
+  if (backward) *backward = (int64_t)h->lev_ptr[1].size() - 1;
+  return MA_OK;
+}
+
+// smooth(matrix, x, b, config) (smoother.rs:44-68). kind 0 = Gauss-Seidel (the reference's default): `iterations` forward
+// sweeps; kind 1 = Jacobi: x <- omega (b - sigma)/a_ii + (1 - omega) x; kind 2 = symmetric Gauss-Seidel: forward then
+// backward sweep per iteration. The Gauss-Seidel sweeps run level by level (see build_levels) and equal the sequential ones.
 int ma_fem_smooth(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int kind, int iterations, double omega) {
   MA_REQUIRE(h && x_inout && b, MA_ERR_INVALID, "NULL argument");
-  MA_REQUIRE(kind == 1, MA_ERR_UNSUPPORTED, "smoother kind %d (Gauss-Seidel family) is a sequential sweep; the device offers Jacobi (kind 1)", kind);
-  return ma_csr_jacobi(h, x_inout, b, omega, iterations);
+  MA_REQUIRE(kind >= 0 && kind <= 2 && iterations >= 0, MA_ERR_INVALID, "smoother kind %d / %d iterations", kind, iterations);
+  if (kind == 1) return ma_csr_jacobi(h, x_inout, b, omega, iterations);
+  MA_HIP(hipSetDevice(h->device));
+  int rc = up(h, h->d_x, x_inout);
+  if (!rc) rc = up(h, h->d_b, b);
+  for (int it = 0; it < iterations && !rc; ++it) {
+    rc = ma_csr_gauss_seidel_sweep_dev(h, h->d_x, h->d_b, 0, 0, nullptr);
+    if (!rc && kind == 2) rc = ma_csr_gauss_seidel_sweep_dev(h, h->d_x, h->d_b, 0, 1, nullptr);
+  }
+  if (!rc) rc = down(h, x_inout, h->d_x);
+  return rc;
 }
 
 // compute_residual (smoother.rs:163-176): r = b - A x

@@ -219,6 +219,7 @@ struct ma_precond {
 
 extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
 extern "C" int ma_csr_l1jacobi_dev(ma_csr* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
+extern "C" int ma_csr_sym_gauss_seidel_dev(ma_csr* h, void* d_x, const void* d_b, int sweeps, void* stream);
 
 int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
@@ -236,6 +237,11 @@ int ma_precond_create_l1jacobi(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out
   if (!rc) (*out)->kind = 2;
   return rc;
 }
+int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out) {
+  int rc = ma_precond_create_jacobi(csr, 1.0, sweeps, out);
+  if (!rc) (*out)->kind = 3;
+  return rc;
+}
 int ma_precond_destroy(ma_precond_t* M) {
   if (!M) return MA_OK;
   if (M->d_tmp) (void)hipFree(M->d_tmp);
@@ -247,6 +253,7 @@ int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stre
   if (M->kind == 0) { MA_HIP(hipMemcpyAsync(d_z, d_r, sizeof(c64) * (size_t)M->n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return MA_OK; }
   MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
   if (M->kind == 1) return ma_csr_jacobi_dev(M->csr, d_z, d_r, M->omega, M->sweeps, M->d_tmp, stream);
+  if (M->kind == 3) return ma_csr_sym_gauss_seidel_dev(M->csr, d_z, d_r, M->sweeps, stream);
   return ma_csr_l1jacobi_dev(M->csr, d_z, d_r, M->sweeps, M->d_tmp, stream);
 }
 

@@ -130,10 +130,82 @@ def test_fem_coo_smoother_matches_oracle(gpu):
         x_dev = A.fem_smooth(x, b, kind=1, iterations=its, omega=omega)
         assert np.abs(x_dev - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
         assert x_dev[7] == x[7]                           # zero diagonal: skipped
-    with pytest.raises(ma.MaError) as ei:                 # Gauss-Seidel is a sequential sweep: refused, never emulated
-        A.fem_smooth(x, b, kind=0)
-    assert ei.value.status == ma.MA_ERR_UNSUPPORTED
+    # Gauss-Seidel (the reference's default smoother, smoother.rs:31-39, 71-117) and its symmetric form: level-scheduled
+    # sweeps on the device equal the sequential sweep of the restatement (duplicates are pre-summed: rounding only)
+    for kind, its in ((0, 2), (0, 5), (2, 2)):
+        x_ref = O.fem_smooth(n, rows, cols, vals, x, b, kind=kind, iterations=its)
+        x_dev = A.fem_smooth(x, b, kind=kind, iterations=its)
+        assert np.abs(x_dev - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+        assert x_dev[7] == x[7]                           # zero diagonal: skipped (smoother.rs:100-102)
+    with pytest.raises(ma.MaError) as ei:
+        A.fem_smooth(x, b, kind=3)
+    assert ei.value.status == ma.MA_ERR_INVALID
     A.close()
+
+
+def test_sym_gauss_seidel_matches_oracle(gpu):
+    """smooth_sym_gauss_seidel (amg.rs:932-978): forward + backward sweeps by dependency levels == the sequential sweeps.
+    Cases: FEM operator in fused K - k^2 M form and with stored complex values; an unsymmetric pattern (a_ij stored without
+    a_ji: the levels must still order the two rows) with a row that stores no diagonal (uses 1) and a zero diagonal (skipped)."""
+    _, rp, col, K, M = fem.helmholtz_box(9, 8, 7)
+    n = len(rp) - 1
+    k = 2.0 + 0.05j
+    vals = O.helmholtz_values(K, M, k)
+    x = _x0(n); b = np.sin(0.2 * np.arange(n)) + 1j * np.cos(0.1 * np.arange(n))
+    for mode in ("km", "values"):
+        A = ma.CsrOperator(rp, col, K=K, M=M) if mode == "km" else ma.CsrOperator(rp, col, values=vals)
+        if mode == "km":
+            A.set_wavenumber(k)
+        for sweeps in (1, 3):
+            x_ref = O.amg_sym_gauss_seidel(rp, col, vals, x, b, sweeps)
+            x_dev = A.sym_gauss_seidel(x, b, sweeps)
+            assert np.abs(x_dev - x_ref).max() <= 1e-12 * np.abs(x_ref).max(), (mode, sweeps)
+        nf, nb = A.gauss_seidel_levels()
+        assert 1 < nf < n and 1 < nb < n
+        A.close()
+    rng = np.random.default_rng(5)
+    n = 300
+    rows = []
+    for i in range(n):
+        c = set(int(j) for j in rng.choice(n, size=6, replace=False)) - {i}
+        if i == 11 or i != 20:
+            c.add(i)                    # row 20 stores no diagonal at all (amg.rs:944 uses 1)
+        rows.append(sorted(c))
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    col = np.concatenate(rows).astype(np.int64)
+    vals = 0.2 * (rng.standard_normal(len(col)) + 1j * rng.standard_normal(len(col)))
+    for i in range(n):
+        for idx in range(rp[i], rp[i + 1]):
+            if col[idx] == i:
+                vals[idx] = 0.0 if i == 11 else 4.0 + 0.5j   # row 11: stored zero diagonal, left alone (amg.rs:952)
+    x = _x0(n); b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    A = ma.CsrOperator(rp, col, values=vals)
+    x_ref = O.amg_sym_gauss_seidel(rp, col, vals, x, b, 2)
+    x_dev = A.sym_gauss_seidel(x, b, 2)
+    assert np.abs(x_dev - x_ref).max() <= 1e-12 * np.abs(x_ref).max()
+    assert x_dev[11] == x[11]
+    # as a preconditioner: z = M^-1 r from z = 0
+    Mp = ma.Preconditioner(A, kind="sgs", sweeps=2)
+    z_ref = O.amg_sym_gauss_seidel(rp, col, vals, np.zeros(n, dtype=complex), b, 2)
+    assert np.abs(Mp.apply(b) - z_ref).max() <= 1e-12 * np.abs(z_ref).max()
+    Mp.close()
+    A.close()
+
+
+def test_gauss_seidel_level_counts(gpu):
+    """A tridiagonal operator is one long dependency chain (n levels); a diagonal one has a single level."""
+    n = 50
+    rp = [0]; col = []
+    for i in range(n):
+        col += [j for j in (i - 1, i, i + 1) if 0 <= j < n]; rp.append(len(col))
+    A = ma.CsrOperator(rp, col, values=np.ones(len(col)))
+    assert A.gauss_seidel_levels() == (n, n)
+    A.close()
+    D = ma.CsrOperator(list(range(n + 1)), list(range(n)), values=np.full(n, 2.0))
+    assert D.gauss_seidel_levels() == (1, 1)
+    x = D.sym_gauss_seidel(np.zeros(n), np.arange(n) + 1j, 1)
+    assert np.abs(x - (np.arange(n) + 1j) / 2.0).max() < 1e-15
+    D.close()
 
 
 @pytest.mark.parametrize("layout", ["sell", "csr"])
