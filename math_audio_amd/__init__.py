@@ -277,14 +277,16 @@ class BemPlan:
         return out
 
 
-def zgesv(A, b):
-    """Host-buffer drop-in of lu_solve (lu.rs:142): returns x; raises MaError(MA_ERR_SINGULAR / MA_ERR_DIM)."""
+def zgesv(A, b, return_pivots=False):
+    """Host-buffer drop-in of lu_solve (lu.rs:142): returns x; raises MaError(MA_ERR_SINGULAR / MA_ERR_DIM).
+    return_pivots: also the 0-based row interchanges (LAPACK ipiv - 1)."""
     A = np.array(A, dtype=np.complex128, order="C")
     x = np.array(b, dtype=np.complex128)
     if A.ndim != 2 or A.shape[0] != A.shape[1] or x.shape != (A.shape[0],):
         raise MaError(MA_ERR_DIM, "A must be n x n and b of length n")
-    check(lib().ma_zgesv(A.shape[0], _vp(A), _vp(x), None))
-    return x
+    piv = np.zeros(A.shape[0], dtype=np.int32)
+    check(lib().ma_zgesv(A.shape[0], _vp(A), _vp(x), _vp(piv) if return_pivots else None))
+    return (x, piv) if return_pivots else x
 
 
 class LuPlan:

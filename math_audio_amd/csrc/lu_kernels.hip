@@ -44,13 +44,13 @@ __device__ __forceinline__ dc crecip(dc z) {
 __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) { return v > bv || (v == bv && r < br); }
 
 // ------------------------------------------------------------------ panel factorisation
-// Dynamic LDS: P[rpb][nb+1] | urow[nb] | drow[nb] | small scalars.
+// Dynamic LDS: P[rpb][nb+1] | urow[2][nb] | drow[nb] | small scalars.
 // Per column c every workgroup publishes its best pivot candidate (value, row, the row's nb panel
 // entries) and, if it owns it, the current diagonal row; every workgroup sweeps the tagged
 // candidate granules until all are present, reduces them to the same pivot and fetches its row. The candidate of
-// column c+1 is published BEFORE the bulk of step c's rank-1 update (only column c+1 and the two
-// rows that are about to be published are brought up to date first), so the chip-wide wait
-// overlaps the local update.
+// column c+1 is published BEFORE the bulk of step c's rank-1 update: only column c+1 is brought up to date first, the
+// rows go out as they stand and the receivers finish step c's update on the one row they fetch. The chip-wide wait
+// therefore overlaps the local update, and nothing but the scan of column c+1 sits between a pivot and the next publish.
 struct PanelCand { double v; int row; };
 
 __device__ __forceinline__ PanelCand wave_best(PanelCand c) {
@@ -62,13 +62,26 @@ __device__ __forceinline__ PanelCand wave_best(PanelCand c) {
   return c;
 }
 
+// maximum of an unsigned value over the wavefront (DPP shifts inside the rows of 16 lanes, then the two row broadcasts);
+// lanes that receive nothing contribute 0
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8 -> lane 15 of a row holds the row's maximum
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, int n, int k0, int nb, int rpb, LuPanelWs ws,
                                                           int* __restrict__ ipiv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int pitch = nb + 1;
   dc* P = reinterpret_cast<dc*>(smem);
-  dc* urow = P + (size_t)rpb * pitch;
-  dc* drow = urow + nb;
+  dc* urow_a = P + (size_t)rpb * pitch;                  // pivot rows of the current and the previous column (ping-pong)
+  dc* urow_b = urow_a + nb;
+  dc* drow = urow_b + nb;
   double* s_wv = reinterpret_cast<double*>(drow + nb);   // [4] wave maxima
   int* s_wr = reinterpret_cast<int*>(s_wv + 4);          // [4] rows
   int* s_misc = s_wr + 4;                                // [0] best row, [3] fail
@@ -151,6 +164,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
 #define MA_STAMP(i) do { } while (0)
 #endif
 
+  bool pending = false;                                  // the previous column's rank-1 update is missing from the published rows
   for (int c = 0; c < nb; ++c) {
     const int gc = k0 + c;
     const int buf = c & 1;
@@ -197,25 +211,40 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     if (s_misc[3]) return;                               // uniform: the whole workgroup leaves
     const int p = s_misc[1], wb = s_misc[2];
     MA_STAMP(1);
-    // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads
+    // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads. Rows are published as they stood BEFORE
+    // the bulk of the previous column's rank-1 update (publish() below), so the receiver finishes that update itself:
+    // row[j] -= row[c-1] * u_{c-1}[j] for j > c, with the previous pivot row still in LDS. Every workgroup does the
+    // same arithmetic on the same data, so all hold the same pivot row.
+    dc* urow = (c & 1) ? urow_b : urow_a;
+    const dc* uprev = (c & 1) ? urow_a : urow_b;
     {
       // wb < 0 (no candidate anywhere): the diagonal row stands in as the pivot row
       const u64* src = wb >= 0 ? ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX) : ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      double* dst = reinterpret_cast<double*>(urow);
-      for (int t = tid; t < 2 * nb; t += 256) dst[t] = ld_sc1(src + t);
-      if (p != gc) {
-        const u64* s2 = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-        double* d2 = reinterpret_cast<double*>(drow);
-        for (int t = tid; t < 2 * nb; t += 256) d2[t] = ld_sc1(s2 + t);
+      const u64* s2 = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+      for (int j = tid; j < nb; j += 256) {
+        dc v = dc_make(ld_sc1(src + 2 * j), ld_sc1(src + 2 * j + 1));
+        dc d = dc_make(0.0, 0.0);
+        if (p != gc) d = dc_make(ld_sc1(s2 + 2 * j), ld_sc1(s2 + 2 * j + 1));
+        if (pending && j > c) {
+          const dc u = uprev[j];
+          const dc lv = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
+          v.re -= lv.re * u.re - lv.im * u.im; v.im -= lv.re * u.im + lv.im * u.re;
+          if (p != gc) {
+            const dc ld = dc_make(ld_sc1(s2 + 2 * (c - 1)), ld_sc1(s2 + 2 * (c - 1) + 1));
+            d.re -= ld.re * u.re - ld.im * u.im; d.im -= ld.re * u.im + ld.im * u.re;
+          }
+        }
+        urow[j] = v;
+        if (p != gc) drow[j] = d;
       }
     }
     __syncthreads();
     MA_STAMP(2);
     // ---- interchange inside the panel
-    if (p != gc) {
-      if (p >= r0 && p < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(p - r0) * pitch + t] = drow[t];
-      if (gc >= r0 && gc < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(gc - r0) * pitch + t] = urow[t];
-    }
+    if (p != gc && p >= r0 && p < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(p - r0) * pitch + t] = drow[t];
+    // the diagonal slot always takes the pivot row as every workgroup holds it (also when p == gc: the owner's own copy went
+    // through the bulk update, the shared one through the receivers' completion above -- keep the one that was used)
+    if (gc >= r0 && gc < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(gc - r0) * pitch + t] = urow[t];
     if (b == 0 && tid == 0) ipiv[gc] = p;
     const dc piv = urow[c];
     const bool singular = (piv.re == 0.0 && piv.im == 0.0);
@@ -223,37 +252,39 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     __syncthreads();
     // ---- multipliers l = a / pivot (reciprocal scaling, zgetf2) and the update of column c+1 only
     const bool more = c + 1 < nb;
-    if (!singular && tid < nrows && myrow > gc) {
-      const dc l = P[tid * pitch + c] * crecip(piv);
-      P[tid * pitch + c] = l;
-      if (more) {
-        dc a = P[tid * pitch + c + 1]; const dc u = urow[c + 1];
-        a.re -= l.re * u.re - l.im * u.im; a.im -= l.re * u.im + l.im * u.re;
-        P[tid * pitch + c + 1] = a;
+    dc anext = dc_make(0.0, 0.0);                        // this thread's row, column c+1, after the update
+    if (tid < nrows && myrow > gc) {
+      if (more) anext = P[tid * pitch + c + 1];
+      if (!singular) {
+        const dc l = P[tid * pitch + c] * crecip(piv);
+        P[tid * pitch + c] = l;
+        if (more) {
+          const dc u = urow[c + 1];
+          anext.re -= l.re * u.re - l.im * u.im; anext.im -= l.re * u.im + l.im * u.re;
+          P[tid * pitch + c + 1] = anext;
+        }
       }
     }
     MA_STAMP(3);
-    int br = INT_MAX;
     if (more) {
-      scan_column(c + 1);
-      br = s_misc[0];
-      // ---- bring the two rows that are about to be published fully up to date (columns c+2..)
-      if (!singular) {
-        const int rowsel[2] = {br, gc + 1};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int gr = rowsel[q];
-          if (gr == INT_MAX || gr < r0 || gr >= r0 + nrows || gr <= gc || (q == 1 && gr == br)) continue;
-          const int rr = gr - r0;
-          const dc l = P[rr * pitch + c];
-          for (int j = c + 2 + tid; j < nb; j += 256) {
-            dc a = P[rr * pitch + j]; const dc u = urow[j];
-            a.re -= l.re * u.re - l.im * u.im; a.im -= l.re * u.im + l.im * u.re;
-            P[rr * pitch + j] = a;
+      if (nrows <= 64) {
+        // one wavefront holds every row: the next column's candidate straight from the registers. Magnitudes compare on
+        // their top 32 bits (what the granule carries anyway), ties go to the lowest row = lowest lane.
+        if (wave == 0) {
+          const double mag = cabs1(anext);
+          const bool valid = tid < nrows && myrow > gc && mag == mag;      // a NaN is never offered (as in scan_column)
+          const unsigned hi = valid ? (unsigned)((u64)__double_as_longlong(mag) >> 32) : 0u;
+          const unsigned m = wave_umax(hi);
+          const u64 mask = __ballot(valid && hi == m);
+          if (lane == 0) {
+            s_misc[0] = mask ? r0 + (int)__builtin_ctzll(mask) : INT_MAX;
+            s_bestv[0] = __longlong_as_double((long long)((u64)m << 32));
           }
         }
+        __syncthreads();
+      } else {
+        scan_column(c + 1);
       }
-      __syncthreads();
       MA_STAMP(4);
       publish(c + 1);
       MA_STAMP(5);
@@ -265,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       for (int rbase = 0; rbase < nrows; rbase += 64) {
         const int rr = rbase + lane;
         const int gr = r0 + rr;
-        const bool on = rr < nrows && gr > gc && gr != br && gr != gc + 1;
+        const bool on = rr < nrows && gr > gc;
         const dc l = on ? P[rr * pitch + c] : dc_make(0.0, 0.0);
         dc* Pr = P + (size_t)(on ? rr : 0) * pitch;
         for (int j0 = c + 2 + 4 * wave; j0 < nb; j0 += 16) {
@@ -281,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
         }
       }
     }
+    pending = !singular && more;
     // LDS-only barrier: the granule store of publish() may still be in flight (write-through ack ~1 us)
     // and nothing in the next column depends on it, so do not drain the vector-memory counter here.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -822,7 +854,7 @@ __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(double* out, int it
 
 // ------------------------------------------------------------------ launchers
 size_t lu_panel_lds_bytes(int nb, int rpb) {
-  return (size_t)rpb * (nb + 1) * sizeof(dc) + 2 * (size_t)nb * sizeof(dc) + 4 * sizeof(double) + 12 * sizeof(int) + sizeof(double) + 64;
+  return (size_t)rpb * (nb + 1) * sizeof(dc) + 3 * (size_t)nb * sizeof(dc) + 4 * sizeof(double) + 12 * sizeof(int) + sizeof(double) + 64;
 }
 
 int lu_panel_configure() {

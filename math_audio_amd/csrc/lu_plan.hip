@@ -210,10 +210,10 @@ static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vect
   for (int k0 = 0; k0 < n;) {
     int nb, rpb, nblk;
     // rows per panel workgroup: at most 47.5 KB of LDS, so that two systems' panel workgroups AND two trailing-update
-    // workgroups fit on a CU together (the launcher admits panel kernels up to 96 KB per CU): 44 rows at nb = 64.
+    // workgroups fit on a CU together (the launcher admits panel kernels up to 96 KB per CU): 43 rows at nb = 64.
     // Few rows per workgroup also keep the per-column local work -- which a co-tenant update slows down -- short.
     const int wnb = std::min(n - k0, P->want_nb);
-    const int cap = P->rpb_env ? P->rpb_cap : std::max(8, (int)((48640 - 2 * wnb * 16 - 256) / ((wnb + 1) * 16)));
+    const int cap = P->rpb_env ? P->rpb_cap : std::max(8, (int)((48640 - 3 * wnb * 16 - 256) / ((wnb + 1) * 16)));
     panel_shape(n - k0, P->ncu, std::min(n - k0, P->want_nb), cap, &nb, &rpb, &nblk);
     k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
     k0 += nb;

@@ -76,6 +76,17 @@ def test_lu_random_matches_lapack(gpu, n):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-13 * kappa
 
 
+@pytest.mark.parametrize("n", [64, 300, 777])
+def test_lu_pivots_are_lapacks(gpu, n):
+    """Partial pivoting picks LAPACK's rows (izamax on |re| + |im|, first maximum): on generic data, where no two candidates
+    of a column agree to 1e-6 (the device compares the top 32 bits of the magnitude), the interchanges are identical."""
+    import scipy.linalg as sla
+    A, b = _rand(n, 1000 + n)
+    x, piv = ma.zgesv(A, b, return_pivots=True)
+    _, piv_ref = sla.lu_factor(A)
+    assert np.array_equal(piv, piv_ref)
+
+
 def test_lu_needs_pivoting(gpu):
     """Zero leading diagonal forces interchanges across workgroups and across panels."""
     n = 400
