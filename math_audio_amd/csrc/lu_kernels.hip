@@ -25,6 +25,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifndef LU_GRANULE_STRIDE
+#define LU_GRANULE_STRIDE 1
+#endif
 
 __device__ __forceinline__ void st_sc1(u64* p, double v) { __hip_atomic_store(p, (u64)__double_as_longlong(v), RLX_AGENT); }
 __device__ __forceinline__ double ld_sc1(const u64* p) { return __longlong_as_double((long long)__hip_atomic_load(p, RLX_AGENT)); }
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     if (tid == 0) {
       const u64 hi = br != INT_MAX ? ((u64)__double_as_longlong(bv) >> 32) : 0ull;
       const u64 lo = ((u64)(unsigned)(col + 1) << 24) | (u64)(br != INT_MAX ? (unsigned)br : 0xFFFFFFu);
-      __hip_atomic_store(ws.cand + (size_t)buf * ws.max_blocks + b, (hi << 32) | lo, RLX_AGENT);
+      __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE, (hi << 32) | lo, RLX_AGENT);
     }
   };
 
@@ -171,14 +174,14 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     // ---- wavefront 0 sweeps every workgroup's granule until all carry this column's tag, and
     // reduces them on the way (the data is the flag: no counter, no second round trip)
     if (wave == 0) {
-      const u64* cbase = ws.cand + (size_t)buf * ws.max_blocks;
+      const u64* cbase = ws.cand + (size_t)buf * ws.max_blocks * LU_GRANULE_STRIDE;
       const unsigned want = (unsigned)(c + 1);
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
       u64 best; int bblk; bool fail = false;
       for (;;) {
         bool ok = true; best = 0; bblk = 0; unsigned brow = 0xFFFFFFu; unsigned bhi = 0;
         for (int t = lane; t < nblk; t += 64) {
-          const u64 g = __hip_atomic_load(cbase + t, RLX_AGENT);
+          const u64 g = __hip_atomic_load(cbase + (size_t)t * LU_GRANULE_STRIDE, RLX_AGENT);
           const unsigned tag = (unsigned)(g >> 24) & 0xFFu, row = (unsigned)g & 0xFFFFFFu, hi = (unsigned)(g >> 32);
           ok = ok && (tag == want);
           if (hi > bhi || (hi == bhi && row < brow)) { bhi = hi; brow = row; bblk = t; }
@@ -878,6 +881,8 @@ struct PanelSequencer {
 PanelSequencer g_seq;
 }  // namespace
 
+size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long) * LU_GRANULE_STRIDE * 2 * (size_t)max_blocks; }
+
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
@@ -903,7 +908,7 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   // see the previous launch's granules, which carry that launch's last two tags (nb and nb - 1): they differ from the
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
-  if (clear_tags) MA_HIP(hipMemsetAsync(ws.cand, 0, sizeof(unsigned long long) * 2 * (size_t)ws.max_blocks, st));
+  if (clear_tags) MA_HIP(hipMemsetAsync(ws.cand, 0, lu_panel_granule_bytes(ws.max_blocks), st));
   hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(A), n, k0, nb, rpb, ws, ipiv);
   MA_HIP(hipGetLastError());
   MA_HIP(hipEventRecord(g_seq.ring[dev][i & 7], st));

@@ -14,13 +14,14 @@ struct LuPanelWs {
   unsigned* counter;            // arrivals
   unsigned* timeout;
   int* info;
-  unsigned long long* cand;     // [2][max_blocks][2]   {|re|+|im| bits, row}
+  unsigned long long* cand;     // [2][max_blocks] granules {|re|+|im| bits, tag, row}, LU_GRANULE_STRIDE words apart
   unsigned long long* candrow;  // [2][max_blocks][2*LU_NB_MAX] candidate row of the panel
   unsigned long long* diagrow;  // [2][2*LU_NB_MAX]            current diagonal row of the panel
   int max_blocks;
 };
 
 size_t lu_panel_lds_bytes(int nb, int rpb);
+size_t lu_panel_granule_bytes(int max_blocks);
 int lu_panel_configure();
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, hipStream_t st);

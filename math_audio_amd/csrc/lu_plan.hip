@@ -111,7 +111,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   const size_t o_sync = take(16), o_info = take(64);
   size_t o_cand[LU_BATCH_MAX], o_crow[LU_BATCH_MAX], o_drow[LU_BATCH_MAX];
   for (int m = 0; m < LU_BATCH_MAX; ++m) {
-    o_cand[m] = take(sizeof(unsigned long long) * 2 * mb * 2);
+    o_cand[m] = take(lu_panel_granule_bytes(mb));
     o_crow[m] = take(sizeof(unsigned long long) * 2 * (size_t)mb * 2 * LU_NB_MAX);
     o_drow[m] = take(sizeof(unsigned long long) * (2 * 2 * LU_NB_MAX + 16));
   }
