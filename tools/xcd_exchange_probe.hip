@@ -135,6 +135,36 @@ __global__ __launch_bounds__(64) void round3_kernel(unsigned* flags, unsigned* x
   if (lane == 0 && b == 0) out_ticks[0] = fail ? 0 : t1 - t0;
 }
 
+// MODE 6: flat round over all workgroups (flags 8 B apart, like the panel kernel's granules) with a delay before the
+// first poll and a sleep between polls (units of 64 clocks): do fewer, later polls shorten the round?
+template <int D0, int DS>
+__global__ __launch_bounds__(64) void round4_kernel(unsigned long long* flags, int rounds, u64* out_ticks) {
+  const int b = blockIdx.x, lane = threadIdx.x, G = gridDim.x;
+  const u64 t0 = __builtin_amdgcn_s_memrealtime();
+  bool fail = false;
+  for (int r = 1; r <= rounds && !fail; ++r) {
+    if (lane == 0) __hip_atomic_store(flags + b, (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (D0 > 0) __builtin_amdgcn_s_sleep(D0);
+    for (;;) {
+      bool ok = true;
+      for (int t = lane; t < G; t += 64) ok = ok && (__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)r);
+      if (__all(ok)) break;
+      if (DS > 0) __builtin_amdgcn_s_sleep(DS);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { fail = true; break; }
+    }
+  }
+  const u64 t1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && b == 0) out_ticks[0] = fail ? 0 : t1 - t0;
+}
+template <int D0, int DS>
+static void run4(unsigned long long* f, u64* ticks, int rounds) {
+  hipMemset(f, 0, 4096 * 8); hipMemset(ticks, 0, 8);
+  hipLaunchKernelGGL((round4_kernel<D0, DS>), dim3(227), dim3(64), 0, 0, f, rounds, ticks);
+  hipDeviceSynchronize();
+  u64 t; hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+  printf("flat, 227 workgroups, first poll after %3d x 64 clk, %3d x 64 clk between polls: %.3f us per round\n", D0, DS, t / 100.0 / rounds);
+}
+
 int main() {
   unsigned *flags, *claim; u64* ticks; int *xcc, *np;
   const int G = 256;
@@ -197,5 +227,9 @@ int main() {
       u64 t; hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
       printf("256 workgroups, %2d groups, flags %3d B apart: %.3f us per round\n", ng, stride * 4, t / 100.0 / rounds);
     }
+  unsigned long long* f8; hipMalloc(&f8, 4096 * 8);
+  run4<0, 0>(f8, ticks, rounds); run4<0, 1>(f8, ticks, rounds); run4<0, 8>(f8, ticks, rounds); run4<0, 32>(f8, ticks, rounds);
+  run4<20, 1>(f8, ticks, rounds); run4<40, 1>(f8, ticks, rounds); run4<60, 1>(f8, ticks, rounds); run4<40, 8>(f8, ticks, rounds);
+  run4<60, 16>(f8, ticks, rounds); run4<80, 8>(f8, ticks, rounds);
   return 0;
 }
