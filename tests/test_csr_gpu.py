@@ -248,3 +248,42 @@ def test_helmholtz_assemble_with_boundary_terms(gpu, layout, monkeypatch):
     y1 = O.csr_matvec(rp, ci, O.helmholtz_values(K, M, 0.5 * k), x, nthreads=4)
     assert np.abs(lo.apply_transpose(x) - y1).max() <= 1e-12 * np.abs(y1).max()
     lo.close(); op.close()
+
+
+def test_full_size_fem_box(gpu):
+    """BASELINE.json config #4 at full size (F1M: 100^3 nodes, 1.48e7 non-zeros): checksums that do not depend on the size
+    (K annihilates constants, M's entries sum to the volume, so (K - k^2 M) 1 sums to -k^2 V; linearity) and every device
+    smoother against the CPU restatement, whose sequential sweeps finish in well under a second per sweep."""
+    _, rp, ci, K, M = fem.helmholtz_box(99, 99, 99)
+    n = len(rp) - 1
+    assert n == 1000000
+    op = ma.CsrOperator(rp, ci, K=K, M=M)
+    ones = np.ones(n, dtype=complex)
+    op.set_wavenumber(0.0)
+    y0 = op.matvec(ones)
+    assert np.abs(y0).max() <= 1e-12 * np.abs(K).max()                 # stiffness rows sum to zero
+    k = 2 * np.pi * 100.0 / 343.0 + 0.01j
+    op.set_wavenumber(k)
+    y1 = op.matvec(ones)
+    vol = 5.0 * 4.0 * 2.5
+    assert abs(y1.sum() - (-(k * k) * vol)) <= 1e-10 * abs(k * k * vol)  # sum of the mass matrix = volume of the box
+    x = _x0(n); z = np.cos(0.3 * np.arange(n)) + 0.25j
+    a, b_ = 0.7 - 0.2j, -1.3 + 0.4j
+    lin = op.matvec(a * x + b_ * z) - (a * op.matvec(x) + b_ * op.matvec(z))
+    assert np.abs(lin).max() <= 1e-12 * np.abs(op.matvec(x)).max()
+    vals = O.helmholtz_values(K, M, k)
+    b = np.sin(0.2 * np.arange(n)) + 1j * np.cos(0.1 * np.arange(n))
+    y_ref = O.csr_matvec(rp, ci, vals, x, nthreads=8)
+    assert np.abs(op.matvec(x) - y_ref).max() <= 1e-13 * np.abs(y_ref).max()
+    xj = O.amg_jacobi(rp, ci, vals, x, b, 0.8, 2, nthreads=8)
+    assert np.abs(op.jacobi(x, b, 0.8, 2) - xj).max() <= 1e-12 * np.abs(xj).max()
+    xl = O.amg_l1_jacobi(rp, ci, vals, x, b, 2, nthreads=8)
+    assert np.abs(op.l1_jacobi(x, b, 2) - xl).max() <= 1e-12 * np.abs(xl).max()
+    xs = O.amg_sym_gauss_seidel(rp, ci, vals, x, b, 1)
+    xd = op.sym_gauss_seidel(x, b, 1)
+    assert np.abs(xd - xs).max() <= 1e-11 * np.abs(xs).max()
+    # the sweep is sequential: the row updated last (row 0 of the backward sweep) satisfies its equation exactly
+    r = op.residual(xd, b)
+    assert abs(r[0]) <= 1e-12 * abs(b[0])
+    assert op.gauss_seidel_levels() == (298, 298)
+    op.close()
