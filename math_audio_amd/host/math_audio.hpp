@@ -460,4 +460,52 @@ inline GmresSolution gmres_preconditioned_with_guess(const LinearOperator& a, co
   return detail::run_gmres(a, &m, b, x0, c);
 }
 
+// AmgPreconditioner's smoothers (preconditioners/amg.rs:855-884, 887-929, 932-978) on the device operator: x is updated in place
+inline void smooth_jacobi(const CsrMatrix& a, std::vector<Complex64>& x, const std::vector<Complex64>& b, double omega, size_t num_sweeps) {
+  solver_check(ma_csr_jacobi(a.csr_handle(), reinterpret_cast<ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), omega, (int)num_sweeps));
+}
+inline void smooth_l1_jacobi(const CsrMatrix& a, std::vector<Complex64>& x, const std::vector<Complex64>& b, size_t num_sweeps) {
+  solver_check(ma_csr_l1jacobi(a.csr_handle(), reinterpret_cast<ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), (int)num_sweeps));
+}
+inline void smooth_sym_gauss_seidel(const CsrMatrix& a, std::vector<Complex64>& x, const std::vector<Complex64>& b, size_t num_sweeps) {
+  solver_check(ma_csr_sym_gauss_seidel(a.csr_handle(), reinterpret_cast<ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), (int)num_sweeps));
+}
+
 }  // namespace math_solvers
+
+// ---- math-fem/src/multigrid/smoother.rs:12-68, 163-176 and assembly/helmholtz.rs:22-33: the COO system matrix and its smoothers
+namespace math_fem {
+using math_solvers::Complex64;
+enum class SmootherType { GaussSeidel = 0, Jacobi = 1, SymmetricGaussSeidel = 2 };
+struct SmootherConfig {
+  SmootherType smoother_type = SmootherType::GaussSeidel;
+  size_t iterations = 2;
+  double omega = 2.0 / 3.0;
+};
+class HelmholtzMatrix {
+ public:
+  std::vector<int64_t> rows, cols;
+  std::vector<Complex64> values;
+  size_t dim = 0;
+  HelmholtzMatrix(size_t n, std::vector<int64_t> r, std::vector<int64_t> c, std::vector<Complex64> v) : rows(std::move(r)), cols(std::move(c)), values(std::move(v)), dim(n) {}
+  HelmholtzMatrix(const HelmholtzMatrix&) = delete;
+  HelmholtzMatrix& operator=(const HelmholtzMatrix&) = delete;
+  ~HelmholtzMatrix() { if (h_) ma_csr_destroy(h_); }
+  ma_csr_t* handle() const {
+    if (!h_) math_solvers::solver_check(ma_fem_matrix_create((int64_t)dim, (int64_t)values.size(), rows.data(), cols.data(), reinterpret_cast<const ma_c64*>(values.data()), 0, &h_));
+    return h_;
+  }
+ private:
+  mutable ma_csr_t* h_ = nullptr;
+};
+// smooth(matrix, x, b, config): x updated in place
+inline void smooth(const HelmholtzMatrix& m, std::vector<Complex64>& x, const std::vector<Complex64>& b, const SmootherConfig& c) {
+  math_solvers::solver_check(ma_fem_smooth(m.handle(), reinterpret_cast<ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), (int)c.smoother_type, (int)c.iterations, c.omega));
+}
+inline std::vector<Complex64> compute_residual(const HelmholtzMatrix& m, const std::vector<Complex64>& x, const std::vector<Complex64>& b) {
+  std::vector<Complex64> r(b.size());
+  math_solvers::solver_check(ma_fem_residual(m.handle(), reinterpret_cast<const ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), reinterpret_cast<ma_c64*>(r.data())));
+  return r;
+}
+}  // namespace math_fem
+

@@ -128,12 +128,52 @@ static void test_gmres_simple_identity_preconditioned() {
   CHECK(s4.converged && s4.iterations <= 1);
 }
 
+// ---- math-fem/src/multigrid/smoother.rs:192-237 (the reference's own smoother tests, on a 1D Laplacian given as COO triplets with
+// the diagonal split in two) and amg.rs's symmetric Gauss-Seidel on the CSR form
+static void test_fem_smoothers_reduce_residual() {
+  using namespace math_fem;
+  const size_t n = 40;
+  std::vector<int64_t> r, c; std::vector<Complex64> v;
+  for (size_t i = 0; i < n; ++i) {
+    r.push_back((int64_t)i); c.push_back((int64_t)i); v.push_back(Complex64(1.0, 0.0));
+    r.push_back((int64_t)i); c.push_back((int64_t)i); v.push_back(Complex64(1.0, 0.0));      // duplicates are summed (helmholtz.rs:22-33)
+    if (i > 0) { r.push_back((int64_t)i); c.push_back((int64_t)i - 1); v.push_back(Complex64(-1.0, 0.0)); }
+    if (i + 1 < n) { r.push_back((int64_t)i); c.push_back((int64_t)i + 1); v.push_back(Complex64(-1.0, 0.0)); }
+  }
+  HelmholtzMatrix m(n, r, c, v);
+  std::vector<Complex64> b(n); for (size_t i = 0; i < n; ++i) b[i] = Complex64(std::sin(0.3 * (double)i), 0.0);
+  auto norm = [](const std::vector<Complex64>& z) { double s = 0; for (auto& e : z) s += std::norm(e); return std::sqrt(s); };
+  for (SmootherType t : {SmootherType::GaussSeidel, SmootherType::Jacobi, SmootherType::SymmetricGaussSeidel}) {
+    std::vector<Complex64> x(n, Complex64(0.0, 0.0));
+    const double r0 = norm(compute_residual(m, x, b));
+    SmootherConfig cfg; cfg.smoother_type = t; if (t == SmootherType::Jacobi) { cfg.iterations = 5; cfg.omega = 0.6; }
+    smooth(m, x, b, cfg);
+    CHECK(norm(compute_residual(m, x, b)) < r0);
+  }
+  // one forward Gauss-Seidel sweep of the 1D Laplacian from x = 0 is the recurrence x_i = (b_i + x_{i-1}) / 2
+  std::vector<Complex64> x(n, Complex64(0.0, 0.0));
+  SmootherConfig one; one.iterations = 1;
+  smooth(m, x, b, one);
+  Complex64 prev(0.0, 0.0); double e = 0.0;
+  for (size_t i = 0; i < n; ++i) { prev = (b[i] + prev) / 2.0; e = std::max(e, std::abs(x[i] - prev)); }
+  CHECK(e < 1e-14);
+  std::vector<std::tuple<size_t, size_t, Complex64>> trip;
+  for (size_t k = 0; k < v.size(); ++k) trip.emplace_back((size_t)r[k], (size_t)c[k], v[k]);
+  math_solvers::CsrMatrix a = math_solvers::CsrMatrix::from_triplets(n, n, trip);
+  std::vector<Complex64> xs(n, Complex64(0.0, 0.0));
+  const double r0 = norm(b);
+  math_solvers::smooth_sym_gauss_seidel(a, xs, b, 2);
+  auto ax = a.matvec(xs); for (size_t i = 0; i < n; ++i) ax[i] = b[i] - ax[i];
+  CHECK(norm(ax) < r0);
+}
+
 int main() {
   int n = 0;
   if (ma_device_count(&n) != MA_OK || n <= 0) { std::printf("no HIP device: the host mirror has no CPU fallback\n"); return 77; }
   test_lu_solve_real(); test_lu_solve_complex(); test_lu_identity(); test_lu_singular(); test_lu_dimension_mismatch(); test_lu_factorize_then_solve();
   test_tbem_diagonal_nonzero_and_qa();
   test_csr_from_dense_matvec_triplets(); test_diagonal_preconditioner(); test_gmres_simple_identity_preconditioned();
+  test_fem_smoothers_reduce_residual();
   std::printf(failures ? "%d check(s) failed\n" : "host mirror: all checks passed\n", failures);
   return failures ? 1 : 0;
 }
