@@ -242,8 +242,9 @@ int ma_op_destroy(ma_op_t* op);
 int ma_op_num_rows(const ma_op_t* op, int64_t* n);
 int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);
 int ma_op_apply_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
-/* apply_transpose (y = A^T x) and apply_hermitian (y = A^H x), traits.rs:326-358; dense and CSR operators
- * (the matrix-free TBEM operator returns MA_ERR_UNSUPPORTED) */
+/* apply_transpose (y = A^T x) and apply_hermitian (y = A^H x), traits.rs:326-358, for every operator kind. A matrix-free
+ * operator created over a row block [row0, row1) returns that block's contribution to all entries of y (the blocks' results
+ * add up). */
 int ma_op_apply_transpose(ma_op_t* op, const ma_c64* x, ma_c64* y);
 int ma_op_apply_hermitian(ma_op_t* op, const ma_c64* x, ma_c64* y);
 int ma_op_apply_transpose_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);

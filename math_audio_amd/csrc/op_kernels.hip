@@ -155,6 +155,54 @@ __global__ __launch_bounds__(256) void tbem_matvec_kernel(BemGeom g, BemPhys ph,
   if (valid) partial[(size_t)blockIdx.y * (row1 - row0) + (i - row0)] = dc_make(yr, yi);
 }
 
+// Transposed product y = A^T x of the streamed operator: lane = FIELD panel j (its geometry stays in registers), the
+// collocation rows of the chunk go by on the scalar path -- the loop nest of tbem_far_kernel, accumulating instead of
+// storing. grid.x: strips of 256 panels; grid.y: row chunks of [row0, row1). partial[chunk][j] = sum_i A13_ij x[dof_i]
+__global__ __launch_bounds__(256) void tbem_matvec_t_kernel(BemGeom g, BemPhys ph, int row0, int row1, int chunk_rows, const dc* __restrict__ x,
+                                                            dc* __restrict__ partial) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = j < g.np;
+  const int jj = valid ? j : g.np - 1;
+  const double p0x = g.p0[0][jj], p0y = g.p0[1][jj], p0z = g.p0[2][jj];
+  const double e1x = g.e1[0][jj], e1y = g.e1[1][jj], e1z = g.e1[2][jj];
+  const double e2x = g.e2[0][jj], e2y = g.e2[1][jj], e2z = g.e2[2][jj];
+  const double nyx = g.ny[0][jj], nyy = g.ny[1][jj], nyz = g.ny[2][jj];
+  const double jw = g.jac[jj] * MA_INV4PI;
+  const int fbc = g.bc_type[jj];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  const int i0 = row0 + blockIdx.y * chunk_rows, i1 = min(i0 + chunk_rows, row1);
+  double yr = 0.0, yi = 0.0;
+  for (int i = i0; i < i1; ++i) {
+    const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];          // wave-uniform collocation row (scalar loads)
+    const dc xi = x[g.dof[i]];
+    const dc a = pair_coeff_13(p0x - cx, p0y - cy, p0z - cz, e1x, e1y, e1z, e2x, e2y, e2z, nyx, nyy, nyz, g.nx[0][i], g.nx[1][i], g.nx[2][i],
+                               jw, fbc, ph, k, k2);
+    yr += a.re * xi.re - a.im * xi.im; yi += a.re * xi.im + a.im * xi.re;
+  }
+  if (valid) partial[(size_t)blockIdx.y * g.np + j] = dc_make(yr, yi);
+}
+
+// y[dof_j] = sum_chunks partial[c][j] + diag_corr[j] x[dof_j] + sum over the near pairs (i, j) of column j of corr[q] x[dof_i];
+// t_off / t_idx list the plan's pairs by column (built once per operator); rows outside [row0, row1) belong to other shards
+__global__ __launch_bounds__(256) void tbem_matvec_t_finish_kernel(BemGeom g, int row0, int row1, int nchunks, const dc* __restrict__ partial,
+                                                                  const long long* __restrict__ t_off, const int* __restrict__ t_idx,
+                                                                  const int2* __restrict__ pairs, const dc* __restrict__ corr,
+                                                                  const dc* __restrict__ diag_corr, const dc* __restrict__ x, dc* __restrict__ y) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= g.np) return;
+  double yr = 0.0, yi = 0.0;
+  for (int c = 0; c < nchunks; ++c) { const dc p = partial[(size_t)c * g.np + j]; yr += p.re; yi += p.im; }
+  if (j >= row0 && j < row1) { const dc d = diag_corr[j], xv = x[g.dof[j]]; yr += d.re * xv.re - d.im * xv.im; yi += d.re * xv.im + d.im * xv.re; }
+  for (long long t = t_off[j]; t < t_off[j + 1]; ++t) {
+    const int q = t_idx[t];
+    const int i = pairs[q].x;
+    if (i < row0 || i >= row1) continue;
+    const dc a = corr[q], xv = x[g.dof[i]];
+    yr += a.re * xv.re - a.im * xv.im; yi += a.re * xv.im + a.im * xv.re;
+  }
+  y[g.dof[j]] = dc_make(yr, yi);
+}
+
 // 13-point coefficient of listed pairs (to form corrections A_true - A_13): out[q] for pairs[q] = (i, j)
 __global__ __launch_bounds__(256) void tbem_pairs13_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs, long long npairs, dc* __restrict__ out) {
   const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -293,6 +341,19 @@ int op_launch_tbem_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row
   hipLaunchKernelGGL(tbem_matvec_kernel, grid, block, 0, st, g, ph, row0, row1, chunk_cols, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
   hipLaunchKernelGGL(tbem_matvec_finish_kernel, dim3((nr + 255) / 256), block, 0, st, g, row0, row1, nchunks, reinterpret_cast<const dc*>(partial),
                      pair_off, pairs, reinterpret_cast<const dc*>(corr), reinterpret_cast<const dc*>(diag_corr), reinterpret_cast<const dc*>(x),
+                     reinterpret_cast<dc*>(y));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_tbem_matvec_t(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,
+                            const long long* t_off, const int* t_idx, const int2* pairs, const c64* corr, const c64* diag_corr, c64* y, hipStream_t st) {
+  const int nr = row1 - row0;
+  if (nr <= 0 || g.np <= 0) return MA_OK;
+  const int chunk_rows = (nr + nchunks - 1) / nchunks;
+  dim3 grid((g.np + 255) / 256, nchunks), block(256);
+  hipLaunchKernelGGL(tbem_matvec_t_kernel, grid, block, 0, st, g, ph, row0, row1, chunk_rows, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
+  hipLaunchKernelGGL(tbem_matvec_t_finish_kernel, dim3((g.np + 255) / 256), block, 0, st, g, row0, row1, nchunks, reinterpret_cast<const dc*>(partial),
+                     t_off, t_idx, pairs, reinterpret_cast<const dc*>(corr), reinterpret_cast<const dc*>(diag_corr), reinterpret_cast<const dc*>(x),
                      reinterpret_cast<dc*>(y));
   MA_HIP(hipGetLastError());
   return MA_OK;

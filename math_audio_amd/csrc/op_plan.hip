@@ -31,6 +31,8 @@ struct ma_op {
   // TBEM
   ma_bem_plan* plan = nullptr; BemPhys ph{}; int row0 = 0, row1 = 0, nchunks = 1;
   c64* d_corr = nullptr; c64* d_diag = nullptr; c64* d_partial = nullptr;
+  // transposed apply: the plan's near pairs listed by column, and per-row-chunk partial sums over all np columns
+  long long* d_t_off = nullptr; int* d_t_idx = nullptr; c64* d_tpartial = nullptr;
   // staging for the host-buffer entry points
   c64* d_x = nullptr; c64* d_y = nullptr;
 };
@@ -38,7 +40,7 @@ struct ma_op {
 namespace {
 void op_free(ma_op* o) {
   if (o->own_A && o->dA) (void)hipFree(o->dA);
-  void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y, o->d_tpart, o->d_cx};
+  void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y, o->d_tpart, o->d_cx, o->d_t_off, o->d_t_idx, o->d_tpartial};
   for (void* q : p) if (q) (void)hipFree(q);
   if (o->csr_t) (void)ma_csr_destroy(o->csr_t);
 }
@@ -170,12 +172,47 @@ int ma_op_apply(ma_op_t* o, const ma_c64* x, ma_c64* y) {
 
 // LinearOperator::apply_transpose (y = A^T x) and apply_hermitian (y = A^H x = conj(A^T conj(x)), traits.rs:326-358),
 // device pointers (x and y distinct). Dense: DenseOperator's matrix.t().dot(x) (fmm_interface.rs:40-48); CSR: an SpMV on
-// the transposed operator, built once. The matrix-free TBEM operator has no transpose on the device (the reference's
-// GMRES path never asks for one): MA_ERR_UNSUPPORTED.
+// the transposed operator, built once. Matrix-free TBEM: the streamed kernel with the loop nest turned around.
+// column-sorted view of the plan's near-pair list (pairs are stored by row): one counting sort on the host, once per operator
+static int tbem_build_column_index(ma_op* o) {
+  if (o->d_t_off) return MA_OK;
+  const ma_bem_plan* P = o->plan;
+  const long long np = P->np, npairs = P->npairs;
+  std::vector<int2> hp((size_t)std::max<long long>(npairs, 1));
+  if (npairs > 0) MA_HIP(hipMemcpy(hp.data(), P->d_pairs, sizeof(int2) * (size_t)npairs, hipMemcpyDeviceToHost));
+  std::vector<long long> off((size_t)np + 1, 0);
+  for (long long q = 0; q < npairs; ++q) off[(size_t)hp[(size_t)q].y + 1]++;
+  for (long long j = 0; j < np; ++j) off[(size_t)j + 1] += off[(size_t)j];
+  std::vector<long long> cur(off.begin(), off.end() - 1);
+  std::vector<int> idx((size_t)std::max<long long>(npairs, 1));
+  for (long long q = 0; q < npairs; ++q) idx[(size_t)cur[(size_t)hp[(size_t)q].y]++] = (int)q;     // ascending q = ascending row inside a column
+  MA_HIP(hipMalloc(&o->d_t_off, sizeof(long long) * ((size_t)np + 1)));
+  MA_HIP(hipMalloc(&o->d_t_idx, sizeof(int) * idx.size()));
+  MA_HIP(hipMalloc(&o->d_tpartial, sizeof(c64) * (size_t)o->nchunks * (size_t)np));
+  MA_HIP(hipMemcpy(o->d_t_off, off.data(), sizeof(long long) * ((size_t)np + 1), hipMemcpyHostToDevice));
+  MA_HIP(hipMemcpy(o->d_t_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+  return MA_OK;
+}
+
 static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStream_t st) {
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
-  MA_REQUIRE(o->kind != 2, MA_ERR_UNSUPPORTED, "the matrix-free TBEM operator has no transpose on the device");
   MA_HIP(hipSetDevice(o->device));
+  if (o->kind == 2) {
+    // streamed like apply, with the loop nest turned around (lane = field panel). A row-sharded operator returns its
+    // rows' contribution to every entry of y: the shards' results add up (the caller's all-reduce).
+    MA_REQUIRE(o->plan->npairs < 2147483647LL, MA_ERR_UNSUPPORTED, "near-pair list too long for the column index");
+    int rc = tbem_build_column_index(o); if (rc) return rc;
+    const c64* xin = (const c64*)d_x;
+    if (herm) {
+      if (!o->d_cx) MA_HIP(hipMalloc(&o->d_cx, sizeof(c64) * (size_t)o->n));
+      rc = op_launch_conj(o->n, xin, o->d_cx, st); if (rc) return rc;
+      xin = o->d_cx;
+    }
+    rc = op_launch_tbem_matvec_t(o->plan->geom, o->ph, o->row0, o->row1, o->nchunks, xin, o->d_tpartial, o->d_t_off, o->d_t_idx,
+                                 o->plan->d_pairs, o->d_corr, o->d_diag, (c64*)d_y, st);
+    if (!rc && herm) rc = op_launch_conj(o->n, (const c64*)d_y, (c64*)d_y, st);
+    return rc;
+  }
   if (o->kind == 0) {
     if (!o->d_tpart) MA_HIP(hipMalloc(&o->d_tpart, sizeof(c64) * (size_t)op_zgemv_t_chunks() * (size_t)o->n));
     return op_launch_zgemv_t(o->n, o->dA, (const c64*)d_x, o->d_tpart, (c64*)d_y, herm, st);

@@ -49,6 +49,20 @@ def test_matrix_free_tbem_equals_dense_matvec(gpu, sub, ka):
         parts[r0:r1] = blk.apply(x)[r0:r1]
         blk.close()
     assert np.array_equal(parts, y)
+    # apply_transpose / apply_hermitian (traits.rs:326-358) of the streamed operator: same entries, loop nest turned around
+    yt = op.apply_transpose(x)
+    assert np.abs(yt - A.T @ x).max() <= 1e-12 * np.abs(A.T @ x).max()
+    yh = op.apply_hermitian(x)
+    assert np.abs(yh - A.conj().T @ x).max() <= 1e-12 * np.abs(A.conj().T @ x).max()
+    # a row block contributes its rows' part of A^T x: the blocks' results add up
+    acc = np.zeros(n, dtype=complex)
+    for r0, r1 in ((0, h), (h, 2 * h), (2 * h, n)):
+        blk = ma.LinearOperator.tbem(plan, k, beta, rows=(r0, r1))
+        part = blk.apply_transpose(x)
+        assert np.abs(part - A[r0:r1].T @ x[r0:r1]).max() <= 1e-12 * np.abs(A.T @ x).max()
+        acc += part
+        blk.close()
+    assert np.abs(acc - yt).max() <= 1e-13 * np.abs(yt).max()
     op.close(); plan.close()
 
 
