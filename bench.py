@@ -90,6 +90,11 @@ def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
         t_probe = time.perf_counter() - t0
         rows = rows2
     asm_pairs_per_s = rows * n / t_probe
+    # the reference assembles on ONE thread (tbem.rs:96-222 is a serial double loop): the same strip kernel on one core
+    rows1 = max(4, min(64, int(asm_pairs_per_s / cores * 3.0 / n)))
+    t0 = time.perf_counter()
+    O.build_tbem_system_with_beta(om, k, beta, nthreads=1, rows=(0, rows1), A=A, rhs=rhs)
+    asm_1thread = rows1 * n / (time.perf_counter() - t0)
     del A
     # dense solve: LAPACK on a 3000 x 3000 complex system
     ns = min(n, 3000)
@@ -112,6 +117,7 @@ def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
                   "dense solve: %s, n=%d, %.2f s -> %.1f GFLOP/s; step time = N^2/asm + ((8/3)N^3+8N^2)/solve" % (
                       rows, n, freq, cores, t_probe, asm_pairs_per_s, lib, ns, t_lu, solve_gflops),
         "assembly_pairs_per_s": asm_pairs_per_s, "solve_gflops": solve_gflops,
+        "assembly_pairs_per_s_one_thread": asm_1thread,
     }
 
 
