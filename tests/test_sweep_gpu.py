@@ -168,3 +168,38 @@ def test_solve_sweep_driver_matches_per_frequency_path(gpu):
     x_ref, _, rc = O.zgesv(A_ref, rhs_ref + O.compute_rhs_with_beta(om.center, om.normal, k, beta), nthreads=8)
     assert rc == 0 and rel_l2(X[1], x_ref) <= 1e-8
     plan.close()
+
+
+def test_two_host_threads_one_frequency_each(gpu):
+    """The reference's drivers solve frequencies from rayon workers (room_simulator_fem.rs:1143-1158; traits are Send + Sync):
+    two host threads, each with its own plans and buffers, must reproduce the serial results bit for bit (the panel
+    kernels of both go through the launcher's sequencer; errors are thread-local)."""
+    import threading
+    om = O.icosphere(RADIUS, 3)
+    mesh = to_ma_mesh(om)
+    ks = [k_from_ka(1.0), k_from_ka(3.0)]
+
+    def solve(k):
+        beta, _ = O.beta_adaptive(k, RADIUS)
+        A, rhs0 = ma.assemble_tbem(mesh, k, beta)
+        b = rhs0 + ma.incident_rhs(om.center, om.normal, k, beta)
+        return ma.zgesv(A, b)
+
+    serial = [solve(k) for k in ks]
+    out = [None, None]; err = []
+
+    def worker(t):
+        try:
+            for _ in range(3):
+                out[t] = solve(ks[t])
+        except Exception as e:       # surfaced below: a thread must not swallow a failure
+            err.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for t in range(2):
+        assert np.array_equal(out[t], serial[t])
