@@ -158,6 +158,19 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_
 /* solve further right-hand sides with the factors a previous ma_lu_plan_factor_solve_dev call on this plan left in d_A */
 int ma_lu_plan_solve_dev(ma_lu_plan_t* plan, void* d_A_factored, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* const* d_As, void* const* d_Bs, int32_t nrhs, void* stream);
+/* Staged use of a plan: a pipeline over a long sequence of systems (the frequencies of a sweep). factor_solve_batch moves
+ * its systems in lock step; here every slot (0..3) is at its own block of columns, so a driver can start slot s a third of a
+ * factorisation after slot s-1: each round then carries one big, one medium and one small trailing update, and every slot's
+ * latency-bound panel chain has the time of all of them to finish. Per slot: stage_begin when A and b of its next system are
+ * ready on `stream` (it starts the first block column), then one stage_round per block 0..num_blocks-1 -- together with the
+ * other slots' current blocks, in one call per round --, then stage_finish (backward substitution; `stream` waits for it,
+ * x is in b). stage_reset clears the status words and the timing accumulators before a run; ma_lu_plan_status reports as
+ * for the batch. Same kernels and arithmetic as ma_lu_plan_factor_solve_batch_dev. */
+int ma_lu_plan_num_blocks(ma_lu_plan_t* plan, int32_t* blocks);
+int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
+int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
+int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
+int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -83,6 +83,11 @@ def lib():
             "ma_lu_factorization_solve": [vp, vp, vp],
             "ma_lu_factorization_destroy": [vp],
             "ma_lu_plan_factor_solve_batch_dev": [vp, i32, vp, vp, i32, vp],
+            "ma_lu_plan_num_blocks": [vp, P(i32)],
+            "ma_lu_plan_stage_reset": [vp, vp],
+            "ma_lu_plan_stage_begin": [vp, i32, vp, vp, i32, vp],
+            "ma_lu_plan_stage_round": [vp, i32, vp, vp, vp],
+            "ma_lu_plan_stage_finish": [vp, i32, vp],
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],
@@ -316,6 +321,26 @@ class LuPlan:
         m = len(d_As)
         pa = (C.c_void_p * m)(*[C.c_void_p(p) for p in d_As]); pb = (C.c_void_p * m)(*[C.c_void_p(p) for p in d_Bs])
         check(lib().ma_lu_plan_factor_solve_batch_dev(self.h, m, pa, pb, nrhs, C.c_void_p(stream)))
+
+    # staged (pipelined) use: see include/mathaudio_hip.h
+    def num_blocks(self):
+        g = C.c_int32()
+        check(lib().ma_lu_plan_num_blocks(self.h, C.byref(g)))
+        return g.value
+
+    def stage_reset(self, stream=0):
+        check(lib().ma_lu_plan_stage_reset(self.h, C.c_void_p(stream)))
+
+    def stage_begin(self, slot, d_A, d_B, nrhs=1, stream=0):
+        check(lib().ma_lu_plan_stage_begin(self.h, int(slot), C.c_void_p(d_A), C.c_void_p(d_B), nrhs, C.c_void_p(stream)))
+
+    def stage_round(self, slots, blocks, stream=0):
+        m = len(slots)
+        a = (C.c_int32 * m)(*slots); b = (C.c_int32 * m)(*blocks)
+        check(lib().ma_lu_plan_stage_round(self.h, m, a, b, C.c_void_p(stream)))
+
+    def stage_finish(self, slot, stream=0):
+        check(lib().ma_lu_plan_stage_finish(self.h, int(slot), C.c_void_p(stream)))
 
     def status(self, stream=0):
         return lib().ma_lu_plan_status(self.h, C.c_void_p(stream))

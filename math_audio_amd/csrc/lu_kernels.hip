@@ -346,6 +346,7 @@ __device__ void lu_invert_diag32(const dc* __restrict__ T, int ldt, int nb, int 
   __shared__ dc Xs[32 * 33];
   const int lane = threadIdx.x, base = d * 32;
   const int m = min(32, nb - base);
+#pragma unroll 4
   for (int idx = lane; idx < 1024; idx += 64) {
     const int i = idx >> 5, k = idx & 31;
     Ls[i * 33 + k] = (i < m && k < i) ? T[(size_t)(base + i) * ldt + base + k] : dc_make(0.0, 0.0);
@@ -353,40 +354,49 @@ __device__ void lu_invert_diag32(const dc* __restrict__ T, int ldt, int nb, int 
   }
   __syncthreads();
   if (lane < 32) {
+    // column j of A^-1 (lanes 0-15) / B^-1 (lanes 16-31): x_i = e_i - sum_{k<i} l_ik x_k, the x_k read back from this lane's
+    // own column of Xs (registers are what this kernel must not need)
     const int off = lane & 16, j = lane & 15;
-    dc x[16];
-#pragma unroll
     for (int i = 0; i < 16; ++i) {
       dc acc = dc_make(i == j ? 1.0 : 0.0, 0.0);
-#pragma unroll
-      for (int k = 0; k < i; ++k) { const dc t = Ls[(off + i) * 33 + off + k]; acc.re -= t.re * x[k].re - t.im * x[k].im; acc.im -= t.re * x[k].im + t.im * x[k].re; }
-      x[i] = acc;
+      for (int k = j; k < i; ++k) {                       // x_k = 0 for k < j
+        const dc t = Ls[(off + i) * 33 + off + k], xk = Xs[(off + k) * 33 + off + j];
+        acc.re -= t.re * xk.re - t.im * xk.im; acc.im -= t.re * xk.im + t.im * xk.re;
+      }
+      Xs[(off + i) * 33 + off + j] = acc;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Xs[(off + i) * 33 + off + j] = x[i];
   }
   __syncthreads();
   {
+    // lane (j, q): rows 4q..4q+3 of column j of W = C A^-1, parked in the (empty) upper-right block of Ls, then the same
+    // rows of -B^-1 W. Four accumulators per lane: the kernel must stay small in registers, it runs beside trailing updates.
     const int j = lane & 15, q = lane >> 4;
-    dc w[16];
+    dc w[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = dc_make(0.0, 0.0);
-#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = dc_make(0.0, 0.0);
+#pragma unroll 1
     for (int k = 0; k < 16; ++k) {
       const dc a = Xs[k * 33 + j];                        // A^-1[k][j]
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const dc c = Ls[(16 + i) * 33 + k]; w[i].re += c.re * a.re - c.im * a.im; w[i].im += c.re * a.im + c.im * a.re; }
+      for (int r = 0; r < 4; ++r) { const dc c = Ls[(16 + 4 * q + r) * 33 + k]; w[r].re += c.re * a.re - c.im * a.im; w[r].im += c.re * a.im + c.im * a.re; }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ls[(4 * q + r) * 33 + 16 + j] = w[r];
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * q + r;
       dc acc = dc_make(0.0, 0.0);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { const dc bi = Xs[(16 + i) * 33 + 16 + k]; acc.re -= bi.re * w[k].re - bi.im * w[k].im; acc.im -= bi.re * w[k].im + bi.im * w[k].re; }
+#pragma unroll 2
+      for (int k = 0; k < 16; ++k) {
+        const dc bi = Xs[(16 + i) * 33 + 16 + k], wk = Ls[k * 33 + 16 + j];
+        acc.re -= bi.re * wk.re - bi.im * wk.im; acc.im -= bi.re * wk.im + bi.im * wk.re;
+      }
       Xs[(16 + i) * 33 + j] = acc;
     }
   }
   __syncthreads();
+#pragma unroll 4
   for (int idx = lane; idx < 1024; idx += 64) invd[(size_t)base * 32 + idx] = Xs[(idx >> 5) * 33 + (idx & 31)];
 }
 
@@ -574,6 +584,109 @@ __global__ __launch_bounds__(128) void lu_trsm_mfma_kernel(const dc* __restrict_
       }
     }
   }
+}
+
+// The same solve for panels of <= 64 columns with the four 16-row tiles of the wavefront's block of A12 in NAMED accumulators
+// (an indexed array of tiles makes the compiler carry the whole array through every update): few registers, so the
+// wavefront fits beside two update wavefronts on a SIMD instead of queueing behind a running trailing update -- where these
+// launches, which sit on every system's critical chain, took 0.2-0.35 ms instead of 20 us.
+__global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict__ T, int ldt, int nb, const dc* __restrict__ invd,
+                                                           dc* __restrict__ X, size_t xrs, size_t xcs, int nc, int nmain,
+                                                           dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* Lre = reinterpret_cast<double*>(smem);
+  double* Lim = Lre + (size_t)max(32, ((nb + 15) >> 4) * 16) * TM_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const bool extra = (int)blockIdx.x >= nmain;
+  dc* Xp = extra ? X2 : X;
+  const size_t rs = extra ? x2rs : xrs, cs = extra ? x2cs : xcs;
+  const int ncols = extra ? nc2 : nc;
+  const int c0 = extra ? wave * 16 : ((int)blockIdx.x * 2 + wave) * 16;
+  const bool active = c0 < ncols;
+  const int col = c0 + li;
+  const int NT = (nb + 15) >> 4;
+  const v4d zero = (v4d){0, 0, 0, 0};
+  v4d b0r = zero, b0i = zero, b1r = zero, b1i = zero, b2r = zero, b2i = zero, b3r = zero, b3i = zero;
+  auto load_tile = [&](int t, v4d& br, v4d& bi) {
+    if (t < NT && active && col < ncols) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + lk + 4 * r;
+        if (row < nb) { const dc v = Xp[(size_t)row * rs + (size_t)col * cs]; br[r] = v.re; bi[r] = v.im; }
+      }
+    }
+  };
+  auto store_tile = [&](int t, const v4d& br, const v4d& bi) {
+    if (t < NT && active && col < ncols) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + lk + 4 * r;
+        if (row < nb) Xp[(size_t)row * rs + (size_t)col * cs] = dc_make(br[r], bi[r]);
+      }
+    }
+  };
+  load_tile(0, b0r, b0i); load_tile(1, b1r, b1i); load_tile(2, b2r, b2i); load_tile(3, b3r, b3i);
+  // slab of diagonal block `blk`: rows 0..31 the inverted 32 x 32 block, below it L's rows down to the panel's last tile
+  auto load_slab = [&](int blk) {
+    const int rows = max(32, NT * 16 - blk * 32);
+    __syncthreads();
+    for (int idx = tid; idx < rows * 32; idx += 128) {
+      const int rr = idx >> 5, c = idx & 31;
+      dc v;
+      if (rr < 32) v = invd[((size_t)blk * 32 + rr) * 32 + c];
+      else v = (blk * 32 + rr < nb && blk * 32 + c < nb) ? T[(size_t)(blk * 32 + rr) * ldt + blk * 32 + c] : dc_make(0.0, 0.0);
+      Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
+    }
+    __syncthreads();
+  };
+  // (Ba; Bb) <- D (Ba; Bb) with the unit-lower-triangular inverse D: X1 = D[16:32, 0:32] (Ba; Bb), X0 = D[0:16, 0:16] Ba
+  auto solve_pair = [&](v4d& ar_, v4d& ai_, v4d& br_, v4d& bi_) {
+    v4d x0r = zero, x0i = zero, x1r = zero, x1i = zero;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double ar = Lre[(16 + li) * TM_PITCH + ks * 4 + lk], ai = Lim[(16 + li) * TM_PITCH + ks * 4 + lk];
+      const double br = (ks < 4) ? ar_[ks & 3] : br_[ks & 3], bi = (ks < 4) ? ai_[ks & 3] : bi_[ks & 3];
+      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x1r, 0, 0, 0);
+      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x1i, 0, 0, 0);
+      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x1r, 0, 0, 0);
+      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x1i, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double ar = Lre[li * TM_PITCH + ks * 4 + lk], ai = Lim[li * TM_PITCH + ks * 4 + lk];
+      const double br = ar_[ks], bi = ai_[ks];
+      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x0r, 0, 0, 0);
+      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x0i, 0, 0, 0);
+      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x0r, 0, 0, 0);
+      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x0i, 0, 0, 0);
+    }
+    ar_ = x0r; ai_ = x0i; br_ = x1r; bi_ = x1i;
+  };
+  // Bt -= L[tile t rows, slab columns] (X0; X1); slab row of tile t below diagonal block 0: 16 t + li
+  auto update_tile = [&](int t, v4d& tr, v4d& ti, const v4d& x0r, const v4d& x0i, const v4d& x1r, const v4d& x1i) {
+    const int lr = t * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double ar = Lre[lr * TM_PITCH + ks * 4 + lk], ai = Lim[lr * TM_PITCH + ks * 4 + lk];
+      const double xr = (ks < 4) ? x0r[ks & 3] : x1r[ks & 3], xi = (ks < 4) ? x0i[ks & 3] : x1i[ks & 3];
+      tr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xr, tr, 0, 0, 0);
+      ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xi, ti, 0, 0, 0);
+      tr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, xi, tr, 0, 0, 0);
+      ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, xr, ti, 0, 0, 0);
+    }
+  };
+  load_slab(0);
+  if (active) {
+    solve_pair(b0r, b0i, b1r, b1i);
+    if (NT > 2) update_tile(2, b2r, b2i, b0r, b0i, b1r, b1i);
+    if (NT > 3) update_tile(3, b3r, b3i, b0r, b0i, b1r, b1i);
+  }
+  if (nb > 32) {
+    load_slab(1);
+    if (active) solve_pair(b2r, b2i, b3r, b3i);
+  }
+  store_tile(0, b0r, b0i); store_tile(1, b1r, b1i); store_tile(2, b2r, b2i); store_tile(3, b3r, b3i);
 }
 
 // ------------------------------------------------------------------ triangular solves for the right-hand sides
@@ -952,6 +1065,7 @@ int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, 
 
 int lu_trsm_configure() {
   MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TM_PITCH * 8));
+  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * TM_PITCH * 8));
   return MA_OK;
 }
 
@@ -964,7 +1078,9 @@ int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, 
   // LDS for the slab of this nb only (34.8 KB at nb = 64): the launch then fits on a CU that already holds two panel
   // workgroups (with the full 128-row 69.6 KB it never did, and queued behind them)
   const size_t lds = 2 * (size_t)std::max(32, ((nb + 15) / 16) * 16) * TM_PITCH * 8;
-  hipLaunchKernelGGL(lu_trsm_mfma_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
+  static const bool wide_only = [] { const char* e = getenv("MA_LU_TRSM_WIDE"); return e && atoi(e) != 0; }();   // diagnostic: the 8-tile kernel for every width
+  auto kern = (nb <= 64 && !wide_only) ? lu_trsm64_kernel : lu_trsm_mfma_kernel;
+  hipLaunchKernelGGL(kern, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
                      reinterpret_cast<const dc*>(invd), reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
   MA_HIP(hipGetLastError());
   return MA_OK;

@@ -31,6 +31,10 @@ struct ma_lu_plan {
   double gemm_flops = 0.0;        // algorithmic flops of the update launches of the last call
   double gemm_cbytes = 0.0;       // and their algorithmic C read + write bytes
   int last_batch = 1;
+  // staged (pipelined) use: the system currently in each slot, and the event that says its A/b are ready
+  c64* cur_A[LU_BATCH_MAX] = {}; c64* cur_B[LU_BATCH_MAX] = {}; int cur_nrhs = 0;
+  hipEvent_t ev_prep[LU_BATCH_MAX] = {};
+  int stage_first_mark = -1;
   hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {}, ev_mid[LU_BATCH_MAX] = {}, ev_big[LU_BATCH_MAX] = {};
   int ensure_batch(int nmat);
   int nrhs_max = 4;
@@ -161,6 +165,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipStreamCreateWithPriority(&P->mid_streams[i], hipStreamNonBlocking, hi);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_mid[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_big[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_prep[i], hipEventDisableTiming);
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
   }
   if (rc) { ma_lu_plan_destroy(P); return rc; }
@@ -174,7 +179,7 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]);
-    if (P->ev_mid[i]) (void)hipEventDestroy(P->ev_mid[i]); if (P->ev_big[i]) (void)hipEventDestroy(P->ev_big[i]); if (P->mid_streams[i]) (void)hipStreamDestroy(P->mid_streams[i]); }
+    if (P->ev_prep[i]) (void)hipEventDestroy(P->ev_prep[i]); if (P->ev_mid[i]) (void)hipEventDestroy(P->ev_mid[i]); if (P->ev_big[i]) (void)hipEventDestroy(P->ev_big[i]); if (P->mid_streams[i]) (void)hipStreamDestroy(P->mid_streams[i]); }
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
     if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); }
@@ -397,6 +402,185 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   if (P->timing) P->ev_valid = true;
   return MA_OK;
 }
+
+// ------------------------------------------------------------------ staged use: a pipeline over many systems
+// factor_solve_batch moves its systems in lock step: all of them are in the update-bound early blocks together and in the
+// latency-bound last blocks together. A driver that has a long sequence of systems (a frequency sweep) can instead keep the
+// slots at DIFFERENT block indices -- slot s starts a third of a factorisation after slot s-1 -- so that in every round one
+// slot brings a big update, one a medium one and one a small one: the caller's stream always has update work and every
+// slot's latency-bound chain has the time of three updates to finish. The driver calls, per slot, stage_begin (A and b of
+// the next system are ready on `stream`), then one stage_round per block index 0..G-1 together with the other slots, then
+// stage_finish (backward substitution; `stream` waits for it). Same kernels, same arithmetic as factor_solve_batch.
+namespace {
+struct Stage {
+  ma_lu_plan* P; int n, tstride, nrhs; hipStream_t st; int rc = MA_OK;
+  std::vector<int> k0s, nbs, rpbs, nblks; int Q = 0, kb = 1, G = 0;
+  explicit Stage(ma_lu_plan* P_, hipStream_t st_) : P(P_), n(P_->n), tstride(P_->n + P_->nrhs_max), nrhs(P_->cur_nrhs), st(st_) {
+    panel_schedule(P, k0s, nbs, rpbs, nblks);
+    Q = (int)k0s.size();
+    kb = std::max(1, std::min(P->kb, LU_KB_MAX));
+    while (kb > 1 && (kb - 1) * P->want_nb > LU_LANE_TSTRIDE) --kb;
+    G = (Q + kb - 1) / kb;
+  }
+  int blk_first(int g) const { return g * kb; }
+  int blk_last(int g) const { return std::min(Q, (g + 1) * kb); }
+  int blk_end(int g) const { int q = blk_last(g) - 1; return k0s[q] + nbs[q]; }
+  hipStream_t lane_stream(int m) const { return P->panel_streams[m]; }
+  int gemm(int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_) {
+    if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
+    P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;
+    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m);
+  }
+  // the look-ahead lane: factor the block column of block g of slot m
+  int lane(int m, int g) {
+    c64* A = P->cur_A[m]; hipStream_t sp = lane_stream(m);
+    const int e = blk_end(g);
+    for (int q = blk_first(g); q < blk_last(g); ++q) {
+      const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+      MA_MARK(t0, sp);
+      if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp))) return rc;
+      MA_MARK(t1, sp);
+      interval(P, t0, t1, 0);
+      const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
+      int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
+      c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
+      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, sp))) return rc;
+      if (a1 < e) {
+        if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
+        if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        MA_MARK(t2, sp);
+        if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
+        MA_MARK(t3, sp);
+        interval(P, t2, t3, 5);
+      }
+    }
+    return MA_OK;
+  }
+  // the per-panel work of block g right of the block, the update of the next block's columns, then the next lane
+  int mwork(int m, int g) {
+    c64* A = P->cur_A[m]; c64* B = P->cur_B[m]; hipStream_t sm = lane_stream(m);
+    const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
+    const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
+    if (g > 0) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));               // block g-1's big update of this slot
+    MA_MARK(t0, sm);
+    for (int q = blk_first(g); q < blk_last(g); ++q)
+      if ((rc = lu_launch_row_moves(A, n, nbs[q], P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs, sm))) return rc;
+    MA_MARK(t1, sm);
+    interval(P, t0, t1, 1);
+    for (int q = blk_first(g); q < blk_last(g); ++q) {
+      const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+      const c64* invd = P->d_invd[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_NB_MAX * 32;
+      MA_MARK(u0, sm);
+      if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + e, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, sm))) return rc;
+      MA_MARK(u1, sm);
+      interval(P, u0, u1, 2);
+      for (int r = 0; r < nrhs && a1 < n; ++r)
+        if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, sm))) return rc;
+      MA_MARK(u2, sm);
+      interval(P, u1, u2, 4);
+      if (a1 < e && (rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, sm))) return rc;
+      MA_MARK(u3, sm);
+      interval(P, u2, u3, 5);
+    }
+    MA_MARK(t3, sm);
+    const bool narrow = nright > 0 && g + 1 < G;
+    if (narrow && (rc = gemm(nright, enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, sm))) return rc;
+    MA_MARK(t4, sm);
+    interval(P, t3, t4, 5);
+    MA_HIP(hipEventRecord(P->ev_mid[m], sm));
+    if (narrow && (rc = lane(m, g + 1))) return rc;
+    return MA_OK;
+  }
+  int big(int m, int g) {
+    c64* A = P->cur_A[m];
+    const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
+    const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
+    if (nright <= 0) return MA_OK;
+    MA_HIP(hipStreamWaitEvent(st, P->ev_mid[m], 0));
+    MA_MARK(t5, st);
+    if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, st))) return rc;
+    MA_MARK(t6, st);
+    interval(P, t5, t6, 3);
+    MA_HIP(hipEventRecord(P->ev_big[m], st));
+    return MA_OK;
+  }
+  int backsub(int m) {
+    c64* A = P->cur_A[m]; c64* B = P->cur_B[m]; hipStream_t sb = lane_stream(m);
+    MA_MARK(t7, sb);
+    for (int q = Q - 1; q >= 0 && nrhs > 0; --q) {
+      const int k0 = k0s[q], nb = nbs[q];
+      if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, sb))) return rc;
+      for (int r = 0; r < nrhs && k0 > 0; ++r)
+        if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, sb))) return rc;
+    }
+    MA_MARK(t8, sb);
+    interval(P, t7, t8, 4);
+    MA_HIP(hipEventRecord(P->ev_panel[m], sb));
+    MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
+    MA_MARK(e_end, st);
+    interval(P, P->stage_first_mark, e_end, 6);
+    P->ev_last = e_end;
+    if (P->timing) P->ev_valid = true;
+    return MA_OK;
+  }
+};
+}  // namespace
+
+extern "C" {
+int ma_lu_plan_num_blocks(ma_lu_plan_t* P, int32_t* blocks) {
+  MA_REQUIRE(P && blocks, MA_ERR_INVALID, "NULL argument");
+  Stage S(P, nullptr);
+  *blocks = S.G;
+  return MA_OK;
+}
+// before a pipelined run: clear the status words and the timing accumulators
+int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
+  MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
+  MA_REQUIRE(P->lookahead && P->panel_overlap, MA_ERR_UNSUPPORTED, "the staged schedule needs the look-ahead lanes (MA_LU_LOOKAHEAD / MA_LU_PANEL_OVERLAP)");
+  MA_HIP(hipSetDevice(P->device));
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->ev_valid = false; P->last_batch = 0;
+  MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
+  MA_MARK(e0, st);
+  P->stage_first_mark = e0;
+  return MA_OK;
+}
+int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, int32_t nrhs, void* stream) {
+  MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "slot %d outside 0..%d", slot, LU_BATCH_MAX - 1);
+  MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max && (nrhs == 0 || dB), MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
+  MA_REQUIRE(P->lookahead && P->panel_overlap, MA_ERR_UNSUPPORTED, "the staged schedule needs the look-ahead lanes");
+  MA_HIP(hipSetDevice(P->device));
+  int rc = P->ensure_batch(slot + 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  P->cur_A[slot] = (c64*)dA; P->cur_B[slot] = (c64*)dB; P->cur_nrhs = nrhs;
+  if (slot + 1 > P->last_batch) P->last_batch = slot + 1;
+  MA_HIP(hipEventRecord(P->ev_prep[slot], st));
+  MA_HIP(hipStreamWaitEvent(P->panel_streams[slot], P->ev_prep[slot], 0));
+  Stage S(P, st);
+  return S.lane(slot, 0);
+}
+// one round: slot slots[i] does block blocks[i] (consecutive rounds of a slot use consecutive blocks 0..G-1)
+int ma_lu_plan_stage_round(ma_lu_plan_t* P, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream) {
+  MA_REQUIRE(P && slots && blocks && count >= 0 && count <= LU_BATCH_MAX, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(P->device));
+  Stage S(P, (hipStream_t)stream);
+  for (int i = 0; i < count; ++i) {
+    MA_REQUIRE(slots[i] >= 0 && slots[i] < LU_BATCH_MAX && P->cur_A[slots[i]] && blocks[i] >= 0 && blocks[i] < S.G, MA_ERR_INVALID, "slot %d / block %d", slots[i], blocks[i]);
+    int rc = S.mwork(slots[i], blocks[i]); if (rc) return rc;
+  }
+  for (int i = 0; i < count; ++i) { int rc = S.big(slots[i], blocks[i]); if (rc) return rc; }
+  return MA_OK;
+}
+int ma_lu_plan_stage_finish(ma_lu_plan_t* P, int32_t slot, void* stream) {
+  MA_REQUIRE(P && slot >= 0 && slot < LU_BATCH_MAX && P->cur_A[slot], MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(P->device));
+  Stage S(P, (hipStream_t)stream);
+  return S.backsub(slot);
+}
+}  // extern "C"
 
 // Solve with factors that an earlier ma_lu_plan_factor_solve_dev call on THIS plan left in d_A (the plan still holds
 // the pivots): b <- P b panel by panel, forward substitution with the unit-lower factor, backward with the upper one.
