@@ -195,12 +195,14 @@ def main():
     ap.add_argument("--workload", choices=["bem", "fem"], default="bem", help="bem = the headline sweep (default); fem = CSR SpMV / smoother bandwidth")
     ap.add_argument("--fem-n", type=int, default=100, help="nodes per box edge for --workload fem")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-theta", type=int, default=51)
     ap.add_argument("--n-phi", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--schedule", choices=["pipeline", "batch"], default="pipeline",
+                    help="pipeline: slots at staggered block indices (staged plan API); batch: lock-step batches of --slots systems")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "3")),
                     help="frequencies in flight per GPU (systems factored as one interleaved batch, 1..4)")
     args = ap.parse_args()
@@ -255,12 +257,58 @@ def main():
             lu_ms[:] += lu.last_timing()
             upd[:] += lu.last_update_stats()
 
-    def run(first, nsteps):
+    def run_batches(first, nsteps):
         s = 0
         while s < nsteps:
             c = min(S, nsteps - s)
             batch(first + s, c)
             s += c
+
+    def assemble_into(step, slot):
+        f = freqs[(rank + step * world) % len(freqs)]
+        k = mm.wave_number(f, C_SOUND)
+        beta = mm.burton_miller_beta_scaled(k, 4.0)
+        plan.assemble_dev(k, beta, As[slot].data_ptr(), xs_[slot].data_ptr(), stream=stream)
+        plan.incident_rhs_dev(k, beta, xs_[slot].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
+
+    def run_pipeline(first, nsteps):
+        """The same frequencies through the staged schedule: slot s works on steps s, s + S, ... and starts a third of a
+        factorisation after slot s - 1, so every round of block updates carries a big, a medium and a small one and no
+        slot's latency-bound panel chain is ever the only thing running. No host synchronisation inside."""
+        slots = max(1, min(S, nsteps))
+        G = lu.num_blocks()
+        off = [s * ((G + slots - 1) // slots) for s in range(slots)]
+        lu.stage_reset(stream)
+        r = 0
+        while True:
+            sl, bl, live = [], [], False
+            for s in range(slots):
+                lr = r - off[s]
+                if lr < 0:
+                    live = True
+                    continue
+                sysno, g = divmod(lr, G)
+                idx = s + slots * sysno
+                if idx >= nsteps:
+                    continue
+                live = True
+                if g == 0:
+                    assemble_into(first + idx, s)
+                    lu.stage_begin(s, As[s].data_ptr(), xs_[s].data_ptr(), 1, stream)
+                sl.append(s); bl.append(g)
+            if not live:
+                break
+            if sl:
+                lu.stage_round(sl, bl, stream)
+            for s, g in zip(sl, bl):
+                if g == G - 1:
+                    lu.stage_finish(s, stream)
+            r += 1
+        if timing:
+            lu_ms[:] += lu.last_timing()
+            upd[:] += lu.last_update_stats()
+
+    run = run_pipeline if args.schedule == "pipeline" else run_batches
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -268,7 +316,9 @@ def main():
         raise SystemExit("warm-up solve failed: %s" % ma.lib().ma_last_error_string().decode())
 
     timing = not args.no_timing
-    plan.set_timing(timing); lu.set_timing(timing)
+    plan.set_timing(timing); lu.set_timing(2 if (timing and args.schedule == "pipeline") else timing)
+    if timing and args.schedule == "pipeline":
+        lu.reserve_events(1800 * args.steps)       # the event pool must not grow inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -285,6 +335,22 @@ def main():
         elapsed = float(t.item())
     if lu.status(stream) != ma.MA_OK:
         raise SystemExit("solve failed: %s" % ma.lib().ma_last_error_string().decode())
+    if timing and args.schedule == "pipeline":
+        # per-call assembly events would need a host synchronisation per system inside the pipeline: the assembly phases
+        # are timed in a separate pass over the same frequencies, after the timed region
+        for i in range(args.steps):
+            assemble_into(args.warmup + i, 0)
+            asm_ms[:] += plan.last_timing()
+        # the other phases of the factorisation (panel, interchanges, U12, substitutions) are bracketed in one lock-step batch
+        # outside the timed region: inside it only the trailing-update launches carry events (every event sits on a
+        # latency-bound chain; all of them cost 2.4 ms per frequency)
+        keep = (lu_ms.copy(), upd.copy(), asm_ms.copy())
+        lu_ms[:] = 0; upd[:] = 0
+        lu.set_timing(1)
+        batch(args.warmup, S)
+        torch.cuda.synchronize()
+        diag_ms = lu_ms / S
+        lu_ms[:], upd[:], asm_ms[:] = keep
     for v in xs_:
         if not np.all(np.isfinite(v.cpu().numpy().view(np.float64))):
             raise SystemExit("non-finite solution")
@@ -299,13 +365,15 @@ def main():
             "config": {"workload": "S10 UV-sphere r=0.1 n_theta=%d n_phi=%d -> %d Tri3 panels; 64 log-spaced frequencies 100 Hz-8 kHz sharded "
                                    "f -> rank f mod N; rigid BC, beta=4i/k, plane wave +z; step = TBEM assembly + incident RHS + dense complex LU "
                                    "solve (zgesv) of one frequency, device-resident" % (args.n_theta, args.n_phi, n),
-                       "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": S,
+                       "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": S, "schedule": args.schedule,
                        "sharding": "frequency sweep, no data-path collective"},
         }
         if timing:
             asm_t = asm_ms.sum() / K * 1e-3
             gemm_t = (lu_ms[3] + lu_ms[7]) / K * 1e-3   # every zgemm launch: main lane + look-ahead lanes
             lu_t = lu_ms[6] / K * 1e-3                 # whole factor+solve on the caller's stream (panel overlaps zgemm)
+            if args.schedule == "pipeline":            # the span also holds the assemblies, which share the caller's stream with the big updates
+                lu_t = max(lu_t - asm_t, 1e-9)
             n_gemm = max(1.0, upd[0] / K)
             gf = upd[1] / K
             out["assembly_pairs_per_s"] = n * n / asm_t
@@ -314,6 +382,11 @@ def main():
                                         "lu_panel": lu_ms[0] / K, "lu_swaps": lu_ms[1] / K, "lu_trsm": lu_ms[2] / K, "lu_zgemm": lu_ms[3] / K,
                                         "lu_rhs_and_triangular": lu_ms[4] / K, "lu_zgemm_lookahead_lanes": lu_ms[7] / K, "lu_total": lu_ms[6] / K,
                                         "note": "lu_panel and lu_zgemm_lookahead_lanes run on the look-ahead streams concurrently with the main lane; lu_panel intervals include queueing behind other systems' panels"}
+            if args.schedule == "pipeline":
+                ph = out["phase_ms_per_step"]
+                for key, idx in (("lu_panel", 0), ("lu_swaps", 1), ("lu_trsm", 2), ("lu_rhs_and_triangular", 4)):
+                    ph[key] = diag_ms[idx]
+                ph["note"] += "; pipeline schedule: lu_panel / lu_swaps / lu_trsm / lu_rhs_and_triangular and the assembly phases come from separate passes after the timed region, lu_zgemm* and lu_total from events inside it (lu_total spans the assemblies too)"
             ach = gf / gemm_t / 1e12
             out["roofline"] = {"kernel": "zgemm3m_sub_kernel (LU trailing updates, v_mfma_f64_16x16x4_f64; every launch of the step)", "bound": "mfma", "achieved": ach,
                                "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic("ma::zgemm3m_sub_kernel"),

@@ -166,6 +166,7 @@ int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* co
  * other slots' current blocks, in one call per round --, then stage_finish (backward substitution; `stream` waits for it,
  * x is in b). stage_reset clears the status words and the timing accumulators before a run; ma_lu_plan_status reports as
  * for the batch. Same kernels and arithmetic as ma_lu_plan_factor_solve_batch_dev. */
+int ma_lu_plan_reserve_events(ma_lu_plan_t* plan, int64_t count);   /* timing events created ahead of a timed run */
 int ma_lu_plan_num_blocks(ma_lu_plan_t* plan, int32_t* blocks);
 int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
@@ -336,7 +337,7 @@ int ma_probe_mfma_f64(int device, double* tflops);
 int ma_bem_plan_set_timing(ma_bem_plan_t* plan, int enable);
 /* out[0]=far kernel, out[1]=near kernel, out[2]=self kernel ms of the last assemble */
 int ma_bem_plan_last_timing(ma_bem_plan_t* plan, double* out3);
-int ma_lu_plan_set_timing(ma_lu_plan_t* plan, int enable);
+int ma_lu_plan_set_timing(ma_lu_plan_t* plan, int enable);   /* 0 off, 1 every phase, 2 only the trailing-update launches (staged runs) */
 /* out[0]=panel kernels (on the look-ahead streams, overlap out[3]), out[1]=row swaps, out[2]=trsm, out[3]=zgemm launches
  * of the main lane, out[4]=right-hand-side and triangular solves (ms); out[5]=number of zgemm launches (all lanes);
  * out[6]=whole factor+solve on the caller's stream (ms); out[7]=zgemm launches of the look-ahead lanes (ms) */

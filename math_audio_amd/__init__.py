@@ -84,6 +84,7 @@ def lib():
             "ma_lu_factorization_destroy": [vp],
             "ma_lu_plan_factor_solve_batch_dev": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_num_blocks": [vp, P(i32)],
+            "ma_lu_plan_reserve_events": [vp, C.c_int64],
             "ma_lu_plan_stage_reset": [vp, vp],
             "ma_lu_plan_stage_begin": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_stage_round": [vp, i32, vp, vp, vp],
@@ -328,6 +329,9 @@ class LuPlan:
         check(lib().ma_lu_plan_num_blocks(self.h, C.byref(g)))
         return g.value
 
+    def reserve_events(self, count):
+        check(lib().ma_lu_plan_reserve_events(self.h, int(count)))
+
     def stage_reset(self, stream=0):
         check(lib().ma_lu_plan_stage_reset(self.h, C.c_void_p(stream)))
 
@@ -346,7 +350,8 @@ class LuPlan:
         return lib().ma_lu_plan_status(self.h, C.c_void_p(stream))
 
     def set_timing(self, on=True):
-        check(lib().ma_lu_plan_set_timing(self.h, 1 if on else 0))
+        """True / 1: every phase is bracketed by HIP events; 2: only the trailing-update launches; False / 0: off."""
+        check(lib().ma_lu_plan_set_timing(self.h, int(on)))
 
     def last_timing(self):
         out = np.zeros(8)

@@ -39,6 +39,7 @@ struct ma_lu_plan {
   int ensure_batch(int nmat);
   int nrhs_max = 4;
   bool timing = false;
+  bool timing_detail = true;
   std::vector<hipEvent_t> ev;     // event pool for per-phase timing
   size_t ev_used = 0;
   struct Iv { int a, b, phase; };
@@ -188,17 +189,27 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   return MA_OK;
 }
 
+// create timing events ahead of a timed run (the pool otherwise grows inside it: a pipelined sweep of K systems records
+// about 1700 K events)
+int ma_lu_plan_reserve_events(ma_lu_plan_t* P, int64_t count) {
+  MA_REQUIRE(P && count >= 0, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(P->device));
+  while ((int64_t)P->ev.size() < count) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); P->ev.push_back(e); }
+  return MA_OK;
+}
+
 int ma_lu_plan_set_timing(ma_lu_plan_t* P, int enable) {
   MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
   P->timing = enable != 0;
+  P->timing_detail = enable != 2;    // 2: only the trailing-update launches are bracketed (fewer events on the latency-bound chains)
   P->ev_valid = false;
   return MA_OK;
 }
 
 // timing bookkeeping: events are taken from a pool; an interval is (begin event, end event, phase)
-static int mark(ma_lu_plan* P, hipStream_t st, int* idx_out) {
+static int mark(ma_lu_plan* P, hipStream_t st, int* idx_out, bool detail = false) {
   *idx_out = -1;
-  if (!P->timing) return MA_OK;
+  if (!P->timing || (detail && !P->timing_detail)) return MA_OK;
   if (P->ev_used >= P->ev.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); P->ev.push_back(e); }
   MA_HIP(hipEventRecord(P->ev[P->ev_used], st));
   *idx_out = (int)P->ev_used++;
@@ -208,6 +219,7 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
   if (a >= 0 && b >= 0) P->iv.push_back({a, b, phase});
 }
 #define MA_MARK(var, stream) int var; if ((rc = mark(P, (stream), &var))) return rc
+#define MA_MARKD(var, stream) int var; if ((rc = mark(P, (stream), &var, true))) return rc   /* phases other than the trailing updates */
 
 // panels of the factorisation: first column, width, rows per panel workgroup, workgroups
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks) {
@@ -437,9 +449,9 @@ struct Stage {
     const int e = blk_end(g);
     for (int q = blk_first(g); q < blk_last(g); ++q) {
       const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
-      MA_MARK(t0, sp);
+      MA_MARKD(t0, sp);
       if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp))) return rc;
-      MA_MARK(t1, sp);
+      MA_MARKD(t1, sp);
       interval(P, t0, t1, 0);
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
@@ -462,25 +474,28 @@ struct Stage {
     const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
     if (g > 0) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));               // block g-1's big update of this slot
-    MA_MARK(t0, sm);
+    MA_MARKD(t0, sm);
     for (int q = blk_first(g); q < blk_last(g); ++q)
       if ((rc = lu_launch_row_moves(A, n, nbs[q], P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs, sm))) return rc;
-    MA_MARK(t1, sm);
+    MA_MARKD(t1, sm);
     interval(P, t0, t1, 1);
     for (int q = blk_first(g); q < blk_last(g); ++q) {
       const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
       const c64* invd = P->d_invd[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_NB_MAX * 32;
-      MA_MARK(u0, sm);
+      MA_MARKD(u0, sm);
       if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + e, (size_t)n, nright, nrhs ? B + k0 : nullptr, (size_t)n, nrhs, sm))) return rc;
-      MA_MARK(u1, sm);
+      MA_MARKD(u1, sm);
       interval(P, u0, u1, 2);
       for (int r = 0; r < nrhs && a1 < n; ++r)
         if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, sm))) return rc;
-      MA_MARK(u2, sm);
+      MA_MARKD(u2, sm);
       interval(P, u1, u2, 4);
-      if (a1 < e && (rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, sm))) return rc;
-      MA_MARK(u3, sm);
-      interval(P, u2, u3, 5);
+      if (a1 < e && nright > 0) {
+        MA_MARK(v0, sm);
+        if ((rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, sm))) return rc;
+        MA_MARK(v1, sm);
+        interval(P, v0, v1, 5);
+      }
     }
     MA_MARK(t3, sm);
     const bool narrow = nright > 0 && g + 1 < G;
@@ -506,14 +521,14 @@ struct Stage {
   }
   int backsub(int m) {
     c64* A = P->cur_A[m]; c64* B = P->cur_B[m]; hipStream_t sb = lane_stream(m);
-    MA_MARK(t7, sb);
+    MA_MARKD(t7, sb);
     for (int q = Q - 1; q >= 0 && nrhs > 0; --q) {
       const int k0 = k0s[q], nb = nbs[q];
       if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, sb))) return rc;
       for (int r = 0; r < nrhs && k0 > 0; ++r)
         if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, sb))) return rc;
     }
-    MA_MARK(t8, sb);
+    MA_MARKD(t8, sb);
     interval(P, t7, t8, 4);
     MA_HIP(hipEventRecord(P->ev_panel[m], sb));
     MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));

@@ -187,3 +187,63 @@ def test_lu_factorize_then_solve_and_lu_solve(gpu, n):
     with pytest.raises(ma.MaError) as e:
         ma.LuFactorization(np.ones((4, 4)))
     assert e.value.status == ma.MA_ERR_SINGULAR
+
+
+def test_staged_pipeline_is_bitwise_the_single_solve(gpu):
+    """The staged plan API (slots at their own block index, staggered by a third of a factorisation) runs the same kernels on
+    the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit."""
+    import torch
+    n = 900
+    dev = torch.device("cuda", 0)
+    mats = [_rand(n, 300 + i) for i in range(7)]
+    lu = ma.LuPlan(n)
+    st = torch.cuda.current_stream().cuda_stream
+    singles = []
+    for A, b in mats:
+        dA = torch.tensor(A, device=dev).reshape(-1); db = torch.tensor(b, device=dev)
+        lu.factor_solve_dev(dA.data_ptr(), db.data_ptr(), 1, st)
+        assert lu.status(st) == ma.MA_OK
+        singles.append((dA.cpu().numpy().copy(), db.cpu().numpy().copy()))
+    S = 3
+    G = lu.num_blocks()
+    assert G >= 3
+    bufA = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
+    bufB = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
+    srcA = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; srcB = [torch.tensor(b, device=dev) for _, b in mats]
+    outA = [None] * len(mats); outB = [None] * len(mats)
+    off = [s * ((G + S - 1) // S) for s in range(S)]
+    lu.stage_reset(st)
+    r = 0
+    while True:
+        sl, bl, live = [], [], False
+        for s in range(S):
+            lr = r - off[s]
+            if lr < 0:
+                live = True
+                continue
+            sysno, g = divmod(lr, G)
+            idx = s + S * sysno
+            if idx >= len(mats):
+                continue
+            live = True
+            if g == 0:
+                bufA[s].copy_(srcA[idx]); bufB[s].copy_(srcB[idx])
+                lu.stage_begin(s, bufA[s].data_ptr(), bufB[s].data_ptr(), 1, st)
+            sl.append(s); bl.append(g)
+        if not live:
+            break
+        if sl:
+            lu.stage_round(sl, bl, st)
+        for s, g in zip(sl, bl):
+            if g == G - 1:
+                lu.stage_finish(s, st)
+                idx = s + S * ((r - off[s]) // G)
+                outA[idx] = bufA[s].clone(); outB[idx] = bufB[s].clone()
+        r += 1
+    assert lu.status(st) == ma.MA_OK
+    for i, (Af, xf) in enumerate(singles):
+        assert np.array_equal(outA[i].cpu().numpy(), Af), i
+        assert np.array_equal(outB[i].cpu().numpy(), xf), i
+    with pytest.raises(ma.MaError):
+        lu.stage_round([0], [G], st)                       # block index out of range
+    lu.close()
