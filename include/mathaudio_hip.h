@@ -172,6 +172,8 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
 int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);
+/* after stage_finish: the slot's status word (0, or 1 + the column of the first zero pivot) copied to a device int on `stream` */
+int ma_lu_plan_stage_info_dev(ma_lu_plan_t* plan, int32_t slot, int32_t* d_out, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -89,6 +89,7 @@ def lib():
             "ma_lu_plan_stage_begin": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_stage_round": [vp, i32, vp, vp, vp],
             "ma_lu_plan_stage_finish": [vp, i32, vp],
+            "ma_lu_plan_stage_info_dev": [vp, i32, vp, vp],
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],

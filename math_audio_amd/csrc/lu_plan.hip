@@ -572,6 +572,7 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
   hipStream_t st = (hipStream_t)stream;
   P->cur_A[slot] = (c64*)dA; P->cur_B[slot] = (c64*)dB; P->cur_nrhs = nrhs;
   if (slot + 1 > P->last_batch) P->last_batch = slot + 1;
+  MA_HIP(hipMemsetAsync(P->pws.info + slot, 0, sizeof(int), st));          // this slot's first-zero-pivot word
   MA_HIP(hipEventRecord(P->ev_prep[slot], st));
   MA_HIP(hipStreamWaitEvent(P->panel_streams[slot], P->ev_prep[slot], 0));
   Stage S(P, st);
@@ -587,6 +588,13 @@ int ma_lu_plan_stage_round(ma_lu_plan_t* P, int32_t count, const int32_t* slots,
     int rc = S.mwork(slots[i], blocks[i]); if (rc) return rc;
   }
   for (int i = 0; i < count; ++i) { int rc = S.big(slots[i], blocks[i]); if (rc) return rc; }
+  return MA_OK;
+}
+// after stage_finish: copy the slot's status word (0, or 1 + the column of the first zero pivot) to a device int on `stream`
+int ma_lu_plan_stage_info_dev(ma_lu_plan_t* P, int32_t slot, int32_t* d_out, void* stream) {
+  MA_REQUIRE(P && d_out && slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(P->device));
+  MA_HIP(hipMemcpyAsync(d_out, P->pws.info + slot, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return MA_OK;
 }
 int ma_lu_plan_stage_finish(ma_lu_plan_t* P, int32_t slot, void* stream) {
