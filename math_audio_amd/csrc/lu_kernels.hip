@@ -338,75 +338,96 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
 // Blocks 1.. of the same launch invert the 32 x 32 unit-lower diagonal blocks of the panel's L11 (they are final once
 // the panel kernel has ended): invd[d*32 + i][j] = (L_dd^-1)[i][j], padded with the identity beyond nb. Lane j carries
 // column j of the inverse through the forward substitution; the multipliers are LDS broadcasts.
-__device__ void lu_invert_diag32(const dc* __restrict__ T, int ldt, int nb, int d, dc* __restrict__ invd) {
+// LDS of lu_perm_kernel, shared by its two roles: the 16 x 16 blocks of one 32 x 32 diagonal block and of its inverse (26 KB),
+// or the fold's index arrays (2 KB). Kept well under 31 KB: on a CU that holds two panel workgroups and a trailing-update
+// workgroup that is what is left, and a launch that needs more waits for the update to drain (these launches are on
+// every system's critical chain; with 35 KB they took 79 us on average and up to 4 ms instead of 17 us).
+struct PermLds {
+  union {
+    struct { dc LA[16][17], LB[16][17], LC[16][17], XA[16][17], XB[16][17], XC[16][17]; } inv;
+    struct { int top[LU_NB_MAX], ext_row[LU_NB_MAX], ext_src[LU_NB_MAX], piv[LU_NB_MAX]; } fold;
+  };
+};
+
+__device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, int nb, int d, dc* __restrict__ invd) {
   // L = [A 0; C B] in 16 x 16 blocks:  L^-1 = [A^-1 0; -B^-1 C A^-1  B^-1].  Lanes 0-15 / 16-31 carry the columns of
   // A^-1 / B^-1 through a 16-row forward substitution (a quarter of the 32-row dependent chain); then lane (j, q)
-  // forms column j of W = C A^-1 and rows 4q..4q+3 of -B^-1 W: products with 16 independent accumulators.
-  __shared__ dc Ls[32 * 33];
-  __shared__ dc Xs[32 * 33];
+  // forms rows 4q..4q+3 of column j of W = C A^-1 and of -B^-1 W.
+  auto& V = S.inv;
   const int lane = threadIdx.x, base = d * 32;
   const int m = min(32, nb - base);
 #pragma unroll 4
   for (int idx = lane; idx < 1024; idx += 64) {
     const int i = idx >> 5, k = idx & 31;
-    Ls[i * 33 + k] = (i < m && k < i) ? T[(size_t)(base + i) * ldt + base + k] : dc_make(0.0, 0.0);
-    Xs[i * 33 + k] = dc_make(0.0, 0.0);
+    if (i < 16 && k >= 16) continue;
+    const dc v = (i < m && k < i) ? T[(size_t)(base + i) * ldt + base + k] : dc_make(0.0, 0.0);
+    if (i < 16) V.LA[i][k] = v; else if (k >= 16) V.LB[i - 16][k - 16] = v; else V.LC[i - 16][k] = v;
   }
   __syncthreads();
   if (lane < 32) {
     // column j of A^-1 (lanes 0-15) / B^-1 (lanes 16-31): x_i = e_i - sum_{k<i} l_ik x_k, the x_k read back from this lane's
-    // own column of Xs (registers are what this kernel must not need)
-    const int off = lane & 16, j = lane & 15;
+    // own column (registers are what this kernel must not need)
+    const int j = lane & 15;
+    dc (*Lm)[17] = lane < 16 ? V.LA : V.LB;
+    dc (*Xm)[17] = lane < 16 ? V.XA : V.XB;
     for (int i = 0; i < 16; ++i) {
       dc acc = dc_make(i == j ? 1.0 : 0.0, 0.0);
       for (int k = j; k < i; ++k) {                       // x_k = 0 for k < j
-        const dc t = Ls[(off + i) * 33 + off + k], xk = Xs[(off + k) * 33 + off + j];
+        const dc t = Lm[i][k], xk = Xm[k][j];
         acc.re -= t.re * xk.re - t.im * xk.im; acc.im -= t.re * xk.im + t.im * xk.re;
       }
-      Xs[(off + i) * 33 + off + j] = acc;
+      Xm[i][j] = acc;
     }
   }
   __syncthreads();
   {
-    // lane (j, q): rows 4q..4q+3 of column j of W = C A^-1, parked in the (empty) upper-right block of Ls, then the same
-    // rows of -B^-1 W. Four accumulators per lane: the kernel must stay small in registers, it runs beside trailing updates.
     const int j = lane & 15, q = lane >> 4;
     dc w[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[r] = dc_make(0.0, 0.0);
 #pragma unroll 1
     for (int k = 0; k < 16; ++k) {
-      const dc a = Xs[k * 33 + j];                        // A^-1[k][j]
+      const dc a = (k >= j) ? V.XA[k][j] : dc_make(0.0, 0.0);          // A^-1 is lower triangular; above the diagonal XA was never written
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const dc c = Ls[(16 + 4 * q + r) * 33 + k]; w[r].re += c.re * a.re - c.im * a.im; w[r].im += c.re * a.im + c.im * a.re; }
+      for (int r = 0; r < 4; ++r) { const dc c = V.LC[4 * q + r][k]; w[r].re += c.re * a.re - c.im * a.im; w[r].im += c.re * a.im + c.im * a.re; }
     }
+    __syncthreads();                                      // LA is free now: W is parked there
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ls[(4 * q + r) * 33 + 16 + j] = w[r];
+    for (int r = 0; r < 4; ++r) V.LA[4 * q + r][j] = w[r];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * q + r;
       dc acc = dc_make(0.0, 0.0);
 #pragma unroll 2
-      for (int k = 0; k < 16; ++k) {
-        const dc bi = Xs[(16 + i) * 33 + 16 + k], wk = Ls[k * 33 + 16 + j];
+      for (int k = 0; k <= i; ++k) {                      // B^-1 is lower triangular
+        const dc bi = V.XB[i][k], wk = V.LA[k][j];
         acc.re -= bi.re * wk.re - bi.im * wk.im; acc.im -= bi.re * wk.im + bi.im * wk.re;
       }
-      Xs[(16 + i) * 33 + j] = acc;
+      V.XC[i][j] = acc;
     }
   }
   __syncthreads();
 #pragma unroll 4
-  for (int idx = lane; idx < 1024; idx += 64) invd[(size_t)base * 32 + idx] = Xs[(idx >> 5) * 33 + (idx & 31)];
+  for (int idx = lane; idx < 1024; idx += 64) {
+    const int i = idx >> 5, k = idx & 31;
+    dc v = dc_make(0.0, 0.0);
+    if (i < 16) { if (k <= i) v = V.XA[i][k]; }
+    else if (k >= 16) { if (k <= i) v = V.XB[i - 16][k - 16]; }
+    else v = V.XC[i - 16][k];
+    invd[(size_t)base * 32 + idx] = v;
+  }
 }
+
 
 __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
                                                      const dc* __restrict__ T, int ldt, dc* __restrict__ invd) {
-  if (blockIdx.x > 0) { lu_invert_diag32(T, ldt, nb, blockIdx.x - 1, invd); return; }
-  __shared__ int top[LU_NB_MAX];       // content of row k0+c
-  __shared__ int ext_row[LU_NB_MAX];   // rows >= k0+nb that were touched
-  __shared__ int ext_src[LU_NB_MAX];
-  __shared__ int piv[LU_NB_MAX];       // the panel's pivots, fetched in one coalesced load (not one dependent load per column)
+  __shared__ PermLds S;
+  if (blockIdx.x > 0) { lu_invert_diag32(S, T, ldt, nb, blockIdx.x - 1, invd); return; }
+  int* top = S.fold.top;               // content of row k0+c
+  int* ext_row = S.fold.ext_row;       // rows >= k0+nb that were touched
+  int* ext_src = S.fold.ext_src;
+  int* piv = S.fold.piv;               // the panel's pivots, fetched in one coalesced load (not one dependent load per column)
   const int lane = threadIdx.x;
   for (int c = lane; c < nb; c += 64) { top[c] = k0 + c; piv[c] = ipiv[k0 + c]; }
   int next = 0;
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
                                                            dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* Lre = reinterpret_cast<double*>(smem);
-  double* Lim = Lre + (size_t)max(32, ((nb + 15) >> 4) * 16) * TM_PITCH;
+  double* Lim = Lre + 32 * TM_PITCH;                    // two planes of 32 rows: 17 KB, loaded three times (see below)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const bool extra = (int)blockIdx.x >= nmain;
@@ -627,15 +648,15 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
     }
   };
   load_tile(0, b0r, b0i); load_tile(1, b1r, b1i); load_tile(2, b2r, b2i); load_tile(3, b3r, b3i);
-  // slab of diagonal block `blk`: rows 0..31 the inverted 32 x 32 block, below it L's rows down to the panel's last tile
-  auto load_slab = [&](int blk) {
-    const int rows = max(32, NT * 16 - blk * 32);
+  // 32 rows of LDS at a time -- the inverted diagonal block `blk` (what = 0) or L's rows 32..63 below diagonal block 0
+  // (what = 1) -- so that the launch needs 17 KB, not 35: it has to fit on CUs that hold panel and update workgroups
+  auto load_rows = [&](int what, int blk) {
     __syncthreads();
-    for (int idx = tid; idx < rows * 32; idx += 128) {
+    for (int idx = tid; idx < 32 * 32; idx += 128) {
       const int rr = idx >> 5, c = idx & 31;
       dc v;
-      if (rr < 32) v = invd[((size_t)blk * 32 + rr) * 32 + c];
-      else v = (blk * 32 + rr < nb && blk * 32 + c < nb) ? T[(size_t)(blk * 32 + rr) * ldt + blk * 32 + c] : dc_make(0.0, 0.0);
+      if (what == 0) v = invd[((size_t)blk * 32 + rr) * 32 + c];
+      else v = (32 + rr < nb && c < nb) ? T[(size_t)(32 + rr) * ldt + c] : dc_make(0.0, 0.0);
       Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
     }
     __syncthreads();
@@ -663,9 +684,9 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
     }
     ar_ = x0r; ai_ = x0i; br_ = x1r; bi_ = x1i;
   };
-  // Bt -= L[tile t rows, slab columns] (X0; X1); slab row of tile t below diagonal block 0: 16 t + li
+  // Bt -= L[tile t rows, columns 0..31] (X0; X1); tile t (2 or 3) sits in LDS rows 16 (t - 2) + li
   auto update_tile = [&](int t, v4d& tr, v4d& ti, const v4d& x0r, const v4d& x0i, const v4d& x1r, const v4d& x1i) {
-    const int lr = t * 16 + li;
+    const int lr = (t - 2) * 16 + li;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const double ar = Lre[lr * TM_PITCH + ks * 4 + lk], ai = Lim[lr * TM_PITCH + ks * 4 + lk];
@@ -676,14 +697,15 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
       ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, xr, ti, 0, 0, 0);
     }
   };
-  load_slab(0);
-  if (active) {
-    solve_pair(b0r, b0i, b1r, b1i);
-    if (NT > 2) update_tile(2, b2r, b2i, b0r, b0i, b1r, b1i);
-    if (NT > 3) update_tile(3, b3r, b3i, b0r, b0i, b1r, b1i);
-  }
+  load_rows(0, 0);
+  if (active) solve_pair(b0r, b0i, b1r, b1i);
   if (nb > 32) {
-    load_slab(1);
+    load_rows(1, 0);
+    if (active) {
+      update_tile(2, b2r, b2i, b0r, b0i, b1r, b1i);
+      if (NT > 3) update_tile(3, b3r, b3i, b0r, b0i, b1r, b1i);
+    }
+    load_rows(0, 1);
     if (active) solve_pair(b2r, b2i, b3r, b3i);
   }
   store_tile(0, b0r, b0i); store_tile(1, b1r, b1i); store_tile(2, b2r, b2i); store_tile(3, b3r, b3i);
@@ -1065,7 +1087,7 @@ int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, 
 
 int lu_trsm_configure() {
   MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TM_PITCH * 8));
-  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * TM_PITCH * 8));
+
   return MA_OK;
 }
 
@@ -1077,7 +1099,8 @@ int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, 
   const int nmain = ncols > 0 ? (ncols + 31) / 32 : 0;
   // LDS for the slab of this nb only (34.8 KB at nb = 64): the launch then fits on a CU that already holds two panel
   // workgroups (with the full 128-row 69.6 KB it never did, and queued behind them)
-  const size_t lds = 2 * (size_t)std::max(32, ((nb + 15) / 16) * 16) * TM_PITCH * 8;
+  static const bool wide_only_ = [] { const char* e = getenv("MA_LU_TRSM_WIDE"); return e && atoi(e) != 0; }();
+  const size_t lds = (nb <= 64 && !wide_only_) ? 2 * (size_t)32 * TM_PITCH * 8 : 2 * (size_t)std::max(32, ((nb + 15) / 16) * 16) * TM_PITCH * 8;
   static const bool wide_only = [] { const char* e = getenv("MA_LU_TRSM_WIDE"); return e && atoi(e) != 0; }();   // diagnostic: the 8-tile kernel for every width
   auto kern = (nb <= 64 && !wide_only) ? lu_trsm64_kernel : lu_trsm_mfma_kernel;
   hipLaunchKernelGGL(kern, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
