@@ -587,7 +587,13 @@ int ma_lu_plan_stage_round(ma_lu_plan_t* P, int32_t count, const int32_t* slots,
     MA_REQUIRE(slots[i] >= 0 && slots[i] < LU_BATCH_MAX && P->cur_A[slots[i]] && blocks[i] >= 0 && blocks[i] < S.G, MA_ERR_INVALID, "slot %d / block %d", slots[i], blocks[i]);
     int rc = S.mwork(slots[i], blocks[i]); if (rc) return rc;
   }
-  for (int i = 0; i < count; ++i) { int rc = S.big(slots[i], blocks[i]); if (rc) return rc; }
+  // the big updates of the round, smallest first: the slot closest to the end of its factorisation has the least slack in
+  // its chain (its next block waits for this update), the one at the start has the most
+  int order[LU_BATCH_MAX];
+  for (int i = 0; i < count; ++i) order[i] = i;
+  static const bool by_size = [] { const char* e = getenv("MA_LU_STAGE_ORDER"); return !e || atoi(e) != 0; }();
+  if (by_size) std::sort(order, order + count, [&](int a, int b) { return blocks[a] > blocks[b]; });
+  for (int i = 0; i < count; ++i) { int rc = S.big(slots[order[i]], blocks[order[i]]); if (rc) return rc; }
   return MA_OK;
 }
 // after stage_finish: copy the slot's status word (0, or 1 + the column of the first zero pivot) to a device int on `stream`

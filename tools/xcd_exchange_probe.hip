@@ -231,5 +231,29 @@ int main() {
   run4<0, 0>(f8, ticks, rounds); run4<0, 1>(f8, ticks, rounds); run4<0, 8>(f8, ticks, rounds); run4<0, 32>(f8, ticks, rounds);
   run4<20, 1>(f8, ticks, rounds); run4<40, 1>(f8, ticks, rounds); run4<60, 1>(f8, ticks, rounds); run4<40, 8>(f8, ticks, rounds);
   run4<60, 16>(f8, ticks, rounds); run4<80, 8>(f8, ticks, rounds);
+  {  // two (three) independent flat rounds at the same time on separate streams and flag arrays: do they slow each other?
+    hipStream_t sa[3]; unsigned long long* fl[3]; u64* tk[3];
+    for (int i = 0; i < 3; ++i) { hipStreamCreateWithFlags(&sa[i], hipStreamNonBlocking); hipMalloc(&fl[i], 4096 * 8); hipMalloc(&tk[i], 8); }
+    for (int nk = 1; nk <= 3; ++nk) {
+      for (int i = 0; i < nk; ++i) { hipMemset(fl[i], 0, 4096 * 8); hipMemset(tk[i], 0, 8); }
+      hipDeviceSynchronize();
+      for (int i = 0; i < nk; ++i) hipLaunchKernelGGL((round4_kernel<40, 1>), dim3(227), dim3(64), 0, sa[i], fl[i], rounds, tk[i]);
+      hipDeviceSynchronize();
+      printf("%d concurrent flat rounds of 227 workgroups:", nk);
+      for (int i = 0; i < nk; ++i) { u64 t; hipMemcpy(&t, tk[i], 8, hipMemcpyDeviceToHost); printf(" %.3f us", t / 100.0 / rounds); }
+      printf(" per round\n");
+    }
+    unsigned *f3[3], *x3[3];
+    for (int i = 0; i < 3; ++i) { hipMalloc(&f3[i], 256 * 64 * 4); hipMalloc(&x3[i], 64 * 64 * 4); }
+    for (int nk = 1; nk <= 3; ++nk) {
+      for (int i = 0; i < nk; ++i) { hipMemset(f3[i], 0, 256 * 64 * 4); hipMemset(x3[i], 0, 64 * 64 * 4); hipMemset(tk[i], 0, 8); }
+      hipDeviceSynchronize();
+      for (int i = 0; i < nk; ++i) hipLaunchKernelGGL(round3_kernel, dim3(224), dim3(64), 0, sa[i], f3[i], x3[i], 8, 32, rounds, tk[i]);
+      hipDeviceSynchronize();
+      printf("%d concurrent two-level rounds (8 groups, flags 128 B apart) of 224 workgroups:", nk);
+      for (int i = 0; i < nk; ++i) { u64 t; hipMemcpy(&t, tk[i], 8, hipMemcpyDeviceToHost); printf(" %.3f us", t / 100.0 / rounds); }
+      printf(" per round\n");
+    }
+  }
   return 0;
 }
