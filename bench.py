@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--workload", choices=["bem", "fem"], default="bem", help="bem = the headline sweep (default); fem = CSR SpMV / smoother bandwidth")
     ap.add_argument("--fem-n", type=int, default=100, help="nodes per box edge for --workload fem")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-theta", type=int, default=51)
     ap.add_argument("--n-phi", type=int, default=100)
