@@ -172,8 +172,8 @@ def fem_workload(args):
            "data": "synthetic", "config": {"workload": "F1M-family box 5x4x2.5 m, %d^3 nodes, P1 Kuhn tets: N=%d, nnz=%d; A = K - k^2 M fused; k = 2 pi 100/343 + 0.01i" % (args.fem_n, n, nnz),
                                            "host_generation_s": t_gen},
            "kernels": res,
-           "roofline": {"kernel": "sell_rows_kernel (SpMV, sliced-ELLPACK copy of the CSR operator)", "bound": "hbm", "achieved": res["spmv"]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": res["spmv"]["frac_of_8TBs"], "traffic": pmc_traffic("ma::sell_rows_kernel<true, 0>"),
+           "roofline": {"kernel": "sell_rows_kernel (SpMV, sliced-ELLPACK copy of the CSR operator, 16-bit relative columns)", "bound": "hbm", "achieved": res["spmv"]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": res["spmv"]["frac_of_8TBs"], "traffic": pmc_traffic("ma::sell_rows_kernel<true, 0, true>"),
                         "algorithmic_bytes_per_launch": byts["spmv"]}}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(CsrView A, const dc* __re
 // the slice's rows sit side by side, so every load of K, M (or values) and col is one contiguous 512-B / 256-B run and
 // no cross-lane reduction is needed; rows of a structured FEM mesh have neighbouring columns, so the gather of x is
 // nearly coalesced too. Used when padding to the slice's longest row costs < 30 % (a P1 tet mesh: 4 %).
-template <bool KM, int EPI>
+template <bool KM, int EPI, bool C16>
 __global__ __launch_bounds__(256) void sell_rows_kernel(CsrView A, const dc* __restrict__ x, const dc* __restrict__ b,
                                                         dc* __restrict__ out, double omega) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -75,13 +75,14 @@ __global__ __launch_bounds__(256) void sell_rows_kernel(CsrView A, const dc* __r
   const int width = (int)((A.sell_ptr[slice + 1] - beg) >> 6);
   double sr = 0.0, si = 0.0;
   const long long base = beg + lane;
+  const int rowc = (int)(row < A.n ? row : A.n - 1);       // 16-bit columns are stored relative to the row
 #pragma unroll 4
   for (int kk = 0; kk < width; ++kk) {
     const long long idx = base + (long long)kk * 64;
     double ar, ai;
     if (KM) { const double kv = A.sell_K[idx], mv = A.sell_M[idx]; ar = kv - A.k2_re * mv; ai = -(A.k2_im * mv); }
     else { const dc v = A.sell_val[idx]; ar = v.re; ai = v.im; }
-    const dc xv = x[A.sell_col[idx]];
+    const dc xv = x[C16 ? rowc + (int)A.sell_col16[idx] : A.sell_col[idx]];
     sr += ar * xv.re - ai * xv.im;
     si += ar * xv.im + ai * xv.re;
   }
@@ -102,18 +103,22 @@ __global__ __launch_bounds__(256) void sell_rows_kernel(CsrView A, const dc* __r
   }
 }
 
-template <bool KM>
-static int launch_sell(const CsrView& A, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st) {
+template <bool KM, bool C16>
+static int launch_sell2(const CsrView& A, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st) {
   dim3 grid((unsigned)((A.n + 255) / 256)), block(256);
   const dc* xx = reinterpret_cast<const dc*>(x); const dc* bb = reinterpret_cast<const dc*>(b); dc* oo = reinterpret_cast<dc*>(out);
   switch (epi) {
-    case 0: hipLaunchKernelGGL((sell_rows_kernel<KM, 0>), grid, block, 0, st, A, xx, bb, oo, omega); break;
-    case 1: hipLaunchKernelGGL((sell_rows_kernel<KM, 1>), grid, block, 0, st, A, xx, bb, oo, omega); break;
-    case 2: hipLaunchKernelGGL((sell_rows_kernel<KM, 2>), grid, block, 0, st, A, xx, bb, oo, omega); break;
-    default: hipLaunchKernelGGL((sell_rows_kernel<KM, 3>), grid, block, 0, st, A, xx, bb, oo, omega); break;
+    case 0: hipLaunchKernelGGL((sell_rows_kernel<KM, 0, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
+    case 1: hipLaunchKernelGGL((sell_rows_kernel<KM, 1, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
+    case 2: hipLaunchKernelGGL((sell_rows_kernel<KM, 2, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
+    default: hipLaunchKernelGGL((sell_rows_kernel<KM, 3, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
   }
   MA_HIP(hipGetLastError());
   return MA_OK;
+}
+template <bool KM>
+static int launch_sell(const CsrView& A, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st) {
+  return A.sell_col16 ? launch_sell2<KM, true>(A, epi, x, b, out, omega, st) : launch_sell2<KM, false>(A, epi, x, b, out, omega, st);
 }
 
 // per-wavenumber diagonal data: dinv_i = 1 / a_ii (1 if |a_ii| <= 1e-15, amg.rs:400-413) and

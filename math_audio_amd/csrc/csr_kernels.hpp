@@ -20,6 +20,7 @@ struct CsrView {
   // sliced ELLPACK copy (slices of 64 rows = one wavefront, entries column-major inside a slice), or null
   const long long* sell_ptr;   // n_slices + 1 entry offsets
   const int* sell_col;
+  const short* sell_col16;     // column - row as 16 bits when every entry of the matrix allows it (banded FEM operators): 2 B less per entry
   const ::ma::dc* sell_val;
   const double* sell_K;
   const double* sell_M;

@@ -22,7 +22,7 @@ struct ma_csr {
   bool diag_valid = false;
   double zero_diag_dinv = 1.0;
   // sliced-ELLPACK copy (null when the padding would cost too much or MA_CSR_SELL=0)
-  long long* d_sell_ptr = nullptr; int* d_sell_col = nullptr; c64* d_sell_val = nullptr; double* d_sell_K = nullptr; double* d_sell_M = nullptr;
+  long long* d_sell_ptr = nullptr; int* d_sell_col = nullptr; short* d_sell_col16 = nullptr; c64* d_sell_val = nullptr; double* d_sell_K = nullptr; double* d_sell_M = nullptr;
   int* d_sell_src = nullptr; long long sell_tot = 0;      // CSR index behind every sliced-ELLPACK slot (-1 = padding)
   // boundary matrices of the HelmholtzAssembler (tag -> real values on the shared pattern); with a non-empty coefficient
   // set the complex values are materialised (assemble) and the kernels run in complex-value mode
@@ -38,7 +38,7 @@ struct ma_csr {
     if (km && materialised) { v.K = nullptr; v.M = nullptr; }
     v.k2_re = k2_re; v.k2_im = k2_im; v.dinv = reinterpret_cast<const dc*>(d_dinv); v.l1 = d_l1;
     v.zero_diag_dinv = zero_diag_dinv;
-    v.sell_ptr = d_sell_ptr; v.sell_col = d_sell_col; v.sell_val = reinterpret_cast<const dc*>(d_sell_val); v.sell_K = d_sell_K; v.sell_M = d_sell_M;
+    v.sell_ptr = d_sell_ptr; v.sell_col = d_sell_col; v.sell_col16 = d_sell_col16; v.sell_val = reinterpret_cast<const dc*>(d_sell_val); v.sell_K = d_sell_K; v.sell_M = d_sell_M;
     if (km && materialised && !d_sell_val) v.sell_ptr = nullptr;      // no complex sliced copy: the CSR-vector kernel serves it
     return v;
   }
@@ -54,7 +54,7 @@ int pick_group(long long n, long long nnz) {
 }
 void free_all(ma_csr* h) {
   void* p[] = {h->d_rowptr, h->d_col, h->d_val, h->d_K, h->d_M, h->d_dinv, h->d_l1, h->d_x, h->d_y, h->d_b,
-               h->d_sell_ptr, h->d_sell_col, h->d_sell_val, h->d_sell_K, h->d_sell_M, h->d_sell_src};
+               h->d_sell_ptr, h->d_sell_col, h->d_sell_col16, h->d_sell_val, h->d_sell_K, h->d_sell_M, h->d_sell_src};
   for (double* b : h->d_B) if (b) (void)hipFree(b);
   for (int* r : h->d_lev_rows) if (r) (void)hipFree(r);
   for (void* q : p) if (q) (void)hipFree(q);
@@ -119,8 +119,28 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
         } else sc[q] = (int)(r < n ? r : 0);             // padding: zero coefficient, a column that is in cache anyway
       }
     }
+  // columns relative to the row in 16 bits when the whole operator allows it (MA_CSR_COL16=0 keeps 32-bit columns)
+  bool c16 = true;
+  if (const char* e16 = getenv("MA_CSR_COL16")) c16 = atoi(e16) != 0;
+  std::vector<short> sc16;
+  if (c16) {
+    sc16.assign((size_t)tot, 0);
+    for (int64_t s2 = 0; s2 < ns && c16; ++s2)
+      for (int l = 0; l < 64 && c16; ++l) {
+        const int64_t r = s2 * 64 + l, rc_ = std::min<int64_t>(r, n - 1);
+        const long long w = (sp[(size_t)s2 + 1] - sp[(size_t)s2]) / 64;
+        const int64_t len = r < n ? rowptr[r + 1] - rowptr[r] : 0;
+        for (long long kk = 0; kk < len && kk < w; ++kk) {
+          const long long dlt = (long long)col[rowptr[r] + kk] - (long long)rc_;
+          if (dlt < -32768 || dlt > 32767) { c16 = false; break; }
+          sc16[(size_t)(sp[(size_t)s2] + kk * 64 + l)] = (short)dlt;
+        }
+      }
+  }
   hipError_t e = hipMalloc(&h->d_sell_ptr, sizeof(long long) * ((size_t)ns + 1));
   if (e == hipSuccess) e = hipMalloc(&h->d_sell_col, sizeof(int) * (size_t)tot);
+  if (e == hipSuccess && c16) e = hipMalloc(&h->d_sell_col16, sizeof(short) * (size_t)tot);
+  if (e == hipSuccess && c16) e = hipMemcpy(h->d_sell_col16, sc16.data(), sizeof(short) * (size_t)tot, hipMemcpyHostToDevice);
   if (e == hipSuccess && vals) e = hipMalloc(&h->d_sell_val, sizeof(c64) * (size_t)tot);
   if (e == hipSuccess && !vals) e = hipMalloc(&h->d_sell_K, sizeof(double) * (size_t)tot);
   if (e == hipSuccess && !vals) e = hipMalloc(&h->d_sell_M, sizeof(double) * (size_t)tot);
