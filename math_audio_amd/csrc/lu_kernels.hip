@@ -611,7 +611,7 @@ __global__ __launch_bounds__(128) void lu_trsm_mfma_kernel(const dc* __restrict_
 // (an indexed array of tiles makes the compiler carry the whole array through every update): few registers, so the
 // wavefront fits beside two update wavefronts on a SIMD instead of queueing behind a running trailing update -- where these
 // launches, which sit on every system's critical chain, took 0.2-0.35 ms instead of 20 us.
-__global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict__ T, int ldt, int nb, const dc* __restrict__ invd,
+__global__ __launch_bounds__(128, 5) void lu_trsm64_kernel(const dc* __restrict__ T, int ldt, int nb, const dc* __restrict__ invd,
                                                            dc* __restrict__ X, size_t xrs, size_t xcs, int nc, int nmain,
                                                            dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
       }
     }
   };
-  load_tile(0, b0r, b0i); load_tile(1, b1r, b1i); load_tile(2, b2r, b2i); load_tile(3, b3r, b3i);
+  load_tile(0, b0r, b0i); load_tile(1, b1r, b1i);   // tiles 2 and 3 are fetched once tiles 0 and 1 are solved: 64 accumulator registers live at a time
   // 32 rows of LDS at a time -- the inverted diagonal block `blk` (what = 0) or L's rows 32..63 below diagonal block 0
   // (what = 1) -- so that the launch needs 17 KB, not 35: it has to fit on CUs that hold panel and update workgroups
   auto load_rows = [&](int what, int blk) {
@@ -699,7 +699,9 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
   };
   load_rows(0, 0);
   if (active) solve_pair(b0r, b0i, b1r, b1i);
+  store_tile(0, b0r, b0i); store_tile(1, b1r, b1i);
   if (nb > 32) {
+    load_tile(2, b2r, b2i); load_tile(3, b3r, b3i);
     load_rows(1, 0);
     if (active) {
       update_tile(2, b2r, b2i, b0r, b0i, b1r, b1i);
@@ -707,8 +709,8 @@ __global__ __launch_bounds__(128, 4) void lu_trsm64_kernel(const dc* __restrict_
     }
     load_rows(0, 1);
     if (active) solve_pair(b2r, b2i, b3r, b3i);
+    store_tile(2, b2r, b2i); store_tile(3, b3r, b3i);
   }
-  store_tile(0, b0r, b0i); store_tile(1, b1r, b1i); store_tile(2, b2r, b2i); store_tile(3, b3r, b3i);
 }
 
 // ------------------------------------------------------------------ triangular solves for the right-hand sides
