@@ -169,6 +169,7 @@ int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* co
 int ma_lu_plan_reserve_events(ma_lu_plan_t* plan, int64_t count);   /* timing events created ahead of a timed run */
 int ma_lu_plan_num_blocks(ma_lu_plan_t* plan, int32_t* blocks);
 int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
+int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);   /* the stream a slot's chain runs on */
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
 int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);

@@ -86,6 +86,7 @@ def lib():
             "ma_lu_plan_num_blocks": [vp, P(i32)],
             "ma_lu_plan_reserve_events": [vp, C.c_int64],
             "ma_lu_plan_stage_reset": [vp, vp],
+            "ma_lu_plan_slot_stream": [vp, i32, P(vp)],
             "ma_lu_plan_stage_begin": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_stage_round": [vp, i32, vp, vp, vp],
             "ma_lu_plan_stage_finish": [vp, i32, vp],
@@ -332,6 +333,11 @@ class LuPlan:
 
     def reserve_events(self, count):
         check(lib().ma_lu_plan_reserve_events(self.h, int(count)))
+
+    def slot_stream(self, slot):
+        p = C.c_void_p()
+        check(lib().ma_lu_plan_slot_stream(self.h, int(slot), C.byref(p)))
+        return p.value
 
     def stage_reset(self, stream=0):
         check(lib().ma_lu_plan_stage_reset(self.h, C.c_void_p(stream)))

@@ -561,6 +561,13 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
   P->stage_first_mark = e0;
   return MA_OK;
 }
+// the stream slot `slot`'s chain runs on (idle between stage_finish and the next stage_begin: a driver may assemble the
+// slot's next system there, beside the other slots' work, and pass the same stream to stage_begin)
+int ma_lu_plan_slot_stream(ma_lu_plan_t* P, int32_t slot, void** stream) {
+  MA_REQUIRE(P && stream && slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "bad argument");
+  *stream = (void*)P->panel_streams[slot];
+  return MA_OK;
+}
 int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, int32_t nrhs, void* stream) {
   MA_REQUIRE(P && dA, MA_ERR_INVALID, "NULL argument");
   MA_REQUIRE(slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "slot %d outside 0..%d", slot, LU_BATCH_MAX - 1);

@@ -20,10 +20,11 @@ keep = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(K)]
 st = torch.cuda.current_stream().cuda_stream
 
 
-def assemble(i, s):
+def assemble(i, s, stream=None):
+    stream = st if stream is None else stream
     k = mm.wave_number(freqs[i % 64], 343.0); beta = mm.burton_miller_beta_scaled(k, 4.0)
-    plan.assemble_dev(k, beta, As[s].data_ptr(), xs[s].data_ptr(), stream=st)
-    plan.incident_rhs_dev(k, beta, xs[s].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=st)
+    plan.assemble_dev(k, beta, As[s].data_ptr(), xs[s].data_ptr(), stream=stream)
+    plan.incident_rhs_dev(k, beta, xs[s].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
 
 
 def batch_mode():
@@ -38,8 +39,14 @@ def batch_mode():
         i += c
 
 
+ASM_ON_LANE = False
+
+
 def staged_mode():
     G = lu.num_blocks()
+    lanes = [lu.slot_stream(s) for s in range(S)]
+    ext = [torch.cuda.ExternalStream(p) for p in lanes]
+    copied = [None] * S
     off = [s * ((G + S - 1) // S) for s in range(S)]
     lu.stage_reset(st)
     r = 0
@@ -56,8 +63,16 @@ def staged_mode():
                 continue
             active = True
             if g == 0:
-                assemble(idx, s)
-                lu.stage_begin(s, As[s].data_ptr(), xs[s].data_ptr(), 1, st)
+                if ASM_ON_LANE:
+                    if copied[s] is not None:
+                        ext[s].wait_event(copied[s])       # the previous solution of this slot has been copied out
+                    else:
+                        ev0 = torch.cuda.Event(); ev0.record(); ext[s].wait_event(ev0)
+                    assemble(idx, s, lanes[s])
+                    lu.stage_begin(s, As[s].data_ptr(), xs[s].data_ptr(), 1, lanes[s])
+                else:
+                    assemble(idx, s)
+                    lu.stage_begin(s, As[s].data_ptr(), xs[s].data_ptr(), 1, st)
             sl.append(s); bl.append(g)
         if not active:
             break
@@ -68,15 +83,25 @@ def staged_mode():
                 lu.stage_finish(s, st)
                 idx = s + S * ((r - off[s]) // G)
                 keep[idx].copy_(xs[s])
+                copied[s] = torch.cuda.Event(); copied[s].record()
         r += 1
 
 
-for name, fn in (("batch", batch_mode), ("staged", staged_mode), ("batch", batch_mode), ("staged", staged_mode)):
+def staged_lane_asm():
+    global ASM_ON_LANE
+    ASM_ON_LANE = True
+    try:
+        staged_mode()
+    finally:
+        ASM_ON_LANE = False
+
+
+for name, fn in (("batch", batch_mode), ("staged", staged_mode), ("staged+asm-on-lane", staged_lane_asm), ("staged", staged_mode), ("staged+asm-on-lane", staged_lane_asm)):
     fn(); torch.cuda.synchronize()          # warm-up of the mode
     t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     assert lu.status(st) == 0
     res = [k.clone() for k in keep]
-    print("%-7s K=%d slots=%d: %.2f ms per system" % (name, K, S, dt / K * 1e3))
+    print("%-19s K=%d slots=%d: %.2f ms per system" % (name, K, S, dt / K * 1e3))
     if name == "batch":
         ref = res
     else:
