@@ -274,6 +274,9 @@ typedef struct ma_precond ma_precond_t;
 int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out);
 int ma_precond_create_l1jacobi(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
 int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
+/* DiagonalPreconditioner::from_diagonal of an operator's diagonal (math-bem/src/core/solver/fmm_interface.rs:177-212): any
+ * operator kind; for the matrix-free TBEM operator the diagonal is the self terms */
+int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out);
 int ma_precond_destroy(ma_precond_t* M);
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
 int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */

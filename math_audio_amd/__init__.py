@@ -134,6 +134,7 @@ def lib():
             "ma_precond_create_jacobi": [vp, dbl, i32, P(vp)],
             "ma_precond_create_l1jacobi": [vp, i32, P(vp)],
             "ma_precond_create_sym_gauss_seidel": [vp, i32, P(vp)],
+            "ma_precond_create_diagonal": [vp, P(vp)],
             "ma_precond_destroy": [vp],
             "ma_precond_apply_dev": [vp, vp, vp, vp],
             "ma_precond_apply": [vp, vp, vp],
@@ -586,7 +587,9 @@ class Preconditioner:
     def __init__(self, csr_operator, kind="jacobi", omega=2.0 / 3.0, sweeps=2):
         self.h = C.c_void_p()
         self._keep = csr_operator
-        if kind == "jacobi":
+        if kind == "diagonal":         # csr_operator is a LinearOperator of any kind here (fmm_interface.rs:177-212)
+            check(lib().ma_precond_create_diagonal(csr_operator.h, C.byref(self.h)))
+        elif kind == "jacobi":
             check(lib().ma_precond_create_jacobi(csr_operator.h, float(omega), int(sweeps), C.byref(self.h)))
         elif kind in ("sgs", "sym_gauss_seidel"):
             check(lib().ma_precond_create_sym_gauss_seidel(csr_operator.h, int(sweeps), C.byref(self.h)))

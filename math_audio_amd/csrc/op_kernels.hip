@@ -278,6 +278,21 @@ __global__ __launch_bounds__(256) void conj_kernel(long long n, const dc* in, dc
   if (i < n) { const dc v = in[i]; out[i] = dc_make(v.re, -v.im); }
 }
 
+// DiagonalPreconditioner::from_diagonal (fmm_interface.rs:196-206): inv[slot(i)] = 1 / d_i, or 1 where |d_i| <= 1e-15. `d` is
+// read with stride `ds` (n + 1: the diagonal of a dense row-major matrix); slot(i) = map[i] (panel -> dof) or i
+__global__ __launch_bounds__(256) void diag_invert_kernel(long long n, const dc* __restrict__ d, long long ds, const int* __restrict__ map, dc* __restrict__ inv) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const dc v = d[i * ds];
+  const double ns = v.re * v.re + v.im * v.im;
+  inv[map ? map[i] : i] = hypot(v.re, v.im) > 1e-15 ? dc_make(v.re / ns, -v.im / ns) : dc_make(1.0, 0.0);
+}
+// z = a .* x (Preconditioner::apply of the diagonal preconditioner, fmm_interface.rs:208-212)
+__global__ __launch_bounds__(256) void cmul_kernel(long long n, const dc* __restrict__ a, const dc* __restrict__ x, dc* __restrict__ z) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] = a[i] * x[i];
+}
+
 // ------------------------------------------------------------------ launchers
 // partial: ZT_CHUNKS * n entries
 int op_launch_zgemv_t(long long n, const c64* A, const c64* x, c64* partial, c64* y, bool conj, hipStream_t st) {
@@ -290,6 +305,18 @@ int op_launch_zgemv_t(long long n, const c64* A, const c64* x, c64* partial, c64
   return MA_OK;
 }
 int op_zgemv_t_chunks() { return ZT_CHUNKS; }
+int op_launch_diag_invert(long long n, const c64* d, long long ds, const int* map, c64* inv, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(diag_invert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(d), ds, map, reinterpret_cast<dc*>(inv));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_launch_cmul(long long n, const c64* a, const c64* x, c64* z, hipStream_t st) {
+  if (n <= 0) return MA_OK;
+  hipLaunchKernelGGL(cmul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(a), reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(z));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
 int op_launch_conj(long long n, const c64* in, c64* out, hipStream_t st) {
   if (n <= 0) return MA_OK;
   hipLaunchKernelGGL(conj_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, reinterpret_cast<const dc*>(in), reinterpret_cast<dc*>(out));

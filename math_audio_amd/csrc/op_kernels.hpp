@@ -10,6 +10,8 @@ int op_launch_zgemv(long long n, const c64* A, const c64* x, c64* y, hipStream_t
 int op_launch_zgemv_t(long long n, const c64* A, const c64* x, c64* partial, c64* y, bool conj, hipStream_t st);
 int op_zgemv_t_chunks();
 int op_launch_conj(long long n, const c64* in, c64* out, hipStream_t st);
+int op_launch_diag_invert(long long n, const c64* d, long long ds, const int* map, c64* inv, hipStream_t st);
+int op_launch_cmul(long long n, const c64* a, const c64* x, c64* z, hipStream_t st);
 // mode 0: out = conj(x).y ; mode 1: out = ||x||_2 (real part)
 int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st);
 int op_launch_axpy_dev(long long n, const c64* alpha_dev, double sgn, const c64* x, c64* y, hipStream_t st);

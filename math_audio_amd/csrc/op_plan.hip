@@ -252,6 +252,7 @@ int ma_op_apply_hermitian(ma_op_t* o, const ma_c64* x, ma_c64* y) { return op_ap
 struct ma_precond {
   int kind = 0; ma_csr* csr = nullptr; double omega = 2.0 / 3.0; int sweeps = 2; long long n = 0; int device = 0;
   c64* d_tmp = nullptr;
+  c64* d_invdiag = nullptr;      // kind 4: 1 / a_ii of an operator (DiagonalPreconditioner::from_diagonal)
 };
 
 extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
@@ -279,15 +280,42 @@ int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond
   if (!rc) (*out)->kind = 3;
   return rc;
 }
+// DiagonalPreconditioner::from_diagonal(diag of the operator) (math-bem/src/core/solver/fmm_interface.rs:177-212): z_i = r_i / a_ii
+// (z_i = r_i where |a_ii| <= 1e-15). Dense: the matrix diagonal; CSR: jacobi(omega = 1, one sweep); matrix-free TBEM: the
+// self terms (singular integration + free term), i.e. the true diagonal of the operator.
+int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(op, MA_ERR_INVALID, "operator is NULL");
+  if (op->kind == 1) return ma_precond_create_jacobi(op->csr, 1.0, 1, out);
+  MA_HIP(hipSetDevice(op->device));
+  ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
+  M->kind = 4; M->n = op->n; M->device = op->device;
+  if (hipMalloc(&M->d_invdiag, sizeof(c64) * (size_t)op->n) != hipSuccess) { delete M; set_error("diagonal preconditioner: out of device memory"); return MA_ERR_NOMEM; }
+  int rc = MA_OK;
+  if (op->kind == 0) rc = op_launch_diag_invert(op->n, op->dA, op->n + 1, nullptr, M->d_invdiag, nullptr);
+  else {
+    const ma_bem_plan* P = op->plan;
+    c64* d = nullptr;
+    if (hipMalloc(&d, sizeof(c64) * (size_t)P->np) != hipSuccess) { set_error("diagonal preconditioner: out of device memory"); rc = MA_ERR_NOMEM; }
+    if (!rc) rc = bem_launch_self_list_values(P->geom, op->ph, d, nullptr);
+    if (!rc) rc = op_launch_diag_invert(P->np, d, 1, P->geom.dof, M->d_invdiag, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("diagonal preconditioner: kernels failed"); rc = MA_ERR_HIP; }
+    if (d) (void)hipFree(d);
+  }
+  if (rc) { (void)hipFree(M->d_invdiag); delete M; return rc; }
+  *out = M; return MA_OK;
+}
 int ma_precond_destroy(ma_precond_t* M) {
   if (!M) return MA_OK;
   if (M->d_tmp) (void)hipFree(M->d_tmp);
+  if (M->d_invdiag) (void)hipFree(M->d_invdiag);
   delete M; return MA_OK;
 }
 // z = M^-1 r on device vectors (z and r distinct)
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream) {
   MA_REQUIRE(M && d_r && d_z, MA_ERR_INVALID, "NULL argument");
   if (M->kind == 0) { MA_HIP(hipMemcpyAsync(d_z, d_r, sizeof(c64) * (size_t)M->n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return MA_OK; }
+  if (M->kind == 4) return op_launch_cmul(M->n, M->d_invdiag, (const c64*)d_r, (c64*)d_z, (hipStream_t)stream);
   MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
   if (M->kind == 1) return ma_csr_jacobi_dev(M->csr, d_z, d_r, M->omega, M->sweeps, M->d_tmp, stream);
   if (M->kind == 3) return ma_csr_sym_gauss_seidel_dev(M->csr, d_z, d_r, M->sweeps, stream);

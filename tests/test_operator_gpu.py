@@ -218,3 +218,29 @@ def test_row_sharded_operator_and_gmres_on_one_gpu(gpu):
     assert rel_l2(xs.cpu().numpy(), xr) <= 1e-9
     assert np.linalg.norm(A @ xs.cpu().numpy() - b) / np.linalg.norm(b) < 1e-7
     op.close(); plan.close()
+
+
+def test_diagonal_preconditioner_of_an_operator(gpu):
+    """DiagonalPreconditioner::from_diagonal (math-bem/src/core/solver/fmm_interface.rs:177-212) for the dense and the
+    matrix-free operator: z = r / a_ii with the operator's true diagonal; left-preconditioned GMRES (tolerance relative to
+    |M^-1 b|, gmres.rs:299-300) converges to the solution of plain GMRES."""
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+    mesh = to_ma_mesh(om)
+    A, _ = ma.assemble_tbem(mesh, k, beta)
+    plan = ma.BemPlan(mesh)
+    r = _xvec(om.n_elem)
+    for op in (ma.LinearOperator.dense(A), ma.LinearOperator.tbem(plan, k, beta)):
+        Mp = ma.Preconditioner(op, kind="diagonal")
+        z = Mp.apply(r)
+        assert np.abs(z - r / np.diag(A)).max() <= 1e-12 * np.abs(z).max()
+        b = ma.incident_rhs(om.center, om.normal, k, beta)
+        x0, i0 = ma.gmres(op, b, restart=30, max_iterations=200, tol=1e-8)
+        x1, i1 = ma.gmres_preconditioned(op, Mp, b, restart=30, max_iterations=200, tol=1e-8)
+        assert i0.converged == 1 and i1.converged == 1
+        assert np.linalg.norm(x1 - x0) <= 1e-6 * np.linalg.norm(x0)
+        Mp.close(); op.close()
+    D = ma.LinearOperator.dense(np.array([[0.0, 1.0], [1.0, 2.0]], dtype=complex))     # zero diagonal entry: left alone (:199-204)
+    Mz = ma.Preconditioner(D, kind="diagonal")
+    assert np.allclose(Mz.apply(np.array([3.0, 4.0], dtype=complex)), [3.0, 2.0])
+    Mz.close(); D.close(); plan.close()
