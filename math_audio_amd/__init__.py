@@ -560,6 +560,9 @@ class LinearOperator:
     def apply_dev(self, d_x, d_y, stream=0):
         check(lib().ma_op_apply_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream)))
 
+    def apply_transpose_dev(self, d_x, d_y, stream=0):
+        check(lib().ma_op_apply_transpose_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(stream)))
+
     def apply_transpose(self, x):
         x = np.ascontiguousarray(x, dtype=np.complex128); y = np.empty(self.n, dtype=np.complex128)
         check(lib().ma_op_apply_transpose(self.h, _vp(x), _vp(y)))

@@ -19,6 +19,7 @@ int op_launch_axpy_host(long long n, double are, double aim, const c64* x, c64* 
 int op_launch_axpby(long long n, double are, double aim, const c64* x, double bre, double bim, const c64* y, c64* out, hipStream_t st);
 int op_launch_tbem_matvec_t(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,
                             const long long* t_off, const int* t_idx, const int2* pairs, const c64* corr, const c64* diag_corr, c64* y, hipStream_t st);
+int op_tbem_matvec_strips(int np);
 int op_launch_tbem_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,
                           const long long* pair_off, const int2* pairs, const c64* corr, const c64* diag_corr, c64* y, hipStream_t st);
 int op_launch_pairs13(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st);

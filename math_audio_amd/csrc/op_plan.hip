@@ -3,6 +3,7 @@
 #include "op_kernels.hpp"
 #include "ma_tables.h"
 #include <vector>
+#include <algorithm>
 #include <complex>
 #include <new>
 #include <cmath>
@@ -107,7 +108,7 @@ int ma_op_create_tbem(ma_bem_plan_t* P, const ma_physics_t* physics, double beta
   o->nchunks = nch;
   hipError_t e = hipMalloc(&o->d_corr, sizeof(c64) * (size_t)(P->npairs > 0 ? P->npairs : 1));
   if (e == hipSuccess) e = hipMalloc(&o->d_diag, sizeof(c64) * (size_t)P->np);
-  if (e == hipSuccess) e = hipMalloc(&o->d_partial, sizeof(c64) * (size_t)nch * (size_t)(row1 - row0));
+  if (e == hipSuccess) e = hipMalloc(&o->d_partial, sizeof(c64) * (size_t)std::max(nch, op_tbem_matvec_strips(P->np)) * (size_t)(row1 - row0));
   c64* tmp = nullptr;
   if (e == hipSuccess) e = hipMalloc(&tmp, sizeof(c64) * (size_t)((P->npairs > P->np ? P->npairs : P->np) + 1));
   int2* dpairs_diag = nullptr;
