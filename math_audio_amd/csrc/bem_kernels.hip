@@ -51,7 +51,7 @@ __device__ __forceinline__ void green_point(double dx, double dy, double dz, dou
   double r, ri;
   sqrt_rsqrt(r2, r, ri);
   double sn, cs;
-  sincos_fast(k * r, sn, cs);
+  sincos_bounded(k * r, sn, cs);
   double gsc = w4pi * ri;
   double gre = cs * gsc, gim = sn * gsc;             // zg
   // zhh_base = zg * (-1/r + i k)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
       double r2 = dx * dx + dy * dy + dz * dz;
       if (r2 >= 1e-30) {
         double r, ri; sqrt_rsqrt(r2, r, ri);
-        double sn, cs; sincos_fast(k * r, sn, cs);
+        double sn, cs; sincos_bounded(k * r, sn, cs);
         double gs = MA_INV4PI * ri;
         double gre = cs * gs, gim = sn * gs;
         double fre = -(gre * ri) - gim * k, fim = gre * k - gim * ri;   // zg * (-1/r + ik)
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void tbem_self_kernel(BemGeom g, BemPhys ph, d
       double r2 = dx * dx + dy * dy + dz * dz;
       if (r2 >= 1e-30) {
         double r, ri; sqrt_rsqrt(r2, r, ri);
-        double sn, cs; sincos_fast(k * r, sn, cs);
+        double sn, cs; sincos_bounded(k * r, sn, cs);
         double gs = wga * MA_INV4PI * ri;
         double gre = cs * gs, gim = sn * gs;
         double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void tbem_self_quad_kernel(BemGeom g, BemPhys 
       const double r2 = dx * dx + dy * dy + dz * dz;
       if (r2 >= 1e-30) {
         double r, ri; sqrt_rsqrt(r2, r, ri);
-        double sn, cs; sincos_fast(k * r, sn, cs);
+        double sn, cs; sincos_bounded(k * r, sn, cs);
         const double gs = MA_INV4PI * ri;
         const double gre = cs * gs, gim = sn * gs;
         const double fre = -(gre * ri) - gim * k, fim = gre * k - gim * ri;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void tbem_self_quad_kernel(BemGeom g, BemPhys 
       const double r2 = q.dx * q.dx + q.dy * q.dy + q.dz * q.dz;
       if (r2 >= 1e-30) {
         double r, ri; sqrt_rsqrt(r2, r, ri);
-        double sn, cs; sincos_fast(k * r, sn, cs);
+        double sn, cs; sincos_bounded(k * r, sn, cs);
         const double gs = wga * MA_INV4PI * ri;
         const double gre = cs * gs, gim = sn * gs;
         const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
@@ -797,7 +797,7 @@ __device__ __forceinline__ dc green_point_k(double dx, double dy, double dz, dou
   const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
   if (!(r2 >= 1e-30)) return dc_make(0.0, 0.0);
   double r, ri; sqrt_rsqrt(r2, r, ri);
-  double sn, cs; sincos_fast(k * r, sn, cs);
+  double sn, cs; sincos_bounded(k * r, sn, cs);
   const double gsc = w4pi * ri;
   const double gre = cs * gsc, gim = sn * gsc;
   const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;

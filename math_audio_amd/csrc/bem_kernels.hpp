@@ -68,6 +68,7 @@ struct ma_bem_plan {
   int device = 0;
   int np = 0, nd = 0;
   double avg_radius = 0.0;         // tbem.rs:108-117
+  double diameter = 0.0;           // diagonal of the nodes' bounding box: every distance the kernels see is below it
   void* pool = nullptr;            // one HBM allocation holding every SoA array
   ma::BemGeom geom{};
   int2* d_pairs = nullptr;         // near pairs, sorted by collocation row i then j

@@ -162,6 +162,12 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   MA_REQUIRE(P, MA_ERR_NOMEM, "host allocation failed");
   P->device = device; P->np = np; P->nd = np;
   P->avg_radius = avg_center_radius(m);
+  {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < m->n_nodes; ++i)
+      for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], m->nodes[3 * i + d]); hi[d] = std::max(hi[d], m->nodes[3 * i + d]); }
+    P->diameter = m->n_nodes > 0 ? std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2])) : 0.0;
+  }
 
   const size_t bytes_d = (size_t)(ND + 1) * stride * sizeof(double);
   const size_t nq_pad = (hquads.size() + 63) & ~(size_t)63;
@@ -289,6 +295,9 @@ extern "C++" {
 int ma_bem_make_phys(const ma_bem_plan* P, const ma_physics_t* ph, double bre, double bim, ma::BemPhys* o) {
   MA_REQUIRE(ph, MA_ERR_INVALID, "physics is NULL");
   MA_REQUIRE(std::isfinite(ph->wave_number) && ph->wave_number > 0.0, MA_ERR_INVALID, "wave_number must be finite and > 0");
+  // the kernels' sin/cos takes arguments below 2^30 (ma_device_math.hpp: sincos_bounded); k r never gets near that for acoustics
+  MA_REQUIRE(std::fabs(ph->wave_number * ph->harmonic_factor) * P->diameter < 5.0e8, MA_ERR_UNSUPPORTED, "k * mesh diameter = %g is beyond the kernels' sin/cos range",
+             std::fabs(ph->wave_number * ph->harmonic_factor) * P->diameter);
   o->k = ph->wave_number; o->harmonic = ph->harmonic_factor; o->tau = ph->tau; o->gamma = ph->gamma;
   o->beta_re = bre; o->beta_im = bim;
   const double ka = ph->wave_number * P->avg_radius;       // tbem.rs:118-123

@@ -109,7 +109,7 @@ __device__ __forceinline__ dc pair_coeff_13(double d0x, double d0y, double d0z, 
     const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
     if (!(r2 >= 1e-30)) continue;
     double r, ri; sqrt_rsqrt(r2, r, ri);
-    double sn, cs; sincos_fast(k * r, sn, cs);
+    double sn, cs; sincos_bounded(k * r, sn, cs);
     const double gsc = w4pi * ri;
     const double gre = cs * gsc, gim = sn * gsc;
     const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
