@@ -272,12 +272,13 @@ def main():
         plan.incident_rhs_dev(k, beta, xs_[slot].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
 
     def run_pipeline(first, nsteps):
-        """The same frequencies through the staged schedule: slot s works on steps s, s + S, ... and starts a third of a
-        factorisation after slot s - 1, so every round of block updates carries a big, a medium and a small one and no
+        """The same frequencies through the staged schedule: slot s works on steps s, s + S, ... and starts a quarter of a
+        factorisation after slot s - 1, so every round of block updates carries a bigger, a medium and a smaller one and no
         slot's latency-bound panel chain is ever the only thing running. No host synchronisation inside."""
         slots = max(1, min(S, nsteps))
         G = lu.num_blocks()
-        off = [s * ((G + slots - 1) // slots) for s in range(slots)]
+        spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or max(1, (G + slots) // (slots + 1))   # rounds between the starts of two slots (G/4 for 3 slots measured best: 59.9 vs 60.7 ms at G/3)
+        off = [s * spacing for s in range(slots)]
         lu.stage_reset(stream)
         r = 0
         while True:

@@ -2,10 +2,11 @@
 // (math-bem/bin/room_simulator_bem.rs:329-360 and BemSolver::solve, bem_solver.rs:355-480: per frequency
 // PhysicsParams::new, beta = burton_miller_beta_scaled, build_tbem_system_with_beta, compute_rhs_with_beta, lu_solve).
 // Built on the public entry points only: the systems go through the staged plan API as a pipeline -- `slots` of them in
-// HBM at a time, slot s a third of a factorisation behind slot s-1 (see ma_lu_plan_stage_*) -- without a host
+// HBM at a time, slot s a quarter of a factorisation behind slot s-1 (see ma_lu_plan_stage_*) -- without a host
 // synchronisation inside; the solutions are parked on the device and travel back once at the end.
 #include "ma_common.hpp"
 #include <vector>
+#include <algorithm>
 #include <cmath>
 
 using namespace ma;
@@ -57,7 +58,7 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
       return MA_ERR_NOMEM;
     }
     std::vector<int> off((size_t)slots);
-    for (int s = 0; s < slots; ++s) off[(size_t)s] = s * ((G + slots - 1) / slots);
+    for (int s = 0; s < slots; ++s) off[(size_t)s] = s * std::max(1, (G + slots) / (slots + 1));   // G/4 apart for 3 slots (measured best)
     for (int r = 0; !rc; ++r) {
       int32_t sl[4], bl[4]; int cnt = 0; bool live = false;
       for (int s = 0; s < slots && !rc; ++s) {
