@@ -159,7 +159,7 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_
 int ma_lu_plan_solve_dev(ma_lu_plan_t* plan, void* d_A_factored, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* const* d_As, void* const* d_Bs, int32_t nrhs, void* stream);
 /* Staged use of a plan: a pipeline over a long sequence of systems (the frequencies of a sweep). factor_solve_batch moves
- * its systems in lock step; here every slot (0..3) is at its own block of columns, so a driver can start slot s a third of a
+ * its systems in lock step; here every slot (0..3) is at its own block of columns, so a driver can start slot s a quarter of a
  * factorisation after slot s-1: each round then carries one big, one medium and one small trailing update, and every slot's
  * latency-bound panel chain has the time of all of them to finish. Per slot: stage_begin when A and b of its next system are
  * ready on `stream` (it starts the first block column), then one stage_round per block 0..num_blocks-1 -- together with the

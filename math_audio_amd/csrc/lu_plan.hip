@@ -418,7 +418,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
 // ------------------------------------------------------------------ staged use: a pipeline over many systems
 // factor_solve_batch moves its systems in lock step: all of them are in the update-bound early blocks together and in the
 // latency-bound last blocks together. A driver that has a long sequence of systems (a frequency sweep) can instead keep the
-// slots at DIFFERENT block indices -- slot s starts a third of a factorisation after slot s-1 -- so that in every round one
+// slots at DIFFERENT block indices -- slot s starts a quarter of a factorisation after slot s-1 -- so that in every round one
 // slot brings a big update, one a medium one and one a small one: the caller's stream always has update work and every
 // slot's latency-bound chain has the time of three updates to finish. The driver calls, per slot, stage_begin (A and b of
 // the next system are ready on `stream`), then one stage_round per block index 0..G-1 together with the other slots, then

@@ -190,7 +190,7 @@ def test_lu_factorize_then_solve_and_lu_solve(gpu, n):
 
 
 def test_staged_pipeline_is_bitwise_the_single_solve(gpu):
-    """The staged plan API (slots at their own block index, staggered by a third of a factorisation) runs the same kernels on
+    """The staged plan API (slots at their own block index, staggered by a fraction of a factorisation) runs the same kernels on
     the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit."""
     import torch
     n = 900
