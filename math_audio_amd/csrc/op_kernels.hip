@@ -21,12 +21,21 @@ __global__ __launch_bounds__(256) void zgemv_kernel(long long n, const dc* __res
   const long long row = (long long)blockIdx.x * 4 + wave;
   if (row >= n) return;
   const dc* Ar = A + row * n;
-  double sr = 0.0, si = 0.0;
-  for (long long j = lane; j < n; j += 64) {
+  double sr = 0.0, si = 0.0, tr = 0.0, ti = 0.0;
+  long long j = lane;
+  for (; j + 192 < n; j += 256) {                         // four independent 1-KB loads of the row in flight per wavefront
+    const dc a0 = Ar[j], a1 = Ar[j + 64], a2 = Ar[j + 128], a3 = Ar[j + 192];
+    const dc v0 = x[j], v1 = x[j + 64], v2 = x[j + 128], v3 = x[j + 192];
+    sr += a0.re * v0.re - a0.im * v0.im; si += a0.re * v0.im + a0.im * v0.re;
+    tr += a1.re * v1.re - a1.im * v1.im; ti += a1.re * v1.im + a1.im * v1.re;
+    sr += a2.re * v2.re - a2.im * v2.im; si += a2.re * v2.im + a2.im * v2.re;
+    tr += a3.re * v3.re - a3.im * v3.im; ti += a3.re * v3.im + a3.im * v3.re;
+  }
+  for (; j < n; j += 64) {
     const dc a = Ar[j], v = x[j];
     sr += a.re * v.re - a.im * v.im; si += a.re * v.im + a.im * v.re;
   }
-  sr = wave_sum(sr); si = wave_sum(si);
+  sr = wave_sum(sr + tr); si = wave_sum(si + ti);
   if (lane == 0) y[row] = dc_make(sr, si);
 }
 
