@@ -247,3 +247,24 @@ def test_staged_pipeline_is_bitwise_the_single_solve(gpu):
     with pytest.raises(ma.MaError):
         lu.stage_round([0], [G], st)                       # block index out of range
     lu.close()
+
+
+def test_lu_tall_system_switches_panel_width(gpu):
+    """Above 36 352 rows a 64-column panel no longer fits the LDS of the co-resident workgroups: the factorisation starts with
+    32-column panels (8 per trailing update) and widens to 64 once the remaining rows fit. 36 900 rows cross that boundary;
+    the residual of the device solve is checked with a device matvec (21 GB matrix + copy: everything stays in HBM)."""
+    import torch
+    n = 36900
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(7)
+    A = torch.complex(torch.randn(n * n, dtype=torch.float64, device=dev, generator=g), torch.randn(n * n, dtype=torch.float64, device=dev, generator=g))
+    b = torch.complex(torch.randn(n, dtype=torch.float64, device=dev, generator=g), torch.randn(n, dtype=torch.float64, device=dev, generator=g))
+    A0 = A.clone(); x = b.clone()
+    lu = ma.LuPlan(n)
+    st = torch.cuda.current_stream().cuda_stream
+    lu.factor_solve_dev(A.data_ptr(), x.data_ptr(), 1, st)
+    assert lu.status(st) == ma.MA_OK
+    r = torch.mv(A0.reshape(n, n), x) - b
+    res = float(r.norm() / (A0.reshape(n, n)[:64].norm() * (n / 64) ** 0.5 * x.norm()))
+    assert res <= 1e-14 * n
+    lu.close()
