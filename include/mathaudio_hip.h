@@ -151,12 +151,12 @@ int ma_lu_plan_destroy(ma_lu_plan_t* plan);
  * d_B[nrhs][n] (each contiguous). Asynchronous on `stream`; the singularity flag is reported by
  * ma_lu_plan_status(), which synchronises the stream. */
 int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* plan, void* d_A, void* d_B, int32_t nrhs, void* stream);
-/* The same for nmat (1..4) independent systems of size n kept in flight together (d_As[m], d_Bs[m] device
- * pointers): the panels of the systems are interleaved on the plan's panel stream so that one system's
- * latency-bound panel chain runs underneath another's trailing updates. Results per system are
- * bit-identical to separate ma_lu_plan_factor_solve_dev calls. */
 /* solve further right-hand sides with the factors a previous ma_lu_plan_factor_solve_dev call on this plan left in d_A */
 int ma_lu_plan_solve_dev(ma_lu_plan_t* plan, void* d_A_factored, void* d_B, int32_t nrhs, void* stream);
+/* The same for nmat (1..4) independent systems of size n kept in flight together (d_As[m], d_Bs[m] device
+ * pointers), in lock step: every system has its own look-ahead stream, so that one system's latency-bound
+ * panel chain runs underneath the others' trailing updates. Results per system are bit-identical to separate
+ * ma_lu_plan_factor_solve_dev calls. */
 int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* plan, int32_t nmat, void* const* d_As, void* const* d_Bs, int32_t nrhs, void* stream);
 /* Staged use of a plan: a pipeline over a long sequence of systems (the frequencies of a sweep). factor_solve_batch moves
  * its systems in lock step; here every slot (0..3) is at its own block of columns, so a driver can start slot s a quarter of a
