@@ -165,6 +165,36 @@ static void run4(unsigned long long* f, u64* ticks, int rounds) {
   printf("flat, 227 workgroups, first poll after %3d x 64 clk, %3d x 64 clk between polls: %.3f us per round\n", D0, DS, t / 100.0 / rounds);
 }
 
+// MODE 7: one flat round that carries REC 8-byte flags per participant (the candidates of REC systems packed side by
+// side, 8*REC bytes per workgroup): what a panel kernel batched over REC systems would exchange per column
+template <int REC>
+__global__ __launch_bounds__(64) void round5_kernel(unsigned long long* flags, int rounds, u64* out_ticks) {
+  const int b = blockIdx.x, lane = threadIdx.x, G = gridDim.x;
+  const u64 t0 = __builtin_amdgcn_s_memrealtime();
+  bool fail = false;
+  for (int r = 1; r <= rounds && !fail; ++r) {
+    if (lane < REC) __hip_atomic_store(flags + (size_t)b * REC + lane, (unsigned long long)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_sleep(40);
+    for (;;) {
+      bool ok = true;
+      for (int t = lane; t < G * REC; t += 64) ok = ok && (__hip_atomic_load(flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)r);
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { fail = true; break; }
+    }
+  }
+  const u64 t1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && b == 0) out_ticks[0] = fail ? 0 : t1 - t0;
+}
+template <int REC>
+static void run5(unsigned long long* f, u64* ticks, int rounds) {
+  hipMemset(f, 0, 4096 * 8); hipMemset(ticks, 0, 8);
+  hipLaunchKernelGGL((round5_kernel<REC>), dim3(227), dim3(64), 0, 0, f, rounds, ticks);
+  hipDeviceSynchronize();
+  u64 t; hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+  printf("one flat round of 227 workgroups carrying %d flags each: %.3f us per round\n", REC, t / 100.0 / rounds);
+}
+
 int main() {
   unsigned *flags, *claim; u64* ticks; int *xcc, *np;
   const int G = 256;
@@ -228,6 +258,7 @@ int main() {
       printf("256 workgroups, %2d groups, flags %3d B apart: %.3f us per round\n", ng, stride * 4, t / 100.0 / rounds);
     }
   unsigned long long* f8; hipMalloc(&f8, 4096 * 8);
+  run5<1>(f8, ticks, rounds); run5<2>(f8, ticks, rounds); run5<3>(f8, ticks, rounds); run5<4>(f8, ticks, rounds);
   run4<0, 0>(f8, ticks, rounds); run4<0, 1>(f8, ticks, rounds); run4<0, 8>(f8, ticks, rounds); run4<0, 32>(f8, ticks, rounds);
   run4<20, 1>(f8, ticks, rounds); run4<40, 1>(f8, ticks, rounds); run4<60, 1>(f8, ticks, rounds); run4<40, 8>(f8, ticks, rounds);
   run4<60, 16>(f8, ticks, rounds); run4<80, 8>(f8, ticks, rounds);
