@@ -25,8 +25,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define LU_GROUPS 8              // candidate-gather groups of the panel kernel (workgroup b -> group b % 8 = its XCD)
 #ifndef LU_GRANULE_STRIDE
-#define LU_GRANULE_STRIDE 1
+#define LU_GRANULE_STRIDE 16
 #endif
 
 __device__ __forceinline__ void st_sc1(u64* p, double v) { __hip_atomic_store(p, (u64)__double_as_longlong(v), RLX_AGENT); }
@@ -157,8 +158,42 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     }
   };
 
+  // group leader (the group's last member), wavefront 0: gather the group's granules of column `col` and publish the group's
+  // granule. Runs right after the leader's own publish, in place of its share of the bulk update: every workgroup waits for it.
+  const int g_ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
+  const int g_grp = b % g_ngrp;
+  const int g_per = (nblk - g_grp + g_ngrp - 1) / g_ngrp;  // members g_grp, g_grp + g_ngrp, ...
+  const bool lead = b == g_grp + (g_per - 1) * g_ngrp;
+  auto leader_gather = [&](int col) {
+    const int buf = col & 1;
+    const unsigned want = (unsigned)(col + 1);
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    const u64* mbase = ws.cand + ((size_t)buf * ws.max_blocks + g_grp) * LU_GRANULE_STRIDE;
+    unsigned bhi = 0, brow = 0xFFFFFFu; bool fail = false;
+    for (;;) {
+      bool ok = true; bhi = 0; brow = 0xFFFFFFu;
+      if (lane < g_per) {
+        const u64 g = __hip_atomic_load(mbase + (size_t)lane * g_ngrp * LU_GRANULE_STRIDE, RLX_AGENT);
+        ok = ((unsigned)(g >> 24) & 0xFFu) == want;
+        bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
+      }
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }   // 4 s at 100 MHz: never hang (the sweep below reports it)
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
+      if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
+    }
+    if (lane == 0 && !fail)
+      __hip_atomic_store(ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS + g_grp) * LU_GRANULE_STRIDE,
+                         ((u64)bhi << 32) | ((u64)want << 24) | (u64)brow, RLX_AGENT);
+  };
+
   scan_column(0);
   publish(0);
+  if (lead && wave == 0) leader_gather(0);
 #ifdef MA_PANEL_STAMPS
   u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   u64 stamp_t = __builtin_amdgcn_s_memrealtime();
@@ -173,36 +208,38 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     const int buf = c & 1;
     // ---- wavefront 0 sweeps every workgroup's granule until all carry this column's tag, and
     // reduces them on the way (the data is the flag: no counter, no second round trip)
+    // ---- two-level gather of the candidates: workgroup b belongs to group b % 8 (its XCD under the round-robin placement);
+    // the group's last member gathers the group's <= 32 granules and publishes the group's granule, every workgroup
+    // sweeps only the 8 group granules (128 B apart). The leader's wavefront 0 starts its sweep right after publishing
+    // (it takes no part in the bulk update, see below): the group result is on the critical path of every workgroup.
     if (wave == 0) {
-      const u64* cbase = ws.cand + (size_t)buf * ws.max_blocks * LU_GRANULE_STRIDE;
       const unsigned want = (unsigned)(c + 1);
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
-      u64 best; int bblk; bool fail = false;
-      for (;;) {
-        bool ok = true; best = 0; bblk = 0; unsigned brow = 0xFFFFFFu; unsigned bhi = 0;
-        for (int t = lane; t < nblk; t += 64) {
-          const u64 g = __hip_atomic_load(cbase + (size_t)t * LU_GRANULE_STRIDE, RLX_AGENT);
-          const unsigned tag = (unsigned)(g >> 24) & 0xFFu, row = (unsigned)g & 0xFFFFFFu, hi = (unsigned)(g >> 32);
-          ok = ok && (tag == want);
-          if (hi > bhi || (hi == bhi && row < brow)) { bhi = hi; brow = row; bblk = t; }
+      const int ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
+      bool fail = false;
+      unsigned bhi = 0, brow = 0xFFFFFFu;
+      const u64* gbase = ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS) * LU_GRANULE_STRIDE;
+      while (!fail) {
+        bool ok = true; bhi = 0; brow = 0xFFFFFFu;
+        if (lane < ngrp) {
+          const u64 g = __hip_atomic_load(gbase + (size_t)lane * LU_GRANULE_STRIDE, RLX_AGENT);
+          ok = ((unsigned)(g >> 24) & 0xFFu) == want;
+          bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
         }
-        if (__all(ok)) {
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) {
-            const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64); const int ob = __shfl_xor(bblk, off, 64);
-            if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; bblk = ob; }
-          }
-          best = brow;
-          break;
-        }
+        if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }   // 4 s at 100 MHz: never hang
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;
+      }
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) {
+        const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
+        if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
       }
       if (lane == 0) {
+        u64 best = brow; int bblk;
         if (fail) { __hip_atomic_store(ws.timeout, 1u, RLX_AGENT); s_misc[3] = 1; }
-        // no workgroup offered a row (a column of NaNs compares false everywhere): keep the diagonal row and report
-        // the column as a failed pivot, so that no out-of-range row index ever reaches the interchange kernels
-        if (!fail && best >= (u64)n) { best = (u64)gc; bblk = -1; if (b == 0) atomicCAS(ws.info, 0, gc + 1); }
+        if (fail || best >= (u64)n || best < (u64)gc) { best = (u64)gc; bblk = -1; if (!fail && b == 0) atomicCAS(ws.info, 0, gc + 1); }
+        else bblk = ((int)best - k0) / rpb;              // rows are dealt to the workgroups in runs of rpb
         s_misc[1] = (int)best; s_misc[2] = bblk;
       }
     }
@@ -291,18 +328,22 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       MA_STAMP(4);
       publish(c + 1);
       MA_STAMP(5);
+      if (lead && wave == 0) leader_gather(c + 1);
     }
     // ---- bulk rank-1 update (overlaps the other workgroups' arrival): lane = row (the row pitch of
     // nb+1 complex spreads the lanes over all LDS banks); each wavefront takes every 4th group of 4
     // columns, loads the group before touching it so the LDS latency is paid once per group
-    if (!singular && more) {
+    // a group leader's wavefront 0 goes straight to the gather (the group's result is on everyone's critical path); its
+    // share of the columns goes to the other three wavefronts
+    const int bwn = lead ? 3 : 4, bw = lead ? wave - 1 : wave;
+    if (!singular && more && bw >= 0) {
       for (int rbase = 0; rbase < nrows; rbase += 64) {
         const int rr = rbase + lane;
         const int gr = r0 + rr;
         const bool on = rr < nrows && gr > gc;
         const dc l = on ? P[rr * pitch + c] : dc_make(0.0, 0.0);
         dc* Pr = P + (size_t)(on ? rr : 0) * pitch;
-        for (int j0 = c + 2 + 4 * wave; j0 < nb; j0 += 16) {
+        for (int j0 = c + 2 + 4 * bw; j0 < nb; j0 += 4 * bwn) {
           dc u[4], a[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) { const int j = min(j0 + q, nb - 1); u[q] = urow[j]; a[q] = Pr[j]; }
@@ -1018,7 +1059,7 @@ struct PanelSequencer {
 PanelSequencer g_seq;
 }  // namespace
 
-size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long) * LU_GRANULE_STRIDE * 2 * (size_t)max_blocks; }
+size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long) * LU_GRANULE_STRIDE * (2 * (size_t)max_blocks + 2 * LU_GROUPS); }
 
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
   int dev = 0;
