@@ -25,7 +25,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifndef LU_GROUPS
 #define LU_GROUPS 8              // candidate-gather groups of the panel kernel (workgroup b -> group b % 8 = its XCD)
+#endif
 #ifndef LU_GRANULE_STRIDE
 #define LU_GRANULE_STRIDE 16
 #endif
