@@ -140,20 +140,33 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
   auto publish = [&](int col) {
     const int buf = col & 1;
     const double bv = s_bestv[0]; const int br = s_misc[0];
-    if (br != INT_MAX) {
-      const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
-      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
-      for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
-    }
     const int gd = k0 + col;
-    if (gd >= r0 && gd < r0 + nrows) {
-      const double* src = reinterpret_cast<const double*>(P + (size_t)(gd - r0) * pitch);
-      u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      for (int t = tid; t < 2 * nb; t += 256) st_sc1(dst + t, src[t]);
+    const bool own_diag = gd >= r0 && gd < r0 + nrows;
+    // Wavefront 0 alone publishes (a row of <= 128 columns is 4 doubles per lane): it reads the rows from LDS, releases
+    // the other wavefronts to the bulk update with one barrier, and only then waits for its write-through stores.
+    double cv[4], dv[4];
+    if (wave == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = lane + 64 * u;
+        cv[u] = (br != INT_MAX && t < 2 * nb) ? reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch)[t] : 0.0;
+        dv[u] = (own_diag && t < 2 * nb) ? reinterpret_cast<const double*>(P + (size_t)(gd - r0) * pitch)[t] : 0.0;
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
     __syncthreads();
-    if (tid == 0) {
+    if (wave != 0) return;
+    if (br != INT_MAX) {
+      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (lane + 64 * u < 2 * nb) st_sc1(dst + lane + 64 * u, cv[u]);
+    }
+    if (own_diag) {
+      u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (lane + 64 * u < 2 * nb) st_sc1(dst + lane + 64 * u, dv[u]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the payload is out before the granule says so
+    if (lane == 0) {
       const u64 hi = br != INT_MAX ? ((u64)__double_as_longlong(bv) >> 32) : 0ull;
       const u64 lo = ((u64)(unsigned)(col + 1) << 24) | (u64)(br != INT_MAX ? (unsigned)br : 0xFFFFFFu);
       __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE, (hi << 32) | lo, RLX_AGENT);
@@ -335,9 +348,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     // ---- bulk rank-1 update (overlaps the other workgroups' arrival): lane = row (the row pitch of
     // nb+1 complex spreads the lanes over all LDS banks); each wavefront takes every 4th group of 4
     // columns, loads the group before touching it so the LDS latency is paid once per group
-    // a group leader's wavefront 0 goes straight to the gather (the group's result is on everyone's critical path); its
-    // share of the columns goes to the other three wavefronts
-    const int bwn = lead ? 3 : 4, bw = lead ? wave - 1 : wave;
+    const int bwn = 3, bw = wave - 1;                    // wavefront 0 is busy publishing (and, in a leader, gathering)
     if (!singular && more && bw >= 0) {
       for (int rbase = 0; rbase < nrows; rbase += 64) {
         const int rr = rbase + lane;
