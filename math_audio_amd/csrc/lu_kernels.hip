@@ -52,8 +52,9 @@ __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) 
 // ------------------------------------------------------------------ panel factorisation
 // Dynamic LDS: P[rpb][nb+1] | urow[2][nb] | drow[nb] | small scalars.
 // Per column c every workgroup publishes its best pivot candidate (value, row, the row's nb panel
-// entries) and, if it owns it, the current diagonal row; every workgroup sweeps the tagged
-// candidate granules until all are present, reduces them to the same pivot and fetches its row. The candidate of
+// entries) and, if it owns it, the current diagonal row; the granules are gathered in two levels (a leader per group of
+// <= 32 workgroups reduces its group, every workgroup sweeps the 8 group granules), all reduce to the same pivot and fetch its
+// row. Wavefront 0 carries this chain; wavefronts 1-3 do the bulk of the rank-1 update. The candidate of
 // column c+1 is published BEFORE the bulk of step c's rank-1 update: only column c+1 is brought up to date first, the
 // rows go out as they stand and the receivers finish step c's update on the one row they fetch. The chip-wide wait
 // therefore overlaps the local update, and nothing but the scan of column c+1 sits between a pivot and the next publish.
