@@ -3,13 +3,15 @@
 // Replaces the arithmetic behind lu_solve (math-solvers/src/direct/lu.rs:142-153 -> LAPACK zgesv).
 // The matrix is ndarray C-order (row-major) and stays resident in HBM; pivoting is by rows
 // (swaps are contiguous 16-B-per-lane row copies). Per panel of nb <= 128 columns:
-//   lu_panel_kernel    co-resident workgroups, each keeping its <= 72 rows of the panel in LDS
-//                      (160 KB/CU makes the whole 10k x 128 panel on-chip); one chip-wide
-//                      gather per column (sc1 write-through stores, tagged 8-byte granules, sc1 loads)
-//                      picks the pivot and hands every workgroup the pivot row.
-//   lu_perm_kernel     one wavefront folds the panel's swap sequence into a gather list;
-//   lu_gather/scatter  apply it to the columns left and right of the panel (and to the RHS).
-//   lu_trsm_mfma       U12 = L11^-1 A12 as MFMA products with inverted 32 x 32 diagonal blocks (the RHS rides along);
+//   lu_panel_kernel    co-resident workgroups, each keeping its <= 43 rows of a 64-column panel in LDS (48 KB: two
+//                      systems' panels and two update workgroups share a CU); one chip-wide exchange per column (sc1
+//                      write-through stores, tagged 8-byte granules gathered in two levels, sc1 loads) picks the pivot
+//                      and hands every workgroup the pivot row.
+//   lu_perm_kernel     one wavefront folds the panel's swap sequence into a gather list; further blocks invert the 32 x 32
+//                      diagonal blocks of L11 (16 x 16 blocks through LDS: 47 registers, 26 KB);
+//   lu_gather/scatter  apply the list to the columns left and right of the panel (and to the RHS).
+//   lu_trsm64_kernel   U12 = L11^-1 A12 as MFMA products with the inverted diagonal blocks, panels of <= 64 columns, 94
+//                      registers and 17 KB so that it runs beside a trailing update (lu_trsm_mfma_kernel: up to 128 columns);
 //   lu_trsv_kernel     the nb x nb triangular solves of the backward substitution, one wavefront each.
 //   zgemm3m_sub_kernel A22 -= L21 U12 on v_mfma_f64_16x16x4_f64, 3 real products per complex product, 64 x 64 tiles
 //                      (zgemm_sub_kernel: the 4-product form, 128 x 128 tiles).
