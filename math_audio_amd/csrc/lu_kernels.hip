@@ -30,6 +30,9 @@ typedef unsigned long long u64;
 #ifndef LU_GROUPS
 #define LU_GROUPS 8              // candidate-gather groups of the panel kernel (workgroup b -> group b % 8 = its XCD)
 #endif
+#ifndef LU_POLL_SLEEP
+#define LU_POLL_SLEEP 1          // x 64 clocks between two sweeps of the group granules
+#endif
 #ifndef LU_GRANULE_STRIDE
 #define LU_GRANULE_STRIDE 16
 #endif
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
           bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
         }
         if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;
       }
 #pragma unroll
