@@ -201,11 +201,14 @@ def main():
     ap.add_argument("--n-phi", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--schedule", choices=["pipeline", "batch"], default="pipeline",
-                    help="pipeline: slots at staggered block indices (staged plan API); batch: lock-step batches of --slots systems")
+    ap.add_argument("--schedule", choices=["auto", "pipeline", "batch"], default="auto",
+                    help="pipeline: slots at staggered block indices (staged plan API); batch: lock-step batches of --slots systems; "
+                         "auto: pipeline from 12 steps on (below that its fill and drain cost more than the lock step does)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "3")),
                     help="frequencies in flight per GPU (systems factored as one interleaved batch, 1..4)")
     args = ap.parse_args()
+    if args.schedule == "auto":
+        args.schedule = "pipeline" if args.steps >= 12 else "batch"
     if args.workload == "fem":
         return fem_workload(args)
 
