@@ -246,6 +246,7 @@ int ma_fem_residual(ma_csr_t* h, const ma_c64* x, const ma_c64* b, ma_c64* r);
  *           gmres / gmres_with_guess(operator, b, x0, config)            math-solvers/src/iterative/gmres.rs:96-277
  * ma_op_create_tbem is the matrix-free TBEM operator of BASELINE.json configs[4] (new; it must equal A x of
  * the dense matrix): rows [row0, row1) of y are produced; the plan is borrowed and must outlive the operator.
+ * Tri3, Quad4 and mixed meshes (ElementType, types.rs) are all streamed.
  * A Rust struct holding the handle implements the trait; Drop calls ma_op_destroy.
  * ------------------------------------------------------------------------------------------ */
 typedef struct ma_op ma_op_t;

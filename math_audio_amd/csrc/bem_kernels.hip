@@ -518,6 +518,26 @@ __device__ __forceinline__ void quad_green(const double* v, double s, double t, 
   green_point(q.dx, q.dy, q.dz, w * q.jac * MA_INV4PI, k, k2, q.nyx, q.nyy, q.nyz, nxx, nxy, nxz, m, acc);
 }
 
+// un-subdivided coefficient of the pair (row i, quad panel with vertices v): the rule of the order the distance asks for
+__device__ __forceinline__ dc quad_far_coeff(const BemGeom& g, const double* v, double sq, int fbc, int i, const BemPhys& ph, double k, double k2) {
+  const double cs[4] = {1.0, -1.0, -1.0, 1.0}, ct[4] = {1.0, 1.0, -1.0, -1.0};
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  const int order = quad_gauss_order(quad_ratio(cs, ct, v, cx, cy, cz, sq));
+  const int off = c_gl_index[order][0], n = c_gl_index[order][1];
+  Acc4 s;
+  s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b)
+      quad_green(v, c_gl_x[off + a], c_gl_x[off + b], c_gl_w[off + a] * c_gl_w[off + b], cx, cy, cz, nxx, nxy, nxz, k, k2, s);
+  return bm_coeff(s, fbc, ph);
+}
+__device__ __forceinline__ double quad_sq_area(const BemGeom& g, int j) {
+#pragma clang fp contract(off)
+  double arels = g.area[j] * 1.0 * 1.0;
+  return __builtin_sqrt(arels);
+}
+
 // K1q: every pair whose field panel is a quad, un-subdivided rule of the order the distance asks for.
 // grid.x: strips of 256 quad panels (lane = panel), grid.y: strips of collocation rows.
 __global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block) {
@@ -528,26 +548,80 @@ __global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys p
   const int fbc = g.bc_type[j];
   const long long col = g.dof[j];
   const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
-  double sq;
-  {
-#pragma clang fp contract(off)
-    double arels = g.area[j] * 1.0 * 1.0;
-    sq = __builtin_sqrt(arels);
-  }
-  const double cs[4] = {1.0, -1.0, -1.0, 1.0}, ct[4] = {1.0, 1.0, -1.0, -1.0};
+  const double sq = quad_sq_area(g, j);
   const int i0 = blockIdx.y * rows_per_block, i1 = min(i0 + rows_per_block, g.np);
   for (int i = i0; i < i1; ++i) {
-    const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
-    const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
-    const int order = quad_gauss_order(quad_ratio(cs, ct, v, cx, cy, cz, sq));
-    const int off = c_gl_index[order][0], n = c_gl_index[order][1];
-    Acc4 s;
-    s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
-    for (int a = 0; a < n; ++a)
-      for (int b = 0; b < n; ++b)
-        quad_green(v, c_gl_x[off + a], c_gl_x[off + b], c_gl_w[off + a] * c_gl_w[off + b], cx, cy, cz, nxx, nxy, nxz, k, k2, s);
-    if (valid) A[(long long)g.dof[i] * g.nd + col] = bm_coeff(s, fbc, ph);
+    const dc a = quad_far_coeff(g, v, sq, fbc, i, ph, k, k2);
+    if (valid) A[(long long)g.dof[i] * g.nd + col] = a;
   }
+}
+
+// ---- the Quad4 columns of the matrix-free operator (op_kernels.hip streams the Tri3 columns): the loop nest of
+// tbem_far_quad_kernel, accumulating a_ij x_j instead of storing a_ij. Lane = quad panel; the 64 lanes' products of a row are
+// summed with DPP, a wavefront collects 64 consecutive rows in its lanes, the four wavefronts are added through LDS.
+// grid.x: strips of 256 quad panels, grid.y: tiles of rows_per_block rows (a multiple of 64) of [row0, row1);
+// partial[strip][row - row0] (the caller passes the first quad strip's address).
+__global__ __launch_bounds__(256) void tbem_matvec_quad_kernel(BemGeom g, BemPhys ph, int row0, int row1, int rows_per_block, const dc* __restrict__ x,
+                                                               dc* __restrict__ partial) {
+  __shared__ double s_re[4][64], s_im[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = q < g.nquad;
+  const int j = g.quad_ids[valid ? q : 0];
+  double v[12]; quad_load(g, j, v);
+  const int fbc = g.bc_type[j];
+  const dc xj = valid ? x[g.dof[j]] : dc_make(0.0, 0.0);
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  const double sq = quad_sq_area(g, j);
+  const int nr = row1 - row0;
+  const int t0 = row0 + blockIdx.y * rows_per_block, t1 = min(t0 + rows_per_block, row1);
+  for (int base = t0; base < t1; base += 64) {
+    double acc_re = 0.0, acc_im = 0.0;
+    const int iend = min(base + 64, t1);
+    for (int i = base; i < iend; ++i) {
+      const dc a = quad_far_coeff(g, v, sq, fbc, i, ph, k, k2);
+      const double pr = wave_sum_lane63(a.re * xj.re - a.im * xj.im), pi = wave_sum_lane63(a.re * xj.im + a.im * xj.re);
+      const int tl = i - base;
+      const int rl = __builtin_amdgcn_readlane(__double2loint(pr), 63), rh = __builtin_amdgcn_readlane(__double2hiint(pr), 63);
+      const int il = __builtin_amdgcn_readlane(__double2loint(pi), 63), ih = __builtin_amdgcn_readlane(__double2hiint(pi), 63);
+      if (lane == tl) { acc_re = __hiloint2double(rh, rl); acc_im = __hiloint2double(ih, il); }
+    }
+    s_re[wave][lane] = acc_re; s_im[wave][lane] = acc_im;
+    __syncthreads();
+    if (wave == 0 && base + lane < iend)
+      partial[(size_t)blockIdx.x * nr + (base + lane - row0)] = dc_make(s_re[0][lane] + s_re[1][lane] + s_re[2][lane] + s_re[3][lane],
+                                                                        s_im[0][lane] + s_im[1][lane] + s_im[2][lane] + s_im[3][lane]);
+    __syncthreads();
+  }
+}
+// transposed: partial[chunk][j] = sum over the chunk's rows of a_ij x[dof_i] for the quad panels j (overwrites what the Tri3
+// kernel left in those slots; same chunking)
+__global__ __launch_bounds__(256) void tbem_matvec_quad_t_kernel(BemGeom g, BemPhys ph, int row0, int row1, int chunk_rows, const dc* __restrict__ x,
+                                                                 dc* __restrict__ partial) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = q < g.nquad;
+  const int j = g.quad_ids[valid ? q : 0];
+  double v[12]; quad_load(g, j, v);
+  const int fbc = g.bc_type[j];
+  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
+  const double sq = quad_sq_area(g, j);
+  const int i0 = row0 + blockIdx.y * chunk_rows, i1 = min(i0 + chunk_rows, row1);
+  double yr = 0.0, yi = 0.0;
+  for (int i = i0; i < i1; ++i) {
+    const dc xi = x[g.dof[i]];
+    const dc a = quad_far_coeff(g, v, sq, fbc, i, ph, k, k2);
+    yr += a.re * xi.re - a.im * xi.im; yi += a.re * xi.im + a.im * xi.re;
+  }
+  if (valid) partial[(size_t)blockIdx.y * g.np + j] = dc_make(yr, yi);
+}
+// the streamed coefficient of listed pairs whose field panel is a quad (to form corrections A_true - A_streamed)
+__global__ __launch_bounds__(256) void tbem_pairs_quad_far_kernel(BemGeom g, BemPhys ph, const int2* __restrict__ pairs, long long npairs, dc* __restrict__ out) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npairs) return;
+  const int i = pairs[q].x, j = pairs[q].y;
+  if (g.ptype[j] != 4) return;
+  double v[12]; quad_load(g, j, v);
+  out[q] = quad_far_coeff(g, v, quad_sq_area(g, j), g.bc_type[j], i, ph, ph.k * ph.harmonic, ph.k * ph.k);
 }
 
 // generate_subelements for nv = 4: leaves {xi centre, eta centre, half-width, Gauss order} in s_leaf[wave][0..nleaf)
@@ -1219,6 +1293,29 @@ int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st)
   dim3 grid((g.np + 3) / 4), block(256);
   hipLaunchKernelGGL(tbem_self_kernel<0>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
   if (g.nquad > 0) hipLaunchKernelGGL(tbem_self_quad_kernel<0>, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// Quad4 columns of the matrix-free operator (no-ops on a Tri3 mesh)
+int bem_quad_strips(const BemGeom& g) { return (g.nquad + 255) / 256; }
+int bem_launch_quad_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row1, int rows_per_block, const c64* x, c64* partial_quad_strips, hipStream_t st) {
+  if (g.nquad <= 0 || row1 <= row0) return MA_OK;
+  dim3 grid(bem_quad_strips(g), (row1 - row0 + rows_per_block - 1) / rows_per_block), block(256);
+  hipLaunchKernelGGL(tbem_matvec_quad_kernel, grid, block, 0, st, g, ph, row0, row1, rows_per_block, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial_quad_strips));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int bem_launch_quad_matvec_t(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, int chunk_rows, const c64* x, c64* partial, hipStream_t st) {
+  if (g.nquad <= 0 || row1 <= row0) return MA_OK;
+  dim3 grid(bem_quad_strips(g), nchunks), block(256);
+  hipLaunchKernelGGL(tbem_matvec_quad_t_kernel, grid, block, 0, st, g, ph, row0, row1, chunk_rows, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int bem_launch_quad_pairs_far(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st) {
+  if (g.nquad <= 0 || npairs <= 0) return MA_OK;
+  hipLaunchKernelGGL(tbem_pairs_quad_far_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

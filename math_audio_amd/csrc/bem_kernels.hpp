@@ -55,6 +55,11 @@ int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pair
 int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st);
 int bem_launch_near_list_values(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st);
 int bem_launch_self_list_values(const BemGeom& g, const BemPhys& ph, c64* out, hipStream_t st);
+// Quad4 columns of the matrix-free operator
+int bem_quad_strips(const BemGeom& g);
+int bem_launch_quad_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row1, int rows_per_block, const c64* x, c64* partial_quad_strips, hipStream_t st);
+int bem_launch_quad_matvec_t(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, int chunk_rows, const c64* x, c64* partial, hipStream_t st);
+int bem_launch_quad_pairs_far(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out, hipStream_t st);
 int bem_launch_zero(c64* v, int n, hipStream_t st);
 int bem_launch_rhs_bc(const BemGeom& g, const BemPhys& ph, const BemBc& bc, const int2* pairs, const long long* pair_off, long long npairs,
                       c64* scratch, c64* rhs, hipStream_t st);

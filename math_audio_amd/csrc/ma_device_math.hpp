@@ -86,6 +86,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// sum of a double over the wavefront, valid in lane 63 (DPP shifts inside the rows of 16 lanes, then the two row broadcasts;
+// lanes that receive nothing add 0)
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+#define MA_DPP_ADD(ctrl, rmask)                                                                                         \
+  {                                                                                                                     \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false);                          \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false);                          \
+    v += __hiloint2double(hi, lo);                                                                                      \
+  }
+  MA_DPP_ADD(0x111, 0xf) MA_DPP_ADD(0x112, 0xf) MA_DPP_ADD(0x114, 0xf) MA_DPP_ADD(0x118, 0xf)   // row_shr 1, 2, 4, 8: lane 15 of a row = row sum
+  MA_DPP_ADD(0x142, 0xa) MA_DPP_ADD(0x143, 0xc)                                                 // row_bcast 15 / 31: lane 63 = total
+#undef MA_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
   unsigned lane = threadIdx.x & 63u;
   return lane == 0 ? 0ull : (~0ull >> (64u - lane));

@@ -190,21 +190,6 @@ __global__ __launch_bounds__(256) void tbem_matvec_t_finish_kernel(BemGeom g, in
   y[g.dof[j]] = dc_make(yr, yi);
 }
 
-// sum of a double over the wavefront, valid in lane 63 (DPP shifts inside the rows of 16 lanes, then the two row broadcasts;
-// lanes that receive nothing add 0)
-__device__ __forceinline__ double wave_sum_lane63(double v) {
-#define MA_DPP_ADD(ctrl, rmask)                                                                                         \
-  {                                                                                                                     \
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rmask, 0xf, false);                          \
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rmask, 0xf, false);                          \
-    v += __hiloint2double(hi, lo);                                                                                      \
-  }
-  MA_DPP_ADD(0x111, 0xf) MA_DPP_ADD(0x112, 0xf) MA_DPP_ADD(0x114, 0xf) MA_DPP_ADD(0x118, 0xf)   // row_shr 1, 2, 4, 8: lane 15 of a row = row sum
-  MA_DPP_ADD(0x142, 0xa) MA_DPP_ADD(0x143, 0xc)                                                 // row_bcast 15 / 31: lane 63 = total
-#undef MA_DPP_ADD
-  return v;
-}
-
 // y = A x with lane = FIELD panel j (geometry and x_j in registers) and the collocation rows on the scalar path -- the loop
 // nest of the assembly kernel, 1/3 faster than lane = row (16 scalar loads per panel there, 7 per row here). The 64 lanes'
 // products of a row are summed with DPP; a wavefront collects the sums of 64 consecutive rows in its lanes, the workgroup's
@@ -215,8 +200,8 @@ __global__ __launch_bounds__(256) void tbem_matvec_lp_kernel(BemGeom g, BemPhys 
   __shared__ double s_re[4][64], s_im[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = j < g.np;
-  const int jj = valid ? j : g.np - 1;
+  const int jj = j < g.np ? j : g.np - 1;
+  const bool valid = j < g.np && !(g.nquad > 0 && g.ptype[jj] == 4);   // Quad4 columns: tbem_matvec_quad_kernel's strips
   const double p0x = g.p0[0][jj], p0y = g.p0[1][jj], p0z = g.p0[2][jj];
   const double e1x = g.e1[0][jj], e1y = g.e1[1][jj], e1z = g.e1[2][jj];
   const double e2x = g.e2[0][jj], e2y = g.e2[1][jj], e2z = g.e2[2][jj];
@@ -406,7 +391,7 @@ int op_launch_axpby(long long n, double are, double aim, const c64* x, double br
   return MA_OK;
 }
 int op_tbem_matvec_strips(int np) { return (np + 255) / 256; }
-// partial: op_tbem_matvec_strips(np) x (row1 - row0) entries
+// partial: (op_tbem_matvec_strips(np) + bem_quad_strips(g)) x (row1 - row0) entries
 int op_launch_tbem_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,
                           const long long* pair_off, const int2* pairs, const c64* corr, const c64* diag_corr, c64* y, hipStream_t st) {
   (void)nchunks;
@@ -417,7 +402,11 @@ int op_launch_tbem_matvec(const BemGeom& g, const BemPhys& ph, int row0, int row
   while (rpb > 64 && (long long)strips * ((nr + rpb - 1) / rpb) < 2048) rpb >>= 1;
   dim3 grid(strips, (nr + rpb - 1) / rpb), block(256);
   hipLaunchKernelGGL(tbem_matvec_lp_kernel, grid, block, 0, st, g, ph, row0, row1, rpb, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
-  hipLaunchKernelGGL(tbem_matvec_finish_kernel, dim3((nr + 255) / 256), block, 0, st, g, row0, row1, strips, reinterpret_cast<const dc*>(partial),
+  // Quad4 columns: their own strips behind the Tri3 ones (bem_kernels.hip; nothing on a Tri3 mesh)
+  const int qstrips = bem_quad_strips(g);
+  int rc = bem_launch_quad_matvec(g, ph, row0, row1, rpb, x, partial + (size_t)strips * (size_t)nr, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tbem_matvec_finish_kernel, dim3((nr + 255) / 256), block, 0, st, g, row0, row1, strips + qstrips, reinterpret_cast<const dc*>(partial),
                      pair_off, pairs, reinterpret_cast<const dc*>(corr), reinterpret_cast<const dc*>(diag_corr), reinterpret_cast<const dc*>(x),
                      reinterpret_cast<dc*>(y));
   MA_HIP(hipGetLastError());
@@ -430,6 +419,8 @@ int op_launch_tbem_matvec_t(const BemGeom& g, const BemPhys& ph, int row0, int r
   const int chunk_rows = (nr + nchunks - 1) / nchunks;
   dim3 grid((g.np + 255) / 256, nchunks), block(256);
   hipLaunchKernelGGL(tbem_matvec_t_kernel, grid, block, 0, st, g, ph, row0, row1, chunk_rows, reinterpret_cast<const dc*>(x), reinterpret_cast<dc*>(partial));
+  int rc = bem_launch_quad_matvec_t(g, ph, row0, row1, nchunks, chunk_rows, x, partial, st);      // overwrites the Quad4 panels' slots
+  if (rc) return rc;
   hipLaunchKernelGGL(tbem_matvec_t_finish_kernel, dim3((g.np + 255) / 256), block, 0, st, g, row0, row1, nchunks, reinterpret_cast<const dc*>(partial),
                      t_off, t_idx, pairs, reinterpret_cast<const dc*>(corr), reinterpret_cast<const dc*>(diag_corr), reinterpret_cast<const dc*>(x),
                      reinterpret_cast<dc*>(y));
@@ -440,7 +431,7 @@ int op_launch_pairs13(const BemGeom& g, const BemPhys& ph, const int2* pairs, lo
   if (npairs <= 0) return MA_OK;
   hipLaunchKernelGGL(tbem_pairs13_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(out));
   MA_HIP(hipGetLastError());
-  return MA_OK;
+  return bem_launch_quad_pairs_far(g, ph, pairs, npairs, out, st);       // pairs with a Quad4 field panel: what tbem_matvec_quad_kernel streams
 }
 int op_launch_sub_inplace(long long n, c64* corr, const c64* a13, hipStream_t st) {
   if (n <= 0) return MA_OK;

@@ -96,7 +96,6 @@ int ma_op_create_tbem(ma_bem_plan_t* P, const ma_physics_t* physics, double beta
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
   MA_REQUIRE(P, MA_ERR_INVALID, "plan is NULL");
   MA_REQUIRE(row0 >= 0 && row1 <= P->np && row0 < row1, MA_ERR_INVALID, "row range [%d,%d) outside 0..%d", row0, row1, P->np);
-  MA_REQUIRE(P->geom.nquad == 0, MA_ERR_UNSUPPORTED, "the matrix-free operator streams the 13-point Tri3 rule; the mesh has %d Quad4 panels", P->geom.nquad);
   ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
   int rc = ma_bem_make_phys(P, physics, beta_re, beta_im, &o->ph);
   if (rc) { delete o; return rc; }
@@ -108,7 +107,7 @@ int ma_op_create_tbem(ma_bem_plan_t* P, const ma_physics_t* physics, double beta
   o->nchunks = nch;
   hipError_t e = hipMalloc(&o->d_corr, sizeof(c64) * (size_t)(P->npairs > 0 ? P->npairs : 1));
   if (e == hipSuccess) e = hipMalloc(&o->d_diag, sizeof(c64) * (size_t)P->np);
-  if (e == hipSuccess) e = hipMalloc(&o->d_partial, sizeof(c64) * (size_t)std::max(nch, op_tbem_matvec_strips(P->np)) * (size_t)(row1 - row0));
+  if (e == hipSuccess) e = hipMalloc(&o->d_partial, sizeof(c64) * (size_t)std::max(nch, op_tbem_matvec_strips(P->np) + bem_quad_strips(P->geom)) * (size_t)(row1 - row0));
   c64* tmp = nullptr;
   if (e == hipSuccess) e = hipMalloc(&tmp, sizeof(c64) * (size_t)((P->npairs > P->np ? P->npairs : P->np) + 1));
   int2* dpairs_diag = nullptr;

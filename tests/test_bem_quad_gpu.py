@@ -102,13 +102,50 @@ def test_quad_very_near_point_hits_the_split_limit(gpu):
     plan.close()
 
 
-def test_quad_matrix_free_operator_is_refused(gpu):
-    om = cube_sphere(RADIUS, 3)
-    plan = ma.BemPlan(to_ma_mesh(om))
-    with pytest.raises(ma.MaError) as e:                  # the streaming operator is the Tri3 13-point rule
-        ma.LinearOperator.tbem(plan, 10.0, 0.4j)
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED
-    plan.close()
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("ka", [0.2, 2.5])
+def test_quad_matrix_free_operator_equals_dense_matvec(gpu, mixed, ka):
+    """The streamed operator over Quad4 (and mixed) meshes: Quad4 columns stream the un-subdivided n x n rule the distance
+    asks for (what the assembly's far kernel writes), Tri3 columns the 13-point rule; near pairs and the diagonal come in
+    as corrections. Same entries as the dense matrix, different summation order -- for A x, row blocks, A^T x, A^H x and
+    the diagonal preconditioner (fmm_interface.rs:177-212)."""
+    om = cube_sphere(RADIUS, 6, split_some=mixed)
+    n = om.n_elem
+    k = k_from_ka(ka)
+    beta = complex(0.0, 4.0 / k)
+    mesh = to_ma_mesh(om)
+    A, _ = ma.assemble_tbem(mesh, k, beta)
+    plan = ma.BemPlan(mesh)
+    op = ma.LinearOperator.tbem(plan, k, beta)
+    i = np.arange(n)
+    x = np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
+    y = op.apply(x)
+    ref = A @ x
+    assert np.all(np.isfinite(y.view(np.float64)))
+    assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+    h = n // 3
+    parts = np.zeros(n, dtype=complex)
+    acc = np.zeros(n, dtype=complex)
+    yt = op.apply_transpose(x)
+    assert np.abs(yt - A.T @ x).max() <= 1e-12 * np.abs(A.T @ x).max()
+    yh = op.apply_hermitian(x)
+    assert np.abs(yh - A.conj().T @ x).max() <= 1e-12 * np.abs(A.conj().T @ x).max()
+    for r0, r1 in ((0, h), (h, 2 * h), (2 * h, n)):
+        blk = ma.LinearOperator.tbem(plan, k, beta, rows=(r0, r1))
+        parts[r0:r1] = blk.apply(x)[r0:r1]
+        acc += blk.apply_transpose(x)
+        blk.close()
+    assert np.array_equal(parts, y)
+    assert np.abs(acc - yt).max() <= 1e-13 * np.abs(yt).max()
+    Mp = ma.Preconditioner(op, kind="diagonal")
+    z = Mp.apply(x)
+    assert np.abs(z - x / np.diag(A)).max() <= 1e-12 * np.abs(z).max()
+    b = ma.incident_rhs(om.center, om.normal, k, beta)
+    xs, info = ma.gmres_preconditioned(op, Mp, b, restart=30, max_iterations=200, tol=1e-9)
+    assert info.converged == 1
+    xd = np.linalg.solve(A, b)
+    assert np.linalg.norm(xs - xd) <= 1e-6 * np.linalg.norm(xd)
+    Mp.close(); op.close(); plan.close()
 
 
 @pytest.mark.parametrize("case", ["velocity_const", "nodal", "pressure_patch"])
