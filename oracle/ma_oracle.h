@@ -93,6 +93,14 @@ int mao_build_tbem_system_with_beta(int n_elem, const double* nodes, const int* 
         const unsigned char* is_eval,
         double k, double harmonic, double tau, double beta_re, double beta_im,
         mao_c64* A, mao_c64* rhs, int num_dofs, int row_begin, int row_end, int nthreads);
+/* packed != 0: A is a (row_end - row_begin) x num_dofs strip and rhs has row_end - row_begin entries (sampled rows of
+ * systems too large to hold whole, e.g. 50 172 panels) */
+int mao_build_tbem_rows(int n_elem, const double* nodes, const int* conn4,
+        const double* center, const double* normal, const double* area,
+        const int* dof, const unsigned char* bc_type, const mao_c64* bc_values, const int* bc_len,
+        const unsigned char* is_eval,
+        double k, double harmonic, double tau, double beta_re, double beta_im,
+        mao_c64* A, mao_c64* rhs, int num_dofs, int row_begin, int row_end, int nthreads, int packed);
 
 /* ---- incident field (incident.rs:93-342); kind 0 plane wave (dir, amplitude), 1 point source (pos, strength) */
 void mao_incident_pressure(int kind, const double* vec3, mao_c64 amp, int n, const double* points, double k, mao_c64* out);

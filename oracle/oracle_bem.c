@@ -597,6 +597,7 @@ typedef struct {
   double k, harmonic, tau; mao_c64 beta; double sign;
   mao_c64* A; mao_c64* rhs; int num_dofs;
   int row_begin, row_end, stride, offset;
+  int packed;     /* test convenience: rows [row_begin, row_end) stored as a (row_end - row_begin) x num_dofs strip */
 } tbem_job;
 
 static int has_nonzero_bc(const mao_c64* v, int n) {
@@ -621,13 +622,14 @@ static void* tbem_rows(void* arg) {
     mao_c64 s = C(0.0, 0.0);
     for (int i = 0; i < bcl; ++i) s = cadd(s, bcv[i]);
     mao_c64 avg = cdivr(s, (double)bcl);
-    mao_c64* Arow = J->A + (size_t)sdof * (size_t)J->num_dofs;
+    int srow = J->packed ? iel - J->row_begin : sdof;                /* where this source row is stored */
+    mao_c64* Arow = J->A + (size_t)srow * (size_t)J->num_dofs;
     if (bct == 0) {
       Arow[sdof] = csub(Arow[sdof], cscale(cg, 0.5));
-      J->rhs[sdof] = cadd(J->rhs[sdof], cscale(cmul(cmul(avg, J->beta), ct), 0.5));
+      J->rhs[srow] = cadd(J->rhs[srow], cscale(cmul(cmul(avg, J->beta), ct), 0.5));
     } else if (bct == 1) {
       Arow[sdof] = csub(Arow[sdof], cscale(cmul(J->beta, ct), 0.5));
-      J->rhs[sdof] = cadd(J->rhs[sdof], cscale(cmul(avg, ct), 0.5));
+      J->rhs[srow] = cadd(J->rhs[srow], cscale(cmul(avg, ct), 0.5));
     }
     for (int jel = 0; jel < J->n_elem; ++jel) {
       if (J->is_eval && J->is_eval[jel]) continue;
@@ -651,7 +653,7 @@ static void* tbem_rows(void* arg) {
       else if (fbt == 1) coeff = cneg(cadd(cmul(cmul(r.g, cg), ct), cmul(r.dg_dnx, J->beta)));
       else coeff = C(0.0, 0.0);
       Arow[fdof] = cadd(Arow[fdof], coeff);
-      if (crhs) J->rhs[sdof] = cadd(J->rhs[sdof], r.rhs);
+      if (crhs) J->rhs[srow] = cadd(J->rhs[srow], r.rhs);
     }
   }
   return NULL;
@@ -662,6 +664,17 @@ int mao_build_tbem_system_with_beta(int n_elem, const double* nodes, const int* 
         const int* dof, const unsigned char* bc_type, const mao_c64* bc_values, const int* bc_len,
         const unsigned char* is_eval, double k, double harmonic, double tau, double bre, double bim,
         mao_c64* A, mao_c64* rhs, int num_dofs, int row_begin, int row_end, int nthreads) {
+  return mao_build_tbem_rows(n_elem, nodes, conn, center, normal, area, dof, bc_type, bc_values, bc_len, is_eval, k, harmonic, tau,
+                             bre, bim, A, rhs, num_dofs, row_begin, row_end, nthreads, 0);
+}
+
+/* The same rows; packed != 0 stores source rows [row_begin, row_end) as a (row_end - row_begin) x num_dofs strip (A) and
+ * row_end - row_begin right-hand-side entries, so that sampled rows of a 50k-panel system need no N x N buffer. */
+int mao_build_tbem_rows(int n_elem, const double* nodes, const int* conn,
+        const double* center, const double* normal, const double* area,
+        const int* dof, const unsigned char* bc_type, const mao_c64* bc_values, const int* bc_len,
+        const unsigned char* is_eval, double k, double harmonic, double tau, double bre, double bim,
+        mao_c64* A, mao_c64* rhs, int num_dofs, int row_begin, int row_end, int nthreads, int packed) {
   /* tbem.rs:108-123 sign switch from the first <=100 element centres */
   double avg = 0.0; int nc = n_elem < 100 ? n_elem : 100;
   for (int e = 0; e < nc; ++e) avg += sqrt(dot3(center + 3*e, center + 3*e));
@@ -671,15 +684,16 @@ int mao_build_tbem_system_with_beta(int n_elem, const double* nodes, const int* 
   /* TbemSystem::new zeroes (tbem.rs:24-30): only the rows in range */
   for (int e = row_begin; e < row_end; ++e) {
     if (is_eval && is_eval[e]) continue;
-    memset(A + (size_t)dof[e] * (size_t)num_dofs, 0, sizeof(mao_c64) * (size_t)num_dofs);
-    rhs[dof[e]] = C(0.0, 0.0);
+    int srow = packed ? e - row_begin : dof[e];
+    memset(A + (size_t)srow * (size_t)num_dofs, 0, sizeof(mao_c64) * (size_t)num_dofs);
+    rhs[srow] = C(0.0, 0.0);
   }
   if (nthreads < 1) nthreads = 1;
   tbem_job* jobs = (tbem_job*)malloc(sizeof(tbem_job) * (size_t)nthreads);
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
   for (int t = 0; t < nthreads; ++t) {
     tbem_job j = {n_elem, nodes, conn, center, normal, area, dof, bc_type, bc_values, bc_len, is_eval,
-                  k, harmonic, tau, {bre, bim}, sign, A, rhs, num_dofs, row_begin, row_end, nthreads, t};
+                  k, harmonic, tau, {bre, bim}, sign, A, rhs, num_dofs, row_begin, row_end, nthreads, t, packed};
     jobs[t] = j;
     if (nthreads > 1) pthread_create(&th[t], NULL, tbem_rows, &jobs[t]);
   }

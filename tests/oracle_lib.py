@@ -205,6 +205,21 @@ def build_tbem_system_with_beta(mesh, k, beta, harmonic=1.0, tau=1.0, nthreads=1
     return A, rhs
 
 
+def build_tbem_rows(mesh, k, beta, r0, r1, harmonic=1.0, tau=1.0, nthreads=1):
+    """Source rows [r0, r1) of the system as an (r1 - r0) x N strip (+ their right-hand-side entries)."""
+    n = mesh.n_elem
+    nd = int((mesh.is_eval == 0).sum())
+    A = np.zeros((r1 - r0, nd), dtype=np.complex128); rhs = np.zeros(r1 - r0, dtype=np.complex128)
+    beta = complex(beta)
+    rc = lib().mao_build_tbem_rows(
+        n, _p(mesh.nodes), _p(mesh.conn, C.c_int), _p(mesh.center), _p(mesh.normal), _p(mesh.area),
+        _p(mesh.dof, C.c_int), _p(mesh.bc_type, C.c_ubyte), _vp(mesh.bc_values), _p(mesh.bc_len, C.c_int),
+        _p(mesh.is_eval, C.c_ubyte), C.c_double(k), C.c_double(harmonic), C.c_double(tau),
+        C.c_double(beta.real), C.c_double(beta.imag), _vp(A), _vp(rhs), nd, r0, r1, nthreads, 1)
+    assert rc == 0
+    return A, rhs
+
+
 def compute_rhs_with_beta(centers, normals, k, beta, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, tau=1.0):
     centers = np.ascontiguousarray(centers, dtype=np.float64); normals = np.ascontiguousarray(normals, dtype=np.float64)
     v = np.ascontiguousarray(vec, dtype=np.float64)

@@ -128,3 +128,28 @@ def test_boundary_values_reach_the_rhs(gpu, case):
         assert np.abs(rhs_ref).max() > 0
         assert np.abs(rhs - rhs_ref).max() <= 1e-10 * np.abs(rhs_ref).max()
         assert rowscaled_maxerr(A, A_ref) <= 1e-9
+
+
+def test_self_term_fourth_tier(gpu):
+    """QuadratureParams::for_ka's last tier (6, 7, 10, 4), singular.rs:74-81: element ka >= 2. The 10 000-panel sweep only
+    reaches the third tier at 8 kHz; coarse icospheres at 8 kHz put every panel in the fourth (edge 55 mm and 28 mm,
+    k = 146.5: element ka = 8.0 and 4.1). Raw self integrals, then the assembled system, against the CPU restatement."""
+    k = O.wave_number(8000.0, 343.0)
+    for sub in (1, 2):
+        om = O.icosphere(RADIUS, sub)
+        edge = np.array([np.mean([np.linalg.norm(om.coords(e)[a] - om.coords(e)[(a + 1) % 3]) for a in range(3)]) for e in range(om.n_elem)])
+        assert (k * edge).min() >= 2.0
+        mesh = to_ma_mesh(om)
+        plan = ma.BemPlan(mesh)
+        selfs = plan.probe_self(k)
+        for e in range(om.n_elem):
+            ref = O.singular_integration(om.center[e], om.normal[e], om.coords(e), k)[:4]
+            ref4 = O.singular_integration(om.center[e], om.normal[e], om.coords(e), k, params=(6, 7, 10, 4))[:4]
+            assert np.array_equal(ref, ref4)
+            assert np.all(np.abs(selfs[e, 1:5] - ref) <= 1e-10 * np.abs(ref).max()), (sub, e)
+        assert int(round(selfs[0, 0].real)) == 3 * 10 * 6 + 3 * 4 * 7 * 7         # edge points + sub-triangle points
+        plan.close()
+        beta = complex(0.0, 4.0 / k)
+        A_ref, _ = O.build_tbem_system_with_beta(om, k, beta, nthreads=8)
+        A, _ = ma.assemble_tbem(mesh, k, beta)
+        assert rowscaled_maxerr(A, A_ref) <= 1e-9

@@ -1,0 +1,180 @@
+"""BASELINE.json configs[4] on the device: the closed 0.30 x 0.40 x 0.60 m box (loudspeaker-cabinet stand-in),
+f = 1 kHz, monopole at (0.15, 0.20, 1.0), Burton-Miller beta = 4 i / k, GMRES(50).
+
+A box is a different input class from the spheres of configs 1-3: flat faces (d . n_y = 0 exactly for coplanar pairs, so
+the double-layer part of those entries vanishes and only the hypersingular part remains), 90 degree edges (near pairs whose
+panels are perpendicular), and anisotropic right triangles. Sizes: 516 panels (every entry against the CPU restatement),
+3456 panels (sampled rows + GMRES iteration count), and the full 50 172 panels (sampled rows of the stored matrix and of
+`apply` against oracle rows, stored-vs-matrix-free agreement, GMRES to convergence with the true residual checked)."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from math_audio_amd import mesh as mm
+from helpers import to_ma_mesh, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BOX = (0.30, 0.40, 0.60)
+SRC = (0.15, 0.20, 1.0)
+K1K = mm.wave_number(1000.0)
+BETA = mm.burton_miller_beta_scaled(K1K, 4.0)
+
+
+def _xvec(n):
+    i = np.arange(n)
+    return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)          # test_fmm_validation.rs:121
+
+
+def _box(nx, ny, nz, reverse_every=0):
+    m = mm.generate_box_mesh(*BOX, nx, ny, nz)
+    conn = m.conn.copy()
+    if reverse_every:                                      # reversed winding: n_y = -(stored normal) on those panels
+        idx = np.arange(0, conn.shape[0], reverse_every)
+        conn[idx, 1], conn[idx, 2] = m.conn[idx, 2], m.conn[idx, 1]
+    om = O.Mesh(m.nodes, conn)
+    return om, to_ma_mesh(om)
+
+
+@pytest.mark.parametrize("reverse_every", [0, 3])
+def test_small_box_every_entry_and_the_operator(gpu, reverse_every):
+    om, mesh = _box(5, 6, 9, reverse_every)
+    n = om.n_elem
+    assert n == 516
+    A_ref, r_ref = O.build_tbem_system_with_beta(om, K1K, BETA, nthreads=8)
+    A, r0 = ma.assemble_tbem(mesh, K1K, BETA)
+    plan = ma.BemPlan(mesh)
+    near = plan.near_pairs()
+    # the level-0 split decision pair for pair (singular.rs:553-556)
+    ref_near = set()
+    for i in range(n):
+        d = np.linalg.norm(om.center - om.center[i], axis=1)
+        for j in np.nonzero(d < 6.0 * np.sqrt(om.area.max()))[0]:
+            if i != j:
+                subs = O.generate_subelements(om.center[i], om.coords(j), om.area[j])
+                if not (len(subs) == 1 and abs(subs[0].factor - 1.0) < 1e-10):
+                    ref_near.add((i, int(j)))
+    assert set(map(tuple, near.tolist())) == ref_near
+    mask = np.zeros(A.shape, dtype=bool); mask[near[:, 0], near[:, 1]] = True; np.fill_diagonal(mask, True)
+    err = np.abs(A - A_ref) / np.abs(A_ref).max(axis=1, keepdims=True)
+    assert err[~mask].max() <= 1e-11 and err[mask].max() <= 1e-9
+    # coplanar pairs exist and their entries are pure hypersingular terms: present in both, and equal
+    dc = om.center[None, :, :] - om.center[:, None, :]
+    coplanar = (np.abs(om.normal @ om.normal.T - 1.0) < 1e-14) & (np.abs(np.einsum("ijd,id->ij", dc, om.normal)) < 1e-15)
+    np.fill_diagonal(coplanar, False)
+    assert coplanar.sum() > 10 * n and np.all(np.abs(A_ref[coplanar]) > 0.0)
+    assert (np.abs(A - A_ref)[coplanar] / np.broadcast_to(np.abs(A_ref).max(axis=1, keepdims=True), A.shape)[coplanar]).max() <= 1e-9
+    # matrix-free operator: apply / transpose / hermitian / row blocks against the restatement's A
+    x = _xvec(n)
+    op = ma.LinearOperator.tbem(plan, K1K, BETA)
+    y_ref = A_ref @ x
+    assert np.abs(op.apply(x) - y_ref).max() <= 1e-10 * np.abs(y_ref).max()
+    yt_ref = A_ref.T @ x
+    assert np.abs(op.apply_transpose(x) - yt_ref).max() <= 1e-10 * np.abs(yt_ref).max()
+    yh_ref = A_ref.conj().T @ x
+    assert np.abs(op.apply_hermitian(x) - yh_ref).max() <= 1e-10 * np.abs(yh_ref).max()
+    blocks = [(0, 130), (130, 131), (131, 400), (400, n)]
+    yb = np.zeros(n, dtype=np.complex128)
+    for r0_, r1_ in blocks:
+        ob = ma.LinearOperator.tbem(plan, K1K, BETA, rows=(r0_, r1_))
+        yblock = ob.apply(x)                               # a row block returns its rows, zero elsewhere
+        assert np.all(yblock[:r0_] == 0.0) and np.all(yblock[r1_:] == 0.0)
+        yb[r0_:r1_] = yblock[r0_:r1_]
+        ob.close()
+    assert np.abs(yb - y_ref).max() <= 1e-10 * np.abs(y_ref).max()
+    # GMRES(50) with the point source of config #5: same iteration count as the restatement's gmres on its own matrix
+    b_ref = r_ref + O.compute_rhs_with_beta(om.center, om.normal, K1K, BETA, kind=1, vec=SRC)
+    b = r0 + ma.incident_rhs(om.center, om.normal, K1K, BETA, kind=1, vec=SRC)
+    assert np.abs(b - b_ref).max() <= 1e-13 * np.abs(b_ref).max()
+    x_ref, info_ref = O.gmres(b_ref, dense=A_ref, restart=50, max_iterations=20, tol=1e-6)
+    x_dev, info = ma.gmres(op, b, restart=50, max_iterations=20, tol=1e-6)
+    assert info_ref.converged == 1 and info.converged == 1
+    assert abs(info.iterations - info_ref.iterations) <= 1 and info.restarts == info_ref.restarts
+    assert rel_l2(x_dev, x_ref) <= 1e-5                   # both stop at 1e-6 relative residual
+    # and the direct solve of the same system
+    xs = ma.zgesv(A, b)
+    xs_ref, _, rc = O.zgesv(A_ref, b_ref, nthreads=4)
+    assert rc == 0 and rel_l2(xs, xs_ref) <= 1e-8
+    op.close(); plan.close()
+
+
+def test_mid_box_sampled_rows_and_gmres_counts(gpu):
+    import torch
+    om, mesh = _box(12, 16, 24)
+    n = om.n_elem
+    assert n == 3456
+    plan = ma.BemPlan(mesh)
+    dev = torch.device("cuda", 0)
+    A = torch.empty(n * n, dtype=torch.complex128, device=dev); r0 = torch.empty(n, dtype=torch.complex128, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.assemble_dev(K1K, BETA, A.data_ptr(), r0.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    Ah = A.view(n, n)
+    x = _xvec(n)
+    free = ma.LinearOperator.tbem(plan, K1K, BETA)
+    stored = ma.LinearOperator.dense_dev(n, A.data_ptr(), keep=A)
+    yf, ys = free.apply(x), stored.apply(x)
+    assert np.abs(yf - ys).max() <= 1e-11 * np.abs(ys).max()
+    rows = [0, 1, 383, 384, 1151, 1152, 2400, n - 1]       # face corners, face interiors, the first panel of each face pair
+    for r in rows:
+        S, _ = O.build_tbem_rows(om, K1K, BETA, r, r + 1)
+        row = Ah[r].cpu().numpy()
+        assert np.abs(row - S[0]).max() <= 1e-9 * np.abs(S[0]).max(), r
+        assert abs(yf[r] - S[0] @ x) <= 1e-10 * np.abs(ys).max(), r
+    b = ma.incident_rhs(om.center, om.normal, K1K, BETA, kind=1, vec=SRC)
+    A_ref, r_ref = O.build_tbem_system_with_beta(om, K1K, BETA, nthreads=8)
+    assert np.abs(r_ref).max() == 0.0
+    x_ref, info_ref = O.gmres(b, dense=A_ref, restart=50, max_iterations=20, tol=1e-6)
+    for op in (free, stored):
+        xd, info = ma.gmres(op, b, restart=50, max_iterations=20, tol=1e-6)
+        assert info.converged == info_ref.converged == 1
+        assert abs(info.iterations - info_ref.iterations) <= 2 and info.restarts == info_ref.restarts
+        assert np.linalg.norm(A_ref @ xd - b) / np.linalg.norm(b) <= 2e-6
+    free.close(); stored.close(); plan.close()
+
+
+def test_full_50k_box_stored_and_matrix_free(gpu):
+    """The whole configuration: 46 x 61 x 91 cells = 50 172 panels (40 GB stored)."""
+    import torch
+    om, mesh = _box(46, 61, 91)
+    n = om.n_elem
+    assert n == 50172
+    plan = ma.BemPlan(mesh)
+    dev = torch.device("cuda", 0)
+    A = torch.empty(n * n, dtype=torch.complex128, device=dev); r0 = torch.empty(n, dtype=torch.complex128, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.assemble_dev(K1K, BETA, A.data_ptr(), r0.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert float(r0.abs().max()) == 0.0
+    Ah = A.view(n, n)
+    x = _xvec(n)
+    free = ma.LinearOperator.tbem(plan, K1K, BETA)
+    stored = ma.LinearOperator.dense_dev(n, A.data_ptr(), keep=A)
+    yf, ys = free.apply(x), stored.apply(x)
+    scale = np.abs(ys).max()
+    assert np.all(np.isfinite(yf.view(np.float64)))
+    assert np.abs(yf - ys).max() <= 1e-10 * scale
+    ytf, yts = free.apply_transpose(x), stored.apply_transpose(x)
+    assert np.abs(ytf - yts).max() <= 1e-10 * np.abs(yts).max()
+    # sampled rows against the CPU restatement: a corner panel and an interior panel of each face family, first and last
+    rows = [0, 1, 2805, 5612 + 17, 5612 + 8372 // 2, 13984 + 37, 13984 + 11102 + 5000, n // 2, n - 1]
+    for r in rows:
+        S, _ = O.build_tbem_rows(om, K1K, BETA, r, r + 1)
+        row = Ah[r].cpu().numpy()
+        assert np.abs(row - S[0]).max() <= 1e-9 * np.abs(S[0]).max(), r
+        assert abs(yf[r] - S[0] @ x) <= 1e-10 * scale, r
+        assert abs(ys[r] - S[0] @ x) <= 1e-10 * scale, r
+    # row blocks of the matrix-free operator (the 8-GPU sharding unit): block g of 8 reproduces its slice
+    g0, g1 = (3 * n) // 8, (4 * n) // 8
+    ob = ma.LinearOperator.tbem(plan, K1K, BETA, rows=(g0, g1))
+    yb = ob.apply(x)
+    assert np.abs(yb[g0:g1] - ys[g0:g1]).max() <= 1e-10 * scale and np.all(yb[:g0] == 0.0) and np.all(yb[g1:] == 0.0)
+    ob.close()
+    # GMRES(50) + DiagonalPreconditioner on the stored operator to 1e-6; the true residual through the matrix-free operator
+    b = ma.incident_rhs(om.center, om.normal, K1K, BETA, kind=1, vec=SRC)
+    Mp = ma.Preconditioner(stored, kind="diagonal")
+    xs, info = ma.gmres_preconditioned(stored, Mp, b, restart=50, max_iterations=60, tol=1e-6)
+    assert info.converged == 1 and info.residual <= 1e-6
+    res = np.linalg.norm(free.apply(xs) - b) / np.linalg.norm(b)
+    assert res <= 1e-4, res                                # left-preconditioned stop: |M^-1 r| / |M^-1 b| <= 1e-6
+    Mp.close(); free.close(); stored.close(); plan.close()

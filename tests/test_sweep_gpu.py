@@ -102,24 +102,38 @@ def test_level_overflow_quirk_on_device(gpu):
     plan.close()
 
 
-def test_full_size_sphere_properties(gpu):
-    """S10 (10 000 panels, BASELINE.json configs[2]) at 926 Hz: sampled rows against the CPU restatement,
-    residual and linearity of the device solve."""
+@pytest.mark.parametrize("fidx", [0, 32, 63])
+def test_full_size_sphere_properties(gpu, fidx):
+    """S10 (10 000 panels, BASELINE.json configs[2]) at the two ends and the middle of the 64-point sweep -- 100 Hz
+    (ka = 0.18: dg_dn sign +1, tbem.rs:123; self terms in for_ka's first tier), 926 Hz, 8 kHz (ka = 14.7: sign -1, the
+    equatorial triangles' self terms in the third tier): sampled rows against the CPU restatement, the self terms of
+    sampled panels, residual and linearity of the device solve."""
     import torch
     mesh = mm.generate_sphere_mesh(RADIUS, 51, 100)
     n = mesh.n_elem
-    f = mm.log_space(100.0, 8000.0, 64)[32]
+    f = mm.log_space(100.0, 8000.0, 64)[fidx]
     k = mm.wave_number(f); beta = mm.burton_miller_beta_scaled(k, 4.0)
+    assert (k * RADIUS < 0.5) == (fidx == 0)
     A, b, x = _device_solve(mesh, k, beta)
     # (1) sampled rows vs the oracle (first, last, and three interior rows incl. polar caps)
     om = O.uv_sphere(RADIUS, 51, 100)
     assert np.abs(om.nodes - mesh.nodes).max() <= 2e-17
     om.nodes[:] = mesh.nodes; om.center[:] = mesh.center; om.normal[:] = mesh.normal; om.area[:] = mesh.area
-    Aref = np.zeros((n, n), dtype=np.complex128); rref = np.zeros(n, dtype=np.complex128)
     for r0 in (0, 137, 5000, 9999):
-        O.build_tbem_system_with_beta(om, k, beta, nthreads=8, rows=(r0, r0 + 1), A=Aref, rhs=rref)
+        S, _ = O.build_tbem_rows(om, k, beta, r0, r0 + 1)
         row = A[r0].cpu().numpy()
-        assert np.abs(row - Aref[r0]).max() <= 1e-9 * np.abs(Aref[r0]).max()
+        assert np.abs(row - S[0]).max() <= 1e-9 * np.abs(S[0]).max()
+    # the for_ka tier of the self terms (singular.rs:48-82) at this frequency: polar cap and equator panels
+    tiers = set()
+    plan = ma.BemPlan(mesh)
+    selfs = plan.probe_self(k)
+    for e in (0, 137, 4950, 5000, 9999):
+        ka_el = k * np.mean([np.linalg.norm(om.coords(e)[a] - om.coords(e)[(a + 1) % 3]) for a in range(3)])
+        tiers.add(0 if ka_el < 0.3 else 1 if ka_el < 1.0 else 2 if ka_el < 2.0 else 3)
+        ref = O.singular_integration(om.center[e], om.normal[e], om.coords(e), k)[:4]
+        assert np.all(np.abs(selfs[e, 1:5] - ref) <= 1e-10 * np.abs(ref).max()), e
+    plan.close()
+    assert tiers == ({1, 2} if fidx == 63 else {0}), tiers     # 8 kHz: 7600 panels in the second tier, 2400 (equator) in the third
     # (2) residual of the solve, computed on the device with the saved copy of A
     res = torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)
     assert float(res) <= 1e-10
