@@ -82,6 +82,9 @@ def test_small_box_every_entry_and_the_operator(gpu, reverse_every):
         yb[r0_:r1_] = yblock[r0_:r1_]
         ob.close()
     assert np.abs(yb - y_ref).max() <= 1e-10 * np.abs(y_ref).max()
+    if reverse_every:          # panels with inward n_y make the system physically inconsistent: entries and operator parity only
+        op.close(); plan.close()
+        return
     # GMRES(50) with the point source of config #5: same iteration count as the restatement's gmres on its own matrix
     b_ref = r_ref + O.compute_rhs_with_beta(om.center, om.normal, K1K, BETA, kind=1, vec=SRC)
     b = r0 + ma.incident_rhs(om.center, om.normal, K1K, BETA, kind=1, vec=SRC)
