@@ -95,6 +95,7 @@ typedef struct ma_bem_plan ma_bem_plan_t;
 int ma_bem_plan_create(const ma_mesh_t* mesh, int device, ma_bem_plan_t** out);
 int ma_bem_plan_destroy(ma_bem_plan_t* plan);
 int ma_bem_plan_num_dofs(const ma_bem_plan_t* plan, int32_t* num_dofs);
+int ma_bem_plan_device(const ma_bem_plan_t* plan, int* device);   /* the device the plan's arrays live on */
 int ma_bem_plan_num_near_pairs(const ma_bem_plan_t* plan, int64_t* n);
 /* d_A (num_dofs^2 ma_c64) and d_rhs (num_dofs) are DEVICE pointers; work is enqueued on `stream`. */
 int ma_bem_plan_assemble_dev(ma_bem_plan_t* plan, const ma_physics_t* physics, double beta_re, double beta_im,
@@ -136,6 +137,16 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
                        double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, int32_t slots,
                        ma_c64* X_out, int32_t* status_or_null);
 
+/* The same loop over the GPUs of one node (BASELINE.json configs[2]): frequency f is solved on devices[f mod ndev]
+ * (ma_sweep_owner), one host thread, BEM plan, LU plan and stream per device, no collective on the data path; X_out
+ * (n_freq x num_dofs) and status_or_null are indexed by f as above. A Rust caller replaces the `for freq` loop of
+ * math-bem/bin/room_simulator_bem.rs:329 by this one call. ma_bem_solve_sweep itself runs on its plan's device, whatever
+ * device the calling thread has selected, and leaves the thread's current device unchanged. */
+int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz,
+                             double speed_of_sound, double harmonic_factor, double tau, double beta_scale, int incident_kind,
+                             const double* incident_vec3, double amp_re, double amp_im, int32_t slots, ma_c64* X_out, int32_t* status_or_null);
+int ma_sweep_owner(int32_t frequency_index, int32_t ndev);      /* index into devices[] of the owner of a frequency */
+
 /* The same solve with the reference's own signature, lu_solve(&a, &b) -> x: inputs untouched, factors not copied back. */
 int ma_lu_solve(int32_t n, const ma_c64* A_rowmajor, const ma_c64* b, ma_c64* x);
 /* lu_factorize(&a) -> LuFactorization (lu.rs:83-137) and LuFactorization::solve(&b) (lu.rs:38-78): the factors stay in HBM. */
@@ -176,6 +187,12 @@ int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);
 /* after stage_finish: the slot's status word (0, or 1 + the column of the first zero pivot) copied to a device int on `stream` */
 int ma_lu_plan_stage_info_dev(ma_lu_plan_t* plan, int32_t slot, int32_t* d_out, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
+/* Status values of the dense solve: MA_ERR_SINGULAR when a pivot column's largest entry is below 1e-30 in modulus (lu.rs:106-110,
+ * which includes zgetf2's exact zero) or holds no comparable value (NaN); MA_ERR_HIP when a panel kernel was abandoned (its
+ * co-resident workgroups did not complete an exchange within the limit: the plan is poisoned until the next factorisation starts,
+ * no rows are moved with pivots of an abandoned panel). The rule that keeps panel kernels co-resident, as a pure function
+ * (DESIGN.md 4 "Residency"): a CU can always take `slots` spinning workgroups of lds_bytes / regs registers per lane. */
+int ma_lu_panel_slots_per_cu(int64_t lds_bytes, int32_t regs, int32_t* slots);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse FEM side: complex CSR operator, SpMV, residual, Jacobi-type smoother sweeps.
@@ -256,6 +273,16 @@ int ma_op_create_dense_dev(int64_t n, const void* d_A, int device, ma_op_t** out
 int ma_op_create_csr(ma_csr_t* csr, ma_op_t** out);
 int ma_op_create_tbem(ma_bem_plan_t* plan, const ma_physics_t* physics, double beta_re, double beta_im,
                       int32_t row0, int32_t row1, ma_op_t** out);
+/* The same operator ROW-SHARDED over the GPUs of one node (BASELINE.json configs[4], the memory-capped
+ * dense-free path): devices[g] owns collocation rows [g N / ndev, (g+1) N / ndev) with its own BEM plan (the geometry is O(N)),
+ * applies its row block against all field panels, and the y slices are gathered on devices[0] by peer copies inside the library
+ * (one exchange per apply, 16 B N in total, no reduction). Every vector the caller passes lives on devices[0], so ma_gmres,
+ * ma_gmres_preconditioned and ma_precond_create_diagonal drive it like any other ma_op_t. apply_transpose / apply_hermitian sum
+ * the shards' contributions on devices[0] in shard order. The mesh is only borrowed during the call. */
+int ma_op_create_tbem_multi(const ma_mesh_t* mesh, const ma_physics_t* physics, double beta_re, double beta_im,
+                            const int32_t* devices, int32_t ndev, ma_op_t** out);
+/* number of shards of an operator (1 unless row-sharded) and, optionally, their first rows and devices */
+int ma_op_num_shards(const ma_op_t* op, int32_t* shards, int32_t* row_begin_or_null, int32_t* device_or_null);
 int ma_op_destroy(ma_op_t* op);
 int ma_op_num_rows(const ma_op_t* op, int64_t* n);
 int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);

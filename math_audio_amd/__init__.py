@@ -79,6 +79,9 @@ def lib():
             "ma_lu_plan_solve_dev": [vp, vp, vp, i32, vp],
             "ma_lu_solve": [i32, vp, vp, vp],
             "ma_bem_solve_sweep": [vp, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
+            "ma_bem_solve_sweep_multi": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
+            "ma_sweep_owner": [i32, i32],
+            "ma_bem_plan_device": [vp, P(C.c_int)],
             "ma_lu_factorize": [i32, vp, P(vp)],
             "ma_lu_factorization_solve": [vp, vp, vp],
             "ma_lu_factorization_destroy": [vp],
@@ -121,6 +124,8 @@ def lib():
             "ma_op_create_dense_dev": [i64, vp, C.c_int, P(vp)],
             "ma_op_create_csr": [vp, P(vp)],
             "ma_op_create_tbem": [vp, P(ma_physics_t), dbl, dbl, i32, i32, P(vp)],
+            "ma_op_create_tbem_multi": [P(ma_mesh_t), P(ma_physics_t), dbl, dbl, vp, i32, P(vp)],
+            "ma_op_num_shards": [vp, P(i32), vp, vp],
             "ma_op_destroy": [vp],
             "ma_op_num_rows": [vp, P(i64)],
             "ma_op_apply": [vp, vp, vp],
@@ -235,6 +240,9 @@ class BemPlan:
         m = C.c_int64()
         check(lib().ma_bem_plan_num_near_pairs(self.h, C.byref(m)))
         self.num_near_pairs = m.value
+        d = C.c_int()
+        check(lib().ma_bem_plan_device(self.h, C.byref(d)))
+        self.device = d.value
 
     def close(self):
         if self.h:
@@ -541,6 +549,23 @@ class LinearOperator:
         check(lib().ma_op_create_tbem(plan.h, C.byref(ph), beta.real, beta.imag, r0, r1, C.byref(h)))
         return LinearOperator(h, plan)
 
+    @staticmethod
+    def tbem_multi(mesh, k, beta, devices, harmonic=1.0, tau=1.0):
+        """ma_op_create_tbem_multi: the matrix-free operator row-sharded over `devices` (vectors live on devices[0])."""
+        ph = physics(k, harmonic, tau); beta = complex(beta)
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().ma_op_create_tbem_multi(C.byref(mesh.c), C.byref(ph), beta.real, beta.imag, _vp(dv), len(dv), C.byref(h)))
+        return LinearOperator(h, mesh)
+
+    def shards(self):
+        """(first rows, devices) of the operator's shards."""
+        ns = C.c_int32()
+        check(lib().ma_op_num_shards(self.h, C.byref(ns), None, None))
+        rows = np.zeros(ns.value, dtype=np.int32); devs = np.zeros(ns.value, dtype=np.int32)
+        check(lib().ma_op_num_shards(self.h, C.byref(ns), _vp(rows), _vp(devs)))
+        return rows, devs
+
     def close(self):
         if self.h:
             lib().ma_op_destroy(self.h)
@@ -769,6 +794,25 @@ def solve_sweep(plan, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind
     X = np.empty((len(f), plan.num_dofs), dtype=np.complex128); st = np.zeros(len(f), dtype=np.int32)
     rc = lib().ma_bem_solve_sweep(plan.h, len(f), _vp(f), float(speed_of_sound), float(harmonic), float(tau), float(beta_scale), int(kind), _vp(v),
                                   amp.real, amp.imag, int(slots), _vp(X), _vp(st))
+    if rc not in (MA_OK, MA_ERR_SINGULAR):
+        check(rc)
+    return X, st
+
+
+def sweep_owner(frequency_index, ndev):
+    """Index into `devices` of the device that solves a frequency in ma_bem_solve_sweep_multi (f mod ndev)."""
+    return lib().ma_sweep_owner(int(frequency_index), int(ndev))
+
+
+def solve_sweep_multi(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, slots=3, harmonic=1.0, tau=1.0):
+    """ma_bem_solve_sweep_multi: the frequency loop over the GPUs of one node, frequency f on devices[f mod ndev], one host
+    thread per device inside the library. Returns (X[n_freq, n], status[n_freq])."""
+    f = np.ascontiguousarray(frequencies_hz, dtype=np.float64); v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)
+    dv = np.ascontiguousarray(devices, dtype=np.int32)
+    nd = int((mesh.is_eval == 0).sum()) if mesh.is_eval is not None else mesh.n_elem
+    X = np.empty((len(f), nd), dtype=np.complex128); st = np.zeros(len(f), dtype=np.int32)
+    rc = lib().ma_bem_solve_sweep_multi(C.byref(mesh.c), _vp(dv), len(dv), len(f), _vp(f), float(speed_of_sound), float(harmonic), float(tau), float(beta_scale),
+                                        int(kind), _vp(v), amp.real, amp.imag, int(slots), _vp(X), _vp(st))
     if rc not in (MA_OK, MA_ERR_SINGULAR):
         check(rc)
     return X, st

@@ -279,6 +279,12 @@ int ma_bem_plan_destroy(ma_bem_plan_t* P) {
   return MA_OK;
 }
 
+int ma_bem_plan_device(const ma_bem_plan_t* P, int* device) {
+  MA_REQUIRE(P && device, MA_ERR_INVALID, "NULL argument");
+  *device = P->device;
+  return MA_OK;
+}
+
 int ma_bem_plan_num_dofs(const ma_bem_plan_t* P, int32_t* n) {
   MA_REQUIRE(P && n, MA_ERR_INVALID, "NULL argument");
   *n = P->nd;

@@ -112,8 +112,15 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     int rr = idx / nb, j = idx - rr * nb;
     P[rr * pitch + j] = A[(size_t)(r0 + rr) * n + k0 + j];
   }
-  if (tid == 0) s_misc[3] = 0;
+  if (tid == 0) { s_misc[3] = 0; s_misc[2] = (int)__hip_atomic_load(ws.timeout, RLX_AGENT); }
   __syncthreads();
+  // A plan whose earlier panel was aborted (exchange timed out, see below) is poisoned: every later panel kernel leaves at
+  // once and records identity pivots, so that nothing downstream ever sees an unwritten pivot. Workgroups that miss the
+  // flag here meet it in their first sweep.
+  if (s_misc[2] != 0) {
+    if (b == 0) for (int j = tid; j < nb; j += 256) ipiv[k0 + j] = k0 + j;
+    return;
+  }
 
   // local candidate of column `col` among rows >= k0+col -> s_bestv[0], s_misc[0] (after the barriers)
   auto scan_column = [&](int col) {
@@ -193,12 +200,14 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     unsigned bhi = 0, brow = 0xFFFFFFu; bool fail = false;
     for (;;) {
       bool ok = true; bhi = 0; brow = 0xFFFFFFu;
+      unsigned ab = 0u;
       if (lane < g_per) {
         const u64 g = __hip_atomic_load(mbase + (size_t)lane * g_ngrp * LU_GRANULE_STRIDE, RLX_AGENT);
         ok = ((unsigned)(g >> 24) & 0xFFu) == want;
         bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
-      }
+      } else if (lane == 63) ab = __hip_atomic_load(ws.timeout, RLX_AGENT);          // the plan's abort flag rides along
       if (__all(ok)) break;
+      if (__any(ab != 0u)) { fail = true; break; }
       __builtin_amdgcn_s_sleep(1);
       if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }   // 4 s at 100 MHz: never hang (the sweep below reports it)
     }
@@ -240,14 +249,17 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
       bool fail = false;
       unsigned bhi = 0, brow = 0xFFFFFFu;
       const u64* gbase = ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS) * LU_GRANULE_STRIDE;
+      if (gc == ws.test_abort_col && b == nblk - 1) fail = true;   // test hook: this workgroup behaves as if its wait had expired
       while (!fail) {
         bool ok = true; bhi = 0; brow = 0xFFFFFFu;
+        unsigned ab = 0u;
         if (lane < ngrp) {
           const u64 g = __hip_atomic_load(gbase + (size_t)lane * LU_GRANULE_STRIDE, RLX_AGENT);
           ok = ((unsigned)(g >> 24) & 0xFFu) == want;
           bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
-        }
+        } else if (lane == 63) ab = __hip_atomic_load(ws.timeout, RLX_AGENT);        // another workgroup (or system of the plan) gave up
         if (__all(ok)) break;
+        if (__any(ab != 0u)) { fail = true; break; }
         __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;
       }
@@ -269,7 +281,10 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     if (c == 0 && tid == 0) stamp_acc[7] += __builtin_amdgcn_s_memrealtime() - stamp_t;   // residency wait: first column only
 #endif
     MA_STAMP(0);
-    if (s_misc[3]) return;                               // uniform: the whole workgroup leaves
+    if (s_misc[3]) {                                     // uniform: the whole workgroup leaves; the columns it did not reach get
+      if (b == 0) for (int j = c + tid; j < nb; j += 256) ipiv[k0 + j] = k0 + j;   // identity pivots (the plan is poisoned: MA_ERR_HIP)
+      return;
+    }
     const int p = s_misc[1], wb = s_misc[2];
     MA_STAMP(1);
     // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads. Rows are published as they stood BEFORE
@@ -308,8 +323,10 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     if (gc >= r0 && gc < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(gc - r0) * pitch + t] = urow[t];
     if (b == 0 && tid == 0) ipiv[gc] = p;
     const dc piv = urow[c];
-    const bool singular = (piv.re == 0.0 && piv.im == 0.0);
-    if (singular && b == 0 && tid == 0) atomicCAS(ws.info, 0, gc + 1);   // first zero pivot, as zgetf2's INFO
+    // lu.rs:106-110: a pivot column whose largest |z| is below 1e-30 is LuError::SingularMatrix (an exact zero is zgetf2's
+    // INFO); the elimination of that column is skipped either way
+    const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
+    if (singular && b == 0 && tid == 0) atomicCAS(ws.info, 0, gc + 1);   // first such pivot, 1-based
     __syncthreads();
     // ---- multipliers l = a / pivot (reciprocal scaling, zgetf2) and the update of column c+1 only
     const bool more = c + 1 < nb;
@@ -481,21 +498,28 @@ __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, 
 
 
 __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
-                                                     const dc* __restrict__ T, int ldt, dc* __restrict__ invd) {
+                                                     const dc* __restrict__ T, int ldt, dc* __restrict__ invd, unsigned* __restrict__ poison) {
   __shared__ PermLds S;
   if (blockIdx.x > 0) { lu_invert_diag32(S, T, ldt, nb, blockIdx.x - 1, invd); return; }
+  // An aborted panel (the plan's poison word is set) has no valid pivots: no rows are moved. The same for a pivot outside
+  // [k0 + c, n) -- which a completed panel never produces: the plan is poisoned (code 2) instead of acting on it.
+  if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) { if (threadIdx.x == 0) lists[0] = 0; return; }
   int* top = S.fold.top;               // content of row k0+c
   int* ext_row = S.fold.ext_row;       // rows >= k0+nb that were touched
   int* ext_src = S.fold.ext_src;
   int* piv = S.fold.piv;               // the panel's pivots, fetched in one coalesced load (not one dependent load per column)
   const int lane = threadIdx.x;
-  for (int c = lane; c < nb; c += 64) { top[c] = k0 + c; piv[c] = ipiv[k0 + c]; }
+  bool bad = false;
+  for (int c = lane; c < nb; c += 64) { top[c] = k0 + c; const int pv = ipiv[k0 + c]; piv[c] = pv; bad = bad || pv < k0 + c || pv >= n; }
+  if (__any(bad)) {
+    if (lane == 0) { lists[0] = 0; if (poison) __hip_atomic_store(poison, 2u, RLX_AGENT); }
+    return;
+  }
   int next = 0;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int c = 0; c < nb; ++c) {
-    int p = piv[c];
-    if (p < k0 + c || p >= n) p = k0 + c;                // never act on an out-of-range pivot (stale or failed panel)
+    const int p = piv[c];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (p == k0 + c) continue;
     if (p < k0 + nb) {
@@ -537,6 +561,7 @@ __global__ __launch_bounds__(256) void lu_gather_rows_kernel(const dc* __restric
   const int idx = blockIdx.y;
   if (idx >= m) return;
   const int s = lists[1 + 2 * LU_NB_MAX + idx];
+  if (s < 0 || s >= n) return;
   const int nx = x1 - x0, nxy = nx + (y1 - y0), ncol = nxy + nrhs;
   for (int q = blockIdx.x * 256 + threadIdx.x; q < ncol; q += gridDim.x * 256) {
     dc v;
@@ -552,6 +577,7 @@ __global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A
   const int idx = blockIdx.y;
   if (idx >= m) return;
   const int d = lists[1 + idx];
+  if (d < 0 || d >= n) return;
   const int nx = x1 - x0, nxy = nx + (y1 - y0), ncol = nxy + nrhs;
   for (int q = blockIdx.x * 256 + threadIdx.x; q < ncol; q += gridDim.x * 256) {
     const dc v = tmp[(size_t)idx * tstride + q];
@@ -1062,45 +1088,136 @@ int lu_panel_configure() {
   return MA_OK;
 }
 
-// Panel kernels need ALL their workgroups co-resident (they wait for each other every column). Several
-// of them in flight on one device (frequencies in flight on several streams, several plans or host
-// threads) must therefore fit on the chip TOGETHER, or each could hold part of the CUs and wait for the
-// rest forever. The launcher bounds the number of panel kernels in flight per device: launch i waits for
-// the panel kernel launched `lag` launches earlier, where lag x (workgroups per panel) never exceeds what
-// the CUs can hold by LDS. Kernels of other kinds always terminate, so they only delay residency.
+// ---- Residency of the panel kernels (the argument behind the admission rule below)
+// A panel kernel exchanges by spinning: none of its workgroups finishes before ALL of them are resident. Several panel
+// kernels may be in flight on a device (the systems of a batch, other plans, other host threads), next to kernels that
+// always terminate (updates, trsm, row moves). A spinning workgroup that is resident never leaves, so the question is
+// whether every workgroup of every ADMITTED grid can always be placed once the terminating kernels have drained.
+//   LDS is allocated to a workgroup as ONE contiguous range of a CU's 160 KB. A CU that holds j spinning workgroups of
+//   at most s bytes each has 160 KB - j s free, in at most j + 1 holes (the other kernels' ranges come and go and leave
+//   the spinning ones at arbitrary offsets), so its largest hole is >= (160 KB - j s) / (j + 1). That is >= s as long as
+//   (2 j + 1) s <= 160 KB. With p(s) = floor((160 KB / s + 1) / 2) slots per CU, any CU holding fewer than p(s) spinning
+//   workgroups can therefore ALWAYS take one more. If the admitted grids together have at most p(s_max) x ncu workgroups
+//   (s_max: the largest of their LDS sizes), a workgroup can only be left without a place when every CU already holds
+//   >= p of them, i.e. when all of them are resident. The same holds for the vector registers (a wave's registers are
+//   one contiguous range of the SIMD's 512): p_v(r) = floor((512 / r + 1) / 2) waves of r registers.
+// The first version of this rule (round 1, commit 9958a60) counted slots as floor(160 KB / s): with 32 rows of a
+// 128-column panel per workgroup (MA_LU_RPB=32: s = 70 KB) it admitted two grids of 256 workgroups = 2 per CU, which only
+// fit if every CU packs them at offsets 0 and 70 KB. A workgroup that landed behind a departing 32 KB update workgroup
+// (offset 32 KB) left two holes of 32 and 58 KB: that CU could never take its second panel workgroup, the grids stayed
+// partially resident and ran into the 4 s limit of the spin; the aborted panels left pivots unwritten (d_ipiv was not
+// even initialised then) and the interchange kernels indexed rows with them -- the memory-access fault recorded in
+// gpurun_out/bench_rpb32.log (a wild address, 0xc6290bf7a000). By the rule above p(70 KB) = 1.
+// Now: (1) admission by p(s) and p_v(r), checked against the occupancy the runtime reports for the kernel;
+// (2) a grid that does not fit the chip ALONE is refused with a status (never launched); (3) an expired wait poisons the
+// plan (LuPanelWs::timeout): every poll reads the word, all workgroups of all the plan's panel kernels leave within one
+// sweep, the columns not reached get identity pivots, lu_perm_kernel moves no rows for a poisoned plan and poisons it
+// itself on any pivot outside [k0 + c, n); ma_lu_plan_status reports MA_ERR_HIP. No kernel indexes memory with a value
+// read from an aborted panel.
 namespace {
+constexpr int kSeqRing = 256;                          // launches remembered per device
+constexpr int kSeqWindow = 8;                          // at most this many panel kernels are ever admitted together
+struct PanelLaunch { hipEvent_t ev = nullptr; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; bool used = false; };
 struct PanelSequencer {
   std::mutex mu;
-  hipEvent_t ring[16][8] = {};
+  PanelLaunch ring[16][kSeqRing];
   bool made[16] = {};
   unsigned long long count[16] = {};
+  int regs = 0, occ_checked_lds = 0;
 };
 PanelSequencer g_seq;
+constexpr size_t kLdsPerCu = 160 * 1024;
 }  // namespace
 
+// slots per CU for spinning workgroups of `lds` bytes and `regs` vector registers per lane (see the argument above)
+int lu_panel_slots_per_cu(size_t lds, int regs) {
+  if (lds == 0) return 0;
+  int p = (int)((kLdsPerCu / (double)lds + 1.0) / 2.0);
+  if (regs > 0) { const int r8 = (regs + 7) & ~7; const int pv = (int)((512.0 / r8 + 1.0) / 2.0); if (pv < p) p = pv; }
+  if (p > 4) p = 4;
+  return p;
+}
+
 size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long) * LU_GRANULE_STRIDE * (2 * (size_t)max_blocks + 2 * LU_GROUPS); }
+
+int lu_panel_regs() {
+  std::lock_guard<std::mutex> lock(g_seq.mu);
+  if (g_seq.regs == 0) {
+    hipFuncAttributes fa;
+    MA_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(lu_panel_kernel)));
+    g_seq.regs = fa.numRegs > 0 ? fa.numRegs : 128;
+  }
+  return g_seq.regs;
+}
+
+// MA_OK when a grid of nblk workgroups with this panel shape can be co-resident on ncu CUs on its own
+int lu_panel_admissible(int nb, int rpb, int nblk, int ncu) {
+  const size_t lds = lu_panel_lds_bytes(nb, rpb);
+  const int regs = lu_panel_regs();
+  const int p = lu_panel_slots_per_cu(lds, regs);
+  MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
+             "panel grid of %d workgroups x %zu B LDS (%d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nb, rpb, ncu, p);
+  return MA_OK;
+}
 
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
-  // Admission: the panel kernels in flight may hold at most 96 KB of a CU's LDS between them, i.e. two trailing-update
-  // workgroups (2 x 32 KB) still fit beside them on every CU. Then every admitted workgroup finds room as soon as kernels
-  // that always terminate have drained. (Packing the LDS full with spinning panel workgroups -- 2 x 68 KB per CU, three
-  // kernels in flight -- timed out on the chip: partially resident panel kernels and the other kernels blocked each other.)
+  MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
+  MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,
+             "panel grid (%d workgroups of %d rows from row %d) does not tile the %d rows", nblk, rpb, k0, n);
+  int rc = lu_panel_admissible(nb, rpb, nblk, ncu);
+  if (rc) return rc;
   const size_t lds = lu_panel_lds_bytes(nb, rpb);
-  int per_cu = (int)((96 * 1024) / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 4) per_cu = 4;
-  int lag = (ncu * per_cu) / (nblk > 0 ? nblk : 1);
-  if (lag < 1) lag = 1;
-  if (lag > 8) lag = 8;
+  const int regs = lu_panel_regs();
   std::lock_guard<std::mutex> lock(g_seq.mu);
   if (!g_seq.made[dev]) {
-    for (int i = 0; i < 8; ++i) MA_HIP(hipEventCreateWithFlags(&g_seq.ring[dev][i], hipEventDisableTiming));
+    for (int i = 0; i < kSeqRing; ++i) MA_HIP(hipEventCreateWithFlags(&g_seq.ring[dev][i].ev, hipEventDisableTiming));
     g_seq.made[dev] = true;
   }
+  if ((int)lds > g_seq.occ_checked_lds) {
+    // the runtime's own occupancy figure must not be below the slots the rule assumes (registers, waves, LDS granularity)
+    int occ = 0;
+    MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
+    MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU at %zu B LDS is below the %d slots the admission rule assumes",
+               occ, lds, lu_panel_slots_per_cu(lds, regs));
+    g_seq.occ_checked_lds = (int)lds;
+  }
+  // Admission: the launches that may be in flight together with this one are a WINDOW of the launch order ending here: walk
+  // back from the newest while everything taken so far fits p(s_max) x ncu workgroups (and kSeqWindow launches); every
+  // launch at or before the window's start c must have finished before this kernel starts. Streams are in order, so it is
+  // enough to wait, per other stream, for that stream's latest launch <= c (one or two waits per launch with three or four
+  // lanes; none for the launch's own stream). Then every running panel kernel lies inside the window its newest member
+  // computed, whatever the streams' relative progress, and the residency argument above applies to the window.
   const unsigned long long i = g_seq.count[dev];
-  // slot (i mod 8) still holds launch i-8; launch i-lag sits in slot (i - lag) mod 8
-  if (i >= (unsigned long long)lag) MA_HIP(hipStreamWaitEvent(st, g_seq.ring[dev][(i - lag) & 7], 0));
+  PanelLaunch* ring = g_seq.ring[dev];
+  PanelLaunch& me = ring[i % kSeqRing];
+  if (me.used && hipEventQuery(me.ev) != hipSuccess) {        // launch i - 256 not finished yet: the host is that far ahead
+    (void)hipGetLastError();
+    MA_HIP(hipEventSynchronize(me.ev));
+  }
+  const unsigned long long oldest = i >= (unsigned long long)(kSeqRing - 1) ? i - (kSeqRing - 1) : 0ull;
+  long long tot = nblk; size_t smax = lds; int taken = 1;
+  unsigned long long c = i;                                   // launches with index < c are outside the window (c = i: window is this launch alone)
+  while (c > oldest) {
+    const PanelLaunch& L = ring[(c - 1) % kSeqRing];
+    const size_t s2 = L.lds > smax ? L.lds : smax;
+    if (taken >= kSeqWindow || tot + L.nblk > (long long)lu_panel_slots_per_cu(s2, regs) * ncu) break;
+    tot += L.nblk; smax = s2; ++taken; --c;
+  }
+  hipStream_t seen[8]; int nseen = 0;
+  for (unsigned long long j = c; j-- > oldest && nseen < 8;) {
+    const PanelLaunch& L = ring[j % kSeqRing];
+    if (L.st == st) continue;                                 // own stream: in order anyway
+    bool dup = false;
+    for (int q = 0; q < nseen; ++q) dup = dup || seen[q] == L.st;
+    if (dup) continue;                                        // an older launch of a stream already waited for
+    seen[nseen++] = L.st;
+    if (hipEventQuery(L.ev) == hipSuccess) continue;          // finished: nothing to wait for (and nothing older on that stream either)
+    (void)hipGetLastError();
+    MA_HIP(hipStreamWaitEvent(st, L.ev, 0));
+  }
   // Stale tags must not match. A workgroup rewrites its granule every column, so only columns 0 and 1 of a launch can
   // see the previous launch's granules, which carry that launch's last two tags (nb and nb - 1): they differ from the
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
@@ -1108,7 +1225,8 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   if (clear_tags) MA_HIP(hipMemsetAsync(ws.cand, 0, lu_panel_granule_bytes(ws.max_blocks), st));
   hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(A), n, k0, nb, rpb, ws, ipiv);
   MA_HIP(hipGetLastError());
-  MA_HIP(hipEventRecord(g_seq.ring[dev][i & 7], st));
+  MA_HIP(hipEventRecord(me.ev, st));
+  me.nblk = nblk; me.lds = lds; me.st = st; me.used = true;
   g_seq.count[dev] = i + 1;
   return MA_OK;
 }
@@ -1117,9 +1235,10 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
 // `tmp` holds 2 nb rows of `tstride` >= (x1-x0)+(y1-y0)+nrhs entries. With `invd`, blocks 1.. of the first launch
 // also invert the 32 x 32 diagonal blocks of the panel's L11 for lu_trsm_mfma_kernel.
 // fold the panel's interchange sequence into its gather lists and invert the 32 x 32 diagonal blocks of L11
-int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, hipStream_t st) {
+int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st) {
+  MA_REQUIRE(nb >= 1 && nb <= LU_NB_MAX && k0 >= 0 && k0 + nb <= n, MA_ERR_INVALID, "panel [%d, %d) outside 0..%d", k0, k0 + nb, n);
   hipLaunchKernelGGL(lu_perm_kernel, dim3(invd ? 1 + (nb + 31) / 32 : 1), dim3(64), 0, st, ipiv, n, k0, nb, lists,
-                     reinterpret_cast<const dc*>(A + (size_t)k0 * n + k0), n, reinterpret_cast<dc*>(invd));
+                     reinterpret_cast<const dc*>(A + (size_t)k0 * n + k0), n, reinterpret_cast<dc*>(invd), poison);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -1141,8 +1260,8 @@ int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int t
 }
 
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
-                    c64* invd, hipStream_t st) {
-  int rc = lu_launch_perm(A, n, k0, nb, ipiv, lists, invd, st);
+                    c64* invd, unsigned* poison, hipStream_t st) {
+  int rc = lu_launch_perm(A, n, k0, nb, ipiv, lists, invd, poison, st);
   if (rc) return rc;
   return lu_launch_row_moves(A, n, nb, lists, tmp, tstride, x0, x1, y0, y1, B, nrhs, st);
 }

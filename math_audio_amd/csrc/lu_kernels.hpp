@@ -12,22 +12,27 @@ namespace ma {
 // launch); `info` (first zero pivot, 1-based; 0 = none) and `timeout` persist over a factorisation.
 struct LuPanelWs {
   unsigned* counter;            // arrivals
-  unsigned* timeout;
+  unsigned* timeout;            // the plan's poison word: 1 an exchange wait expired (or the test hook fired), 2 lu_perm_kernel met a pivot
+                                // outside [k0 + c, n); every poll of every panel kernel of the plan reads it and leaves when it is set
   int* info;
   unsigned long long* cand;     // [2][max_blocks] granules {|re|+|im| bits, tag, row}, LU_GRANULE_STRIDE words apart
   unsigned long long* candrow;  // [2][max_blocks][2*LU_NB_MAX] candidate row of the panel
   unsigned long long* diagrow;  // [2][2*LU_NB_MAX]            current diagonal row of the panel
   int max_blocks;
+  int test_abort_col;           // test hook (MA_LU_TEST_ABORT_COL): the last workgroup gives up at this global column; -1 = off
 };
 
 size_t lu_panel_lds_bytes(int nb, int rpb);
 size_t lu_panel_granule_bytes(int max_blocks);
 int lu_panel_configure();
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
-int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, hipStream_t st);
+int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);
+int lu_panel_slots_per_cu(size_t lds, int regs);
+int lu_panel_regs();
+int lu_panel_admissible(int nb, int rpb, int nblk, int ncu);
 int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs, hipStream_t st);
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
-                    c64* invd, hipStream_t st);
+                    c64* invd, unsigned* poison, hipStream_t st);
 int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st);
 int lu_trsm_configure();
 int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st);

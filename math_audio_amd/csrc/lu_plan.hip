@@ -60,6 +60,8 @@ struct ma_lu_plan {
   int rpb_cap = 44;               // rows per panel workgroup when MA_LU_RPB is given
 };
 
+static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
+
 namespace {
 
 // Panel geometry: widest panel (128/64/32/16) whose rows fit the co-resident workgroups' LDS.
@@ -151,6 +153,18 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (const char* e5 = getenv("MA_LU_PANEL_OVERLAP")) P->panel_overlap = atoi(e5) != 0;
   if (const char* e7 = getenv("MA_LU_MIDLANE")) P->midlane = atoi(e7);
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
+  for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
+  if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
+  P->pws = P->pws_m[0];
+  if (!rc) {
+    // every panel shape of this plan's schedule must be co-resident on its own (lu_kernels.hip, "Residency"): a tuning switch
+    // that asks for more LDS per workgroup than the chip can hold at the grid's size is refused here, not at the first launch
+    std::vector<int> k0s, nbs, rpbs, nblks;
+    panel_schedule(P, k0s, nbs, rpbs, nblks);
+    for (size_t q = 0; q < k0s.size() && !rc; ++q)
+      if (q == 0 || rpbs[q] != rpbs[q - 1] || nbs[q] != nbs[q - 1] || nblks[q] > nblks[q - 1]) rc = lu_panel_admissible(nbs[q], rpbs[q], nblks[q], P->ncu);
+    if (rc && (P->rpb_env || getenv("MA_LU_NB"))) rc = MA_ERR_INVALID;      // the text of the refusal is already in the error string
+  }
   if (!rc) {
     int lo = 0, hi = 0;
     hipError_t e4 = hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -314,7 +328,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
-      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, sp))) return rc;
+      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
       if (a1 < e) {
         if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
         const c64* T = A + (size_t)k0 * n + k0;
@@ -468,7 +482,7 @@ struct Stage {
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
-      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, sp))) return rc;
+      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
       if (a1 < e) {
         if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
         if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
@@ -643,10 +657,10 @@ static int solve_only(ma_lu_plan* P, c64* A, c64* B, int32_t nrhs, hipStream_t s
   // the stored factors are in their final row order (later interchanges were applied to the earlier L columns), so every
   // interchange goes onto b first (zgetrs: laswp, then the triangular solves)
   for (int q = 0; q < Q; ++q)
-    if ((rc = lu_launch_swaps(A, n, k0s[q], nbs[q], P->d_ipiv[0], P->d_lists[0], P->d_tmp[0], tstride, 0, 0, 0, 0, B, nrhs, nullptr, st))) return rc;
+    if ((rc = lu_launch_swaps(A, n, k0s[q], nbs[q], P->d_ipiv[0], P->d_lists[0], P->d_tmp[0], tstride, 0, 0, 0, 0, B, nrhs, nullptr, nullptr, st))) return rc;
   for (int q = 0; q < Q; ++q) {
     const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
-    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[0], P->d_lists[0], P->d_tmp[0], tstride, 0, 0, 0, 0, nullptr, 0, P->d_invd[0], st))) return rc;   // inverted diagonal blocks only
+    if ((rc = lu_launch_swaps(A, n, k0, nb, P->d_ipiv[0], P->d_lists[0], P->d_tmp[0], tstride, 0, 0, 0, 0, nullptr, 0, P->d_invd[0], nullptr, st))) return rc;   // inverted diagonal blocks only
     if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, P->d_invd[0], A, (size_t)n, 0, B + k0, (size_t)n, nrhs, st))) return rc;
     for (int r = 0; r < nrhs && a1 < n; ++r)
       if ((rc = lu_launch_zgemv_sub(n - a1, nb, A + (size_t)a1 * n + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n + a1, st))) return rc;
@@ -701,7 +715,8 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i])); if (P->mid_streams[i]) MA_HIP(hipStreamSynchronize(P->mid_streams[i])); }
   int info[16];
   MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
-  MA_REQUIRE(info[LU_BATCH_MAX] == 0, MA_ERR_HIP, "panel factorisation timed out waiting for co-resident workgroups");
+  MA_REQUIRE(info[LU_BATCH_MAX] != 2, MA_ERR_HIP, "a panel left a pivot outside its range: the factorisation was abandoned (no rows were moved with it)");
+  MA_REQUIRE(info[LU_BATCH_MAX] == 0, MA_ERR_HIP, "panel factorisation abandoned: an exchange between the co-resident workgroups did not complete within its limit");
   for (int m = 0; m < P->last_batch; ++m)
     MA_REQUIRE(info[m] == 0, MA_ERR_SINGULAR, "system %d is singular: zero pivot at column %d", m, info[m] - 1);
   return MA_OK;
@@ -849,6 +864,14 @@ int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma
   if (!rc) { hipError_t e = hipMemcpy(C, dC, sizeof(c64) * (size_t)M * N, hipMemcpyDeviceToHost); if (e != hipSuccess) { set_error("copy back: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; } }
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
   return rc;
+}
+
+// The admission rule of the panel kernels as a pure function (lu_kernels.hip, "Residency"): spinning workgroups of `lds_bytes`
+// of LDS and `regs` vector registers per lane that a CU can ALWAYS take, whatever offsets terminating kernels left them at.
+int ma_lu_panel_slots_per_cu(int64_t lds_bytes, int32_t regs, int32_t* slots) {
+  MA_REQUIRE(slots && lds_bytes > 0 && regs >= 0, MA_ERR_INVALID, "bad argument");
+  *slots = lu_panel_slots_per_cu((size_t)lds_bytes, regs);
+  return MA_OK;
 }
 
 // Diagnostic build only (-DMA_PANEL_STAMPS): per-phase 100 MHz tick totals of workgroup 0 of every panel kernel

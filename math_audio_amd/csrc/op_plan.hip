@@ -19,8 +19,18 @@ extern "C" int ma_csr_destroy(ma_csr* h);
 extern "C" unsigned long long ma_csr_epoch(const ma_csr* h);
 extern "C" int ma_csr_refresh_transpose(const ma_csr* src, ma_csr* dst, int* rebuild);
 
+struct ma_op;
+// one row block of a matrix-free TBEM operator spread over several GPUs (kind 3): its own plan, operator, stream and
+// replicas of x and y on its device
+struct OpShard {
+  int device = 0; int row0 = 0, row1 = 0;
+  ma_bem_plan* plan = nullptr; ma_op* op = nullptr;
+  hipStream_t st = nullptr; hipEvent_t done = nullptr;
+  c64* d_x = nullptr; c64* d_y = nullptr;
+};
+
 struct ma_op {
-  int kind = 0;                 // 0 dense, 1 csr, 2 on-the-fly TBEM
+  int kind = 0;                 // 0 dense, 1 csr, 2 on-the-fly TBEM, 3 on-the-fly TBEM row-sharded over several devices
   int device = 0;
   long long n = 0;
   c64* dA = nullptr; bool own_A = false;
@@ -36,10 +46,27 @@ struct ma_op {
   long long* d_t_off = nullptr; int* d_t_idx = nullptr; c64* d_tpartial = nullptr;
   // staging for the host-buffer entry points
   c64* d_x = nullptr; c64* d_y = nullptr;
+  // kind 3: the shards (shards[0] lives on `device`, the home of every vector the callers pass), the event that says x is
+  // ready on the caller's stream, and ndev x n partial results of a transposed apply gathered on the home device
+  std::vector<OpShard> shards; hipEvent_t ev_home = nullptr; c64* d_tgather = nullptr;
 };
 
+extern "C" int ma_op_destroy(ma_op_t* o);
 namespace {
 void op_free(ma_op* o) {
+  for (OpShard& sh : o->shards) {
+    (void)hipSetDevice(sh.device);
+    if (sh.op) (void)ma_op_destroy(sh.op);
+    if (sh.plan) (void)ma_bem_plan_destroy(sh.plan);
+    if (sh.d_x) (void)hipFree(sh.d_x);
+    if (sh.d_y) (void)hipFree(sh.d_y);
+    if (sh.done) (void)hipEventDestroy(sh.done);
+    if (sh.st) (void)hipStreamDestroy(sh.st);
+  }
+  o->shards.clear();
+  (void)hipSetDevice(o->device);
+  if (o->ev_home) (void)hipEventDestroy(o->ev_home);
+  if (o->d_tgather) (void)hipFree(o->d_tgather);
   if (o->own_A && o->dA) (void)hipFree(o->dA);
   void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y, o->d_tpart, o->d_cx, o->d_t_off, o->d_t_idx, o->d_tpartial};
   for (void* q : p) if (q) (void)hipFree(q);
@@ -136,6 +163,63 @@ int ma_op_create_tbem(ma_bem_plan_t* P, const ma_physics_t* physics, double beta
   *out = o; return MA_OK;
 }
 
+// Matrix-free TBEM operator row-sharded over the GPUs of one node (BASELINE.json configs[4]): device g
+// owns the collocation rows [g N / G, (g+1) N / G) -- a whole BEM plan per device (geometry is O(N)), the row-block operator of
+// ma_op_create_tbem on it. All vectors the callers see live on devices[0] ("home"), so ma_gmres and the preconditioners
+// drive this operator like any other. The exchange per apply is the all-gather of SURVEY C2, done with peer copies inside
+// the library: x goes from home to every shard, every shard returns its y slice into the caller's y (16 B N in total).
+int ma_op_create_tbem_multi(const ma_mesh_t* mesh, const ma_physics_t* physics, double beta_re, double beta_im, const int32_t* devices, int32_t ndev,
+                            ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(mesh && physics && devices && ndev >= 1 && ndev <= 64, MA_ERR_INVALID, "bad argument");
+  int count = 0;
+  int rc = ma_device_count(&count); if (rc) return rc;
+  MA_REQUIRE(count > 0, MA_ERR_NO_DEVICE, "no gfx950 device visible");
+  for (int g = 0; g < ndev; ++g) {
+    MA_REQUIRE(devices[g] >= 0 && devices[g] < count, MA_ERR_INVALID, "device %d (entry %d) outside 0..%d", devices[g], g, count - 1);
+    // (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1: several shards on one GPU, so that a one-GPU box exercises the exchange)
+    for (int q = 0; q < g; ++q) MA_REQUIRE(devices[q] != devices[g] || getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES"), MA_ERR_INVALID, "device %d listed twice", devices[g]);
+  }
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 3; o->device = devices[0];
+  o->shards.resize((size_t)ndev);
+  auto fail = [&](int code) { op_free(o); delete o; return code; };
+  for (int g = 0; g < ndev && !rc; ++g) {
+    OpShard& sh = o->shards[(size_t)g];
+    sh.device = devices[g];
+    rc = ma_bem_plan_create(mesh, sh.device, &sh.plan);
+    if (rc) break;
+    const long long np = sh.plan->np;
+    if (np < ndev) { set_error("%d devices for %lld panels", ndev, np); rc = MA_ERR_INVALID; break; }
+    sh.row0 = (int)(np * g / ndev); sh.row1 = (int)(np * (g + 1) / ndev);
+    o->n = sh.plan->nd;
+    rc = ma_op_create_tbem(sh.plan, physics, beta_re, beta_im, sh.row0, sh.row1, &sh.op);
+    if (rc) break;
+    hipError_t e = hipSetDevice(sh.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sh.st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.done, hipEventDisableTiming);
+    if (e == hipSuccess && g > 0) e = hipMalloc(&sh.d_x, sizeof(c64) * (size_t)o->n);
+    if (e == hipSuccess) e = hipMalloc(&sh.d_y, sizeof(c64) * (size_t)o->n);
+    if (e != hipSuccess) { set_error("sharded operator: device %d: %s", sh.device, hipGetErrorString(e)); rc = MA_ERR_HIP; }
+  }
+  if (rc) return fail(rc);
+  hipError_t e = hipSetDevice(o->device);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev_home, hipEventDisableTiming);
+  if (e != hipSuccess) { set_error("sharded operator: %s", hipGetErrorString(e)); return fail(MA_ERR_HIP); }
+  rc = op_stage(o);
+  if (rc) return fail(rc);
+  *out = o; return MA_OK;
+}
+int ma_op_num_shards(const ma_op_t* o, int32_t* shards, int32_t* row_begin_or_null, int32_t* device_or_null) {
+  MA_REQUIRE(o && shards, MA_ERR_INVALID, "NULL argument");
+  *shards = o->kind == 3 ? (int32_t)o->shards.size() : 1;
+  for (size_t g = 0; o->kind == 3 && g < o->shards.size(); ++g) {
+    if (row_begin_or_null) row_begin_or_null[g] = o->shards[g].row0;
+    if (device_or_null) device_or_null[g] = o->shards[g].device;
+  }
+  return MA_OK;
+}
+
 int ma_op_destroy(ma_op_t* o) {
   if (!o) return MA_OK;
   (void)hipSetDevice(o->device);
@@ -148,11 +232,50 @@ int ma_op_num_rows(const ma_op_t* o, int64_t* n) {
   *n = o->n; return MA_OK;
 }
 
+// mode 0: y = A x (every shard writes its own slice of y); 1 / 2: y = A^T x / A^H x (every shard's rows contribute to all of y:
+// the contributions are gathered on the home device and summed there, in shard order, so that the result does not depend on
+// the timing of the copies). x and y live on the home device; `st` is the caller's stream there.
+static int op_apply_sharded(ma_op* o, const c64* d_x, c64* d_y, int mode, hipStream_t st) {
+  const size_t n = (size_t)o->n, bytes = sizeof(c64) * n;
+  const int home = o->device, G = (int)o->shards.size();
+  MA_HIP(hipSetDevice(home));
+  MA_HIP(hipEventRecord(o->ev_home, st));
+  if (mode != 0 && !o->d_tgather) MA_HIP(hipMalloc(&o->d_tgather, bytes * (size_t)G));
+  int rc = MA_OK;
+  for (int g = 0; g < G && !rc; ++g) {
+    OpShard& sh = o->shards[(size_t)g];
+    MA_HIP(hipSetDevice(sh.device));
+    MA_HIP(hipStreamWaitEvent(sh.st, o->ev_home, 0));
+    const c64* xg = d_x;
+    const bool remote = g > 0;                           // shard 0 is the home shard: it works on the caller's vectors
+    if (remote) { MA_HIP(hipMemcpyPeerAsync(sh.d_x, sh.device, d_x, home, bytes, sh.st)); xg = sh.d_x; }
+    if (mode == 0) {
+      c64* yg = remote ? sh.d_y : d_y;                   // the home shard writes straight into the caller's y
+      rc = ma_op_apply_dev(sh.op, xg, yg, sh.st);
+      if (!rc && remote)
+        MA_HIP(hipMemcpyPeerAsync(d_y + sh.row0, home, sh.d_y + sh.row0, sh.device, sizeof(c64) * (size_t)(sh.row1 - sh.row0), sh.st));
+    } else {
+      rc = mode == 1 ? ma_op_apply_transpose_dev(sh.op, xg, sh.d_y, sh.st) : ma_op_apply_hermitian_dev(sh.op, xg, sh.d_y, sh.st);
+      if (!rc) MA_HIP(hipMemcpyPeerAsync(o->d_tgather + (size_t)g * n, home, sh.d_y, sh.device, bytes, sh.st));
+    }
+    if (!rc) MA_HIP(hipEventRecord(sh.done, sh.st));
+  }
+  MA_HIP(hipSetDevice(home));
+  if (rc) return rc;
+  for (int g = 0; g < G; ++g) MA_HIP(hipStreamWaitEvent(st, o->shards[(size_t)g].done, 0));
+  if (mode != 0) {
+    MA_HIP(hipMemcpyAsync(d_y, o->d_tgather, bytes, hipMemcpyDeviceToDevice, st));
+    for (int g = 1; g < G && !rc; ++g) rc = op_launch_axpby((long long)n, 1.0, 0.0, d_y, 1.0, 0.0, o->d_tgather + (size_t)g * n, d_y, st);
+  }
+  return rc;
+}
+
 // LinearOperator::apply: y = A x, device pointers
 int ma_op_apply_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) {
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(o->device));
   hipStream_t st = (hipStream_t)stream;
+  if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, 0, st);
   if (o->kind == 0) return op_launch_zgemv(o->n, o->dA, (const c64*)d_x, (c64*)d_y, st);
   if (o->kind == 1) return ma_csr_spmv_dev(o->csr, d_x, d_y, stream);
   return op_launch_tbem_matvec(o->plan->geom, o->ph, o->row0, o->row1, o->nchunks, (const c64*)d_x, o->d_partial, o->plan->d_pair_off,
@@ -197,6 +320,7 @@ static int tbem_build_column_index(ma_op* o) {
 static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStream_t st) {
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(o->device));
+  if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, herm ? 2 : 1, st);
   if (o->kind == 2) {
     // streamed like apply, with the loop nest turned around (lane = field panel). A row-sharded operator returns its
     // rows' contribution to every entry of y: the shards' results add up (the caller's all-reduce).
@@ -287,6 +411,7 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
   MA_REQUIRE(op, MA_ERR_INVALID, "operator is NULL");
   if (op->kind == 1) return ma_precond_create_jacobi(op->csr, 1.0, 1, out);
+  if (op->kind == 3) return ma_precond_create_diagonal(op->shards[0].op, out);    // the home shard's plan holds every panel
   MA_HIP(hipSetDevice(op->device));
   ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
   M->kind = 4; M->n = op->n; M->device = op->device;

@@ -4,35 +4,53 @@
 // Built on the public entry points only: the systems go through the staged plan API as a pipeline -- `slots` of them in
 // HBM at a time, slot s a quarter of a factorisation behind slot s-1 (see ma_lu_plan_stage_*) -- without a host
 // synchronisation inside; the solutions are parked on the device and travel back once at the end.
+//
+// Multi-GPU: frequencies are independent, so ma_bem_solve_sweep_multi gives device d the
+// frequencies f = d, d + ndev, ... : one host thread per device, each with its own BEM plan, LU plan, stream and buffers on
+// ITS device; no data-path collective, the solutions land in the caller's X_out rows directly.
 #include "ma_common.hpp"
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <thread>
+#include <string>
 
 using namespace ma;
 
-extern "C" {
+namespace {
 
-int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
-                       double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, int32_t slots,
-                       ma_c64* X_out, int32_t* status_or_null) {
-  MA_REQUIRE(plan && n_freq > 0 && frequencies_hz && incident_vec3 && X_out, MA_ERR_INVALID, "bad argument");
-  MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
+struct SweepArgs {
+  double speed_of_sound, harmonic_factor, tau, beta_scale; int incident_kind; const double* incident_vec3; double amp_re, amp_im; int32_t slots;
+};
+
+// frequencies first, first + stride, ... of frequencies_hz[0..n_freq) on the plan's own device; X_out / status are indexed by
+// the GLOBAL frequency index
+int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* frequencies_hz, int32_t first, int32_t stride, const SweepArgs& a,
+                         ma_c64* X_out, int32_t* status_or_null) {
   int32_t n = 0;
   int rc = ma_bem_plan_num_dofs(plan, &n);
   if (rc) return rc;
+  int device = 0;
+  if ((rc = ma_bem_plan_device(plan, &device))) return rc;
+  // everything this call allocates lives on the PLAN's device, whatever device the calling thread had selected
+  MA_HIP(hipSetDevice(device));
+  std::vector<int> mine;
+  for (int f = first; f < n_freq; f += stride) mine.push_back(f);
+  const int n_mine = (int)mine.size();
+  if (n_mine == 0) return MA_OK;
+  int32_t slots = a.slots;
   if (slots < 1) slots = 3;
   if (slots > 4) slots = 4;
-  if (slots > n_freq) slots = n_freq;
-  int device = 0;
-  MA_HIP(hipGetDevice(&device));
+  if (slots > n_mine) slots = n_mine;
   ma_lu_plan_t* lu = nullptr;
   if ((rc = ma_lu_plan_create(n, device, &lu))) return rc;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("sweep: stream creation failed"); ma_lu_plan_destroy(lu); return MA_ERR_HIP; }
   std::vector<void*> dA((size_t)slots, nullptr), dx((size_t)slots, nullptr);
-  auto cleanup = [&]() { for (void* p : dA) if (p) (void)hipFree(p); for (void* p : dx) if (p) (void)hipFree(p); ma_lu_plan_destroy(lu); };
+  auto cleanup = [&]() { for (void* p : dA) if (p) (void)hipFree(p); for (void* p : dx) if (p) (void)hipFree(p); ma_lu_plan_destroy(lu); (void)hipStreamDestroy(st); };
   for (int s = 0; s < slots; ++s)
     if (hipMalloc(&dA[(size_t)s], sizeof(ma_c64) * (size_t)n * (size_t)n) != hipSuccess || hipMalloc(&dx[(size_t)s], sizeof(ma_c64) * (size_t)n) != hipSuccess) {
-      set_error("sweep: %d systems of %d x %d do not fit the device", slots, n, n);
+      set_error("sweep: %d systems of %d x %d do not fit device %d", slots, n, n, device);
       cleanup();
       return MA_ERR_NOMEM;
     }
@@ -40,20 +58,20 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
   auto assemble = [&](int f, int s) -> int {
     const double freq = frequencies_hz[f];
     ma_physics_t ph;
-    ph.wave_number = 2.0 * 3.14159265358979323846 * freq / speed_of_sound;     // PhysicsParams::new, types.rs:39-58
-    ph.harmonic_factor = harmonic_factor; ph.tau = tau; ph.gamma = 1.0;
-    const double bim = tau > 0.0 ? harmonic_factor * beta_scale / ph.wave_number : 0.0;   // burton_miller_beta_scaled, types.rs:144-150
-    int r = ma_bem_plan_assemble_dev(plan, &ph, 0.0, bim, dA[(size_t)s], dx[(size_t)s], nullptr);
-    if (!r) r = ma_bem_plan_incident_rhs_dev(plan, &ph, 0.0, bim, incident_kind, incident_vec3, amp_re, amp_im, 1, dx[(size_t)s], nullptr);
+    ph.wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;     // PhysicsParams::new, types.rs:39-58
+    ph.harmonic_factor = a.harmonic_factor; ph.tau = a.tau; ph.gamma = 1.0;
+    const double bim = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / ph.wave_number : 0.0;   // burton_miller_beta_scaled, types.rs:144-150
+    int r = ma_bem_plan_assemble_dev(plan, &ph, 0.0, bim, dA[(size_t)s], dx[(size_t)s], st);
+    if (!r) r = ma_bem_plan_incident_rhs_dev(plan, &ph, 0.0, bim, a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, dx[(size_t)s], st);
     return r;
   };
   int32_t G = 0;
   ma_c64* dX = nullptr; int32_t* dinfo = nullptr;
-  const bool staged = ma_lu_plan_num_blocks(lu, &G) == MA_OK && G > 0 && ma_lu_plan_stage_reset(lu, nullptr) == MA_OK;
+  const bool staged = ma_lu_plan_num_blocks(lu, &G) == MA_OK && G > 0 && ma_lu_plan_stage_reset(lu, st) == MA_OK;
   if (staged) {
-    if (hipMalloc(&dX, sizeof(ma_c64) * (size_t)n_freq * (size_t)n) != hipSuccess || hipMalloc(&dinfo, sizeof(int32_t) * (size_t)n_freq) != hipSuccess) {
+    if (hipMalloc(&dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n) != hipSuccess || hipMalloc(&dinfo, sizeof(int32_t) * (size_t)n_mine) != hipSuccess) {
       if (dX) (void)hipFree(dX);
-      set_error("sweep: the solutions of %d frequencies do not fit the device", n_freq);
+      set_error("sweep: the solutions of %d frequencies do not fit the device", n_mine);
       cleanup();
       return MA_ERR_NOMEM;
     }
@@ -64,37 +82,41 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
       for (int s = 0; s < slots && !rc; ++s) {
         const int lr = r - off[(size_t)s];
         if (lr < 0) { live = true; continue; }
-        const int f = s + slots * (lr / G), g = lr % G;
-        if (f >= n_freq) continue;
+        const int i = s + slots * (lr / G), g = lr % G;       // i: index into this device's frequencies
+        if (i >= n_mine) continue;
         live = true;
         if (g == 0) {
-          rc = assemble(f, s);
-          if (!rc) rc = ma_lu_plan_stage_begin(lu, s, dA[(size_t)s], dx[(size_t)s], 1, nullptr);
+          rc = assemble(mine[(size_t)i], s);
+          if (!rc) rc = ma_lu_plan_stage_begin(lu, s, dA[(size_t)s], dx[(size_t)s], 1, st);
         }
         sl[cnt] = s; bl[cnt] = g; ++cnt;
       }
       if (!live || rc) break;
-      if (cnt) rc = ma_lu_plan_stage_round(lu, cnt, sl, bl, nullptr);
-      for (int i = 0; i < cnt && !rc; ++i) {
-        if (bl[i] != G - 1) continue;
-        const int s = sl[i], f = s + slots * ((r - off[(size_t)s]) / G);
-        rc = ma_lu_plan_stage_finish(lu, s, nullptr);
-        if (!rc && hipMemcpyAsync(dX + (size_t)f * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
-        if (!rc) rc = ma_lu_plan_stage_info_dev(lu, s, dinfo + f, nullptr);
+      if (cnt) rc = ma_lu_plan_stage_round(lu, cnt, sl, bl, st);
+      for (int q = 0; q < cnt && !rc; ++q) {
+        if (bl[q] != G - 1) continue;
+        const int s = sl[q], i = s + slots * ((r - off[(size_t)s]) / G);
+        rc = ma_lu_plan_stage_finish(lu, s, st);
+        if (!rc && hipMemcpyAsync(dX + (size_t)i * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
+        if (!rc) rc = ma_lu_plan_stage_info_dev(lu, s, dinfo + i, st);
       }
     }
     if (!rc) {
-      int st = ma_lu_plan_status(lu, nullptr);                 // synchronises; a time-out of the panel kernels surfaces here
-      if (st != MA_OK && st != MA_ERR_SINGULAR) rc = st;
+      int stt = ma_lu_plan_status(lu, st);                     // synchronises; an abandoned panel (poisoned plan) surfaces here
+      if (stt != MA_OK && stt != MA_ERR_SINGULAR) rc = stt;
     }
     if (!rc) {
-      std::vector<int32_t> hinfo((size_t)n_freq);
-      if (hipMemcpy(X_out, dX, sizeof(ma_c64) * (size_t)n_freq * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(hinfo.data(), dinfo, sizeof(int32_t) * (size_t)n_freq, hipMemcpyDeviceToHost) != hipSuccess) { set_error("sweep: copy back failed"); rc = MA_ERR_HIP; }
-      for (int f = 0; f < n_freq && !rc; ++f) {
-        const int st = hinfo[(size_t)f] ? MA_ERR_SINGULAR : MA_OK;
-        if (status_or_null) status_or_null[f] = st;
-        if (st != MA_OK) worst = st;
+      std::vector<int32_t> hinfo((size_t)n_mine);
+      std::vector<ma_c64> hX;
+      hipError_t e = hipMemcpy(hinfo.data(), dinfo, sizeof(int32_t) * (size_t)n_mine, hipMemcpyDeviceToHost);
+      if (stride == 1 && first == 0) { if (e == hipSuccess) e = hipMemcpy(X_out, dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n, hipMemcpyDeviceToHost); }
+      else for (int i = 0; i < n_mine && e == hipSuccess; ++i)
+        e = hipMemcpy(X_out + (size_t)mine[(size_t)i] * (size_t)n, dX + (size_t)i * (size_t)n, sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { set_error("sweep: copy back failed: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; }
+      for (int i = 0; i < n_mine && !rc; ++i) {
+        const int sf = hinfo[(size_t)i] ? MA_ERR_SINGULAR : MA_OK;
+        if (status_or_null) status_or_null[mine[(size_t)i]] = sf;
+        if (sf != MA_OK) worst = sf;
       }
     }
     if (rc) (void)hipDeviceSynchronize();                       // nothing may still be running on buffers that are about to go
@@ -103,22 +125,85 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
     return rc ? rc : worst;
   }
   // look-ahead lanes switched off (MA_LU_LOOKAHEAD=0 / MA_LU_PANEL_OVERLAP=0): lock-step batches
-  for (int f0 = 0; f0 < n_freq && !rc; f0 += slots) {
-    const int cnt = std::min(slots, n_freq - f0);
-    for (int s = 0; s < cnt && !rc; ++s) rc = assemble(f0 + s, s);
+  for (int i0 = 0; i0 < n_mine && !rc; i0 += slots) {
+    const int cnt = std::min((int)slots, n_mine - i0);
+    for (int s = 0; s < cnt && !rc; ++s) rc = assemble(mine[(size_t)(i0 + s)], s);
     if (rc) break;
-    rc = ma_lu_plan_factor_solve_batch_dev(lu, cnt, dA.data(), dx.data(), 1, nullptr);
+    rc = ma_lu_plan_factor_solve_batch_dev(lu, cnt, dA.data(), dx.data(), 1, st);
     if (rc) break;
-    int st = ma_lu_plan_status(lu, nullptr);
-    if (st != MA_OK && st != MA_ERR_SINGULAR) { rc = st; break; }
+    int stt = ma_lu_plan_status(lu, st);
+    if (stt != MA_OK && stt != MA_ERR_SINGULAR) { rc = stt; break; }
     for (int s = 0; s < cnt; ++s) {
-      if (status_or_null) status_or_null[f0 + s] = st;       // a singular member marks its whole batch; the caller may re-run those singly
-      if (hipMemcpy(X_out + (size_t)(f0 + s) * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("sweep: copy back failed"); rc = MA_ERR_HIP; }
+      const int f = mine[(size_t)(i0 + s)];
+      if (status_or_null) status_or_null[f] = stt;            // a singular member marks its whole batch; the caller may re-run those singly
+      if (hipMemcpy(X_out + (size_t)f * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("sweep: copy back failed"); rc = MA_ERR_HIP; }
     }
-    if (st != MA_OK) worst = st;
+    if (stt != MA_OK) worst = stt;
   }
+  if (rc) (void)hipDeviceSynchronize();
   cleanup();
   return rc ? rc : worst;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
+                       double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, int32_t slots,
+                       ma_c64* X_out, int32_t* status_or_null) {
+  MA_REQUIRE(plan && n_freq > 0 && frequencies_hz && incident_vec3 && X_out, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
+  const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im, slots};
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  const int rc = sweep_on_plan_device(plan, n_freq, frequencies_hz, 0, 1, a, X_out, status_or_null);
+  if (had) (void)hipSetDevice(prev);                            // the caller's current device is left as it was
+  return rc;
+}
+
+// The sharding rule of the multi-device sweep, exposed so that callers, tests and bench.py agree on it: frequency f belongs
+// to device slot f mod ndev (room_simulator_bem.rs:329's loop dealt round-robin).
+int ma_sweep_owner(int32_t frequency_index, int32_t ndev) { return ndev > 0 ? frequency_index % ndev : 0; }
+
+int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
+                             double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
+                             int32_t slots, ma_c64* X_out, int32_t* status_or_null) {
+  MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && n_freq > 0 && frequencies_hz && incident_vec3 && X_out, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
+  int count = 0;
+  int rc = ma_device_count(&count);
+  if (rc) return rc;
+  MA_REQUIRE(count > 0, MA_ERR_NO_DEVICE, "no gfx950 device visible");
+  for (int d = 0; d < ndev; ++d) {
+    MA_REQUIRE(devices[d] >= 0 && devices[d] < count, MA_ERR_INVALID, "device %d (entry %d) outside 0..%d", devices[d], d, count - 1);
+    // (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1: several host threads on one GPU, so that a one-GPU box exercises the sharding)
+    for (int o = 0; o < d; ++o) MA_REQUIRE(devices[o] != devices[d] || getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES"), MA_ERR_INVALID, "device %d listed twice", devices[d]);
+  }
+  const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im, slots};
+  std::vector<int> rcs((size_t)ndev, MA_OK);
+  std::vector<std::string> texts((size_t)ndev);
+  auto work = [&](int d) {
+    // one host thread per device: its own plans, stream and buffers; errors are thread-local and carried back as text
+    ma_bem_plan_t* plan = nullptr;
+    int r = ma_bem_plan_create(mesh, devices[d], &plan);
+    if (!r) r = sweep_on_plan_device(plan, n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null);
+    if (r && r != MA_ERR_SINGULAR) texts[(size_t)d] = ma_last_error_string();
+    if (plan) ma_bem_plan_destroy(plan);
+    rcs[(size_t)d] = r;
+  };
+  std::vector<std::thread> th;
+  for (int d = 1; d < ndev; ++d) th.emplace_back(work, d);
+  work(0);
+  for (auto& t : th) t.join();
+  int worst = MA_OK;
+  for (int d = 0; d < ndev; ++d) {
+    if (rcs[(size_t)d] == MA_OK) continue;
+    if (rcs[(size_t)d] == MA_ERR_SINGULAR) { if (worst == MA_OK) worst = MA_ERR_SINGULAR; continue; }
+    set_error("sweep on device %d: %s", devices[d], texts[(size_t)d].c_str());
+    return rcs[(size_t)d];
+  }
+  return worst;
 }
 
 }  // extern "C"

@@ -78,3 +78,44 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"oracle_lib|libma_oracle|ma_oracle\.h|mao_[a-z]", t):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_panel_admission_rule():
+    """Slots per CU for co-resident (spinning) panel workgroups: p = floor((160 KB / s + 1) / 2), so that a CU holding fewer
+    than p of them always has a contiguous hole of s bytes whatever offsets other kernels left them at; the same for the 512
+    vector registers of a SIMD (DESIGN 4 "Residency")."""
+    L = ma.lib()
+    L.ma_lu_panel_slots_per_cu.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
+
+    def slots(lds, regs=0):
+        out = C.c_int32(-1)
+        assert L.ma_lu_panel_slots_per_cu(lds, regs, C.byref(out)) == ma.MA_OK
+        return out.value
+    assert slots(47960) == 2          # 43 rows x 64 columns: the shipped shape, two systems' panels per CU
+    assert slots(71000) == 1          # 32 rows x 128 columns (MA_LU_RPB=32): the round-1 fault; floor(160/70) = 2 was wrong
+    assert slots(55000) == 1 and slots(54000) == 2      # (2 p - 1) s <= 160 KB at p = 2: s <= 53.3 KiB
+    assert slots(33000) == 2 and slots(32000) == 3
+    assert slots(100000) == 1 and slots(170000) == 0    # a workgroup beyond 160 KB never fits
+    assert slots(10000) == 4                            # capped
+    assert slots(20000, regs=80) == 3                   # registers: floor((512 / 80 + 1) / 2)
+    assert slots(20000, regs=168) == 2 and slots(20000, regs=256) == 1
+    for s in range(8000, 165000, 1000):                 # the hole argument itself, brute force over the worst placements
+        p = slots(s)
+        for j in range(p):
+            assert (160 * 1024 - j * s) / (j + 1) >= s, (s, p, j)
+
+
+def test_multi_device_sweep_entry_validates_and_shards():
+    L = ma.lib()
+    assert [ma.sweep_owner(f, 4) for f in range(9)] == [0, 1, 2, 3, 0, 1, 2, 3, 0]
+    assert ma.sweep_owner(5, 1) == 0
+    om = O.icosphere(RADIUS, 0)
+    mesh = to_ma_mesh(om)
+    f = np.array([100.0, 200.0]); v = np.array([0.0, 0.0, 1.0]); X = np.zeros((2, om.n_elem), dtype=complex)
+    dv = np.array([0], dtype=np.int32)
+    args = lambda m, d, nd, nf: L.ma_bem_solve_sweep_multi(m, d, nd, nf, f.ctypes.data, 343.0, 1.0, 1.0, 4.0, 0, v.ctypes.data, 1.0, 0.0, 3, X.ctypes.data, None)
+    assert args(None, dv.ctypes.data, 1, 2) == ma.MA_ERR_INVALID
+    assert args(C.byref(mesh.c), dv.ctypes.data, 0, 2) == ma.MA_ERR_INVALID
+    assert args(C.byref(mesh.c), None, 1, 2) == ma.MA_ERR_INVALID
+    if ma.device_count() == 0:
+        assert args(C.byref(mesh.c), dv.ctypes.data, 1, 2) == ma.MA_ERR_NO_DEVICE

@@ -268,3 +268,114 @@ def test_lu_tall_system_switches_panel_width(gpu):
     res = float(r.norm() / (A0.reshape(n, n)[:64].norm() * (n / 64) ** 0.5 * x.norm()))
     assert res <= 1e-14 * n
     lu.close()
+
+
+def _with_env(**kv):
+    """Context manager: the library reads its tuning / test switches once per plan (getenv at ma_lu_plan_create)."""
+    import contextlib, os
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in kv}
+        os.environ.update({k: str(v) for k, v in kv.items()})
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return cm()
+
+
+def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu):
+    """The failure path behind the round-1 memory fault (DESIGN 4 "Residency", lu_kernels.hip): a panel kernel whose exchange
+    does not complete must (1) make every workgroup of every panel kernel of the plan leave at once -- the poison word is
+    read in every poll, no 4 s wait per workgroup --, (2) leave identity pivots behind, so that the interchange kernels,
+    which are already enqueued, move no rows, (3) surface as MA_ERR_HIP, and (4) leave the plan usable after the next
+    factorisation clears the word. The test hook makes the last workgroup of the panel that owns global column 200 give up
+    in a 3-system batch of 11 panels each; every later kernel of all three systems still runs, on garbage but in bounds."""
+    import time
+    import torch
+    n = 700
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    mats = [_rand(n, 300 + i) for i in range(3)]
+    with _with_env(MA_LU_TEST_ABORT_COL=200):
+        lu = ma.LuPlan(n)
+    dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
+    guard = torch.full((1 << 20,), 7.0, dtype=torch.float64, device=dev)       # a canary allocated right after the operands
+    t0 = time.perf_counter()
+    lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
+    rc = lu.status(st)
+    dt = time.perf_counter() - t0
+    assert rc == ma.MA_ERR_HIP
+    assert b"abandoned" in ma.lib().ma_last_error_string()
+    assert dt < 2.0, dt                                    # nobody sat out the 4 s limit
+    assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
+    lu.close()
+    # the same three systems on a plan without the hook: bit for bit the single solves
+    lu = ma.LuPlan(n)
+    dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
+    lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
+    assert lu.status(st) == ma.MA_OK
+    for (A, b), db in zip(mats, dbs):
+        x = db.cpu().numpy()
+        assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-11
+    lu.close()
+
+
+def test_nan_column_and_tiny_pivot_inside_a_batch(gpu):
+    """A column of NaNs in the fourth panel of one system of a 3-system batch: no workgroup offers a candidate, the diagonal
+    row stands in, the system is reported singular (MA_ERR_SINGULAR) -- and the two healthy systems of the batch still hold
+    their exact solutions. Then lu.rs:106-110: a pivot column whose largest |z| is below 1e-30 is LuError::SingularMatrix
+    (the LAPACK path only errors on an exact zero; the stricter of the two is reported)."""
+    import torch
+    n = 700
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    mats = [_rand(n, 400 + i) for i in range(3)]
+    bad = mats[1][0].copy(); bad[:, 200] = np.nan
+    lu = ma.LuPlan(n)
+    dAs = [torch.tensor(A if i != 1 else bad, device=dev).reshape(-1) for i, (A, _) in enumerate(mats)]
+    dbs = [torch.tensor(b, device=dev) for _, b in mats]
+    lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
+    assert lu.status(st) == ma.MA_ERR_SINGULAR
+    assert b"system 1" in ma.lib().ma_last_error_string()
+    for i in (0, 2):
+        x = dbs[i].cpu().numpy()
+        assert np.linalg.norm(mats[i][0] @ x - mats[i][1]) / np.linalg.norm(mats[i][1]) < 1e-11
+    lu.close()
+    # a numerically singular system: column 3 scaled to 1e-40
+    A, b = _rand(6, 9)
+    A[:, 3] *= 1e-40
+    with pytest.raises(ma.MaError) as e:
+        ma.zgesv(A, b)
+    assert e.value.status == ma.MA_ERR_SINGULAR
+    A2, b2 = _rand(6, 9)
+    A2[:, 3] *= 1e-20                                      # small but above the threshold: solved
+    x = ma.zgesv(A2, b2)
+    assert np.linalg.norm(A2 @ x - b2) / np.linalg.norm(b2) < 1e-6
+
+
+def test_round1_fault_configuration_now_runs(gpu):
+    """MA_LU_RPB=32 with 128-column panels and three systems in flight is the configuration of gpurun_out/bench_rpb32.log
+    (70 KB of LDS per spinning workgroup). The old admission counted floor(160 KB / 70 KB) = 2 slots per CU and let two
+    256-workgroup grids in; the fragmentation-safe count is 1 (lu_kernels.hip "Residency"), so the grids now run one at a
+    time -- and complete."""
+    import torch
+    n = 6000
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    As = [torch.randn(n, n, dtype=torch.complex128, device=dev, generator=gen) for _ in range(3)]
+    bs = [torch.randn(n, dtype=torch.complex128, device=dev, generator=gen) for _ in range(3)]
+    with _with_env(MA_LU_RPB=32, MA_LU_NB=128):
+        lu = ma.LuPlan(n)
+    dAs = [A.clone().reshape(-1) for A in As]; dbs = [b.clone() for b in bs]
+    lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
+    assert lu.status(st) == ma.MA_OK
+    for A, b, x in zip(As, bs, dbs):
+        assert float(torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)) < 1e-10
+    lu.close()

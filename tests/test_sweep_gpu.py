@@ -217,3 +217,45 @@ def test_two_host_threads_one_frequency_each(gpu):
     assert not err, err
     for t in range(2):
         assert np.array_equal(out[t], serial[t])
+
+
+def test_multi_device_sweep_inside_the_library(gpu, monkeypatch):
+    """ma_bem_solve_sweep_multi: frequency f on devices[f mod ndev], one host thread, BEM plan, LU plan and stream per device
+    inside the library (SURVEY 8e.1 behind the C-ABI). On a one-GPU box the 'devices' are the same GPU twice / three times
+    (test hook): the sharding rule, the threads, the strided solution scatter and the per-frequency status are the multi-GPU
+    code path; results must equal the single-device sweep bit for bit (same kernels, same order per system)."""
+    om = O.icosphere(RADIUS, 2)
+    mesh = to_ma_mesh(om)
+    freqs = [150.0, 545.9, 900.0, 1400.0, 2100.0, 2600.0, 3100.0]
+    plan = ma.BemPlan(mesh)
+    X1, s1 = ma.solve_sweep(plan, freqs, slots=2)
+    plan.close()
+    Xa, sa = ma.solve_sweep_multi(mesh, [0], freqs, slots=2)
+    assert np.array_equal(Xa, X1) and np.array_equal(sa, s1)
+    monkeypatch.setenv("MA_TEST_ALLOW_DUPLICATE_DEVICES", "1")
+    for devs in ([0, 0], [0, 0, 0]):
+        Xm, sm = ma.solve_sweep_multi(mesh, devs, freqs, slots=2)
+        assert np.all(sm == ma.MA_OK)
+        for f in range(len(freqs)):
+            assert rel_l2(Xm[f], X1[f]) <= 1e-12, (devs, f)
+    monkeypatch.delenv("MA_TEST_ALLOW_DUPLICATE_DEVICES")
+    with pytest.raises(ma.MaError) as e:
+        ma.solve_sweep_multi(mesh, [0, 0], freqs)
+    assert e.value.status == ma.MA_ERR_INVALID
+    with pytest.raises(ma.MaError) as e:
+        ma.solve_sweep_multi(mesh, [ma.device_count()], freqs)
+    assert e.value.status == ma.MA_ERR_INVALID
+
+
+def test_sweep_runs_on_its_plans_device_not_the_callers(gpu):
+    """ma_bem_solve_sweep took the calling thread's current device for the LU plan and the buffers. It now runs on
+    the plan's device and restores the caller's; with one GPU the observable part is that the call leaves the current device
+    and torch's current stream untouched and that the plan reports its device."""
+    import torch
+    om = O.icosphere(RADIUS, 1)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    assert plan.device == 0
+    before = torch.cuda.current_device()
+    X, st = ma.solve_sweep(plan, [300.0, 600.0], slots=2)
+    assert torch.cuda.current_device() == before and np.all(st == ma.MA_OK) and np.all(np.isfinite(X.view(np.float64)))
+    plan.close()
