@@ -9,7 +9,10 @@ complex LU solve, everything resident in HBM (geometry and the near-pair plan ar
 before the timed region; nothing crosses PCIe inside it).
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      N > 1 without WORLD_SIZE in the environment: bench.py starts its own N ranks (one per GPU) with
+      torch.distributed.run before anything touches a GPU, and exits with their status;
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+      (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE come from the environment).
 
 Frequencies shard over ranks (rank r takes points r, r+N, ...): no data-path collective;
 "scaling": "weak" (K frequencies per GPU whatever N is). Rank 0 prints ONE JSON line.
@@ -96,26 +99,31 @@ def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
     O.build_tbem_system_with_beta(om, k, beta, nthreads=1, rows=(0, rows1), A=A, rhs=rhs)
     asm_1thread = rows1 * n / (time.perf_counter() - t0)
     del A
-    # dense solve: LAPACK on a 3000 x 3000 complex system
-    ns = min(n, 3000)
-    rng = np.random.default_rng(0)
-    M = rng.standard_normal((ns, ns)) + 1j * rng.standard_normal((ns, ns)) + ns * np.eye(ns)
-    b = rng.standard_normal(ns) + 0j
-    try:
-        import scipy.linalg as sl
-        t0 = time.perf_counter(); lu, piv = sl.lu_factor(M, check_finite=False); sl.lu_solve((lu, piv), b, check_finite=False)
-        t_lu = time.perf_counter() - t0
-        lib = "scipy.linalg.lu_factor/lu_solve (LAPACK zgetrf/zgetrs)"
-    except Exception:
-        t0 = time.perf_counter(); np.linalg.solve(M, b); t_lu = time.perf_counter() - t0
-        lib = "numpy.linalg.solve (LAPACK zgesv)"
+    # dense solve: host LAPACK (zgetrf + zgetrs) on a system of the workload's OWN size (n = 10 000: 2.67 TFLOP) unless a probe at
+    # n = 2000 says that would take more than 90 s, in which case the largest size that fits ~30 s is timed and scaled by flops
+    def lapack(ns_):
+        rng = np.random.default_rng(0)
+        M = rng.standard_normal((ns_, ns_)) + 1j * rng.standard_normal((ns_, ns_)); M[np.arange(ns_), np.arange(ns_)] += ns_
+        b = rng.standard_normal(ns_) + 0j
+        try:
+            import scipy.linalg as sl
+            t0_ = time.perf_counter(); lu_, piv_ = sl.lu_factor(M, check_finite=False, overwrite_a=True); sl.lu_solve((lu_, piv_), b, check_finite=False)
+            return time.perf_counter() - t0_, "scipy.linalg.lu_factor/lu_solve (LAPACK zgetrf/zgetrs)"
+        except Exception:
+            t0_ = time.perf_counter(); np.linalg.solve(M, b)
+            return time.perf_counter() - t0_, "numpy.linalg.solve (LAPACK zgesv)"
+    t_probe_lu, lib = lapack(min(n, 2000))
+    predicted = t_probe_lu * lu_flops(n) / lu_flops(min(n, 2000))
+    ns = n if predicted <= 90.0 else int(max(2000, min(n, 2000 * (30.0 / t_probe_lu) ** (1.0 / 3.0))))
+    t_lu, lib = lapack(ns) if ns > 2000 else (t_probe_lu, lib)
     solve_gflops = lu_flops(ns) / t_lu / 1e9
     t_step = n * n / asm_pairs_per_s + lu_flops(n) / (solve_gflops * 1e9)
     return {
         "value": n * n / t_step, "unit": "panel-pairs/s", "cores": cores, "kind": "port",
         "sample": "oracle C restatement of build_tbem_system_with_beta: %d of %d rows at %.0f Hz on %d threads (%.1f s) -> %.3e pairs/s; "
-                  "dense solve: %s, n=%d, %.2f s -> %.1f GFLOP/s; step time = N^2/asm + ((8/3)N^3+8N^2)/solve" % (
-                      rows, n, freq, cores, t_probe, asm_pairs_per_s, lib, ns, t_lu, solve_gflops),
+                  "dense solve: %s, n=%d%s, %.2f s -> %.1f GFLOP/s; step time = N^2/asm + ((8/3)N^3+8N^2)/solve" % (
+                      rows, n, freq, cores, t_probe, asm_pairs_per_s, lib, ns, " (the workload's own size)" if ns == n else " (scaled by flops to n=%d)" % n, t_lu, solve_gflops),
+        "solve_n": ns,
         "assembly_pairs_per_s": asm_pairs_per_s, "solve_gflops": solve_gflops,
         "assembly_pairs_per_s_one_thread": asm_1thread,
     }
@@ -211,6 +219,18 @@ def main():
         args.schedule = "pipeline" if args.steps >= 12 else "batch"
     if args.workload == "fem":
         return fem_workload(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here, as child processes, BEFORE this process touches a GPU
+        # (nothing GPU-related has been imported yet), and hand their status back. One rank per GPU over RCCL, rendezvous on
+        # 127.0.0.1; the ranks re-enter this file with RANK / LOCAL_RANK / WORLD_SIZE set.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -223,8 +243,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if world != args.gpus and rank == 0:
-        print("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU; start it as `python bench.py --gpus N` or with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -394,6 +414,8 @@ def main():
             ach = gf / gemm_t / 1e12
             out["roofline"] = {"kernel": "zgemm3m_sub_kernel (LU trailing updates, v_mfma_f64_16x16x4_f64; every launch of the step)", "bound": "mfma", "achieved": ach,
                                "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic("ma::zgemm3m_sub_kernel"),
+                               "raw_mfma_frac": 0.75 * ach / FP64_MFMA_PEAK_TF,
+                               "raw_mfma_note": "achieved/frac count ALGORITHMIC flops (8 M N K per complex update); the 3M kernel issues 3 real products per complex product, i.e. 3/4 of them on the matrix cores",
                                "traffic_note": "HBM-side bytes per launch from a separate rocprofv3 --pmc pass (profiles/); the algorithmic C read+write "
                                                "is %.3g B per launch on average" % (upd[2] / K / n_gemm),
                                "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,

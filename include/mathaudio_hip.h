@@ -213,6 +213,10 @@ typedef struct ma_csr ma_csr_t;
 int ma_csr_create(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr_t** out);
 int ma_csr_create_helmholtz(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const double* K, const double* M,
                             int device, ma_csr_t** out);
+/* A rectangular CSR operator (nrows x ncols): the AMG transfer operators P and R (amg.rs:236-243). SpMV only (x: ncols entries,
+ * y: nrows); the diagonal-based sweeps and the transpose need a square handle. */
+int ma_csr_create_rect(int64_t nrows, int64_t ncols, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr_t** out);
+int ma_csr_num_cols(const ma_csr_t* h, int64_t* ncols);
 int ma_csr_destroy(ma_csr_t* h);
 int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz);
 int ma_csr_set_wavenumber(ma_csr_t* h, double k_re, double k_im);
@@ -305,6 +309,14 @@ int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond
 /* DiagonalPreconditioner::from_diagonal of an operator's diagonal (math-bem/src/core/solver/fmm_interface.rs:177-212): any
  * operator kind; for the matrix-free TBEM operator the diagonal is the self terms */
 int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out);
+/* AmgPreconditioner::apply = v_cycle from z = 0 (math-solvers/src/preconditioners/amg.rs:981-1065, 1068-1103) on the device, over a
+ * hierarchy the caller built (AmgPreconditioner::from_csr, amg.rs:276-372, stays on the host): level l = operator A[l] (square
+ * ma_csr_t) and, for l < nlevels-1, prolongation P[l] (n_l x n_{l+1}) and restriction R[l] (n_{l+1} x n_l) from ma_csr_create_rect;
+ * all handles are borrowed. smoother 0 Jacobi(jacobi_weight) (AmgSmoother::Jacobi / Chebyshev), 1 L1Jacobi, 2 SymmetricGaussSeidel;
+ * pre / post sweeps per level, the coarsest level runs 20 / 20 / 10 sweeps (:986-1003); cycle 0 V, 1 W (two V-cycles), 2 F (a second
+ * V-cycle on the residual). Use with ma_gmres_preconditioned (SolverType::GmresAmg, math-fem/src/solver/mod.rs:667). */
+int ma_precond_create_amg(int32_t nlevels, ma_csr_t* const* A, ma_csr_t* const* P, ma_csr_t* const* R, int32_t smoother, double jacobi_weight,
+                          int32_t num_pre_smooth, int32_t num_post_smooth, int32_t cycle, ma_precond_t** out);
 int ma_precond_destroy(ma_precond_t* M);
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
 int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */

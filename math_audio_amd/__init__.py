@@ -100,6 +100,9 @@ def lib():
             "ma_lu_plan_last_update_stats": [vp, P(dbl), P(dbl), P(dbl)],
             "ma_csr_create": [i64, vp, vp, vp, C.c_int, P(vp)],
             "ma_csr_create_helmholtz": [i64, vp, vp, vp, vp, C.c_int, P(vp)],
+            "ma_csr_create_rect": [i64, i64, vp, vp, vp, C.c_int, P(vp)],
+            "ma_csr_num_cols": [vp, P(i64)],
+            "ma_precond_create_amg": [i32, vp, vp, vp, i32, dbl, i32, i32, i32, P(vp)],
             "ma_csr_destroy": [vp],
             "ma_csr_num_rows": [vp, P(i64), P(i64)],
             "ma_csr_set_wavenumber": [vp, dbl, dbl],
@@ -409,6 +412,16 @@ class CsrOperator:
         else:
             k = np.ascontiguousarray(K, dtype=np.float64); m = np.ascontiguousarray(M, dtype=np.float64)
             check(lib().ma_csr_create_helmholtz(self.n, _vp(self.rp), _vp(self.ci), _vp(k), _vp(m), device, C.byref(self.h)))
+
+    @staticmethod
+    def rect(nrows, ncols, row_ptrs, col_indices, values, device=0):
+        """ma_csr_create_rect: a rectangular operator (the AMG transfer operators P and R); matvec only."""
+        self = CsrOperator.__new__(CsrOperator)
+        rp = np.ascontiguousarray(row_ptrs, dtype=np.int64); ci = np.ascontiguousarray(col_indices, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.complex128)
+        self.n = int(nrows); self.ncols = int(ncols); self.nnz = int(rp[-1]); self.h = C.c_void_p()
+        check(lib().ma_csr_create_rect(self.n, self.ncols, _vp(rp), _vp(ci), _vp(v), device, C.byref(self.h)))
+        return self
 
     @staticmethod
     def from_coo(n, rows, cols, values, device=0):
@@ -816,3 +829,36 @@ def solve_sweep_multi(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_
     if rc not in (MA_OK, MA_ERR_SINGULAR):
         check(rc)
     return X, st
+
+
+class AmgPreconditioner:
+    """ma_precond_create_amg: AmgPreconditioner::apply (amg.rs:981-1103) on the device over a host-built hierarchy.
+    levels: list of dicts {"A": CsrOperator[, "P": CsrOperator.rect, "R": CsrOperator.rect]} (the coarsest without P / R);
+    smoother "jacobi" | "l1" | "sgs"; cycle "V" | "W" | "F". The handles are borrowed and kept alive here."""
+
+    def __init__(self, levels, smoother="jacobi", jacobi_weight=0.6667, num_pre_smooth=1, num_post_smooth=1, cycle="V"):
+        self._keep = levels
+        L = len(levels)
+        A = (C.c_void_p * L)(*[lv["A"].h.value for lv in levels])
+        Pm = (C.c_void_p * L)(*[lv["P"].h.value if lv.get("P") is not None else None for lv in levels])
+        R = (C.c_void_p * L)(*[lv["R"].h.value if lv.get("R") is not None else None for lv in levels])
+        sm = {"jacobi": 0, "l1": 1, "sgs": 2}[smoother]; cy = {"V": 0, "W": 1, "F": 2}[cycle]
+        self.h = C.c_void_p()
+        check(lib().ma_precond_create_amg(L, C.cast(A, C.c_void_p), C.cast(Pm, C.c_void_p), C.cast(R, C.c_void_p), sm, float(jacobi_weight),
+                                          int(num_pre_smooth), int(num_post_smooth), cy, C.byref(self.h)))
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.complex128); z = np.empty_like(r)
+        check(lib().ma_precond_apply(self.h, _vp(r), _vp(z)))
+        return z
+
+    def close(self):
+        if self.h:
+            lib().ma_precond_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

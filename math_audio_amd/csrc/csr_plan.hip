@@ -12,6 +12,7 @@ using namespace ma;
 struct ma_csr {
   int device = 0;
   long long n = 0, nnz = 0;
+  long long ncols = 0;            // = n for the square operators; the AMG transfer operators P / R are rectangular (ma_csr_create_rect)
   bool km = false;
   int group = 16;
   long long* d_rowptr = nullptr; int* d_col = nullptr;
@@ -59,29 +60,31 @@ void free_all(ma_csr* h) {
   for (int* r : h->d_lev_rows) if (r) (void)hipFree(r);
   for (void* q : p) if (q) (void)hipFree(q);
 }
-int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out) {
+int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out, int64_t ncols = -1) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
   *out = nullptr;
-  MA_REQUIRE(n > 0 && rowptr && col, MA_ERR_INVALID, "bad CSR arguments");
+  if (ncols < 0) ncols = n;
+  MA_REQUIRE(n > 0 && ncols > 0 && rowptr && col, MA_ERR_INVALID, "bad CSR arguments");
   MA_REQUIRE(rowptr[0] == 0, MA_ERR_INVALID, "row_ptrs[0] must be 0");
   const int64_t nnz = rowptr[n];
   MA_REQUIRE(nnz >= 0, MA_ERR_INVALID, "row_ptrs[n] is negative");
   for (int64_t i = 0; i < n; ++i) MA_REQUIRE(rowptr[i + 1] >= rowptr[i], MA_ERR_INVALID, "row_ptrs must be non-decreasing (row %lld)", (long long)i);
-  MA_REQUIRE(n < 2147483647LL, MA_ERR_UNSUPPORTED, "more than 2^31-1 columns");
+  MA_REQUIRE(n < 2147483647LL && ncols < 2147483647LL, MA_ERR_UNSUPPORTED, "more than 2^31-1 rows or columns");
   std::vector<int> c32((size_t)nnz);
-  for (int64_t i = 0; i < nnz; ++i) { MA_REQUIRE(col[i] >= 0 && col[i] < n, MA_ERR_INVALID, "column index %lld out of range at %lld", (long long)col[i], (long long)i); c32[(size_t)i] = (int)col[i]; }
+  for (int64_t i = 0; i < nnz; ++i) { MA_REQUIRE(col[i] >= 0 && col[i] < ncols, MA_ERR_INVALID, "column index %lld out of range at %lld", (long long)col[i], (long long)i); c32[(size_t)i] = (int)col[i]; }
   int rc = use_device(device);
   if (rc) return rc;
   ma_csr* h = new (std::nothrow) ma_csr();
   MA_REQUIRE(h, MA_ERR_NOMEM, "host allocation failed");
-  h->device = device; h->n = n; h->nnz = nnz; h->group = pick_group(n, nnz);
+  h->device = device; h->n = n; h->ncols = ncols; h->nnz = nnz; h->group = pick_group(n, nnz);
+  const int64_t nvec = std::max<int64_t>(n, ncols);      // staging vectors serve x (ncols entries) and y (n entries) alike
   hipError_t e = hipMalloc(&h->d_rowptr, sizeof(long long) * (size_t)(n + 1));
   if (e == hipSuccess) e = hipMalloc(&h->d_col, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
   if (e == hipSuccess) e = hipMalloc(&h->d_dinv, sizeof(c64) * (size_t)n);
   if (e == hipSuccess) e = hipMalloc(&h->d_l1, sizeof(double) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&h->d_x, sizeof(c64) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&h->d_y, sizeof(c64) * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&h->d_b, sizeof(c64) * (size_t)n);
+  if (e == hipSuccess) e = hipMalloc(&h->d_x, sizeof(c64) * (size_t)nvec);
+  if (e == hipSuccess) e = hipMalloc(&h->d_y, sizeof(c64) * (size_t)nvec);
+  if (e == hipSuccess) e = hipMalloc(&h->d_b, sizeof(c64) * (size_t)nvec);
   if (e == hipSuccess) e = hipMemcpy(h->d_rowptr, rowptr, sizeof(long long) * (size_t)(n + 1), hipMemcpyHostToDevice);
   if (e == hipSuccess && nnz > 0) e = hipMemcpy(h->d_col, c32.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice);
   if (e != hipSuccess) { set_error("CSR upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; return e == hipErrorOutOfMemory ? MA_ERR_NOMEM : MA_ERR_HIP; }
@@ -116,7 +119,7 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
           const int64_t t = rowptr[r] + kk;
           sc[q] = (int)col[t]; ssrc[q] = (int)t;
           if (vals) { sv[q].re = vals[t].re; sv[q].im = vals[t].im; } else { sk[q] = K[t]; sm[q] = M[t]; }
-        } else sc[q] = (int)(r < n ? r : 0);             // padding: zero coefficient, a column that is in cache anyway
+        } else sc[q] = (int)std::min<int64_t>(r < n ? r : 0, h->ncols - 1);   // padding: zero coefficient, a column that is in cache anyway (and exists)
       }
     }
   // columns relative to the row in 16 bits when the whole operator allows it (MA_CSR_COL16=0 keeps 32-bit columns)
@@ -130,10 +133,11 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
         const int64_t r = s2 * 64 + l, rc_ = std::min<int64_t>(r, n - 1);
         const long long w = (sp[(size_t)s2 + 1] - sp[(size_t)s2]) / 64;
         const int64_t len = r < n ? rowptr[r + 1] - rowptr[r] : 0;
-        for (long long kk = 0; kk < len && kk < w; ++kk) {
-          const long long dlt = (long long)col[rowptr[r] + kk] - (long long)rc_;
+        for (long long kk = 0; kk < w; ++kk) {             // padding slots too: their column must exist (rectangular operators)
+          const size_t q = (size_t)(sp[(size_t)s2] + kk * 64 + l);
+          const long long dlt = (kk < len ? (long long)col[rowptr[r] + kk] : (long long)sc[q]) - (long long)rc_;
           if (dlt < -32768 || dlt > 32767) { c16 = false; break; }
-          sc16[(size_t)(sp[(size_t)s2] + kk * 64 + l)] = (short)dlt;
+          sc16[q] = (short)dlt;
         }
       }
   }
@@ -175,6 +179,26 @@ int ma_csr_create(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices
   if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_val, values, sizeof(c64) * (size_t)h->nnz, hipMemcpyHostToDevice);
   if (e != hipSuccess) { set_error("CSR value upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; *out = nullptr; return MA_ERR_HIP; }
   if ((rc = build_sell(h, row_ptrs, col_indices, values, nullptr, nullptr))) { free_all(h); delete h; *out = nullptr; return rc; }
+  return MA_OK;
+}
+
+// A rectangular operator (nrows x ncols): the prolongation P (fine x coarse) and restriction R (coarse x fine) of an AMG level
+// (amg.rs:236-243). SpMV only (ma_csr_spmv / ma_csr_spmv_dev: x has ncols entries, y nrows); the diagonal-based sweeps and
+// the transpose are for square operators.
+int ma_csr_create_rect(int64_t nrows, int64_t ncols, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr_t** out) {
+  MA_REQUIRE(values, MA_ERR_INVALID, "values is NULL");
+  int rc = create_common(nrows, row_ptrs, col_indices, device, out, ncols);
+  if (rc) return rc;
+  ma_csr* h = *out;
+  hipError_t e = hipMalloc(&h->d_val, sizeof(c64) * (size_t)(h->nnz > 0 ? h->nnz : 1));
+  if (e == hipSuccess && h->nnz > 0) e = hipMemcpy(h->d_val, values, sizeof(c64) * (size_t)h->nnz, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { set_error("CSR value upload failed: %s", hipGetErrorString(e)); free_all(h); delete h; *out = nullptr; return MA_ERR_HIP; }
+  if ((rc = build_sell(h, row_ptrs, col_indices, values, nullptr, nullptr))) { free_all(h); delete h; *out = nullptr; return rc; }
+  return MA_OK;
+}
+int ma_csr_num_cols(const ma_csr_t* h, int64_t* ncols) {
+  MA_REQUIRE(h && ncols, MA_ERR_INVALID, "NULL argument");
+  *ncols = h->ncols;
   return MA_OK;
 }
 
@@ -273,6 +297,7 @@ int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r
 }
 // `sweeps` Jacobi sweeps on d_x (in place from the caller's view; d_tmp is a scratch vector of n entries)
 int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream) {
+  MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_jacobi_dev needs a square operator");
   MA_REQUIRE(h && d_x && d_b && d_tmp && sweeps >= 0, MA_ERR_INVALID, "bad argument");
   MA_HIP(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
@@ -283,6 +308,7 @@ int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int
   return rc;
 }
 int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream) {
+  MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_l1jacobi_dev needs a square operator");
   MA_REQUIRE(h && d_x && d_b && d_tmp && sweeps >= 0, MA_ERR_INVALID, "bad argument");
   MA_HIP(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
@@ -300,7 +326,8 @@ static int down(ma_csr* h, ma_c64* d, const c64* s) { MA_HIP(hipMemcpy(d, s, siz
 int ma_csr_spmv(ma_csr_t* h, const ma_c64* x, ma_c64* y) {
   MA_REQUIRE(h && x && y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(h->device));
-  int rc = up(h, h->d_x, x);
+  int rc = MA_OK;
+  MA_HIP(hipMemcpy(h->d_x, x, sizeof(c64) * (size_t)h->ncols, hipMemcpyHostToDevice));
   if (!rc) rc = ma_csr_spmv_dev(h, h->d_x, h->d_y, nullptr);
   if (!rc) rc = down(h, y, h->d_y);
   return rc;
@@ -337,6 +364,7 @@ int ma_csr_l1jacobi(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps) {
 // by a counting sort of the downloaded pattern. CsrMatrix's LinearOperator::apply_transpose (csr.rs:420-440) is then an
 // SpMV on it -- a scatter with atomics would not be reproducible.
 int ma_csr_transpose(ma_csr_t* h, ma_csr_t** out) {
+  MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_transpose needs a square operator");
   MA_REQUIRE(h && out, MA_ERR_INVALID, "NULL argument");
   *out = nullptr;
   MA_HIP(hipSetDevice(h->device));
@@ -465,6 +493,7 @@ static int build_levels(ma_csr* h) {
 
 // one sweep over all rows in index order (backward = 0) or reverse order (1); mode 0 = smoother.rs:71-117, 1 = amg.rs:932-978
 int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int mode, int backward, void* stream) {
+  MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_gauss_seidel_sweep_dev needs a square operator");
   MA_REQUIRE(h && d_x && d_b && (mode == 0 || mode == 1), MA_ERR_INVALID, "bad argument");
   MA_HIP(hipSetDevice(h->device));
   int rc = build_levels(h);
@@ -479,6 +508,7 @@ int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int m
 
 // smooth_sym_gauss_seidel(matrix, x, b, num_sweeps) (amg.rs:932-978): forward then backward sweep, num_sweeps times
 int ma_csr_sym_gauss_seidel_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* stream) {
+  MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_sym_gauss_seidel_dev needs a square operator");
   MA_REQUIRE(sweeps >= 0, MA_ERR_INVALID, "negative sweep count");
   int rc = MA_OK;
   for (int s = 0; s < sweeps && !rc; ++s) {
@@ -498,6 +528,7 @@ int ma_csr_sym_gauss_seidel(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int s
 }
 // number of dependency levels of the forward / backward Gauss-Seidel schedule (diagnostics: launches per sweep)
 int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward) {
+  MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_gauss_seidel_levels needs a square operator");
   MA_REQUIRE(h, MA_ERR_INVALID, "NULL handle");
   MA_HIP(hipSetDevice(h->device));
   int rc = build_levels(h);

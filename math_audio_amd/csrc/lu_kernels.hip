@@ -1193,9 +1193,12 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   const unsigned long long i = g_seq.count[dev];
   PanelLaunch* ring = g_seq.ring[dev];
   PanelLaunch& me = ring[i % kSeqRing];
-  if (me.used && hipEventQuery(me.ev) != hipSuccess) {        // launch i - 256 not finished yet: the host is that far ahead
+  // an event counts as pending only while the runtime says "not ready": anything else (success, or an error because the
+  // stream it was recorded on has been destroyed since -- plans come and go, the table is per device) means its work is over
+  auto pending = [](hipEvent_t ev) { const hipError_t q = hipEventQuery(ev); (void)hipGetLastError(); return q == hipErrorNotReady; };
+  if (me.used && pending(me.ev)) {                            // launch i - 256 not finished yet: the host is that far ahead
+    (void)hipEventSynchronize(me.ev);
     (void)hipGetLastError();
-    MA_HIP(hipEventSynchronize(me.ev));
   }
   const unsigned long long oldest = i >= (unsigned long long)(kSeqRing - 1) ? i - (kSeqRing - 1) : 0ull;
   long long tot = nblk; size_t smax = lds; int taken = 1;
@@ -1214,8 +1217,7 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
     for (int q = 0; q < nseen; ++q) dup = dup || seen[q] == L.st;
     if (dup) continue;                                        // an older launch of a stream already waited for
     seen[nseen++] = L.st;
-    if (hipEventQuery(L.ev) == hipSuccess) continue;          // finished: nothing to wait for (and nothing older on that stream either)
-    (void)hipGetLastError();
+    if (!pending(L.ev)) continue;                             // finished: nothing to wait for (and nothing older on that stream either)
     MA_HIP(hipStreamWaitEvent(st, L.ev, 0));
   }
   // Stale tags must not match. A workgroup rewrites its granule every column, so only columns 0 and 1 of a launch can

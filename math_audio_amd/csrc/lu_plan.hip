@@ -192,6 +192,9 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
 int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (!P) return MA_OK;
   (void)hipSetDevice(P->device);
+  // nothing of this plan may still be running when its streams and workspaces go (the panel sequencer keeps events that
+  // were recorded on these streams)
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) (void)hipStreamSynchronize(P->panel_streams[i]); if (P->mid_streams[i]) (void)hipStreamSynchronize(P->mid_streams[i]); }
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]);

@@ -373,15 +373,50 @@ int ma_op_apply_hermitian(ma_op_t* o, const ma_c64* x, ma_c64* y) { return op_ap
 // apply(r) -> z. The device preconditioners are the one-level smoothers of the AMG V-cycle applied from z = 0
 // (what AmgPreconditioner::apply does on its coarsest level, amg.rs:981-1005): `sweeps` Jacobi (kind 1) or
 // l1-Jacobi (kind 2) sweeps on A z = r with the CSR handle's current values. kind 0 is the identity.
+// one level of an AMG hierarchy on the device (AmgLevel, amg.rs:229-249): the level's operator, its transfer operators (null on
+// the coarsest level) and the level's work vectors
+struct AmgLevelDev {
+  ma_csr* A = nullptr; ma_csr* P = nullptr; ma_csr* R = nullptr; long long n = 0;
+  c64* x = nullptr; c64* b = nullptr; c64* r = nullptr; c64* tmp = nullptr;     // x / b: this level's unknown and right-hand side (levels > 0)
+};
 struct ma_precond {
   int kind = 0; ma_csr* csr = nullptr; double omega = 2.0 / 3.0; int sweeps = 2; long long n = 0; int device = 0;
   c64* d_tmp = nullptr;
   c64* d_invdiag = nullptr;      // kind 4: 1 / a_ii of an operator (DiagonalPreconditioner::from_diagonal)
+  // kind 5: AmgPreconditioner::apply (amg.rs:1068-1103)
+  std::vector<AmgLevelDev> lv; int amg_smoother = 0, amg_pre = 1, amg_post = 1, amg_cycle = 0;
 };
 
 extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
 extern "C" int ma_csr_l1jacobi_dev(ma_csr* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream);
 extern "C" int ma_csr_sym_gauss_seidel_dev(ma_csr* h, void* d_x, const void* d_b, int sweeps, void* stream);
+extern "C" int ma_csr_residual_dev(ma_csr* h, const void* d_x, const void* d_b, void* d_r, void* stream);
+extern "C" int ma_csr_num_cols(const ma_csr* h, int64_t* ncols);
+
+// AmgPreconditioner::v_cycle (amg.rs:981-1065) on device vectors of level `level`: smoothers are the AMG sweeps of the CSR
+// handles (smooth_jacobi :855-884, smooth_l1_jacobi :887-929, smooth_sym_gauss_seidel :932-978), the coarsest level runs 20
+// Jacobi / 20 l1-Jacobi / 10 symmetric Gauss-Seidel sweeps (:986-1003), restriction and prolongation are SpMVs with the level's R and P.
+static int amg_smooth(ma_precond* M, AmgLevelDev& L, c64* x, const c64* b, int sweeps, hipStream_t st) {
+  if (sweeps <= 0) return MA_OK;
+  if (M->amg_smoother == 1) return ma_csr_l1jacobi_dev(L.A, x, b, sweeps, L.tmp, st);
+  if (M->amg_smoother == 2) return ma_csr_sym_gauss_seidel_dev(L.A, x, b, sweeps, st);
+  return ma_csr_jacobi_dev(L.A, x, b, M->omega, sweeps, L.tmp, st);
+}
+static int amg_v_cycle(ma_precond* M, size_t level, c64* x, const c64* b, hipStream_t st) {
+  AmgLevelDev& L = M->lv[level];
+  if (level + 1 == M->lv.size() || !L.P)
+    return amg_smooth(M, L, x, b, M->amg_smoother == 2 ? 10 : 20, st);
+  int rc = amg_smooth(M, L, x, b, M->amg_pre, st);
+  if (!rc) rc = ma_csr_residual_dev(L.A, x, b, L.r, st);                       // r = b - A x
+  AmgLevelDev& C = M->lv[level + 1];
+  if (!rc) rc = ma_csr_spmv_dev(L.R, L.r, C.b, st);                            // r_c = R r
+  if (!rc && hipMemsetAsync(C.x, 0, sizeof(c64) * (size_t)C.n, st) != hipSuccess) { set_error("AMG: clearing the coarse correction failed"); rc = MA_ERR_HIP; }
+  if (!rc) rc = amg_v_cycle(M, level + 1, C.x, C.b, st);
+  if (!rc) rc = ma_csr_spmv_dev(L.P, C.x, L.r, st);                            // e = P e_c
+  if (!rc) rc = op_launch_axpby(L.n, 1.0, 0.0, x, 1.0, 0.0, L.r, x, st);      // x = x + e
+  if (!rc) rc = amg_smooth(M, L, x, b, M->amg_post, st);
+  return rc;
+}
 
 int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
@@ -430,8 +465,50 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
   if (rc) { (void)hipFree(M->d_invdiag); delete M; return rc; }
   *out = M; return MA_OK;
 }
+// AmgPreconditioner over a hierarchy built on the host (AmgPreconditioner::from_csr keeps the setup -- strength, coarsening,
+// interpolation, Galerkin products, amg.rs:276-372 -- where it is): level l brings its operator A_l and, except the
+// coarsest, the prolongation P_l (n_l x n_{l+1}) and restriction R_l (n_{l+1} x n_l) as CSR handles (borrowed).
+// smoother: 0 Jacobi(omega) (AmgSmoother::Jacobi / Chebyshev), 1 l1-Jacobi, 2 symmetric Gauss-Seidel; cycle: 0 V, 1 W, 2 F.
+int ma_precond_create_amg(int32_t nlevels, ma_csr_t* const* A, ma_csr_t* const* P, ma_csr_t* const* R, int32_t smoother, double jacobi_weight,
+                          int32_t num_pre_smooth, int32_t num_post_smooth, int32_t cycle, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(nlevels >= 1 && nlevels <= 64 && A, MA_ERR_INVALID, "bad level count");
+  MA_REQUIRE(nlevels == 1 || (P && R), MA_ERR_INVALID, "transfer operators missing");
+  MA_REQUIRE(smoother >= 0 && smoother <= 2 && cycle >= 0 && cycle <= 2 && num_pre_smooth >= 0 && num_post_smooth >= 0, MA_ERR_INVALID, "bad smoother / cycle");
+  ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
+  M->kind = 5; M->amg_smoother = smoother; M->omega = jacobi_weight; M->amg_pre = num_pre_smooth; M->amg_post = num_post_smooth; M->amg_cycle = cycle;
+  M->lv.resize((size_t)nlevels);
+  int rc = MA_OK;
+  MA_HIP(hipGetDevice(&M->device));
+  for (int l = 0; l < nlevels && !rc; ++l) {
+    AmgLevelDev& L = M->lv[(size_t)l];
+    int64_t n = 0, nnz = 0, nc = 0;
+    if (!A[l]) { set_error("level %d has no operator", l); rc = MA_ERR_INVALID; break; }
+    rc = ma_csr_num_rows(A[l], &n, &nnz); if (rc) break;
+    rc = ma_csr_num_cols(A[l], &nc); if (rc) break;
+    if (nc != n) { set_error("level %d: operator is %lld x %lld", l, (long long)n, (long long)nc); rc = MA_ERR_DIM; break; }
+    L.A = A[l]; L.n = n;
+    if (l + 1 < nlevels) {
+      if (!P[l] || !R[l]) { set_error("level %d lacks P or R", l); rc = MA_ERR_INVALID; break; }
+      int64_t pr = 0, pc = 0, rr = 0, rcn = 0, cn = 0, z = 0;
+      (void)ma_csr_num_rows(P[l], &pr, &z); (void)ma_csr_num_cols(P[l], &pc); (void)ma_csr_num_rows(R[l], &rr, &z); (void)ma_csr_num_cols(R[l], &rcn);
+      if (A[l + 1]) (void)ma_csr_num_rows(A[l + 1], &cn, &z);
+      if (pr != n || rcn != n || pc != cn || rr != cn) { set_error("level %d: P is %lld x %lld, R is %lld x %lld, levels have %lld and %lld rows", l, (long long)pr, (long long)pc, (long long)rr, (long long)rcn, (long long)n, (long long)cn); rc = MA_ERR_DIM; break; }
+      L.P = P[l]; L.R = R[l];
+    }
+    hipError_t e = hipMalloc(&L.r, sizeof(c64) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc(&L.tmp, sizeof(c64) * (size_t)n);
+    if (e == hipSuccess && l > 0) e = hipMalloc(&L.x, sizeof(c64) * (size_t)n);
+    if (e == hipSuccess && l > 0) e = hipMalloc(&L.b, sizeof(c64) * (size_t)n);
+    if (e != hipSuccess) { set_error("AMG level %d vectors: %s", l, hipGetErrorString(e)); rc = MA_ERR_NOMEM; }
+  }
+  if (!rc) { M->n = M->lv[0].n; if (hipMalloc(&M->d_tmp, sizeof(c64) * (size_t)M->n * 2) != hipSuccess) { set_error("AMG workspace"); rc = MA_ERR_NOMEM; } }
+  if (rc) { ma_precond_destroy(M); return rc; }
+  *out = M; return MA_OK;
+}
 int ma_precond_destroy(ma_precond_t* M) {
   if (!M) return MA_OK;
+  for (AmgLevelDev& L : M->lv) { void* p[] = {L.x, L.b, L.r, L.tmp}; for (void* q : p) if (q) (void)hipFree(q); }
   if (M->d_tmp) (void)hipFree(M->d_tmp);
   if (M->d_invdiag) (void)hipFree(M->d_invdiag);
   delete M; return MA_OK;
@@ -442,6 +519,20 @@ int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stre
   if (M->kind == 0) { MA_HIP(hipMemcpyAsync(d_z, d_r, sizeof(c64) * (size_t)M->n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return MA_OK; }
   if (M->kind == 4) return op_launch_cmul(M->n, M->d_invdiag, (const c64*)d_r, (c64*)d_z, (hipStream_t)stream);
   MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
+  if (M->kind == 5) {                                    // AmgPreconditioner::apply, amg.rs:1068-1103: z = 0, then the cycle
+    hipStream_t st = (hipStream_t)stream;
+    c64* z = (c64*)d_z; const c64* r = (const c64*)d_r;
+    int rc = amg_v_cycle(M, 0, z, r, st);
+    if (!rc && M->amg_cycle == 1) rc = amg_v_cycle(M, 0, z, r, st);             // W: the V-cycle twice (:1084-1087)
+    if (!rc && M->amg_cycle == 2) {                                              // F: a second V-cycle on the residual (:1088-1094)
+      c64* res = M->d_tmp; c64* corr = M->d_tmp + M->n;
+      rc = ma_csr_residual_dev(M->lv[0].A, z, r, res, st);
+      if (!rc && hipMemsetAsync(corr, 0, sizeof(c64) * (size_t)M->n, st) != hipSuccess) { set_error("AMG: clearing the correction failed"); rc = MA_ERR_HIP; }
+      if (!rc) rc = amg_v_cycle(M, 0, corr, res, st);
+      if (!rc) rc = op_launch_axpby(M->n, 1.0, 0.0, z, 1.0, 0.0, corr, z, st);
+    }
+    return rc;
+  }
   if (M->kind == 1) return ma_csr_jacobi_dev(M->csr, d_z, d_r, M->omega, M->sweeps, M->d_tmp, stream);
   if (M->kind == 3) return ma_csr_sym_gauss_seidel_dev(M->csr, d_z, d_r, M->sweeps, stream);
   return ma_csr_l1jacobi_dev(M->csr, d_z, d_r, M->sweeps, M->d_tmp, stream);

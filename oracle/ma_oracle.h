@@ -154,6 +154,20 @@ void mao_gmres(int n, int op_kind, const mao_c64* dense, const long long* row_pt
 void mao_gmres_preconditioned(int n, const long long* row_ptr, const long long* col, const mao_c64* val, int pkind, double omega, int sweeps,
                               const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol, mao_c64* x, mao_gmres_info* info);
 
+/* AmgPreconditioner::v_cycle / apply (preconditioners/amg.rs:981-1065, 1068-1103) over a hierarchy given level by level: operator
+ * a_*[l] (n[l] x n[l]); prolongation p_*[l] (n[l] x n[l+1]) and restriction r_*[l] (n[l+1] x n[l]) for l < nlevels-1 (NULL on the
+ * coarsest). smoother 0 Jacobi(jacobi_weight), 1 l1-Jacobi, 2 symmetric Gauss-Seidel; cycle 0 V, 1 W, 2 F. */
+typedef struct {
+  int nlevels; const int* n;
+  const long long* const* a_rp; const long long* const* a_col; const mao_c64* const* a_val;
+  const long long* const* p_rp; const long long* const* p_col; const mao_c64* const* p_val;
+  const long long* const* r_rp; const long long* const* r_col; const mao_c64* const* r_val;
+  int smoother; double jacobi_weight; int num_pre_smooth, num_post_smooth, cycle;
+} mao_amg_hierarchy;
+void mao_amg_apply(const mao_amg_hierarchy* H, const mao_c64* r, mao_c64* z);
+void mao_gmres_amg(const mao_amg_hierarchy* H, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
+                   mao_c64* x, mao_gmres_info* info);
+
 /* ---- room-acoustics collocation assembly (room_acoustics/solver.rs:448-493) ---- */
 void mao_room_build_matrix(int n_elem, const double* center, const double* normal, const double* area,
                            double k, mao_c64* A, int nthreads);

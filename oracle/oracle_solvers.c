@@ -423,9 +423,51 @@ void mao_gmres(int n, int kind, const mao_c64* dense, const long long* rp, const
  * (kind 1, amg.rs:855-884) or l1-Jacobi (kind 2, amg.rs:887-929) sweeps on A z = r, i.e. what
  * AmgPreconditioner::apply does on its coarsest level (amg.rs:981-1005, 1068-1087).
  * ====================================================================== */
+/* ---- AmgPreconditioner::v_cycle / apply (preconditioners/amg.rs:981-1065, 1068-1103) over a given hierarchy ---- */
+static void amg_smooth(const mao_amg_hierarchy* H, int l, mao_c64* x, const mao_c64* b, int sweeps) {
+  if (H->smoother == 1) mao_amg_l1_jacobi(H->n[l], H->a_rp[l], H->a_col[l], H->a_val[l], x, b, sweeps, 1);
+  else if (H->smoother == 2) mao_amg_sym_gauss_seidel(H->n[l], H->a_rp[l], H->a_col[l], H->a_val[l], x, b, sweeps);
+  else mao_amg_jacobi(H->n[l], H->a_rp[l], H->a_col[l], H->a_val[l], x, b, H->jacobi_weight, sweeps, 1);
+}
+static void amg_v_cycle(const mao_amg_hierarchy* H, int level, mao_c64* x, const mao_c64* b) {
+  const int n = H->n[level];
+  /* amg.rs:985-1003: coarsest level (or no prolongation): 20 Jacobi / 20 l1-Jacobi / 10 symmetric Gauss-Seidel sweeps */
+  if (level == H->nlevels - 1 || !H->p_rp[level]) { amg_smooth(H, level, x, b, H->smoother == 2 ? 10 : 20); return; }
+  amg_smooth(H, level, x, b, H->num_pre_smooth);                                  /* :1006-1024 */
+  mao_c64* r = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+  mao_csr_matvec(n, H->a_rp[level], H->a_col[level], H->a_val[level], x, r, 1);    /* :1027 r = b - A x */
+  for (int i = 0; i < n; ++i) r[i] = csub(b[i], r[i]);
+  const int nc = H->n[level + 1];
+  mao_c64* rc = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)nc);
+  mao_c64* ec = (mao_c64*)calloc((size_t)nc, sizeof(mao_c64));                     /* :1033-1034 e_c = 0 */
+  mao_csr_matvec(nc, H->r_rp[level], H->r_col[level], H->r_val[level], r, rc, 1);  /* :1030 r_c = R r */
+  amg_v_cycle(H, level + 1, ec, rc);                                              /* :1037 */
+  mao_csr_matvec(n, H->p_rp[level], H->p_col[level], H->p_val[level], ec, r, 1);   /* :1040 e = P e_c */
+  for (int i = 0; i < n; ++i) x[i] = cadd(x[i], r[i]);                             /* :1043 */
+  amg_smooth(H, level, x, b, H->num_post_smooth);                                 /* :1046-1064 */
+  free(r); free(rc); free(ec);
+}
+void mao_amg_apply(const mao_amg_hierarchy* H, const mao_c64* r, mao_c64* z) {
+  const int n = H->n[0];
+  memset(z, 0, sizeof(mao_c64) * (size_t)n);                                       /* :1079 */
+  amg_v_cycle(H, 0, z, r);
+  if (H->cycle == 1) amg_v_cycle(H, 0, z, r);                                      /* W: :1084-1087 */
+  if (H->cycle == 2) {                                                             /* F: :1088-1094 */
+    mao_c64* res = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+    mao_c64* corr = (mao_c64*)calloc((size_t)n, sizeof(mao_c64));
+    mao_csr_matvec(n, H->a_rp[0], H->a_col[0], H->a_val[0], z, res, 1);
+    for (int i = 0; i < n; ++i) res[i] = csub(r[i], res[i]);
+    amg_v_cycle(H, 0, corr, res);
+    for (int i = 0; i < n; ++i) z[i] = cadd(z[i], corr[i]);
+    free(res); free(corr);
+  }
+}
+static const mao_amg_hierarchy* g_amg = NULL;     /* the hierarchy behind pkind 3 (test infrastructure: one caller at a time) */
+
 static void precond_apply(int n, const long long* rp, const long long* col, const mao_c64* val, int kind, double omega, int sweeps,
                           const mao_c64* r, mao_c64* z) {
   if (kind == 0) { memcpy(z, r, sizeof(mao_c64) * (size_t)n); return; }
+  if (kind == 3) { mao_amg_apply(g_amg, r, z); return; }
   memset(z, 0, sizeof(mao_c64) * (size_t)n);
   if (kind == 1) mao_amg_jacobi(n, rp, col, val, z, r, omega, sweeps, 1);
   else mao_amg_l1_jacobi(n, rp, col, val, z, r, sweeps, 1);
@@ -517,4 +559,13 @@ void mao_gmres_preconditioned(int n, const long long* rp, const long long* col, 
   }
 #undef HH
   free(V); free(H); free(cs); free(sn); free(g); free(w); free(t); free(y);
+}
+
+/* gmres_preconditioned with an AmgPreconditioner (SolverType::GmresAmg, math-fem/src/solver/mod.rs:667): the fine operator is
+ * the hierarchy's level 0 */
+void mao_gmres_amg(const mao_amg_hierarchy* H, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
+                   mao_c64* x, mao_gmres_info* info) {
+  g_amg = H;
+  mao_gmres_preconditioned(H->n[0], H->a_rp[0], H->a_col[0], H->a_val[0], 3, 0.0, 0, b, x0, restart, max_iterations, tol, x, info);
+  g_amg = NULL;
 }

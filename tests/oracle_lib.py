@@ -414,3 +414,47 @@ def room_field_pressure(center, normal, area, surface_pressure, src_pos, amp, po
     lib().mao_room_field_pressure(len(a), _p(c), _p(nr), _p(a), _vp(ps), sp.shape[0], _p(sp), _p(amp), 1 if amp.ndim == 2 else 0, pts.shape[0], _p(pts),
                                   C.c_double(k), _vp(out))
     return out
+
+
+# ---------------------------------------------------------------- AMG V-cycle over a given hierarchy (amg.rs:981-1103)
+class _AmgStruct(C.Structure):
+    _PP = C.POINTER(C.c_void_p)
+    _fields_ = [("nlevels", C.c_int), ("n", C.POINTER(C.c_int)),
+                ("a_rp", _PP), ("a_col", _PP), ("a_val", _PP), ("p_rp", _PP), ("p_col", _PP), ("p_val", _PP),
+                ("r_rp", _PP), ("r_col", _PP), ("r_val", _PP),
+                ("smoother", C.c_int), ("jacobi_weight", C.c_double), ("num_pre_smooth", C.c_int), ("num_post_smooth", C.c_int), ("cycle", C.c_int)]
+
+
+class AmgHierarchy:
+    """levels: list of dicts {A: (rp, col, val)[, P: (rp, col, val), R: (rp, col, val)]}; the coarsest has no P / R."""
+
+    def __init__(self, levels, smoother=0, jacobi_weight=0.6667, num_pre_smooth=1, num_post_smooth=1, cycle=0):
+        self._keep = []
+        L = len(levels)
+        self.n = (C.c_int * L)(*[len(lv["A"][0]) - 1 for lv in levels])
+
+        def ptrs(key, part, dt):
+            arr = (C.c_void_p * L)()
+            for i, lv in enumerate(levels):
+                if key in lv and lv[key] is not None:
+                    a = np.ascontiguousarray(lv[key][part], dtype=dt); self._keep.append(a)
+                    arr[i] = a.ctypes.data
+                else:
+                    arr[i] = None
+            self._keep.append(arr)
+            return C.cast(arr, C.POINTER(C.c_void_p))
+        self.s = _AmgStruct(L, self.n, ptrs("A", 0, np.int64), ptrs("A", 1, np.int64), ptrs("A", 2, np.complex128),
+                            ptrs("P", 0, np.int64), ptrs("P", 1, np.int64), ptrs("P", 2, np.complex128),
+                            ptrs("R", 0, np.int64), ptrs("R", 1, np.int64), ptrs("R", 2, np.complex128),
+                            smoother, jacobi_weight, num_pre_smooth, num_post_smooth, cycle)
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.complex128); z = np.zeros_like(r)
+        lib().mao_amg_apply(C.byref(self.s), _vp(r), _vp(z))
+        return z
+
+    def gmres(self, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
+        b = np.ascontiguousarray(b, dtype=np.complex128); x = np.zeros_like(b); info = GmresInfo()
+        x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+        lib().mao_gmres_amg(C.byref(self.s), _vp(b), _vp(x0a), restart, max_iterations, C.c_double(tol), _vp(x), C.byref(info))
+        return x, info
