@@ -325,6 +325,12 @@ int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /
  * ||M^-1 b||   math-solvers/src/iterative/gmres.rs:282-585 */
 int ma_gmres_preconditioned(ma_op_t* op, ma_precond_t* M, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations,
                             double tol, ma_c64* x_out, ma_gmres_info_t* info);
+/* gmres_pipelined(operator, precond, b, x0, config) (math-solvers/src/iterative/gmres_pipelined.rs:18-250, p-GMRES): auxiliary
+ * basis Z = M^-1 A V, classical Gram-Schmidt; the inner products of a step run on a second stream beside the operator apply of
+ * the next (the reference's rayon::join). M may be NULL (IdentityPreconditioner). Left preconditioning, tolerance relative to
+ * ||M^-1 (b - A x0)||. */
+int ma_gmres_pipelined(ma_op_t* op, ma_precond_t* M_or_null, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations,
+                       double tol, ma_c64* x_out, ma_gmres_info_t* info);
 /* Restarted GMRES(m), relative tolerance on ||b||; defaults of GmresConfig: restart 30, tol 1e-6, 100 restarts
  * (gmres.rs:27-35). x0 may be NULL. Non-convergence is reported in info->converged, not as an error. */
 int ma_gmres(ma_op_t* op, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol,

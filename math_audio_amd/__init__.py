@@ -147,6 +147,7 @@ def lib():
             "ma_precond_apply_dev": [vp, vp, vp, vp],
             "ma_precond_apply": [vp, vp, vp],
             "ma_gmres_preconditioned": [vp, vp, vp, vp, i32, i32, dbl, vp, vp],
+            "ma_gmres_pipelined": [vp, vp, vp, vp, i32, i32, dbl, vp, vp],
             "ma_bem_plan_scattered_field": [vp, P(ma_physics_t), i32, vp, vp, vp, vp],
             "ma_room_build_matrix": [i32, vp, vp, vp, dbl, vp],
             "ma_room_build_matrix_dev": [i32, vp, vp, vp, dbl, vp, vp],
@@ -862,3 +863,12 @@ class AmgPreconditioner:
             self.close()
         except Exception:
             pass
+
+
+def gmres_pipelined(op, b, precond=None, x0=None, restart=30, max_iterations=100, tol=1e-6):
+    """gmres_pipelined (gmres_pipelined.rs:18-250) on the device: returns (x, GmresInfo); precond None = identity."""
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    x = np.empty(op.n, dtype=np.complex128); info = GmresInfo()
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    check(lib().ma_gmres_pipelined(op.h, precond.h if precond is not None else None, _vp(b), _vp(x0a), restart, max_iterations, float(tol), _vp(x), C.byref(info)))
+    return x, info

@@ -673,6 +673,150 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
   return MA_OK;
 }
 
+// ------------------------------------------------------------------ gmres_pipelined (iterative/gmres_pipelined.rs:18-250)
+// p-GMRES: with the auxiliary basis Z = M^-1 A V the inner products of step j (z_j against v_0..v_j, classical Gram-Schmidt) do
+// not depend on q = M^-1 A z_j, so the reference runs the two concurrently (rayon::join, :106-119). Here: the operator (and
+// preconditioner) on the caller's stream, the j + 1 inner products on a second stream, joined by events; the scalars stay on the
+// device, one host synchronisation per inner step (the column of H for the Givens update), as in ma_gmres.
+static int gmres_pipelined_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const ma_c64* x0_host, int32_t restart, int32_t max_iterations, double tol,
+                                ma_c64* x_out, ma_gmres_info_t* info) {
+  MA_REQUIRE(o && b_host && x_out && info, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(!Mp || Mp->n == o->n, MA_ERR_DIM, "preconditioner and operator sizes differ");
+  MA_REQUIRE(restart >= 1 && max_iterations >= 0, MA_ERR_INVALID, "restart must be >= 1");
+  MA_HIP(hipSetDevice(o->device));
+  const long long n = o->n; const int m = restart;
+  hipStream_t st = nullptr, s2 = nullptr;
+  hipEvent_t ev_z = nullptr, ev_h = nullptr;
+  c64 *V = nullptr, *Z = nullptr, *x = nullptr, *b = nullptr, *scal = nullptr, *partial = nullptr, *partial2 = nullptr, *t = nullptr, *q = nullptr, *vn = nullptr;
+  auto cleanup = [&]() {
+    void* p[] = {V, Z, x, b, scal, partial, partial2, t, q, vn}; for (void* r : p) if (r) (void)hipFree(r);
+    if (ev_z) (void)hipEventDestroy(ev_z); if (ev_h) (void)hipEventDestroy(ev_h); if (s2) (void)hipStreamDestroy(s2);
+  };
+#define GM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return MA_ERR_HIP; } } while (0)
+#define GM_RC(call) do { int rc_ = (call); if (rc_) { cleanup(); return rc_; } } while (0)
+  GM_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  GM_HIP(hipEventCreateWithFlags(&ev_z, hipEventDisableTiming)); GM_HIP(hipEventCreateWithFlags(&ev_h, hipEventDisableTiming));
+  GM_HIP(hipMalloc(&V, sizeof(c64) * (size_t)n * (size_t)(m + 1)));
+  GM_HIP(hipMalloc(&Z, sizeof(c64) * (size_t)n * (size_t)(m + 1)));
+  for (c64** p : {&x, &b, &t, &q, &vn}) GM_HIP(hipMalloc(p, sizeof(c64) * (size_t)n));
+  GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 4)));
+  GM_HIP(hipMalloc(&partial, sizeof(c64) * 256)); GM_HIP(hipMalloc(&partial2, sizeof(c64) * 256));
+  GM_HIP(hipMemcpy(b, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
+  if (x0_host) GM_HIP(hipMemcpy(x, x0_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
+  else GM_HIP(hipMemset(x, 0, sizeof(c64) * (size_t)n));
+  auto norm_of = [&](const c64* v, double* out) -> int {
+    int rc = op_launch_dot(n, v, nullptr, 1, partial, scal, st); if (rc) return rc;
+    c64 h; MA_HIP(hipMemcpy(&h, scal, sizeof(c64), hipMemcpyDeviceToHost)); *out = h.re; return MA_OK;
+  };
+  auto precond = [&](const c64* in, c64* out) -> int {        // M^-1 in -> out (identity: a copy)
+    if (Mp) return ma_precond_apply_dev(Mp, in, out, st);
+    MA_HIP(hipMemcpyAsync(out, in, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice, st)); return MA_OK;
+  };
+  auto residual_into = [&](c64* out) -> int {                // out = M^-1 (b - A x)   (:40-48, :72-76)
+    int rc = ma_op_apply_dev(o, x, t, st); if (rc) return rc;
+    rc = op_launch_axpby(n, 1.0, 0.0, b, -1.0, 0.0, t, t, st); if (rc) return rc;
+    return precond(t, out);
+  };
+  double b_norm = 0.0;
+  GM_RC(residual_into(q)); GM_RC(norm_of(q, &b_norm));
+  info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
+  if (b_norm < 1e-15) { GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost)); cleanup(); return MA_OK; }
+
+  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2);
+  auto Hh = [&](int i, int j) -> cplx& { return H[(size_t)i * m + j]; };
+  auto givens = [](cplx a, cplx bb, cplx* c, cplx* s) {
+    if (std::abs(bb) < 1e-30) { *c = 1.0; *s = 0.0; return; }
+    if (std::abs(a) < 1e-30) { *c = 0.0; *s = 1.0; return; }
+    const double r = std::sqrt(std::norm(a) + std::norm(bb));
+    *c = a * (1.0 / r); *s = bb * (1.0 / r);
+  };
+  auto solve_upper = [&](int k) {
+    for (int i = k - 1; i >= 0; --i) {
+      cplx sum = g[i];
+      for (int p = i + 1; p < k; ++p) sum -= Hh(i, p) * y[p];
+      y[i] = std::abs(Hh(i, i)) > 1e-30 ? sum * (1.0 / Hh(i, i)) : cplx(0.0, 0.0);
+    }
+  };
+  auto update_x = [&](int k) -> int {
+    for (int i = 0; i < k; ++i) { int rc = op_launch_axpy_host(n, y[i].real(), y[i].imag(), V + (size_t)i * n, x, st); if (rc) return rc; }
+    return MA_OK;
+  };
+  int total = 0, restarts = 0; bool done = false;
+  for (int outer = 0; outer < max_iterations && !done; ++outer) {
+    GM_RC(residual_into(V));
+    double beta = 0.0; GM_RC(norm_of(V, &beta));
+    double rel = beta / b_norm;
+    if (rel < tol) { info->iterations = total; info->restarts = restarts; info->residual = rel; info->converged = 1; done = true; break; }
+    GM_RC(op_launch_axpby(n, 1.0 / beta, 0.0, V, 0.0, 0.0, nullptr, V, st));                       // v0 = r / beta (:93)
+    GM_RC(ma_op_apply_dev(o, V, t, st)); GM_RC(precond(t, Z));                                    // z0 = M^-1 A v0 (:96-97)
+    std::fill(H.begin(), H.end(), cplx(0.0, 0.0)); std::fill(g.begin(), g.end(), cplx(0.0, 0.0));
+    g[0] = beta;
+    int nv = 1; bool inner_conv = false, finished = false;
+    for (int j = 0; j < m; ++j) {
+      total += 1;
+      const c64* zj = Z + (size_t)j * n;
+      GM_HIP(hipEventRecord(ev_z, st)); GM_HIP(hipStreamWaitEvent(s2, ev_z, 0));
+      GM_RC(ma_op_apply_dev(o, zj, t, st)); GM_RC(precond(t, q));                                  // q = M^-1 A z_j        | concurrently
+      for (int i = 0; i <= j; ++i) GM_RC(op_launch_dot(n, V + (size_t)i * n, zj, 0, partial2, scal + 1 + i, s2));   // h_ij = <v_i, z_j> |
+      GM_HIP(hipEventRecord(ev_h, s2)); GM_HIP(hipStreamWaitEvent(st, ev_h, 0));
+      GM_HIP(hipMemcpyAsync(vn, zj, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice, st));       // :129-136
+      for (int i = 0; i <= j; ++i) {
+        GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, V + (size_t)i * n, vn, st));
+        GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, Z + (size_t)i * n, q, st));
+      }
+      GM_RC(op_launch_dot(n, vn, nullptr, 1, partial, scal + 2 + j, st));                          // :139
+      GM_HIP(hipMemcpy(hcol.data(), scal + 1, sizeof(c64) * (size_t)(j + 2), hipMemcpyDeviceToHost));
+      for (int i = 0; i <= j; ++i) Hh(i, j) = hcol[i];
+      const double wn = hcol[j + 1].real();
+      Hh(j + 1, j) = wn;
+      if (wn < 1e-14) inner_conv = true;
+      else {
+        GM_RC(op_launch_axpby(n, 1.0 / wn, 0.0, vn, 0.0, 0.0, nullptr, V + (size_t)nv * n, st));
+        GM_RC(op_launch_axpby(n, 1.0 / wn, 0.0, q, 0.0, 0.0, nullptr, Z + (size_t)nv * n, st));
+        nv += 1;
+      }
+      for (int i = 0; i < j; ++i) {
+        const cplx tt = std::conj(cs[i]) * Hh(i, j) + std::conj(sn[i]) * Hh(i + 1, j);
+        Hh(i + 1, j) = cplx(0.0, 0.0) - sn[i] * Hh(i, j) + cs[i] * Hh(i + 1, j);
+        Hh(i, j) = tt;
+      }
+      cplx c, s_; givens(Hh(j, j), Hh(j + 1, j), &c, &s_);
+      cs[j] = c; sn[j] = s_;
+      Hh(j, j) = std::conj(c) * Hh(j, j) + std::conj(s_) * Hh(j + 1, j);
+      Hh(j + 1, j) = 0.0;
+      const cplx tt = std::conj(c) * g[j] + std::conj(s_) * g[j + 1];
+      g[j + 1] = cplx(0.0, 0.0) - s_ * g[j] + c * g[j + 1];
+      g[j] = tt;
+      rel = std::abs(g[j + 1]) / b_norm;
+      if (rel < tol || inner_conv) {
+        solve_upper(j + 1);
+        GM_RC(update_x(j + 1));
+        info->iterations = total; info->restarts = restarts; info->residual = rel; info->converged = 1;
+        finished = true; done = true; break;
+      }
+    }
+    if (finished) break;
+    solve_upper(m);
+    GM_RC(update_x(m));
+    restarts += 1;
+  }
+  if (!done) {
+    GM_RC(residual_into(q));
+    double rn = 0.0; GM_RC(norm_of(q, &rn));
+    info->iterations = total; info->restarts = restarts; info->residual = rn / b_norm; info->converged = 0;
+  }
+  GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost));
+  cleanup();
+#undef GM_HIP
+#undef GM_RC
+  return MA_OK;
+}
+// gmres_pipelined(operator, precond, b, x0, config): M may be NULL (IdentityPreconditioner)
+int ma_gmres_pipelined(ma_op_t* o, ma_precond_t* M, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol,
+                       ma_c64* x_out, ma_gmres_info_t* info) {
+  return gmres_pipelined_impl(o, M, b, x0, restart, max_iterations, tol, x_out, info);
+}
+
 int ma_gmres(ma_op_t* o, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info) {
   return gmres_impl(o, nullptr, b, x0, restart, max_iterations, tol, x_out, info);
 }

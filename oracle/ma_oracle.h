@@ -168,6 +168,14 @@ void mao_amg_apply(const mao_amg_hierarchy* H, const mao_c64* r, mao_c64* z);
 void mao_gmres_amg(const mao_amg_hierarchy* H, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
                    mao_c64* x, mao_gmres_info* info);
 
+/* gmres_pipelined (iterative/gmres_pipelined.rs:18-250): op_kind 0 dense / 1 CSR; pkind 0 identity, 1 Jacobi(omega, sweeps),
+ * 2 l1-Jacobi(sweeps) (CSR operators), the _amg form preconditions with the hierarchy's V-cycle */
+void mao_gmres_pipelined(int n, int op_kind, const mao_c64* dense, const long long* row_ptr, const long long* col, const mao_c64* val,
+                         int pkind, double omega, int sweeps, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
+                         mao_c64* x, mao_gmres_info* info);
+void mao_gmres_pipelined_amg(const mao_amg_hierarchy* H, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
+                             mao_c64* x, mao_gmres_info* info);
+
 /* ---- room-acoustics collocation assembly (room_acoustics/solver.rs:448-493) ---- */
 void mao_room_build_matrix(int n_elem, const double* center, const double* normal, const double* area,
                            double k, mao_c64* A, int nthreads);

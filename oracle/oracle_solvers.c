@@ -569,3 +569,115 @@ void mao_gmres_amg(const mao_amg_hierarchy* H, const mao_c64* b, const mao_c64* 
   mao_gmres_preconditioned(H->n[0], H->a_rp[0], H->a_col[0], H->a_val[0], 3, 0.0, 0, b, x0, restart, max_iterations, tol, x, info);
   g_amg = NULL;
 }
+
+/* ======================================================================
+ * gmres_pipelined — iterative/gmres_pipelined.rs:18-250 (p-GMRES, Ghysels et al.): auxiliary basis Z = M^-1 A V, the dot
+ * products of step j (classical Gram-Schmidt of z_j against v_0..v_j) are independent of q = M^-1 A z_j, which the reference
+ * computes concurrently (rayon::join, :106-119). op_kind 0 dense / 1 CSR; pkind 0 identity, 1 Jacobi, 2 l1-Jacobi (on a CSR
+ * operator), 3 the AMG hierarchy of mao_gmres_pipelined_amg.
+ * ====================================================================== */
+void mao_gmres_pipelined(int n, int op_kind, const mao_c64* dense, const long long* rp, const long long* col, const mao_c64* val,
+                         int pkind, double omega, int sweeps, const mao_c64* b, const mao_c64* x0, int m, int max_it, double tol,
+                         mao_c64* x, mao_gmres_info* info) {
+  if (x0) memcpy(x, x0, sizeof(mao_c64) * (size_t)n); else memset(x, 0, sizeof(mao_c64) * (size_t)n);
+  mao_c64* V = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n * (size_t)(m + 1));
+  mao_c64* Z = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n * (size_t)(m + 1));
+  mao_c64* H = (mao_c64*)calloc((size_t)(m + 1) * (size_t)m, sizeof(mao_c64));
+  mao_c64* cs = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)m);
+  mao_c64* sn = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)m);
+  mao_c64* g = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)(m + 1));
+  mao_c64* t = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+  mao_c64* q = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+  mao_c64* vn = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)n);
+  mao_c64* y = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)m);
+#define HH(i, j) H[(size_t)(i) * (size_t)m + (size_t)(j)]
+  /* :40-48: r0 = M^-1 (b - A x0); b_norm = |r0| */
+  op_apply(n, op_kind, dense, rp, col, val, x, t);
+  for (int i = 0; i < n; ++i) t[i] = csub(b[i], t[i]);
+  precond_apply(n, rp, col, val, pkind, omega, sweeps, t, q);
+  const double bnorm = vnorm(n, q);
+  info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
+  int total = 0, restarts = 0, done = 0;
+  if (bnorm < 1e-15) done = 2;                                                     /* :52-60 */
+  for (int outer = 0; outer < max_it && !done; ++outer) {
+    op_apply(n, op_kind, dense, rp, col, val, x, t);                               /* :72-76 */
+    for (int i = 0; i < n; ++i) t[i] = csub(b[i], t[i]);
+    precond_apply(n, rp, col, val, pkind, omega, sweeps, t, V);
+    const double beta = vnorm(n, V);
+    double rel = beta / bnorm;
+    if (rel < tol) { info->iterations = total; info->restarts = restarts; info->residual = rel; done = 1; break; }
+    { const mao_c64 ib = C(1.0 / beta, 0.0); for (int i = 0; i < n; ++i) V[i] = cmul(V[i], ib); }     /* :93 */
+    op_apply(n, op_kind, dense, rp, col, val, V, t);                               /* :96-97 z0 = M^-1 A v0 */
+    precond_apply(n, rp, col, val, pkind, omega, sweeps, t, Z);
+    memset(H, 0, sizeof(mao_c64) * (size_t)(m + 1) * (size_t)m);
+    memset(g, 0, sizeof(mao_c64) * (size_t)(m + 1));
+    g[0] = C(beta, 0.0);
+    int nv = 1, inner_conv = 0, finished = 0;
+    for (int j = 0; j < m; ++j) {
+      total += 1;
+      const mao_c64* zj = Z + (size_t)j * n;
+      op_apply(n, op_kind, dense, rp, col, val, zj, t);                            /* :107-110 q = M^-1 A z_j */
+      precond_apply(n, rp, col, val, pkind, omega, sweeps, t, q);
+      for (int i = 0; i <= j; ++i) HH(i, j) = inner(n, V + (size_t)i * n, zj);     /* :111-118 */
+      memcpy(vn, zj, sizeof(mao_c64) * (size_t)n);                                 /* :129-136 */
+      for (int i = 0; i <= j; ++i) {
+        const mao_c64 f = HH(i, j); const mao_c64* vi = V + (size_t)i * n; const mao_c64* zi = Z + (size_t)i * n;
+        for (int p = 0; p < n; ++p) { vn[p] = csub(vn[p], cmul(vi[p], f)); q[p] = csub(q[p], cmul(zi[p], f)); }
+      }
+      const double nrm = vnorm(n, vn);                                             /* :139-140 */
+      HH(j + 1, j) = C(nrm, 0.0);
+      if (nrm < 1e-14) inner_conv = 1;                                             /* :143-151 */
+      else {
+        const mao_c64 in = C(1.0 / nrm, 0.0);
+        mao_c64* vp = V + (size_t)nv * n; mao_c64* zp = Z + (size_t)nv * n;
+        for (int p = 0; p < n; ++p) { vp[p] = cmul(vn[p], in); zp[p] = cmul(q[p], in); }
+        nv += 1;
+      }
+      for (int i = 0; i < j; ++i) {                                                /* :154-158 */
+        mao_c64 tt = cadd(cmul(cconj(cs[i]), HH(i, j)), cmul(cconj(sn[i]), HH(i + 1, j)));
+        HH(i + 1, j) = cadd(csub(C(0.0, 0.0), cmul(sn[i], HH(i, j))), cmul(cs[i], HH(i + 1, j)));
+        HH(i, j) = tt;
+      }
+      mao_c64 c, s2; givens(HH(j, j), HH(j + 1, j), &c, &s2);
+      cs[j] = c; sn[j] = s2;
+      HH(j, j) = cadd(cmul(cconj(c), HH(j, j)), cmul(cconj(s2), HH(j + 1, j)));
+      HH(j + 1, j) = C(0.0, 0.0);
+      mao_c64 tt = cadd(cmul(cconj(c), g[j]), cmul(cconj(s2), g[j + 1]));
+      g[j + 1] = cadd(csub(C(0.0, 0.0), cmul(s2, g[j])), cmul(c, g[j + 1]));
+      g[j] = tt;
+      rel = cnorm(g[j + 1]) / bnorm;
+      if (rel < tol || inner_conv) {                                               /* :181-195 */
+        const int kk = j + 1;
+        for (int i = kk - 1; i >= 0; --i) {
+          mao_c64 sum = g[i];
+          for (int p = i + 1; p < kk; ++p) sum = csub(sum, cmul(HH(i, p), y[p]));
+          y[i] = cnorm(HH(i, i)) > 1e-30 ? cmul(sum, cinv(HH(i, i))) : C(0.0, 0.0);
+        }
+        for (int i = 0; i < kk; ++i) axpy(n, y[i], V + (size_t)i * n, x);
+        info->iterations = total; info->restarts = restarts; info->residual = rel; finished = 1; done = 1; break;
+      }
+    }
+    if (finished) break;
+    for (int i = m - 1; i >= 0; --i) {                                             /* :199-203 */
+      mao_c64 sum = g[i];
+      for (int p = i + 1; p < m; ++p) sum = csub(sum, cmul(HH(i, p), y[p]));
+      y[i] = cnorm(HH(i, i)) > 1e-30 ? cmul(sum, cinv(HH(i, i))) : C(0.0, 0.0);
+    }
+    for (int i = 0; i < m; ++i) axpy(n, y[i], V + (size_t)i * n, x);
+    restarts += 1;
+  }
+  if (!done) {                                                                     /* :207-219 */
+    op_apply(n, op_kind, dense, rp, col, val, x, t);
+    for (int i = 0; i < n; ++i) t[i] = csub(b[i], t[i]);
+    precond_apply(n, rp, col, val, pkind, omega, sweeps, t, q);
+    info->iterations = total; info->restarts = restarts; info->residual = vnorm(n, q) / bnorm; info->converged = 0;
+  }
+#undef HH
+  free(V); free(Z); free(H); free(cs); free(sn); free(g); free(t); free(q); free(vn); free(y);
+}
+void mao_gmres_pipelined_amg(const mao_amg_hierarchy* Hh, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
+                             mao_c64* x, mao_gmres_info* info) {
+  g_amg = Hh;
+  mao_gmres_pipelined(Hh->n[0], 1, NULL, Hh->a_rp[0], Hh->a_col[0], Hh->a_val[0], 3, 0.0, 0, b, x0, restart, max_iterations, tol, x, info);
+  g_amg = NULL;
+}

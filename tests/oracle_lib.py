@@ -458,3 +458,19 @@ class AmgHierarchy:
         x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
         lib().mao_gmres_amg(C.byref(self.s), _vp(b), _vp(x0a), restart, max_iterations, C.c_double(tol), _vp(x), C.byref(info))
         return x, info
+
+
+def gmres_pipelined(b, dense=None, csr=None, pkind=0, omega=2.0 / 3.0, sweeps=2, x0=None, restart=30, max_iterations=100, tol=1e-6):
+    """gmres_pipelined (iterative/gmres_pipelined.rs:18-250) on a dense or CSR operator."""
+    b = np.ascontiguousarray(b, dtype=np.complex128); n = len(b)
+    x = np.zeros(n, dtype=np.complex128); info = GmresInfo()
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    if dense is not None:
+        d = np.ascontiguousarray(dense, dtype=np.complex128)
+        lib().mao_gmres_pipelined(n, 0, _vp(d), None, None, None, pkind, C.c_double(omega), sweeps, _vp(b), _vp(x0a), restart, max_iterations,
+                                  C.c_double(tol), _vp(x), C.byref(info))
+    else:
+        rp, col, val = _csr_args(*csr)
+        lib().mao_gmres_pipelined(n, 1, None, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), pkind, C.c_double(omega), sweeps, _vp(b), _vp(x0a),
+                                  restart, max_iterations, C.c_double(tol), _vp(x), C.byref(info))
+    return x, info

@@ -314,3 +314,42 @@ def test_row_sharded_operator_inside_the_library(gpu, monkeypatch):
     with pytest.raises(ma.MaError) as e:
         ma.LinearOperator.tbem_multi(mesh, k, beta, [0, 0])
     assert e.value.status == ma.MA_ERR_INVALID
+
+
+def test_pipelined_gmres_on_the_device(gpu):
+    """gmres_pipelined (gmres_pipelined.rs:18-250): the reference's own 2 x 2 test (:258-285), a dense BEM system, and a CSR
+    operator with the Jacobi and the identity preconditioner, against the restatement: same iteration counts, same solution."""
+    A2 = np.array([[4.0, 1.0], [1.0, 3.0]], dtype=complex); b2 = np.array([1.0, 2.0], dtype=complex)
+    op = ma.LinearOperator.dense(A2)
+    x, info = ma.gmres_pipelined(op, b2, restart=10, max_iterations=100, tol=1e-10)
+    assert info.converged == 1 and np.linalg.norm(A2 @ x - b2) < 1e-8
+    op.close()
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+    mesh = to_ma_mesh(om)
+    A, _ = ma.assemble_tbem(mesh, k, beta)
+    b = ma.incident_rhs(om.center, om.normal, k, beta)
+    xr, ir = O.gmres_pipelined(b, dense=A, restart=30, max_iterations=10, tol=1e-8)
+    for op in (ma.LinearOperator.dense(A), ma.LinearOperator.tbem(ma.BemPlan(mesh), k, beta)):
+        x, info = ma.gmres_pipelined(op, b, restart=30, max_iterations=10, tol=1e-8)
+        assert info.converged == ir.converged == 1 and info.iterations == ir.iterations and info.restarts == ir.restarts
+        assert rel_l2(x, xr) <= 1e-8
+        Mp = ma.Preconditioner(op, kind="diagonal")
+        xd, idg = ma.gmres_pipelined(op, b, precond=Mp, restart=30, max_iterations=10, tol=1e-8)
+        assert idg.converged == 1 and np.linalg.norm(A @ xd - b) <= 1e-6 * np.linalg.norm(b)
+        Mp.close(); op.close()
+    nodes, rp, ci, K, M = fem.helmholtz_box(6, 5, 4)
+    vals = O.helmholtz_values(K, M, 0.4 + 0.05j) + 0.0
+    n = len(rp) - 1
+    vals = vals.copy(); diag_idx = np.array([np.nonzero(ci[rp[i]:rp[i + 1]] == i)[0][0] + rp[i] for i in range(n)]); vals[diag_idx] += 0.3
+    h = ma.CsrOperator(rp, ci, values=vals); opc = ma.LinearOperator.csr(h)
+    bb = _xvec(n)
+    for pk, pkind in ((None, 0), ("jacobi", 1)):
+        Mj = None if pk is None else ma.Preconditioner(h, kind="jacobi", omega=0.8, sweeps=2)
+        xo, io = O.gmres_pipelined(bb, csr=(rp, ci, vals), pkind=pkind, omega=0.8, sweeps=2, restart=30, max_iterations=20, tol=1e-9)
+        xg, ig = ma.gmres_pipelined(opc, bb, precond=Mj, restart=30, max_iterations=20, tol=1e-9)
+        assert ig.converged == io.converged == 1 and abs(ig.iterations - io.iterations) <= 1
+        assert rel_l2(xg, xo) <= 1e-7
+        if Mj is not None:
+            Mj.close()
+    opc.close(); h.close()

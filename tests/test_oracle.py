@@ -439,3 +439,48 @@ def test_room_path_restatement_consistency():
     p = O.room_field_pressure(c, nr, a, np.zeros(3, dtype=complex), src, np.array([2.0]), pts, k)
     rr = np.linalg.norm(pts[0] - src[0])
     assert abs(p[0] - 2.0 * np.exp(1j * k * rr) / (4 * np.pi * rr)) < 1e-15
+
+
+def test_amg_v_cycle_restatement_behaves_like_the_reference_tests():
+    """amg.rs:1220+ (test_amg_*): the preconditioner reduces the residual of a Poisson-like system, apply() of a zero vector is
+    zero, and a W-cycle is two V-cycles; F = V + V on the residual (amg.rs:1068-1103)."""
+    import scipy.sparse as sp
+    from amg_hierarchy import box_hierarchy, csr_triplet
+    from math_audio_amd import fem
+    nx, ny, nz = 8, 8, 4
+    nodes, rp, ci, K, M = fem.helmholtz_box(nx, ny, nz)
+    n = len(rp) - 1
+    A = (sp.csr_matrix((K + 0.2 * M, ci, rp), shape=(n, n))).astype(np.complex128)
+    levels = [{key: csr_triplet(l[key]) for key in l} for l in box_hierarchy(A, nx, ny, nz, 3)]
+    b = A @ (np.sin(0.1 * np.arange(n)) + 1j * np.cos(0.2 * np.arange(n)))
+    for sm in (0, 1, 2):
+        H = O.AmgHierarchy(levels, smoother=sm)
+        z = H.apply(b)
+        assert np.linalg.norm(b - A @ z) < 0.6 * np.linalg.norm(b)          # one V-cycle from zero is a contraction
+        assert np.abs(H.apply(np.zeros(n))).max() == 0.0
+    V = O.AmgHierarchy(levels, cycle=0); F = O.AmgHierarchy(levels, cycle=2)
+    z1 = V.apply(b)
+    assert np.allclose(F.apply(b), z1 + V.apply(b - A @ z1), rtol=1e-13, atol=0)
+    x, info = V.gmres(b, restart=30, max_iterations=5, tol=1e-8)
+    assert info.converged == 1 and info.iterations < 15 and np.linalg.norm(A @ x - b) < 1e-6 * np.linalg.norm(b)
+
+
+def test_pipelined_gmres_restatement():
+    """gmres_pipelined.rs:258-285 (test_pgmres_simple_solver): [[4,1],[1,3]] x = [1,2], restart 10, tol 1e-10 -> converged with
+    |Ax - b| < 1e-8; and on a larger well-conditioned system p-GMRES (classical Gram-Schmidt on Z = A V) reaches the solution
+    of the standard GMRES (modified Gram-Schmidt) within the tolerance, with the same iteration count."""
+    A = np.array([[4.0, 1.0], [1.0, 3.0]], dtype=complex); b = np.array([1.0, 2.0], dtype=complex)
+    x, info = O.gmres_pipelined(b, dense=A, restart=10, max_iterations=100, tol=1e-10)
+    assert info.converged == 1 and np.linalg.norm(A @ x - b) < 1e-8
+    rng = np.random.default_rng(2)
+    n = 150
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) + 40.0 * np.eye(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    xp, ip = O.gmres_pipelined(b, dense=A, restart=30, max_iterations=20, tol=1e-10)
+    xs, is_ = O.gmres(b, dense=A, restart=30, max_iterations=20, tol=1e-10)
+    assert ip.converged == 1 and is_.converged == 1 and abs(ip.iterations - is_.iterations) <= 1
+    assert np.linalg.norm(xp - xs) <= 1e-8 * np.linalg.norm(xs)
+    x0 = rng.standard_normal(n) + 0j
+    xg, ig = O.gmres_pipelined(b, dense=A, x0=x0, restart=30, max_iterations=20, tol=1e-10)
+    assert ig.converged == 1 and np.linalg.norm(A @ xg - b) <= 1e-8 * np.linalg.norm(b)
+    assert O.gmres_pipelined(np.zeros(5, dtype=complex), dense=np.eye(5, dtype=complex))[1].iterations == 0
