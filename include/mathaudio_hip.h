@@ -285,6 +285,29 @@ int ma_op_create_tbem(ma_bem_plan_t* plan, const ma_physics_t* physics, double b
  * the shards' contributions on devices[0] in shard order. The mesh is only borrowed during the call. */
 int ma_op_create_tbem_multi(const ma_mesh_t* mesh, const ma_physics_t* physics, double beta_re, double beta_im,
                             const int32_t* devices, int32_t ndev, ma_op_t** out);
+/* Single-level fast multipole operator A = [N] + [S][D][T].
+ * Replaces: build_slfmm_system(elements, nodes, clusters, physics, n_theta, n_phi, n_terms) -> SlfmmSystem and its
+ *           LinearOperator impl: apply = SlfmmSystem::matvec, apply_transpose = matvec_transpose
+ *           math-bem/src/core/assembly/slfmm.rs:417-470, 150-257, 262-376, 378-395 (callers: bem_solver.rs:371-392,
+ *           room_acoustics/solver.rs:754-1148); extract_near_field_matrix :104-132.
+ * Clusters are the caller's (the reference builds them with its octree, which stays on the host): per cluster its centre,
+ * its element indices, its near_clusters and far_clusters (types.rs:445-488) as offset / index lists. n_theta must be a
+ * tabulated Gauss-Legendre order (1..8, 10, 12, 16, 20). The near blocks are integrated by the TBEM kernels with
+ * compute_near_block's coefficient; the far field is the reference's (its D entry is h_0(k r) i k on the whole diagonal,
+ * slfmm.rs:707-710). Velocity-type boundary conditions, no evaluation elements, every element in at most one cluster. */
+typedef struct {
+  int32_t        n_clusters;
+  const double*  center;      /* n_clusters*3  Cluster.center                                   */
+  const int32_t* elem_ptr;    /* n_clusters+1  offsets into elem_idx                            */
+  const int32_t* elem_idx;    /*               Cluster.element_indices, cluster after cluster   */
+  const int32_t* near_ptr;    /* n_clusters+1 */
+  const int32_t* near_idx;    /*               Cluster.near_clusters                            */
+  const int32_t* far_ptr;     /* n_clusters+1 */
+  const int32_t* far_idx;     /*               Cluster.far_clusters                             */
+} ma_clusters_t;
+int ma_op_create_slfmm(ma_bem_plan_t* plan, const ma_clusters_t* clusters, const ma_physics_t* physics,
+                       int32_t n_theta, int32_t n_phi, int32_t n_terms, ma_op_t** out);
+int ma_op_slfmm_near_matrix(ma_op_t* op, ma_c64* A_rowmajor);
 /* number of shards of an operator (1 unless row-sharded) and, optionally, their first rows and devices */
 int ma_op_num_shards(const ma_op_t* op, int32_t* shards, int32_t* row_begin_or_null, int32_t* device_or_null);
 int ma_op_destroy(ma_op_t* op);

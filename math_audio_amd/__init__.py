@@ -38,6 +38,11 @@ class ma_mesh_t(C.Structure):
                 ("bc_type", C.c_void_p), ("bc_values", C.c_void_p), ("bc_len", C.c_void_p), ("is_eval", C.c_void_p)]
 
 
+class ma_clusters_t(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("center", C.c_void_p), ("elem_ptr", C.c_void_p), ("elem_idx", C.c_void_p),
+                ("near_ptr", C.c_void_p), ("near_idx", C.c_void_p), ("far_ptr", C.c_void_p), ("far_idx", C.c_void_p)]
+
+
 class ma_physics_t(C.Structure):
     _fields_ = [("wave_number", C.c_double), ("harmonic_factor", C.c_double), ("tau", C.c_double), ("gamma", C.c_double)]
 
@@ -129,6 +134,8 @@ def lib():
             "ma_op_create_tbem": [vp, P(ma_physics_t), dbl, dbl, i32, i32, P(vp)],
             "ma_op_create_tbem_multi": [P(ma_mesh_t), P(ma_physics_t), dbl, dbl, vp, i32, P(vp)],
             "ma_op_num_shards": [vp, P(i32), vp, vp],
+            "ma_op_create_slfmm": [vp, P(ma_clusters_t), P(ma_physics_t), i32, i32, i32, P(vp)],
+            "ma_op_slfmm_near_matrix": [vp, vp],
             "ma_op_destroy": [vp],
             "ma_op_num_rows": [vp, P(i64)],
             "ma_op_apply": [vp, vp, vp],
@@ -571,6 +578,24 @@ class LinearOperator:
         h = C.c_void_p()
         check(lib().ma_op_create_tbem_multi(C.byref(mesh.c), C.byref(ph), beta.real, beta.imag, _vp(dv), len(dv), C.byref(h)))
         return LinearOperator(h, mesh)
+
+    @staticmethod
+    def slfmm(plan, clusters, k, n_theta, n_phi, n_terms, harmonic=1.0, tau=1.0):
+        """ma_op_create_slfmm: build_slfmm_system + SlfmmSystem::matvec / matvec_transpose (assembly/slfmm.rs). `clusters` carries
+        center [nc, 3], elem_ptr / elem_idx, near_ptr / near_idx, far_ptr / far_idx (int32 arrays)."""
+        ph = physics(k, harmonic, tau)
+        arrs = [np.ascontiguousarray(clusters.center, dtype=np.float64)] + [np.ascontiguousarray(getattr(clusters, f), dtype=np.int32)
+                                                                           for f in ("elem_ptr", "elem_idx", "near_ptr", "near_idx", "far_ptr", "far_idx")]
+        cs = ma_clusters_t(len(arrs[1]) - 1, *[a.ctypes.data if a.size else None for a in arrs])
+        h = C.c_void_p()
+        check(lib().ma_op_create_slfmm(plan.h, C.byref(cs), C.byref(ph), int(n_theta), int(n_phi), int(n_terms), C.byref(h)))
+        return LinearOperator(h, (plan, arrs))
+
+    def slfmm_near_matrix(self):
+        """SlfmmSystem::extract_near_field_matrix (slfmm.rs:104-132)."""
+        A = np.empty((self.n, self.n), dtype=np.complex128)
+        check(lib().ma_op_slfmm_near_matrix(self.h, _vp(A)))
+        return A
 
     def shards(self):
         """(first rows, devices) of the operator's shards."""

@@ -1,6 +1,7 @@
 // op_plan.hip — the operator boundary (LinearOperator<Complex64>, math-solvers/src/traits.rs:316-327) and
 // restarted GMRES (math-solvers/src/iterative/gmres.rs:105-277) on the device.
 #include "op_kernels.hpp"
+#include "fmm_plan.hpp"
 #include "ma_tables.h"
 #include <vector>
 #include <algorithm>
@@ -49,6 +50,8 @@ struct ma_op {
   // kind 3: the shards (shards[0] lives on `device`, the home of every vector the callers pass), the event that says x is
   // ready on the caller's stream, and ndev x n partial results of a transposed apply gathered on the home device
   std::vector<OpShard> shards; hipEvent_t ev_home = nullptr; c64* d_tgather = nullptr;
+  // kind 4: the reference's single-level fast multipole operator (SlfmmSystem, assembly/slfmm.rs)
+  ma_slfmm* fmm = nullptr;
 };
 
 extern "C" int ma_op_destroy(ma_op_t* o);
@@ -65,6 +68,7 @@ void op_free(ma_op* o) {
   }
   o->shards.clear();
   (void)hipSetDevice(o->device);
+  if (o->fmm) { slfmm_destroy(o->fmm); o->fmm = nullptr; }
   if (o->ev_home) (void)hipEventDestroy(o->ev_home);
   if (o->d_tgather) (void)hipFree(o->d_tgather);
   if (o->own_A && o->dA) (void)hipFree(o->dA);
@@ -210,6 +214,30 @@ int ma_op_create_tbem_multi(const ma_mesh_t* mesh, const ma_physics_t* physics, 
   if (rc) return fail(rc);
   *out = o; return MA_OK;
 }
+// SlfmmSystem as a LinearOperator (slfmm.rs:378-395): build_slfmm_system(elements, nodes, clusters, physics, n_theta, n_phi, n_terms)
+// over the plan's mesh; apply = matvec, apply_transpose = matvec_transpose. The plan is borrowed.
+int ma_op_create_slfmm(ma_bem_plan_t* plan, const ma_clusters_t* clusters, const ma_physics_t* physics, int32_t n_theta, int32_t n_phi, int32_t n_terms, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(plan, MA_ERR_INVALID, "plan is NULL");
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 4; o->device = plan->device; o->n = plan->nd; o->plan = plan;
+  int rc = slfmm_create(plan, clusters, physics, n_theta, n_phi, n_terms, &o->fmm);
+  if (!rc) rc = op_stage(o);
+  if (rc) { op_free(o); delete o; return rc; }
+  *out = o; return MA_OK;
+}
+// SlfmmSystem::extract_near_field_matrix (slfmm.rs:104-132): [N] as a dense num_dofs x num_dofs matrix (host buffer, row-major)
+int ma_op_slfmm_near_matrix(ma_op_t* o, ma_c64* A_rowmajor) {
+  MA_REQUIRE(o && A_rowmajor && o->kind == 4 && o->fmm, MA_ERR_INVALID, "not a single-level FMM operator");
+  MA_HIP(hipSetDevice(o->device));
+  c64* dA = nullptr;
+  const size_t bytes = sizeof(c64) * (size_t)o->n * (size_t)o->n;
+  if (hipMalloc(&dA, bytes) != hipSuccess) { set_error("near-field matrix of %lld dofs does not fit the device", o->n); return MA_ERR_NOMEM; }
+  int rc = slfmm_near_matrix(o->fmm, dA, nullptr);
+  if (!rc && hipMemcpy(A_rowmajor, dA, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("copy back failed"); rc = MA_ERR_HIP; }
+  (void)hipFree(dA);
+  return rc;
+}
 int ma_op_num_shards(const ma_op_t* o, int32_t* shards, int32_t* row_begin_or_null, int32_t* device_or_null) {
   MA_REQUIRE(o && shards, MA_ERR_INVALID, "NULL argument");
   *shards = o->kind == 3 ? (int32_t)o->shards.size() : 1;
@@ -276,6 +304,7 @@ int ma_op_apply_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) {
   MA_HIP(hipSetDevice(o->device));
   hipStream_t st = (hipStream_t)stream;
   if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, 0, st);
+  if (o->kind == 4) return slfmm_apply(o->fmm, (const c64*)d_x, (c64*)d_y, 0, st);
   if (o->kind == 0) return op_launch_zgemv(o->n, o->dA, (const c64*)d_x, (c64*)d_y, st);
   if (o->kind == 1) return ma_csr_spmv_dev(o->csr, d_x, d_y, stream);
   return op_launch_tbem_matvec(o->plan->geom, o->ph, o->row0, o->row1, o->nchunks, (const c64*)d_x, o->d_partial, o->plan->d_pair_off,
@@ -321,6 +350,18 @@ static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStre
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(o->device));
   if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, herm ? 2 : 1, st);
+  if (o->kind == 4) {                                    // matvec_transpose (slfmm.rs:262-376); hermitian = conj(A^T conj(x)) (traits.rs:340-358)
+    const c64* xin = (const c64*)d_x;
+    int rc = MA_OK;
+    if (herm) {
+      if (!o->d_cx) MA_HIP(hipMalloc(&o->d_cx, sizeof(c64) * (size_t)o->n));
+      rc = op_launch_conj(o->n, xin, o->d_cx, st); if (rc) return rc;
+      xin = o->d_cx;
+    }
+    rc = slfmm_apply(o->fmm, xin, (c64*)d_y, 1, st);
+    if (!rc && herm) rc = op_launch_conj(o->n, (const c64*)d_y, (c64*)d_y, st);
+    return rc;
+  }
   if (o->kind == 2) {
     // streamed like apply, with the loop nest turned around (lane = field panel). A row-sharded operator returns its
     // rows' contribution to every entry of y: the shards' results add up (the caller's all-reduce).
@@ -447,6 +488,7 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
   MA_REQUIRE(op, MA_ERR_INVALID, "operator is NULL");
   if (op->kind == 1) return ma_precond_create_jacobi(op->csr, 1.0, 1, out);
   if (op->kind == 3) return ma_precond_create_diagonal(op->shards[0].op, out);    // the home shard's plan holds every panel
+  MA_REQUIRE(op->kind != 4, MA_ERR_UNSUPPORTED, "diagonal preconditioner of a fast multipole operator: take the diagonal of ma_op_slfmm_near_matrix");
   MA_HIP(hipSetDevice(op->device));
   ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
   M->kind = 4; M->n = op->n; M->device = op->device;

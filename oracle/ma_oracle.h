@@ -176,6 +176,19 @@ void mao_gmres_pipelined(int n, int op_kind, const mao_c64* dense, const long lo
 void mao_gmres_pipelined_amg(const mao_amg_hierarchy* H, const mao_c64* b, const mao_c64* x0, int restart, int max_iterations, double tol,
                              mao_c64* x, mao_gmres_info* info);
 
+/* ---- single-level fast multipole operator (assembly/slfmm.rs): build_slfmm_system + SlfmmSystem::matvec / matvec_transpose /
+ * extract_near_field_matrix. Clusters arrive as CSR-style lists (element_indices, near_clusters, far_clusters, centres). */
+typedef struct mao_slfmm mao_slfmm;
+void mao_spherical_hankel_first_kind(int order, double x, double harmonic, mao_c64* result);
+int mao_unit_sphere_quadrature(int n_theta, int n_phi, double* coords, double* weights);
+mao_slfmm* mao_slfmm_build(int n_elem, const double* nodes, const int* conn, const double* center, const double* normal, const double* area,
+                           const int* dof, const unsigned char* bc_type, int n_clusters, const double* cluster_center, const int* elem_ptr, const int* elem_idx,
+                           const int* near_ptr, const int* near_idx, const int* far_ptr, const int* far_idx,
+                           double k, double harmonic, double tau, int n_theta, int n_phi, int n_terms);
+void mao_slfmm_free(mao_slfmm* S);
+void mao_slfmm_matvec(const mao_slfmm* S, int transpose, const mao_c64* x, mao_c64* y);
+void mao_slfmm_near_matrix(const mao_slfmm* S, mao_c64* A);
+
 /* ---- room-acoustics collocation assembly (room_acoustics/solver.rs:448-493) ---- */
 void mao_room_build_matrix(int n_elem, const double* center, const double* normal, const double* area,
                            double k, mao_c64* A, int nthreads);

@@ -474,3 +474,48 @@ def gmres_pipelined(b, dense=None, csr=None, pkind=0, omega=2.0 / 3.0, sweeps=2,
         lib().mao_gmres_pipelined(n, 1, None, _p(rp, C.c_longlong), _p(col, C.c_longlong), _vp(val), pkind, C.c_double(omega), sweeps, _vp(b), _vp(x0a),
                                   restart, max_iterations, C.c_double(tol), _vp(x), C.byref(info))
     return x, info
+
+
+# ---------------------------------------------------------------- single-level FMM operator (assembly/slfmm.rs)
+class Slfmm:
+    """build_slfmm_system(elements, nodes, clusters, physics, n_theta, n_phi, n_terms) + matvec / matvec_transpose."""
+
+    def __init__(self, mesh, clusters, k, n_theta, n_phi, n_terms, harmonic=1.0, tau=1.0):
+        L = lib()
+        L.mao_slfmm_build.restype = C.c_void_p
+        cl = clusters
+        self.n = mesh.n_elem
+        self.h = C.c_void_p(L.mao_slfmm_build(
+            mesh.n_elem, _p(mesh.nodes), _p(mesh.conn, C.c_int), _p(mesh.center), _p(mesh.normal), _p(mesh.area), _p(mesh.dof, C.c_int),
+            _p(mesh.bc_type, C.c_ubyte), cl.n, _p(cl.center), _p(cl.elem_ptr, C.c_int), _p(cl.elem_idx, C.c_int), _p(cl.near_ptr, C.c_int),
+            _p(cl.near_idx, C.c_int), _p(cl.far_ptr, C.c_int), _p(cl.far_idx, C.c_int), C.c_double(k), C.c_double(harmonic), C.c_double(tau),
+            n_theta, n_phi, n_terms))
+
+    def matvec(self, x, transpose=False):
+        x = np.ascontiguousarray(x, dtype=np.complex128); y = np.zeros(self.n, dtype=np.complex128)
+        lib().mao_slfmm_matvec(self.h, 1 if transpose else 0, _vp(x), _vp(y))
+        return y
+
+    def near_matrix(self):
+        A = np.zeros((self.n, self.n), dtype=np.complex128)
+        lib().mao_slfmm_near_matrix(self.h, _vp(A))
+        return A
+
+    def __del__(self):
+        try:
+            lib().mao_slfmm_free(self.h)
+        except Exception:
+            pass
+
+
+def spherical_hankel_first_kind(order, x, harmonic=1.0):
+    out = np.zeros(order, dtype=np.complex128)
+    lib().mao_spherical_hankel_first_kind(order, C.c_double(x), C.c_double(harmonic), _vp(out))
+    return out
+
+
+def unit_sphere_quadrature(n_theta, n_phi):
+    c = np.zeros((4 * n_theta * n_phi, 3)); w = np.zeros(4 * n_theta * n_phi)
+    lib().mao_unit_sphere_quadrature.restype = C.c_int
+    n = lib().mao_unit_sphere_quadrature(n_theta, n_phi, _p(c), _p(w))
+    return c[:n].copy(), w[:n].copy()

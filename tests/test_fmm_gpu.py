@@ -1,0 +1,75 @@
+"""GPU parity of the single-level fast multipole operator (math-bem/src/core/assembly/slfmm.rs: build_slfmm_system, SlfmmSystem::
+matvec / matvec_transpose / extract_near_field_matrix) against the CPU restatement, on the sphere of the QA suite and on the
+box of BASELINE.json configs[4]; the checks math-bem/tests/test_fmm_validation.rs makes (operator vs assembled matrix on
+x_i = sin(0.1 i) + i cos(0.2 i), :103-130) are made against the reference's own near-field matrix, which is what a single
+cluster reduces the operator to."""
+import numpy as np
+import pytest
+import oracle_lib as O
+import math_audio_amd as ma
+from math_audio_amd import mesh as mm
+from helpers import to_ma_mesh, k_from_ka, RADIUS, rel_l2
+from fmm_clusters import grid_clusters
+
+pytestmark = pytest.mark.gpu
+
+
+def _xvec(n):
+    i = np.arange(n)
+    return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
+
+
+@pytest.mark.parametrize("sub,ka,cell,nt,nphi", [(2, 1.0, 0.07, 4, 8), (3, 3.0, 0.05, 6, 12), (2, 0.2, 10.0, 4, 8)])
+def test_slfmm_operator_matches_the_restatement(gpu, sub, ka, cell, nt, nphi):
+    om = O.icosphere(RADIUS, sub)
+    k = k_from_ka(ka)
+    cl = grid_clusters(om.center, cell)
+    ref = O.Slfmm(om, cl, k, nt, nphi, 5)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    op = ma.LinearOperator.slfmm(plan, cl, k, nt, nphi, 5)
+    n = om.n_elem
+    N_ref = ref.near_matrix(); N = op.slfmm_near_matrix()
+    scale = np.abs(N_ref).max(axis=1, keepdims=True)
+    assert (np.abs(N - N_ref) / scale).max() <= 1e-9                    # blocks integrated by the TBEM near / self kernels
+    for x in (_xvec(n), np.ones(n, dtype=complex)):
+        y = op.apply(x); yr = ref.matvec(x)
+        assert np.abs(y - yr).max() <= 1e-10 * np.abs(yr).max()
+        yt = op.apply_transpose(x); ytr = ref.matvec(x, transpose=True)
+        assert np.abs(yt - ytr).max() <= 1e-10 * np.abs(ytr).max()
+        assert np.abs(op.apply_hermitian(x) - np.conj(ref.matvec(np.conj(x), transpose=True))).max() <= 1e-10 * np.abs(ytr).max()
+    if cl.n == 1:                                                       # bem_solver.rs:375-381: one cluster holding everything: A = [N]
+        assert np.abs(op.apply(_xvec(n)) - N_ref @ _xvec(n)).max() <= 1e-10 * np.abs(N_ref @ _xvec(n)).max()
+    # the far field is a genuine contribution when clusters are apart
+    if cl.n > 1:
+        assert np.abs(ref.matvec(_xvec(n)) - N_ref @ _xvec(n)).max() > 1e-6 * np.abs(N_ref @ _xvec(n)).max()
+    # GMRES through the LinearOperator boundary (SlfmmSystem implements LinearOperator, slfmm.rs:378-395)
+    b = ma.incident_rhs(om.center, om.normal, k, complex(0.0, 1.0 / k))
+    xg, info = ma.gmres(op, b, restart=30, max_iterations=5, tol=1e-6)
+    y = ref.matvec(xg)
+    assert info.converged == 0 or np.linalg.norm(y - b) <= 1e-4 * np.linalg.norm(b)
+    op.close(); plan.close()
+
+
+def test_slfmm_on_the_box_and_input_validation(gpu):
+    m = mm.generate_box_mesh(0.30, 0.40, 0.60, 5, 6, 9)
+    om = O.Mesh(m.nodes, m.conn)
+    k = mm.wave_number(1000.0)
+    cl = grid_clusters(om.center, 0.12)
+    assert cl.n > 20
+    ref = O.Slfmm(om, cl, k, 8, 16, 6)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    op = ma.LinearOperator.slfmm(plan, cl, k, 8, 16, 6)
+    x = _xvec(om.n_elem)
+    yr = ref.matvec(x)
+    assert np.abs(op.apply(x) - yr).max() <= 1e-10 * np.abs(yr).max()
+    ytr = ref.matvec(x, transpose=True)
+    assert np.abs(op.apply_transpose(x) - ytr).max() <= 1e-10 * np.abs(ytr).max()
+    op.close()
+    with pytest.raises(ma.MaError) as e:                               # 9 is not a tabulated Gauss-Legendre order (gauss.rs:27-60)
+        ma.LinearOperator.slfmm(plan, cl, k, 9, 16, 6)
+    assert e.value.status == ma.MA_ERR_INVALID
+    bad = grid_clusters(om.center, 0.12); bad.elem_idx = bad.elem_idx.copy(); bad.elem_idx[1] = bad.elem_idx[0]
+    with pytest.raises(ma.MaError) as e:
+        ma.LinearOperator.slfmm(plan, bad, k, 4, 8, 5)
+    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    plan.close()

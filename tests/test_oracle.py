@@ -484,3 +484,35 @@ def test_pipelined_gmres_restatement():
     xg, ig = O.gmres_pipelined(b, dense=A, x0=x0, restart=30, max_iterations=20, tol=1e-10)
     assert ig.converged == 1 and np.linalg.norm(A @ xg - b) <= 1e-8 * np.linalg.norm(b)
     assert O.gmres_pipelined(np.zeros(5, dtype=complex), dense=np.eye(5, dtype=complex))[1].iterations == 0
+
+
+def test_slfmm_restatement_known_answers():
+    """slfmm.rs tests (:790-877): system sizes (test_slfmm_system_creation / test_build_slfmm_system: 2 dofs, one T and S matrix),
+    near block 2 x 2 with non-zero diagonal (test_near_field_block); plus what pins the ingredients: spherical_hankel_first_kind
+    against SciPy, the sphere rule's weights summing to 1, <A x, z> = <x, A^T z> for matvec / matvec_transpose, and the single
+    cluster of bem_solver.rs:375-381 reducing the operator to its near-field matrix."""
+    import scipy.special as ss
+    from fmm_clusters import Clusters, grid_clusters
+    for x in (0.3, 2.0, 17.5):
+        h = O.spherical_hankel_first_kind(6, x)
+        ref = np.array([ss.spherical_jn(n, x) + 1j * ss.spherical_yn(n, x) for n in range(6)])
+        assert np.abs(h - ref).max() <= 1e-10 * np.abs(ref).max()
+    c, w = O.unit_sphere_quadrature(4, 8)
+    assert len(w) == 32 and abs(w.sum() - 1.0) < 1e-14 and np.abs(np.linalg.norm(c, axis=1) - 1.0).max() < 1e-15
+    nodes = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.5, 1.0, 0.0], [1.5, 1.0, 0.0]])          # slfmm.rs:801-841
+    conn = np.array([[0, 1, 2, -1], [1, 3, 2, -1]], dtype=np.int32)
+    om = O.Mesh(nodes, conn)
+    one = Clusters([[0.5, 0.5, 0.0]], [0, 2], [0, 1], [0, 0], [], [0, 0], [])
+    k = O.wave_number(100.0, 343.0)
+    S = O.Slfmm(om, one, k, 4, 8, 5)
+    N = S.near_matrix()
+    assert N.shape == (2, 2) and abs(N[0, 0]) > 0.0 and abs(N[1, 1]) > 0.0
+    sph = O.icosphere(RADIUS, 2)
+    cl = grid_clusters(sph.center, 0.07)
+    F = O.Slfmm(sph, cl, 10.0, 4, 8, 5)
+    n = sph.n_elem
+    x = np.sin(0.1 * np.arange(n)) + 1j * np.cos(0.2 * np.arange(n)); z = np.cos(0.3 * np.arange(n)) + 0.5j
+    assert abs((F.matvec(x) * z).sum() - (x * F.matvec(z, transpose=True)).sum()) <= 1e-12 * abs((F.matvec(x) * z).sum())
+    whole = grid_clusters(sph.center, 10.0)
+    W = O.Slfmm(sph, whole, 10.0, 4, 8, 5)
+    assert whole.n == 1 and np.abs(W.matvec(x) - W.near_matrix() @ x).max() <= 1e-12 * np.abs(W.matvec(x)).max()
