@@ -137,3 +137,22 @@ def test_incident_evaluate_and_total_field(gpu):
     assert np.abs(pi - np.exp(1j * k * ep[:, 2])).max() <= 1e-13
     assert np.abs(psc - O.compute_scattered_field(ep, om, ps, k)).max() <= 1e-12 * np.abs(psc).max()
     plan.close()
+
+
+def test_room_config_json_feeds_the_room_path(gpu):
+    """RoomConfig JSON (math-xem-common/src/config.rs:583-604) -> RectangularRoom::generate_mesh -> the room-acoustics
+    collocation path on the device, against the restatement: the reference's example_rectangular.json at its first frequency."""
+    import os
+    from math_audio_amd import io as mio
+    cfg = mio.RoomConfig.from_file(os.path.join(os.path.dirname(__file__), "golden", "room_example_rectangular.json"))
+    nodes, conn = cfg.generate_mesh()
+    k = 2.0 * np.pi * cfg.generate_frequencies()[0] / 343.0
+    c, nr, a, cl = ma.room_element_data(nodes, conn)
+    c0, n0, a0, l0 = O.room_element_data(nodes, conn)
+    assert np.array_equal(c, c0) and np.array_equal(nr, n0) and np.array_equal(a, a0) and np.array_equal(cl, l0)
+    A = ma.room_build_matrix(c, nr, a, k)
+    Ar = O.room_build_matrix(c0, n0, a0, k, nthreads=8)
+    assert np.abs(A - Ar).max() <= 1e-12 * np.abs(Ar).max()
+    src = np.array([cfg.sources[0]["position"]]); amp = np.array([cfg.sources[0]["amplitude"]])
+    rhs = ma.room_incident_derivative(c, nr, src, amp, k)
+    assert np.abs(rhs - O.room_incident_derivative(c0, n0, src, amp, k)).max() <= 1e-13 * np.abs(rhs).max()
