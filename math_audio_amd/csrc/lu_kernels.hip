@@ -408,6 +408,252 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
   }
 }
 
+// ------------------------------------------------------------------ panel factorisation of several systems, a wavefront each
+// The systems of a lock-step batch (frequencies of a sweep: same n, same panel) share ONE co-resident grid. A first form walked
+// the systems one after the other inside the workgroup (all four wavefronts on one system's column step, then the next system):
+// measured, it LOSES (0.63 ms per 32 columns of three systems = 6.6 us per system column against 5.8 alone; 99.9 ms per
+// frequency against 63.1 with a panel kernel per system) -- with the exchange hidden, the bulk rank-1 update that the
+// single-system kernel tucks under the exchange wait lands on the critical path of every step, and the steps' own memory
+// round trips (pivot-row fetch, write-through publish) are paid system after system.
+// Here every system of the batch has its OWN wavefront in the workgroup (<= 64 rows per workgroup: lane = row): the wavefront
+// runs the whole column step for its system -- poll, fetch, interchange, multipliers, next candidate, publish, rank-1 update
+// -- with no workgroup barrier anywhere, so the systems' chains advance independently and their latencies overlap on the
+// CU's SIMDs; one co-resident grid instead of nsys grids that slow each other down, and the per-system arithmetic (and
+// therefore every pivot, factor and solution) is the single-system kernel's at the same panel width.
+struct LuPanelBatch { int nsys; dc* A[LU_BATCH_MAX]; int* ipiv[LU_BATCH_MAX]; LuPanelWs ws[LU_BATCH_MAX]; };
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, int n, int k0, int nb, int rpb, unsigned sys_lds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int pitch = nb + 1;
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int sy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // this wavefront's system
+  const int b = blockIdx.x, nblk = gridDim.x;
+  const int r0 = k0 + b * rpb;
+  const int nrows = min(rpb, n - r0);                    // <= 64: lane = row
+  const int myrow = r0 + lane;
+  const int g_ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
+  const int g_grp = b % g_ngrp;
+  const int g_per = (nblk - g_grp + g_ngrp - 1) / g_ngrp;
+  const bool lead = b == g_grp + (g_per - 1) * g_ngrp;
+  const LuPanelWs ws = B.ws[sy];
+  dc* __restrict__ A = B.A[sy];
+  int* __restrict__ ipiv = B.ipiv[sy];
+  unsigned* const poison = ws.timeout;
+
+  dc* const P = reinterpret_cast<dc*>(smem + (size_t)sy * sys_lds);
+  dc* const urow_a = P + (size_t)rpb * pitch;
+  dc* const urow_b = urow_a + nb;
+  dc* const drow = urow_b + nb;
+
+  for (int idx = lane; idx < nrows * nb; idx += 64) {
+    int rr = idx / nb, j = idx - rr * nb;
+    P[rr * pitch + j] = A[(size_t)(r0 + rr) * n + k0 + j];
+  }
+  if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(poison, RLX_AGENT)) != 0) {
+    if (b == 0) for (int j = lane; j < nb; j += 64) ipiv[k0 + j] = k0 + j;
+    return;
+  }
+  wave_sync_lds();
+
+  // candidate of a column from a per-lane magnitude: top 32 bits compared, ties to the lowest row (= lowest lane)
+  auto pick = [=](bool valid, double mag, int* row_out, double* val_out) {
+    const unsigned hi = valid ? (unsigned)((u64)__double_as_longlong(mag) >> 32) : 0u;
+    const unsigned m = wave_umax(hi);
+    const u64 mask = __ballot(valid && hi == m);
+    *row_out = mask ? r0 + (int)__builtin_ctzll(mask) : INT_MAX;
+    *val_out = __longlong_as_double((long long)((u64)m << 32));
+  };
+  auto publish = [&](int col, int br, double bv) {
+    const int buf = col & 1;
+    const int gd = k0 + col;
+    const bool own_diag = gd >= r0 && gd < r0 + nrows;
+    if (br != INT_MAX) {
+      const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
+      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
+      for (int t = lane; t < 2 * nb; t += 64) st_sc1(dst + t, src[t]);
+    }
+    if (own_diag) {
+      const double* src = reinterpret_cast<const double*>(P + (size_t)(gd - r0) * pitch);
+      u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+      for (int t = lane; t < 2 * nb; t += 64) st_sc1(dst + t, src[t]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the payload is out before the granule says so
+    if (lane == 0) {
+      const u64 hi = br != INT_MAX ? ((u64)__double_as_longlong(bv) >> 32) : 0ull;
+      const u64 lo = ((u64)(unsigned)(col + 1) << 24) | (u64)(br != INT_MAX ? (unsigned)br : 0xFFFFFFu);
+      __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE, (hi << 32) | lo, RLX_AGENT);
+    }
+  };
+  auto leader_gather = [&](int col) {
+    const int buf = col & 1;
+    const unsigned want = (unsigned)(col + 1);
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    const u64* mbase = ws.cand + ((size_t)buf * ws.max_blocks + g_grp) * LU_GRANULE_STRIDE;
+    unsigned bhi = 0, brow = 0xFFFFFFu; bool fail = false;
+    for (;;) {
+      bool ok = true; bhi = 0; brow = 0xFFFFFFu;
+      unsigned ab = 0u;
+      if (lane < g_per) {
+        const u64 g = __hip_atomic_load(mbase + (size_t)lane * g_ngrp * LU_GRANULE_STRIDE, RLX_AGENT);
+        ok = ((unsigned)(g >> 24) & 0xFFu) == want;
+        bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
+      } else if (lane == 63) ab = __hip_atomic_load(poison, RLX_AGENT);
+      if (__all(ok)) break;
+      if (__any(ab != 0u)) { fail = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
+      if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
+    }
+    if (lane == 0 && !fail)
+      __hip_atomic_store(ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS + g_grp) * LU_GRANULE_STRIDE,
+                         ((u64)bhi << 32) | ((u64)want << 24) | (u64)brow, RLX_AGENT);
+  };
+
+  {
+    int br; double bv;
+    // column 0: the full-magnitude comparison of lu_panel_kernel's scan_column (cand_better), lowest row on ties
+    PanelCand cd; cd.v = -1.0; cd.row = INT_MAX;
+    if (lane < nrows && myrow >= k0) { cd.v = cabs1(P[lane * pitch]); cd.row = myrow; }
+    cd = wave_best(cd);
+    br = __builtin_amdgcn_readfirstlane(cd.row); bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cd.v)), __builtin_amdgcn_readfirstlane(__double2loint(cd.v)));
+    publish(0, br, bv);
+    if (lead) leader_gather(0);
+  }
+
+  bool pending = false;
+  for (int c = 0; c < nb; ++c) {
+    const int gc = k0 + c;
+    const int buf = c & 1;
+    int p, wb; bool fail = false;
+    {
+      const unsigned want = (unsigned)(c + 1);
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      const int ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
+      unsigned bhi = 0, brow = 0xFFFFFFu;
+      const u64* gbase = ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS) * LU_GRANULE_STRIDE;
+      if (gc == ws.test_abort_col && b == nblk - 1 && sy == B.nsys - 1) fail = true;
+      while (!fail) {
+        bool ok = true; bhi = 0; brow = 0xFFFFFFu;
+        unsigned ab = 0u;
+        if (lane < ngrp) {
+          const u64 g = __hip_atomic_load(gbase + (size_t)lane * LU_GRANULE_STRIDE, RLX_AGENT);
+          ok = ((unsigned)(g >> 24) & 0xFFu) == want;
+          bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
+        } else if (lane == 63) ab = __hip_atomic_load(poison, RLX_AGENT);
+        if (__all(ok)) break;
+        if (__any(ab != 0u)) { fail = true; break; }
+        __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;
+      }
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) {
+        const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
+        if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
+      }
+      const unsigned best = (unsigned)__builtin_amdgcn_readfirstlane((int)brow);
+      if (fail) {                                         // this system's chain gives up: poison the plan, identity pivots for what is left
+        if (lane == 0) __hip_atomic_store(poison, 1u, RLX_AGENT);
+        if (b == 0) for (int j = c + lane; j < nb; j += 64) ipiv[k0 + j] = k0 + j;
+        return;                                           // the other wavefronts (systems) meet the word in their next poll
+      }
+      if (best >= (unsigned)n || best < (unsigned)gc) { p = gc; wb = -1; if (b == 0 && lane == 0) atomicCAS(ws.info, 0, gc + 1); }
+      else { p = (int)best; wb = (p - k0) / rpb; }
+    }
+    // ---- fetch the pivot row (and the displaced diagonal row); finish the previous column's pending update on them
+    dc* urow = (c & 1) ? urow_b : urow_a;
+    const dc* uprev = (c & 1) ? urow_a : urow_b;
+    {
+      const u64* src = wb >= 0 ? ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX) : ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+      const u64* s2 = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
+      for (int j = lane; j < nb; j += 64) {
+        dc v = dc_make(ld_sc1(src + 2 * j), ld_sc1(src + 2 * j + 1));
+        dc d = dc_make(0.0, 0.0);
+        if (p != gc) d = dc_make(ld_sc1(s2 + 2 * j), ld_sc1(s2 + 2 * j + 1));
+        if (pending && j > c) {
+          const dc u = uprev[j];
+          const dc lv = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
+          v.re -= lv.re * u.re - lv.im * u.im; v.im -= lv.re * u.im + lv.im * u.re;
+          if (p != gc) {
+            const dc ld = dc_make(ld_sc1(s2 + 2 * (c - 1)), ld_sc1(s2 + 2 * (c - 1) + 1));
+            d.re -= ld.re * u.re - ld.im * u.im; d.im -= ld.re * u.im + ld.im * u.re;
+          }
+        }
+        urow[j] = v;
+        if (p != gc) drow[j] = d;
+      }
+    }
+    wave_sync_lds();
+    // ---- interchange inside the panel
+    if (p != gc && p >= r0 && p < r0 + nrows) for (int t = lane; t < nb; t += 64) P[(size_t)(p - r0) * pitch + t] = drow[t];
+    if (gc >= r0 && gc < r0 + nrows) for (int t = lane; t < nb; t += 64) P[(size_t)(gc - r0) * pitch + t] = urow[t];
+    if (b == 0 && lane == 0) ipiv[gc] = p;
+    const dc piv = urow[c];
+    const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
+    if (singular && b == 0 && lane == 0) atomicCAS(ws.info, 0, gc + 1);
+    wave_sync_lds();
+    // ---- multipliers and the update of column c+1
+    const bool more = c + 1 < nb;
+    const bool below = lane < nrows && myrow > gc;
+    dc l = dc_make(0.0, 0.0), anext = dc_make(0.0, 0.0);
+    if (below) {
+      if (more) anext = P[lane * pitch + c + 1];
+      if (!singular) {
+        l = P[lane * pitch + c] * crecip(piv);
+        P[lane * pitch + c] = l;
+        if (more) {
+          const dc u = urow[c + 1];
+          anext.re -= l.re * u.re - l.im * u.im; anext.im -= l.re * u.im + l.im * u.re;
+          P[lane * pitch + c + 1] = anext;
+        }
+      }
+    }
+    if (more) {
+      const double mag = cabs1(anext);
+      int br; double bv;
+      pick(below && mag == mag, mag, &br, &bv);
+      wave_sync_lds();
+      publish(c + 1, br, bv);
+      if (lead) leader_gather(c + 1);
+      // ---- bulk rank-1 update of this system's rows (hidden behind the other systems' steps and this one's exchange)
+      if (!singular && below) {
+        dc* Pr = P + (size_t)lane * pitch;
+        for (int j0 = c + 2; j0 < nb; j0 += 4) {
+          dc u[4], a[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int j = min(j0 + q, nb - 1); u[q] = urow[j]; a[q] = Pr[j]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { a[q].re -= l.re * u[q].re - l.im * u[q].im; a[q].im -= l.re * u[q].im + l.im * u[q].re; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (j0 + q < nb) Pr[j0 + q] = a[q];
+        }
+      }
+    }
+    pending = !singular && more;
+    wave_sync_lds();
+  }
+  for (int idx = lane; idx < nrows * nb; idx += 64) {
+    int rr = idx / nb, j = idx - rr * nb;
+    A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
+  }
+}
+
+// (A third form kept the rows in REGISTERS -- lane = row with its 32 panel entries in 128 vector registers, columns picked with
+// compare-and-select chains, published rows gathered with v_readlane, 200 VGPRs, no scratch once the 64 values were named
+// scalars instead of arrays: bit-identical again, but 61.9 ms of panel time per frequency against 31.7-37.5 for the LDS form
+// above: ~1500 vector instructions per column step, most of them selects and lane reads, cost more than the LDS traffic they
+// replace. Removed; the measurements are in DESIGN.md 4.)
+
 // ------------------------------------------------------------------ row interchanges outside the panel
 // One wavefront replays the panel's nb interchanges on an index map and emits (dst,src) row lists:
 // after the sequence, row dst holds what row src held before it. m <= 2 nb entries.
@@ -1085,6 +1331,7 @@ size_t lu_panel_lds_bytes(int nb, int rpb) {
 
 int lu_panel_configure() {
   MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_panel_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return MA_OK;
 }
 
@@ -1116,14 +1363,14 @@ int lu_panel_configure() {
 // read from an aborted panel.
 namespace {
 constexpr int kSeqRing = 256;                          // launches remembered per device
-constexpr int kSeqWindow = 8;                          // at most this many panel kernels are ever admitted together
-struct PanelLaunch { hipEvent_t ev = nullptr; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; bool used = false; };
+struct PanelLaunch { hipEvent_t ev = nullptr; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; int regs = 0; bool used = false; };
 struct PanelSequencer {
   std::mutex mu;
   PanelLaunch ring[16][kSeqRing];
   bool made[16] = {};
   unsigned long long count[16] = {};
-  int regs = 0, occ_checked_lds = 0;
+  int regs[2] = {0, 0};      // vector registers per lane of lu_panel_kernel, lu_panel_wave_kernel
+  int occ_checked_lds = 0;
 };
 PanelSequencer g_seq;
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -1140,37 +1387,48 @@ int lu_panel_slots_per_cu(size_t lds, int regs) {
 
 size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long) * LU_GRANULE_STRIDE * (2 * (size_t)max_blocks + 2 * LU_GROUPS); }
 
-int lu_panel_regs() {
+int lu_panel_regs(int kind) {
   std::lock_guard<std::mutex> lock(g_seq.mu);
-  if (g_seq.regs == 0) {
-    hipFuncAttributes fa;
-    MA_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(lu_panel_kernel)));
-    g_seq.regs = fa.numRegs > 0 ? fa.numRegs : 128;
+  if (g_seq.regs[0] == 0) {
+    const void* f[2] = {reinterpret_cast<const void*>(lu_panel_kernel), reinterpret_cast<const void*>(lu_panel_wave_kernel)};
+    for (int q = 0; q < 2; ++q) {
+      hipFuncAttributes fa;
+      MA_HIP(hipFuncGetAttributes(&fa, f[q]));
+      g_seq.regs[q] = fa.numRegs > 0 ? fa.numRegs : 128;
+    }
   }
-  return g_seq.regs;
+  return g_seq.regs[kind == 1 ? 1 : 0];
 }
 
 // MA_OK when a grid of nblk workgroups with this panel shape can be co-resident on ncu CUs on its own
 int lu_panel_admissible(int nb, int rpb, int nblk, int ncu) {
   const size_t lds = lu_panel_lds_bytes(nb, rpb);
-  const int regs = lu_panel_regs();
+  const int regs = lu_panel_regs(0);
   const int p = lu_panel_slots_per_cu(lds, regs);
   MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
              "panel grid of %d workgroups x %zu B LDS (%d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nb, rpb, ncu, p);
   return MA_OK;
 }
 
-int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
+// admission + launch of either panel kernel: nsys = 1 -> lu_panel_kernel on (A[0], ws[0], ipiv[0]); nsys > 1 -> lu_panel_wave_kernel
+static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
+  MA_REQUIRE(nsys >= 1 && nsys <= LU_BATCH_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
+  const LuPanelWs& ws = wss[0];
   MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
   MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,
              "panel grid (%d workgroups of %d rows from row %d) does not tile the %d rows", nblk, rpb, k0, n);
-  int rc = lu_panel_admissible(nb, rpb, nblk, ncu);
-  if (rc) return rc;
-  const size_t lds = lu_panel_lds_bytes(nb, rpb);
-  const int regs = lu_panel_regs();
+  const int kind = nsys == 1 ? 0 : 1;                                    // lu_panel_kernel or lu_panel_wave_kernel
+  const size_t sys_lds = (lu_panel_lds_bytes(nb, rpb) + 15) & ~(size_t)15;
+  const size_t lds = kind == 0 ? lu_panel_lds_bytes(nb, rpb) : sys_lds * (size_t)nsys;
+  const int regs = lu_panel_regs(kind);
+  {
+    const int p = lu_panel_slots_per_cu(lds, regs);
+    MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
+               "panel grid of %d workgroups x %zu B LDS (%d systems, %d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nsys, nb, rpb, ncu, p);
+  }
   std::lock_guard<std::mutex> lock(g_seq.mu);
   if (!g_seq.made[dev]) {
     for (int i = 0; i < kSeqRing; ++i) MA_HIP(hipEventCreateWithFlags(&g_seq.ring[dev][i].ev, hipEventDisableTiming));
@@ -1179,17 +1437,20 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   if ((int)lds > g_seq.occ_checked_lds) {
     // the runtime's own occupancy figure must not be below the slots the rule assumes (registers, waves, LDS granularity)
     int occ = 0;
-    MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
+    if (kind == 0) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
+    else MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_wave_kernel), 64 * nsys, lds));
     MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU at %zu B LDS is below the %d slots the admission rule assumes",
                occ, lds, lu_panel_slots_per_cu(lds, regs));
     g_seq.occ_checked_lds = (int)lds;
   }
-  // Admission: the launches that may be in flight together with this one are a WINDOW of the launch order ending here: walk
-  // back from the newest while everything taken so far fits p(s_max) x ncu workgroups (and kSeqWindow launches); every
-  // launch at or before the window's start c must have finished before this kernel starts. Streams are in order, so it is
-  // enough to wait, per other stream, for that stream's latest launch <= c (one or two waits per launch with three or four
-  // lanes; none for the launch's own stream). Then every running panel kernel lies inside the window its newest member
-  // computed, whatever the streams' relative progress, and the residency argument above applies to the window.
+  // Admission. Streams are in order, so at most ONE panel kernel per stream runs at any time, and what may run beside this
+  // launch is, per other stream, one of that stream's earlier launches (later launches do their own admission and count this
+  // one). Per other stream take the largest grid and LDS size among its launches of the last 256 panel launches; if this
+  // launch plus one such grid per stream fits p(s_max) x ncu workgroups, nothing has to be waited for. Otherwise the launch
+  // waits for the LATEST launch of the stream whose latest launch is oldest (that stream then contributes nothing: all its
+  // earlier launches are over when this kernel starts), and so on until the rest fits. For equal shapes on three lanes this
+  // is "wait for the launch before the previous one"; the running set is always bounded by what its newest member computed,
+  // so the residency argument above applies to it.
   const unsigned long long i = g_seq.count[dev];
   PanelLaunch* ring = g_seq.ring[dev];
   PanelLaunch& me = ring[i % kSeqRing];
@@ -1201,36 +1462,60 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
     (void)hipGetLastError();
   }
   const unsigned long long oldest = i >= (unsigned long long)(kSeqRing - 1) ? i - (kSeqRing - 1) : 0ull;
-  long long tot = nblk; size_t smax = lds; int taken = 1;
-  unsigned long long c = i;                                   // launches with index < c are outside the window (c = i: window is this launch alone)
-  while (c > oldest) {
-    const PanelLaunch& L = ring[(c - 1) % kSeqRing];
-    const size_t s2 = L.lds > smax ? L.lds : smax;
-    if (taken >= kSeqWindow || tot + L.nblk > (long long)lu_panel_slots_per_cu(s2, regs) * ncu) break;
-    tot += L.nblk; smax = s2; ++taken; --c;
-  }
-  hipStream_t seen[8]; int nseen = 0;
-  for (unsigned long long j = c; j-- > oldest && nseen < 8;) {
+  struct Lane { hipStream_t st; unsigned long long latest; long long nblk; size_t lds; int regs; };
+  Lane lanes[16]; int nlanes = 0;
+  for (unsigned long long j = i; j-- > oldest;) {             // newest first: the first hit of a stream is its latest launch
     const PanelLaunch& L = ring[j % kSeqRing];
-    if (L.st == st) continue;                                 // own stream: in order anyway
-    bool dup = false;
-    for (int q = 0; q < nseen; ++q) dup = dup || seen[q] == L.st;
-    if (dup) continue;                                        // an older launch of a stream already waited for
-    seen[nseen++] = L.st;
-    if (!pending(L.ev)) continue;                             // finished: nothing to wait for (and nothing older on that stream either)
-    MA_HIP(hipStreamWaitEvent(st, L.ev, 0));
+    if (!L.used || L.st == st) continue;
+    int q = 0;
+    while (q < nlanes && lanes[q].st != L.st) ++q;
+    if (q == nlanes) { if (nlanes == 16) continue; lanes[nlanes++] = {L.st, j, L.nblk, L.lds, L.regs}; }
+    else { if (L.nblk > lanes[q].nblk) lanes[q].nblk = L.nblk; if (L.lds > lanes[q].lds) lanes[q].lds = L.lds; if (L.regs > lanes[q].regs) lanes[q].regs = L.regs; }
+  }
+  bool pruned = false;
+  for (;;) {
+    long long tot = nblk; size_t smax = lds; int rmax = regs; int victim = -1;
+    for (int q = 0; q < nlanes; ++q) {
+      if (!lanes[q].st) continue;
+      tot += lanes[q].nblk; if (lanes[q].lds > smax) smax = lanes[q].lds; if (lanes[q].regs > rmax) rmax = lanes[q].regs;
+      if (victim < 0 || lanes[q].latest < lanes[victim].latest) victim = q;
+    }
+    if (victim < 0 || tot <= (long long)lu_panel_slots_per_cu(smax, rmax) * ncu) break;
+    if (!pruned) {                                            // over capacity: forget the streams whose latest launch is over (idle lanes, plans of the past)
+      pruned = true;
+      for (int q = 0; q < nlanes; ++q) if (lanes[q].st && !pending(ring[lanes[q].latest % kSeqRing].ev)) lanes[q].st = nullptr;
+      continue;
+    }
+    const PanelLaunch& L = ring[lanes[victim].latest % kSeqRing];
+    if (pending(L.ev)) MA_HIP(hipStreamWaitEvent(st, L.ev, 0));
+    lanes[victim].st = nullptr;                               // everything that stream launched before is over when this kernel starts
   }
   // Stale tags must not match. A workgroup rewrites its granule every column, so only columns 0 and 1 of a launch can
   // see the previous launch's granules, which carry that launch's last two tags (nb and nb - 1): they differ from the
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
-  if (clear_tags) MA_HIP(hipMemsetAsync(ws.cand, 0, lu_panel_granule_bytes(ws.max_blocks), st));
-  hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(A), n, k0, nb, rpb, ws, ipiv);
+  if (clear_tags) for (int t = 0; t < nsys; ++t) MA_HIP(hipMemsetAsync(wss[t].cand, 0, lu_panel_granule_bytes(wss[t].max_blocks), st));
+  if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
+  else {
+    LuPanelBatch B;
+    B.nsys = nsys;
+    for (int t = 0; t < LU_BATCH_MAX; ++t) { const int q = t < nsys ? t : 0; B.A[t] = reinterpret_cast<dc*>(As[q]); B.ipiv[t] = ipivs[q]; B.ws[t] = wss[q]; }
+    MA_REQUIRE(rpb <= 64, MA_ERR_INVALID, "the batched panel kernel holds <= 64 rows per workgroup (lane = row), got %d", rpb);
+    hipLaunchKernelGGL(lu_panel_wave_kernel, dim3(nblk), dim3(64 * nsys), lds, st, B, n, k0, nb, rpb, (unsigned)sys_lds);
+  }
   MA_HIP(hipGetLastError());
   MA_HIP(hipEventRecord(me.ev, st));
-  me.nblk = nblk; me.lds = lds; me.st = st; me.used = true;
+  me.nblk = nblk; me.lds = lds; me.regs = regs; me.st = st; me.used = true;
   g_seq.count[dev] = i + 1;
   return MA_OK;
+}
+
+int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
+  return launch_panel_any(1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
+}
+// the same panel of nsys systems (a lock-step batch) in one co-resident grid, a wavefront per system: lu_panel_wave_kernel
+int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
+  return launch_panel_any(nsys, As, n, k0, nb, rpb, nblk, ncu, wss, ipivs, clear_tags, st);
 }
 
 // Apply panel (k0, nb)'s interchanges to the columns [x0, x1) U [y0, y1) of A and to the nrhs right-hand sides.

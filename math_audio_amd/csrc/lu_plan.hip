@@ -58,6 +58,11 @@ struct ma_lu_plan {
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
   bool rpb_env = false;           // MA_LU_RPB given
   int rpb_cap = 44;               // rows per panel workgroup when MA_LU_RPB is given
+  // lock-step batches: ONE panel kernel factors the same panel of every system of the batch (lu_panel_batch_kernel); panels of
+  // batch_nb columns, batch_lds bytes of LDS per workgroup over all systems (off by default: MA_LU_BATCH_PANEL=1)
+  bool batch_panel = false; int batch_nb = 32; int batch_lds = 56 * 1024;   // measured: the staged pipeline of per-system panel kernels is faster; MA_LU_BATCH_PANEL=1 selects this form
+  hipEvent_t ev_bp = nullptr, ev_lane[LU_BATCH_MAX] = {};
+  int last_bp_nsys = 0;           // > 0: the last factorisation used batched panels over that many systems (its panel partition differs)
 };
 
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
@@ -94,6 +99,10 @@ int ma_lu_plan::ensure_batch(int nmat) {
     MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * 2 * LU_KB_MAX * LU_LISTS_LEN));
     MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * 2 * LU_KB_MAX * LU_NB_MAX * 32));
     MA_HIP(hipMalloc(&d_tmp_l[m], sizeof(c64) * 2 * LU_NB_MAX * LU_LANE_TSTRIDE));
+    // the memset above runs on the null stream; the plan's lanes and the callers' streams may be non-blocking streams that do
+    // not order themselves against it: without this wait it can land AFTER a panel kernel has written its pivots (seen as
+    // "pivot outside its range" under two host threads)
+    MA_HIP(hipStreamSynchronize(nullptr));
   }
   return MA_OK;
 }
@@ -152,6 +161,9 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (const char* e6 = getenv("MA_LU_KB")) { int v = atoi(e6); if (v >= 1 && v <= LU_KB_MAX) { P->kb = v; P->kb_env = true; } }
   if (const char* e5 = getenv("MA_LU_PANEL_OVERLAP")) P->panel_overlap = atoi(e5) != 0;
   if (const char* e7 = getenv("MA_LU_MIDLANE")) P->midlane = atoi(e7);
+  if (const char* eb = getenv("MA_LU_BATCH_PANEL")) P->batch_panel = atoi(eb) != 0;
+  if (const char* eb = getenv("MA_LU_BATCH_NB")) { int v = atoi(eb); if (v >= 16 && v <= LU_NB_MAX && v % 16 == 0) P->batch_nb = v; }
+  if (const char* eb = getenv("MA_LU_BATCH_LDS")) { int v = atoi(eb); if (v >= 16 && v <= 150) P->batch_lds = v * 1024; }
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
   for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
   if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
@@ -182,6 +194,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_mid[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_big[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_prep[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_lane[i], hipEventDisableTiming);
+    if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&P->ev_bp, hipEventDisableTiming);
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
   }
   if (rc) { ma_lu_plan_destroy(P); return rc; }
@@ -197,6 +211,8 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) (void)hipStreamSynchronize(P->panel_streams[i]); if (P->mid_streams[i]) (void)hipStreamSynchronize(P->mid_streams[i]); }
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
+  if (P->ev_bp) (void)hipEventDestroy(P->ev_bp);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->ev_lane[i]) (void)hipEventDestroy(P->ev_lane[i]);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]);
     if (P->ev_prep[i]) (void)hipEventDestroy(P->ev_prep[i]); if (P->ev_mid[i]) (void)hipEventDestroy(P->ev_mid[i]); if (P->ev_big[i]) (void)hipEventDestroy(P->ev_big[i]); if (P->mid_streams[i]) (void)hipStreamDestroy(P->mid_streams[i]); }
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
@@ -255,6 +271,20 @@ static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vect
   }
 }
 
+// the same for a batch whose panels are factored by ONE kernel for all `nsys` systems: narrower panels, and rows per workgroup such
+// that the workgroup's LDS over all systems stays within batch_lds (two trailing-update workgroups still fit beside it)
+static void panel_schedule_batched(const ma_lu_plan* P, int nsys, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks) {
+  const int n = P->n;
+  for (int k0 = 0; k0 < n;) {
+    const int nb = std::min(n - k0, P->batch_nb);
+    int rpb = P->rpb_env ? P->rpb_cap : std::min(64, std::max(8, (int)((P->batch_lds / nsys - 3 * nb * 16 - 256) / ((nb + 1) * 16))));
+    int nblk = (n - k0 + rpb - 1) / rpb;
+    if (nblk > P->ncu) { rpb = (n - k0 + P->ncu - 1) / P->ncu; nblk = (n - k0 + rpb - 1) / rpb; }
+    k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
+    k0 += nb;
+  }
+}
+
 // panels per trailing update: K = kb * nb = 256 (tall systems factor in narrower panels -- 32 columns from 36 353 rows
 // on -- and then take 8 of them per update: 65.8 -> 72.1 TFLOP/s on a 50 172-row system); the look-ahead lane's interchange
 // staging holds (kb - 1) panels' columns
@@ -302,7 +332,18 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   MA_MARK(e_begin, st);
 
   std::vector<int> k0s, nbs, rpbs, nblks;
-  panel_schedule(P, k0s, nbs, rpbs, nblks);
+  // batched panels: the systems of the batch share one panel kernel per panel (lock step is what this schedule is anyway)
+  bool bp = nmat >= 2 && P->batch_panel && la && P->panel_overlap && P->midlane == 1;
+  if (bp) {
+    panel_schedule_batched(P, nmat, k0s, nbs, rpbs, nblks);
+    for (size_t q = 0; q < k0s.size() && bp; ++q) {
+      const size_t lds = ((lu_panel_lds_bytes(nbs[q], rpbs[q]) + 15) & ~(size_t)15) * (size_t)nmat;
+      if (rpbs[q] > 64 || (long long)nblks[q] > (long long)lu_panel_slots_per_cu(lds, lu_panel_regs(1)) * P->ncu) bp = false;    // tall systems: one kernel per system after all
+    }
+    if (!bp) { k0s.clear(); nbs.clear(); rpbs.clear(); nblks.clear(); }
+  }
+  if (!bp) panel_schedule(P, k0s, nbs, rpbs, nblks);
+  P->last_bp_nsys = bp ? nmat : 0;
   const int Q = (int)k0s.size();
   // the lane's interchange staging holds (kb-1) panels' columns
   const int kb = effective_kb(P, nbs);
@@ -346,11 +387,52 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     return MA_OK;
   };
 
+  // batched panels: block g's panels for ALL systems. Stream sps[0] carries the panel kernels; after each one every system
+  // does its own small work for that panel (lists + inverted blocks, interchanges, U12, the update of the block's remaining
+  // columns) on its own stream, and the next panel kernel waits for all of them.
+  bool lane_pending[LU_BATCH_MAX] = {false, false, false, false};
+  auto lane_bp = [&](int g) -> int {
+    hipStream_t s0 = sps[0];
+    const int e = blk_end(g);
+    for (int q = blk_first(g); q < blk_last(g); ++q) {
+      const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+      for (int m = 1; m < nmat; ++m) if (lane_pending[m]) { MA_HIP(hipStreamWaitEvent(s0, P->ev_lane[m], 0)); lane_pending[m] = false; }
+      MA_MARK(t0, s0);
+      int* ipivs[LU_BATCH_MAX]; for (int m = 0; m < LU_BATCH_MAX; ++m) ipivs[m] = P->d_ipiv[m < nmat ? m : 0];
+      if ((rc = lu_launch_panel_batch(nmat, As, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m, ipivs, q == 0 || nbs[q - 1] < 4, s0))) return rc;
+      MA_MARK(t1, s0);
+      interval(P, t0, t1, 0);
+      MA_HIP(hipEventRecord(P->ev_bp, s0));
+      const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
+      for (int m = 0; m < nmat; ++m) {
+        c64* A = As[m];
+        hipStream_t sp = sps[m];
+        if (m > 0) MA_HIP(hipStreamWaitEvent(sp, P->ev_bp, 0));
+        int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
+        c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
+        if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
+        if (a1 < e) {
+          if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
+          const c64* T = A + (size_t)k0 * n + k0;
+          if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+          MA_MARK(t2, sp);
+          if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
+          MA_MARK(t3, sp);
+          interval(P, t2, t3, 5);
+        }
+        if (m > 0) { MA_HIP(hipEventRecord(P->ev_lane[m], sp)); lane_pending[m] = true; }
+      }
+    }
+    for (int m = 0; m < nmat; ++m) MA_HIP(hipEventRecord(P->ev_panel[m], sps[m]));
+    return MA_OK;
+  };
+
   if (la) {
     MA_HIP(hipEventRecord(P->ev_start, st));
     for (int m = 0; m < nmat; ++m) if (m == 0 || sps[m] != sps[0]) MA_HIP(hipStreamWaitEvent(sps[m], P->ev_start, 0));
   }
-  for (int m = 0; m < nmat; ++m) if ((rc = lane(m, 0))) return rc;
+  if (bp) { if ((rc = lane_bp(0))) return rc; }
+  else for (int m = 0; m < nmat; ++m) if ((rc = lane(m, 0))) return rc;
   // With several systems in flight the per-panel work of the current block (interchanges, U12 = L11^-1 A12, the updates
   // inside the block and of the next block's columns: short, latency-bound launches) runs on a stream of its own per
   // system; the caller's stream carries only the big updates, back to back over the systems.
@@ -395,11 +477,14 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       MA_MARK(t4, sm);
       interval(P, t3, t4, split ? 5 : 3);
       if (split) MA_HIP(hipEventRecord(P->ev_mid[m], sm));
-      if (narrow) {
+      if (narrow && !bp) {
         if (sm != sps[m]) { MA_HIP(hipEventRecord(P->ev_narrow[m], sm)); MA_HIP(hipStreamWaitEvent(sps[m], P->ev_narrow[m], 0)); }
         if ((rc = lane(m, g + 1))) return rc;
       }
+      if (narrow && bp && m > 0) { MA_HIP(hipEventRecord(P->ev_lane[m], sm)); lane_pending[m] = true; }   // sm == sps[m] here (midlane 1)
     }
+    // batched panels: the next block's panels once every system's columns of that block are up to date
+    if (bp && la && nright > 0 && g + 1 < G && (rc = lane_bp(g + 1))) return rc;
     for (int m = 0; m < nmat && nright > 0; ++m) {
       c64* A = As[m];
       if (split) MA_HIP(hipStreamWaitEvent(st, P->ev_mid[m], 0));
@@ -585,6 +670,7 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
   P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->ev_valid = false; P->last_batch = 0;
+  P->last_bp_nsys = 0;
   MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
   MA_MARK(e0, st);
   P->stage_first_mark = e0;
@@ -654,7 +740,8 @@ static int solve_only(ma_lu_plan* P, c64* A, c64* B, int32_t nrhs, hipStream_t s
   const int n = P->n;
   const int tstride = n + P->nrhs_max;
   std::vector<int> k0s, nbs, rpbs, nblks;
-  panel_schedule(P, k0s, nbs, rpbs, nblks);
+  if (P->last_bp_nsys > 0) panel_schedule_batched(P, P->last_bp_nsys, k0s, nbs, rpbs, nblks);    // the panels the factors were built with
+  else panel_schedule(P, k0s, nbs, rpbs, nblks);
   const int Q = (int)k0s.size();
   int rc;
   // the stored factors are in their final row order (later interchanges were applied to the earlier L columns), so every

@@ -108,6 +108,10 @@ __device__ __forceinline__ dc pair_coeff_13(double d0x, double d0y, double d0z, 
                                             double e2z, double nyx, double nyy, double nyz, double nxx, double nxy, double nxz, double jw,
                                             int fbc, const BemPhys& ph, double k, double k2) {
   const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+  // as tbem_far_kernel: (y - x) . n_y is constant over the flat panel, (y - x) . n_x affine in (xi, eta)
+  const double dny = d0x * nyx + d0y * nyy + d0z * nyz;
+  const double dnx0 = d0x * nxx + d0y * nxy + d0z * nxz;
+  const double e1nx = e1x * nxx + e1y * nxy + e1z * nxz, e2nx = e2x * nxx + e2y * nxy + e2z * nxz;
   double g_re = 0, g_im = 0, h_re = 0, h_im = 0, t_re = 0, t_im = 0, e_re = 0, e_im = 0;
 #pragma unroll
   for (int q = 0; q < 13; ++q) {
@@ -122,8 +126,8 @@ __device__ __forceinline__ dc pair_coeff_13(double d0x, double d0y, double d0z, 
     const double gsc = w4pi * ri;
     const double gre = cs * gsc, gim = sn * gsc;
     const double bre = -(gre * ri) - gim * k, bim = gre * k - gim * ri;
-    const double a = (dx * nyx + dy * nyy + dz * nyz) * ri;
-    const double b = -((dx * nxx + dy * nxy + dz * nxz) * ri);
+    const double a = dny * ri;
+    const double b = -(__builtin_fma(eta, e2nx, __builtin_fma(xi, e1nx, dnx0)) * ri);
     const double rq = a * b, ri2 = ri * ri;
     const double fr = (3.0 * ri2 - k2) * rq + m * ri2;
     const double fi = -(k * ri) * (3.0 * rq + m);

@@ -113,13 +113,18 @@ def test_lu_on_bem_system_matches_oracle(gpu):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
 
 
-def test_batched_factor_solve_is_bitwise_the_single_one(gpu):
-    """Frequencies in flight: interleaving the panels of independent systems must not change any of them."""
+@pytest.mark.parametrize("batch_panel", [1, 0])
+def test_batched_factor_solve_is_bitwise_the_single_one(gpu, batch_panel):
+    """Frequencies in flight: factoring independent systems together must not change any of them. batch_panel = 1: one panel
+    kernel walks the systems round-robin inside every column (lu_panel_batch_kernel, 32-column panels) -- each system's
+    arithmetic is the single-system kernel's at that panel width, whatever the rows per workgroup; batch_panel = 0: a panel
+    kernel per system, interleaved."""
     import torch
     n = 900
     dev = torch.device("cuda", 0)
     mats = [_rand(n, 100 + i) for i in range(3)]
-    lu = ma.LuPlan(n)
+    with _with_env(MA_LU_NB=32 if batch_panel else 64, MA_LU_BATCH_PANEL=batch_panel):
+        lu = ma.LuPlan(n)                                  # the switches are read once per plan
     st = torch.cuda.current_stream().cuda_stream
     singles = []
     for A, b in mats:
@@ -289,7 +294,8 @@ def _with_env(**kv):
     return cm()
 
 
-def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu):
+@pytest.mark.parametrize("batch_panel", [0, 1])
+def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu, batch_panel):
     """The failure path behind the round-1 memory fault (DESIGN 4 "Residency", lu_kernels.hip): a panel kernel whose exchange
     does not complete must (1) make every workgroup of every panel kernel of the plan leave at once -- the poison word is
     read in every poll, no 4 s wait per workgroup --, (2) leave identity pivots behind, so that the interchange kernels,
@@ -302,7 +308,7 @@ def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu):
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     mats = [_rand(n, 300 + i) for i in range(3)]
-    with _with_env(MA_LU_TEST_ABORT_COL=200):
+    with _with_env(MA_LU_TEST_ABORT_COL=200, MA_LU_BATCH_PANEL=batch_panel):      # 1: one panel kernel for the three systems, a wavefront each
         lu = ma.LuPlan(n)
     dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
     guard = torch.full((1 << 20,), 7.0, dtype=torch.float64, device=dev)       # a canary allocated right after the operands
