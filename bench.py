@@ -213,7 +213,9 @@ def main():
                     help="pipeline: slots at staggered block indices (staged plan API); batch: lock-step batches of --slots systems; "
                          "auto: pipeline from 12 steps on (below that its fill and drain cost more than the lock step does)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "3")),
-                    help="frequencies in flight per GPU (systems factored as one interleaved batch, 1..4)")
+                    help="frequencies in flight per GPU (systems factored as one interleaved batch, 1..4; with --group-size g: a multiple of g, up to 8)")
+    ap.add_argument("--group-size", type=int, default=int(os.environ.get("MA_SWEEP_GROUP", "0")),
+                    help="pipeline schedule: slots in groups of this size share one panel kernel per panel and move in lock step (0 = every slot on its own)")
     args = ap.parse_args()
     if args.schedule == "auto":
         args.schedule = "pipeline" if args.steps >= 12 else "batch"
@@ -256,7 +258,10 @@ def main():
     # Frequencies are independent, and 288 GB of HBM holds many 1.6 GB systems: S systems are kept in flight and
     # factored as ONE interleaved batch, so one frequency's latency-bound panel factorisation (one chip-wide
     # gather per column) runs underneath another's MFMA-bound trailing update. A step is still one frequency.
-    S = max(1, min(args.slots, args.steps, 4))
+    gsz = args.group_size if (args.group_size >= 2 and args.schedule == "pipeline") else 0
+    S = max(1, min(args.slots, args.steps, 8 if gsz else 4))
+    if gsz:
+        S = max(gsz, (S // gsz) * gsz)
     plan = ma.BemPlan(mesh, device=local_rank)
     lu = ma.LuPlan(n, device=local_rank)
     As = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
@@ -299,6 +304,8 @@ def main():
         factorisation after slot s - 1, so every round of block updates carries a bigger, a medium and a smaller one and no
         slot's latency-bound panel chain is ever the only thing running. No host synchronisation inside."""
         slots = max(1, min(S, nsteps))
+        if gsz:
+            return run_pipeline_groups(first, nsteps)
         G = lu.num_blocks()
         spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or max(1, (G + slots) // (slots + 1))   # rounds between the starts of two slots (G/4 for 3 slots measured best: 59.9 vs 60.7 ms at G/3)
         off = [s * spacing for s in range(slots)]
@@ -327,6 +334,50 @@ def main():
             for s, g in zip(sl, bl):
                 if g == G - 1:
                     lu.stage_finish(s, stream)
+            r += 1
+        if timing:
+            lu_ms[:] += lu.last_timing()
+            upd[:] += lu.last_update_stats()
+
+    if gsz and (args.steps % gsz or args.warmup % gsz):
+        raise SystemExit("bench.py: with --group-size %d, --steps and --warmup must be multiples of it (no frequency may be skipped)" % gsz)
+
+    def run_pipeline_groups(first, nsteps):
+        """Groups of gsz slots in lock step (one panel kernel per panel for the whole group: a wavefront per system), the groups
+        staggered against each other: a group's latency-bound chain runs under the other groups' trailing updates."""
+        U = S // gsz
+        lu.stage_set_group(gsz)
+        G = lu.num_blocks()
+        spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or max(1, G // U)
+        off = [u * spacing for u in range(U)]
+        lu.stage_reset(stream)
+        r = 0
+        while True:
+            sl, bl, live = [], [], False
+            for u in range(U):
+                lr = r - off[u]
+                if lr < 0:
+                    live = True
+                    continue
+                sysno, g = divmod(lr, G)
+                base = (u + U * sysno) * gsz                 # first step index of this group's current systems
+                if base + gsz > nsteps:
+                    continue
+                live = True
+                if g == 0:
+                    for t in range(gsz):
+                        assemble_into(first + base + t, u * gsz + t)
+                        lu.stage_begin(u * gsz + t, As[u * gsz + t].data_ptr(), xs_[u * gsz + t].data_ptr(), 1, stream)
+                    lu.stage_begin_group(u * gsz, stream)
+                for t in range(gsz):
+                    sl.append(u * gsz + t); bl.append(g)
+            if not live:
+                break
+            if sl:
+                lu.stage_round(sl, bl, stream)
+            for s_, g in zip(sl, bl):
+                if g == G - 1:
+                    lu.stage_finish(s_, stream)
             r += 1
         if timing:
             lu_ms[:] += lu.last_timing()
@@ -371,9 +422,9 @@ def main():
         keep = (lu_ms.copy(), upd.copy(), asm_ms.copy())
         lu_ms[:] = 0; upd[:] = 0
         lu.set_timing(1)
-        batch(args.warmup, S)
+        batch(args.warmup, min(S, 4))
         torch.cuda.synchronize()
-        diag_ms = lu_ms / S
+        diag_ms = lu_ms / min(S, 4)
         lu_ms[:], upd[:], asm_ms[:] = keep
     for v in xs_:
         if not np.all(np.isfinite(v.cpu().numpy().view(np.float64))):

@@ -183,6 +183,12 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
 int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);   /* the stream a slot's chain runs on */
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
+/* Groups of slots (up to 8 slots): with group_size 2..4 the slots [k g, (k+1) g) move in lock step and share ONE panel kernel per panel
+ * (a wavefront per system), while different groups sit at different block indices. Set before stage_reset; every slot of a group
+ * calls stage_begin, then one stage_begin_group(first slot) starts the group's first block column; in stage_round the slots of a
+ * group appear together with equal block indices. group_size 0 / 1: every slot on its own (default). */
+int ma_lu_plan_stage_set_group(ma_lu_plan_t* plan, int32_t group_size);
+int ma_lu_plan_stage_begin_group(ma_lu_plan_t* plan, int32_t first_slot, void* stream);
 int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);
 /* after stage_finish: the slot's status word (0, or 1 + the column of the first zero pivot) copied to a device int on `stream` */
 int ma_lu_plan_stage_info_dev(ma_lu_plan_t* plan, int32_t slot, int32_t* d_out, void* stream);

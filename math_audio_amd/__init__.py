@@ -98,6 +98,8 @@ def lib():
             "ma_lu_plan_stage_begin": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_stage_round": [vp, i32, vp, vp, vp],
             "ma_lu_plan_stage_finish": [vp, i32, vp],
+            "ma_lu_plan_stage_set_group": [vp, i32],
+            "ma_lu_plan_stage_begin_group": [vp, i32, vp],
             "ma_lu_plan_stage_info_dev": [vp, i32, vp, vp],
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
@@ -369,6 +371,13 @@ class LuPlan:
         m = len(slots)
         a = (C.c_int32 * m)(*slots); b = (C.c_int32 * m)(*blocks)
         check(lib().ma_lu_plan_stage_round(self.h, m, a, b, C.c_void_p(stream)))
+
+    def stage_set_group(self, group_size):
+        """Slots [k g, (k+1) g) share one panel kernel per panel (ma_lu_plan_stage_set_group); 0 = every slot on its own."""
+        check(lib().ma_lu_plan_stage_set_group(self.h, int(group_size)))
+
+    def stage_begin_group(self, first_slot, stream=0):
+        check(lib().ma_lu_plan_stage_begin_group(self.h, int(first_slot), C.c_void_p(stream)))
 
     def stage_finish(self, slot, stream=0):
         check(lib().ma_lu_plan_stage_finish(self.h, int(slot), C.c_void_p(stream)))

@@ -531,6 +531,13 @@ __global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, i
     if (lead) leader_gather(0);
   }
 
+#ifdef MA_PANEL_STAMPS
+  u64 wst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 wst_t = __builtin_amdgcn_s_memrealtime();
+#define MA_WSTAMP(i) do { if (b == 0 && sy == 0) { u64 now_ = __builtin_amdgcn_s_memrealtime(); wst_acc[i] += now_ - wst_t; wst_t = now_; } } while (0)
+#else
+#define MA_WSTAMP(i) do { } while (0)
+#endif
   bool pending = false;
   for (int c = 0; c < nb; ++c) {
     const int gc = k0 + c;
@@ -570,6 +577,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, i
       if (best >= (unsigned)n || best < (unsigned)gc) { p = gc; wb = -1; if (b == 0 && lane == 0) atomicCAS(ws.info, 0, gc + 1); }
       else { p = (int)best; wb = (p - k0) / rpb; }
     }
+    MA_WSTAMP(0);
     // ---- fetch the pivot row (and the displaced diagonal row); finish the previous column's pending update on them
     dc* urow = (c & 1) ? urow_b : urow_a;
     const dc* uprev = (c & 1) ? urow_a : urow_b;
@@ -594,6 +602,7 @@ __global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, i
       }
     }
     wave_sync_lds();
+    MA_WSTAMP(1);
     // ---- interchange inside the panel
     if (p != gc && p >= r0 && p < r0 + nrows) for (int t = lane; t < nb; t += 64) P[(size_t)(p - r0) * pitch + t] = drow[t];
     if (gc >= r0 && gc < r0 + nrows) for (int t = lane; t < nb; t += 64) P[(size_t)(gc - r0) * pitch + t] = urow[t];
@@ -623,8 +632,11 @@ __global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, i
       int br; double bv;
       pick(below && mag == mag, mag, &br, &bv);
       wave_sync_lds();
+      MA_WSTAMP(2);
       publish(c + 1, br, bv);
+      MA_WSTAMP(3);
       if (lead) leader_gather(c + 1);
+      MA_WSTAMP(4);
       // ---- bulk rank-1 update of this system's rows (hidden behind the other systems' steps and this one's exchange)
       if (!singular && below) {
         dc* Pr = P + (size_t)lane * pitch;
@@ -641,7 +653,11 @@ __global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, i
     }
     pending = !singular && more;
     wave_sync_lds();
+    MA_WSTAMP(5);
   }
+#ifdef MA_PANEL_STAMPS
+  if (lane == 0 && b == 0 && sy == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, wst_acc[i]);
+#endif
   for (int idx = lane; idx < nrows * nb; idx += 64) {
     int rr = idx / nb, j = idx - rr * nb;
     A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
@@ -1415,7 +1431,7 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
-  MA_REQUIRE(nsys >= 1 && nsys <= LU_BATCH_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
+  MA_REQUIRE(nsys >= 1 && nsys <= LU_GROUP_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
   const LuPanelWs& ws = wss[0];
   MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
   MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,

@@ -3,7 +3,8 @@
 #include "ma_common.hpp"
 
 #define LU_NB_MAX 128
-#define LU_BATCH_MAX 4
+#define LU_BATCH_MAX 8          /* systems (slots) a plan keeps resources for */
+#define LU_GROUP_MAX 4          /* systems one panel kernel factors together (a wavefront each) / lock-step batch size of the public API */
 
 namespace ma {
 

@@ -63,6 +63,11 @@ struct ma_lu_plan {
   bool batch_panel = false; int batch_nb = 32; int batch_lds = 56 * 1024;   // measured: the staged pipeline of per-system panel kernels is faster; MA_LU_BATCH_PANEL=1 selects this form
   hipEvent_t ev_bp = nullptr, ev_lane[LU_BATCH_MAX] = {};
   int last_bp_nsys = 0;           // > 0: the last factorisation used batched panels over that many systems (its panel partition differs)
+  // staged use with GROUPS: slots [k group, (k+1) group) move in lock step and share one panel kernel per panel (a wavefront per
+  // system, lu_panel_wave_kernel); different groups sit at different block indices, so one group's latency-bound chain runs under
+  // the other groups' trailing updates. 0 / 1: every slot on its own (the round-1 pipeline).
+  int stage_group = 0;
+  bool stage_lane_pending[LU_BATCH_MAX] = {};
 };
 
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
@@ -390,7 +395,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   // batched panels: block g's panels for ALL systems. Stream sps[0] carries the panel kernels; after each one every system
   // does its own small work for that panel (lists + inverted blocks, interchanges, U12, the update of the block's remaining
   // columns) on its own stream, and the next panel kernel waits for all of them.
-  bool lane_pending[LU_BATCH_MAX] = {false, false, false, false};
+  bool lane_pending[LU_BATCH_MAX] = {};
   auto lane_bp = [&](int g) -> int {
     hipStream_t s0 = sps[0];
     const int e = blk_end(g);
@@ -543,7 +548,8 @@ struct Stage {
   ma_lu_plan* P; int n, tstride, nrhs; hipStream_t st; int rc = MA_OK;
   std::vector<int> k0s, nbs, rpbs, nblks; int Q = 0, kb = 1, G = 0;
   explicit Stage(ma_lu_plan* P_, hipStream_t st_) : P(P_), n(P_->n), tstride(P_->n + P_->nrhs_max), nrhs(P_->cur_nrhs), st(st_) {
-    panel_schedule(P, k0s, nbs, rpbs, nblks);
+    if (P->stage_group >= 2) panel_schedule_batched(P, P->stage_group, k0s, nbs, rpbs, nblks);
+    else panel_schedule(P, k0s, nbs, rpbs, nblks);
     Q = (int)k0s.size();
     kb = effective_kb(P, nbs);
     G = (Q + kb - 1) / kb;
@@ -578,6 +584,42 @@ struct Stage {
         if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
         MA_MARK(t3, sp);
         interval(P, t2, t3, 5);
+      }
+    }
+    return MA_OK;
+  }
+  // group form of the lane: block g's panels for the `cnt` slots of a group, ONE panel kernel per panel (on the first slot's
+  // stream), then every slot's own small work for that panel on its stream; the next panel kernel waits for all of them
+  int lane_group(const int* slots, int cnt, int g) {
+    hipStream_t s0 = lane_stream(slots[0]);
+    const int e = blk_end(g);
+    c64* As_[LU_BATCH_MAX]; int* ipivs[LU_BATCH_MAX]; LuPanelWs wss[LU_BATCH_MAX];
+    for (int i = 0; i < LU_BATCH_MAX; ++i) { const int m = slots[i < cnt ? i : 0]; As_[i] = P->cur_A[m]; ipivs[i] = P->d_ipiv[m]; wss[i] = P->pws_m[m]; }
+    for (int q = blk_first(g); q < blk_last(g); ++q) {
+      const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
+      for (int i = 1; i < cnt; ++i) { const int m = slots[i]; if (P->stage_lane_pending[m]) { MA_HIP(hipStreamWaitEvent(s0, P->ev_lane[m], 0)); P->stage_lane_pending[m] = false; } }
+      MA_MARKD(t0, s0);
+      if ((rc = lu_launch_panel_batch(cnt, As_, n, k0, nb, rpbs[q], nblks[q], P->ncu, wss, ipivs, q == 0 || nbs[q - 1] < 4, s0))) return rc;
+      MA_MARKD(t1, s0);
+      interval(P, t0, t1, 0);
+      MA_HIP(hipEventRecord(P->ev_lane[slots[0]], s0));                        // the group leader's event doubles as "panel done"
+      const int slot_q = (g & 1) * LU_KB_MAX + (q - blk_first(g));
+      for (int i = 0; i < cnt; ++i) {
+        const int m = slots[i];
+        c64* A = P->cur_A[m]; hipStream_t sp = lane_stream(m);
+        if (i > 0) MA_HIP(hipStreamWaitEvent(sp, P->ev_lane[slots[0]], 0));
+        int* lists = P->d_lists[m] + (size_t)slot_q * LU_LISTS_LEN;
+        c64* invd = P->d_invd[m] + (size_t)slot_q * LU_NB_MAX * 32;
+        if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
+        if (a1 < e) {
+          if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
+          if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+          MA_MARK(t2, sp);
+          if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
+          MA_MARK(t3, sp);
+          interval(P, t2, t3, 5);
+        }
+        if (i > 0) { MA_HIP(hipEventRecord(P->ev_lane[m], sp)); P->stage_lane_pending[m] = true; }
       }
     }
     return MA_OK;
@@ -617,6 +659,10 @@ struct Stage {
     MA_MARK(t4, sm);
     interval(P, t3, t4, 5);
     MA_HIP(hipEventRecord(P->ev_mid[m], sm));
+    if (P->stage_group >= 2) {                              // the group's next panels are launched once for all its slots (stage_round)
+      if (narrow && m % P->stage_group != 0) { MA_HIP(hipEventRecord(P->ev_lane[m], sm)); P->stage_lane_pending[m] = true; }
+      return MA_OK;
+    }
     if (narrow && (rc = lane(m, g + 1))) return rc;
     return MA_OK;
   }
@@ -697,8 +743,39 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
   MA_HIP(hipMemsetAsync(P->pws.info + slot, 0, sizeof(int), st));          // this slot's first-zero-pivot word
   MA_HIP(hipEventRecord(P->ev_prep[slot], st));
   MA_HIP(hipStreamWaitEvent(P->panel_streams[slot], P->ev_prep[slot], 0));
+  if (P->stage_group >= 2) {                               // group mode: the first panels start when the whole group has begun (stage_begin_group)
+    if (slot % P->stage_group != 0) { MA_HIP(hipEventRecord(P->ev_lane[slot], P->panel_streams[slot])); P->stage_lane_pending[slot] = true; }
+    return MA_OK;
+  }
   Stage S(P, st);
   return S.lane(slot, 0);
+}
+// Staged use with groups (see ma_lu_plan::stage_group): group_size 0 / 1 = every slot on its own; 2..4 = slots [k g, (k+1) g) share
+// one panel kernel per panel. Set before stage_reset; the slots of a group call stage_begin (any order), then ONE
+// stage_begin_group(first_slot) starts the group's first block column; rounds and finishes as before, the slots of a group
+// always with equal block indices.
+int ma_lu_plan_stage_set_group(ma_lu_plan_t* P, int32_t group_size) {
+  MA_REQUIRE(P && group_size >= 0 && group_size <= LU_GROUP_MAX, MA_ERR_INVALID, "group size must be 0..%d", LU_GROUP_MAX);
+  if (group_size >= 2) {
+    std::vector<int> k0s, nbs, rpbs, nblks;
+    panel_schedule_batched(P, group_size, k0s, nbs, rpbs, nblks);
+    for (size_t q = 0; q < k0s.size(); ++q) {
+      const size_t lds = ((lu_panel_lds_bytes(nbs[q], rpbs[q]) + 15) & ~(size_t)15) * (size_t)group_size;
+      MA_REQUIRE(rpbs[q] <= 64 && (long long)nblks[q] <= (long long)lu_panel_slots_per_cu(lds, lu_panel_regs(1)) * P->ncu, MA_ERR_UNSUPPORTED,
+                 "systems of %d rows are too tall for the shared panel kernel (%d rows per workgroup)", P->n, rpbs[q]);
+    }
+  }
+  P->stage_group = group_size;
+  for (int i = 0; i < LU_BATCH_MAX; ++i) P->stage_lane_pending[i] = false;
+  return MA_OK;
+}
+int ma_lu_plan_stage_begin_group(ma_lu_plan_t* P, int32_t first_slot, void* stream) {
+  MA_REQUIRE(P && P->stage_group >= 2 && first_slot >= 0 && first_slot % P->stage_group == 0 && first_slot + P->stage_group <= LU_BATCH_MAX, MA_ERR_INVALID, "bad group");
+  MA_HIP(hipSetDevice(P->device));
+  int slots[LU_GROUP_MAX];
+  for (int i = 0; i < P->stage_group; ++i) { slots[i] = first_slot + i; MA_REQUIRE(P->cur_A[slots[i]], MA_ERR_INVALID, "slot %d has not begun", slots[i]); }
+  Stage S(P, (hipStream_t)stream);
+  return S.lane_group(slots, P->stage_group, 0);
 }
 // one round: slot slots[i] does block blocks[i] (consecutive rounds of a slot use consecutive blocks 0..G-1)
 int ma_lu_plan_stage_round(ma_lu_plan_t* P, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream) {
@@ -708,6 +785,22 @@ int ma_lu_plan_stage_round(ma_lu_plan_t* P, int32_t count, const int32_t* slots,
   for (int i = 0; i < count; ++i) {
     MA_REQUIRE(slots[i] >= 0 && slots[i] < LU_BATCH_MAX && P->cur_A[slots[i]] && blocks[i] >= 0 && blocks[i] < S.G, MA_ERR_INVALID, "slot %d / block %d", slots[i], blocks[i]);
     int rc = S.mwork(slots[i], blocks[i]); if (rc) return rc;
+  }
+  if (P->stage_group >= 2) {
+    // every group present in this round (all its slots, same block) launches the panels of its next block
+    for (int i = 0; i < count; ++i) {
+      if (slots[i] % P->stage_group != 0) continue;
+      int gs[LU_GROUP_MAX];
+      for (int t = 0; t < P->stage_group; ++t) {
+        gs[t] = slots[i] + t;
+        bool found = false;
+        for (int q = 0; q < count; ++q) found = found || (slots[q] == gs[t] && blocks[q] == blocks[i]);
+        MA_REQUIRE(found, MA_ERR_INVALID, "slot %d of the group of slot %d is missing from the round (or at another block)", gs[t], slots[i]);
+      }
+      const int g = blocks[i];
+      const int e = S.blk_end(g);
+      if (P->n - e > 0 && g + 1 < S.G) { int rc = S.lane_group(gs, P->stage_group, g + 1); if (rc) return rc; }
+    }
   }
   // the big updates of the round, smallest first: the slot closest to the end of its factorisation has the least slack in
   // its chain (its next block waits for this update), the one at the start has the most
@@ -783,7 +876,7 @@ int ma_lu_plan_factor_solve_dev(ma_lu_plan_t* P, void* dA, void* dB, int32_t nrh
 // nmat (1..MA_LU_BATCH_MAX) independent n x n systems, e.g. the frequencies of a sweep kept in flight together.
 int ma_lu_plan_factor_solve_batch_dev(ma_lu_plan_t* P, int32_t nmat, void* const* dAs, void* const* dBs, int32_t nrhs, void* stream) {
   MA_REQUIRE(P && dAs, MA_ERR_INVALID, "NULL argument");
-  MA_REQUIRE(nmat >= 1 && nmat <= LU_BATCH_MAX, MA_ERR_INVALID, "batch must be 1..%d systems", LU_BATCH_MAX);
+  MA_REQUIRE(nmat >= 1 && nmat <= LU_GROUP_MAX, MA_ERR_INVALID, "batch must be 1..%d systems", LU_GROUP_MAX);
   MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max, MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
   MA_REQUIRE(nrhs == 0 || dBs, MA_ERR_INVALID, "d_Bs is NULL");
   c64* As[LU_BATCH_MAX]; c64* Bs[LU_BATCH_MAX];

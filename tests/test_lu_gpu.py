@@ -254,6 +254,76 @@ def test_staged_pipeline_is_bitwise_the_single_solve(gpu):
     lu.close()
 
 
+def test_staged_groups_are_bitwise_the_single_solve(gpu):
+    """The staged API with GROUPS: two groups of three slots, each group in lock step with ONE panel kernel per panel for its
+    three systems (lu_panel_wave_kernel, a wavefront per system, 32-column panels), the groups staggered by half a
+    factorisation. Twelve systems; every factor and solution bit for bit what a single factor+solve with 32-column panels gives."""
+    import torch
+    n = 900
+    dev = torch.device("cuda", 0)
+    mats = [_rand(n, 500 + i) for i in range(12)]
+    st = torch.cuda.current_stream().cuda_stream
+    with _with_env(MA_LU_NB=32):
+        lu1 = ma.LuPlan(n)
+    singles = []
+    for A, b in mats:
+        dA = torch.tensor(A, device=dev).reshape(-1); db = torch.tensor(b, device=dev)
+        lu1.factor_solve_dev(dA.data_ptr(), db.data_ptr(), 1, st)
+        assert lu1.status(st) == ma.MA_OK
+        singles.append((dA.cpu().numpy().copy(), db.cpu().numpy().copy()))
+    lu1.close()
+    lu = ma.LuPlan(n)
+    gsz, U = 3, 2
+    lu.stage_set_group(gsz)
+    G = lu.num_blocks()
+    S = gsz * U
+    bufA = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
+    bufB = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
+    srcA = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; srcB = [torch.tensor(b, device=dev) for _, b in mats]
+    outA = [None] * len(mats); outB = [None] * len(mats)
+    off = [u * (G // U) for u in range(U)]
+    lu.stage_reset(st)
+    r = 0
+    while True:
+        sl, bl, live = [], [], False
+        for u in range(U):
+            lr = r - off[u]
+            if lr < 0:
+                live = True
+                continue
+            sysno, g = divmod(lr, G)
+            base = (u + U * sysno) * gsz
+            if base + gsz > len(mats):
+                continue
+            live = True
+            if g == 0:
+                for t in range(gsz):
+                    s_ = u * gsz + t
+                    bufA[s_].copy_(srcA[base + t]); bufB[s_].copy_(srcB[base + t])
+                    lu.stage_begin(s_, bufA[s_].data_ptr(), bufB[s_].data_ptr(), 1, st)
+                lu.stage_begin_group(u * gsz, st)
+            for t in range(gsz):
+                sl.append(u * gsz + t); bl.append(g)
+        if not live:
+            break
+        if sl:
+            lu.stage_round(sl, bl, st)
+        for s_, g in zip(sl, bl):
+            if g == G - 1:
+                lu.stage_finish(s_, st)
+                u, t = divmod(s_, gsz)
+                idx = (u + U * ((r - off[u]) // G)) * gsz + t
+                outA[idx] = bufA[s_].clone(); outB[idx] = bufB[s_].clone()
+        r += 1
+    assert lu.status(st) == ma.MA_OK
+    for i, (Af, xf) in enumerate(singles):
+        assert np.array_equal(outA[i].cpu().numpy(), Af), i
+        assert np.array_equal(outB[i].cpu().numpy(), xf), i
+    with pytest.raises(ma.MaError):
+        lu.stage_round([0, 1], [0, 0], st)                 # a group must appear whole
+    lu.close()
+
+
 def test_lu_tall_system_switches_panel_width(gpu):
     """Above 36 352 rows a 64-column panel no longer fits the LDS of the co-resident workgroups: the factorisation starts with
     32-column panels (8 per trailing update) and widens to 64 once the remaining rows fit. 36 900 rows cross that boundary;
