@@ -248,7 +248,11 @@ int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, voi
 int ma_csr_sym_gauss_seidel(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int sweeps);
 int ma_csr_sym_gauss_seidel_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* stream);
 int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int mode, int backward, void* stream);
-int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward);   /* launches per sweep (diagnostic) */
+int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward);   /* dependency levels per sweep (diagnostic) */
+/* MA_CSR_GS_PERSISTENT=1 runs a sweep as ONE persistent launch (a device-wide barrier per level instead of a kernel boundary; same
+ * arithmetic, same results; measured slower than the launches, so off by default); ma_csr_status synchronises and reports
+ * MA_ERR_HIP if such a sweep ever gave up at a barrier (bounded spin). */
+int ma_csr_status(ma_csr_t* h);
 
 /* math-fem geometric-multigrid smoothers on the COO HelmholtzMatrix (math-fem/src/assembly/helmholtz.rs:22-33,
  * multigrid/smoother.rs:44-68, 120-160, 163-176). The triplets are summed once into a CSR operator (an ma_csr_t: all

@@ -252,6 +252,89 @@ __global__ __launch_bounds__(256) void csr_gs_level_kernel(CsrView A, const int*
   }
 }
 
+// One Gauss-Seidel sweep as ONE persistent launch: the workgroups walk the dependency levels together, with a device-wide barrier
+// between two levels instead of a kernel boundary (298 levels per direction on the 10^6-DoF box: 596 launches of ~3000 rows
+// each per symmetric sweep were launch-latency-bound). Rows are handled exactly as in csr_gs_level_kernel (16 lanes per row, the
+// same reduction), so the results are the level launches' bit for bit. x is the only array written during the sweep and read
+// by other workgroups afterwards: its loads and stores go to the device coherence point (agent-scope relaxed atomics = sc1
+// accesses on gfx950: the per-XCD L2s are not coherent with each other inside a kernel), a workgroup's stores are drained
+// (s_waitcnt vmcnt(0)) before it arrives at the barrier, and the barrier is a monotonic counter (bar[0]) that workgroup
+// leaders increment and poll. The grid is sized by the caller to be co-resident (no LDS, few registers: one workgroup per
+// CU always fits next to anything that terminates); every spin is bounded (2 s) and reports through bar[1].
+__device__ __forceinline__ dc ld_coherent(const dc* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return dc_make(__longlong_as_double((long long)a), __longlong_as_double((long long)b));
+}
+__device__ __forceinline__ void st_coherent(dc* p, dc v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q, (unsigned long long)__double_as_longlong(v.re), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (unsigned long long)__double_as_longlong(v.im), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool KM, int MODE>
+__global__ __launch_bounds__(256) void csr_gs_persistent_kernel(CsrView A, const int* __restrict__ rows, const long long* __restrict__ lev_ptr, int nlev,
+                                                                dc* x, const dc* __restrict__ b, unsigned* bar, unsigned base, unsigned gbase) {
+  constexpr int G = 16;
+  const int lg = threadIdx.x & (G - 1);
+  const long long group0 = ((long long)blockIdx.x * 256 + threadIdx.x) / G, ngroups = (long long)gridDim.x * (256 / G);
+  for (int L = 0; L < nlev; ++L) {
+    const long long beg_l = lev_ptr[L], end_l = lev_ptr[L + 1];
+    for (long long t = beg_l + group0; t < end_l; t += ngroups) {
+      const int i = rows[t];
+      const long long beg = A.row_ptr[i], end = A.row_ptr[i + 1];
+      double sr = 0.0, si = 0.0, dr = 0.0, di = 0.0, have = 0.0;
+      for (long long idx = beg + lg; idx < end; idx += G) {
+        double ar, ai;
+        if (KM) { const double kv = A.K[idx], mv = A.M[idx]; ar = kv - A.k2_re * mv; ai = -(A.k2_im * mv); }
+        else { const dc v = A.val[idx]; ar = v.re; ai = v.im; }
+        const int j = A.col[idx];
+        if (j == i) { dr += ar; di += ai; have = 1.0; }
+        else { const dc xv = ld_coherent(x + j); sr += ar * xv.re - ai * xv.im; si += ar * xv.im + ai * xv.re; }
+      }
+      sr = group_sum<G>(sr); si = group_sum<G>(si); dr = group_sum<G>(dr); di = group_sum<G>(di); have = group_sum<G>(have);
+      if (lg != 0) continue;
+      if (MODE == 1 && have == 0.0) { dr = 1.0; di = 0.0; }
+      const double nd = hypot(dr, di);
+      if (MODE == 1 ? !(nd > 1e-15) : (nd < 1e-15)) continue;
+      const dc bb = b[i];
+      const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
+      if (MODE == 1) { const double ir = dr / ns, ii = -di / ns; st_coherent(x + i, dc_make(nr * ir - ni * ii, nr * ii + ni * ir)); }
+      else st_coherent(x + i, dc_make((nr * dr + ni * di) / ns, (ni * dr - nr * di) / ns));
+    }
+    if (L + 1 == nlev) break;                              // the kernel boundary orders the last level
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's x stores have reached the coherence point
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // two-level arrival: 8 groups (workgroup b -> group b % 8 = its XCD under the round-robin placement) count their members on
+      // their own cache lines; the last member of a group arrives at the global counter, which everybody polls
+      const unsigned ngrp = gridDim.x < 8u ? gridDim.x : 8u, grp = blockIdx.x % ngrp;
+      const unsigned gsize = (gridDim.x - grp + ngrp - 1) / ngrp;
+      const unsigned old = __hip_atomic_fetch_add(bar + 32 * (1 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((old + 1u - gbase) == (unsigned)(L + 1) * gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned target = base + (unsigned)(L + 1) * ngrp;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 2 s at 100 MHz
+      }
+    }
+    __syncthreads();
+  }
+}
+// returns the number of barrier arrivals the launch adds to bar[0] (the caller keeps the running total for `base`)
+int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* rows, const long long* lev_ptr, int nlev, int grid, c64* x, const c64* b,
+                             unsigned* bar, unsigned base, unsigned gbase, hipStream_t st) {
+  if (nlev <= 0) return MA_OK;
+  dc* xx = reinterpret_cast<dc*>(x); const dc* bb = reinterpret_cast<const dc*>(b);
+  dim3 g((unsigned)grid), block(256);
+  if (km) { if (mode) hipLaunchKernelGGL((csr_gs_persistent_kernel<true, 1>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase);
+            else hipLaunchKernelGGL((csr_gs_persistent_kernel<true, 0>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase); }
+  else { if (mode) hipLaunchKernelGGL((csr_gs_persistent_kernel<false, 1>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase);
+         else hipLaunchKernelGGL((csr_gs_persistent_kernel<false, 0>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase); }
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, int count, c64* x, const c64* b, hipStream_t st) {
   if (count <= 0) return MA_OK;
   dim3 grid((unsigned)(((long long)count * 16 + 255) / 256)), block(256);

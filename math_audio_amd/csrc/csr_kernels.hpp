@@ -28,6 +28,8 @@ struct CsrView {
 };
 
 int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st);
+int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* rows, const long long* lev_ptr, int nlev, int grid, c64* x, const c64* b,
+                             unsigned* bar, unsigned base, unsigned gbase, hipStream_t st);
 int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, int count, c64* x, const c64* b, hipStream_t st);
 int csr_launch_diag(const CsrView& A, bool km, c64* dinv, double* l1, hipStream_t st);
 int csr_launch_assemble(long long nnz, const double* K, const double* M, double k2re, double k2im, int nb, const double* const* B, const double* cre, const double* cim,

@@ -287,3 +287,47 @@ def test_full_size_fem_box(gpu):
     assert abs(r[0]) <= 1e-12 * abs(b[0])
     assert op.gauss_seidel_levels() == (298, 298)
     op.close()
+
+
+def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
+    """The persistent sweep (one launch, a device-wide barrier per dependency level) against a launch per level: the same rows, the
+    same 16-lane reduction, so the iterates must agree bit for bit -- forward, backward, both modes, the fused K - k^2 M operator
+    and stored complex values, on a box with 46 levels and on an unsymmetric random pattern."""
+    def _xvec(m):
+        i = np.arange(m)
+        return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
+    nodes, rp, ci, K, M = fem.helmholtz_box(12, 10, 8)
+    n = len(rp) - 1
+    b = _xvec(n); x0 = 0.3 * _xvec(n)[::-1].copy()
+    k = 1.3 + 0.2j
+    outs = {}
+    for pers in ("1", "0"):
+        monkeypatch.setenv("MA_CSR_GS_PERSISTENT", pers)
+        h = ma.CsrOperator(rp, ci, K=K, M=M); h.set_wavenumber(k)
+        fwd, bwd = h.gauss_seidel_levels()
+        assert fwd >= 8 and bwd >= 8
+        x1 = h.sym_gauss_seidel(x0, b, 2)
+        hc = ma.CsrOperator.from_coo(n, np.repeat(np.arange(n), np.diff(rp)), ci, O.helmholtz_values(K, M, k))
+        x2 = hc.fem_smooth(x0, b, kind=0, iterations=3)
+        x3 = hc.fem_smooth(x0, b, kind=2, iterations=1)
+        outs[pers] = (x1, x2, x3)
+        h.close(); hc.close()
+    for a, c in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a, c)
+    vals = O.helmholtz_values(K, M, k)
+    ref = O.amg_sym_gauss_seidel(rp, ci, vals, x0, b, 2)
+    assert np.abs(outs["1"][0] - ref).max() <= 1e-12 * np.abs(ref).max()
+    rng = np.random.default_rng(11)
+    import scipy.sparse as sp
+    R = sp.random(700, 700, density=0.01, random_state=5, format="csr").astype(np.complex128)
+    R.data = rng.standard_normal(R.nnz) + 1j * rng.standard_normal(R.nnz)
+    R = (R + sp.diags(8.0 + rng.standard_normal(700))).tocsr(); R.sort_indices()
+    bb = _xvec(700); res = {}
+    for pers in ("1", "0"):
+        monkeypatch.setenv("MA_CSR_GS_PERSISTENT", pers)
+        h = ma.CsrOperator(R.indptr, R.indices, values=R.data)
+        res[pers] = h.sym_gauss_seidel(np.zeros(700, dtype=complex), bb, 3)
+        h.close()
+    assert np.array_equal(res["1"], res["0"])
+    refu = O.amg_sym_gauss_seidel(R.indptr, R.indices, R.data, np.zeros(700, dtype=complex), bb, 3)
+    assert np.abs(res["1"] - refu).max() <= 1e-12 * np.abs(refu).max()
