@@ -316,12 +316,13 @@ def main():
             batch(first + s, c)
             s += c
 
-    def assemble_into(step, slot):
+    def assemble_into(step, slot, on=None):
+        on = stream if on is None else on
         f = freqs[(rank + step * world) % len(freqs)]
         k = mm.wave_number(f, C_SOUND)
         beta = mm.burton_miller_beta_scaled(k, 4.0)
-        plan.assemble_dev(k, beta, As[slot].data_ptr(), xs_[slot].data_ptr(), stream=stream)
-        plan.incident_rhs_dev(k, beta, xs_[slot].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
+        plan.assemble_dev(k, beta, As[slot].data_ptr(), xs_[slot].data_ptr(), stream=on)
+        plan.incident_rhs_dev(k, beta, xs_[slot].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=on)
 
     def run_pipeline(first, nsteps):
         """The same frequencies through the staged schedule: slot s works on steps s, s + S, ... and starts a quarter of a
@@ -334,6 +335,8 @@ def main():
         spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or max(1, (G + slots) // (slots + 1))   # rounds between the starts of two slots (G/4 for 3 slots measured best: 59.9 vs 60.7 ms at G/3)
         off = [s * spacing for s in range(slots)]
         lu.stage_reset(stream)
+        asm_lane = os.environ.get("MA_BENCH_ASM_LANE", "0") != "0"
+        lanes = [lu.slot_stream(s) for s in range(slots)]
         r = 0
         while True:
             sl, bl, live = [], [], False
@@ -347,9 +350,10 @@ def main():
                 if idx >= nsteps:
                     continue
                 live = True
+                own = lanes[s] if asm_lane else stream
                 if g == 0:
-                    assemble_into(first + idx, s)
-                    lu.stage_begin(s, As[s].data_ptr(), xs_[s].data_ptr(), 1, stream)
+                    assemble_into(first + idx, s, own)
+                    lu.stage_begin(s, As[s].data_ptr(), xs_[s].data_ptr(), 1, own)
                 sl.append(s); bl.append(g)
             if not live:
                 break
@@ -357,8 +361,60 @@ def main():
                 lu.stage_round(sl, bl, stream)
             for s, g in zip(sl, bl):
                 if g == G - 1:
-                    lu.stage_finish(s, stream)
+                    lu.stage_finish(s, lanes[s] if asm_lane else stream)
             r += 1
+        if timing:
+            lu_ms[:] += lu.last_timing()
+            upd[:] += lu.last_update_stats()
+
+    def run_pipeline_model(first, nsteps):
+        """The staged schedule WITHOUT rounds. The caller's stream carries the big updates (and the assemblies) of all slots in
+        ONE order; in rounds -- every slot one block per round -- a slot near the end of its factorisation (tiny update, 2 ms
+        of chain per block) waits each round for the updates of the slots near their start (2.5 ms of matrix-core work each).
+        Here the order comes from a small model of the pipeline (lane chain, per-panel work, update time ~ (rows left)^2): the
+        next job on the caller's stream is always the one that becomes ready first, so slots advance at their own pace."""
+        slots = max(1, min(S, nsteps))
+        G = lu.num_blocks()
+        lanes = [lu.slot_stream(s_) for s_ in range(slots)]
+        Lm = float(os.environ.get("MA_MODEL_LANE", "2.6")); Mm = float(os.environ.get("MA_MODEL_MWORK", "0.9"))
+        Bm = float(os.environ.get("MA_MODEL_BIG", "3.0")); Am = float(os.environ.get("MA_MODEL_ASM", "5.5")); Km = float(os.environ.get("MA_MODEL_BACK", "1.5"))
+        gap0 = float(os.environ.get("MA_MODEL_STAGGER", "0")) or (G * (Lm + Mm) + Am) / slots
+        blk = 256.0
+        def big_ms(g):
+            left = max(0.0, n - blk * (g + 1))
+            return Bm * (left / n) ** 2
+        lu.stage_reset(stream)
+        t_main = 0.0
+        # per slot: next job ("asm" or block index), when it becomes eligible, lane end time of the block, end of the previous big
+        sysno = [0] * slots; job = ["asm"] * slots; elig = [s_ * gap0 for s_ in range(slots)]
+        t_lane = [0.0] * slots; t_bigdone = [0.0] * slots
+        active = [s_ < nsteps for s_ in range(slots)]
+        while any(active):
+            s_ = min((i for i in range(slots) if active[i]), key=lambda i: elig[i])
+            idx = s_ + slots * sysno[s_]
+            if job[s_] == "asm":
+                start = max(t_main, elig[s_]); t_main = start + Am
+                assemble_into(first + idx, s_, stream)
+                lu.stage_begin(s_, As[s_].data_ptr(), xs_[s_].data_ptr(), 1, stream)
+                t_lane[s_] = t_main + Lm; t_bigdone[s_] = t_main
+                job[s_] = 0
+                elig[s_] = max(t_lane[s_], t_bigdone[s_]) + Mm          # t_mid of block 0
+            else:
+                g = job[s_]
+                t_mid = elig[s_]
+                start = max(t_main, t_mid); dur = big_ms(g); t_main = start + dur
+                lu.stage_round([s_], [g], stream)
+                t_bigdone[s_] = t_main if dur > 0 else t_mid
+                t_lane[s_] = t_mid + Lm
+                if g == G - 1:
+                    lu.stage_finish(s_, stream)
+                    sysno[s_] += 1
+                    job[s_] = "asm"; elig[s_] = t_mid + Km
+                    if s_ + slots * sysno[s_] >= nsteps:
+                        active[s_] = False
+                else:
+                    job[s_] = g + 1
+                    elig[s_] = max(t_lane[s_], t_bigdone[s_]) + Mm
         if timing:
             lu_ms[:] += lu.last_timing()
             upd[:] += lu.last_update_stats()
@@ -408,12 +464,21 @@ def main():
             upd[:] += lu.last_update_stats()
 
     run = run_pipeline if args.schedule == "pipeline" else run_batches
+    if args.schedule == "pipeline" and not gsz and os.environ.get("MA_SWEEP_ORDER", "rounds") == "model":
+        run = run_pipeline_model
 
     run(0, args.warmup)
     torch.cuda.synchronize()
     if lu.status(stream) != ma.MA_OK:
         raise SystemExit("warm-up solve failed: %s" % ma.lib().ma_last_error_string().decode())
 
+    if os.environ.get("MA_BENCH_HOST_PROBE"):
+        # how fast can the host enqueue? three systems into empty queues on an idle device: no back-pressure yet
+        th = time.perf_counter()
+        run(args.warmup, min(S, 3))
+        th = time.perf_counter() - th
+        torch.cuda.synchronize()
+        sys.stderr.write("host probe: %.1f ms to enqueue %d systems into empty queues\n" % (th * 1e3, min(S, 3)))
     timing = not args.no_timing
     plan.set_timing(timing); lu.set_timing(2 if (timing and args.schedule == "pipeline") else timing)
     if timing and args.schedule == "pipeline":
@@ -423,6 +488,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
+    t_enqueued = time.perf_counter() - t0            # host time to enqueue the timed steps (the device may still be running)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -456,6 +522,7 @@ def main():
 
     if rank == 0:
         K = args.steps
+        sys.stderr.write("host enqueue %.1f ms per step of %.1f ms per step\n" % (t_enqueued * 1e3 / K, elapsed * 1e3 / K))
         total_pairs = float(n) * n * K * world
         out = {
             "metric": "bem_sweep_panel_pairs_per_s", "value": total_pairs / elapsed, "unit": "panel-pairs/s",

@@ -414,6 +414,10 @@ int ma_bem_plan_get_near_pairs(const ma_bem_plan_t* plan, int32_t* out_pairs);
 int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma_c64* B, ma_c64* C);
 /* Measured issue rate of v_mfma_f64_16x16x4_f64 over the whole chip, TFLOP/s (roofline peak check). */
 int ma_probe_mfma_f64(int device, double* tflops);
+/* Diagnostics (tools/panel_cotenancy.py): `repeat` launches of the trailing-update kernel on device buffers (C[M][N] -= A[M][K] B[K][N],
+ * tight leading dimensions) / of the matrix-core probe (d_out: 256 * blocks doubles) on `stream`, as background load. */
+int ma_diag_zgemm_dev(int32_t M, int32_t N, int32_t K, const void* dA, const void* dB, void* dC, int32_t repeat, void* stream);
+int ma_diag_mfma_burn(void* d_out, int32_t blocks, int32_t iters, int32_t repeat, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diagnostics used by bench.py / tests: elapsed GPU time (ms) of the tagged phases of the most

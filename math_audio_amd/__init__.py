@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmathaudio_hip.so")
+LIB_PATH = os.environ.get("MA_LIB_PATH") or os.path.join(_HERE, "lib", "libmathaudio_hip.so")     # MA_LIB_PATH: a diagnostic build (tools/)
 
 MA_OK, MA_ERR_SINGULAR, MA_ERR_DIM, MA_ERR_INVALID, MA_ERR_UNSUPPORTED, MA_ERR_HIP, MA_ERR_NO_DEVICE, MA_ERR_NOMEM = range(8)
 _STATUS_NAMES = ["MA_OK", "MA_ERR_SINGULAR", "MA_ERR_DIM", "MA_ERR_INVALID", "MA_ERR_UNSUPPORTED", "MA_ERR_HIP",
@@ -167,6 +167,8 @@ def lib():
             "ma_room_field_pressure": [i32, vp, vp, vp, vp, i32, vp, vp, C.c_int, i32, vp, dbl, vp],
             "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
             "ma_probe_mfma_f64": [C.c_int, P(dbl)],
+            "ma_diag_zgemm_dev": [i32, i32, i32, vp, vp, vp, i32, vp],
+            "ma_diag_mfma_burn": [vp, i32, i32, i32, vp],
         }
         for name, args in sig.items():
             if hasattr(L, name):

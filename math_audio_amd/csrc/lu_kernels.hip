@@ -1526,6 +1526,14 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
   return MA_OK;
 }
 
+// a stream is about to be destroyed (its work is over): the sequencer must not wait on, or query, events recorded on it
+void lu_panel_forget_stream(int dev, hipStream_t st) {
+  if (dev < 0 || dev >= 16 || !st) return;
+  std::lock_guard<std::mutex> lock(g_seq.mu);
+  if (!g_seq.made[dev]) return;
+  for (int i = 0; i < kSeqRing; ++i) if (g_seq.ring[dev][i].used && g_seq.ring[dev][i].st == st) { g_seq.ring[dev][i].used = false; g_seq.ring[dev][i].st = nullptr; }
+}
+
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
   return launch_panel_any(1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
 }

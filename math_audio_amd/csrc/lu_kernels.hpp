@@ -28,6 +28,7 @@ size_t lu_panel_granule_bytes(int max_blocks);
 int lu_panel_configure();
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
 int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st);
+void lu_panel_forget_stream(int dev, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);
 int lu_panel_slots_per_cu(size_t lds, int regs);
 int lu_panel_regs(int kind);   /* 0 lu_panel_kernel, 1 lu_panel_wave_kernel */

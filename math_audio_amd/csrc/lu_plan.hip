@@ -214,6 +214,8 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   // nothing of this plan may still be running when its streams and workspaces go (the panel sequencer keeps events that
   // were recorded on these streams)
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) (void)hipStreamSynchronize(P->panel_streams[i]); if (P->mid_streams[i]) (void)hipStreamSynchronize(P->mid_streams[i]); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { lu_panel_forget_stream(P->device, P->panel_streams[i]); lu_panel_forget_stream(P->device, P->mid_streams[i]); }
+  lu_panel_forget_stream(P->device, P->panel_stream);
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
   if (P->ev_bp) (void)hipEventDestroy(P->ev_bp);
@@ -1066,6 +1068,22 @@ int ma_lu_plan_panel_stamps(ma_lu_plan_t* P, unsigned long long* out8, int reset
   MA_HIP(hipMemcpy(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   if (reset) MA_HIP(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
   return MA_OK;
+}
+
+// Diagnostics (tools/panel_cotenancy.py): background load on a stream of the caller's -- `repeat` launches of the trailing-update
+// kernel on device buffers (tight leading dimensions), or of the matrix-core probe (d_out: 256 * blocks doubles)
+int ma_diag_zgemm_dev(int32_t M, int32_t N, int32_t K, const void* dA, const void* dB, void* dC, int32_t repeat, void* stream) {
+  MA_REQUIRE(dA && dB && dC && M > 0 && N > 0 && K > 0, MA_ERR_INVALID, "bad argument");
+  int rc = MA_OK;
+  for (int i = 0; i < repeat && !rc; ++i)
+    rc = lu_launch_zgemm_sub(M, N, K, (const c64*)dA, (size_t)K, (const c64*)dB, (size_t)N, (c64*)dC, (size_t)N, (hipStream_t)stream, true);
+  return rc;
+}
+int ma_diag_mfma_burn(void* d_out, int32_t blocks, int32_t iters, int32_t repeat, void* stream) {
+  MA_REQUIRE(d_out && blocks > 0 && iters > 0, MA_ERR_INVALID, "bad argument");
+  int rc = MA_OK;
+  for (int i = 0; i < repeat && !rc; ++i) rc = lu_launch_mfma_probe((double*)d_out, blocks, iters, (hipStream_t)stream);
+  return rc;
 }
 
 // MFMA f64 issue-rate probe (bench.py uses it to state the measured matrix-core peak next to the

@@ -451,7 +451,7 @@ def test_round1_fault_configuration_now_runs(gpu):
         lu = ma.LuPlan(n)
     dAs = [A.clone().reshape(-1) for A in As]; dbs = [b.clone() for b in bs]
     lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
-    assert lu.status(st) == ma.MA_OK
+    assert lu.status(st) == ma.MA_OK, ma.lib().ma_last_error_string()
     for A, b, x in zip(As, bs, dbs):
         assert float(torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)) < 1e-10
     lu.close()
