@@ -1227,14 +1227,66 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
 #ifndef MA_ZGEMM_MAXWAVES
 #define MA_ZGEMM_MAXWAVES 2
 #endif
+// Tile order. ctr == nullptr: workgroup (bx, by) takes tile (bx, by). ctr != nullptr (large updates): a grid of <= 2 workgroups
+// per CU DRAWS its tiles: the tiles are grouped in blocks of 8 x 8, block s belongs to XCD s mod 8, and a workgroup asks the
+// counter of the XCD it runs on (XCC_ID, read at run time -- the dispatcher's placement is not a function of blockIdx once other
+// kernels are in flight) for the next tile of that XCD's blocks; 64 consecutive draws are one block, so the <= 64 workgroups
+// an XCD runs at a time share 8 row panels of A and 8 column panels of B in that XCD's L2 instead of fetching each over the
+// fabric (every tile needs 2 x 64 x K entries of A and B for 64 x 64 of C). An XCD whose blocks are exhausted draws from the
+// next XCD's. ctr[0..7] draws, ctr[8] workgroups that have left; the last one zeroes the counters for the launch that
+// reuses them.
+__device__ __forceinline__ unsigned zg_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7u;
+}
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
-                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
+                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc, unsigned* __restrict__ ctr, int one_tile) {
   __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
   __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_tile[2];
+  const int tid0 = threadIdx.x;
+  const int gx = (N + Z3_BN - 1) / Z3_BN, gy = (M + Z3_BM - 1) / Z3_BM;
+  const int sgx = (gx + 7) >> 3, NS = sgx * ((gy + 7) >> 3);
+  const unsigned myx = ctr ? zg_xcc_id() : 0u;
+  for (bool first = true;; first = false) {
+  // the per-thread index arithmetic is redone for every tile (the opaque copy keeps it from being hoisted out of the tile loop
+  // and carried in registers across it: the kernel has to stay within 176 of them to share a SIMD with two panel wavefronts)
+  int tid = tid0;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * Z3_BM, n0 = blockIdx.x * Z3_BN;
   const int li = lane & 15, lk = lane >> 4;
+  int m0, n0;
+  if (!ctr) {
+    if (!first) break;
+    m0 = blockIdx.y * Z3_BM; n0 = blockIdx.x * Z3_BN;
+  } else {
+    if (tid == 0) {
+      int ty = -1, tx = -1;
+      for (int v = 0; v < 8 && ty < 0; ++v) {
+        const int x = (int)((myx + (unsigned)v) & 7u);
+        const unsigned space = (unsigned)((NS - x + 7) / 8) * 64u;          // draws of XCD x: its blocks s = x, x + 8, ... times 64 tiles
+        for (;;) {
+          const unsigned r = atomicAdd(ctr + x, 1u);
+          if (r >= space) break;
+          const int sblk = x + 8 * (int)(r >> 6), t = (int)(r & 63u);
+          const int sy = sblk / sgx, sx = sblk - sy * sgx;
+          const int y = sy * 8 + (t >> 3), xx = sx * 8 + (t & 7);
+          if (y < gy && xx < gx) { ty = y; tx = xx; break; }
+        }
+      }
+      s_tile[0] = ty; s_tile[1] = tx;
+    }
+    __syncthreads();
+    const int ty = __builtin_amdgcn_readfirstlane(s_tile[0]), tx = __builtin_amdgcn_readfirstlane(s_tile[1]);   // uniform: keep the tile origin on the scalar side
+    __syncthreads();                                                        // s_tile is rewritten by the next draw
+    if (ty < 0) {
+      if (tid == 0 && atomicAdd(ctr + 8, 1u) == gridDim.x - 1u) { for (int i = 0; i < 9; ++i) ctr[i] = 0u; }
+      break;
+    }
+    m0 = ty * Z3_BM; n0 = tx * Z3_BN;
+  }
 
   v4d t1[2][2], t2[2][2], t3[2][2];
 #pragma unroll
@@ -1308,6 +1360,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZG
           *pc = c;
         }
       }
+  __syncthreads();                                                          // the next tile's first stage overwrites the LDS buffers
+  if (ctr && one_tile) {                                             // one tile per workgroup (grid = tiles): leave, counting out
+    if (tid == 0 && atomicAdd(ctr + 8, 1u) == gridDim.x - 1u) { for (int i = 0; i < 9; ++i) ctr[i] = 0u; }
+    break;
+  }
+  }
 }
 
 // thin-N variant for the right-hand sides (N = nrhs small): y[m] -= sum_k A[m][k] x[k]; one wave per row
@@ -1614,8 +1672,41 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
   if (use_3m) {
     dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
-    hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
-                       reinterpret_cast<dc*>(C), ldc);
+    // large updates draw their tiles XCD by XCD (see the kernel): a ring of counter blocks per device, one block per launch,
+    // zeroed at allocation and again by the last workgroup of the launch that used it
+    const char* e_xcd = getenv("MA_ZGEMM_XCD_TILES");                       // read per launch: the tests switch it
+    const int xcd_min_tiles = e_xcd ? atoi(e_xcd) : 1024;
+    unsigned* ctr = nullptr;
+    unsigned grid_draw = 0;
+    if (xcd_min_tiles > 0 && (long long)g3.x * g3.y >= xcd_min_tiles) {
+      int dev = 0;
+      MA_HIP(hipGetDevice(&dev));
+      if (dev >= 0 && dev < 16) {
+        static std::mutex mu;
+        static unsigned* ring[16] = {};
+        static unsigned long long seq[16] = {};
+        static int ncu[16] = {};
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev]) {
+          hipDeviceProp_t prop;
+          MA_HIP(hipGetDeviceProperties(&prop, dev));
+          ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+          MA_HIP(hipMalloc(&ring[dev], sizeof(unsigned) * 16 * 4096));
+          MA_HIP(hipMemset(ring[dev], 0, sizeof(unsigned) * 16 * 4096));
+          MA_HIP(hipDeviceSynchronize());
+        }
+        ctr = ring[dev] + 16 * (size_t)(seq[dev]++ % 4096ull);
+        grid_draw = (unsigned)std::min<long long>((long long)g3.x * g3.y, 2LL * ncu[dev]);
+      }
+    }
+    const char* e_per = getenv("MA_ZGEMM_XCD_PERSIST");
+    const bool one_tile = !(e_per && atoi(e_per) != 0);
+    if (ctr && one_tile) hipLaunchKernelGGL(zgemm3m_sub_kernel, dim3(g3.x * g3.y), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+                                reinterpret_cast<dc*>(C), ldc, ctr, 1);
+    else if (ctr) hipLaunchKernelGGL(zgemm3m_sub_kernel, dim3(grid_draw), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+                                reinterpret_cast<dc*>(C), ldc, ctr, 0);
+    else hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+                            reinterpret_cast<dc*>(C), ldc, (unsigned*)nullptr, 0);
     MA_HIP(hipGetLastError());
     return MA_OK;
   }

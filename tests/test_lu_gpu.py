@@ -31,6 +31,23 @@ def test_zgemm_sub_kernel(gpu, M, N, K):
     assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K,persist", [(700, 1100, 64, 0), (1300, 900, 256, 0), (515, 2100, 40, 1), (64, 64, 8, 0)])
+def test_zgemm_sub_kernel_drawing_its_tiles(gpu, M, N, K, persist):
+    """Large updates draw their tiles XCD by XCD (8 x 8 blocks of tiles per XCD, counters per launch, stealing when an XCD runs
+    dry; lu_kernels.hip): every tile exactly once whatever the placement, ragged edges, blocks that are partly outside the
+    matrix, and the counters are left at zero for the launch that reuses them (the same shape twice)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)) + 1j * rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    Cm = rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))
+    ref = Cm - A @ B
+    with _with_env(MA_ZGEMM_XCD_TILES=1, MA_ZGEMM_XCD_PERSIST=persist):
+        for _ in range(2):
+            got = ma.test_zgemm_sub(A, B, Cm)
+            assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
+    assert np.array_equal(ma.test_zgemm_sub(A, B, Cm), got)      # the plain tile order gives the same bits: tiles are independent
+
+
 def test_lu_solve_real_2x2(gpu):            # lu.rs:163-175
     A = np.array([[4.0, 1.0], [1.0, 3.0]]); b = np.array([1.0, 2.0])
     x = ma.zgesv(A, b)
