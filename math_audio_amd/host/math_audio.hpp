@@ -7,6 +7,9 @@
 //   math_solvers::lu_solve -> Result (LuError)            (math-solvers/src/direct/lu.rs)
 //   math_solvers::CsrMatrix / LinearOperator / DenseOperator / DiagonalPreconditioner / GmresConfig / GmresSolution /
 //            gmres / gmres_with_guess / gmres_preconditioned   (math-solvers/src/{sparse/csr,traits,iterative/gmres,preconditioners/diagonal}.rs)
+//   math_solvers::AmgPreconditioner (V/W/F cycle over a hierarchy the caller built) / gmres_pipelined   (preconditioners/amg.rs, iterative/gmres_pipelined.rs)
+//   math_bem::Cluster / SlfmmSystem (build_slfmm_system + its LinearOperator) / TbemOperator (matrix-free, one or several GPUs) /
+//            solve_frequency_sweep (the `for freq` loop of bin/room_simulator_bem.rs:329 as one call, one or several GPUs)
 // Header-only; links against libmathaudio_hip.so. No CPU fallback: errors come back as exceptions or
 // Result values carrying the C status code.
 #pragma once
@@ -460,6 +463,58 @@ inline GmresSolution gmres_preconditioned_with_guess(const LinearOperator& a, co
   return detail::run_gmres(a, &m, b, x0, c);
 }
 
+// preconditioners/amg.rs:74-118 (AmgConfig), 981-1103 (v_cycle, apply): the hierarchy is the caller's (AmgPreconditioner::from_csr,
+// amg.rs:276-372, stays on the host); levels[l] = {A_l, P_l (n_l x n_{l+1}), R_l (n_{l+1} x n_l)}, P and R empty on the coarsest level
+enum class AmgSmoother { Jacobi = 0, L1Jacobi = 1, SymmetricGaussSeidel = 2 };
+enum class AmgCycle { V = 0, W = 1, F = 2 };
+struct AmgConfig {
+  AmgSmoother smoother = AmgSmoother::Jacobi;
+  double jacobi_weight = 0.6667;
+  size_t num_pre_smooth = 1, num_post_smooth = 1;
+  AmgCycle cycle = AmgCycle::V;
+};
+struct AmgLevel { const CsrMatrix* matrix = nullptr; const CsrMatrix* prolongation = nullptr; const CsrMatrix* restriction = nullptr; };
+class AmgPreconditioner : public Preconditioner {
+ public:
+  AmgPreconditioner(const std::vector<AmgLevel>& levels, const AmgConfig& c) {
+    if (levels.empty()) throw SolverError(MA_ERR_INVALID, "AmgPreconditioner: no levels");
+    std::vector<ma_csr_t*> a, p, r;
+    for (size_t l = 0; l < levels.size(); ++l) {
+      if (!levels[l].matrix) throw SolverError(MA_ERR_INVALID, "AmgPreconditioner: level without a matrix");
+      a.push_back(levels[l].matrix->csr_handle());
+      if (l + 1 < levels.size()) {
+        if (!levels[l].prolongation || !levels[l].restriction) throw SolverError(MA_ERR_INVALID, "AmgPreconditioner: level without P / R");
+        p.push_back(rect(*levels[l].prolongation)); r.push_back(rect(*levels[l].restriction));
+      }
+    }
+    solver_check(ma_precond_create_amg((int32_t)levels.size(), a.data(), p.data(), r.data(), (int32_t)c.smoother, c.jacobi_weight,
+                                       (int32_t)c.num_pre_smooth, (int32_t)c.num_post_smooth, (int32_t)c.cycle, &h_));
+  }
+  ~AmgPreconditioner() override { if (h_) ma_precond_destroy(h_); for (ma_csr_t* q : owned_) ma_csr_destroy(q); }
+  AmgPreconditioner(const AmgPreconditioner&) = delete;
+  AmgPreconditioner& operator=(const AmgPreconditioner&) = delete;
+  ma_precond_t* handle() const override { return h_; }
+ private:
+  ma_csr_t* rect(const CsrMatrix& m) {
+    ma_csr_t* q = nullptr;
+    solver_check(ma_csr_create_rect((int64_t)m.num_rows_, (int64_t)m.num_cols_, m.row_ptrs.data(), m.col_indices.data(), reinterpret_cast<const ma_c64*>(m.values.data()), 0, &q));
+    owned_.push_back(q);
+    return q;
+  }
+  ma_precond_t* h_ = nullptr;
+  std::vector<ma_csr_t*> owned_;
+};
+
+// iterative/gmres_pipelined.rs:18-250: gmres_pipelined(operator, precond, b, x0, config); precond may be null (IdentityPreconditioner)
+inline GmresSolution gmres_pipelined(const LinearOperator& a, const Preconditioner* m, const std::vector<Complex64>& b, const std::vector<Complex64>* x0, const GmresConfig& c) {
+  GmresSolution s; s.x.resize(b.size());
+  ma_gmres_info_t info{};
+  solver_check(ma_gmres_pipelined(a.handle(), m ? m->handle() : nullptr, reinterpret_cast<const ma_c64*>(b.data()), x0 ? reinterpret_cast<const ma_c64*>(x0->data()) : nullptr,
+                                  (int32_t)c.restart, (int32_t)c.max_iterations, c.tolerance, reinterpret_cast<ma_c64*>(s.x.data()), &info));
+  s.iterations = (size_t)info.iterations; s.restarts = (size_t)info.restarts; s.residual = info.residual; s.converged = info.converged != 0;
+  return s;
+}
+
 // AmgPreconditioner's smoothers (preconditioners/amg.rs:855-884, 887-929, 932-978) on the device operator: x is updated in place
 inline void smooth_jacobi(const CsrMatrix& a, std::vector<Complex64>& x, const std::vector<Complex64>& b, double omega, size_t num_sweeps) {
   solver_check(ma_csr_jacobi(a.csr_handle(), reinterpret_cast<ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), omega, (int)num_sweeps));
@@ -509,3 +564,111 @@ inline std::vector<Complex64> compute_residual(const HelmholtzMatrix& m, const s
 }
 }  // namespace math_fem
 
+// ---------------------------------------------------------------- operators over a mesh: matrix-free TBEM, SLFMM, the sweep
+namespace math_bem {
+
+// types.rs:445-488, the fields build_slfmm_system reads
+struct Cluster {
+  std::array<double, 3> center{};
+  std::vector<size_t> element_indices, near_clusters, far_clusters;
+};
+
+// owns the device copy of a mesh (ma_bem_plan_t): what the operators below borrow
+class BemPlan {
+ public:
+  BemPlan(const std::vector<Element>& elements, const std::vector<double>& nodes, int device = 0) {
+    detail::flatten(elements, nodes, F_);
+    const int rc = ma_bem_plan_create(&F_.c, device, &h_);
+    if (rc != MA_OK) throw BemError(rc, ma_last_error_string());
+  }
+  ~BemPlan() { if (h_) ma_bem_plan_destroy(h_); }
+  BemPlan(const BemPlan&) = delete;
+  BemPlan& operator=(const BemPlan&) = delete;
+  ma_bem_plan_t* handle() const { return h_; }
+  const ma_mesh_t& mesh() const { return F_.c; }
+  size_t num_dofs() const { int32_t n = 0; ma_bem_plan_num_dofs(h_, &n); return (size_t)n; }
+ private:
+  detail::Flat F_;
+  ma_bem_plan_t* h_ = nullptr;
+};
+
+// the matrix-free TBEM operator (BASELINE configs[4]): y = A x of the dense Burton-Miller matrix without storing it; with
+// several devices the collocation rows are sharded inside the library (ma_op_create_tbem_multi)
+class TbemOperator : public math_solvers::LinearOperator {
+ public:
+  TbemOperator(const BemPlan& plan, const PhysicsParams& p, Complex64 beta) : n_(plan.num_dofs()) {
+    const ma_physics_t ph = detail::phys(p);
+    math_solvers::solver_check(ma_op_create_tbem(plan.handle(), &ph, beta.real(), beta.imag(), 0, (int32_t)n_, &op_));
+  }
+  TbemOperator(const std::vector<Element>& elements, const std::vector<double>& nodes, const PhysicsParams& p, Complex64 beta, const std::vector<int32_t>& devices) {
+    detail::Flat F; detail::flatten(elements, nodes, F);
+    const ma_physics_t ph = detail::phys(p);
+    math_solvers::solver_check(ma_op_create_tbem_multi(&F.c, &ph, beta.real(), beta.imag(), devices.data(), (int32_t)devices.size(), &op_));
+    int64_t n = 0; ma_op_num_rows(op_, &n); n_ = (size_t)n;
+  }
+  ~TbemOperator() override { if (op_) ma_op_destroy(op_); }
+  TbemOperator(const TbemOperator&) = delete;
+  TbemOperator& operator=(const TbemOperator&) = delete;
+  size_t num_rows() const override { return n_; }
+  size_t num_cols() const override { return n_; }
+  ma_op_t* handle() const override { return op_; }
+  size_t num_shards() const { int32_t s = 0; ma_op_num_shards(op_, &s, nullptr, nullptr); return (size_t)s; }
+ private:
+  size_t n_ = 0; ma_op_t* op_ = nullptr;
+};
+
+// build_slfmm_system(elements, nodes, clusters, physics, n_theta, n_phi, n_terms) -> SlfmmSystem (slfmm.rs:417-470) with its
+// LinearOperator impl (matvec :150-257, matvec_transpose :262-376) and extract_near_field_matrix (:104-132)
+class SlfmmSystem : public math_solvers::LinearOperator {
+ public:
+  SlfmmSystem(const BemPlan& plan, const std::vector<Cluster>& clusters, const PhysicsParams& p, size_t n_theta, size_t n_phi, size_t n_terms) : n_(plan.num_dofs()) {
+    std::vector<double> center; std::vector<int32_t> ep{0}, ei, np_{0}, ni, fp{0}, fi;
+    for (const Cluster& c : clusters) {
+      center.insert(center.end(), c.center.begin(), c.center.end());
+      for (size_t e : c.element_indices) ei.push_back((int32_t)e);
+      for (size_t e : c.near_clusters) ni.push_back((int32_t)e);
+      for (size_t e : c.far_clusters) fi.push_back((int32_t)e);
+      ep.push_back((int32_t)ei.size()); np_.push_back((int32_t)ni.size()); fp.push_back((int32_t)fi.size());
+    }
+    const ma_clusters_t cl{(int32_t)clusters.size(), center.data(), ep.data(), ei.data(), np_.data(), ni.data(), fp.data(), fi.data()};
+    const ma_physics_t ph = detail::phys(p);
+    math_solvers::solver_check(ma_op_create_slfmm(plan.handle(), &cl, &ph, (int32_t)n_theta, (int32_t)n_phi, (int32_t)n_terms, &op_));
+  }
+  ~SlfmmSystem() override { if (op_) ma_op_destroy(op_); }
+  SlfmmSystem(const SlfmmSystem&) = delete;
+  SlfmmSystem& operator=(const SlfmmSystem&) = delete;
+  std::vector<Complex64> matvec(const std::vector<Complex64>& x) const { return apply(x); }
+  std::vector<Complex64> matvec_transpose(const std::vector<Complex64>& x) const { return apply_transpose(x); }
+  std::vector<Complex64> extract_near_field_matrix() const {
+    std::vector<Complex64> a(n_ * n_);
+    math_solvers::solver_check(ma_op_slfmm_near_matrix(op_, reinterpret_cast<ma_c64*>(a.data())));
+    return a;
+  }
+  size_t num_rows() const override { return n_; }
+  size_t num_cols() const override { return n_; }
+  ma_op_t* handle() const override { return op_; }
+ private:
+  size_t n_; ma_op_t* op_ = nullptr;
+};
+
+// the `for freq in frequencies` loop of bin/room_simulator_bem.rs:329 (assemble, incident RHS, solve per frequency) as one call:
+// beta = i beta_scale / k per frequency (BemSolver, bem_solver.rs:225, 366); devices.size() > 1 shards the frequencies
+// (frequency f on devices[f mod ndev]). Returns the surface solutions, one vector per frequency; status[f] is MA_OK or MA_ERR_SINGULAR.
+inline std::vector<std::vector<Complex64>> solve_frequency_sweep(const std::vector<Element>& elements, const std::vector<double>& nodes,
+                                                                 const std::vector<double>& frequencies_hz, double speed_of_sound, double beta_scale,
+                                                                 const IncidentField& incident, const std::vector<int32_t>& devices = {0},
+                                                                 std::vector<int32_t>* status = nullptr, double harmonic_factor = 1.0, double tau = 1.0) {
+  detail::Flat F; detail::flatten(elements, nodes, F);
+  const size_t nf = frequencies_hz.size(), n = (size_t)F.c.n_elem;
+  std::vector<Complex64> X(nf * n);
+  std::vector<int32_t> st(nf, 0);
+  const int rc = ma_bem_solve_sweep_multi(&F.c, devices.data(), (int32_t)devices.size(), (int32_t)nf, frequencies_hz.data(), speed_of_sound, harmonic_factor, tau,
+                                          beta_scale, incident.kind, incident.v, incident.amp.real(), incident.amp.imag(), 3, reinterpret_cast<ma_c64*>(X.data()), st.data());
+  if (rc != MA_OK) throw BemError(rc, ma_last_error_string());
+  if (status) *status = st;
+  std::vector<std::vector<Complex64>> out(nf);
+  for (size_t f = 0; f < nf; ++f) out[f].assign(X.begin() + (std::ptrdiff_t)(f * n), X.begin() + (std::ptrdiff_t)((f + 1) * n));
+  return out;
+}
+
+}  // namespace math_bem

@@ -167,6 +167,100 @@ static void test_fem_smoothers_reduce_residual() {
   CHECK(norm(ax) < r0);
 }
 
+// ---- round 2: AMG cycle + pipelined GMRES (amg.rs:981-1103, gmres_pipelined.rs:258-285), the operators over a mesh, the sweep
+static void test_amg_and_pipelined_gmres() {
+  using namespace math_solvers;
+  // gmres_pipelined.rs:258-285: the 2 x 2 system
+  CsrMatrix a2 = CsrMatrix::from_dense({4, 1, 1, 3}, 2, 2, 1e-15);
+  std::vector<Complex64> b2 = {{1, 0}, {2, 0}};
+  auto sp = gmres_pipelined(a2, nullptr, b2, nullptr, GmresConfig{100, 10, 1e-10, 0});
+  CHECK(sp.converged);
+  auto ax = a2.matvec(sp.x);
+  CHECK(std::sqrt(std::norm(ax[0] - b2[0]) + std::norm(ax[1] - b2[1])) < 1e-8);
+  // two-level hierarchy of the 1D Laplacian: aggregates of two, P piecewise constant, R = P^T, A_c = R A P
+  const size_t n = 64, nc = n / 2;
+  std::vector<std::tuple<size_t, size_t, Complex64>> ta, tp, tr, tc;
+  for (size_t i = 0; i < n; ++i) {
+    ta.emplace_back(i, i, Complex64(2.0, 0.1));
+    if (i > 0) ta.emplace_back(i, i - 1, Complex64(-1.0, 0.0));
+    if (i + 1 < n) ta.emplace_back(i, i + 1, Complex64(-1.0, 0.0));
+    tp.emplace_back(i, i / 2, Complex64(1.0, 0.0)); tr.emplace_back(i / 2, i, Complex64(1.0, 0.0));
+  }
+  for (size_t I = 0; I < nc; ++I) {                        // R A P of the tridiagonal matrix: (2 (2 + 0.1i) - 2) on the diagonal, -1 beside it
+    tc.emplace_back(I, I, Complex64(2.0, 0.2));
+    if (I > 0) tc.emplace_back(I, I - 1, Complex64(-1.0, 0.0));
+    if (I + 1 < nc) tc.emplace_back(I, I + 1, Complex64(-1.0, 0.0));
+  }
+  CsrMatrix A = CsrMatrix::from_triplets(n, n, ta), P = CsrMatrix::from_triplets(n, nc, tp), R = CsrMatrix::from_triplets(nc, n, tr), Ac = CsrMatrix::from_triplets(nc, nc, tc);
+  AmgConfig cfg; cfg.num_pre_smooth = 2; cfg.num_post_smooth = 2;
+  AmgPreconditioner amg({AmgLevel{&A, &P, &R}, AmgLevel{&Ac, nullptr, nullptr}}, cfg);
+  std::vector<Complex64> b(n); for (size_t i = 0; i < n; ++i) b[i] = Complex64(std::sin(0.2 * (double)i), std::cos(0.1 * (double)i));
+  auto norm = [](const std::vector<Complex64>& z) { double s = 0; for (auto& e : z) s += std::norm(e); return std::sqrt(s); };
+  auto z = amg.apply(b);                                   // one V-cycle from zero is a contraction: ||b - A z|| < ||b||
+  auto az = A.matvec(z); for (size_t i = 0; i < n; ++i) az[i] = b[i] - az[i];
+  CHECK(norm(az) < norm(b));
+  auto s_amg = gmres_preconditioned(A, amg, b, GmresConfig{200, 30, 1e-10, 0});
+  auto s_plain = gmres(A, b, GmresConfig{200, 30, 1e-10, 0});
+  CHECK(s_amg.converged && s_plain.converged && s_amg.iterations < s_plain.iterations);
+  auto s_pp = gmres_pipelined(A, &amg, b, nullptr, GmresConfig{200, 30, 1e-10, 0});
+  CHECK(s_pp.converged);
+  auto r = A.matvec(s_pp.x); for (size_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
+  CHECK(norm(r) < 1e-7 * norm(b));
+}
+static void test_mesh_operators_and_sweep() {
+  using namespace math_bem;
+  Mesh mesh = generate_icosphere_mesh(0.1, 2);             // 320 panels
+  const size_t n = mesh.elements.size();
+  const double c0 = 343.0, f1 = 500.0;
+  PhysicsParams ph(f1, c0, 1.21, false);
+  const Complex64 beta = ph.burton_miller_beta_scaled(4.0);
+  TbemSystem sys = build_tbem_system_with_beta(mesh.elements, mesh.nodes, ph, beta);
+  std::vector<Complex64> x(n); for (size_t i = 0; i < n; ++i) x[i] = Complex64(std::cos(0.37 * (double)i), std::sin(0.11 * (double)i));
+  auto dense = [&](const std::vector<Complex64>& v) { std::vector<Complex64> y(n); for (size_t i = 0; i < n; ++i) { Complex64 s(0, 0); for (size_t j = 0; j < n; ++j) s += sys.matrix[i * n + j] * v[j]; y[i] = s; } return y; };
+  auto norm = [](const std::vector<Complex64>& z) { double s = 0; for (auto& e : z) s += std::norm(e); return std::sqrt(s); };
+  auto diff = [&](const std::vector<Complex64>& a, const std::vector<Complex64>& b) { std::vector<Complex64> d(a.size()); for (size_t i = 0; i < a.size(); ++i) d[i] = a[i] - b[i]; return norm(d); };
+  BemPlan plan(mesh.elements, mesh.nodes);
+  const auto yd = dense(x);
+  TbemOperator op(plan, ph, beta);                         // matrix-free: equals A x of the stored matrix
+  CHECK(diff(op.apply(x), yd) < 1e-10 * norm(yd));
+  TbemOperator op1(mesh.elements, mesh.nodes, ph, beta, {0});   // the sharded form with one shard
+  CHECK(op1.num_shards() == 1 && diff(op1.apply(x), yd) < 1e-10 * norm(yd));
+  // SLFMM over grid clusters: <A x, z> = <x, A^T z>, near matrix with a non-zero diagonal (slfmm.rs:790-877)
+  std::map<std::array<long, 3>, std::vector<size_t>> cells;
+  const double cell = 0.07;
+  for (size_t e = 0; e < n; ++e) { std::array<long, 3> k; for (int d = 0; d < 3; ++d) k[d] = (long)std::floor((mesh.elements[e].center[d] + 0.2) / cell); cells[k].push_back(e); }
+  std::vector<Cluster> cl; std::vector<std::array<long, 3>> keys;
+  for (auto& kv : cells) { Cluster c; for (int d = 0; d < 3; ++d) c.center[d] = -0.2 + ((double)kv.first[d] + 0.5) * cell; c.element_indices = kv.second; cl.push_back(c); keys.push_back(kv.first); }
+  for (size_t a = 0; a < cl.size(); ++a) for (size_t b = 0; b < cl.size(); ++b) {
+    if (a == b) continue;
+    bool nb = true; for (int d = 0; d < 3; ++d) nb = nb && std::labs(keys[a][d] - keys[b][d]) <= 1;
+    (nb ? cl[a].near_clusters : cl[a].far_clusters).push_back(b);
+  }
+  SlfmmSystem fmm(plan, cl, ph, 4, 8, 6);
+  std::vector<Complex64> z(n); for (size_t i = 0; i < n; ++i) z[i] = Complex64(std::sin(0.23 * (double)i), 0.5);
+  auto Ax = fmm.matvec(x), Atz = fmm.matvec_transpose(z);
+  Complex64 l(0, 0), r(0, 0); for (size_t i = 0; i < n; ++i) { l += Ax[i] * z[i]; r += x[i] * Atz[i]; }
+  CHECK(std::abs(l - r) < 1e-10 * std::abs(l));
+  auto nearm = fmm.extract_near_field_matrix();
+  bool diag_ok = true; for (size_t i = 0; i < n; ++i) diag_ok = diag_ok && std::abs(nearm[i * n + i]) > 0.0;
+  CHECK(diag_ok);
+  // the sweep: two frequencies in one call against assemble + RHS + lu_solve per frequency
+  const std::vector<double> freqs = {300.0, 700.0};
+  std::vector<int32_t> status;
+  auto sols = solve_frequency_sweep(mesh.elements, mesh.nodes, freqs, c0, 4.0, IncidentField::plane_wave_z(), {0}, &status);
+  std::vector<double> centers, normals;
+  for (auto& e : mesh.elements) { for (int d = 0; d < 3; ++d) { centers.push_back(e.center[d]); normals.push_back(e.normal[d]); } }
+  for (size_t f = 0; f < freqs.size(); ++f) {
+    PhysicsParams pf(freqs[f], c0, 1.21, false);
+    const Complex64 bf = pf.burton_miller_beta_scaled(4.0);
+    TbemSystem sf = build_tbem_system_with_beta(mesh.elements, mesh.nodes, pf, bf);
+    auto rhs = IncidentField::plane_wave_z().compute_rhs_with_beta(centers, normals, pf, bf);
+    for (size_t i = 0; i < n; ++i) rhs[i] += sf.rhs[i];
+    auto ref = math_solvers::lu_solve(sf.matrix, n, n, rhs);
+    CHECK(ref.is_ok() && status[f] == MA_OK && diff(sols[f], ref.value) < 1e-9 * norm(ref.value));
+  }
+}
+
 int main() {
   int n = 0;
   if (ma_device_count(&n) != MA_OK || n <= 0) { std::printf("no HIP device: the host mirror has no CPU fallback\n"); return 77; }
@@ -174,6 +268,8 @@ int main() {
   test_tbem_diagonal_nonzero_and_qa();
   test_csr_from_dense_matvec_triplets(); test_diagonal_preconditioner(); test_gmres_simple_identity_preconditioned();
   test_fem_smoothers_reduce_residual();
+  test_amg_and_pipelined_gmres();
+  test_mesh_operators_and_sweep();
   std::printf(failures ? "%d check(s) failed\n" : "host mirror: all checks passed\n", failures);
   return failures ? 1 : 0;
 }
