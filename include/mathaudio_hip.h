@@ -318,6 +318,29 @@ typedef struct {
 int ma_op_create_slfmm(ma_bem_plan_t* plan, const ma_clusters_t* clusters, const ma_physics_t* physics,
                        int32_t n_theta, int32_t n_phi, int32_t n_terms, ma_op_t** out);
 int ma_op_slfmm_near_matrix(ma_op_t* op, ma_c64* A_rowmajor);
+/* Multi-level fast multipole operator.
+ * Replaces: build_cluster_tree(elements, target_elements_per_leaf, physics) -> Vec<ClusterLevel>   math-bem/src/core/assembly/mlfmm.rs:979-1038
+ *           (estimate_num_levels :954-974, subdivide_level :1056-1180, compute_near_far_lists :1183-1223): host code, the reference's
+ *           arithmetic in the reference's order; ma_cluster_tree_level_get hands the lists back (any pointer may be NULL; sizes from
+ *           ma_cluster_tree_level_info: n_clusters(+1 for the *_ptr arrays), n_elem_listed, n_near, n_far, n_sons);
+ *           build_mlfmm_system(elements, nodes, cluster_tree, physics) -> MlfmmSystem (:483-558) and MlfmmOperator's LinearOperator impl
+ *           (solver/fmm_interface.rs:98-135): apply = MlfmmSystem::matvec (:128-460); apply_transpose is unimplemented!() there and
+ *           MA_ERR_UNSUPPORTED here.
+ * The reference's operator is its "simplified model" (:838-840), taken as it stands: near blocks for (i, i) and (i, j > i) with the
+ * (j, i) block applied as the transpose, no free term, element centres ON an octant boundary listed in every octant they touch (their
+ * dofs are summed once per leaf). Levels above the first one with a far pair contribute nothing and are skipped; every level from
+ * there down must have a tabulated theta_points (4..8, 10, 12, 16, 20), else MA_ERR_UNSUPPORTED: gauss.rs:27-60 would give the
+ * reference a longer sphere rule than theta_points * phi_points and its length guards would drop stages. Velocity-type boundary
+ * conditions, no evaluation elements. */
+typedef struct ma_cluster_tree ma_cluster_tree_t;
+int ma_cluster_tree_build(const ma_mesh_t* mesh, int32_t target_elements_per_leaf, double wave_number, ma_cluster_tree_t** out);
+int ma_cluster_tree_destroy(ma_cluster_tree_t* tree);
+int ma_cluster_tree_num_levels(const ma_cluster_tree_t* tree, int32_t* levels);
+int ma_cluster_tree_level_info(const ma_cluster_tree_t* tree, int32_t level, int32_t* n_clusters, int32_t* expansion_terms, int32_t* theta_points, int32_t* phi_points,
+                               int64_t* n_elem_listed, int64_t* n_near, int64_t* n_far, int64_t* n_sons);
+int ma_cluster_tree_level_get(const ma_cluster_tree_t* tree, int32_t level, double* center, double* radius, int32_t* elem_ptr, int32_t* elem_idx, int32_t* near_ptr, int32_t* near_idx,
+                              int32_t* far_ptr, int32_t* far_idx, int32_t* son_ptr, int32_t* son_idx, int32_t* father);
+int ma_op_create_mlfmm(ma_bem_plan_t* plan, const ma_cluster_tree_t* tree, const ma_physics_t* physics, ma_op_t** out);
 /* number of shards of an operator (1 unless row-sharded) and, optionally, their first rows and devices */
 int ma_op_num_shards(const ma_op_t* op, int32_t* shards, int32_t* row_begin_or_null, int32_t* device_or_null);
 int ma_op_destroy(ma_op_t* op);

@@ -138,6 +138,12 @@ def lib():
             "ma_op_num_shards": [vp, P(i32), vp, vp],
             "ma_op_create_slfmm": [vp, P(ma_clusters_t), P(ma_physics_t), i32, i32, i32, P(vp)],
             "ma_op_slfmm_near_matrix": [vp, vp],
+            "ma_cluster_tree_build": [P(ma_mesh_t), i32, dbl, P(vp)],
+            "ma_cluster_tree_destroy": [vp],
+            "ma_cluster_tree_num_levels": [vp, P(i32)],
+            "ma_cluster_tree_level_info": [vp, i32, P(i32), P(i32), P(i32), P(i32), P(i64), P(i64), P(i64), P(i64)],
+            "ma_cluster_tree_level_get": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+            "ma_op_create_mlfmm": [vp, vp, P(ma_physics_t), P(vp)],
             "ma_op_destroy": [vp],
             "ma_op_num_rows": [vp, P(i64)],
             "ma_op_apply": [vp, vp, vp],
@@ -540,6 +546,44 @@ class CsrOperator:
         check(lib().ma_csr_l1jacobi_dev(self.h, C.c_void_p(d_x), C.c_void_p(d_b), int(sweeps), C.c_void_p(d_tmp), C.c_void_p(stream)))
 
 
+class ClusterTree:
+    """build_cluster_tree(elements, target_elements_per_leaf, physics) (mlfmm.rs:979-1038), built on the host by the library."""
+
+    def __init__(self, mesh, target_elements_per_leaf, k):
+        self.h = C.c_void_p()
+        check(lib().ma_cluster_tree_build(C.byref(mesh.c), int(target_elements_per_leaf), float(k), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ma_cluster_tree_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_levels(self):
+        n = C.c_int32()
+        check(lib().ma_cluster_tree_num_levels(self.h, C.byref(n)))
+        return n.value
+
+    def level(self, l):
+        """dict of the level's parameters and lists (centres, radii, element / near / far / son lists as offset + index arrays, fathers)."""
+        nc, terms, theta, phi = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        ne, nn, nf, ns = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().ma_cluster_tree_level_info(self.h, l, C.byref(nc), C.byref(terms), C.byref(theta), C.byref(phi), C.byref(ne), C.byref(nn), C.byref(nf), C.byref(ns)))
+        n = nc.value
+        out = {"n_clusters": n, "expansion_terms": terms.value, "theta_points": theta.value, "phi_points": phi.value,
+               "center": np.zeros((n, 3)), "radius": np.zeros(n), "father": np.zeros(n, dtype=np.int32)}
+        for nm, cnt in (("elem", ne.value), ("near", nn.value), ("far", nf.value), ("son", ns.value)):
+            out[nm + "_ptr"] = np.zeros(n + 1, dtype=np.int32); out[nm + "_idx"] = np.zeros(max(cnt, 1), dtype=np.int32)[:cnt]
+        check(lib().ma_cluster_tree_level_get(self.h, l, _vp(out["center"]), _vp(out["radius"]), _vp(out["elem_ptr"]), _vp(out["elem_idx"]), _vp(out["near_ptr"]), _vp(out["near_idx"]),
+                                              _vp(out["far_ptr"]), _vp(out["far_idx"]), _vp(out["son_ptr"]), _vp(out["son_idx"]), _vp(out["father"])))
+        return out
+
+
 class GmresInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("restarts", C.c_int32), ("converged", C.c_int32), ("residual", C.c_double)]
 
@@ -601,6 +645,14 @@ class LinearOperator:
         h = C.c_void_p()
         check(lib().ma_op_create_slfmm(plan.h, C.byref(cs), C.byref(ph), int(n_theta), int(n_phi), int(n_terms), C.byref(h)))
         return LinearOperator(h, (plan, arrs))
+
+    @staticmethod
+    def mlfmm(plan, tree, k, harmonic=1.0, tau=1.0):
+        """ma_op_create_mlfmm: build_mlfmm_system + MlfmmSystem::matvec (assembly/mlfmm.rs) over a ClusterTree."""
+        ph = physics(k, harmonic, tau)
+        h = C.c_void_p()
+        check(lib().ma_op_create_mlfmm(plan.h, tree.h, C.byref(ph), C.byref(h)))
+        return LinearOperator(h, plan)
 
     def slfmm_near_matrix(self):
         """SlfmmSystem::extract_near_field_matrix (slfmm.rs:104-132)."""

@@ -34,6 +34,7 @@ struct ma_slfmm {
   int* d_fptr = nullptr; int* d_foth = nullptr; c64* d_fval = nullptr;      // far pairs grouped by field cluster (forward)
   int* d_tptr = nullptr; int* d_toth = nullptr; c64* d_tval = nullptr;      // grouped by source cluster (transpose)
   c64* d_up = nullptr; c64* d_tr = nullptr;
+  bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
   // host copies for extract_near_field_matrix
   std::vector<int> h_eptr, h_edof, h_bsrc, h_bfld; std::vector<long long> h_boff;
 };
@@ -70,7 +71,7 @@ void spherical_hankel_first_kind(int order, double x, double harmonic, std::vect
 // near blocks: every row of cluster c sums all its contributions in the order of the cluster's entry list
 __global__ __launch_bounds__(256) void slfmm_near_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
                                                          const SlfmmEntry* __restrict__ cent, const dc* __restrict__ bval, const dc* __restrict__ x,
-                                                         dc* __restrict__ y, int tmode) {
+                                                         dc* __restrict__ y, int tmode, int overlap) {
   const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e0 = eptr[c], nc_ = eptr[c + 1] - e0;
   for (int i = wave; i < nc_; i += 4) {
@@ -88,7 +89,11 @@ __global__ __launch_bounds__(256) void slfmm_near_kernel(const int* __restrict__
       }
     }
     sr = wave_sum(sr); si = wave_sum(si);
-    if (lane == 0) y[edof[e0 + i]] = dc_make(sr, si);
+    if (lane == 0) {
+      dc* o = y + edof[e0 + i];
+      if (overlap) { atomicAdd(&o->re, sr); atomicAdd(&o->im, si); }       // the dof is a row of several clusters
+      else *o = dc_make(sr, si);
+    }
   }
 }
 // up[c][p] = sum_j w_p exp(i sgn k s_p . (x_j - C_c)) x[dof_j]     (sgn -1: T x; +1: S^T x)
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void slfmm_translate_kernel(const int* __restr
 // y[dof_j] += sum_p w_p exp(i sgn k s_p . (x_j - C_c)) tr[c][p]     (sgn +1: S l; -1: T^T m)
 __global__ __launch_bounds__(256) void slfmm_down_kernel(BemGeom g, const int* __restrict__ eptr, const int* __restrict__ eidx, const int* __restrict__ edof,
                                                          const double* __restrict__ cc, const double* __restrict__ sc, const double* __restrict__ sw,
-                                                         int P, double k, double sgn, const dc* __restrict__ tr, dc* __restrict__ y) {
+                                                         int P, double k, double sgn, const dc* __restrict__ tr, dc* __restrict__ y, int overlap) {
   const int c = blockIdx.x;
   const int e0 = eptr[c], n = eptr[c + 1] - e0;
   const double Cx = cc[3 * c], Cy = cc[3 * c + 1], Cz = cc[3 * c + 2];
@@ -144,10 +149,12 @@ __global__ __launch_bounds__(256) void slfmm_down_kernel(BemGeom g, const int* _
       sr += er * l.re - ei * l.im; si += er * l.im + ei * l.re;
     }
     dc* o = y + edof[e0 + j];
-    o->re += sr; o->im += si;
+    if (overlap) { atomicAdd(&o->re, sr); atomicAdd(&o->im, si); }
+    else { o->re += sr; o->im += si; }
   }
 }
-// the self blocks' diagonal: singular integral + SLFMM free term. self_vals = coefficient - gamma/2 (TBEM's free term): + gamma
+// the self blocks' diagonal: singular integral (+ SLFMM's free term). self_vals = coefficient - gamma/2 (TBEM's free term): + gamma
+// with slfmm.rs' free term, + gamma / 2 without (mlfmm.rs)
 __global__ void slfmm_fix_diag_kernel(int n, const long long* __restrict__ pos, const int* __restrict__ panel, const dc* __restrict__ selfv, double gamma,
                                       dc* __restrict__ bval) {
   const int q = blockIdx.x * 256 + threadIdx.x;
@@ -187,7 +194,15 @@ void slfmm_destroy(ma_slfmm* S) {
   delete S;
 }
 
+static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_physics_t* physics, int n_theta, int n_phi, int n_terms, bool free_term, bool allow_overlap,
+                           ma_slfmm** out);
 int slfmm_create(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_physics_t* physics, int n_theta, int n_phi, int n_terms, ma_slfmm** out) {
+  return slfmm_create_ex(plan, cl, physics, n_theta, n_phi, n_terms, true, false, out);
+}
+// free_term: slfmm.rs adds gamma / 2 (velocity panels) to the diagonal of the self blocks (:514-533), mlfmm.rs does not (:590-644);
+// allow_overlap: mlfmm.rs' leaves may share elements
+static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_physics_t* physics, int n_theta, int n_phi, int n_terms, bool free_term, bool allow_overlap,
+                           ma_slfmm** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
   MA_REQUIRE(plan && cl && physics, MA_ERR_INVALID, "NULL argument");
   MA_REQUIRE(cl->n_clusters >= 1 && cl->center && cl->elem_ptr && cl->elem_idx && cl->near_ptr && cl->far_ptr, MA_ERR_INVALID, "incomplete cluster lists");
@@ -208,7 +223,7 @@ int slfmm_create(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_physics_t*
     for (int q = cl->elem_ptr[c]; q < cl->elem_ptr[c + 1]; ++q) {
       const int e = cl->elem_idx[q];
       MA_REQUIRE(e >= 0 && e < np, MA_ERR_INVALID, "cluster %d lists element %d outside 0..%d (meshes with evaluation elements are not supported here)", c, e, np - 1);
-      MA_REQUIRE(!seen[(size_t)e], MA_ERR_UNSUPPORTED, "element %d belongs to more than one cluster", e);
+      MA_REQUIRE(allow_overlap || !seen[(size_t)e], MA_ERR_UNSUPPORTED, "element %d belongs to more than one cluster", e);
       MA_REQUIRE(bct[(size_t)e] == 0, MA_ERR_UNSUPPORTED, "element %d: only velocity-type boundary conditions (compute_near_block's coefficient, slfmm.rs:583-584)", e);
       seen[(size_t)e] = 1;
     }
@@ -216,7 +231,7 @@ int slfmm_create(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_physics_t*
     for (int q = cl->far_ptr[c]; q < cl->far_ptr[c + 1]; ++q) MA_REQUIRE(cl->far_idx && cl->far_idx[q] >= 0 && cl->far_idx[q] < nc, MA_ERR_INVALID, "far cluster index out of range");
   }
   ma_slfmm* S = new (std::nothrow) ma_slfmm(); MA_REQUIRE(S, MA_ERR_NOMEM, "host allocation failed");
-  S->device = plan->device; S->plan = plan; S->n = plan->nd; S->nc = nc; S->P = n_theta * n_phi; S->k = physics->wave_number;
+  S->device = plan->device; S->plan = plan; S->n = plan->nd; S->nc = nc; S->P = n_theta * n_phi; S->k = physics->wave_number; S->overlap = allow_overlap;
   auto fail = [&](int code) { slfmm_destroy(S); return code; };
   const int P = S->P;
   // ---- unit_sphere_quadrature (gauss.rs:110-130)
@@ -321,7 +336,7 @@ int slfmm_create(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_physics_t*
   if (!rc) rc = bem_launch_self_list_values(plan->geom, ph, d_self, nullptr);
   if (!rc && !dpos.empty()) {
     hipLaunchKernelGGL(slfmm_fix_diag_kernel, dim3((unsigned)((dpos.size() + 255) / 256)), dim3(256), 0, nullptr, (int)dpos.size(), d_dpos, d_dpanel,
-                       reinterpret_cast<const dc*>(d_self), physics->gamma, reinterpret_cast<dc*>(S->d_bval));
+                       reinterpret_cast<const dc*>(d_self), free_term ? physics->gamma : 0.5 * physics->gamma, reinterpret_cast<dc*>(S->d_bval));
     if (hipGetLastError() != hipSuccess) { set_error("SLFMM diagonal kernel failed"); rc = MA_ERR_HIP; }
   }
   if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("SLFMM near-field kernels failed"); rc = MA_ERR_HIP; }
@@ -336,7 +351,7 @@ int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_
   const BemGeom& g = S->plan->geom;
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));        // dofs outside every cluster receive nothing
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
-  hipLaunchKernelGGL(slfmm_near_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, reinterpret_cast<const dc*>(S->d_bval), x, y, transpose);
+  hipLaunchKernelGGL(slfmm_near_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, reinterpret_cast<const dc*>(S->d_bval), x, y, transpose, S->overlap ? 1 : 0);
   MA_HIP(hipGetLastError());
   // far field: forward T (e^-), D grouped by field, S (e^+); transpose S^T (e^+), D grouped by source, T^T (e^-)
   const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
@@ -347,7 +362,7 @@ int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_
                      reinterpret_cast<const dc*>(transpose ? S->d_tval : S->d_fval), S->P, reinterpret_cast<const dc*>(S->d_up), reinterpret_cast<dc*>(S->d_tr));
   MA_HIP(hipGetLastError());
   hipLaunchKernelGGL(slfmm_down_kernel, dim3(S->nc), dim3(256), 0, st, g, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, s_dn,
-                     reinterpret_cast<const dc*>(S->d_tr), y);
+                     reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -363,5 +378,401 @@ int slfmm_near_matrix(ma_slfmm* S, c64* d_A, hipStream_t st) {
                        S->d_edof + S->h_eptr[(size_t)ci], S->d_edof + S->h_eptr[(size_t)cj], S->n, ci != cj ? 1 : 0, reinterpret_cast<dc*>(d_A));
     MA_HIP(hipGetLastError());
   }
+  return MA_OK;
+}
+
+// =====================================================================================================================
+// Multi-level fast multipole operator (math-bem/src/core/assembly/mlfmm.rs)
+//   build_cluster_tree (:979-1038) with estimate_num_levels (:954-974), subdivide_level (:1056-1180) and
+//   compute_near_far_lists (:1183-1223): HOST code, the same arithmetic in the same order as the reference (the tests compare the
+//   tree with the restatement list by list and centre by centre, bit for bit).
+//   build_mlfmm_system (:483-558) + MlfmmSystem::matvec (:128-460): the leaf level is the single-level machinery above (near
+//   blocks WITHOUT free term, leaf T / D / S); the levels above it add
+//     upward    M_C[p] = w_p sum_sons e^{-i k s_p . (c_son - c_C)} mean(M_son)          (build_t_matrices_level's non-leaf rows
+//                                                                                         are constant over the son's points)
+//     translate L_j[p] += h_0(k |c_i - c_j|) i k  M_i[p]   over the far pairs of every level
+//     downward  L_son[q] += (1 / P_son) sum_p e^{+i k s_p . (c_son - c_C)} w_p L_C[p]     for every point q of the son
+//   None of T, D, S is stored. Levels above the first one that has a far pair carry no information (their locals stay zero) and
+//   are skipped. Supported: every level from that one down has a tabulated theta_points (otherwise gauss_legendre hands the
+//   reference a longer rule than theta_points * phi_points and its length guards drop stages: MA_ERR_UNSUPPORTED here);
+//   velocity-type boundary conditions, no evaluation elements. apply_transpose is unimplemented in the reference
+//   (fmm_interface.rs:131-134) and MA_ERR_UNSUPPORTED here.
+// =====================================================================================================================
+struct HostCluster {
+  double c[3] = {0, 0, 0}; double radius = 0.0;
+  std::vector<int> elems, near, far, sons; int father = -1;
+};
+struct HostLevel {
+  std::vector<HostCluster> cl;
+  int terms = 4, theta = 4, phi = 8;
+  double max_r = 0.0, avg_r = 0.0, min_r = 1.7976931348623157e308;
+};
+struct ma_cluster_tree { std::vector<HostLevel> levels; double k = 0.0; int n_elem = 0; };
+
+namespace {
+int tree_expansion_terms(double kr) {
+  // ((kr + 6.0 * kr.ln().max(1.0)) as usize).clamp(4, 30): f64::max drops a NaN, `as usize` truncates and saturates
+  const double ln = std::log(kr);
+  const double m = (ln != ln || ln < 1.0) ? 1.0 : ln;
+  const double v = kr + 6.0 * m;
+  unsigned long long u;
+  if (v != v || v <= 0.0) u = 0; else if (v >= 1.8446744073709552e19) u = ~0ull; else u = (unsigned long long)v;
+  return (int)std::min<unsigned long long>(std::max<unsigned long long>(u, 4), 30);
+}
+int tree_estimate_num_levels(long long n, long long per_leaf, int min_levels, int max_levels) {
+  if (n == 0) return min_levels;
+  int levels = 1;
+  while (n > per_leaf && levels < max_levels) { n /= 8; levels += 1; }
+  return std::min(std::max(levels, min_levels), max_levels);
+}
+void tree_near_far(std::vector<HostCluster>& cl, double k) {
+  const int n = (int)cl.size();
+  for (int i = 0; i < n; ++i) {
+    cl[(size_t)i].near.clear(); cl[(size_t)i].far.clear();
+    for (int j = 0; j < n; ++j) {
+      if (i == j) continue;
+      const double d0 = cl[(size_t)i].c[0] - cl[(size_t)j].c[0], d1 = cl[(size_t)i].c[1] - cl[(size_t)j].c[1], d2 = cl[(size_t)i].c[2] - cl[(size_t)j].c[2];
+      const double dist = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+      const double separation = dist / std::max(cl[(size_t)i].radius + cl[(size_t)j].radius, 1e-15);
+      const double kr = k * dist;
+      if (separation > 2.0 && kr > 2.0) cl[(size_t)i].far.push_back(j); else cl[(size_t)i].near.push_back(j);
+    }
+  }
+}
+void tree_subdivide(std::vector<HostLevel>& levels, const double* center, int parent_level, long long target, double k) {
+  const std::vector<HostCluster> parents = levels[(size_t)parent_level].cl;      // the reference clones the parents first
+  HostLevel child;
+  double max_r = 0.0, min_r = 1.7976931348623157e308, sum_r = 0.0;
+  static const double off[8][3] = {{-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
+  for (size_t pi = 0; pi < parents.size(); ++pi) {
+    const HostCluster& par = parents[pi];
+    if ((long long)par.elems.size() <= target) {                                 // becomes a leaf: copied to the child level
+      HostCluster leaf = par;
+      leaf.father = (int)pi;
+      max_r = std::max(max_r, leaf.radius); min_r = std::min(min_r, leaf.radius); sum_r += leaf.radius;
+      levels[(size_t)parent_level].cl[pi].sons.push_back((int)child.cl.size());
+      child.cl.push_back(leaf);
+      continue;
+    }
+    const double half = par.radius / 2.0;
+    for (int o = 0; o < 8; ++o) {
+      HostCluster ch;
+      for (int d = 0; d < 3; ++d) ch.c[d] = par.c[d] + off[o][d] * half * 0.5;
+      for (int idx : par.elems) {
+        const double dx = center[3 * (size_t)idx] - par.c[0], dy = center[3 * (size_t)idx + 1] - par.c[1], dz = center[3 * (size_t)idx + 2] - par.c[2];
+        if (dx * off[o][0] >= 0.0 && dy * off[o][1] >= 0.0 && dz * off[o][2] >= 0.0) ch.elems.push_back(idx);
+      }
+      if (ch.elems.empty()) continue;
+      ch.radius = half; ch.father = (int)pi;
+      max_r = std::max(max_r, ch.radius); min_r = std::min(min_r, ch.radius); sum_r += ch.radius;
+      levels[(size_t)parent_level].cl[pi].sons.push_back((int)child.cl.size());
+      child.cl.push_back(ch);
+    }
+  }
+  const size_t nc = child.cl.size();
+  child.max_r = max_r; child.min_r = min_r; child.avg_r = nc > 0 ? sum_r / (double)nc : 0.0;
+  child.terms = tree_expansion_terms(k * child.avg_r); child.theta = child.terms; child.phi = 2 * child.terms;
+  levels.push_back(child);
+  const int cur = (int)levels.size() - 1;
+  bool more = false;
+  for (const HostCluster& c : levels[(size_t)cur].cl) more = more || (long long)c.elems.size() > target;
+  if (more && cur < 7) tree_subdivide(levels, center, cur, target, k);
+}
+}  // namespace
+
+int cluster_tree_build(int n_elem, const double* center, long long target, double k, ma_cluster_tree** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(n_elem >= 1 && center && target >= 1, MA_ERR_INVALID, "bad argument");
+  ma_cluster_tree* T = new (std::nothrow) ma_cluster_tree(); MA_REQUIRE(T, MA_ERR_NOMEM, "host allocation failed");
+  T->k = k; T->n_elem = n_elem;
+  const int num_levels = tree_estimate_num_levels(n_elem, target, 1, 8);
+  double lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, hi[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
+  for (int e = 0; e < n_elem; ++e) for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], center[3 * (size_t)e + d]); hi[d] = std::max(hi[d], center[3 * (size_t)e + d]); }
+  HostLevel l0; HostCluster root;
+  for (int d = 0; d < 3; ++d) root.c[d] = (lo[d] + hi[d]) / 2.0;
+  const double e0 = hi[0] - lo[0], e1 = hi[1] - lo[1], e2 = hi[2] - lo[2];
+  root.radius = std::sqrt(e0 * e0 + e1 * e1 + e2 * e2) / 2.0;
+  root.elems.resize((size_t)n_elem); for (int e = 0; e < n_elem; ++e) root.elems[(size_t)e] = e;
+  l0.terms = tree_expansion_terms(k * root.radius); l0.theta = l0.terms; l0.phi = 2 * l0.terms;
+  l0.max_r = l0.avg_r = l0.min_r = root.radius;
+  l0.cl.push_back(root);
+  T->levels.push_back(l0);
+  if (num_levels > 1) tree_subdivide(T->levels, center, 0, target, k);
+  for (HostLevel& lv : T->levels) tree_near_far(lv.cl, k);
+  *out = T;
+  return MA_OK;
+}
+void cluster_tree_destroy(ma_cluster_tree* T) { delete T; }
+int cluster_tree_num_levels(const ma_cluster_tree* T) { return (int)T->levels.size(); }
+int cluster_tree_level_info(const ma_cluster_tree* T, int level, int* nclusters, int* terms, int* theta, int* phi, long long* n_elem_listed, long long* n_near, long long* n_far,
+                            long long* n_sons) {
+  MA_REQUIRE(T && level >= 0 && level < (int)T->levels.size(), MA_ERR_INVALID, "level %d outside the tree", level);
+  const HostLevel& lv = T->levels[(size_t)level];
+  long long ne = 0, nn = 0, nf = 0, ns = 0;
+  for (const HostCluster& c : lv.cl) { ne += (long long)c.elems.size(); nn += (long long)c.near.size(); nf += (long long)c.far.size(); ns += (long long)c.sons.size(); }
+  if (nclusters) *nclusters = (int)lv.cl.size();
+  if (terms) *terms = lv.terms;
+  if (theta) *theta = lv.theta;
+  if (phi) *phi = lv.phi;
+  if (n_elem_listed) *n_elem_listed = ne;
+  if (n_near) *n_near = nn;
+  if (n_far) *n_far = nf;
+  if (n_sons) *n_sons = ns;
+  return MA_OK;
+}
+int cluster_tree_level_get(const ma_cluster_tree* T, int level, double* center, double* radius, int* elem_ptr, int* elem_idx, int* near_ptr, int* near_idx, int* far_ptr, int* far_idx,
+                           int* son_ptr, int* son_idx, int* father) {
+  MA_REQUIRE(T && level >= 0 && level < (int)T->levels.size(), MA_ERR_INVALID, "level %d outside the tree", level);
+  const HostLevel& lv = T->levels[(size_t)level];
+  int pe = 0, pn = 0, pf = 0, ps = 0;
+  for (size_t c = 0; c < lv.cl.size(); ++c) {
+    const HostCluster& q = lv.cl[c];
+    if (center) for (int d = 0; d < 3; ++d) center[3 * c + (size_t)d] = q.c[d];
+    if (radius) radius[c] = q.radius;
+    if (father) father[c] = q.father;
+    if (elem_ptr) elem_ptr[c] = pe;
+    if (near_ptr) near_ptr[c] = pn;
+    if (far_ptr) far_ptr[c] = pf;
+    if (son_ptr) son_ptr[c] = ps;
+    for (int v : q.elems) { if (elem_idx) elem_idx[pe] = v; ++pe; }
+    for (int v : q.near) { if (near_idx) near_idx[pn] = v; ++pn; }
+    for (int v : q.far) { if (far_idx) far_idx[pf] = v; ++pf; }
+    for (int v : q.sons) { if (son_idx) son_idx[ps] = v; ++ps; }
+  }
+  const size_t nc = lv.cl.size();
+  if (elem_ptr) elem_ptr[nc] = pe;
+  if (near_ptr) near_ptr[nc] = pn;
+  if (far_ptr) far_ptr[nc] = pf;
+  if (son_ptr) son_ptr[nc] = ps;
+  return MA_OK;
+}
+
+struct MlLevel {                                      // one level at or above the leaves that takes part in the far field
+  int nc = 0, P = 0;
+  double* d_cc = nullptr; double* d_sc = nullptr; double* d_sw = nullptr;
+  int* d_fptr = nullptr; int* d_foth = nullptr; c64* d_fval = nullptr;    // far pairs grouped by field cluster
+  int* d_sptr = nullptr; int* d_sidx = nullptr;                            // sons (indices into the level below)
+  c64* d_M = nullptr; c64* d_L = nullptr;                                  // multipoles / locals, nc x P (the leaf level uses the single-level buffers)
+};
+struct ma_mlfmm {
+  int device = 0; ma_slfmm* leaf = nullptr; long long n = 0; double k = 0.0;
+  bool far_field = false;
+  std::vector<MlLevel> up;                            // levels l0 .. leaf-1, top first
+};
+
+namespace {
+// M_C[p] = w_p sum_sons e^{-i k s_p . (c_son - c_C)} * mean over the son's points of M_son
+__global__ __launch_bounds__(256) void mlfmm_m2m_kernel(const int* __restrict__ sptr, const int* __restrict__ sidx, const double* __restrict__ cc, const double* __restrict__ cc_child,
+                                                        const double* __restrict__ sc, const double* __restrict__ sw, int P, int Pc, double k,
+                                                        const dc* __restrict__ Mc, dc* __restrict__ M) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double Cx = cc[3 * c], Cy = cc[3 * c + 1], Cz = cc[3 * c + 2];
+  double ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};                     // this thread's points p = tid + 256 u (P <= 800)
+  for (int q = sptr[c]; q < sptr[c + 1]; ++q) {
+    const int s = sidx[q];
+    double sr = 0.0, si = 0.0;
+    for (int t = tid; t < Pc; t += 256) { const dc v = Mc[(long long)s * Pc + t]; sr += v.re; si += v.im; }
+    red[0][tid] = sr; red[1][tid] = si;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) { red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h]; } __syncthreads(); }
+    const double mr = red[0][0] / (double)Pc, mi = red[1][0] / (double)Pc;
+    __syncthreads();
+    const double dx = cc_child[3 * s] - Cx, dy = cc_child[3 * s + 1] - Cy, dz = cc_child[3 * s + 2] - Cz;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = tid + 256 * u;
+      if (p < P) {
+        const double sd = sc[3 * p] * dx + sc[3 * p + 1] * dy + sc[3 * p + 2] * dz;
+        double sn, cs; sincos(k * sd, &sn, &cs);
+        ar[u] += cs * mr + sn * mi; ai[u] += cs * mi - sn * mr;          // e^{-i t} (mr + i mi)
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int p = tid + 256 * u; if (p < P) M[(long long)c * P + p] = dc_make(sw[p] * ar[u], sw[p] * ai[u]); }
+}
+// L_son[q] += (1 / Pc) sum_p e^{+i k s_p . (c_son - c_C)} w_p L_C[p]
+__global__ __launch_bounds__(256) void mlfmm_l2l_kernel(const int* __restrict__ sptr, const int* __restrict__ sidx, const double* __restrict__ cc, const double* __restrict__ cc_child,
+                                                        const double* __restrict__ sc, const double* __restrict__ sw, int P, int Pc, double k,
+                                                        const dc* __restrict__ L, dc* __restrict__ Lc) {
+  __shared__ double red[2][256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double Cx = cc[3 * c], Cy = cc[3 * c + 1], Cz = cc[3 * c + 2];
+  for (int q = sptr[c]; q < sptr[c + 1]; ++q) {
+    const int s = sidx[q];
+    const double dx = cc_child[3 * s] - Cx, dy = cc_child[3 * s + 1] - Cy, dz = cc_child[3 * s + 2] - Cz;
+    double sr = 0.0, si = 0.0;
+    for (int p = tid; p < P; p += 256) {
+      const double sd = sc[3 * p] * dx + sc[3 * p + 1] * dy + sc[3 * p + 2] * dz;
+      double sn, cs; sincos(k * sd, &sn, &cs);
+      const dc l = L[(long long)c * P + p]; const double w = sw[p];
+      sr += w * (cs * l.re - sn * l.im); si += w * (cs * l.im + sn * l.re);
+    }
+    red[0][tid] = sr; red[1][tid] = si;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) { if (tid < h) { red[0][tid] += red[0][tid + h]; red[1][tid] += red[1][tid + h]; } __syncthreads(); }
+    const double ar = red[0][0] / (double)Pc, ai = red[1][0] / (double)Pc;
+    __syncthreads();
+    for (int t = tid; t < Pc; t += 256) { dc* o = Lc + (long long)s * Pc + t; o->re += ar; o->im += ai; }   // a son has one father: no race
+  }
+}
+void ml_level_free(MlLevel& L) {
+  void* p[] = {L.d_cc, L.d_sc, L.d_sw, L.d_fptr, L.d_foth, L.d_fval, L.d_sptr, L.d_sidx, L.d_M, L.d_L};
+  for (void* q : p) if (q) (void)hipFree(q);
+}
+bool theta_tabulated(int t) { return t >= 1 && t <= 20 && mat_gl_index[t][1] == t; }
+void sphere_rule(int n_theta, int n_phi, std::vector<double>& sc, std::vector<double>& sw) {
+  const int off = mat_gl_index[n_theta][0];
+  const double pi = 3.14159265358979323846, dphi = 2.0 * pi / (double)n_phi;
+  sc.resize((size_t)n_theta * n_phi * 3); sw.resize((size_t)n_theta * n_phi);
+  int q = 0;
+  for (int i = 0; i < n_theta; ++i) {
+    const double ct = mat_gl_x[off + i], st = std::sqrt(1.0 - ct * ct);
+    for (int j = 0; j < n_phi; ++j, ++q) {
+      const double phi = dphi * (double)j;
+      sc[(size_t)3 * q] = st * std::cos(phi); sc[(size_t)3 * q + 1] = st * std::sin(phi); sc[(size_t)3 * q + 2] = ct;
+      sw[(size_t)q] = mat_gl_w[off + i] * dphi / (4.0 * pi);
+    }
+  }
+}
+}  // namespace
+
+void mlfmm_destroy(ma_mlfmm* S) {
+  if (!S) return;
+  (void)hipSetDevice(S->device);
+  for (MlLevel& L : S->up) ml_level_free(L);
+  if (S->leaf) slfmm_destroy(S->leaf);
+  delete S;
+}
+
+int mlfmm_create(ma_bem_plan* plan, const ma_cluster_tree* T, const ma_physics_t* physics, ma_mlfmm** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(plan && T && physics, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(T->n_elem == plan->np, MA_ERR_DIM, "the tree was built for %d elements, the plan holds %d", T->n_elem, plan->np);
+  MA_REQUIRE(!T->levels.empty(), MA_ERR_INVALID, "empty tree");
+  const int nl = (int)T->levels.size(), leaf = nl - 1;
+  const double k = physics->wave_number;
+  // far field: only with more than one level (mlfmm.rs:186); levels above the first far pair carry nothing
+  int l0 = -1;
+  if (nl > 1) for (int l = 0; l < nl && l0 < 0; ++l) for (const HostCluster& c : T->levels[(size_t)l].cl) if (!c.far.empty()) { l0 = l; break; }
+  if (l0 >= 0)
+    for (int l = l0; l < nl; ++l)
+      MA_REQUIRE(theta_tabulated(T->levels[(size_t)l].theta), MA_ERR_UNSUPPORTED,
+                 "level %d has theta_points = %d, not a tabulated Gauss-Legendre order: the reference's sphere rule would be longer than theta_points * phi_points and its "
+                 "matvec would skip stages (gauss.rs:27-60, mlfmm.rs:229-447)", l, T->levels[(size_t)l].theta);
+  ma_mlfmm* S = new (std::nothrow) ma_mlfmm(); MA_REQUIRE(S, MA_ERR_NOMEM, "host allocation failed");
+  S->device = plan->device; S->n = plan->nd; S->k = k; S->far_field = l0 >= 0;
+  auto fail = [&](int code) { mlfmm_destroy(S); return code; };
+  // ---- leaf level through the single-level machinery: near lists, leaf far pairs, leaf sphere rule
+  {
+    const HostLevel& lv = T->levels[(size_t)leaf];
+    const int nc = (int)lv.cl.size();
+    std::vector<double> cc((size_t)nc * 3);
+    std::vector<int> ep(1, 0), ei, np_(1, 0), ni, fp(1, 0), fi;
+    std::vector<char> seen((size_t)plan->np, 0); bool overlap = false;
+    for (int c = 0; c < nc; ++c) {
+      const HostCluster& q = lv.cl[(size_t)c];
+      for (int d = 0; d < 3; ++d) cc[(size_t)3 * c + d] = q.c[d];
+      for (int e : q.elems) { ei.push_back(e); if (seen[(size_t)e]) overlap = true; seen[(size_t)e] = 1; }
+      ni.insert(ni.end(), q.near.begin(), q.near.end());
+      if (S->far_field) fi.insert(fi.end(), q.far.begin(), q.far.end());
+      ep.push_back((int)ei.size()); np_.push_back((int)ni.size()); fp.push_back((int)fi.size());
+    }
+    const ma_clusters_t cl{nc, cc.data(), ep.data(), ei.data(), np_.data(), ni.data(), fp.data(), fi.data()};
+    const int theta = S->far_field ? lv.theta : 4, phi = S->far_field ? lv.phi : 8;
+    int rc = slfmm_create_ex(plan, &cl, physics, theta, phi, lv.terms, false, overlap, &S->leaf);
+    if (rc) return fail(rc);
+  }
+  MA_HIP(hipSetDevice(plan->device));
+  // ---- the levels above the leaves that take part
+  if (S->far_field)
+    for (int l = l0; l < leaf; ++l) {
+      const HostLevel& lv = T->levels[(size_t)l];
+      MlLevel L; L.nc = (int)lv.cl.size(); L.P = lv.theta * lv.phi;
+      if (L.P > 1024) { set_error("level %d: %d sphere points", l, L.P); return fail(MA_ERR_UNSUPPORTED); }
+      std::vector<double> cc((size_t)L.nc * 3), sc, sw;
+      sphere_rule(lv.theta, lv.phi, sc, sw);
+      std::vector<std::vector<std::pair<int, c64>>> by_field((size_t)L.nc);
+      std::vector<int> sptr(1, 0), sidx;
+      const int order = std::max(lv.terms, 2);
+      std::vector<double> hr, hi;
+      for (int i = 0; i < L.nc; ++i) {
+        const HostCluster& q = lv.cl[(size_t)i];
+        for (int d = 0; d < 3; ++d) cc[(size_t)3 * i + d] = q.c[d];
+        for (int j : q.far) {
+          const HostCluster& o = lv.cl[(size_t)j];
+          const double dx = q.c[0] - o.c[0], dy = q.c[1] - o.c[1], dz = q.c[2] - o.c[2];
+          const double r = std::sqrt(dx * dx + dy * dy + dz * dz);
+          if (r < 1e-15) continue;                                         // mlfmm.rs:826-828
+          spherical_hankel_first_kind(order, k * r, 1.0, hr, hi);
+          by_field[(size_t)j].push_back({i, c64{-hi[0] * k, hr[0] * k}});   // locals[field j] += d multipoles[source i]
+        }
+        sidx.insert(sidx.end(), q.sons.begin(), q.sons.end()); sptr.push_back((int)sidx.size());
+      }
+      std::vector<int> fptr(1, 0), foth; std::vector<c64> fval;
+      for (const auto& v : by_field) { for (const auto& e : v) { foth.push_back(e.first); fval.push_back(e.second); } fptr.push_back((int)foth.size()); }
+      int rc = upload(&L.d_cc, cc);
+      if (!rc) rc = upload(&L.d_sc, sc);
+      if (!rc) rc = upload(&L.d_sw, sw);
+      if (!rc) rc = upload(&L.d_fptr, fptr);
+      if (!rc) rc = upload(&L.d_foth, foth);
+      if (!rc) rc = upload(&L.d_fval, fval);
+      if (!rc) rc = upload(&L.d_sptr, sptr);
+      if (!rc) rc = upload(&L.d_sidx, sidx);
+      if (!rc && hipMalloc(&L.d_M, sizeof(c64) * (size_t)L.nc * (size_t)L.P) != hipSuccess) { set_error("MLFMM level buffers"); rc = MA_ERR_NOMEM; }
+      if (!rc && hipMalloc(&L.d_L, sizeof(c64) * (size_t)L.nc * (size_t)L.P) != hipSuccess) { set_error("MLFMM level buffers"); rc = MA_ERR_NOMEM; }
+      S->up.push_back(L);
+      if (rc) return fail(rc);
+    }
+  *out = S;
+  return MA_OK;
+}
+
+int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
+  MA_HIP(hipSetDevice(S->device));
+  ma_slfmm* F = S->leaf;
+  const BemGeom& g = F->plan->geom;
+  MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
+  const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
+  hipLaunchKernelGGL(slfmm_near_kernel, dim3(F->nc), dim3(256), 0, st, F->d_eptr, F->d_edof, F->d_cptr, F->d_cent, reinterpret_cast<const dc*>(F->d_bval), x, y, 0, F->overlap ? 1 : 0);
+  MA_HIP(hipGetLastError());
+  if (!S->far_field) return MA_OK;
+  // upward pass: leaf multipoles, then level by level to the top level that has far pairs
+  hipLaunchKernelGGL(slfmm_up_kernel, dim3(F->nc), dim3(256), 0, st, g, F->d_eptr, F->d_eidx, F->d_edof, F->d_cc, F->d_sc, F->d_sw, F->P, S->k, -1.0, x, reinterpret_cast<dc*>(F->d_up));
+  MA_HIP(hipGetLastError());
+  const int nu = (int)S->up.size();
+  for (int l = nu - 1; l >= 0; --l) {
+    MlLevel& L = S->up[(size_t)l];
+    const bool below_is_leaf = l == nu - 1;
+    const double* ccc = below_is_leaf ? F->d_cc : S->up[(size_t)l + 1].d_cc;
+    const int Pc = below_is_leaf ? F->P : S->up[(size_t)l + 1].P;
+    const dc* Mc = reinterpret_cast<const dc*>(below_is_leaf ? F->d_up : S->up[(size_t)l + 1].d_M);
+    hipLaunchKernelGGL(mlfmm_m2m_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, Mc, reinterpret_cast<dc*>(L.d_M));
+    MA_HIP(hipGetLastError());
+  }
+  // translation at every level
+  for (int l = 0; l < nu; ++l) {
+    MlLevel& L = S->up[(size_t)l];
+    hipLaunchKernelGGL(slfmm_translate_kernel, dim3(L.nc), dim3(256), 0, st, L.d_fptr, L.d_foth, reinterpret_cast<const dc*>(L.d_fval), L.P, reinterpret_cast<const dc*>(L.d_M),
+                       reinterpret_cast<dc*>(L.d_L));
+    MA_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(slfmm_translate_kernel, dim3(F->nc), dim3(256), 0, st, F->d_fptr, F->d_foth, reinterpret_cast<const dc*>(F->d_fval), F->P, reinterpret_cast<const dc*>(F->d_up),
+                     reinterpret_cast<dc*>(F->d_tr));
+  MA_HIP(hipGetLastError());
+  // downward pass
+  for (int l = 0; l < nu; ++l) {
+    MlLevel& L = S->up[(size_t)l];
+    const bool below_is_leaf = l == nu - 1;
+    const double* ccc = below_is_leaf ? F->d_cc : S->up[(size_t)l + 1].d_cc;
+    const int Pc = below_is_leaf ? F->P : S->up[(size_t)l + 1].P;
+    dc* Lc = reinterpret_cast<dc*>(below_is_leaf ? F->d_tr : S->up[(size_t)l + 1].d_L);
+    hipLaunchKernelGGL(mlfmm_l2l_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, reinterpret_cast<const dc*>(L.d_L), Lc);
+    MA_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(slfmm_down_kernel, dim3(F->nc), dim3(256), 0, st, g, F->d_eptr, F->d_eidx, F->d_edof, F->d_cc, F->d_sc, F->d_sw, F->P, S->k, 1.0,
+                     reinterpret_cast<const dc*>(F->d_tr), y, F->overlap ? 1 : 0);
+  MA_HIP(hipGetLastError());
   return MA_OK;
 }

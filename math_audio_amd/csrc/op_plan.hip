@@ -52,6 +52,8 @@ struct ma_op {
   std::vector<OpShard> shards; hipEvent_t ev_home = nullptr; c64* d_tgather = nullptr;
   // kind 4: the reference's single-level fast multipole operator (SlfmmSystem, assembly/slfmm.rs)
   ma_slfmm* fmm = nullptr;
+  // kind 6: the multi-level operator (MlfmmSystem, assembly/mlfmm.rs)
+  ma_mlfmm* mlfmm = nullptr;
 };
 
 extern "C" int ma_op_destroy(ma_op_t* o);
@@ -69,6 +71,7 @@ void op_free(ma_op* o) {
   o->shards.clear();
   (void)hipSetDevice(o->device);
   if (o->fmm) { slfmm_destroy(o->fmm); o->fmm = nullptr; }
+  if (o->mlfmm) { mlfmm_destroy(o->mlfmm); o->mlfmm = nullptr; }
   if (o->ev_home) (void)hipEventDestroy(o->ev_home);
   if (o->d_tgather) (void)hipFree(o->d_tgather);
   if (o->own_A && o->dA) (void)hipFree(o->dA);
@@ -226,6 +229,47 @@ int ma_op_create_slfmm(ma_bem_plan_t* plan, const ma_clusters_t* clusters, const
   if (rc) { op_free(o); delete o; return rc; }
   *out = o; return MA_OK;
 }
+// build_cluster_tree(elements, target_elements_per_leaf, physics) (mlfmm.rs:979-1038): the tree only looks at the elements' centres
+int ma_cluster_tree_build(const ma_mesh_t* mesh, int32_t target_elements_per_leaf, double wave_number, ma_cluster_tree_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(mesh && mesh->center && mesh->n_elem >= 1, MA_ERR_INVALID, "mesh without element centres");
+  return cluster_tree_build(mesh->n_elem, mesh->center, target_elements_per_leaf, wave_number, out);
+}
+int ma_cluster_tree_destroy(ma_cluster_tree_t* tree) { cluster_tree_destroy(tree); return MA_OK; }
+int ma_cluster_tree_num_levels(const ma_cluster_tree_t* tree, int32_t* levels) {
+  MA_REQUIRE(tree && levels, MA_ERR_INVALID, "NULL argument");
+  *levels = cluster_tree_num_levels(tree);
+  return MA_OK;
+}
+int ma_cluster_tree_level_info(const ma_cluster_tree_t* tree, int32_t level, int32_t* n_clusters, int32_t* expansion_terms, int32_t* theta_points, int32_t* phi_points,
+                               int64_t* n_elem_listed, int64_t* n_near, int64_t* n_far, int64_t* n_sons) {
+  MA_REQUIRE(tree, MA_ERR_INVALID, "NULL tree");
+  long long a = 0, b = 0, c = 0, d = 0;
+  int rc = cluster_tree_level_info(tree, level, n_clusters, expansion_terms, theta_points, phi_points, &a, &b, &c, &d);
+  if (rc) return rc;
+  if (n_elem_listed) *n_elem_listed = a;
+  if (n_near) *n_near = b;
+  if (n_far) *n_far = c;
+  if (n_sons) *n_sons = d;
+  return MA_OK;
+}
+int ma_cluster_tree_level_get(const ma_cluster_tree_t* tree, int32_t level, double* center, double* radius, int32_t* elem_ptr, int32_t* elem_idx, int32_t* near_ptr, int32_t* near_idx,
+                              int32_t* far_ptr, int32_t* far_idx, int32_t* son_ptr, int32_t* son_idx, int32_t* father) {
+  MA_REQUIRE(tree, MA_ERR_INVALID, "NULL tree");
+  return cluster_tree_level_get(tree, level, center, radius, elem_ptr, elem_idx, near_ptr, near_idx, far_ptr, far_idx, son_ptr, son_idx, father);
+}
+// MlfmmOperator (fmm_interface.rs:98-135) over build_mlfmm_system(elements, nodes, cluster_tree, physics) (mlfmm.rs:483-558): apply = MlfmmSystem::matvec;
+// apply_transpose is unimplemented!() in the reference and MA_ERR_UNSUPPORTED here. The plan is borrowed, the tree is only read during the call.
+int ma_op_create_mlfmm(ma_bem_plan_t* plan, const ma_cluster_tree_t* tree, const ma_physics_t* physics, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(plan, MA_ERR_INVALID, "plan is NULL");
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 6; o->device = plan->device; o->n = plan->nd; o->plan = plan;
+  int rc = mlfmm_create(plan, tree, physics, &o->mlfmm);
+  if (!rc) rc = op_stage(o);
+  if (rc) { op_free(o); delete o; return rc; }
+  *out = o; return MA_OK;
+}
 // SlfmmSystem::extract_near_field_matrix (slfmm.rs:104-132): [N] as a dense num_dofs x num_dofs matrix (host buffer, row-major)
 int ma_op_slfmm_near_matrix(ma_op_t* o, ma_c64* A_rowmajor) {
   MA_REQUIRE(o && A_rowmajor && o->kind == 4 && o->fmm, MA_ERR_INVALID, "not a single-level FMM operator");
@@ -305,6 +349,7 @@ int ma_op_apply_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, 0, st);
   if (o->kind == 4) return slfmm_apply(o->fmm, (const c64*)d_x, (c64*)d_y, 0, st);
+  if (o->kind == 6) return mlfmm_apply(o->mlfmm, (const c64*)d_x, (c64*)d_y, st);
   if (o->kind == 0) return op_launch_zgemv(o->n, o->dA, (const c64*)d_x, (c64*)d_y, st);
   if (o->kind == 1) return ma_csr_spmv_dev(o->csr, d_x, d_y, stream);
   return op_launch_tbem_matvec(o->plan->geom, o->ph, o->row0, o->row1, o->nchunks, (const c64*)d_x, o->d_partial, o->plan->d_pair_off,
@@ -350,6 +395,7 @@ static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStre
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(o->device));
   if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, herm ? 2 : 1, st);
+  MA_REQUIRE(o->kind != 6, MA_ERR_UNSUPPORTED, "MLFMM transpose not yet implemented (the reference's MlfmmOperator::apply_transpose is unimplemented!(), fmm_interface.rs:131-134)");
   if (o->kind == 4) {                                    // matvec_transpose (slfmm.rs:262-376); hermitian = conj(A^T conj(x)) (traits.rs:340-358)
     const c64* xin = (const c64*)d_x;
     int rc = MA_OK;
@@ -488,7 +534,7 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
   MA_REQUIRE(op, MA_ERR_INVALID, "operator is NULL");
   if (op->kind == 1) return ma_precond_create_jacobi(op->csr, 1.0, 1, out);
   if (op->kind == 3) return ma_precond_create_diagonal(op->shards[0].op, out);    // the home shard's plan holds every panel
-  MA_REQUIRE(op->kind != 4, MA_ERR_UNSUPPORTED, "diagonal preconditioner of a fast multipole operator: take the diagonal of ma_op_slfmm_near_matrix");
+  MA_REQUIRE(op->kind != 4 && op->kind != 6, MA_ERR_UNSUPPORTED, "diagonal preconditioner of a fast multipole operator: take the diagonal of ma_op_slfmm_near_matrix");
   MA_HIP(hipSetDevice(op->device));
   ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
   M->kind = 4; M->n = op->n; M->device = op->device;

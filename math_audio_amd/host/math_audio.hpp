@@ -8,7 +8,7 @@
 //   math_solvers::CsrMatrix / LinearOperator / DenseOperator / DiagonalPreconditioner / GmresConfig / GmresSolution /
 //            gmres / gmres_with_guess / gmres_preconditioned   (math-solvers/src/{sparse/csr,traits,iterative/gmres,preconditioners/diagonal}.rs)
 //   math_solvers::AmgPreconditioner (V/W/F cycle over a hierarchy the caller built) / gmres_pipelined   (preconditioners/amg.rs, iterative/gmres_pipelined.rs)
-//   math_bem::Cluster / SlfmmSystem (build_slfmm_system + its LinearOperator) / TbemOperator (matrix-free, one or several GPUs) /
+//   math_bem::Cluster / SlfmmSystem (build_slfmm_system + its LinearOperator) / ClusterTree + MlfmmSystem (build_cluster_tree, build_mlfmm_system) / TbemOperator (matrix-free, one or several GPUs) /
 //            solve_frequency_sweep (the `for freq` loop of bin/room_simulator_bem.rs:329 as one call, one or several GPUs)
 // Header-only; links against libmathaudio_hip.so. No CPU fallback: errors come back as exceptions or
 // Result values carrying the C status code.
@@ -644,6 +644,65 @@ class SlfmmSystem : public math_solvers::LinearOperator {
     math_solvers::solver_check(ma_op_slfmm_near_matrix(op_, reinterpret_cast<ma_c64*>(a.data())));
     return a;
   }
+  size_t num_rows() const override { return n_; }
+  size_t num_cols() const override { return n_; }
+  ma_op_t* handle() const override { return op_; }
+ private:
+  size_t n_; ma_op_t* op_ = nullptr;
+};
+
+// build_cluster_tree(elements, target_elements_per_leaf, physics) -> Vec<ClusterLevel> (mlfmm.rs:979-1038) and
+// build_mlfmm_system(elements, nodes, cluster_tree, physics) -> MlfmmSystem with MlfmmOperator's LinearOperator impl
+// (mlfmm.rs:483-558, 128-460; fmm_interface.rs:98-135: apply_transpose is unimplemented!() there and throws here)
+struct ClusterLevel {
+  std::vector<Cluster> clusters;
+  std::vector<double> radius;
+  std::vector<std::vector<size_t>> sons; std::vector<long> father;
+  size_t expansion_terms = 4, theta_points = 4, phi_points = 8;
+};
+class ClusterTree {
+ public:
+  ClusterTree(const std::vector<Element>& elements, const std::vector<double>& nodes, size_t target_elements_per_leaf, const PhysicsParams& physics) {
+    detail::Flat F; detail::flatten(elements, nodes, F);
+    const int rc = ma_cluster_tree_build(&F.c, (int32_t)target_elements_per_leaf, physics.wave_number, &h_);
+    if (rc != MA_OK) throw BemError(rc, ma_last_error_string());
+  }
+  ~ClusterTree() { if (h_) ma_cluster_tree_destroy(h_); }
+  ClusterTree(const ClusterTree&) = delete;
+  ClusterTree& operator=(const ClusterTree&) = delete;
+  ma_cluster_tree_t* handle() const { return h_; }
+  size_t num_levels() const { int32_t n = 0; ma_cluster_tree_num_levels(h_, &n); return (size_t)n; }
+  ClusterLevel level(size_t l) const {
+    int32_t nc = 0, terms = 0, theta = 0, phi = 0; int64_t ne = 0, nn = 0, nf = 0, ns = 0;
+    math_solvers::solver_check(ma_cluster_tree_level_info(h_, (int32_t)l, &nc, &terms, &theta, &phi, &ne, &nn, &nf, &ns));
+    std::vector<double> c((size_t)nc * 3), r((size_t)nc);
+    std::vector<int32_t> ep((size_t)nc + 1), ei((size_t)ne + 1), np_((size_t)nc + 1), ni((size_t)nn + 1), fp((size_t)nc + 1), fi((size_t)nf + 1), sp((size_t)nc + 1), si((size_t)ns + 1), fa((size_t)nc);
+    math_solvers::solver_check(ma_cluster_tree_level_get(h_, (int32_t)l, c.data(), r.data(), ep.data(), ei.data(), np_.data(), ni.data(), fp.data(), fi.data(), sp.data(), si.data(), fa.data()));
+    ClusterLevel L; L.expansion_terms = (size_t)terms; L.theta_points = (size_t)theta; L.phi_points = (size_t)phi;
+    L.clusters.resize((size_t)nc); L.radius = r; L.sons.resize((size_t)nc); L.father.resize((size_t)nc);
+    for (size_t q = 0; q < (size_t)nc; ++q) {
+      for (int d = 0; d < 3; ++d) L.clusters[q].center[d] = c[3 * q + (size_t)d];
+      L.clusters[q].element_indices.assign(ei.begin() + ep[q], ei.begin() + ep[q + 1]);
+      L.clusters[q].near_clusters.assign(ni.begin() + np_[q], ni.begin() + np_[q + 1]);
+      L.clusters[q].far_clusters.assign(fi.begin() + fp[q], fi.begin() + fp[q + 1]);
+      L.sons[q].assign(si.begin() + sp[q], si.begin() + sp[q + 1]);
+      L.father[q] = fa[q];
+    }
+    return L;
+  }
+ private:
+  ma_cluster_tree_t* h_ = nullptr;
+};
+class MlfmmSystem : public math_solvers::LinearOperator {
+ public:
+  MlfmmSystem(const BemPlan& plan, const ClusterTree& tree, const PhysicsParams& p) : n_(plan.num_dofs()) {
+    const ma_physics_t ph = detail::phys(p);
+    math_solvers::solver_check(ma_op_create_mlfmm(plan.handle(), tree.handle(), &ph, &op_));
+  }
+  ~MlfmmSystem() override { if (op_) ma_op_destroy(op_); }
+  MlfmmSystem(const MlfmmSystem&) = delete;
+  MlfmmSystem& operator=(const MlfmmSystem&) = delete;
+  std::vector<Complex64> matvec(const std::vector<Complex64>& x) const { return apply(x); }
   size_t num_rows() const override { return n_; }
   size_t num_cols() const override { return n_; }
   ma_op_t* handle() const override { return op_; }

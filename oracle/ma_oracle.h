@@ -178,6 +178,8 @@ void mao_gmres_pipelined_amg(const mao_amg_hierarchy* H, const mao_c64* b, const
 
 /* ---- single-level fast multipole operator (assembly/slfmm.rs): build_slfmm_system + SlfmmSystem::matvec / matvec_transpose /
  * extract_near_field_matrix. Clusters arrive as CSR-style lists (element_indices, near_clusters, far_clusters, centres). */
+void mao_fmm_near_block(const double* nodes, const int* conn, const double* center, const double* normal, const double* area,
+                        int ns, const int* src_idx, int nf, const int* fld_idx, int is_self, double k, double harmonic, double tau, mao_c64* out);
 typedef struct mao_slfmm mao_slfmm;
 void mao_spherical_hankel_first_kind(int order, double x, double harmonic, mao_c64* result);
 int mao_unit_sphere_quadrature(int n_theta, int n_phi, double* coords, double* weights);

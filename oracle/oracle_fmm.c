@@ -67,6 +67,27 @@ int mao_unit_sphere_quadrature(int n_theta, int n_phi, double* coords /* [n][3] 
   return q;
 }
 
+/* compute_near_block (mlfmm.rs:647-710; the same as slfmm.rs:536-612): coefficient dg_dn gamma tau + d2g beta with
+ * beta = physics.burton_miller_beta(), singular integration only for the same element of a self block, NO free term. out: ns x nf */
+void mao_fmm_near_block(const double* nodes, const int* conn, const double* center, const double* normal, const double* area,
+                        int ns, const int* src_idx, int nf, const int* fld_idx, int is_self, double k, double harmonic, double tau, mao_c64* out) {
+  const double gamma = 1.0;
+  const mao_c64 beta = mao_burton_miller_beta(k, harmonic, tau);
+  for (int i = 0; i < ns; ++i) {
+    const int se = src_idx[i];
+    for (int j = 0; j < nf; ++j) {
+      const int fe = fld_idx[j];
+      const int* cn = conn + 4 * fe; const int nn = cn[3] < 0 ? 3 : 4;
+      double coords[12];
+      for (int a = 0; a < nn; ++a) for (int d = 0; d < 3; ++d) coords[3 * a + d] = nodes[3 * cn[a] + d];
+      mao_integration_result r;
+      if (is_self && se == fe) mao_singular_integration(center + 3 * se, normal + 3 * se, coords, nn, k, harmonic, tau, NULL, 0, 0, 0, &r);
+      else mao_regular_integration(center + 3 * se, normal + 3 * se, coords, nn, area[fe], k, harmonic, tau, NULL, 0, 0, 0, &r);
+      out[(size_t)i * nf + j] = cadd(cscale(cscale(r.dg_dn, gamma), tau), cmul(r.d2g, beta));
+    }
+  }
+}
+
 struct mao_slfmm {
   int num_dofs, nc, P;
   int* eptr; int* eidx;            /* cluster -> element indices (cluster_dof_indices: dof = dof_addresses[0]) */

@@ -244,6 +244,28 @@ static void test_mesh_operators_and_sweep() {
   auto nearm = fmm.extract_near_field_matrix();
   bool diag_ok = true; for (size_t i = 0; i < n; ++i) diag_ok = diag_ok && std::abs(nearm[i * n + i]) > 0.0;
   CHECK(diag_ok);
+  // MLFMM (mlfmm.rs:1267-1312): the tree's root holds every element, the system has n dofs, matvec returns n finite entries,
+  // and a tree of ONE level (n <= target) is the near field alone: the dense coefficient matrix without the free term
+  {
+    ClusterTree tree(mesh.elements, mesh.nodes, 20, ph);
+    CHECK(tree.num_levels() >= 2 && tree.level(0).clusters.size() == 1 && tree.level(0).clusters[0].element_indices.size() == n);
+    MlfmmSystem ml(plan, tree, ph);
+    auto ym = ml.matvec(x);
+    bool fin = ym.size() == n; for (auto& v : ym) fin = fin && std::isfinite(v.real()) && std::isfinite(v.imag());
+    CHECK(fin);
+    bool threw = false; try { ml.apply_transpose(x); } catch (const math_solvers::SolverError& e) { threw = e.status == MA_ERR_UNSUPPORTED; }
+    CHECK(threw);
+    ClusterTree one(mesh.elements, mesh.nodes, 1000, ph);
+    CHECK(one.num_levels() == 1);
+    MlfmmSystem m1(plan, one, ph);
+    // ... which is the single-level operator over ONE cluster minus the free term slfmm.rs adds and mlfmm.rs does not (gamma / 2)
+    Cluster all; all.center = {0.0, 0.0, 0.0}; for (size_t e = 0; e < n; ++e) all.element_indices.push_back(e);
+    SlfmmSystem s1(plan, {all}, ph, 4, 8, 5);
+    auto yref = s1.matvec(x);
+    for (size_t i = 0; i < n; ++i) yref[i] -= 0.5 * x[i];
+    auto y1 = m1.matvec(x);
+    CHECK(diff(y1, yref) < 1e-10 * norm(yref));
+  }
   // the sweep: two frequencies in one call against assemble + RHS + lu_solve per frequency
   const std::vector<double> freqs = {300.0, 700.0};
   std::vector<int32_t> status;

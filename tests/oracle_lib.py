@@ -508,6 +508,26 @@ class Slfmm:
             pass
 
 
+def fmm_near_block(mesh, src_idx, fld_idx, is_self, k, harmonic=1.0, tau=1.0):
+    """compute_near_block (mlfmm.rs:647-710): len(src) x len(fld) coefficients, no free term."""
+    src = np.ascontiguousarray(src_idx, dtype=np.int32); fld = np.ascontiguousarray(fld_idx, dtype=np.int32)
+    out = np.zeros((len(src), len(fld)), dtype=np.complex128)
+    if out.size:
+        lib().mao_fmm_near_block(_p(mesh.nodes), _p(mesh.conn, C.c_int), _p(mesh.center), _p(mesh.normal), _p(mesh.area), len(src), _p(src, C.c_int),
+                                 len(fld), _p(fld, C.c_int), int(bool(is_self)), C.c_double(k), C.c_double(harmonic), C.c_double(tau), _vp(out))
+    return out
+
+
+def mlfmm_module():
+    """oracle/oracle_mlfmm.py (numpy restatement of mlfmm.rs)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "oracle_mlfmm.py")
+    spec = importlib.util.spec_from_file_location("oracle_mlfmm", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def spherical_hankel_first_kind(order, x, harmonic=1.0):
     out = np.zeros(order, dtype=np.complex128)
     lib().mao_spherical_hankel_first_kind(order, C.c_double(x), C.c_double(harmonic), _vp(out))

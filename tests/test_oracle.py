@@ -516,3 +516,85 @@ def test_slfmm_restatement_known_answers():
     whole = grid_clusters(sph.center, 10.0)
     W = O.Slfmm(sph, whole, 10.0, 4, 8, 5)
     assert whole.n == 1 and np.abs(W.matvec(x) - W.near_matrix() @ x).max() <= 1e-12 * np.abs(W.matvec(x)).max()
+
+
+def test_mlfmm_restatement_known_answers():
+    """mlfmm.rs tests (:1267-1312): estimate_num_levels(10, 10, 1, 8) = 1, (100, 10, 1, 8) = 3, (1000, ...) >= 3; the tree of the
+    two-triangle mesh has a root that holds both elements; the system has 2 dofs and >= 1 level; matvec returns 2 entries. Plus what
+    pins the restatement: a two-level tree equals the single-level operator over its leaves minus the free term the multi-level
+    near field does not add (the same T, D and S definitions, restated independently in C for slfmm.rs), and the quirks the
+    docstring of oracle/oracle_mlfmm.py lists."""
+    from fmm_clusters import Clusters
+    M = O.mlfmm_module()
+    assert M.estimate_num_levels(10, 10, 1, 8) == 1
+    assert M.estimate_num_levels(100, 10, 1, 8) == 3
+    assert M.estimate_num_levels(1000, 10, 1, 8) >= 3
+    assert M.estimate_num_levels(0, 10, 2, 8) == 2
+    nodes = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.5, 1.0, 0.0], [1.5, 1.0, 0.0]])          # mlfmm.rs:1231-1265
+    conn = np.array([[0, 1, 2, -1], [1, 3, 2, -1]], dtype=np.int32)
+    om = O.Mesh(nodes, conn)
+    k = O.wave_number(100.0, 343.0)
+    tree = M.build_cluster_tree(om.center, 10, k)
+    assert len(tree) >= 1 and len(tree[0].clusters) >= 1 and len(tree[0].clusters[0].element_indices) == 2
+    S = M.MlfmmSystem(om, tree, k, O)
+    assert S.num_dofs == 2 and S.num_levels >= 1
+    y = S.matvec(np.array([1.0, 1.0j]))
+    assert y.shape == (2,) and np.all(np.isfinite(y))
+    # expansion terms: clamp((kr + 6 max(ln kr, 1)) as usize, 4, 30)
+    assert M._expansion_terms(0.0) == 6 and M._expansion_terms(0.5) == 6 and M._expansion_terms(3.1) == 9 and M._expansion_terms(100.0) == 30
+    assert M._expansion_terms(float("nan")) == 4
+    # a sphere, 3 levels at ka = 1: every level's theta is tabulated (6 or 7), lists are complementary, sons partition (or repeat) the father
+    sph = O.icosphere(RADIUS, 3)                      # 1280 panels
+    k1 = 1.0 / RADIUS
+    T = M.build_cluster_tree(sph.center, 20, k1)
+    assert len(T) >= 3
+    for li, lv in enumerate(T):
+        assert lv.theta_points == lv.expansion_terms and lv.phi_points == 2 * lv.expansion_terms
+        for i, c in enumerate(lv.clusters):
+            assert sorted(c.near_clusters + c.far_clusters) == [j for j in range(len(lv.clusters)) if j != i]
+            if li + 1 < len(T):
+                kids = set()
+                for s_ in c.sons:
+                    assert T[li + 1].clusters[s_].father == i
+                    kids |= set(T[li + 1].clusters[s_].element_indices)
+                assert kids == set(c.element_indices)
+    # two levels (root + leaves) against the single-level operator over the same leaves: identical far field, near field without free
+    # term. The sphere is moved off the dividing planes (an element centre ON a plane joins every octant that touches it -- the
+    # centred icosphere has such elements: its leaves overlap, which the single-level restatement does not take)
+    cnt = np.zeros(sph.n_elem, dtype=int)
+    for c in T[1].clusters:
+        cnt[c.element_indices] += 1
+    assert cnt.max() == 2                               # the quirk is there
+    off = O.Mesh(sph.nodes * np.array([1.0, 1.01, 0.99]) + np.array([0.0013, -0.0007, 0.0004]), sph.conn)
+    T2 = M.build_cluster_tree(off.center, 200, k1)
+    assert len(T2) == 2
+    leaf = T2[1].clusters
+    counts = np.zeros(off.n_elem, dtype=int)
+    for c in leaf:
+        counts[c.element_indices] += 1
+    assert counts.max() == 1 and counts.min() == 1
+    eptr = np.concatenate([[0], np.cumsum([len(c.element_indices) for c in leaf])])
+    eidx = np.concatenate([c.element_indices for c in leaf])
+    nptr = np.concatenate([[0], np.cumsum([len(c.near_clusters) for c in leaf])]); nidx = np.concatenate([c.near_clusters for c in leaf] + [[]]).astype(int)
+    fptr = np.concatenate([[0], np.cumsum([len(c.far_clusters) for c in leaf])]); fidx = np.concatenate([c.far_clusters for c in leaf] + [[]]).astype(int)
+    cl = Clusters(np.array([c.center for c in leaf]), eptr, eidx, nptr, nidx, fptr, fidx)
+    lv = T2[1]
+    assert lv.theta_points == 6
+    x = np.sin(0.1 * np.arange(off.n_elem)) + 1j * np.cos(0.2 * np.arange(off.n_elem))
+    from fmm_clusters import grid_clusters
+    for kk, theta in ((k1, 6), (4.0 * k1, 8)):
+        # a hand-made two-level tree: root + the grid clusters the single-level tests use (far pairs exist among them)
+        g = grid_clusters(off.center, 0.07)
+        root = M.Cluster([0.0, 0.0, 0.0]); root.element_indices = list(range(off.n_elem)); root.sons = list(range(g.n))
+        l0 = M.ClusterLevel(); l0.clusters = [root]; l0.expansion_terms = l0.theta_points = 4; l0.phi_points = 8
+        l1 = M.ClusterLevel(); l1.expansion_terms = 5; l1.theta_points = theta; l1.phi_points = 2 * theta
+        for c in range(g.n):
+            q = M.Cluster(g.center[c]); q.element_indices = [int(e) for e in g.elem_idx[g.elem_ptr[c]:g.elem_ptr[c + 1]]]
+            q.near_clusters = [int(j) for j in g.near_idx[g.near_ptr[c]:g.near_ptr[c + 1]]]; q.far_clusters = [int(j) for j in g.far_idx[g.far_ptr[c]:g.far_ptr[c + 1]]]
+            q.father = 0; q.level = 1
+            l1.clusters.append(q)
+        assert sum(len(q.far_clusters) for q in l1.clusters) > 0
+        SL = O.Slfmm(off, g, kk, theta, 2 * theta, 5)
+        ML = M.MlfmmSystem(off, [l0, l1], kk, O)
+        ys, ym = SL.matvec(x), ML.matvec(x)
+        assert np.abs(ym - (ys - 0.5 * x)).max() <= 1e-11 * np.abs(ys).max(), kk
