@@ -387,6 +387,13 @@ int ma_gmres_preconditioned(ma_op_t* op, ma_precond_t* M, const ma_c64* b, const
  * ||M^-1 (b - A x0)||. */
 int ma_gmres_pipelined(ma_op_t* op, ma_precond_t* M_or_null, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations,
                        double tol, ma_c64* x_out, ma_gmres_info_t* info);
+/* The other Krylov solvers behind the same operator boundary: bicgstab(operator, b, config) (math-solvers/src/iterative/bicgstab.rs:46-182; what
+ * BemSolver uses for the fast multipole methods, math-bem/src/core/bem_solver.rs), cgs (cgs.rs:46-139), cg (cg.rs:49-138; correct for Hermitian
+ * positive definite operators only, as the reference says). x starts at 0; converged when ||r|| / ||b|| < tol; breakdown (|rho|, |<r0, v>|,
+ * |<t, t>|, |omega| < 1e-30) returns converged = 0 with the iterate reached; info->restarts is 0. Defaults of the configs: 1000 iterations, 1e-6. */
+int ma_bicgstab(ma_op_t* op, const ma_c64* b, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info);
+int ma_cgs(ma_op_t* op, const ma_c64* b, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info);
+int ma_cg(ma_op_t* op, const ma_c64* b, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info);
 /* Restarted GMRES(m), relative tolerance on ||b||; defaults of GmresConfig: restart 30, tol 1e-6, 100 restarts
  * (gmres.rs:27-35). x0 may be NULL. Non-convergence is reported in info->converged, not as an error. */
 int ma_gmres(ma_op_t* op, const ma_c64* b, const ma_c64* x0, int32_t restart, int32_t max_iterations, double tol,

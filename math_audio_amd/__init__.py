@@ -138,6 +138,9 @@ def lib():
             "ma_op_num_shards": [vp, P(i32), vp, vp],
             "ma_op_create_slfmm": [vp, P(ma_clusters_t), P(ma_physics_t), i32, i32, i32, P(vp)],
             "ma_op_slfmm_near_matrix": [vp, vp],
+            "ma_bicgstab": [vp, vp, i32, dbl, vp, vp],
+            "ma_cgs": [vp, vp, i32, dbl, vp, vp],
+            "ma_cg": [vp, vp, i32, dbl, vp, vp],
             "ma_cluster_tree_build": [P(ma_mesh_t), i32, dbl, P(vp)],
             "ma_cluster_tree_destroy": [vp],
             "ma_cluster_tree_num_levels": [vp, P(i32)],
@@ -709,6 +712,28 @@ def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
     info = GmresInfo()
     check(lib().ma_gmres(op.h, _vp(b), _vp(x0a), restart, max_iterations, float(tol), _vp(x), C.byref(info)))
     return x, info
+
+
+def _krylov(fn, op, b, max_iterations, tol):
+    b = np.ascontiguousarray(b, dtype=np.complex128)
+    x = np.empty_like(b); info = GmresInfo()
+    check(fn(op.h, _vp(b), int(max_iterations), float(tol), _vp(x), C.byref(info)))
+    return x, info
+
+
+def bicgstab(op, b, max_iterations=1000, tol=1e-6):
+    """bicgstab(operator, b, config) (math-solvers/src/iterative/bicgstab.rs:46-182)."""
+    return _krylov(lib().ma_bicgstab, op, b, max_iterations, tol)
+
+
+def cgs(op, b, max_iterations=1000, tol=1e-6):
+    """cgs(operator, b, config) (cgs.rs:46-139)."""
+    return _krylov(lib().ma_cgs, op, b, max_iterations, tol)
+
+
+def cg(op, b, max_iterations=1000, tol=1e-6):
+    """cg(operator, b, config) (cg.rs:49-138)."""
+    return _krylov(lib().ma_cg, op, b, max_iterations, tol)
 
 
 class Preconditioner:

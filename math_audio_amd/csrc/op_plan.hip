@@ -916,3 +916,135 @@ int ma_gmres_preconditioned(ma_op_t* o, ma_precond_t* M, const ma_c64* b, const 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- the other Krylov solvers of math-solvers/src/iterative: bicgstab.rs:46-182, cgs.rs:46-139,
+// cg.rs:49-138. Same operator boundary as GMRES (ma_op_apply_dev), vectors resident, the scalars of a step (inner products <x, y> = sum conj(x_i) y_i and
+// norms, blas_helpers.rs:21-50) come back to the host, where the reference takes its branches: breakdown below 1e-30, b_norm below 1e-15 -> x = 0 converged,
+// relative residual against ||b||. kind 0 BiCGSTAB, 1 CGS, 2 CG. info->restarts is unused (0).
+static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info) {
+  MA_REQUIRE(o && b_host && x_out && info, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(max_iterations >= 0, MA_ERR_INVALID, "max_iterations must be >= 0");
+  MA_HIP(hipSetDevice(o->device));
+  const long long n = o->n;
+  hipStream_t st = nullptr;
+  c64* buf = nullptr; c64* scal = nullptr; c64* partial = nullptr;
+  auto cleanup = [&]() { if (buf) (void)hipFree(buf); if (scal) (void)hipFree(scal); if (partial) (void)hipFree(partial); };
+#define KR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return MA_ERR_HIP; } } while (0)
+#define KR_RC(call) do { int rc_ = (call); if (rc_) { cleanup(); return rc_; } } while (0)
+  KR_HIP(hipMalloc(&buf, sizeof(c64) * (size_t)n * 9));
+  KR_HIP(hipMalloc(&scal, sizeof(c64) * 4));
+  KR_HIP(hipMalloc(&partial, sizeof(c64) * 256));
+  c64 *x = buf, *r = buf + n, *r0 = buf + 2 * n, *p = buf + 3 * n, *v = buf + 4 * n, *sv = buf + 5 * n, *t = buf + 6 * n, *u = buf + 7 * n, *q = buf + 8 * n;
+  KR_HIP(hipMemset(buf, 0, sizeof(c64) * (size_t)n * 9));
+  KR_HIP(hipMemcpy(r, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
+  KR_HIP(hipMemcpy(r0, r, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice));
+  auto dot = [&](const c64* a, const c64* bb, cplx* out) -> int {              // <a, b> = sum conj(a_i) b_i
+    int rc = op_launch_dot(n, a, bb, 0, partial, scal, st); if (rc) return rc;
+    c64 h; MA_HIP(hipMemcpy(&h, scal, sizeof(c64), hipMemcpyDeviceToHost)); *out = cplx(h.re, h.im); return MA_OK;
+  };
+  auto norm = [&](const c64* a, double* out) -> int {
+    int rc = op_launch_dot(n, a, nullptr, 1, partial, scal, st); if (rc) return rc;
+    c64 h; MA_HIP(hipMemcpy(&h, scal, sizeof(c64), hipMemcpyDeviceToHost)); *out = h.re; return MA_OK;
+  };
+  auto axpby = [&](cplx a, const c64* xa, cplx bcoef, const c64* ya, c64* out) { return op_launch_axpby(n, a.real(), a.imag(), xa, bcoef.real(), bcoef.imag(), ya, out, st); };
+  auto finish = [&](int iters, double res, bool conv) -> int {
+    info->iterations = iters; info->restarts = 0; info->residual = res; info->converged = conv ? 1 : 0;
+    hipError_t e = hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); return MA_ERR_HIP; }
+    return MA_OK;
+  };
+  double b_norm = 0.0, rn = 0.0;
+  KR_RC(norm(r, &b_norm));
+  if (b_norm < 1e-15) return finish(0, 0.0, true);
+  const cplx one(1.0, 0.0);
+  if (kind == 0) {                                                             // bicgstab.rs:46-182
+    cplx rho = one, alpha = one, omega = one;
+    for (int it = 0; it < max_iterations; ++it) {
+      cplx rho_new; KR_RC(dot(r0, r, &rho_new));
+      if (std::abs(rho_new) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
+      const cplx beta = (rho_new / rho) * (alpha / omega);
+      rho = rho_new;
+      KR_RC(axpby(one, p, -omega, v, t));                                      // p = r + beta (p - omega v)
+      KR_RC(axpby(one, r, beta, t, p));
+      KR_RC(ma_op_apply_dev(o, p, v, st));
+      cplx r0v; KR_RC(dot(r0, v, &r0v));
+      if (std::abs(r0v) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
+      alpha = rho / r0v;
+      KR_RC(axpby(one, r, -alpha, v, sv));                                     // s = r - alpha v
+      double s_norm; KR_RC(norm(sv, &s_norm));
+      if (s_norm / b_norm < tol) { KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), p, x, st)); return finish(it + 1, s_norm / b_norm, true); }
+      KR_RC(ma_op_apply_dev(o, sv, t, st));
+      cplx tt; KR_RC(dot(t, t, &tt));
+      if (std::abs(tt) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
+      cplx ts; KR_RC(dot(t, sv, &ts));
+      omega = ts / tt;
+      KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), p, x, st));     // x = x + alpha p + omega s
+      KR_RC(op_launch_axpy_host(n, omega.real(), omega.imag(), sv, x, st));
+      KR_RC(axpby(one, sv, -omega, t, r));                                     // r = s - omega t
+      KR_RC(norm(r, &rn));
+      const double rel = rn / b_norm;
+      if (rel < tol) return finish(it + 1, rel, true);
+      if (std::abs(omega) < 1e-30) return finish(it + 1, rel, false);
+    }
+    KR_RC(norm(r, &rn));
+    return finish(max_iterations, rn / b_norm, false);
+  }
+  if (kind == 1) {                                                             // cgs.rs:46-139
+    cplx rho; KR_RC(dot(r0, r, &rho));
+    KR_HIP(hipMemcpy(p, r, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice));
+    KR_HIP(hipMemcpy(u, r, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice));
+    for (int it = 0; it < max_iterations; ++it) {
+      KR_RC(ma_op_apply_dev(o, p, v, st));
+      cplx sigma; KR_RC(dot(r0, v, &sigma));
+      if (std::abs(sigma) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
+      const cplx alpha = rho / sigma;
+      KR_RC(axpby(one, u, -alpha, v, q));                                      // q = u - alpha v
+      KR_RC(axpby(one, u, one, q, sv));                                        // u + q
+      KR_RC(ma_op_apply_dev(o, sv, t, st));                                    // w = A (u + q)
+      KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), sv, x, st));
+      KR_RC(op_launch_axpy_host(n, -alpha.real(), -alpha.imag(), t, r, st));
+      KR_RC(norm(r, &rn));
+      const double rel = rn / b_norm;
+      if (rel < tol) return finish(it + 1, rel, true);
+      cplx rho_new; KR_RC(dot(r0, r, &rho_new));
+      if (std::abs(rho) < 1e-30) return finish(it + 1, rel, false);
+      const cplx beta = rho_new / rho;
+      rho = rho_new;
+      KR_RC(axpby(one, r, beta, q, u));                                        // u = r + beta q
+      KR_RC(axpby(one, q, beta, p, sv));                                       // p = u + beta (q + beta p)
+      KR_RC(axpby(one, u, beta, sv, p));
+    }
+    KR_RC(norm(r, &rn));
+    return finish(max_iterations, rn / b_norm, false);
+  }
+  // cg.rs:49-138 (the reference's <r, r> and <p, q> are the conjugated inner products as well)
+  KR_HIP(hipMemcpy(p, r, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice));
+  cplx rho; KR_RC(dot(r, r, &rho));
+  for (int it = 0; it < max_iterations; ++it) {
+    KR_RC(ma_op_apply_dev(o, p, q, st));
+    cplx pq; KR_RC(dot(p, q, &pq));
+    if (std::abs(pq) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
+    const cplx alpha = rho / pq;
+    KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), p, x, st));
+    KR_RC(op_launch_axpy_host(n, -alpha.real(), -alpha.imag(), q, r, st));
+    KR_RC(norm(r, &rn));
+    const double rel = rn / b_norm;
+    if (rel < tol) return finish(it + 1, rel, true);
+    cplx rho_new; KR_RC(dot(r, r, &rho_new));
+    if (std::abs(rho) < 1e-30) return finish(it + 1, rel, false);
+    const cplx beta = rho_new / rho;
+    rho = rho_new;
+    KR_RC(axpby(one, r, beta, p, p));                                          // p = r + beta p
+  }
+  KR_RC(norm(r, &rn));
+  return finish(max_iterations, rn / b_norm, false);
+#undef KR_HIP
+#undef KR_RC
+}
+
+extern "C" {
+int ma_bicgstab(ma_op_t* o, const ma_c64* b, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info) { return krylov_impl(0, o, b, max_iterations, tol, x_out, info); }
+int ma_cgs(ma_op_t* o, const ma_c64* b, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info) { return krylov_impl(1, o, b, max_iterations, tol, x_out, info); }
+int ma_cg(ma_op_t* o, const ma_c64* b, int32_t max_iterations, double tol, ma_c64* x_out, ma_gmres_info_t* info) { return krylov_impl(2, o, b, max_iterations, tol, x_out, info); }
+}  // extern "C"

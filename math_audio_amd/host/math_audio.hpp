@@ -515,6 +515,26 @@ inline GmresSolution gmres_pipelined(const LinearOperator& a, const Precondition
   return s;
 }
 
+// iterative/bicgstab.rs:12-182, cgs.rs:12-139, cg.rs:12-138: BiCgstabConfig / CgsConfig / CgConfig {max_iterations 1000, tolerance 1e-6} and the
+// solutions {x, iterations, residual, converged}
+struct KrylovConfig { size_t max_iterations = 1000; double tolerance = 1e-6; size_t print_interval = 0; };
+using BiCgstabConfig = KrylovConfig; using CgsConfig = KrylovConfig; using CgConfig = KrylovConfig;
+struct KrylovSolution { std::vector<Complex64> x; size_t iterations = 0; double residual = 0.0; bool converged = false; };
+using BiCgstabSolution = KrylovSolution; using CgsSolution = KrylovSolution; using CgSolution = KrylovSolution;
+namespace detail {
+typedef int (*krylov_fn)(ma_op_t*, const ma_c64*, int32_t, double, ma_c64*, ma_gmres_info_t*);
+inline KrylovSolution run_krylov(krylov_fn fn, const LinearOperator& a, const std::vector<Complex64>& b, const KrylovConfig& c) {
+  KrylovSolution s; s.x.resize(b.size());
+  ma_gmres_info_t info{};
+  solver_check(fn(a.handle(), reinterpret_cast<const ma_c64*>(b.data()), (int32_t)c.max_iterations, c.tolerance, reinterpret_cast<ma_c64*>(s.x.data()), &info));
+  s.iterations = (size_t)info.iterations; s.residual = info.residual; s.converged = info.converged != 0;
+  return s;
+}
+}  // namespace detail
+inline BiCgstabSolution bicgstab(const LinearOperator& a, const std::vector<Complex64>& b, const BiCgstabConfig& c) { return detail::run_krylov(ma_bicgstab, a, b, c); }
+inline CgsSolution cgs(const LinearOperator& a, const std::vector<Complex64>& b, const CgsConfig& c) { return detail::run_krylov(ma_cgs, a, b, c); }
+inline CgSolution cg(const LinearOperator& a, const std::vector<Complex64>& b, const CgConfig& c) { return detail::run_krylov(ma_cg, a, b, c); }
+
 // AmgPreconditioner's smoothers (preconditioners/amg.rs:855-884, 887-929, 932-978) on the device operator: x is updated in place
 inline void smooth_jacobi(const CsrMatrix& a, std::vector<Complex64>& x, const std::vector<Complex64>& b, double omega, size_t num_sweeps) {
   solver_check(ma_csr_jacobi(a.csr_handle(), reinterpret_cast<ma_c64*>(x.data()), reinterpret_cast<const ma_c64*>(b.data()), omega, (int)num_sweeps));

@@ -177,6 +177,21 @@ static void test_amg_and_pipelined_gmres() {
   CHECK(sp.converged);
   auto ax = a2.matvec(sp.x);
   CHECK(std::sqrt(std::norm(ax[0] - b2[0]) + std::norm(ax[1] - b2[1])) < 1e-8);
+  // bicgstab.rs:190-219, cgs.rs:151-180, cg.rs:146-189
+  for (int which = 0; which < 3; ++which) {
+    KrylovConfig kc{100, 1e-10, 0};
+    auto ks = which == 0 ? bicgstab(a2, b2, kc) : (which == 1 ? cgs(a2, b2, kc) : cg(a2, b2, kc));
+    CHECK(ks.converged);
+    auto kax = a2.matvec(ks.x);
+    CHECK(std::sqrt(std::norm(kax[0] - b2[0]) + std::norm(kax[1] - b2[1])) < 1e-8);
+  }
+  {
+    CsrMatrix id5 = CsrMatrix::identity(5);
+    std::vector<Complex64> b5; for (int i = 1; i <= 5; ++i) b5.push_back(Complex64((double)i, 0.0));
+    auto cs5 = cg(id5, b5, KrylovConfig{10, 1e-12, 0});
+    double e5 = 0.0; for (size_t i = 0; i < 5; ++i) e5 += std::norm(cs5.x[i] - b5[i]);
+    CHECK(cs5.converged && cs5.iterations <= 2 && std::sqrt(e5) < 1e-10);
+  }
   // two-level hierarchy of the 1D Laplacian: aggregates of two, P piecewise constant, R = P^T, A_c = R A P
   const size_t n = 64, nc = n / 2;
   std::vector<std::tuple<size_t, size_t, Complex64>> ta, tp, tr, tc;

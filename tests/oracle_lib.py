@@ -518,6 +518,16 @@ def fmm_near_block(mesh, src_idx, fld_idx, is_self, k, harmonic=1.0, tau=1.0):
     return out
 
 
+def krylov_module():
+    """oracle/oracle_krylov.py (numpy restatement of bicgstab.rs, cgs.rs, cg.rs)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "oracle_krylov.py")
+    spec = importlib.util.spec_from_file_location("oracle_krylov", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def mlfmm_module():
     """oracle/oracle_mlfmm.py (numpy restatement of mlfmm.rs)."""
     import importlib.util

@@ -598,3 +598,28 @@ def test_mlfmm_restatement_known_answers():
         ML = M.MlfmmSystem(off, [l0, l1], kk, O)
         ys, ym = SL.matvec(x), ML.matvec(x)
         assert np.abs(ym - (ys - 0.5 * x)).max() <= 1e-11 * np.abs(ys).max(), kk
+
+
+def test_other_krylov_restatements_known_answers():
+    """The reference's own tests on the numpy restatement: bicgstab.rs:190-219 and cgs.rs:151-180 (the 2 x 2 system to 1e-10, ||A x - b||
+    < 1e-8), cg.rs:146-189 (the SPD 2 x 2 system; the identity with b = 1..5 in <= 2 iterations to 1e-10); plus b = 0 -> x = 0, converged,
+    0 iterations (:57-64 of each), and SciPy's answers on a larger system."""
+    K = O.krylov_module()
+    A = np.array([[4.0, 1.0], [1.0, 3.0]], dtype=complex); b = np.array([1.0, 2.0], dtype=complex)
+    for fn in (K.bicgstab, K.cgs, K.cg):
+        x, it, res, conv = fn(lambda v: A @ v, b, 100, 1e-10)
+        assert conv and np.linalg.norm(A @ x - b) < 1e-8 and it <= 3
+        x0, it0, res0, conv0 = fn(lambda v: A @ v, np.zeros(2), 100, 1e-10)
+        assert conv0 and it0 == 0 and res0 == 0.0 and np.all(x0 == 0)
+    bi = np.arange(1, 6, dtype=complex)
+    x, it, res, conv = K.cg(lambda v: v, bi, 10, 1e-12)
+    assert conv and it <= 2 and np.linalg.norm(x - bi) < 1e-10
+    rng = np.random.default_rng(7)
+    n = 60
+    Bm = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    G = Bm @ Bm.conj().T / n + 2.0 * np.eye(n)                          # Hermitian positive definite: all three apply
+    rhs = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ref = np.linalg.solve(G, rhs)
+    for fn in (K.bicgstab, K.cgs, K.cg):
+        x, it, res, conv = fn(lambda v: G @ v, rhs, 500, 1e-10)
+        assert conv and np.linalg.norm(x - ref) <= 1e-7 * np.linalg.norm(ref)
