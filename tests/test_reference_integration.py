@@ -31,3 +31,39 @@ def test_reference_threshold_met_by_the_restatement(case):
     err = RC.run_case(case, OracleBackend(), oracle_mie)
     assert np.isfinite(err)
     assert err < case["limit"], (case["name"], err, case["limit"])
+
+
+# ---- math-bem/tests/test_fmm_validation.rs through the restatements (tests/fmm_validation_cases.py)
+class OracleFmmBackend:
+    def tbem_matrix(self, mesh, k):
+        A, _ = O.build_tbem_system_with_beta(mesh, k, complex(0.0, 1.0 / k), nthreads=4)       # build_tbem_system: physics.burton_miller_beta() = i / k
+        return A
+
+    def slfmm_one_cluster(self, mesh, k):
+        from fmm_clusters import Clusters
+        n = mesh.n_elem
+        one = Clusters([[0.0, 0.0, 0.0]], [0, n], np.arange(n), [0, 0], [], [0, 0], [])
+        S = O.Slfmm(mesh, one, k, 4, 8, 5)
+        return lambda x: S.matvec(np.asarray(x, dtype=complex))
+
+    def mlfmm(self, mesh, target, k):
+        M = O.mlfmm_module()
+        S = M.MlfmmSystem(mesh, M.build_cluster_tree(mesh.center, target, k), k, O)
+        return S.matvec
+
+    def gmres(self, A, b, restart, max_iterations, tol):
+        x, info = O.gmres(b, dense=A, restart=restart, max_iterations=max_iterations, tol=tol)
+        return x, info.iterations, info.restarts, bool(info.converged)
+
+    def cgs(self, A, b, max_iterations, tol):
+        x, it, res, conv = O.krylov_module().cgs(lambda v: A @ v, b, max_iterations, tol)
+        return x, it, conv
+
+
+def test_fmm_validation_thresholds_met_by_the_restatement():
+    import fmm_validation_cases as F
+    mesh = O.icosphere(F.RADIUS, 1)
+    rel = F.check_slfmm_matvec_vs_tbem(OracleFmmBackend(), mesh)
+    assert rel < 0.5
+    F.check_mlfmm_matvec_nonzero(OracleFmmBackend(), mesh)
+    F.check_solvers_with_operator(OracleFmmBackend())

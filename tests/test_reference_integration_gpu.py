@@ -9,6 +9,7 @@ import oracle_lib as O
 import math_audio_amd as ma
 from math_audio_amd import mesh as mm
 import reference_cases as RC
+from helpers import to_ma_mesh
 from test_reference_integration import OracleBackend, oracle_mie
 
 pytestmark = pytest.mark.gpu
@@ -38,3 +39,45 @@ def test_reference_threshold_met_on_the_device(gpu, case):
     assert np.isfinite(err) and err < case["limit"], (case["name"], err, case["limit"])
     ref = RC.run_case(case, OracleBackend(), oracle_mie)
     assert abs(err - ref) <= 1e-6 * max(1.0, abs(ref)), (case["name"], err, ref)
+
+
+# ---- math-bem/tests/test_fmm_validation.rs through the device path (tests/fmm_validation_cases.py)
+class DeviceFmmBackend:
+    def tbem_matrix(self, mesh, k):
+        A, _ = ma.assemble_tbem(to_ma_mesh(mesh), k, complex(0.0, 1.0 / k))
+        return A
+
+    def slfmm_one_cluster(self, mesh, k):
+        from fmm_clusters import Clusters
+        n = mesh.n_elem
+        one = Clusters([[0.0, 0.0, 0.0]], [0, n], np.arange(n), [0, 0], [], [0, 0], [])
+        self._plan = ma.BemPlan(to_ma_mesh(mesh))
+        self._op = ma.LinearOperator.slfmm(self._plan, one, k, 4, 8, 5)
+        return lambda x: self._op.apply(np.asarray(x, dtype=complex))
+
+    def mlfmm(self, mesh, target, k):
+        m = to_ma_mesh(mesh)
+        self._plan2 = ma.BemPlan(m)
+        self._tree = ma.ClusterTree(m, target, k)
+        self._op2 = ma.LinearOperator.mlfmm(self._plan2, self._tree, k)
+        return lambda x: self._op2.apply(np.asarray(x, dtype=complex))
+
+    def gmres(self, A, b, restart, max_iterations, tol):
+        x, info = ma.gmres(ma.LinearOperator.dense(A), b, restart=restart, max_iterations=max_iterations, tol=tol)
+        return x, info.iterations, info.restarts, bool(info.converged)
+
+    def cgs(self, A, b, max_iterations, tol):
+        x, info = ma.cgs(ma.LinearOperator.dense(A), b, max_iterations, tol)
+        return x, info.iterations, bool(info.converged)
+
+
+@pytest.mark.gpu
+def test_fmm_validation_thresholds_met_on_the_device(gpu):
+    import fmm_validation_cases as F
+    from test_reference_integration import OracleFmmBackend
+    mesh = O.icosphere(F.RADIUS, 1)
+    rel_dev = F.check_slfmm_matvec_vs_tbem(DeviceFmmBackend(), mesh)
+    rel_ref = F.check_slfmm_matvec_vs_tbem(OracleFmmBackend(), mesh)
+    assert abs(rel_dev - rel_ref) <= 1e-8                 # the device lands on the restatement's number, not merely under the threshold
+    F.check_mlfmm_matvec_nonzero(DeviceFmmBackend(), mesh)
+    F.check_solvers_with_operator(DeviceFmmBackend())
