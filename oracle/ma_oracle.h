@@ -120,6 +120,7 @@ int mao_lu_solve_fallback(int n, const mao_c64* A, const mao_c64* b, mao_c64* x)
 double mao_spherical_bessel_j(int n, double x);
 double mao_spherical_bessel_y(int n, double x);
 double mao_legendre_p(int n, double x);
+double mao_sphere_rcs_3d(double k, double radius, int num_terms);
 void   mao_sphere_scattering_3d(double k, double radius, int num_terms, int nr, const double* r,
                                 int nt, const double* theta, mao_c64* pressure /* nr*nt */);
 

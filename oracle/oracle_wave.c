@@ -48,6 +48,23 @@ double mao_legendre_p(int n, double x) {                /* solutions_3d.rs:256-2
   return p1;
 }
 
+/* sphere_rcs_3d (solutions_3d.rs:278-288): 4 pi / k^2 sum (2n + 1) |a_n|^2 with compute_rigid_sphere_coefficients (:147-184) */
+double mao_sphere_rcs_3d(double k, double radius, int T) {
+  const double ka = k * radius;
+  double rcs = 0.0;
+  for (int n = 0; n < T; ++n) {
+    double nf = (double)n;
+    double jn = mao_spherical_bessel_j(n, ka), yn = mao_spherical_bessel_y(n, ka);
+    double jm = n > 0 ? mao_spherical_bessel_j(n - 1, ka) : cos(ka) / ka;
+    double jp = jm - (nf + 1.0) / ka * jn;
+    double ym = n > 0 ? mao_spherical_bessel_y(n - 1, ka) : -sin(ka) / ka;
+    double yp = ym - (nf + 1.0) / ka * yn;
+    mao_c64 a = cdiv(C(jp, 0.0), C(jp, yp));
+    rcs += (double)(2 * n + 1) * (a.re * a.re + a.im * a.im);
+  }
+  return 4.0 * PI * rcs / (k * k);
+}
+
 void mao_sphere_scattering_3d(double k, double radius, int T, int nr, const double* r, int nt, const double* th, mao_c64* out) {
   double ka = k * radius;
   mao_c64* a = (mao_c64*)malloc(sizeof(mao_c64) * (size_t)(T > 0 ? T : 1));

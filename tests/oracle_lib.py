@@ -263,6 +263,11 @@ def lu_solve_fallback(A, b):
 
 
 # ---------------------------------------------------------------- Mie
+def sphere_rcs_3d(k, radius, num_terms):
+    lib().mao_sphere_rcs_3d.restype = C.c_double
+    return float(lib().mao_sphere_rcs_3d(C.c_double(k), C.c_double(radius), int(num_terms)))
+
+
 def sphere_scattering_3d(k, radius, num_terms, r, theta):
     r = np.ascontiguousarray(r, dtype=np.float64); theta = np.ascontiguousarray(theta, dtype=np.float64)
     out = np.zeros(len(r) * len(theta), dtype=np.complex128)

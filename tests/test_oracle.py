@@ -623,3 +623,24 @@ def test_other_krylov_restatements_known_answers():
     for fn in (K.bicgstab, K.cgs, K.cg):
         x, it, res, conv = fn(lambda v: G @ v, rhs, 500, 1e-10)
         assert conv and np.linalg.norm(x - ref) <= 1e-7 * np.linalg.norm(ref)
+
+
+def test_sphere_series_known_answers_of_test_3d_sphere():
+    """math-bem/tests/test_3d_sphere.rs on the restated series (the analytical reference of every BEM accuracy test): Rayleigh regime
+    RCS / (pi a^2) < 0.01 at ka = 0.1 (:36-82), geometric limit |RCS / (pi a^2) - 2| < 0.3 at ka = 20 with ka + 20 terms (:124-166),
+    the sweep ka = 0.1 .. 10: every value positive and finite, RCS(ka = 1.1) > RCS(ka = 0.1) (:169-220), and the series' error against
+    150 terms falling from 5 to 10 to 20 terms at ka = 5 (:368-427)."""
+    a = 1.0
+    assert O.sphere_rcs_3d(0.1, a, 10) / (np.pi * a * a) < 0.01
+    assert abs(O.sphere_rcs_3d(0.1, a, 10) / (np.pi * a * a) - (7.0 / 9.0) * 0.1 ** 4) < 0.03 * (7.0 / 9.0) * 0.1 ** 4   # the rigid sphere's Rayleigh law: a_0 = -i (ka)^3 / 3, a_1 = i (ka)^3 / 6 -> sigma = (7 pi / 9) a^2 (ka)^4
+    ratio = O.sphere_rcs_3d(20.0, a, int(20.0 + 20.0)) / (np.pi * a * a)
+    assert abs(ratio - 2.0) < 0.3
+    rcs = [O.sphere_rcs_3d(0.1 * i / a, a, int(0.1 * i + 15.0)) for i in range(1, 101)]
+    assert all(v > 0.0 and np.isfinite(v) for v in rcs) and rcs[10] > rcs[0]
+    th = [0.0, np.pi / 4.0, np.pi / 2.0, 3.0 * np.pi / 4.0, np.pi]
+    ref = O.sphere_scattering_3d(5.0, a, 150, [2.0], th)
+    errs = []
+    for terms in (5, 10, 20):
+        sol = O.sphere_scattering_3d(5.0, a, terms, [2.0], th)
+        errs.append(np.sqrt((np.abs(sol - ref) ** 2).sum() / (np.abs(ref) ** 2).sum()))
+    assert errs[1] < errs[0] and errs[2] < errs[1]
