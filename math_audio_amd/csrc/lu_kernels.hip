@@ -1240,25 +1240,24 @@ __device__ __forceinline__ unsigned zg_xcc_id() {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & 7u;
 }
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
-                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc, unsigned* __restrict__ ctr, int one_tile) {
-  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
-  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
-  __shared__ int s_tile[2];
+// DRAW = false is the plain kernel (one tile per workgroup, tile = blockIdx): the tile loop and everything of the draw fold away
+template <bool DRAW>
+__device__ __forceinline__ void zgemm3m_body(int M, int N, int K, const dc* __restrict__ A, size_t lda, const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc,
+                                             unsigned* __restrict__ ctr, int one_tile, dc (*As)[ZG_BK][Z3_BM], dc (*Bs)[ZG_BK][Z3_BN], int* s_tile) {
   const int tid0 = threadIdx.x;
   const int gx = (N + Z3_BN - 1) / Z3_BN, gy = (M + Z3_BM - 1) / Z3_BM;
   const int sgx = (gx + 7) >> 3, NS = sgx * ((gy + 7) >> 3);
-  const unsigned myx = ctr ? zg_xcc_id() : 0u;
+  const unsigned myx = DRAW ? zg_xcc_id() : 0u;
   for (bool first = true;; first = false) {
   // the per-thread index arithmetic is redone for every tile (the opaque copy keeps it from being hoisted out of the tile loop
   // and carried in registers across it: the kernel has to stay within 176 of them to share a SIMD with two panel wavefronts)
   int tid = tid0;
-  asm volatile("" : "+v"(tid));
+  if (DRAW) asm volatile("" : "+v"(tid));
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
   int m0, n0;
-  if (!ctr) {
+  if (!DRAW) {
     if (!first) break;
     m0 = blockIdx.y * Z3_BM; n0 = blockIdx.x * Z3_BN;
   } else {
@@ -1360,12 +1359,27 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZG
           *pc = c;
         }
       }
-  __syncthreads();                                                          // the next tile's first stage overwrites the LDS buffers
-  if (ctr && one_tile) {                                             // one tile per workgroup (grid = tiles): leave, counting out
-    if (tid == 0 && atomicAdd(ctr + 8, 1u) == gridDim.x - 1u) { for (int i = 0; i < 9; ++i) ctr[i] = 0u; }
-    break;
+  if (DRAW) {
+    __syncthreads();                                                        // the next tile's first stage overwrites the LDS buffers
+    if (one_tile) {                                                         // one tile per workgroup (grid = tiles): leave, counting out
+      if (tid == 0 && atomicAdd(ctr + 8, 1u) == gridDim.x - 1u) { for (int i = 0; i < 9; ++i) ctr[i] = 0u; }
+      break;
+    }
   }
   }
+}
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
+                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
+  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
+  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
+  zgemm3m_body<false>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, As, Bs, nullptr);
+}
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_drawn_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
+                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc, unsigned* __restrict__ ctr, int one_tile) {
+  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
+  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
+  __shared__ int s_tile[2];
+  zgemm3m_body<true>(M, N, K, A, lda, B, ldb, C, ldc, ctr, one_tile, As, Bs, s_tile);
 }
 
 // thin-N variant for the right-hand sides (N = nrhs small): y[m] -= sum_k A[m][k] x[k]; one wave per row
@@ -1675,7 +1689,7 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
     // large updates draw their tiles XCD by XCD (see the kernel): a ring of counter blocks per device, one block per launch,
     // zeroed at allocation and again by the last workgroup of the launch that used it
     const char* e_xcd = getenv("MA_ZGEMM_XCD_TILES");                       // read per launch: the tests switch it
-    const int xcd_min_tiles = e_xcd ? atoi(e_xcd) : 1024;
+    const int xcd_min_tiles = e_xcd ? atoi(e_xcd) : 0;                      // off unless asked for: it halves the fabric traffic and buys no time
     unsigned* ctr = nullptr;
     unsigned grid_draw = 0;
     if (xcd_min_tiles > 0 && (long long)g3.x * g3.y >= xcd_min_tiles) {
@@ -1701,12 +1715,12 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
     }
     const char* e_per = getenv("MA_ZGEMM_XCD_PERSIST");
     const bool one_tile = !(e_per && atoi(e_per) != 0);
-    if (ctr && one_tile) hipLaunchKernelGGL(zgemm3m_sub_kernel, dim3(g3.x * g3.y), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+    if (ctr && one_tile) hipLaunchKernelGGL(zgemm3m_sub_drawn_kernel, dim3(g3.x * g3.y), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
                                 reinterpret_cast<dc*>(C), ldc, ctr, 1);
-    else if (ctr) hipLaunchKernelGGL(zgemm3m_sub_kernel, dim3(grid_draw), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
+    else if (ctr) hipLaunchKernelGGL(zgemm3m_sub_drawn_kernel, dim3(grid_draw), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
                                 reinterpret_cast<dc*>(C), ldc, ctr, 0);
     else hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
-                            reinterpret_cast<dc*>(C), ldc, (unsigned*)nullptr, 0);
+                            reinterpret_cast<dc*>(C), ldc);
     MA_HIP(hipGetLastError());
     return MA_OK;
   }
