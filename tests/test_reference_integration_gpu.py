@@ -81,3 +81,35 @@ def test_fmm_validation_thresholds_met_on_the_device(gpu):
     assert abs(rel_dev - rel_ref) <= 1e-8                 # the device lands on the restatement's number, not merely under the threshold
     F.check_mlfmm_matvec_nonzero(DeviceFmmBackend(), mesh)
     F.check_solvers_with_operator(DeviceFmmBackend())
+
+
+# ---- the analytic checks of tests/analytic_cases.py through the device path: the same numbers as the restatement
+class DeviceAnalyticBackend:
+    def solve(self, mesh, k, beta):
+        m = to_ma_mesh(mesh)
+        A, r0 = ma.assemble_tbem(m, k, beta)
+        return ma.lu_solve(A, r0 + ma.incident_rhs(m.center, m.normal, k, beta))
+
+    def scattered(self, mesh, k, points, ps, vs):
+        self._plan = ma.BemPlan(to_ma_mesh(mesh))
+        return ma.scattered_field(self._plan, k, points, ps, vs)
+
+
+@pytest.mark.gpu
+def test_analytic_checks_on_the_device(gpu):
+    import analytic_cases as AC
+    from test_reference_integration import OracleAnalyticBackend, cube_sphere
+    quad = cube_sphere(AC.RADIUS, 8); tri = O.icosphere(AC.RADIUS, 2)
+    for mesh in (quad, tri):
+        for ka in (0.3, 0.45, 1.0):
+            d = AC.rigid_surface_error(DeviceAnalyticBackend(), mesh, ka)
+            r = AC.rigid_surface_error(OracleAnalyticBackend(), mesh, ka)
+            assert abs(d[0] - r[0]) <= 1e-7 and abs(d[1] - r[1]) <= 1e-7
+            if ka < 0.5:
+                assert d[1] < 0.02                              # the true series, below the sign switch
+    soft = O.icosphere(AC.RADIUS, 3)
+    soft.bc_type[:] = 1
+    for ka in (0.5, 2.0):
+        ed, rd = AC.soft_sphere_errors(DeviceAnalyticBackend(), soft, ka, lambda p, k: ma.incident_evaluate(p, k))
+        eo, ro = AC.soft_sphere_errors(OracleAnalyticBackend(), soft, ka, O.incident_pressure)
+        assert ed < 0.25 and abs(ed - eo) <= 1e-6 and abs(rd - ro) <= 1e-6
