@@ -223,6 +223,9 @@ int ma_csr_create_helmholtz(int64_t n, const int64_t* row_ptrs, const int64_t* c
  * y: nrows); the diagonal-based sweeps and the transpose need a square handle. */
 int ma_csr_create_rect(int64_t nrows, int64_t ncols, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr_t** out);
 int ma_csr_num_cols(const ma_csr_t* h, int64_t* ncols);
+int ma_csr_device(const ma_csr_t* h, int* device);
+/* the operator's CSR arrays back on the host (row_ptrs n+1, col_indices nnz, values nnz; a K / M handle gives K - k^2 M at its wavenumber) */
+int ma_csr_get(ma_csr_t* h, int64_t* row_ptrs, int64_t* col_indices, ma_c64* values);
 int ma_csr_destroy(ma_csr_t* h);
 int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz);
 int ma_csr_set_wavenumber(ma_csr_t* h, double k_re, double k_im);
@@ -373,6 +376,11 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out);
  * V-cycle on the residual). Use with ma_gmres_preconditioned (SolverType::GmresAmg, math-fem/src/solver/mod.rs:667). */
 int ma_precond_create_amg(int32_t nlevels, ma_csr_t* const* A, ma_csr_t* const* P, ma_csr_t* const* R, int32_t smoother, double jacobi_weight,
                           int32_t num_pre_smooth, int32_t num_post_smooth, int32_t cycle, ma_precond_t** out);
+/* IluPreconditioner::from_csr(matrix) (math-solvers/src/preconditioners/ilu.rs:36-140) and its apply (:143-175): ILU(0) on the matrix' own
+ * pattern. The factorisation runs on the host with the reference's loops (setup, like the AMG hierarchy), the two triangular solves of
+ * every apply on the device (level-scheduled). Use with ma_gmres_preconditioned: gmres_solve_with_ilu(_operator)
+ * (math-bem/src/core/solver/fmm_interface.rs:450-474) is ma_op + this preconditioner over the (near-field) matrix as CSR. */
+int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out);
 int ma_precond_destroy(ma_precond_t* M);
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
 int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */

@@ -138,6 +138,8 @@ def lib():
             "ma_op_num_shards": [vp, P(i32), vp, vp],
             "ma_op_create_slfmm": [vp, P(ma_clusters_t), P(ma_physics_t), i32, i32, i32, P(vp)],
             "ma_op_slfmm_near_matrix": [vp, vp],
+            "ma_precond_create_ilu0": [vp, P(vp)],
+            "ma_csr_get": [vp, vp, vp, vp],
             "ma_bicgstab": [vp, vp, i32, dbl, vp, vp],
             "ma_cgs": [vp, vp, i32, dbl, vp, vp],
             "ma_cg": [vp, vp, i32, dbl, vp, vp],
@@ -943,6 +945,32 @@ def solve_sweep_multi(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_
     if rc not in (MA_OK, MA_ERR_SINGULAR):
         check(rc)
     return X, st
+
+
+class IluPreconditioner:
+    """IluPreconditioner::from_csr (math-solvers/src/preconditioners/ilu.rs): ILU(0), factorised on the host by the library, applied on
+    the device; usable wherever a Preconditioner is (gmres_preconditioned, gmres_pipelined)."""
+
+    def __init__(self, csr_operator):
+        self.h = C.c_void_p(); self._keep = csr_operator
+        check(lib().ma_precond_create_ilu0(csr_operator.h, C.byref(self.h)))
+        self.n = csr_operator.n
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.complex128); z = np.empty_like(r)
+        check(lib().ma_precond_apply(self.h, _vp(r), _vp(z)))
+        return z
+
+    def close(self):
+        if self.h:
+            lib().ma_precond_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class AmgPreconditioner:

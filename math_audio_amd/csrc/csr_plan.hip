@@ -289,6 +289,31 @@ int ma_csr_num_rows(const ma_csr_t* h, int64_t* n, int64_t* nnz) {
   return MA_OK;
 }
 
+int ma_csr_device(const ma_csr_t* h, int* device) {
+  MA_REQUIRE(h && device, MA_ERR_INVALID, "NULL argument");
+  *device = h->device;
+  return MA_OK;
+}
+// the operator's CSR arrays back on the host (row_ptrs n+1, col_indices nnz, values nnz; values of a K / M handle are K - k^2 M at the
+// wavenumber set last, boundary terms excluded unless the handle was assembled with them)
+int ma_csr_get(ma_csr_t* h, int64_t* row_ptrs, int64_t* col_indices, ma_c64* values) {
+  MA_REQUIRE(h && row_ptrs && col_indices && values, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)h->n, nnz = (size_t)h->nnz;
+  std::vector<long long> rp(n + 1); std::vector<int> col(std::max<size_t>(nnz, 1));
+  MA_HIP(hipMemcpy(rp.data(), h->d_rowptr, sizeof(long long) * (n + 1), hipMemcpyDeviceToHost));
+  if (nnz) MA_HIP(hipMemcpy(col.data(), h->d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i <= n; ++i) row_ptrs[i] = rp[i];
+  for (size_t q = 0; q < nnz; ++q) col_indices[q] = col[q];
+  if (!h->km || h->materialised) { if (nnz) MA_HIP(hipMemcpy(values, h->d_val, sizeof(c64) * nnz, hipMemcpyDeviceToHost)); }
+  else {
+    std::vector<double> K(std::max<size_t>(nnz, 1)), M(std::max<size_t>(nnz, 1));
+    if (nnz) { MA_HIP(hipMemcpy(K.data(), h->d_K, sizeof(double) * nnz, hipMemcpyDeviceToHost)); MA_HIP(hipMemcpy(M.data(), h->d_M, sizeof(double) * nnz, hipMemcpyDeviceToHost)); }
+    for (size_t q = 0; q < nnz; ++q) { values[q].re = K[q] - h->k2_re * M[q]; values[q].im = -(h->k2_im * M[q]); }
+  }
+  return MA_OK;
+}
+
 // device-pointer forms (x, y, b, r: n complex128 each; distinct buffers)
 int ma_csr_spmv_dev(ma_csr_t* h, const void* d_x, void* d_y, void* stream) {
   MA_REQUIRE(h && d_x && d_y, MA_ERR_INVALID, "NULL argument");

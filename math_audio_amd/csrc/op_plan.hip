@@ -472,6 +472,8 @@ struct ma_precond {
   c64* d_invdiag = nullptr;      // kind 4: 1 / a_ii of an operator (DiagonalPreconditioner::from_diagonal)
   // kind 5: AmgPreconditioner::apply (amg.rs:1068-1103)
   std::vector<AmgLevelDev> lv; int amg_smoother = 0, amg_pre = 1, amg_post = 1, amg_cycle = 0;
+  // kind 6: IluPreconditioner (ilu.rs): L (strictly lower, unit diagonal implied) and U (diagonal + upper) as operators of their own
+  ma_csr* ilu_l = nullptr; ma_csr* ilu_u = nullptr;
 };
 
 extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
@@ -479,6 +481,9 @@ extern "C" int ma_csr_l1jacobi_dev(ma_csr* h, void* d_x, const void* d_b, int sw
 extern "C" int ma_csr_sym_gauss_seidel_dev(ma_csr* h, void* d_x, const void* d_b, int sweeps, void* stream);
 extern "C" int ma_csr_residual_dev(ma_csr* h, const void* d_x, const void* d_b, void* d_r, void* stream);
 extern "C" int ma_csr_num_cols(const ma_csr* h, int64_t* ncols);
+extern "C" int ma_csr_device(const ma_csr* h, int* device);
+extern "C" int ma_csr_get(ma_csr* h, int64_t* row_ptrs, int64_t* col_indices, ma_c64* values);
+extern "C" int ma_csr_gauss_seidel_sweep_dev(ma_csr* h, void* d_x, const void* d_b, int mode, int backward, void* stream);
 
 // AmgPreconditioner::v_cycle (amg.rs:981-1065) on device vectors of level `level`: smoothers are the AMG sweeps of the CSR
 // handles (smooth_jacobi :855-884, smooth_l1_jacobi :887-929, smooth_sym_gauss_seidel :932-978), the coarsest level runs 20
@@ -599,13 +604,85 @@ int ma_precond_destroy(ma_precond_t* M) {
   for (AmgLevelDev& L : M->lv) { void* p[] = {L.x, L.b, L.r, L.tmp}; for (void* q : p) if (q) (void)hipFree(q); }
   if (M->d_tmp) (void)hipFree(M->d_tmp);
   if (M->d_invdiag) (void)hipFree(M->d_invdiag);
+  if (M->ilu_l) (void)ma_csr_destroy(M->ilu_l);
+  if (M->ilu_u) (void)ma_csr_destroy(M->ilu_u);
   delete M; return MA_OK;
+}
+// IluPreconditioner::from_csr(matrix) (math-solvers/src/preconditioners/ilu.rs:36-140): ILU(0) on the matrix' own pattern, the
+// factorisation on the HOST with the reference's loops (its row-k lookups included: first the entry right of the diagonal, then a
+// scan of row k), L and U split into two device operators; apply = the two triangular solves, level-scheduled. Pivots below 1e-30
+// are skipped by the factorisation as in the reference; the solves skip a row whose u_ii is below 1e-15 in modulus (the reference:
+// 1e-30, and it still subtracts the row's sum there).
+int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(csr, MA_ERR_INVALID, "csr is NULL");
+  int64_t n = 0, nnz = 0, nc = 0;
+  int rc = ma_csr_num_rows(csr, &n, &nnz); if (rc) return rc;
+  rc = ma_csr_num_cols(csr, &nc); if (rc) return rc;
+  MA_REQUIRE(nc == n, MA_ERR_INVALID, "ILU(0) needs a square operator");
+  std::vector<int64_t> rp((size_t)n + 1), col((size_t)std::max<int64_t>(nnz, 1));
+  std::vector<ma_c64> v0((size_t)std::max<int64_t>(nnz, 1));
+  rc = ma_csr_get(csr, rp.data(), col.data(), v0.data()); if (rc) return rc;
+  std::vector<cplx> val((size_t)std::max<int64_t>(nnz, 1));
+  for (int64_t q = 0; q < nnz; ++q) val[(size_t)q] = cplx(v0[(size_t)q].re, v0[(size_t)q].im);
+  const int64_t none = -1;
+  std::vector<int64_t> diag((size_t)n, none);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t idx = rp[(size_t)i]; idx < rp[(size_t)i + 1]; ++idx) if (col[(size_t)idx] == i) { diag[(size_t)i] = idx; break; }
+  for (int64_t i = 0; i < n; ++i)                                              // :55-98
+    for (int64_t idx = rp[(size_t)i]; idx < rp[(size_t)i + 1]; ++idx) {
+      const int64_t k = col[(size_t)idx];
+      if (k >= i) break;
+      const int64_t ukk = diag[(size_t)k];
+      if (ukk == none) continue;
+      const cplx u_kk = val[(size_t)ukk];
+      if (std::abs(u_kk) < 1e-30) continue;
+      const cplx l_ik = val[(size_t)idx] * (std::conj(u_kk) / std::norm(u_kk));   // * u_kk.inv()
+      val[(size_t)idx] = l_ik;
+      for (int64_t jx = rp[(size_t)i]; jx < rp[(size_t)i + 1]; ++jx) {
+        const int64_t j = col[(size_t)jx];
+        if (j <= k) continue;
+        const int64_t first = diag[(size_t)k] + 1;
+        if (first < rp[(size_t)k + 1] && col[(size_t)first] == j) val[(size_t)jx] = val[(size_t)jx] - l_ik * val[(size_t)first];
+        else
+          for (int64_t sx = rp[(size_t)k] + 1; sx < rp[(size_t)k + 1]; ++sx)
+            if (col[(size_t)sx] == j) { val[(size_t)jx] = val[(size_t)jx] - l_ik * val[(size_t)sx]; break; }
+      }
+    }
+  std::vector<int64_t> lrp(1, 0), lci, urp(1, 0), uci; std::vector<ma_c64> lv, uv;   // :100-126
+  for (int64_t i = 0; i < n; ++i) {
+    for (int64_t idx = rp[(size_t)i]; idx < rp[(size_t)i + 1]; ++idx) {
+      const int64_t j = col[(size_t)idx]; const cplx z = val[(size_t)idx];
+      if (j < i) { lci.push_back(j); lv.push_back(ma_c64{z.real(), z.imag()}); }
+      else { uci.push_back(j); uv.push_back(ma_c64{z.real(), z.imag()}); }
+    }
+    lrp.push_back((int64_t)lci.size()); urp.push_back((int64_t)uci.size());
+  }
+  ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
+  M->kind = 6; M->n = n;
+  int dev = 0;
+  rc = ma_csr_device(csr, &dev);
+  M->device = dev;
+  static const int64_t zero_i = 0; static const ma_c64 zero_c = {0.0, 0.0};
+  if (!rc) rc = ma_csr_create(n, lrp.data(), lci.empty() ? &zero_i : lci.data(), lv.empty() ? &zero_c : lv.data(), dev, &M->ilu_l);
+  if (!rc) rc = ma_csr_create(n, urp.data(), uci.empty() ? &zero_i : uci.data(), uv.empty() ? &zero_c : uv.data(), dev, &M->ilu_u);
+  if (!rc && hipMalloc(&M->d_tmp, sizeof(c64) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) { set_error("ILU workspace"); rc = MA_ERR_NOMEM; }
+  if (rc) { ma_precond_destroy(M); return rc; }
+  *out = M;
+  return MA_OK;
 }
 // z = M^-1 r on device vectors (z and r distinct)
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream) {
   MA_REQUIRE(M && d_r && d_z, MA_ERR_INVALID, "NULL argument");
   if (M->kind == 0) { MA_HIP(hipMemcpyAsync(d_z, d_r, sizeof(c64) * (size_t)M->n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return MA_OK; }
   if (M->kind == 4) return op_launch_cmul(M->n, M->d_invdiag, (const c64*)d_r, (c64*)d_z, (hipStream_t)stream);
+  if (M->kind == 6) {                                    // IluPreconditioner::apply (ilu.rs:143-175): L y = r forward, U z = y backward
+    // a forward sweep over a matrix without upper entries IS the forward substitution (and a backward sweep over one without lower
+    // entries the backward substitution): the level-scheduled Gauss-Seidel sweeps of the two factors, amg.rs' form sum * diag.inv()
+    int rc = ma_csr_gauss_seidel_sweep_dev(M->ilu_l, M->d_tmp, d_r, 1, 0, stream);
+    if (!rc) rc = ma_csr_gauss_seidel_sweep_dev(M->ilu_u, d_z, M->d_tmp, 1, 1, stream);
+    return rc;
+  }
   MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
   if (M->kind == 5) {                                    // AmgPreconditioner::apply, amg.rs:1068-1103: z = 0, then the cycle
     hipStream_t st = (hipStream_t)stream;

@@ -505,6 +505,18 @@ class AmgPreconditioner : public Preconditioner {
   std::vector<ma_csr_t*> owned_;
 };
 
+// preconditioners/ilu.rs: IluPreconditioner::from_csr(&matrix) (ILU(0), factorised on the host by the library, applied on the device)
+class IluPreconditioner : public Preconditioner {
+ public:
+  static IluPreconditioner from_csr(const CsrMatrix& m) { IluPreconditioner p; solver_check(ma_precond_create_ilu0(m.csr_handle(), &p.h_)); return p; }
+  IluPreconditioner(IluPreconditioner&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  ~IluPreconditioner() override { if (h_) ma_precond_destroy(h_); }
+  ma_precond_t* handle() const override { return h_; }
+ private:
+  IluPreconditioner() = default;
+  ma_precond_t* h_ = nullptr;
+};
+
 // iterative/gmres_pipelined.rs:18-250: gmres_pipelined(operator, precond, b, x0, config); precond may be null (IdentityPreconditioner)
 inline GmresSolution gmres_pipelined(const LinearOperator& a, const Preconditioner* m, const std::vector<Complex64>& b, const std::vector<Complex64>* x0, const GmresConfig& c) {
   GmresSolution s; s.x.resize(b.size());

@@ -192,6 +192,15 @@ static void test_amg_and_pipelined_gmres() {
     double e5 = 0.0; for (size_t i = 0; i < 5; ++i) e5 += std::norm(cs5.x[i] - b5[i]);
     CHECK(cs5.converged && cs5.iterations <= 2 && std::sqrt(e5) < 1e-10);
   }
+  {                                                          // ilu.rs:177-224: the 3 x 3 tridiagonal system
+    CsrMatrix t3 = CsrMatrix::from_dense({4, -1, 0, -1, 4, -1, 0, -1, 4}, 3, 3, 1e-15);
+    auto ilu = IluPreconditioner::from_csr(t3);
+    std::vector<Complex64> r3 = {{1, 0}, {2, 0}, {3, 0}};
+    auto chk = t3.matvec(ilu.apply(r3));
+    CHECK(std::abs(chk[0] - r3[0]) < 0.5 && std::abs(chk[1] - r3[1]) < 0.5 && std::abs(chk[2] - r3[2]) < 0.5);
+    auto sg = gmres_preconditioned(t3, ilu, r3, GmresConfig{50, 10, 1e-10, 0});
+    CHECK(sg.converged);
+  }
   // two-level hierarchy of the 1D Laplacian: aggregates of two, P piecewise constant, R = P^T, A_c = R A P
   const size_t n = 64, nc = n / 2;
   std::vector<std::tuple<size_t, size_t, Complex64>> ta, tp, tr, tc;

@@ -533,6 +533,16 @@ def krylov_module():
     return mod
 
 
+def ilu_module():
+    """oracle/oracle_ilu.py (restatement of preconditioners/ilu.rs)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "oracle_ilu.py")
+    spec = importlib.util.spec_from_file_location("oracle_ilu", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def mlfmm_module():
     """oracle/oracle_mlfmm.py (numpy restatement of mlfmm.rs)."""
     import importlib.util

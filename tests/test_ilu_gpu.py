@@ -1,0 +1,101 @@
+"""GPU parity of the ILU(0) preconditioner (math-solvers/src/preconditioners/ilu.rs: from_csr on the host inside the library, apply =
+two level-scheduled triangular solves on the device) against the restatement, and the reference's ILU tests through the C-ABI
+(ilu.rs:177-274, math-bem/tests/test_fmm_validation.rs:589-640)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import oracle_lib as O
+import math_audio_amd as ma
+from helpers import to_ma_mesh, RADIUS
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(S):
+    S = sp.csr_matrix(S)
+    S.sort_indices()
+    return ma.CsrOperator(S.indptr.astype(np.int64), S.indices.astype(np.int64), values=S.data.astype(np.complex128)), S
+
+
+def test_reference_unit_tests_through_the_c_abi(gpu):
+    csr, A = _csr(np.array([[4.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 4.0]], dtype=complex))
+    P = ma.IluPreconditioner(csr)
+    r = np.array([1.0, 2.0, 3.0], dtype=complex)
+    check = A @ P.apply(r)
+    assert np.abs(check - r).max() < 0.5 and np.abs(check - r).max() < 1e-13          # ilu.rs:177-224 (and: exact for a tridiagonal matrix)
+    n = 10                                                                            # ilu.rs:226-273
+    csr, T = _csr(sp.diags([-1.0, 4.0, -1.0], [-1, 0, 1], shape=(n, n)).astype(complex))
+    b = np.sin(np.arange(n)).astype(complex)
+    op = ma.LinearOperator.csr(csr)
+    x0, i0 = ma.gmres(op, b, restart=10, max_iterations=50, tol=1e-10)
+    x1, i1 = ma.gmres_preconditioned(op, ma.IluPreconditioner(csr), b, restart=10, max_iterations=50, tol=1e-10)
+    assert i0.converged and i1.converged and i1.iterations <= i0.iterations + 5
+    n = 30                                                                            # test_fmm_validation.rs:589-640: gmres_solve_with_ilu
+    M = np.zeros((n, n), dtype=complex)
+    for i in range(n):
+        M[i, i] = 5.0 + 0.5j
+        if i > 0:
+            M[i, i - 1] = -2.0 + 0.2j
+        if i < n - 1:
+            M[i, i + 1] = -2.0 - 0.2j
+        if i + 3 < n:
+            M[i, i + 3] = 0.5
+    csr, S = _csr(M)                                                                  # CsrMatrix::from_dense(matrix, 1e-15): the band's pattern
+    bb = np.sin(0.2 * np.arange(n)) + 0.5 + 0.1j
+    x, info = ma.gmres_preconditioned(ma.LinearOperator.dense(M), ma.IluPreconditioner(csr), bb, restart=20, max_iterations=100, tol=1e-8)
+    assert info.converged and np.linalg.norm(M @ x - bb) / np.linalg.norm(bb) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["band", "fem", "random_pattern"])
+def test_apply_matches_the_restatement(gpu, kind):
+    ILU = O.ilu_module()
+    rng = np.random.default_rng(5)
+    if kind == "band":
+        n = 400
+        S = sp.diags([0.3 - 0.1j, -1.0 + 0.2j, 4.0 + 0.5j, -1.0 - 0.2j, 0.25], [-7, -1, 0, 1, 5], shape=(n, n)).tocsr()
+    elif kind == "fem":
+        from math_audio_amd import fem
+        nodes, rp, ci, Kv, Mv = fem.helmholtz_box(6, 5, 4, 1.0, 0.8, 0.6)
+        kk = 2.0 + 0.05j
+        S = (sp.csr_matrix((Kv, ci, rp)) - kk * kk * sp.csr_matrix((Mv, ci, rp))).tocsr()
+        n = S.shape[0]
+    else:
+        n = 300
+        R = sp.random(n, n, density=0.03, random_state=3, format="csr")
+        R.data = R.data - 0.5
+        S = (R + 1j * 0.3 * R.T + sp.eye(n) * 6.0).tocsr()
+    csr, S = _csr(S)
+    ref = ILU.IluPreconditioner(S.indptr, S.indices, S.data)
+    P = ma.IluPreconditioner(csr)
+    for r in (rng.standard_normal(n) + 1j * rng.standard_normal(n), np.ones(n, dtype=complex)):
+        z = P.apply(r); zr = ref.apply(r)
+        assert np.abs(z - zr).max() <= 1e-11 * np.abs(zr).max()
+    # as a preconditioner: the same iteration count as the restated GMRES driven by the restated ILU would need is not available in C
+    # (the C restatement's preconditioners are the AMG smoothers); what is checked is that the device GMRES converges with it and beats the plain run
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    op = ma.LinearOperator.csr(csr)
+    x1, i1 = ma.gmres_preconditioned(op, P, b, restart=30, max_iterations=200, tol=1e-9)
+    x0, i0 = ma.gmres(op, b, restart=30, max_iterations=200, tol=1e-9)
+    assert i1.converged and np.linalg.norm(S @ x1 - b) <= 1e-7 * np.linalg.norm(b)
+    if i0.converged:
+        assert i1.iterations <= i0.iterations
+
+
+def test_ilu_of_the_near_field_with_the_slfmm_operator(gpu):
+    """gmres_solve_with_ilu_operator(operator, nearfield_matrix, b, config) (fmm_interface.rs:462-474): the SLFMM operator preconditioned
+    by the ILU(0) of its own near-field matrix (from_dense at 1e-15). Fewer iterations than without."""
+    from fmm_clusters import grid_clusters
+    om = O.icosphere(RADIUS, 2)
+    k = 1.0 / RADIUS
+    cl = grid_clusters(om.center, 0.07)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    op = ma.LinearOperator.slfmm(plan, cl, k, 4, 8, 5)
+    N = op.slfmm_near_matrix()
+    Nz = N.copy(); Nz[np.abs(Nz) <= 1e-15] = 0.0
+    csr, S = _csr(Nz)
+    P = ma.IluPreconditioner(csr)
+    b = np.ones(om.n_elem, dtype=complex)
+    x1, i1 = ma.gmres_preconditioned(op, P, b, restart=30, max_iterations=200, tol=1e-8)
+    x0, i0 = ma.gmres(op, b, restart=30, max_iterations=200, tol=1e-8)
+    assert i1.converged and np.linalg.norm(op.apply(x1) - b) <= 1e-6 * np.linalg.norm(b)
+    assert (not i0.converged) or i1.iterations <= i0.iterations

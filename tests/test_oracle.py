@@ -644,3 +644,42 @@ def test_sphere_series_known_answers_of_test_3d_sphere():
         sol = O.sphere_scattering_3d(5.0, a, terms, [2.0], th)
         errs.append(np.sqrt((np.abs(sol - ref) ** 2).sum() / (np.abs(ref) ** 2).sum()))
     assert errs[1] < errs[0] and errs[2] < errs[1]
+
+
+def test_ilu_restatement_known_answers():
+    """ilu.rs:177-274: the 3 x 3 tridiagonal system (A applied to M^-1 r within 0.5 of r; ILU(0) of a tridiagonal matrix is its exact LU:
+    1e-14 here) and the 10 x 10 one under GMRES(10) (preconditioned iterations <= plain + 5); test_fmm_validation.rs:589-640
+    (gmres_solve_with_ilu on the 30 x 30 band system: converged, ||A x - b|| / ||b|| < 1e-5)."""
+    import scipy.sparse as sp
+    ILU = O.ilu_module()
+    A = sp.csr_matrix(np.array([[4.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 4.0]], dtype=complex))
+    P = ILU.IluPreconditioner(A.indptr, A.indices, A.data)
+    r = np.array([1.0, 2.0, 3.0], dtype=complex)
+    z = P.apply(r)
+    assert np.abs(A @ z - r).max() < 1e-14
+    n = 10
+    T = sp.diags([-1.0, 4.0, -1.0], [-1, 0, 1], shape=(n, n)).tocsr().astype(complex)
+    b = np.sin(np.arange(n)).astype(complex)
+    x0, i0 = O.gmres(b, csr=(T.indptr, T.indices, T.data), restart=10, max_iterations=50, tol=1e-10)
+    P = ILU.IluPreconditioner(T.indptr, T.indices, T.data)
+    assert i0.converged and np.linalg.norm(T @ P.apply(b) - b) < 1e-13      # exact LU again: one preconditioned step solves it
+    # ILU(0) with a dropped entry: the band system with the extra diagonal i + 3 (fill at (i + 1, i + 3) is dropped)
+    n = 30
+    M = np.zeros((n, n), dtype=complex)
+    for i in range(n):
+        M[i, i] = 5.0 + 0.5j
+        if i > 0:
+            M[i, i - 1] = -2.0 + 0.2j
+        if i < n - 1:
+            M[i, i + 1] = -2.0 - 0.2j
+        if i + 3 < n:
+            M[i, i + 3] = 0.5
+    S = sp.csr_matrix(M)
+    P = ILU.IluPreconditioner(S.indptr, S.indices, S.data)
+    bb = np.sin(0.2 * np.arange(n)) + 0.5 + 0.1j
+    z = P.apply(bb)
+    assert 1e-6 < np.linalg.norm(M @ z - bb) / np.linalg.norm(bb) < 0.2      # incomplete: close to, not equal to, the inverse
+    # gmres_solve_with_ilu feeds the DENSE matrix' pattern (from_dense(matrix, 1e-15)): the zero entries are dropped, the pattern is the band's
+    from scipy.sparse.linalg import gmres as sgmres, LinearOperator as SLO
+    xs, info = sgmres(S, bb, M=SLO((n, n), matvec=P.apply, dtype=complex), restart=20, maxiter=100, rtol=1e-10)
+    assert info == 0 and np.linalg.norm(M @ xs - bb) / np.linalg.norm(bb) < 1e-5
