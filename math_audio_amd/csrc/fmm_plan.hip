@@ -68,34 +68,102 @@ void spherical_hankel_first_kind(int order, double x, double harmonic, std::vect
   for (int n = 0; n < order; ++n) { re[(size_t)n] = dp * gg[(size_t)n]; im[(size_t)n] *= harmonic; }
 }
 
-// near blocks: every row of cluster c sums all its contributions in the order of the cluster's entry list
+// near blocks, y_c = sum over the cluster's entries of B x (entry stored with this cluster as its rows) or B^T x (stored with this
+// cluster as its columns). The two kinds are read the way they lie in memory: a block used as B^T has the cluster's rows as its
+// COLUMNS, so lane = row streams it contiguously (phase A, the partner's entries one after the other, x_j broadcast); a block used as
+// B has them as its rows, so a group of G lanes walks a row's entries and reduces at the end (phase B). With lanes over j in both
+// cases the transposed half was read with a stride of a whole row (16 x the bytes). WPC wavefronts per cluster: 4 (one workgroup per
+// cluster) for large clusters, 1 (four clusters per workgroup) for the leaves of a multi-level tree. Sums are taken in a fixed order.
+template <int WPC>
 __global__ __launch_bounds__(256) void slfmm_near_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
                                                          const SlfmmEntry* __restrict__ cent, const dc* __restrict__ bval, const dc* __restrict__ x,
-                                                         dc* __restrict__ y, int tmode, int overlap) {
-  const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int e0 = eptr[c], nc_ = eptr[c + 1] - e0;
-  for (int i = wave; i < nc_; i += 4) {
+                                                         dc* __restrict__ y, int tmode, int overlap, int nclusters, int G) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (4 / WPC) + wave / WPC, w = wave % WPC;
+  const bool live = c < nclusters;
+  const int e0 = live ? eptr[c] : 0, nc_ = live ? eptr[c + 1] - e0 : 0;
+  const int q0 = live ? cptr[c] : 0, q1 = live ? cptr[c + 1] : 0;
+  constexpr int U = 8;                                     // independent loads in flight per lane: the loops are latency-bound without them
+  // phase A: the entries this cluster reads as B^T. G consecutive lanes take G consecutive rows (contiguous in the stored block), the
+  // 64 / G lane sets split the partner's elements between them and are summed at the end.
+  const int JG = 64 / G, jg = lane / G, lg = lane % G;
+  for (int ic = w; ic * G < nc_; ic += WPC) {
+    const int i = ic * G + lg;
+    const bool vi = i < nc_;
+    const int ii = vi ? i : 0;
     double sr = 0.0, si = 0.0;
-    for (int q = cptr[c]; q < cptr[c + 1]; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const SlfmmEntry en = cent[q];
-      const int o0 = eptr[en.other], no = eptr[en.other + 1] - o0;
       const bool self = en.other == c;
       const bool tr = (en.tflag != 0) != (self && tmode != 0);
-      const dc* B = bval + en.boff;
-      for (int j = lane; j < no; j += 64) {
-        const dc b = tr ? B[(long long)j * nc_ + i] : B[(long long)i * no + j];
-        const dc xv = x[edof[o0 + j]];
-        sr += b.re * xv.re - b.im * xv.im; si += b.re * xv.im + b.im * xv.re;
+      if (!tr) continue;
+      const int o0 = eptr[en.other], no = eptr[en.other + 1] - o0;
+      const dc* B = bval + en.boff + ii;
+      const int* od = edof + o0;
+      for (int j0 = jg; j0 < no; j0 += JG * U) {
+        dc bb[U], xx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u * JG;
+          const int jj = j < no ? j : j0;
+          bb[u] = B[(long long)jj * nc_];
+          xx[u] = x[od[jj]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (j0 + u * JG < no) { sr += bb[u].re * xx[u].re - bb[u].im * xx[u].im; si += bb[u].re * xx[u].im + bb[u].im * xx[u].re; }
+        }
       }
     }
-    sr = wave_sum(sr); si = wave_sum(si);
-    if (lane == 0) {
+    for (int off = G; off < 64; off <<= 1) { sr += __shfl_xor(sr, off, 64); si += __shfl_xor(si, off, 64); }
+    if (vi && jg == 0) {
       dc* o = y + edof[e0 + i];
       if (overlap) { atomicAdd(&o->re, sr); atomicAdd(&o->im, si); }       // the dof is a row of several clusters
       else *o = dc_make(sr, si);
     }
   }
+  __syncthreads();
+  // phase B: the entries read as B. G lanes walk a row; a lane set carries U rows at once (one gather of x serves all of them).
+  for (int t = w; t * JG * U < nc_; t += WPC) {
+    const int ibase = t * JG * U + jg;                     // rows ibase + r JG
+    double ar[U], ai[U];
+#pragma unroll
+    for (int r = 0; r < U; ++r) { ar[r] = 0.0; ai[r] = 0.0; }
+    for (int q = q0; q < q1; ++q) {
+      const SlfmmEntry en = cent[q];
+      const bool self = en.other == c;
+      const bool tr = (en.tflag != 0) != (self && tmode != 0);
+      if (tr) continue;
+      const int o0 = eptr[en.other], no = eptr[en.other + 1] - o0;
+      const dc* B = bval + en.boff;
+      for (int j = lg; j < no; j += G) {
+        const dc xv = x[edof[o0 + j]];
+        dc bb[U];
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          const int i = ibase + r * JG;
+          bb[r] = B[(long long)(i < nc_ ? i : 0) * no + j];
+        }
+#pragma unroll
+        for (int r = 0; r < U; ++r) {
+          if (ibase + r * JG < nc_) { ar[r] += bb[r].re * xv.re - bb[r].im * xv.im; ai[r] += bb[r].re * xv.im + bb[r].im * xv.re; }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+      double sr = ar[r], si = ai[r];
+      for (int off = G >> 1; off > 0; off >>= 1) { sr += __shfl_xor(sr, off, 64); si += __shfl_xor(si, off, 64); }
+      const int i = ibase + r * JG;
+      if (i < nc_ && lg == 0) {
+        dc* o = y + edof[e0 + i];
+        if (overlap) { atomicAdd(&o->re, sr); atomicAdd(&o->im, si); }
+        else { o->re += sr; o->im += si; }
+      }
+    }
+  }
 }
+
 // up[c][p] = sum_j w_p exp(i sgn k s_p . (x_j - C_c)) x[dof_j]     (sgn -1: T x; +1: S^T x)
 __global__ __launch_bounds__(256) void slfmm_up_kernel(BemGeom g, const int* __restrict__ eptr, const int* __restrict__ eidx, const int* __restrict__ edof,
                                                        const double* __restrict__ cc, const double* __restrict__ sc, const double* __restrict__ sw,
@@ -120,12 +188,50 @@ __global__ __launch_bounds__(256) void slfmm_up_kernel(BemGeom g, const int* __r
 // tr[c][p] = sum over the cluster's far partners of d * up[other][p]   (the diagonal D entry is the same for every p)
 __global__ __launch_bounds__(256) void slfmm_translate_kernel(const int* __restrict__ fptr, const int* __restrict__ foth, const dc* __restrict__ fval, int P,
                                                               const dc* __restrict__ up, dc* __restrict__ tr) {
-  const int c = blockIdx.x;
-  for (int p = threadIdx.x; p < P; p += 256) {
+  // One workgroup per cluster. The far list is walked by 256 / P thread sets at once (P sphere points each), four pairs in flight per
+  // thread: with one thread per point and one pair at a time the loop is a chain of dependent gathers and the kernel latency-bound.
+  // The sets' partial sums are added in set order, so the result does not depend on timing.
+  __shared__ dc part[256];
+  constexpr int U = 4;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int q0 = fptr[c], q1 = fptr[c + 1];
+  if (P <= 128) {
+    const int QG = 256 / P, qg = tid / P, p = tid % P;
     double sr = 0.0, si = 0.0;
-    for (int q = fptr[c]; q < fptr[c + 1]; ++q) {
-      const dc d = fval[q]; const dc m = up[(long long)foth[q] * P + p];
-      sr += d.re * m.re - d.im * m.im; si += d.re * m.im + d.im * m.re;
+    if (qg < QG)
+      for (int q = q0 + qg; q < q1; q += QG * U) {
+        dc d[U], m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int qq = q + u * QG;
+          const int qc = qq < q1 ? qq : q;
+          d[u] = fval[qc]; m[u] = up[(long long)foth[qc] * P + p];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (q + u * QG < q1) { sr += d[u].re * m[u].re - d[u].im * m[u].im; si += d[u].re * m[u].im + d[u].im * m[u].re; }
+      }
+    part[tid] = dc_make(sr, si);
+    __syncthreads();
+    if (tid < P) {
+      double tr_ = 0.0, ti_ = 0.0;
+      for (int g = 0; g < QG; ++g) { tr_ += part[g * P + tid].re; ti_ += part[g * P + tid].im; }
+      tr[(long long)c * P + tid] = dc_make(tr_, ti_);
+    }
+    return;
+  }
+  for (int p = tid; p < P; p += 256) {
+    double sr = 0.0, si = 0.0;
+    for (int q = q0; q < q1; q += U) {
+      dc d[U], m[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int qc = q + u < q1 ? q + u : q;
+        d[u] = fval[qc]; m[u] = up[(long long)foth[qc] * P + p];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (q + u < q1) { sr += d[u].re * m[u].re - d[u].im * m[u].im; si += d[u].re * m[u].im + d[u].im * m[u].re; }
     }
     tr[(long long)c * P + p] = dc_make(sr, si);
   }
@@ -181,6 +287,17 @@ template <typename T> int upload(T** d, const std::vector<T>& h) {
 }
 
 }  // namespace
+
+static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st) {
+  const int avg = S->nc > 0 ? (int)((S->h_eptr.empty() ? 0 : S->h_eptr.back()) / S->nc) : 0;
+  int G = 8; while (G < 64 && G < avg) G <<= 1;
+  if (avg <= 48) hipLaunchKernelGGL(slfmm_near_kernel<1>, dim3((unsigned)((S->nc + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent,
+                                    reinterpret_cast<const dc*>(S->d_bval), x, y, tmode, S->overlap ? 1 : 0, S->nc, G);
+  else hipLaunchKernelGGL(slfmm_near_kernel<4>, dim3((unsigned)S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent,
+                          reinterpret_cast<const dc*>(S->d_bval), x, y, tmode, S->overlap ? 1 : 0, S->nc, G);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
 
 long long slfmm_num_dofs(const ma_slfmm* S) { return S->n; }
 int slfmm_device(const ma_slfmm* S) { return S->device; }
@@ -351,8 +468,7 @@ int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_
   const BemGeom& g = S->plan->geom;
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));        // dofs outside every cluster receive nothing
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
-  hipLaunchKernelGGL(slfmm_near_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, reinterpret_cast<const dc*>(S->d_bval), x, y, transpose, S->overlap ? 1 : 0);
-  MA_HIP(hipGetLastError());
+  { int rc = slfmm_launch_near(S, x, y, transpose, st); if (rc) return rc; }
   // far field: forward T (e^-), D grouped by field, S (e^+); transpose S^T (e^+), D grouped by source, T^T (e^-)
   const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
   hipLaunchKernelGGL(slfmm_up_kernel, dim3(S->nc), dim3(256), 0, st, g, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, s_up, x,
@@ -735,8 +851,7 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   const BemGeom& g = F->plan->geom;
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
-  hipLaunchKernelGGL(slfmm_near_kernel, dim3(F->nc), dim3(256), 0, st, F->d_eptr, F->d_edof, F->d_cptr, F->d_cent, reinterpret_cast<const dc*>(F->d_bval), x, y, 0, F->overlap ? 1 : 0);
-  MA_HIP(hipGetLastError());
+  { int rc = slfmm_launch_near(F, x, y, 0, st); if (rc) return rc; }
   if (!S->far_field) return MA_OK;
   // upward pass: leaf multipoles, then level by level to the top level that has far pairs
   hipLaunchKernelGGL(slfmm_up_kernel, dim3(F->nc), dim3(256), 0, st, g, F->d_eptr, F->d_eidx, F->d_edof, F->d_cc, F->d_sc, F->d_sw, F->P, S->k, -1.0, x, reinterpret_cast<dc*>(F->d_up));
