@@ -22,7 +22,7 @@
 
 using namespace ma;
 
-struct SlfmmEntry { long long boff; int other; int tflag; };   // a near block seen from one of its two clusters
+struct SlfmmEntry { long long boff; long long poff; int other; int tflag; };   // a near block seen from one of its two clusters; poff: its partial sums for this side
 
 struct ma_slfmm {
   int device = 0; ma_bem_plan* plan = nullptr;
@@ -33,6 +33,9 @@ struct ma_slfmm {
   int* d_cptr = nullptr; SlfmmEntry* d_cent = nullptr;
   int* d_fptr = nullptr; int* d_foth = nullptr; c64* d_fval = nullptr;      // far pairs grouped by field cluster (forward)
   int* d_tptr = nullptr; int* d_toth = nullptr; c64* d_tval = nullptr;      // grouped by source cluster (transpose)
+  c64* d_fdense = nullptr; c64* d_tdense = nullptr;                         // the same two as dense nc x nc matrices, when the lists are nearly full
+  int* d_bsrc = nullptr; int* d_bfld = nullptr; long long* d_boff = nullptr; int nblocks = 0;   // the near blocks one by one
+  long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0;   // their partial sums (rows, columns)
   c64* d_up = nullptr; c64* d_tr = nullptr;
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
   // host copies for extract_near_field_matrix
@@ -288,9 +291,224 @@ template <typename T> int upload(T** d, const std::vector<T>& h) {
 
 }  // namespace
 
+// The far lists of this method hold every cluster that is not near, so D is a nearly full nc x nc matrix and tr = D up a dense
+// complex product [nc x nc] [nc x P]. The list kernel above re-reads a row of `up` from L2 for every pair (6 GB per leaf level of the
+// 50k box: L2-bound, 0.5 ms). Here it runs on v_mfma_f64_16x16x4_f64, four real products per complex one. D is stored by SOURCE
+// (DT[s][c], the receiving cluster c contiguous), so the A operand of a step (16 receiving clusters x 4 sources) is four 256-byte
+// runs and the B operands (4 sources x 16 points) rows of `up`. A wavefront owns 16 receiving clusters and up to 128 points; the KS
+// wavefronts of a workgroup split the sources and add their parts in wavefront order through LDS, so the result does not depend on
+// timing. Absent pairs are zeros of D. (Vector-FMA forms were tried first: `up` through scalar loads stalls on the scalar cache,
+// through LDS broadcasts is LDS-bound, through v_readlane reaches 0.31 ms.)
+typedef double fmm_v4d __attribute__((ext_vector_type(4)));
+template <int KS, int NT>                                   // NT point tiles of 16 per workgroup
+__global__ __launch_bounds__(64 * KS) void fmm_translate_dense_kernel(const dc* __restrict__ DT, int nc, int P, const dc* __restrict__ up, dc* __restrict__ tr) {
+  __shared__ dc part[16 * 16 * NT];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int c0 = blockIdx.x * 16;
+  const int pb = blockIdx.y * (16 * NT);
+  const int npts = P - pb < 16 * NT ? P - pb : 16 * NT;
+  const int nt = (npts + 15) / 16;
+  const int steps = (nc + 3) / 4, per = (steps + KS - 1) / KS;
+  const int kb = w * per, ke = kb + per < steps ? kb + per : steps;
+  const dc* acol = DT + (c0 + lr < nc ? c0 + lr : nc - 1);
+  fmm_v4d cr[NT], ci[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { cr[t] = (fmm_v4d){0, 0, 0, 0}; ci[t] = cr[t]; }
+  dc a, bv[NT], an, bn[NT];
+  auto fetch = [&](int ks, dc& fa, dc* fb) {
+    const int sidx = ks * 4 + lk;
+    const int sc = sidx < nc ? sidx : nc - 1;
+    fa = acol[(long long)sc * nc];
+    if (sidx >= nc) fa = dc_make(0.0, 0.0);                 // sources past the end multiply by zero
+    const dc* urow = up + (long long)sc * P + pb;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) { const int col = 16 * t + lr; fb[t] = urow[col < npts ? col : npts - 1]; }
+  };
+  if (kb < ke) fetch(kb, a, bv);
+  for (int ks = kb; ks < ke; ++ks) {
+    if (ks + 1 < ke) fetch(ks + 1, an, bn);                 // the next step's loads are in flight during this step's products
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) {
+        cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].re, cr[t], 0, 0, 0);
+        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].im, ci[t], 0, 0, 0);
+        cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, bv[t].im, cr[t], 0, 0, 0);
+        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, bv[t].re, ci[t], 0, 0, 0);
+      }
+    a = an;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = bn[t];
+  }
+  // C: col = lane & 15, row = (lane >> 4) + 4 reg
+  for (int q = 0; q < KS; ++q) {                            // parts are added in wavefront order
+    if (w == q) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            dc* o = part + (lk + 4 * g) * (16 * NT) + 16 * t + lr;
+            if (q == 0) *o = dc_make(cr[t][g], ci[t][g]);
+            else { o->re += cr[t][g]; o->im += ci[t][g]; }
+          }
+        }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < 16 * npts; idx += 64 * KS) {
+    const int r = idx / npts, j = idx % npts;
+    if (c0 + r < nc) tr[(long long)(c0 + r) * P + pb + j] = part[r * (16 * NT) + j];
+  }
+}
+
+// tr = D up over one level: the dense form when it was built, the pair lists otherwise
+static int fmm_launch_translate(const int* fptr, const int* foth, const c64* fval, const c64* dense, int nc, int P, const c64* up, c64* tr, hipStream_t st) {
+  if (dense) {
+    constexpr int KS = 8;
+    const int rows = (nc + 15) / 16;
+    const dc* Dd = reinterpret_cast<const dc*>(dense); const dc* u = reinterpret_cast<const dc*>(up); dc* t = reinterpret_cast<dc*>(tr);
+    // few row tiles: the points are spread over more workgroups (D is then read once per 32 points, from L2 / Infinity Cache)
+    if (rows * ((P + 127) / 128) < 1024) hipLaunchKernelGGL((fmm_translate_dense_kernel<KS, 2>), dim3((unsigned)rows, (unsigned)((P + 31) / 32)), dim3(64 * KS), 0, st, Dd, nc, P, u, t);
+    else hipLaunchKernelGGL((fmm_translate_dense_kernel<KS, 8>), dim3((unsigned)rows, (unsigned)((P + 127) / 128)), dim3(64 * KS), 0, st, Dd, nc, P, u, t);
+  } else {
+    hipLaunchKernelGGL(slfmm_translate_kernel, dim3((unsigned)nc), dim3(256), 0, st, fptr, foth, reinterpret_cast<const dc*>(fval), P, reinterpret_cast<const dc*>(up),
+                       reinterpret_cast<dc*>(tr));
+  }
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// dense nc x nc form (stored by source) of pair lists grouped by receiving cluster; nullptr (lists stay in use) when fewer than a quarter of the pairs exist or when
+// MA_FMM_DENSE_TRANSLATE=0 asks for the lists
+static int fmm_dense_from_lists(const std::vector<int>& ptr, const std::vector<int>& oth, const std::vector<c64>& val, int nc, c64** d_out) {
+  *d_out = nullptr;
+  const char* e = getenv("MA_FMM_DENSE_TRANSLATE");
+  if (e && atoi(e) == 0) return MA_OK;
+  if (nc < 8 || (double)oth.size() < 0.25 * (double)nc * (double)nc || (double)nc * (double)nc * 16.0 > 16e9) return MA_OK;
+  std::vector<c64> dense((size_t)nc * (size_t)nc, c64{0.0, 0.0});
+  for (int c = 0; c < nc; ++c)
+    for (int q = ptr[(size_t)c]; q < ptr[(size_t)c + 1]; ++q) {
+      c64& o = dense[(size_t)oth[(size_t)q] * (size_t)nc + (size_t)c];          // by source: the receiving cluster is contiguous
+      o.re += val[(size_t)q].re; o.im += val[(size_t)q].im;
+    }
+  return upload(d_out, dense);
+}
+
+// near blocks in two passes. Pass 1, one wavefront (small blocks) or one workgroup (large ones) per block: the block is read ONCE
+// and both products it takes part in are formed, B x[cols] for the cluster that holds its rows and, off the diagonal, B^T x[rows] for
+// the other; they go to the block's two slots of `part`. Pass 2, per cluster: the slots of its entries are added in entry order.
+// The per-cluster kernel above reads every off-diagonal block twice, once from each side; this reads it once and the sums are
+// still taken in a fixed order. G lanes walk a row (G >= the block's width for a leaf), the 64 / G lane sets take eight rows each
+// per pass so that eight loads are in flight.
+template <int WPB>
+__global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ bsrc,
+                                                                const int* __restrict__ bfld, const long long* __restrict__ boff, const long long* __restrict__ broff,
+                                                                const long long* __restrict__ bcoff, int nblocks, const dc* __restrict__ bval,
+                                                                const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
+  __shared__ dc cpart[WPB == 1 ? 1 : 4 * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = WPB == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  const int w = WPB == 1 ? 0 : wave;
+  if (b >= nblocks) return;                                  // WPB == 1: no barrier below; WPB == 4: the whole workgroup leaves
+  const int a = bsrc[b], f = bfld[b];
+  const int a0 = eptr[a], ns = eptr[a + 1] - a0, f0 = eptr[f], nf = eptr[f + 1] - f0;
+  const dc* B = bval + boff[b];
+  const bool both = a != f, self_t = !both && tmode != 0;   // the transpose of a diagonal block: its column sums take the row slot
+  dc* prow = part + broff[b];
+  dc* pcol = both ? part + bcoff[b] : prow;
+  int G = 8; while (G < 64 && G < nf) G <<= 1;
+  const int JG = 64 / G, jg = lane / G, lg = lane % G;
+  constexpr int U = 8;
+  for (int j0 = 0; j0 < nf; j0 += G) {
+    const int j = j0 + lg;
+    const bool vj = j < nf;
+    const int jc = vj ? j : j0;
+    dc xf = x[edof[f0 + jc]];
+    if (!vj) xf = dc_make(0.0, 0.0);
+    double cr = 0.0, ci = 0.0;
+    for (int i0 = w * JG + jg; i0 < ns; i0 += WPB * JG * U) {
+      dc bb[U], xa[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * WPB * JG;
+        const int ii = i < ns ? i : i0;
+        bb[u] = B[(long long)ii * nf + jc];
+        xa[u] = x[edof[a0 + ii]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * WPB * JG;
+        const bool ok = i < ns;                              // the same for the whole lane set
+        double pr = (ok && vj) ? bb[u].re * xf.re - bb[u].im * xf.im : 0.0;
+        double pi = (ok && vj) ? bb[u].re * xf.im + bb[u].im * xf.re : 0.0;
+        for (int off = G >> 1; off > 0; off >>= 1) { pr += __shfl_xor(pr, off, 64); pi += __shfl_xor(pi, off, 64); }
+        if (ok && lg == 0 && !self_t) {
+          if (j0 == 0) prow[i] = dc_make(pr, pi);
+          else { prow[i].re += pr; prow[i].im += pi; }       // wider than 64: the same lane comes back to its row
+        }
+        if (ok && vj) { cr += bb[u].re * xa[u].re - bb[u].im * xa[u].im; ci += bb[u].re * xa[u].im + bb[u].im * xa[u].re; }
+      }
+    }
+    if (both || self_t) {                                    // uniform over the block
+      for (int off = G; off < 64; off <<= 1) { cr += __shfl_xor(cr, off, 64); ci += __shfl_xor(ci, off, 64); }
+      if (WPB == 1) {
+        if (jg == 0 && vj) pcol[j] = dc_make(cr, ci);
+      } else {
+        if (jg == 0) cpart[w * 64 + lg] = dc_make(cr, ci);
+        __syncthreads();
+        if (w == 0 && jg == 0 && vj) {
+          double tr_ = 0.0, ti_ = 0.0;
+          for (int q = 0; q < 4; ++q) { tr_ += cpart[q * 64 + lg].re; ti_ += cpart[q * 64 + lg].im; }
+          pcol[j] = dc_make(tr_, ti_);
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+template <int WPC>
+__global__ __launch_bounds__(256) void slfmm_near_gather_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
+                                                                const SlfmmEntry* __restrict__ cent, const dc* __restrict__ part, dc* __restrict__ y,
+                                                                int overlap, int nclusters) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (4 / WPC) + wave / WPC, w = wave % WPC;
+  if (c >= nclusters) return;
+  const int e0 = eptr[c], nc_ = eptr[c + 1] - e0, q0 = cptr[c], q1 = cptr[c + 1];
+  constexpr int U = 8;
+  for (int i = w * 64 + lane; i < nc_; i += 64 * WPC) {
+    double sr = 0.0, si = 0.0;
+    for (int q = q0; q < q1; q += U) {
+      dc v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = part[cent[q + u < q1 ? q + u : q].poff + i];
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (q + u < q1) { sr += v[u].re; si += v[u].im; }
+    }
+    dc* o = y + edof[e0 + i];
+    if (overlap) { atomicAdd(&o->re, sr); atomicAdd(&o->im, si); }         // the dof is a row of several clusters
+    else *o = dc_make(sr, si);
+  }
+}
+
 static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st) {
   const int avg = S->nc > 0 ? (int)((S->h_eptr.empty() ? 0 : S->h_eptr.back()) / S->nc) : 0;
   int G = 8; while (G < 64 && G < avg) G <<= 1;
+  if (S->d_part) {
+    const dc* bv = reinterpret_cast<const dc*>(S->d_bval); dc* part = reinterpret_cast<dc*>(S->d_part);
+    if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, dim3((unsigned)((S->nblocks + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
+                                                   S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
+    else hipLaunchKernelGGL(slfmm_near_blocks_kernel<4>, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+                            S->d_bcoff, S->nblocks, bv, x, part, tmode);
+    MA_HIP(hipGetLastError());
+    if (avg <= 48) hipLaunchKernelGGL(slfmm_near_gather_kernel<1>, dim3((unsigned)((S->nc + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, part, y,
+                                      S->overlap ? 1 : 0, S->nc);
+    else hipLaunchKernelGGL(slfmm_near_gather_kernel<4>, dim3((unsigned)S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, part, y, S->overlap ? 1 : 0, S->nc);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+  }
   if (avg <= 48) hipLaunchKernelGGL(slfmm_near_kernel<1>, dim3((unsigned)((S->nc + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent,
                                     reinterpret_cast<const dc*>(S->d_bval), x, y, tmode, S->overlap ? 1 : 0, S->nc, G);
   else hipLaunchKernelGGL(slfmm_near_kernel<4>, dim3((unsigned)S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent,
@@ -306,7 +524,7 @@ void slfmm_destroy(ma_slfmm* S) {
   if (!S) return;
   (void)hipSetDevice(S->device);
   void* p[] = {S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->d_bval, S->d_cptr, S->d_cent, S->d_fptr, S->d_foth, S->d_fval, S->d_tptr, S->d_toth,
-               S->d_tval, S->d_up, S->d_tr};
+               S->d_tval, S->d_up, S->d_tr, S->d_fdense, S->d_tdense, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff, S->d_bcoff, S->d_part};
   for (void* q : p) if (q) (void)hipFree(q);
   delete S;
 }
@@ -422,9 +640,14 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   flatten(by_field, fptr, foth, fval); flatten(by_source, tptr, toth, tval);
   // ---- per-cluster views of the blocks: as source (rows of the block) or as field of an off-diagonal block (its transpose)
   std::vector<std::vector<SlfmmEntry>> views((size_t)nc);
+  std::vector<long long> broff(bsrc.size()), bcoff(bsrc.size()); long long npart = 0, max_block = 0;
   for (size_t b = 0; b < bsrc.size(); ++b) {
-    views[(size_t)bsrc[b]].push_back({boff[b], bfld[b], 0});
-    if (bsrc[b] != bfld[b]) views[(size_t)bfld[b]].push_back({boff[b], bsrc[b], 1});
+    const long long ns = eptr[(size_t)bsrc[b] + 1] - eptr[(size_t)bsrc[b]], nf = eptr[(size_t)bfld[b] + 1] - eptr[(size_t)bfld[b]];
+    broff[b] = npart; npart += ns;
+    bcoff[b] = npart; if (bsrc[b] != bfld[b]) npart += nf;
+    max_block = std::max(max_block, ns * nf);
+    views[(size_t)bsrc[b]].push_back({boff[b], broff[b], bfld[b], 0});
+    if (bsrc[b] != bfld[b]) views[(size_t)bfld[b]].push_back({boff[b], bcoff[b], bsrc[b], 1});
   }
   std::vector<int> cptr(1, 0); std::vector<SlfmmEntry> cent;
   for (const auto& v : views) { cent.insert(cent.end(), v.begin(), v.end()); cptr.push_back((int)cent.size()); }
@@ -433,6 +656,16 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   UP(d_eptr, eptr); UP(d_eidx, eidx); UP(d_edof, edof); UP(d_cc, cc); UP(d_sc, sc); UP(d_sw, sw); UP(d_cptr, cptr); UP(d_cent, cent);
   UP(d_fptr, fptr); UP(d_foth, foth); UP(d_fval, fval); UP(d_tptr, tptr); UP(d_toth, toth); UP(d_tval, tval);
 #undef UP
+  if (!rc) rc = fmm_dense_from_lists(fptr, foth, fval, nc, &S->d_fdense);
+  { const char* e = getenv("MA_FMM_NEAR_BLOCKS");           // =0: the per-cluster kernel (every off-diagonal block read from both sides)
+    if (!rc && !(e && atoi(e) == 0) && !bsrc.empty()) {
+      S->nblocks = (int)bsrc.size(); S->max_block = max_block;
+      rc = upload(&S->d_bsrc, bsrc); if (!rc) rc = upload(&S->d_bfld, bfld); if (!rc) rc = upload(&S->d_boff, boff);
+      if (!rc) rc = upload(&S->d_broff, broff);
+      if (!rc) rc = upload(&S->d_bcoff, bcoff);
+      if (!rc && hipMalloc(&S->d_part, sizeof(c64) * (size_t)std::max(npart, 1LL)) != hipSuccess) { set_error("near-field partial sums"); rc = MA_ERR_NOMEM; }
+    } }
+  if (!rc) rc = fmm_dense_from_lists(tptr, toth, tval, nc, &S->d_tdense);
   if (rc) return fail(rc);
   hipError_t e = hipMalloc(&S->d_bval, sizeof(c64) * (size_t)std::max<long long>(tot, 1));
   if (e == hipSuccess) e = hipMalloc(&S->d_up, sizeof(c64) * (size_t)nc * (size_t)P);
@@ -474,9 +707,8 @@ int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_
   hipLaunchKernelGGL(slfmm_up_kernel, dim3(S->nc), dim3(256), 0, st, g, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, s_up, x,
                      reinterpret_cast<dc*>(S->d_up));
   MA_HIP(hipGetLastError());
-  hipLaunchKernelGGL(slfmm_translate_kernel, dim3(S->nc), dim3(256), 0, st, transpose ? S->d_tptr : S->d_fptr, transpose ? S->d_toth : S->d_foth,
-                     reinterpret_cast<const dc*>(transpose ? S->d_tval : S->d_fval), S->P, reinterpret_cast<const dc*>(S->d_up), reinterpret_cast<dc*>(S->d_tr));
-  MA_HIP(hipGetLastError());
+  { int rc = fmm_launch_translate(transpose ? S->d_tptr : S->d_fptr, transpose ? S->d_toth : S->d_foth, transpose ? S->d_tval : S->d_fval,
+                                  transpose ? S->d_tdense : S->d_fdense, S->nc, S->P, S->d_up, S->d_tr, st); if (rc) return rc; }
   hipLaunchKernelGGL(slfmm_down_kernel, dim3(S->nc), dim3(256), 0, st, g, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, s_dn,
                      reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
   MA_HIP(hipGetLastError());
@@ -667,6 +899,7 @@ struct MlLevel {                                      // one level at or above t
   int nc = 0, P = 0;
   double* d_cc = nullptr; double* d_sc = nullptr; double* d_sw = nullptr;
   int* d_fptr = nullptr; int* d_foth = nullptr; c64* d_fval = nullptr;    // far pairs grouped by field cluster
+  c64* d_fdense = nullptr;                                                 // the same as a dense nc x nc matrix, when the lists are nearly full
   int* d_sptr = nullptr; int* d_sidx = nullptr;                            // sons (indices into the level below)
   c64* d_M = nullptr; c64* d_L = nullptr;                                  // multipoles / locals, nc x P (the leaf level uses the single-level buffers)
 };
@@ -734,7 +967,7 @@ __global__ __launch_bounds__(256) void mlfmm_l2l_kernel(const int* __restrict__ 
   }
 }
 void ml_level_free(MlLevel& L) {
-  void* p[] = {L.d_cc, L.d_sc, L.d_sw, L.d_fptr, L.d_foth, L.d_fval, L.d_sptr, L.d_sidx, L.d_M, L.d_L};
+  void* p[] = {L.d_cc, L.d_sc, L.d_sw, L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.d_sptr, L.d_sidx, L.d_M, L.d_L};
   for (void* q : p) if (q) (void)hipFree(q);
 }
 bool theta_tabulated(int t) { return t >= 1 && t <= 20 && mat_gl_index[t][1] == t; }
@@ -834,6 +1067,7 @@ int mlfmm_create(ma_bem_plan* plan, const ma_cluster_tree* T, const ma_physics_t
       if (!rc) rc = upload(&L.d_fptr, fptr);
       if (!rc) rc = upload(&L.d_foth, foth);
       if (!rc) rc = upload(&L.d_fval, fval);
+      if (!rc) rc = fmm_dense_from_lists(fptr, foth, fval, L.nc, &L.d_fdense);
       if (!rc) rc = upload(&L.d_sptr, sptr);
       if (!rc) rc = upload(&L.d_sidx, sidx);
       if (!rc && hipMalloc(&L.d_M, sizeof(c64) * (size_t)L.nc * (size_t)L.P) != hipSuccess) { set_error("MLFMM level buffers"); rc = MA_ERR_NOMEM; }
@@ -869,13 +1103,9 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   // translation at every level
   for (int l = 0; l < nu; ++l) {
     MlLevel& L = S->up[(size_t)l];
-    hipLaunchKernelGGL(slfmm_translate_kernel, dim3(L.nc), dim3(256), 0, st, L.d_fptr, L.d_foth, reinterpret_cast<const dc*>(L.d_fval), L.P, reinterpret_cast<const dc*>(L.d_M),
-                       reinterpret_cast<dc*>(L.d_L));
-    MA_HIP(hipGetLastError());
+    { int rc = fmm_launch_translate(L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.nc, L.P, L.d_M, L.d_L, st); if (rc) return rc; }
   }
-  hipLaunchKernelGGL(slfmm_translate_kernel, dim3(F->nc), dim3(256), 0, st, F->d_fptr, F->d_foth, reinterpret_cast<const dc*>(F->d_fval), F->P, reinterpret_cast<const dc*>(F->d_up),
-                     reinterpret_cast<dc*>(F->d_tr));
-  MA_HIP(hipGetLastError());
+  { int rc = fmm_launch_translate(F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr, st); if (rc) return rc; }
   // downward pass
   for (int l = 0; l < nu; ++l) {
     MlLevel& L = S->up[(size_t)l];
