@@ -37,6 +37,7 @@ struct ma_slfmm {
   int* d_bsrc = nullptr; int* d_bfld = nullptr; long long* d_boff = nullptr; int nblocks = 0;   // the near blocks one by one
   long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0;   // their partial sums (rows, columns)
   c64* d_up = nullptr; c64* d_tr = nullptr;
+  c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=0: recomputed)
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
   // host copies for extract_near_field_matrix
   std::vector<int> h_eptr, h_edof, h_bsrc, h_bfld; std::vector<long long> h_boff;
@@ -397,6 +398,23 @@ static int fmm_dense_from_lists(const std::vector<int>& ptr, const std::vector<i
   return upload(d_out, dense);
 }
 
+// sum over an aligned set of G lanes (8 <= G <= 64, a power of two), every lane receives it: DPP inside a row of 16 lanes
+// (no LDS crossbar), ds_bpermute only for the two widest steps
+template <int CTRL>
+__device__ __forceinline__ double fmm_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fmm_set_sum(double v, int G) {
+  v += fmm_dpp<0xB1>(v);                                     // quad_perm [1,0,3,2]
+  v += fmm_dpp<0x4E>(v);                                     // quad_perm [2,3,0,1]
+  v += fmm_dpp<0x141>(v);                                    // row_half_mirror: the other quad of eight
+  if (G >= 16) v += fmm_dpp<0x140>(v);                       // row_mirror: the other eight of sixteen
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
 // near blocks in two passes. Pass 1, one wavefront (small blocks) or one workgroup (large ones) per block: the block is read ONCE
 // and both products it takes part in are formed, B x[cols] for the cluster that holds its rows and, off the diagonal, B^T x[rows] for
 // the other; they go to the block's two slots of `part`. Pass 2, per cluster: the slots of its entries are added in entry order.
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
   dc* pcol = both ? part + bcoff[b] : prow;
   int G = 8; while (G < 64 && G < nf) G <<= 1;
   const int JG = 64 / G, jg = lane / G, lg = lane % G;
-  constexpr int U = 8;
+  constexpr int U = WPB == 1 ? 2 : 8;                        // small blocks: occupancy pays more than loads in flight (measured 1, 2, 4, 8)
   for (int j0 = 0; j0 < nf; j0 += G) {
     const int j = j0 + lg;
     const bool vj = j < nf;
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
         const bool ok = i < ns;                              // the same for the whole lane set
         double pr = (ok && vj) ? bb[u].re * xf.re - bb[u].im * xf.im : 0.0;
         double pi = (ok && vj) ? bb[u].re * xf.im + bb[u].im * xf.re : 0.0;
-        for (int off = G >> 1; off > 0; off >>= 1) { pr += __shfl_xor(pr, off, 64); pi += __shfl_xor(pi, off, 64); }
+        pr = fmm_set_sum(pr, G); pi = fmm_set_sum(pi, G);
         if (ok && lg == 0 && !self_t) {
           if (j0 == 0) prow[i] = dc_make(pr, pi);
           else { prow[i].re += pr; prow[i].im += pi; }       // wider than 64: the same lane comes back to its row
@@ -493,6 +511,108 @@ __global__ __launch_bounds__(256) void slfmm_near_gather_kernel(const int* __res
   }
 }
 
+// The T and S matrices of the reference (slfmm.rs stores them per cluster) as one table E[listed element][sphere point] =
+// w_p e^{+i k s_p.(x_j - C_c)}: T uses its conjugate phase, S the phase itself (and the other way round for the transpose). Stored,
+// the upward and downward passes stream 16 B per (element, point) instead of evaluating a double-precision sincos for it.
+__global__ __launch_bounds__(256) void slfmm_phase_table_kernel(BemGeom g, const int* __restrict__ eptr, const int* __restrict__ eidx, const double* __restrict__ cc,
+                                                                const double* __restrict__ sc, const double* __restrict__ sw, int P, double k, dc* __restrict__ E) {
+  const int c = blockIdx.x;
+  const int e0 = eptr[c], n = eptr[c + 1] - e0;
+  const double Cx = cc[3 * c], Cy = cc[3 * c + 1], Cz = cc[3 * c + 2];
+  for (long long idx = threadIdx.x; idx < (long long)n * P; idx += 256) {
+    const int j = (int)(idx / P), p = (int)(idx % P);
+    const int e = eidx[e0 + j];
+    const double sd = sc[3 * p] * (g.c[0][e] - Cx) + sc[3 * p + 1] * (g.c[1][e] - Cy) + sc[3 * p + 2] * (g.c[2][e] - Cz);
+    double sn, cs; sincos(k * sd, &sn, &cs);
+    E[(long long)e0 * P + idx] = dc_make(cs * sw[p], sn * sw[p]);
+  }
+}
+// up[c][p] = sum_j (E.re, sgn E.im) x[dof_j]: 256 / P thread sets split the elements, their parts are added in set order
+__global__ __launch_bounds__(256) void slfmm_up_tab_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const dc* __restrict__ E, int P, double sgn,
+                                                           const dc* __restrict__ x, dc* __restrict__ up) {
+  __shared__ dc part[256];
+  constexpr int U = 4;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int e0 = eptr[c], n = eptr[c + 1] - e0;
+  const int QG = P <= 256 ? 256 / P : 1;
+  for (int pb = 0; pb < P; pb += 256) {
+    const int qg = P <= 256 ? tid / P : 0, p = pb + (P <= 256 ? tid % P : tid);
+    double sr = 0.0, si = 0.0;
+    if (qg < QG && p < P)
+      for (int j = qg; j < n; j += QG * U) {
+        dc ev[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jj = j + u * QG < n ? j + u * QG : j;
+          ev[u] = E[(long long)(e0 + jj) * P + p]; xv[u] = x[edof[e0 + jj]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (j + u * QG < n) {
+            const double er = ev[u].re, ei = sgn * ev[u].im;
+            sr += er * xv[u].re - ei * xv[u].im; si += er * xv[u].im + ei * xv[u].re;
+          }
+      }
+    if (P > 256) { if (p < P) up[(long long)c * P + p] = dc_make(sr, si); continue; }
+    part[tid] = dc_make(sr, si);
+    __syncthreads();
+    if (tid < P) {
+      double tr_ = 0.0, ti_ = 0.0;
+      for (int q = 0; q < QG; ++q) { tr_ += part[q * P + tid].re; ti_ += part[q * P + tid].im; }
+      up[(long long)c * P + tid] = dc_make(tr_, ti_);
+    }
+  }
+}
+// y[dof_j] += sum_p (E.re, sgn E.im) tr[c][p]: a wavefront per element (four at a time), lanes over the sphere points
+__global__ __launch_bounds__(256) void slfmm_down_tab_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const dc* __restrict__ E, int P, double sgn,
+                                                             const dc* __restrict__ tr, dc* __restrict__ y, int overlap) {
+  constexpr int U = 4;
+  const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e0 = eptr[c], n = eptr[c + 1] - e0;
+  const dc* l = tr + (long long)c * P;
+  for (int j0 = wave * U; j0 < n; j0 += 4 * U) {
+    double sr[U], si[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { sr[u] = 0.0; si[u] = 0.0; }
+    for (int p = lane; p < P; p += 64) {
+      const dc lv = l[p];
+      dc ev[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) ev[u] = E[(long long)(e0 + (j0 + u < n ? j0 + u : j0)) * P + p];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double er = ev[u].re, ei = sgn * ev[u].im;
+        sr[u] += er * lv.re - ei * lv.im; si[u] += er * lv.im + ei * lv.re;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double a = fmm_set_sum(sr[u], 64), b = fmm_set_sum(si[u], 64);
+      if (lane == 0 && j0 + u < n) {
+        dc* o = y + edof[e0 + j0 + u];
+        if (overlap) { atomicAdd(&o->re, a); atomicAdd(&o->im, b); }
+        else { o->re += a; o->im += b; }
+      }
+    }
+  }
+}
+static int slfmm_launch_up(const ma_slfmm* S, double sgn, const dc* x, hipStream_t st) {
+  if (S->d_phase) hipLaunchKernelGGL(slfmm_up_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn, x,
+                                     reinterpret_cast<dc*>(S->d_up));
+  else hipLaunchKernelGGL(slfmm_up_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn, x,
+                          reinterpret_cast<dc*>(S->d_up));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+static int slfmm_launch_down(const ma_slfmm* S, double sgn, dc* y, hipStream_t st) {
+  if (S->d_phase) hipLaunchKernelGGL(slfmm_down_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn,
+                                     reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
+  else hipLaunchKernelGGL(slfmm_down_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn,
+                          reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st) {
   const int avg = S->nc > 0 ? (int)((S->h_eptr.empty() ? 0 : S->h_eptr.back()) / S->nc) : 0;
   int G = 8; while (G < 64 && G < avg) G <<= 1;
@@ -524,7 +644,7 @@ void slfmm_destroy(ma_slfmm* S) {
   if (!S) return;
   (void)hipSetDevice(S->device);
   void* p[] = {S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->d_bval, S->d_cptr, S->d_cent, S->d_fptr, S->d_foth, S->d_fval, S->d_tptr, S->d_toth,
-               S->d_tval, S->d_up, S->d_tr, S->d_fdense, S->d_tdense, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff, S->d_bcoff, S->d_part};
+               S->d_tval, S->d_up, S->d_tr, S->d_fdense, S->d_tdense, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff, S->d_bcoff, S->d_part, S->d_phase};
   for (void* q : p) if (q) (void)hipFree(q);
   delete S;
 }
@@ -689,6 +809,14 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
                        reinterpret_cast<const dc*>(d_self), free_term ? physics->gamma : 0.5 * physics->gamma, reinterpret_cast<dc*>(S->d_bval));
     if (hipGetLastError() != hipSuccess) { set_error("SLFMM diagonal kernel failed"); rc = MA_ERR_HIP; }
   }
+  { const char* ev = getenv("MA_FMM_STORE_PHASES");
+    const size_t listed = (size_t)eptr.back();
+    if (!rc && !(ev && atoi(ev) == 0) && listed > 0 && hipMalloc(&S->d_phase, sizeof(c64) * listed * (size_t)P) == hipSuccess) {
+      hipLaunchKernelGGL(slfmm_phase_table_kernel, dim3(nc), dim3(256), 0, nullptr, plan->geom, S->d_eptr, S->d_eidx, S->d_cc, S->d_sc, S->d_sw, P, S->k,
+                         reinterpret_cast<dc*>(S->d_phase));
+      if (hipGetLastError() != hipSuccess) { set_error("SLFMM phase table kernel failed"); rc = MA_ERR_HIP; }
+    } else if (!rc) { (void)hipGetLastError(); S->d_phase = nullptr; }       // no room: the passes evaluate the phases
+  }
   if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("SLFMM near-field kernels failed"); rc = MA_ERR_HIP; }
   drop();
   if (rc) return fail(rc);
@@ -698,20 +826,15 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
 
 int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_t st) {
   MA_HIP(hipSetDevice(S->device));
-  const BemGeom& g = S->plan->geom;
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));        // dofs outside every cluster receive nothing
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
   { int rc = slfmm_launch_near(S, x, y, transpose, st); if (rc) return rc; }
   // far field: forward T (e^-), D grouped by field, S (e^+); transpose S^T (e^+), D grouped by source, T^T (e^-)
   const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
-  hipLaunchKernelGGL(slfmm_up_kernel, dim3(S->nc), dim3(256), 0, st, g, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, s_up, x,
-                     reinterpret_cast<dc*>(S->d_up));
-  MA_HIP(hipGetLastError());
+  { int rc = slfmm_launch_up(S, s_up, x, st); if (rc) return rc; }
   { int rc = fmm_launch_translate(transpose ? S->d_tptr : S->d_fptr, transpose ? S->d_toth : S->d_foth, transpose ? S->d_tval : S->d_fval,
                                   transpose ? S->d_tdense : S->d_fdense, S->nc, S->P, S->d_up, S->d_tr, st); if (rc) return rc; }
-  hipLaunchKernelGGL(slfmm_down_kernel, dim3(S->nc), dim3(256), 0, st, g, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, s_dn,
-                     reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
-  MA_HIP(hipGetLastError());
+  { int rc = slfmm_launch_down(S, s_dn, y, st); if (rc) return rc; }
   return MA_OK;
 }
 
@@ -1082,14 +1205,12 @@ int mlfmm_create(ma_bem_plan* plan, const ma_cluster_tree* T, const ma_physics_t
 int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   MA_HIP(hipSetDevice(S->device));
   ma_slfmm* F = S->leaf;
-  const BemGeom& g = F->plan->geom;
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
   { int rc = slfmm_launch_near(F, x, y, 0, st); if (rc) return rc; }
   if (!S->far_field) return MA_OK;
   // upward pass: leaf multipoles, then level by level to the top level that has far pairs
-  hipLaunchKernelGGL(slfmm_up_kernel, dim3(F->nc), dim3(256), 0, st, g, F->d_eptr, F->d_eidx, F->d_edof, F->d_cc, F->d_sc, F->d_sw, F->P, S->k, -1.0, x, reinterpret_cast<dc*>(F->d_up));
-  MA_HIP(hipGetLastError());
+  { int rc = slfmm_launch_up(F, -1.0, x, st); if (rc) return rc; }
   const int nu = (int)S->up.size();
   for (int l = nu - 1; l >= 0; --l) {
     MlLevel& L = S->up[(size_t)l];
@@ -1116,8 +1237,6 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     hipLaunchKernelGGL(mlfmm_l2l_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, reinterpret_cast<const dc*>(L.d_L), Lc);
     MA_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(slfmm_down_kernel, dim3(F->nc), dim3(256), 0, st, g, F->d_eptr, F->d_eidx, F->d_edof, F->d_cc, F->d_sc, F->d_sw, F->P, S->k, 1.0,
-                     reinterpret_cast<const dc*>(F->d_tr), y, F->overlap ? 1 : 0);
-  MA_HIP(hipGetLastError());
+  { int rc = slfmm_launch_down(F, 1.0, y, st); if (rc) return rc; }
   return MA_OK;
 }
