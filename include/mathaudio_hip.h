@@ -376,6 +376,32 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out);
  * V-cycle on the residual). Use with ma_gmres_preconditioned (SolverType::GmresAmg, math-fem/src/solver/mod.rs:667). */
 int ma_precond_create_amg(int32_t nlevels, ma_csr_t* const* A, ma_csr_t* const* P, ma_csr_t* const* R, int32_t smoother, double jacobi_weight,
                           int32_t num_pre_smooth, int32_t num_post_smooth, int32_t cycle, ma_precond_t** out);
+/* AmgPreconditioner::from_csr(matrix, config) (math-solvers/src/preconditioners/amg.rs:276-372): the whole preconditioner from the matrix.
+ * The hierarchy is built on the host inside the library with the reference's steps in their order -- compute_strength_matrix (:418-474),
+ * coarsen_ruge_stuben (:477-532) or coarsen_pmis (:535-642), build_interpolation (:645-807: Standard / Extended / Direct, truncation),
+ * R = transpose_csr(P) (:810-822), A_c = R (A P) with CsrMatrix::matmul (sparse/csr.rs:594-651, entries of norm <= 1e-15 dropped) -- and
+ * uploaded level by level; the V / W / F cycle then runs on the device as for ma_precond_create_amg. The level operators are owned by
+ * the preconditioner, `A` (level 0) is borrowed and read with its current values (after ma_csr_set_wavenumber).
+ * AmgConfig (:104-146), enums in their declaration order:
+ *   coarsening 0 RugeStuben, 1 Pmis, 2 Hmis (the reference runs Pmis for it); interpolation 0 Standard, 1 Extended, 2 Direct;
+ *   smoother 0 Jacobi, 1 L1Jacobi, 2 SymmetricGaussSeidel, 3 Chebyshev (the reference smooths with Jacobi for it); cycle 0 V, 1 W, 2 F.
+ * aggressive_coarsening_levels is carried and, as in the reference, not read. */
+typedef struct ma_amg_config {
+  int32_t coarsening, interpolation, smoother, cycle;
+  double strong_threshold;
+  int32_t max_levels, coarse_size, num_pre_smooth, num_post_smooth;
+  double jacobi_weight, trunc_factor;
+  int32_t max_interp_elements, aggressive_coarsening_levels;
+} ma_amg_config_t;
+/* which: 0 AmgConfig::default() (:148-167), 1 for_bem (:173-181), 2 for_fem (:184-191), 3 for_parallel (:194-203),
+ * 4 for_difficult_problems (:206-218) */
+int ma_amg_config_preset(int32_t which, ma_amg_config_t* cfg);
+int ma_precond_create_amg_from_csr(ma_csr_t* A, const ma_amg_config_t* cfg, ma_precond_t** out);
+/* num_levels / grid_complexity / operator_complexity / setup_time_ms (:375-392); any pointer may be NULL */
+int ma_precond_amg_info(ma_precond_t* M, int32_t* num_levels, double* grid_complexity, double* operator_complexity, double* setup_time_ms);
+/* the handles of one level (borrowed; P and R are NULL on the coarsest): AmgDiagnostics (:1107-1133) reads their sizes, the tests
+ * their entries (ma_csr_get) */
+int ma_precond_amg_level(ma_precond_t* M, int32_t level, ma_csr_t** A, ma_csr_t** P, ma_csr_t** R);
 /* IluPreconditioner::from_csr(matrix) (math-solvers/src/preconditioners/ilu.rs:36-140) and its apply (:143-175): ILU(0) on the matrix' own
  * pattern. The factorisation runs on the host with the reference's loops (setup, like the AMG hierarchy), the two triangular solves of
  * every apply on the device (level-scheduled). Use with ma_gmres_preconditioned: gmres_solve_with_ilu(_operator)

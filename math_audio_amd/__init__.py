@@ -140,6 +140,10 @@ def lib():
             "ma_op_slfmm_near_matrix": [vp, vp],
             "ma_precond_create_ilu0": [vp, P(vp)],
             "ma_csr_get": [vp, vp, vp, vp],
+            "ma_amg_config_preset": [i32, vp],
+            "ma_precond_create_amg_from_csr": [vp, vp, P(vp)],
+            "ma_precond_amg_info": [vp, P(i32), P(dbl), P(dbl), P(dbl)],
+            "ma_precond_amg_level": [vp, i32, P(vp), P(vp), P(vp)],
             "ma_bicgstab": [vp, vp, i32, dbl, vp, vp],
             "ma_cgs": [vp, vp, i32, dbl, vp, vp],
             "ma_cg": [vp, vp, i32, dbl, vp, vp],
@@ -988,6 +992,80 @@ class AmgPreconditioner:
         self.h = C.c_void_p()
         check(lib().ma_precond_create_amg(L, C.cast(A, C.c_void_p), C.cast(Pm, C.c_void_p), C.cast(R, C.c_void_p), sm, float(jacobi_weight),
                                           int(num_pre_smooth), int(num_post_smooth), cy, C.byref(self.h)))
+
+    def apply(self, r):
+        r = np.ascontiguousarray(r, dtype=np.complex128); z = np.empty_like(r)
+        check(lib().ma_precond_apply(self.h, _vp(r), _vp(z)))
+        return z
+
+    def close(self):
+        if self.h:
+            lib().ma_precond_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AmgConfig(C.Structure):
+    """ma_amg_config_t = AmgConfig (amg.rs:104-146), enums as integers in their declaration order:
+    coarsening 0 RugeStuben / 1 Pmis / 2 Hmis, interpolation 0 Standard / 1 Extended / 2 Direct,
+    smoother 0 Jacobi / 1 L1Jacobi / 2 SymmetricGaussSeidel / 3 Chebyshev, cycle 0 V / 1 W / 2 F."""
+    _fields_ = [("coarsening", C.c_int32), ("interpolation", C.c_int32), ("smoother", C.c_int32), ("cycle", C.c_int32),
+                ("strong_threshold", C.c_double), ("max_levels", C.c_int32), ("coarse_size", C.c_int32), ("num_pre_smooth", C.c_int32),
+                ("num_post_smooth", C.c_int32), ("jacobi_weight", C.c_double), ("trunc_factor", C.c_double), ("max_interp_elements", C.c_int32),
+                ("aggressive_coarsening_levels", C.c_int32)]
+    _PRESETS = {"default": 0, "for_bem": 1, "for_fem": 2, "for_parallel": 3, "for_difficult_problems": 4}
+
+    @staticmethod
+    def preset(name="default", **overrides):
+        c = AmgConfig()
+        check(lib().ma_amg_config_preset(AmgConfig._PRESETS[name], C.byref(c)))
+        for k, v in overrides.items():
+            if k not in dict(AmgConfig._fields_):
+                raise KeyError(k)
+            setattr(c, k, v)
+        return c
+
+
+def _csr_arrays(h):
+    n = C.c_int64(); nnz = C.c_int64(); nc = C.c_int64()
+    check(lib().ma_csr_num_rows(h, C.byref(n), C.byref(nnz))); check(lib().ma_csr_num_cols(h, C.byref(nc)))
+    rp = np.empty(n.value + 1, dtype=np.int64); ci = np.empty(max(nnz.value, 1), dtype=np.int64); v = np.empty(max(nnz.value, 1), dtype=np.complex128)
+    check(lib().ma_csr_get(h, _vp(rp), _vp(ci), _vp(v)))
+    return {"shape": (n.value, nc.value), "row_ptrs": rp, "col_indices": ci[:nnz.value], "values": v[:nnz.value]}
+
+
+class AmgFromCsr:
+    """ma_precond_create_amg_from_csr: AmgPreconditioner::from_csr(matrix, config) (amg.rs:276-372) -- hierarchy built on the host inside
+    the library with the reference's steps, V / W / F cycle on the device. `csr_operator` (level 0) is borrowed."""
+
+    def __init__(self, csr_operator, config=None):
+        self._keep = csr_operator
+        self.config = config if config is not None else AmgConfig.preset()
+        self.h = C.c_void_p()
+        check(lib().ma_precond_create_amg_from_csr(csr_operator.h, C.byref(self.config), C.byref(self.h)))
+
+    def info(self):
+        nl = C.c_int32(); gc = C.c_double(); oc = C.c_double(); ms = C.c_double()
+        check(lib().ma_precond_amg_info(self.h, C.byref(nl), C.byref(gc), C.byref(oc), C.byref(ms)))
+        return {"num_levels": nl.value, "grid_complexity": gc.value, "operator_complexity": oc.value, "setup_time_ms": ms.value}
+
+    def level(self, l):
+        """{A, P, R}: each {"shape", "row_ptrs", "col_indices", "values"} read back from the level's handles (P, R None on the coarsest)."""
+        a = C.c_void_p(); p_ = C.c_void_p(); r = C.c_void_p()
+        check(lib().ma_precond_amg_level(self.h, int(l), C.byref(a), C.byref(p_), C.byref(r)))
+        return {"A": _csr_arrays(a), "P": _csr_arrays(p_) if p_ else None, "R": _csr_arrays(r) if r else None}
+
+    def diagnostics(self):
+        """AmgDiagnostics (amg.rs:1107-1133)."""
+        d = self.info()
+        lv = [self.level(l)["A"] for l in range(d["num_levels"])]
+        d.update(level_dofs=[a["shape"][0] for a in lv], level_nnz=[len(a["values"]) for a in lv])
+        return d
 
     def apply(self, r):
         r = np.ascontiguousarray(r, dtype=np.complex128); z = np.empty_like(r)

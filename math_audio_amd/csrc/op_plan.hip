@@ -2,6 +2,8 @@
 // restarted GMRES (math-solvers/src/iterative/gmres.rs:105-277) on the device.
 #include "op_kernels.hpp"
 #include "fmm_plan.hpp"
+#include "amg_setup.hpp"
+#include <chrono>
 #include "ma_tables.h"
 #include <vector>
 #include <algorithm>
@@ -472,6 +474,7 @@ struct ma_precond {
   c64* d_invdiag = nullptr;      // kind 4: 1 / a_ii of an operator (DiagonalPreconditioner::from_diagonal)
   // kind 5: AmgPreconditioner::apply (amg.rs:1068-1103)
   std::vector<AmgLevelDev> lv; int amg_smoother = 0, amg_pre = 1, amg_post = 1, amg_cycle = 0;
+  std::vector<ma_csr*> amg_owned; double amg_gc = 1.0, amg_oc = 1.0, amg_setup_ms = 0.0;   // from_csr: the levels it built, amg.rs:375-392
   // kind 6: IluPreconditioner (ilu.rs): L (strictly lower, unit diagonal implied) and U (diagonal + upper) as operators of their own
   ma_csr* ilu_l = nullptr; ma_csr* ilu_u = nullptr;
 };
@@ -606,7 +609,74 @@ int ma_precond_destroy(ma_precond_t* M) {
   if (M->d_invdiag) (void)hipFree(M->d_invdiag);
   if (M->ilu_l) (void)ma_csr_destroy(M->ilu_l);
   if (M->ilu_u) (void)ma_csr_destroy(M->ilu_u);
+  for (ma_csr* h : M->amg_owned) if (h) (void)ma_csr_destroy(h);
   delete M; return MA_OK;
+}
+// AmgPreconditioner::from_csr (amg.rs:276-372): the matrix' current values come back to the host, the hierarchy is built there with
+// the reference's steps (amg_setup.hip), every level goes up as an operator of its own and the device cycle of
+// ma_precond_create_amg runs over them.
+extern "C" int ma_csr_create(int64_t n, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr** out);
+extern "C" int ma_csr_create_rect(int64_t nrows, int64_t ncols, const int64_t* row_ptrs, const int64_t* col_indices, const ma_c64* values, int device, ma_csr** out);
+int ma_precond_create_amg_from_csr(ma_csr_t* A, const ma_amg_config_t* cfg, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(A && cfg, MA_ERR_INVALID, "A or cfg is NULL");
+  MA_REQUIRE(cfg->coarsening >= 0 && cfg->coarsening <= 2 && cfg->interpolation >= 0 && cfg->interpolation <= 2 && cfg->smoother >= 0 && cfg->smoother <= 3 &&
+             cfg->cycle >= 0 && cfg->cycle <= 2, MA_ERR_INVALID, "AmgConfig: coarsening %d, interpolation %d, smoother %d, cycle %d", (int)cfg->coarsening,
+             (int)cfg->interpolation, (int)cfg->smoother, (int)cfg->cycle);
+  MA_REQUIRE(cfg->max_levels >= 1 && cfg->max_levels <= 64 && cfg->coarse_size >= 0 && cfg->num_pre_smooth >= 0 && cfg->num_post_smooth >= 0 &&
+             cfg->max_interp_elements >= 0, MA_ERR_INVALID, "AmgConfig: max_levels %d (1..64), coarse_size %d, sweeps %d / %d", (int)cfg->max_levels,
+             (int)cfg->coarse_size, (int)cfg->num_pre_smooth, (int)cfg->num_post_smooth);
+  const auto t0 = std::chrono::steady_clock::now();
+  int64_t n = 0, nnz = 0, nc = 0; int dev = 0;
+  int rc = ma_csr_num_rows(A, &n, &nnz); if (rc) return rc;
+  rc = ma_csr_num_cols(A, &nc); if (rc) return rc;
+  rc = ma_csr_device(A, &dev); if (rc) return rc;
+  MA_REQUIRE(nc == n && n > 0, MA_ERR_INVALID, "AMG needs a square, non-empty operator");
+  HostCsr H; H.nr = n; H.nc = n; H.ptr.resize((size_t)n + 1); H.col.resize((size_t)nnz); H.val.resize((size_t)nnz);
+  { std::vector<int64_t> col((size_t)std::max<int64_t>(nnz, 1)); std::vector<ma_c64> v((size_t)std::max<int64_t>(nnz, 1));
+    rc = ma_csr_get(A, H.ptr.data(), col.data(), v.data()); if (rc) return rc;
+    for (int64_t q = 0; q < nnz; ++q) { H.col[(size_t)q] = col[(size_t)q]; H.val[(size_t)q] = c64{v[(size_t)q].re, v[(size_t)q].im}; } }
+  std::vector<HostCsr> As, Ps, Rs; double gc = 1.0, oc = 1.0;
+  rc = amg_setup_host(H, *cfg, As, Ps, Rs, &gc, &oc); if (rc) return rc;
+  const size_t L = As.size();
+  std::vector<ma_csr*> hA(L, nullptr), hP(L, nullptr), hR(L, nullptr), owned;
+  hA[0] = A;
+  auto up = [&](const HostCsr& m, bool square, ma_csr** h) -> int {
+    static const int64_t zero_col = 0; static const ma_c64 zero_val = {0.0, 0.0};
+    const int64_t* cp = m.col.empty() ? &zero_col : m.col.data();
+    const ma_c64* vp = m.val.empty() ? &zero_val : reinterpret_cast<const ma_c64*>(m.val.data());
+    int r = square ? ma_csr_create(m.nr, m.ptr.data(), cp, vp, dev, h) : ma_csr_create_rect(m.nr, m.nc, m.ptr.data(), cp, vp, dev, h);
+    if (!r) owned.push_back(*h);
+    return r;
+  };
+  for (size_t l = 0; l < L && !rc; ++l) {
+    if (l > 0) rc = up(As[l], true, &hA[l]);
+    if (!rc && l + 1 < L) { rc = up(Ps[l], false, &hP[l]); if (!rc) rc = up(Rs[l], false, &hR[l]); }
+  }
+  ma_precond* M = nullptr;
+  if (!rc) rc = ma_precond_create_amg((int32_t)L, hA.data(), hP.data(), hR.data(), cfg->smoother == 3 ? 0 : cfg->smoother, cfg->jacobi_weight, cfg->num_pre_smooth,
+                                      cfg->num_post_smooth, cfg->cycle, &M);
+  if (rc) { for (ma_csr* h : owned) (void)ma_csr_destroy(h); return rc; }
+  M->amg_owned = owned; M->amg_gc = gc; M->amg_oc = oc;
+  M->amg_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *out = M; return MA_OK;
+}
+int ma_precond_amg_info(ma_precond_t* M, int32_t* num_levels, double* grid_complexity, double* operator_complexity, double* setup_time_ms) {
+  MA_REQUIRE(M && M->kind == 5, MA_ERR_INVALID, "not an AMG preconditioner");
+  if (num_levels) *num_levels = (int32_t)M->lv.size();
+  if (grid_complexity) *grid_complexity = M->amg_gc;
+  if (operator_complexity) *operator_complexity = M->amg_oc;
+  if (setup_time_ms) *setup_time_ms = M->amg_setup_ms;
+  return MA_OK;
+}
+int ma_precond_amg_level(ma_precond_t* M, int32_t level, ma_csr_t** A, ma_csr_t** P, ma_csr_t** R) {
+  MA_REQUIRE(M && M->kind == 5, MA_ERR_INVALID, "not an AMG preconditioner");
+  MA_REQUIRE(level >= 0 && (size_t)level < M->lv.size(), MA_ERR_INVALID, "level %d of %d", (int)level, (int)M->lv.size());
+  const AmgLevelDev& L = M->lv[(size_t)level];
+  if (A) *A = L.A;
+  if (P) *P = L.P;
+  if (R) *R = L.R;
+  return MA_OK;
 }
 // IluPreconditioner::from_csr(matrix) (math-solvers/src/preconditioners/ilu.rs:36-140): ILU(0) on the matrix' own pattern, the
 // factorisation on the HOST with the reference's loops (its row-k lookups included: first the entry right of the diagonal, then a

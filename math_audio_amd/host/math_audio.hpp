@@ -463,16 +463,35 @@ inline GmresSolution gmres_preconditioned_with_guess(const LinearOperator& a, co
   return detail::run_gmres(a, &m, b, x0, c);
 }
 
-// preconditioners/amg.rs:74-118 (AmgConfig), 981-1103 (v_cycle, apply): the hierarchy is the caller's (AmgPreconditioner::from_csr,
-// amg.rs:276-372, stays on the host); levels[l] = {A_l, P_l (n_l x n_{l+1}), R_l (n_{l+1} x n_l)}, P and R empty on the coarsest level
-enum class AmgSmoother { Jacobi = 0, L1Jacobi = 1, SymmetricGaussSeidel = 2 };
+// preconditioners/amg.rs:41-218 (enums, AmgConfig and its presets), 276-372 (from_csr: hierarchy built on the host inside the library),
+// 981-1103 (v_cycle, apply: on the device). A hierarchy of the caller's can be given instead: levels[l] = {A_l, P_l (n_l x n_{l+1}),
+// R_l (n_{l+1} x n_l)}, P and R empty on the coarsest level.
+enum class AmgCoarsening { RugeStuben = 0, Pmis = 1, Hmis = 2 };
+enum class AmgInterpolation { Standard = 0, Extended = 1, Direct = 2 };
+enum class AmgSmoother { Jacobi = 0, L1Jacobi = 1, SymmetricGaussSeidel = 2, Chebyshev = 3 };
 enum class AmgCycle { V = 0, W = 1, F = 2 };
 struct AmgConfig {
+  AmgCoarsening coarsening = AmgCoarsening::RugeStuben;
+  AmgInterpolation interpolation = AmgInterpolation::Standard;
   AmgSmoother smoother = AmgSmoother::Jacobi;
-  double jacobi_weight = 0.6667;
-  size_t num_pre_smooth = 1, num_post_smooth = 1;
   AmgCycle cycle = AmgCycle::V;
+  double strong_threshold = 0.25;
+  size_t max_levels = 25, coarse_size = 50, num_pre_smooth = 1, num_post_smooth = 1;
+  double jacobi_weight = 0.6667, trunc_factor = 0.0;
+  size_t max_interp_elements = 4, aggressive_coarsening_levels = 0;
+  static AmgConfig for_bem() { AmgConfig c; c.strong_threshold = 0.5; c.coarsening = AmgCoarsening::Pmis; c.smoother = AmgSmoother::L1Jacobi; c.max_interp_elements = 6; return c; }
+  static AmgConfig for_fem() { AmgConfig c; c.smoother = AmgSmoother::SymmetricGaussSeidel; return c; }
+  static AmgConfig for_parallel() { AmgConfig c; c.coarsening = AmgCoarsening::Pmis; c.jacobi_weight = 0.8; c.num_pre_smooth = 2; c.num_post_smooth = 2; return c; }
+  static AmgConfig for_difficult_problems() {
+    AmgConfig c; c.interpolation = AmgInterpolation::Extended; c.smoother = AmgSmoother::SymmetricGaussSeidel; c.max_interp_elements = 8; c.num_pre_smooth = 2; c.num_post_smooth = 2;
+    return c;
+  }
+  ma_amg_config_t c_config() const {
+    return ma_amg_config_t{(int32_t)coarsening, (int32_t)interpolation, (int32_t)smoother, (int32_t)cycle, strong_threshold, (int32_t)max_levels, (int32_t)coarse_size,
+                           (int32_t)num_pre_smooth, (int32_t)num_post_smooth, jacobi_weight, trunc_factor, (int32_t)max_interp_elements, (int32_t)aggressive_coarsening_levels};
+  }
 };
+struct AmgDiagnostics { size_t num_levels = 0; double grid_complexity = 1.0, operator_complexity = 1.0, setup_time_ms = 0.0; std::vector<size_t> level_dofs, level_nnz; };
 struct AmgLevel { const CsrMatrix* matrix = nullptr; const CsrMatrix* prolongation = nullptr; const CsrMatrix* restriction = nullptr; };
 class AmgPreconditioner : public Preconditioner {
  public:
@@ -487,14 +506,38 @@ class AmgPreconditioner : public Preconditioner {
         p.push_back(rect(*levels[l].prolongation)); r.push_back(rect(*levels[l].restriction));
       }
     }
-    solver_check(ma_precond_create_amg((int32_t)levels.size(), a.data(), p.data(), r.data(), (int32_t)c.smoother, c.jacobi_weight,
+    solver_check(ma_precond_create_amg((int32_t)levels.size(), a.data(), p.data(), r.data(), c.smoother == AmgSmoother::Chebyshev ? 0 : (int32_t)c.smoother, c.jacobi_weight,
                                        (int32_t)c.num_pre_smooth, (int32_t)c.num_post_smooth, (int32_t)c.cycle, &h_));
+  }
+  // AmgPreconditioner::from_csr(&matrix, config), amg.rs:276-372
+  static AmgPreconditioner from_csr(const CsrMatrix& m, const AmgConfig& c) {
+    AmgPreconditioner p;
+    const ma_amg_config_t cc = c.c_config();
+    solver_check(ma_precond_create_amg_from_csr(m.csr_handle(), &cc, &p.h_));
+    return p;
+  }
+  AmgPreconditioner(AmgPreconditioner&& o) noexcept : h_(o.h_), owned_(std::move(o.owned_)) { o.h_ = nullptr; o.owned_.clear(); }
+  size_t num_levels() const { int32_t n = 0; solver_check(ma_precond_amg_info(h_, &n, nullptr, nullptr, nullptr)); return (size_t)n; }
+  double grid_complexity() const { double v = 1.0; solver_check(ma_precond_amg_info(h_, nullptr, &v, nullptr, nullptr)); return v; }
+  double operator_complexity() const { double v = 1.0; solver_check(ma_precond_amg_info(h_, nullptr, nullptr, &v, nullptr)); return v; }
+  double setup_time_ms() const { double v = 0.0; solver_check(ma_precond_amg_info(h_, nullptr, nullptr, nullptr, &v)); return v; }
+  AmgDiagnostics diagnostics() const {                      // amg.rs:1124-1133
+    AmgDiagnostics d; int32_t n = 0;
+    solver_check(ma_precond_amg_info(h_, &n, &d.grid_complexity, &d.operator_complexity, &d.setup_time_ms));
+    d.num_levels = (size_t)n;
+    for (int32_t l = 0; l < n; ++l) {
+      ma_csr_t* a = nullptr; int64_t rows = 0, nnz = 0;
+      solver_check(ma_precond_amg_level(h_, l, &a, nullptr, nullptr)); solver_check(ma_csr_num_rows(a, &rows, &nnz));
+      d.level_dofs.push_back((size_t)rows); d.level_nnz.push_back((size_t)nnz);
+    }
+    return d;
   }
   ~AmgPreconditioner() override { if (h_) ma_precond_destroy(h_); for (ma_csr_t* q : owned_) ma_csr_destroy(q); }
   AmgPreconditioner(const AmgPreconditioner&) = delete;
   AmgPreconditioner& operator=(const AmgPreconditioner&) = delete;
   ma_precond_t* handle() const override { return h_; }
  private:
+  AmgPreconditioner() = default;
   ma_csr_t* rect(const CsrMatrix& m) {
     ma_csr_t* q = nullptr;
     solver_check(ma_csr_create_rect((int64_t)m.num_rows_, (int64_t)m.num_cols_, m.row_ptrs.data(), m.col_indices.data(), reinterpret_cast<const ma_c64*>(m.values.data()), 0, &q));

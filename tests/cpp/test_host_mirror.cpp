@@ -228,6 +228,29 @@ static void test_amg_and_pipelined_gmres() {
   CHECK(s_amg.converged && s_plain.converged && s_amg.iterations < s_plain.iterations);
   auto s_pp = gmres_pipelined(A, &amg, b, nullptr, GmresConfig{200, 30, 1e-10, 0});
   CHECK(s_pp.converged);
+  {                                                        // AmgPreconditioner::from_csr: amg.rs' own tests (:1158-1266) through the mirror
+    std::vector<std::tuple<size_t, size_t, Complex64>> tl;
+    const size_t m = 100;
+    for (size_t i = 0; i < m; ++i) { tl.emplace_back(i, i, Complex64(2.0, 0.0)); if (i > 0) tl.emplace_back(i, i - 1, Complex64(-1.0, 0.0)); if (i + 1 < m) tl.emplace_back(i, i + 1, Complex64(-1.0, 0.0)); }
+    CsrMatrix Lap = CsrMatrix::from_triplets(m, m, tl);
+    auto built = AmgPreconditioner::from_csr(Lap, AmgConfig());
+    CHECK(built.num_levels() >= 2 && built.grid_complexity() >= 1.0 && built.operator_complexity() >= 1.0 && built.setup_time_ms() >= 0.0);
+    auto dg = built.diagnostics();
+    CHECK(dg.level_dofs.size() == dg.num_levels && dg.level_nnz.size() == dg.num_levels && dg.level_dofs[0] == m && dg.level_nnz[0] == 3 * m - 2);
+    AmgConfig pm; pm.coarsening = AmgCoarsening::Pmis;
+    CHECK(AmgPreconditioner::from_csr(Lap, pm).num_levels() >= 2);
+    std::vector<Complex64> rb(m), xx(m, Complex64(0.0, 0.0));
+    for (size_t i = 0; i < m; ++i) rb[i] = Complex64(std::sin((double)i), 0.0);
+    const double r0 = norm(rb);
+    for (int it = 0; it < 10; ++it) {
+      auto ax = Lap.matvec(xx); std::vector<Complex64> rr(m); for (size_t i = 0; i < m; ++i) rr[i] = rb[i] - ax[i];
+      auto zz = built.apply(rr); for (size_t i = 0; i < m; ++i) xx[i] += zz[i];
+    }
+    auto ax = Lap.matvec(xx); std::vector<Complex64> rr(m); for (size_t i = 0; i < m; ++i) rr[i] = rb[i] - ax[i];
+    CHECK(norm(rr) < 0.1 * r0);
+    auto s_b = gmres_preconditioned(Lap, AmgPreconditioner::from_csr(Lap, AmgConfig::for_parallel()), rb, GmresConfig{200, 30, 1e-10, 0});
+    CHECK(s_b.converged);
+  }
   auto r = A.matvec(s_pp.x); for (size_t i = 0; i < n; ++i) r[i] = b[i] - r[i];
   CHECK(norm(r) < 1e-7 * norm(b));
 }

@@ -543,6 +543,29 @@ def ilu_module():
     return mod
 
 
+def amg_setup_module():
+    """oracle/oracle_amg_setup.py (restatement of AmgPreconditioner::from_csr, amg.rs:276-372, and of the CSR algebra it calls)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "oracle_amg_setup.py")
+    spec = importlib.util.spec_from_file_location("oracle_amg_setup", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def amg_levels_as_triplets(levels):
+    """levels of oracle_amg_setup.from_csr -> the {A, P, R: (row_ptrs, col_indices, values)} dicts AmgHierarchy takes."""
+    def t(m):
+        return (np.array(m.ptr, dtype=np.int64), np.array(m.col, dtype=np.int64), np.array(m.val, dtype=np.complex128))
+    out = []
+    for lv in levels:
+        d = {"A": t(lv["A"])}
+        if lv["P"] is not None:
+            d["P"] = t(lv["P"]); d["R"] = t(lv["R"])
+        out.append(d)
+    return out
+
+
 def mlfmm_module():
     """oracle/oracle_mlfmm.py (numpy restatement of mlfmm.rs)."""
     import importlib.util

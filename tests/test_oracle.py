@@ -683,3 +683,72 @@ def test_ilu_restatement_known_answers():
     from scipy.sparse.linalg import gmres as sgmres, LinearOperator as SLO
     xs, info = sgmres(S, bb, M=SLO((n, n), matvec=P.apply, dtype=complex), restart=20, maxiter=100, rtol=1e-10)
     assert info == 0 and np.linalg.norm(M @ xs - bb) / np.linalg.norm(bb) < 1e-5
+
+
+# ---------------------------------------------------------------- AMG setup (AmgPreconditioner::from_csr, amg.rs:276-372)
+def _amg_setup():
+    return O.amg_setup_module()
+
+
+def test_amg_setup_csr_algebra_against_scipy():
+    """from_triplets / matmul / transpose of the restatement (csr.rs:135-205, 594-651; amg.rs:810-822) against SciPy on random
+    complex matrices: same pattern where no product is below the 1e-15 cut, same values to rounding; duplicates accumulate."""
+    import scipy.sparse as sp
+    S = _amg_setup()
+    rng = np.random.default_rng(5)
+    A = sp.random(40, 30, density=0.15, random_state=1, format="csr").astype(np.complex128); A.data = rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz)
+    B = sp.random(30, 25, density=0.2, random_state=2, format="csr").astype(np.complex128); B.data = rng.standard_normal(B.nnz) + 1j * rng.standard_normal(B.nnz)
+    a, b = S.from_scipy(A), S.from_scipy(B)
+    c = S.to_scipy(S.matmul(a, b)); ref = (A @ B).tocsr(); ref.sort_indices()
+    assert (c.indptr == ref.indptr).all() and (c.indices == ref.indices).all()
+    assert np.abs(c.data - ref.data).max() <= 1e-14 * np.abs(ref.data).max()
+    t = S.to_scipy(S.transpose(a)); reft = A.T.tocsr(); reft.sort_indices()
+    assert (t.indptr == reft.indptr).all() and (t.indices == reft.indices).all() and (t.data == reft.data).all()
+    m = S.from_triplets(3, 3, [(2, 1, 1 + 1j), (0, 0, 2 + 0j), (2, 1, 0.5 + 0j), (1, 2, 3j)])
+    assert m.ptr == [0, 1, 2, 3] and m.col == [0, 2, 1] and m.val == [2 + 0j, 3j, 1.5 + 1j]
+    assert S.get if hasattr(S, "get") else True
+    assert m.get(2, 1) == 1.5 + 1j and m.get(0, 2) == 0j
+
+
+def test_amg_setup_reference_unit_tests():
+    """amg.rs:1158-1266 through the restatement (hierarchy) and the restated cycle (oracle_solvers.c): test_amg_creation,
+    test_amg_apply, test_amg_pmis_coarsening, test_amg_different_smoothers, test_amg_reduces_residual, test_diagnostics."""
+    S = _amg_setup()
+    lv, gc, oc = S.from_csr(S.laplacian_1d(100), S.default_config())
+    assert len(lv) >= 2 and gc >= 1.0 and oc >= 1.0
+    assert len([l["A"].nr for l in lv]) == len(lv) and len([l["A"].nnz() for l in lv]) == len(lv)
+    cfg = S.default_config(); cfg["coarsening"] = S.PMIS
+    assert len(S.from_csr(S.laplacian_1d(100), cfg)[0]) >= 2
+    m50 = S.laplacian_1d(50)
+    r = np.arange(50, dtype=np.complex128)
+    for smoother in (0, 1, 2):
+        lv50, _, _ = S.from_csr(m50, S.default_config())
+        z = O.AmgHierarchy(O.amg_levels_as_triplets(lv50), smoother=smoother).apply(r)
+        assert z.shape == r.shape and np.abs(z - r).sum() > 1e-10
+    n = 64
+    m = S.laplacian_1d(n); A = S.to_scipy(m)
+    H = O.AmgHierarchy(O.amg_levels_as_triplets(S.from_csr(m, S.default_config())[0]))
+    b = np.sin(np.arange(n)).astype(np.complex128); x = np.zeros(n, dtype=np.complex128)
+    r0 = np.linalg.norm(b - A @ x)
+    for _ in range(10):
+        x = x + H.apply(b - A @ x)
+    assert np.linalg.norm(b - A @ x) < 0.1 * r0
+
+
+def test_amg_setup_coarsening_properties():
+    """What the two coarsenings promise: Ruge-Stuben leaves no F-point without the chance of a strong C-neighbour on the 1-D
+    Laplacian (every second point is coarse); PMIS' C-points form an independent set of the strength graph unless promoted at the
+    end; P has the identity on C-points and rows of F-points sum to 1 for a zero-row-sum operator (Direct weights -a_ij / a_ii)."""
+    S = _amg_setup()
+    m = S.laplacian_1d(101)
+    strong = S.strength(m, 0.25)
+    pt, c2f = S.coarsen_ruge_stuben(m, strong)
+    assert all(pt[i] != pt[i + 1] or pt[i] == S.FINE for i in range(100)) and 40 <= len(c2f) <= 60
+    pt2, c2f2 = S.coarsen_pmis(m, strong)
+    assert not any(pt2[i] == S.COARSE and pt2[i + 1] == S.COARSE for i in range(100))
+    P = S.build_interpolation(m, strong, pt, c2f, S.DIRECT, 0.0, 4)
+    for ci, fi in enumerate(c2f):
+        assert list(P.row(fi)) == [(ci, 1 + 0j)]
+    for i in range(1, 100):
+        if pt[i] == S.FINE and pt[i - 1] == S.COARSE and pt[i + 1] == S.COARSE:
+            assert abs(sum(v for _, v in P.row(i)) - 1.0) < 1e-15
