@@ -366,7 +366,8 @@ int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_pre
 int ma_precond_create_l1jacobi(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
 int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond_t** out);
 /* DiagonalPreconditioner::from_diagonal of an operator's diagonal (math-bem/src/core/solver/fmm_interface.rs:177-212): any
- * operator kind; for the matrix-free TBEM operator the diagonal is the self terms */
+ * operator kind; for the matrix-free TBEM operator the diagonal is the self terms, for the single-level fast multipole operator the
+ * diagonal of its self blocks (SparseNearfieldIlu::from_slfmm, fmm_interface.rs:249-297); the multi-level operator is MA_ERR_UNSUPPORTED */
 int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out);
 /* AmgPreconditioner::apply = v_cycle from z = 0 (math-solvers/src/preconditioners/amg.rs:981-1065, 1068-1103) on the device, over a
  * hierarchy the caller built (AmgPreconditioner::from_csr, amg.rs:276-372, stays on the host): level l = operator A[l] (square

@@ -637,6 +637,26 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
   return MA_OK;
 }
 
+// the diagonal of the self blocks (SparseNearfieldIlu::from_slfmm, math-bem/src/core/solver/fmm_interface.rs:249-297): diag[dof_i] = B_cc[i][i]
+__global__ __launch_bounds__(256) void slfmm_self_diag_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
+                                                              const SlfmmEntry* __restrict__ cent, const dc* __restrict__ bval, dc* __restrict__ diag) {
+  const int c = blockIdx.x;
+  const int e0 = eptr[c], nc_ = eptr[c + 1] - e0;
+  for (int q = cptr[c]; q < cptr[c + 1]; ++q) {
+    const SlfmmEntry en = cent[q];
+    if (en.other != c) continue;
+    for (int i = threadIdx.x; i < nc_; i += 256) diag[edof[e0 + i]] = bval[en.boff + (long long)i * nc_ + i];
+  }
+}
+int slfmm_self_diagonal(ma_slfmm* S, c64* d_diag, hipStream_t st) {
+  MA_HIP(hipSetDevice(S->device));
+  MA_HIP(hipMemsetAsync(d_diag, 0, sizeof(c64) * (size_t)S->n, st));
+  if (S->nc > 0) hipLaunchKernelGGL(slfmm_self_diag_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, reinterpret_cast<const dc*>(S->d_bval),
+                                    reinterpret_cast<dc*>(d_diag));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 long long slfmm_num_dofs(const ma_slfmm* S) { return S->n; }
 int slfmm_device(const ma_slfmm* S) { return S->device; }
 

@@ -9,6 +9,7 @@ void slfmm_destroy(ma_slfmm* S);
 int slfmm_apply(ma_slfmm* S, const ma::c64* d_x, ma::c64* d_y, int transpose, hipStream_t st);
 // extract_near_field_matrix (slfmm.rs:104-132): [N] as a dense num_dofs x num_dofs matrix on the device
 int slfmm_near_matrix(ma_slfmm* S, ma::c64* d_A, hipStream_t st);
+int slfmm_self_diagonal(ma_slfmm* S, ma::c64* d_diag, hipStream_t st);   // n entries, zero where a dof sits in no cluster
 long long slfmm_num_dofs(const ma_slfmm* S);
 int slfmm_device(const ma_slfmm* S);
 

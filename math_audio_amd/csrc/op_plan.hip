@@ -542,14 +542,21 @@ int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
   MA_REQUIRE(op, MA_ERR_INVALID, "operator is NULL");
   if (op->kind == 1) return ma_precond_create_jacobi(op->csr, 1.0, 1, out);
   if (op->kind == 3) return ma_precond_create_diagonal(op->shards[0].op, out);    // the home shard's plan holds every panel
-  MA_REQUIRE(op->kind != 4 && op->kind != 6, MA_ERR_UNSUPPORTED, "diagonal preconditioner of a fast multipole operator: take the diagonal of ma_op_slfmm_near_matrix");
+  MA_REQUIRE(op->kind != 6, MA_ERR_UNSUPPORTED, "diagonal preconditioner of the multi-level operator: the reference defines it for the single-level system only");
   MA_HIP(hipSetDevice(op->device));
   ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
   M->kind = 4; M->n = op->n; M->device = op->device;
   if (hipMalloc(&M->d_invdiag, sizeof(c64) * (size_t)op->n) != hipSuccess) { delete M; set_error("diagonal preconditioner: out of device memory"); return MA_ERR_NOMEM; }
   int rc = MA_OK;
   if (op->kind == 0) rc = op_launch_diag_invert(op->n, op->dA, op->n + 1, nullptr, M->d_invdiag, nullptr);
-  else {
+  else if (op->kind == 4) {                     // SparseNearfieldIlu::from_slfmm (fmm_interface.rs:249-297): the diagonal of the self blocks, 1 where its norm <= 1e-15
+    c64* d = nullptr;
+    if (hipMalloc(&d, sizeof(c64) * (size_t)op->n) != hipSuccess) { set_error("diagonal preconditioner: out of device memory"); rc = MA_ERR_NOMEM; }
+    if (!rc) rc = slfmm_self_diagonal(op->fmm, d, nullptr);
+    if (!rc) rc = op_launch_diag_invert(op->n, d, 1, nullptr, M->d_invdiag, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("diagonal preconditioner: kernels failed"); rc = MA_ERR_HIP; }
+    if (d) (void)hipFree(d);
+  } else {
     const ma_bem_plan* P = op->plan;
     c64* d = nullptr;
     if (hipMalloc(&d, sizeof(c64) * (size_t)P->np) != hipSuccess) { set_error("diagonal preconditioner: out of device memory"); rc = MA_ERR_NOMEM; }
