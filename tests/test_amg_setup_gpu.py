@@ -171,3 +171,41 @@ def test_setup_follows_the_current_values_and_refuses_bad_input(gpu):
         with pytest.raises(ma.MaError):
             ma.AmgFromCsr(op, ma.AmgConfig.preset("default", **bad))
     op.close()
+
+
+def test_full_size_hierarchy_properties(gpu):
+    """BASELINE.json config #4 at full size (F1M family, 96^3 cells = 912 673 DoF, k = 1.832 + 0.01i), where the Python restatement
+    would take hours: properties of from_csr that do not depend on the size. Level sizes shrink; P is the identity on its C-points
+    (every coarse column is the single entry 1 of some row) and no row is longer than a row of A; R = P^T entry for
+    entry; A_c x = R (A (P x)) for a fixed x up to the 1e-15 cut of CsrMatrix::matmul; GMRES + AMG converges on it."""
+    from math_audio_amd import fem
+    _, rp, ci, K, M = fem.helmholtz_box(96, 96, 96)
+    n = len(rp) - 1
+    assert n == 912673
+    k = 1.832 + 0.01j
+    op = ma.CsrOperator(rp, ci, K=K, M=M); op.set_wavenumber(k)
+    amg = ma.AmgFromCsr(op, ma.AmgConfig.preset("for_parallel"))
+    d = amg.diagnostics()
+    assert d["num_levels"] >= 5 and d["level_dofs"][0] == n and all(a > b for a, b in zip(d["level_dofs"], d["level_dofs"][1:]))
+    assert 1.0 < d["grid_complexity"] < 2.5 and 1.0 < d["operator_complexity"] < 4.0
+    l0 = amg.level(0); l1 = amg.level(1)
+    P = sp.csr_matrix((l0["P"]["values"], l0["P"]["col_indices"], l0["P"]["row_ptrs"]), shape=l0["P"]["shape"])
+    R = sp.csr_matrix((l0["R"]["values"], l0["R"]["col_indices"], l0["R"]["row_ptrs"]), shape=l0["R"]["shape"])
+    Ac = sp.csr_matrix((l1["A"]["values"], l1["A"]["col_indices"], l1["A"]["row_ptrs"]), shape=l1["A"]["shape"])
+    A = sp.csr_matrix((K - (k * k) * M, ci, rp), shape=(n, n))
+    nc = P.shape[1]
+    assert P.shape == (n, nc) and R.shape == (nc, n) and Ac.shape == (nc, nc) and d["level_dofs"][1] == nc
+    assert (R - P.T).nnz == 0                                            # transpose_csr, entry for entry
+    ones_rows = np.flatnonzero((np.diff(P.indptr) == 1) & (P.data[P.indptr[:-1].clip(max=len(P.data) - 1)] == 1.0))
+    cols_of_ones = P.indices[P.indptr[ones_rows]]
+    assert len(np.unique(cols_of_ones)) == nc                            # every coarse column is some C-point's identity row
+    assert np.diff(P.indptr).max() <= 14                                 # never more than the row's strong neighbours
+    x = _xvec(nc)
+    y = R @ (A @ (P @ x)); z = Ac @ x
+    assert np.abs(y - z).max() <= 1e-12 * np.abs(z).max()
+    b = A @ _xvec(n)
+    r0 = np.linalg.norm(b)
+    lin = ma.LinearOperator.csr(op)
+    xg, info = ma.gmres_preconditioned(lin, amg, b, restart=30, max_iterations=300, tol=1e-8)
+    assert info.converged and np.linalg.norm(A @ xg - b) <= 1e-6 * r0
+    amg.close(); lin.close(); op.close()

@@ -73,3 +73,41 @@ def test_slfmm_on_the_box_and_input_validation(gpu):
         ma.LinearOperator.slfmm(plan, bad, k, 4, 8, 5)
     assert e.value.status == ma.MA_ERR_UNSUPPORTED
     plan.close()
+
+
+def test_operator_apply_is_linear_and_reproducible_at_size(gpu):
+    """5 120 panels (icosphere 4), 150 clusters: properties that do not depend on the size. The apply is linear; two applies of the
+    same vector agree BIT FOR BIT (near blocks: partial sums gathered in entry order; translation: parts added in wavefront order;
+    upward / downward passes: fixed lane-set reductions); the first-version kernels (MA_FMM_NEAR_BLOCKS=0, MA_FMM_DENSE_TRANSLATE=0,
+    MA_FMM_STORE_PHASES=0) give the same vector to rounding."""
+    import os
+    om = O.icosphere(RADIUS, 4)
+    k = 3.0 / RADIUS
+    cl = grid_clusters(om.center, 0.035)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    op = ma.LinearOperator.slfmm(plan, cl, k, 6, 12, 5)
+    n = om.n_elem
+    i = np.arange(n)
+    x = np.sin(0.1 * i) + 1j * np.cos(0.2 * i); z = np.cos(0.3 * i) + 0.25j
+    a, b = 0.7 - 0.2j, -1.3 + 0.4j
+    y = op.apply(x)
+    assert np.isfinite(y).all()
+    assert (op.apply(x) == y).all() and (op.apply(x) == y).all()
+    lin = op.apply(a * x + b * z) - (a * y + b * op.apply(z))
+    assert np.abs(lin).max() <= 1e-12 * np.abs(y).max()
+    yt = op.apply_transpose(x)
+    assert (op.apply_transpose(x) == yt).all()
+    old = {v: os.environ.get(v) for v in ("MA_FMM_NEAR_BLOCKS", "MA_FMM_DENSE_TRANSLATE", "MA_FMM_STORE_PHASES")}
+    try:
+        for v in old:
+            os.environ[v] = "0"
+        op0 = ma.LinearOperator.slfmm(plan, cl, k, 6, 12, 5)
+    finally:
+        for v, val in old.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
+    y0 = op0.apply(x); yt0 = op0.apply_transpose(x)
+    assert np.abs(y0 - y).max() <= 1e-12 * np.abs(y).max() and np.abs(yt0 - yt).max() <= 1e-12 * np.abs(yt).max()
+    op0.close(); op.close()
