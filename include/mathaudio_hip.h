@@ -408,6 +408,10 @@ int ma_precond_amg_level(ma_precond_t* M, int32_t level, ma_csr_t** A, ma_csr_t*
  * every apply on the device (level-scheduled). Use with ma_gmres_preconditioned: gmres_solve_with_ilu(_operator)
  * (math-bem/src/core/solver/fmm_interface.rs:450-474) is ma_op + this preconditioner over the (near-field) matrix as CSR. */
 int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out);
+/* IluFixedPointPreconditioner::from_csr(matrix, iterations) (math-solvers/src/preconditioners/ilu_parallel.rs:397-495; from_csr_default: 3)
+ * and its apply (:510-590): x = D^-1 r, then `iterations` times x <- D^-1 (r - (L + U_off) x) over the ILU(0) factors. Factorisation on the
+ * host, the sweeps on the device. IluColoringPreconditioner (:52-148, level-scheduled solves of the same factors) is ma_precond_create_ilu0. */
+int ma_precond_create_ilu_fixed_point(ma_csr_t* csr, int32_t iterations, ma_precond_t** out);
 int ma_precond_destroy(ma_precond_t* M);
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
 int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */

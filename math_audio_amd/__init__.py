@@ -139,6 +139,7 @@ def lib():
             "ma_op_create_slfmm": [vp, P(ma_clusters_t), P(ma_physics_t), i32, i32, i32, P(vp)],
             "ma_op_slfmm_near_matrix": [vp, vp],
             "ma_precond_create_ilu0": [vp, P(vp)],
+            "ma_precond_create_ilu_fixed_point": [vp, i32, P(vp)],
             "ma_csr_get": [vp, vp, vp, vp],
             "ma_amg_config_preset": [i32, vp],
             "ma_precond_create_amg_from_csr": [vp, vp, P(vp)],
@@ -975,6 +976,16 @@ class IluPreconditioner:
             self.close()
         except Exception:
             pass
+
+
+class IluFixedPointPreconditioner(IluPreconditioner):
+    """IluFixedPointPreconditioner::from_csr(matrix, iterations) (ilu_parallel.rs:397-495; default 3): Jacobi-style sweeps over the ILU(0)
+    factors instead of the two triangular solves."""
+
+    def __init__(self, csr_operator, iterations=3):
+        self.h = C.c_void_p(); self._keep = csr_operator
+        check(lib().ma_precond_create_ilu_fixed_point(csr_operator.h, int(iterations), C.byref(self.h)))
+        self.n = csr_operator.n
 
 
 class AmgPreconditioner:

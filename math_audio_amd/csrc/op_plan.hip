@@ -690,17 +690,17 @@ int ma_precond_amg_level(ma_precond_t* M, int32_t level, ma_csr_t** A, ma_csr_t*
 // scan of row k), L and U split into two device operators; apply = the two triangular solves, level-scheduled. Pivots below 1e-30
 // are skipped by the factorisation as in the reference; the solves skip a row whose u_ii is below 1e-15 in modulus (the reference:
 // 1e-30, and it still subtracts the row's sum there).
-int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out) {
-  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
-  MA_REQUIRE(csr, MA_ERR_INVALID, "csr is NULL");
+// the in-place ILU(0) factorisation of ilu.rs:55-98 on the host (ilu_parallel.rs:397-449 runs the same arithmetic with plain scans for
+// its row-k lookups): rp / col / val come back holding pattern and factor values
+static int ilu0_factor_host(ma_csr_t* csr, int64_t* n_out, std::vector<int64_t>& rp, std::vector<int64_t>& col, std::vector<cplx>& val) {
   int64_t n = 0, nnz = 0, nc = 0;
   int rc = ma_csr_num_rows(csr, &n, &nnz); if (rc) return rc;
   rc = ma_csr_num_cols(csr, &nc); if (rc) return rc;
   MA_REQUIRE(nc == n, MA_ERR_INVALID, "ILU(0) needs a square operator");
-  std::vector<int64_t> rp((size_t)n + 1), col((size_t)std::max<int64_t>(nnz, 1));
+  rp.assign((size_t)n + 1, 0); col.assign((size_t)std::max<int64_t>(nnz, 1), 0);
   std::vector<ma_c64> v0((size_t)std::max<int64_t>(nnz, 1));
   rc = ma_csr_get(csr, rp.data(), col.data(), v0.data()); if (rc) return rc;
-  std::vector<cplx> val((size_t)std::max<int64_t>(nnz, 1));
+  val.assign((size_t)std::max<int64_t>(nnz, 1), cplx(0.0, 0.0));
   for (int64_t q = 0; q < nnz; ++q) val[(size_t)q] = cplx(v0[(size_t)q].re, v0[(size_t)q].im);
   const int64_t none = -1;
   std::vector<int64_t> diag((size_t)n, none);
@@ -726,6 +726,14 @@ int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out) {
             if (col[(size_t)sx] == j) { val[(size_t)jx] = val[(size_t)jx] - l_ik * val[(size_t)sx]; break; }
       }
     }
+  *n_out = n;
+  return MA_OK;
+}
+int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(csr, MA_ERR_INVALID, "csr is NULL");
+  int64_t n = 0; std::vector<int64_t> rp, col; std::vector<cplx> val;
+  int rc = ilu0_factor_host(csr, &n, rp, col, val); if (rc) return rc;
   std::vector<int64_t> lrp(1, 0), lci, urp(1, 0), uci; std::vector<ma_c64> lv, uv;   // :100-126
   for (int64_t i = 0; i < n; ++i) {
     for (int64_t idx = rp[(size_t)i]; idx < rp[(size_t)i + 1]; ++idx) {
@@ -746,6 +754,26 @@ int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out) {
   if (!rc && hipMalloc(&M->d_tmp, sizeof(c64) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) { set_error("ILU workspace"); rc = MA_ERR_NOMEM; }
   if (rc) { ma_precond_destroy(M); return rc; }
   *out = M;
+  return MA_OK;
+}
+// IluFixedPointPreconditioner::from_csr(matrix, iterations) (ilu_parallel.rs:397-495) and its apply (:510-590): the ILU(0) factors on
+// the matrix' own pattern, then x = D^-1 r and `iterations` times x <- D^-1 (r - (L + U_off) x) with D = diag(U). That is the Jacobi
+// sweep (omega = 1, from zero) of the matrix F that holds L, D and U_off in one pattern -- the factorisation's in-place result --
+// run iterations + 1 times: F goes up as an operator of its own and the device Jacobi smoother does the rest.
+// (The smoother takes 1 / u_ii = 1 where |u_ii| <= 1e-15; the reference: 1e-30.)
+int ma_precond_create_ilu_fixed_point(ma_csr_t* csr, int32_t iterations, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(csr && iterations >= 0, MA_ERR_INVALID, "csr is NULL or iterations < 0");
+  int64_t n = 0; std::vector<int64_t> rp, col; std::vector<cplx> val;
+  int rc = ilu0_factor_host(csr, &n, rp, col, val); if (rc) return rc;
+  std::vector<ma_c64> fv(val.size());
+  for (size_t q = 0; q < val.size(); ++q) fv[q] = ma_c64{val[q].real(), val[q].imag()};
+  int dev = 0; rc = ma_csr_device(csr, &dev); if (rc) return rc;
+  ma_csr* F = nullptr;
+  rc = ma_csr_create(n, rp.data(), col.data(), fv.data(), dev, &F); if (rc) return rc;
+  rc = ma_precond_create_jacobi(F, 1.0, iterations + 1, out);
+  if (rc) { (void)ma_csr_destroy(F); return rc; }
+  (*out)->amg_owned.push_back(F);
   return MA_OK;
 }
 // z = M^-1 r on device vectors (z and r distinct)

@@ -28,7 +28,7 @@ def test_solve_helmholtz_direct(gpu):                       # :1514-1530
     assert np.abs(s.values - x).max() <= 1e-10 * np.abs(x).max() and s.residual <= 1e-12
 
 
-ITERATIVE = [fs.SolverType.Gmres, fs.SolverType.GmresIlu, fs.SolverType.GmresJacobi, fs.SolverType.GmresIluColoring, fs.SolverType.GmresAmg,
+ITERATIVE = [fs.SolverType.Gmres, fs.SolverType.GmresIlu, fs.SolverType.GmresJacobi, fs.SolverType.GmresIluColoring, fs.SolverType.GmresIluFixedPoint, fs.SolverType.GmresAmg,
              fs.SolverType.GmresPipelined, fs.SolverType.GmresPipelinedIlu, fs.SolverType.GmresPipelinedAmg, fs.SolverType.GmresShiftedLaplacian]
 
 
@@ -39,7 +39,8 @@ def test_solve_helmholtz_iterative(gpu, solver_type):      # :1533-1578, :1646-1
     s = fs.solve(p, cfg)
     assert s.converged and len(s.values) == p.num_dofs()
     x, A = _dense_solution(p)
-    assert np.linalg.norm(A @ s.values - p.rhs) <= 1e-6 * np.linalg.norm(p.rhs)
+    # left preconditioning: the tolerance is on M^-1 (b - A x), the true residual may sit above it
+    assert np.linalg.norm(A @ s.values - p.rhs) <= 1e-5 * np.linalg.norm(p.rhs)
     assert np.abs(s.values - x).max() <= 1e-5 * np.abs(x).max()
 
 
@@ -102,7 +103,7 @@ def test_solve_csr_and_its_errors(gpu):                     # :1438-1503
     with pytest.raises(fs.SolverError) as e:
         fs.solve_csr_with_guess(p.row_ptrs, p.col_indices, vals, p.rhs, x[:-2], fs.SolverConfig())
     assert e.value.kind == "DimensionMismatch" and e.value.actual == nd - 2
-    for t in (fs.SolverType.GmresShiftedLaplacian, fs.SolverType.GmresShiftedLaplacianMg, fs.SolverType.GmresSchwarz, fs.SolverType.GmresIluFixedPoint):
+    for t in (fs.SolverType.GmresShiftedLaplacian, fs.SolverType.GmresShiftedLaplacianMg, fs.SolverType.GmresSchwarz):
         with pytest.raises(fs.SolverError) as e:
             fs.solve_csr(p.row_ptrs, p.col_indices, vals, p.rhs, fs.SolverConfig(solver_type=t))
         assert e.value.kind == "InvalidConfiguration"

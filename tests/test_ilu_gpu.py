@@ -99,3 +99,40 @@ def test_ilu_of_the_near_field_with_the_slfmm_operator(gpu):
     x0, i0 = ma.gmres(op, b, restart=30, max_iterations=200, tol=1e-8)
     assert i1.converged and np.linalg.norm(op.apply(x1) - b) <= 1e-6 * np.linalg.norm(b)
     assert (not i0.converged) or i1.iterations <= i0.iterations
+
+
+def test_fixed_point_ilu(gpu):
+    """IluFixedPointPreconditioner (ilu_parallel.rs:374-590): apply against the restatement for 0, 3 (from_csr_default) and 10 sweeps on
+    a diagonally dominant complex matrix and on the Helmholtz box; the reference's tests (:627-672): the apply changes the vector,
+    GMRES with it converges and solves the system."""
+    I = O.ilu_module()
+    rng = np.random.default_rng(11)
+    n = 60
+    A = sp.random(n, n, density=0.12, random_state=5, format="csr").astype(np.complex128)
+    A.data = rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz)
+    A = (A + sp.diags(np.full(n, 6.0 + 1.0j))).tocsr(); A.sort_indices()
+    from math_audio_amd import fem
+    nodes, rp, ci, K, M = fem.helmholtz_box(5, 4, 3)
+    H = sp.csr_matrix((K - (1.2 + 0.05j) ** 2 * M, ci, rp)); H.sort_indices()
+    for S in (A, H):
+        m = S.shape[0]
+        csr, S = _csr(S)
+        r = np.sin(0.3 * np.arange(m)) + 1j * np.cos(0.2 * np.arange(m))
+        for iterations in (0, 3, 10):
+            P = ma.IluFixedPointPreconditioner(csr, iterations)
+            z = P.apply(r)
+            ref = I.IluFixedPointPreconditioner(S.indptr, S.indices, S.data, iterations).apply(r)
+            assert np.abs(z - ref).max() <= 1e-12 * np.abs(ref).max(), iterations
+            assert np.abs(z - r).sum() > 1e-10
+            P.close()
+        csr.close()
+    csr, S = _csr(A)
+    P = ma.IluFixedPointPreconditioner(csr)                 # from_csr_default
+    lin = ma.LinearOperator.csr(csr)
+    x_true = np.arange(1, n + 1) + 0.5j
+    b = S @ x_true
+    x, info = ma.gmres_preconditioned(lin, P, b, restart=30, max_iterations=200, tol=1e-10)
+    assert info.converged and np.abs(x - x_true).max() <= 1e-7 * np.abs(x_true).max()
+    with pytest.raises(ma.MaError):
+        ma.IluFixedPointPreconditioner(csr, -1)
+    P.close(); lin.close(); csr.close()
