@@ -412,6 +412,12 @@ int ma_precond_create_ilu0(ma_csr_t* csr, ma_precond_t** out);
  * and its apply (:510-590): x = D^-1 r, then `iterations` times x <- D^-1 (r - (L + U_off) x) over the ILU(0) factors. Factorisation on the
  * host, the sweeps on the device. IluColoringPreconditioner (:52-148, level-scheduled solves of the same factors) is ma_precond_create_ilu0. */
 int ma_precond_create_ilu_fixed_point(ma_csr_t* csr, int32_t iterations, ma_precond_t** out);
+/* AdditiveSchwarzPreconditioner::from_csr(matrix, num_subdomains, overlap) (math-solvers/src/preconditioners/schwarz.rs:84-145) and its apply
+ * (:394-408): contiguous index blocks grown `overlap` times along the matrix graph, ILU(0) of every local matrix, the local solutions added
+ * back with weights 1 / (subdomains holding the row). Setup on the host; on the device the subdomains are stacked into one block-diagonal
+ * operator, so all local solves run together. stats (:148-170): subdomains, smallest, largest and mean size. */
+int ma_precond_create_schwarz(ma_csr_t* csr, int32_t num_subdomains, int32_t overlap, ma_precond_t** out);
+int ma_precond_schwarz_stats(ma_precond_t* M, int64_t* num_subdomains, int64_t* min_size, int64_t* max_size, double* avg_size);
 int ma_precond_destroy(ma_precond_t* M);
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream);
 int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host);   /* host buffers */

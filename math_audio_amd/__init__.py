@@ -140,6 +140,8 @@ def lib():
             "ma_op_slfmm_near_matrix": [vp, vp],
             "ma_precond_create_ilu0": [vp, P(vp)],
             "ma_precond_create_ilu_fixed_point": [vp, i32, P(vp)],
+            "ma_precond_create_schwarz": [vp, i32, i32, P(vp)],
+            "ma_precond_schwarz_stats": [vp, P(i64), P(i64), P(i64), P(dbl)],
             "ma_csr_get": [vp, vp, vp, vp],
             "ma_amg_config_preset": [i32, vp],
             "ma_precond_create_amg_from_csr": [vp, vp, P(vp)],
@@ -986,6 +988,22 @@ class IluFixedPointPreconditioner(IluPreconditioner):
         self.h = C.c_void_p(); self._keep = csr_operator
         check(lib().ma_precond_create_ilu_fixed_point(csr_operator.h, int(iterations), C.byref(self.h)))
         self.n = csr_operator.n
+
+
+class AdditiveSchwarzPreconditioner(IluPreconditioner):
+    """AdditiveSchwarzPreconditioner::from_csr(matrix, num_subdomains, overlap) (schwarz.rs:84-145): overlapping index blocks, ILU(0) per
+    block, weighted sum of the local solutions; all blocks solved together on the device."""
+
+    def __init__(self, csr_operator, num_subdomains=8, overlap=2):
+        self.h = C.c_void_p(); self._keep = csr_operator
+        check(lib().ma_precond_create_schwarz(csr_operator.h, int(num_subdomains), int(overlap), C.byref(self.h)))
+        self.n = csr_operator.n
+
+    def stats(self):
+        """(num_subdomains, min_size, max_size, avg_size), schwarz.rs:148-170."""
+        a = C.c_int64(); b = C.c_int64(); c = C.c_int64(); d = C.c_double()
+        check(lib().ma_precond_schwarz_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
 
 class AmgPreconditioner:

@@ -477,6 +477,9 @@ struct ma_precond {
   std::vector<ma_csr*> amg_owned; double amg_gc = 1.0, amg_oc = 1.0, amg_setup_ms = 0.0;   // from_csr: the levels it built, amg.rs:375-392
   // kind 6: IluPreconditioner (ilu.rs): L (strictly lower, unit diagonal implied) and U (diagonal + upper) as operators of their own
   ma_csr* ilu_l = nullptr; ma_csr* ilu_u = nullptr;
+  // kind 7: AdditiveSchwarzPreconditioner (schwarz.rs): restriction E onto the stacked subdomains, ILU(0) of their block-diagonal matrix,
+  // weighted prolongation back; sch_stats = subdomains, min / max size, total size
+  ma_precond* sch_inner = nullptr; ma_csr* sch_E = nullptr; ma_csr* sch_Et = nullptr; c64* sch_a = nullptr; c64* sch_b = nullptr; long long sch_stats[4] = {0, 0, 0, 0};
 };
 
 extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
@@ -617,6 +620,11 @@ int ma_precond_destroy(ma_precond_t* M) {
   if (M->ilu_l) (void)ma_csr_destroy(M->ilu_l);
   if (M->ilu_u) (void)ma_csr_destroy(M->ilu_u);
   for (ma_csr* h : M->amg_owned) if (h) (void)ma_csr_destroy(h);
+  if (M->sch_inner) (void)ma_precond_destroy(M->sch_inner);
+  if (M->sch_E) (void)ma_csr_destroy(M->sch_E);
+  if (M->sch_Et) (void)ma_csr_destroy(M->sch_Et);
+  if (M->sch_a) (void)hipFree(M->sch_a);
+  if (M->sch_b) (void)hipFree(M->sch_b);
   delete M; return MA_OK;
 }
 // AmgPreconditioner::from_csr (amg.rs:276-372): the matrix' current values come back to the host, the hierarchy is built there with
@@ -776,11 +784,93 @@ int ma_precond_create_ilu_fixed_point(ma_csr_t* csr, int32_t iterations, ma_prec
   (*out)->amg_owned.push_back(F);
   return MA_OK;
 }
+// AdditiveSchwarzPreconditioner::from_csr(matrix, num_subdomains, overlap) (math-solvers/src/preconditioners/schwarz.rs:84-145):
+// contiguous index blocks (:90-100), each grown `overlap` times along the matrix graph (extend_partition, :196-229), weights 1 / (number of
+// subdomains holding the row) (:112-128), per subdomain the local matrix and its ILU(0) (build_subdomain / ilu_factorize, :231-352).
+// On the device the subdomains are stacked: E gathers r into the stacked vector, the block-diagonal matrix of the local matrices is
+// one operator whose ILU(0) IS the subdomains' ILU(0)s (no entry couples two blocks) and whose level-scheduled solves run all
+// subdomains at once, and the weighted transpose of E adds the local solutions back in subdomain order (apply, :394-408).
+int ma_precond_create_schwarz(ma_csr_t* csr, int32_t num_subdomains, int32_t overlap, ma_precond_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(csr && overlap >= 0, MA_ERR_INVALID, "csr is NULL or overlap < 0");
+  int64_t n = 0, nnz = 0, nc = 0; int dev = 0;
+  int rc = ma_csr_num_rows(csr, &n, &nnz); if (rc) return rc;
+  rc = ma_csr_num_cols(csr, &nc); if (rc) return rc;
+  rc = ma_csr_device(csr, &dev); if (rc) return rc;
+  MA_REQUIRE(nc == n && n > 0, MA_ERR_INVALID, "additive Schwarz needs a square, non-empty operator");
+  std::vector<int64_t> rp((size_t)n + 1), col((size_t)std::max<int64_t>(nnz, 1)); std::vector<ma_c64> val((size_t)std::max<int64_t>(nnz, 1));
+  rc = ma_csr_get(csr, rp.data(), col.data(), val.data()); if (rc) return rc;
+  const int64_t ns = std::min<int64_t>(std::max<int64_t>(num_subdomains, 1), n);
+  const int64_t base = n / ns, rem = n % ns;
+  std::vector<int64_t> e_rp(1, 0), e_ci, b_rp(1, 0), b_ci; std::vector<ma_c64> e_v, b_v;
+  std::vector<std::vector<int64_t>> cols_of((size_t)n);           // stacked rows that hold global row g, in subdomain order
+  std::vector<char> in((size_t)n); std::vector<int64_t> frontier, next, g2l((size_t)n);
+  int64_t start = 0, mn = n + 1, mx = 0;
+  for (int64_t s_ = 0; s_ < ns; ++s_) {
+    const int64_t size = base + (s_ < rem ? 1 : 0);
+    std::fill(in.begin(), in.end(), 0);
+    frontier.clear();
+    for (int64_t i = start; i < start + size; ++i) { in[(size_t)i] = 1; frontier.push_back(i); }
+    start += size;
+    for (int o = 0; o < overlap; ++o) {                            // extend_partition
+      next.clear();
+      for (int64_t idx : frontier)
+        for (int64_t q = rp[(size_t)idx]; q < rp[(size_t)idx + 1]; ++q) { const int64_t nb = col[(size_t)q]; if (nb != idx && !in[(size_t)nb]) { in[(size_t)nb] = 1; next.push_back(nb); } }
+      frontier.swap(next);
+    }
+    const int64_t off = (int64_t)e_ci.size();
+    int64_t ln = 0;
+    for (int64_t g = 0; g < n; ++g) if (in[(size_t)g]) { g2l[(size_t)g] = off + ln; ++ln; e_ci.push_back(g); e_v.push_back(ma_c64{1.0, 0.0}); e_rp.push_back((int64_t)e_ci.size()); cols_of[(size_t)g].push_back(off + ln - 1); }
+    for (int64_t g = 0; g < n; ++g) {                              // build_subdomain: the rows and columns of the subdomain, in global order
+      if (!in[(size_t)g]) continue;
+      for (int64_t q = rp[(size_t)g]; q < rp[(size_t)g + 1]; ++q) { const int64_t c = col[(size_t)q]; if (in[(size_t)c]) { b_ci.push_back(g2l[(size_t)c]); b_v.push_back(val[(size_t)q]); } }
+      b_rp.push_back((int64_t)b_ci.size());
+    }
+    mn = std::min(mn, ln); mx = std::max(mx, ln);
+  }
+  const int64_t N = (int64_t)e_ci.size();
+  std::vector<int64_t> t_rp(1, 0), t_ci; std::vector<ma_c64> t_v;
+  for (int64_t g = 0; g < n; ++g) {
+    const size_t c = cols_of[(size_t)g].size();
+    const double w = c > 0 ? 1.0 / (double)c : 1.0;
+    for (int64_t e : cols_of[(size_t)g]) { t_ci.push_back(e); t_v.push_back(ma_c64{w, 0.0}); }
+    t_rp.push_back((int64_t)t_ci.size());
+  }
+  ma_precond* M = new (std::nothrow) ma_precond(); MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
+  M->kind = 7; M->n = n; M->device = dev;
+  M->sch_stats[0] = ns; M->sch_stats[1] = mn; M->sch_stats[2] = mx; M->sch_stats[3] = N;
+  static const int64_t zero_i = 0; static const ma_c64 zero_c = {0.0, 0.0};
+  ma_csr* B = nullptr;
+  rc = ma_csr_create_rect(N, n, e_rp.data(), e_ci.data(), e_v.data(), dev, &M->sch_E);
+  if (!rc) rc = ma_csr_create_rect(n, N, t_rp.data(), t_ci.data(), t_v.data(), dev, &M->sch_Et);
+  if (!rc) rc = ma_csr_create(N, b_rp.data(), b_ci.empty() ? &zero_i : b_ci.data(), b_v.empty() ? &zero_c : b_v.data(), dev, &B);
+  if (!rc) rc = ma_precond_create_ilu0(B, &M->sch_inner);
+  if (B) (void)ma_csr_destroy(B);                                   // the factors are operators of their own
+  if (!rc && hipMalloc(&M->sch_a, sizeof(c64) * (size_t)N) != hipSuccess) { set_error("Schwarz workspace"); rc = MA_ERR_NOMEM; }
+  if (!rc && hipMalloc(&M->sch_b, sizeof(c64) * (size_t)N) != hipSuccess) { set_error("Schwarz workspace"); rc = MA_ERR_NOMEM; }
+  if (rc) { ma_precond_destroy(M); return rc; }
+  *out = M; return MA_OK;
+}
+// AdditiveSchwarzPreconditioner::stats (schwarz.rs:148-170): subdomains, smallest, largest, mean size
+int ma_precond_schwarz_stats(ma_precond_t* M, int64_t* num_subdomains, int64_t* min_size, int64_t* max_size, double* avg_size) {
+  MA_REQUIRE(M && M->kind == 7, MA_ERR_INVALID, "not an additive Schwarz preconditioner");
+  if (num_subdomains) *num_subdomains = M->sch_stats[0];
+  if (min_size) *min_size = M->sch_stats[1];
+  if (max_size) *max_size = M->sch_stats[2];
+  if (avg_size) *avg_size = (double)M->sch_stats[3] / (double)M->sch_stats[0];
+  return MA_OK;
+}
 // z = M^-1 r on device vectors (z and r distinct)
 int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stream) {
   MA_REQUIRE(M && d_r && d_z, MA_ERR_INVALID, "NULL argument");
   if (M->kind == 0) { MA_HIP(hipMemcpyAsync(d_z, d_r, sizeof(c64) * (size_t)M->n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return MA_OK; }
   if (M->kind == 4) return op_launch_cmul(M->n, M->d_invdiag, (const c64*)d_r, (c64*)d_z, (hipStream_t)stream);
+  if (M->kind == 7) {                                    // AdditiveSchwarzPreconditioner::apply (schwarz.rs:394-408): gather, local solves, weighted scatter-add
+    int rc = ma_csr_spmv_dev(M->sch_E, d_r, M->sch_a, stream);
+    if (!rc) rc = ma_precond_apply_dev(M->sch_inner, M->sch_a, M->sch_b, stream);
+    if (!rc) rc = ma_csr_spmv_dev(M->sch_Et, M->sch_b, d_z, stream);
+    return rc;
+  }
   if (M->kind == 6) {                                    // IluPreconditioner::apply (ilu.rs:143-175): L y = r forward, U z = y backward
     // a forward sweep over a matrix without upper entries IS the forward substitution (and a backward sweep over one without lower
     // entries the backward substitution): the level-scheduled Gauss-Seidel sweeps of the two factors, amg.rs' form sum * diag.inv()

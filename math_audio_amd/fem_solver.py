@@ -4,8 +4,7 @@ ShiftedLaplacianConfig / Solution / SolverError and `solve`, `solve_csr`, `solve
 The orchestration is the reference's, branch by branch (`solve`, :223-276; `solve_csr_with_guess`, :1456-1503); every numeric step runs
 on the GPU through the C-ABI: the CSR operator with its fused K - k^2 M values, GMRES and pipelined GMRES, the ILU(0) / Jacobi / AMG
 preconditioners (their setup on the host inside the library, as in the reference), the dense LU of `Direct`. There is no CPU fallback:
-without the library or a GPU every call raises. Not built: the additive Schwarz preconditioner (`GmresSchwarz` raises
-InvalidConfiguration); `GmresIluColoring` is ILU(0) with level-scheduled solves in the
+without the library or a GPU every call raises. All thirteen solver types run; `GmresIluColoring` is ILU(0) with level-scheduled solves in the
 reference (ilu_parallel.rs:52-148: "same as sequential" factorisation) -- which is what the device ILU(0) apply is."""
 import enum
 import numpy as np
@@ -137,13 +136,13 @@ def _dispatch(op, lin, arrays, rhs, x0, config, from_solve):
         return Solution(x, 0, float(np.abs(op.matvec(x) - rhs).sum() / n), True)
     if t == SolverType.Gmres:                   # :310-351, :898-921
         return _fail_unless_converged(*ma.gmres(lin, rhs, x0=x0, restart=g.restart, max_iterations=g.max_iterations, tol=g.tolerance))
-    if t == SolverType.GmresSchwarz:
-        raise SolverError("InvalidConfiguration", "Invalid solver configuration: %s is not built on the device (additive Schwarz)" % t.name)
     pipelined = t in (SolverType.GmresPipelined, SolverType.GmresPipelinedIlu, SolverType.GmresPipelinedAmg)
     if t in (SolverType.GmresIlu, SolverType.GmresIluColoring, SolverType.GmresPipelinedIlu):      # :359-416, :469-529, :775-831
         pre = ma.IluPreconditioner(op)
     elif t == SolverType.GmresIluFixedPoint:    # IluFixedPointPreconditioner::from_csr(csr, FP_ITERATIONS = 10), :532-592, :999-1022
         pre = ma.IluFixedPointPreconditioner(op, 10)
+    elif t == SolverType.GmresSchwarz:          # AdditiveSchwarzPreconditioner::from_csr(csr, schwarz_subdomains, schwarz_overlap), :595-664
+        pre = ma.AdditiveSchwarzPreconditioner(op, config.schwarz_subdomains, config.schwarz_overlap)
     elif t == SolverType.GmresJacobi:           # DiagonalPreconditioner::from_csr, :419-466
         pre = ma.Preconditioner(op, "jacobi", omega=1.0, sweeps=1)
     elif t in (SolverType.GmresAmg, SolverType.GmresPipelinedAmg):                                 # :667-727, :834-895, :1054-1077, :1130-1153

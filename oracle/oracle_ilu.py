@@ -137,3 +137,109 @@ class IluFixedPointPreconditioner:
                 xn[i] = s * self.dinv[i]
             x = xn
         return np.array(x, dtype=np.complex128)
+
+
+class AdditiveSchwarzPreconditioner:
+    """math-solvers/src/preconditioners/schwarz.rs: from_csr (:84-145: contiguous blocks, extend_partition :196-229 `overlap` times along
+    the matrix graph, weights 1 / count :112-128, build_subdomain + ilu_factorize :231-352) and apply_sequential (:394-408) with
+    Subdomain::solve (:355-383: forward substitution, backward substitution, times 1 / u_ii when |u_ii| > 1e-30)."""
+
+    def __init__(self, row_ptrs, col_indices, values, num_subdomains, overlap):
+        rp = [int(v) for v in row_ptrs]; ci = [int(v) for v in col_indices]; val = [complex(v) for v in values]
+        n = len(rp) - 1
+        self.n = n
+        ns = min(max(int(num_subdomains), 1), n)
+        base, rem = n // ns, n % ns
+        parts = []; start = 0
+        for s in range(ns):
+            size = base + (1 if s < rem else 0)
+            parts.append(list(range(start, start + size))); start += size
+        adj = [[ci[q] for q in range(rp[i], rp[i + 1]) if ci[q] != i] for i in range(n)]
+        ext = []
+        for part in parts:
+            inp = [False] * n
+            for i in part:
+                inp[i] = True
+            frontier = list(part)
+            for _ in range(int(overlap)):
+                new = []
+                for i in frontier:
+                    for nb in adj[i]:
+                        if not inp[nb]:
+                            inp[nb] = True; new.append(nb)
+                frontier = new
+            ext.append([i for i in range(n) if inp[i]])
+        count = [0] * n
+        for e in ext:
+            for i in e:
+                count[i] += 1
+        self.weights = [1.0 / c if c > 0 else 1.0 for c in count]
+        self.subdomains = []
+        for gi in ext:
+            g2l = {g: l for l, g in enumerate(gi)}
+            lrp = [0]; lci = []; lv = []
+            for g in gi:
+                for q in range(rp[g], rp[g + 1]):
+                    if ci[q] in g2l:
+                        lci.append(g2l[ci[q]]); lv.append(val[q])
+                lrp.append(len(lci))
+            ln = len(gi)
+            v = list(lv)
+            for i in range(ln):                 # ilu_factorize, :253-352
+                for idx in range(lrp[i], lrp[i + 1]):
+                    k = lci[idx]
+                    if k >= i:
+                        break
+                    u_kk = 0j
+                    for kx in range(lrp[k], lrp[k + 1]):
+                        if lci[kx] == k:
+                            u_kk = v[kx]
+                            break
+                    if abs(u_kk) < 1e-30:
+                        continue
+                    d = u_kk.real * u_kk.real + u_kk.imag * u_kk.imag
+                    l_ik = v[idx] * complex(u_kk.real / d, -u_kk.imag / d)
+                    v[idx] = l_ik
+                    for jx in range(lrp[i], lrp[i + 1]):
+                        j = lci[jx]
+                        if j <= k:
+                            continue
+                        for sx in range(lrp[k], lrp[k + 1]):
+                            if lci[sx] == j:
+                                v[jx] = v[jx] - l_ik * v[sx]
+                                break
+            udiag = [1 + 0j] * ln
+            for i in range(ln):
+                for idx in range(lrp[i], lrp[i + 1]):
+                    if lci[idx] == i:
+                        udiag[i] = v[idx]
+            self.subdomains.append((gi, lrp, lci, v, udiag))
+
+    def stats(self):
+        sizes = [len(s[0]) for s in self.subdomains]
+        return len(sizes), min(sizes), max(sizes), sum(sizes) / len(sizes)
+
+    def apply(self, r):
+        r = [complex(x) for x in r]
+        out = [0j] * self.n
+        for gi, lrp, lci, v, udiag in self.subdomains:
+            ln = len(gi)
+            y = [r[g] for g in gi]
+            for i in range(ln):
+                for idx in range(lrp[i], lrp[i + 1]):
+                    j = lci[idx]
+                    if j < i:
+                        y[i] = y[i] - v[idx] * y[j]
+            x = y
+            for i in range(ln - 1, -1, -1):
+                for idx in range(lrp[i], lrp[i + 1]):
+                    j = lci[idx]
+                    if j > i:
+                        x[i] = x[i] - v[idx] * x[j]
+                u = udiag[i]
+                if abs(u) > 1e-30:
+                    d = u.real * u.real + u.imag * u.imag
+                    x[i] = x[i] * complex(u.real / d, -u.imag / d)
+            for l, g in enumerate(gi):
+                out[g] += x[l] * self.weights[g]
+        return np.array(out, dtype=np.complex128)

@@ -28,7 +28,7 @@ def test_solve_helmholtz_direct(gpu):                       # :1514-1530
     assert np.abs(s.values - x).max() <= 1e-10 * np.abs(x).max() and s.residual <= 1e-12
 
 
-ITERATIVE = [fs.SolverType.Gmres, fs.SolverType.GmresIlu, fs.SolverType.GmresJacobi, fs.SolverType.GmresIluColoring, fs.SolverType.GmresIluFixedPoint, fs.SolverType.GmresAmg,
+ITERATIVE = [fs.SolverType.Gmres, fs.SolverType.GmresIlu, fs.SolverType.GmresJacobi, fs.SolverType.GmresIluColoring, fs.SolverType.GmresIluFixedPoint, fs.SolverType.GmresSchwarz, fs.SolverType.GmresAmg,
              fs.SolverType.GmresPipelined, fs.SolverType.GmresPipelinedIlu, fs.SolverType.GmresPipelinedAmg, fs.SolverType.GmresShiftedLaplacian]
 
 
@@ -103,7 +103,7 @@ def test_solve_csr_and_its_errors(gpu):                     # :1438-1503
     with pytest.raises(fs.SolverError) as e:
         fs.solve_csr_with_guess(p.row_ptrs, p.col_indices, vals, p.rhs, x[:-2], fs.SolverConfig())
     assert e.value.kind == "DimensionMismatch" and e.value.actual == nd - 2
-    for t in (fs.SolverType.GmresShiftedLaplacian, fs.SolverType.GmresShiftedLaplacianMg, fs.SolverType.GmresSchwarz):
+    for t in (fs.SolverType.GmresShiftedLaplacian, fs.SolverType.GmresShiftedLaplacianMg):
         with pytest.raises(fs.SolverError) as e:
             fs.solve_csr(p.row_ptrs, p.col_indices, vals, p.rhs, fs.SolverConfig(solver_type=t))
         assert e.value.kind == "InvalidConfiguration"

@@ -136,3 +136,62 @@ def test_fixed_point_ilu(gpu):
     with pytest.raises(ma.MaError):
         ma.IluFixedPointPreconditioner(csr, -1)
     P.close(); lin.close(); csr.close()
+
+
+def _schwarz_test_matrix():
+    """create_test_matrix of schwarz.rs' tests (:433-455): 20 x 20, 4 on the diagonal, -1 beside it, -0.5 five away."""
+    n = 20
+    D = np.zeros((n, n), dtype=np.complex128)
+    for i in range(n):
+        D[i, i] = 4.0
+        if i > 0: D[i, i - 1] = -1.0
+        if i < n - 1: D[i, i + 1] = -1.0
+        if i >= 5: D[i, i - 5] = -0.5
+        if i < n - 5: D[i, i + 5] = -0.5
+    return sp.csr_matrix(D)
+
+
+def test_additive_schwarz(gpu):
+    """AdditiveSchwarzPreconditioner (schwarz.rs): stats and apply against the restatement for several (subdomains, overlap) on the
+    reference's test matrix, on an unsymmetric complex matrix and on the Helmholtz box; the reference's tests (:457-531): bounded
+    apply, 4 subdomains of more than 5 rows with overlap 2, GMRES converges with overlap 0, 1 and 2."""
+    I = O.ilu_module()
+    rng = np.random.default_rng(12)
+    n = 70
+    A = sp.random(n, n, density=0.08, random_state=6, format="csr").astype(np.complex128)
+    A.data = rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz)
+    A = (A + sp.diags(np.full(n, 5.0 - 1.0j))).tocsr()
+    from math_audio_amd import fem
+    nodes, rp, ci, K, M = fem.helmholtz_box(5, 4, 3)
+    H = sp.csr_matrix((K - (1.2 + 0.05j) ** 2 * M, ci, rp))
+    for S0, cases in ((_schwarz_test_matrix(), ((4, 0), (4, 1), (4, 2), (1, 3), (50, 1))), (A, ((8, 2), (3, 1))), (H, ((8, 2), (5, 0)))):
+        csr, S = _csr(S0)
+        m = S.shape[0]
+        r = np.sin(np.arange(m)) + 0.3j * np.cos(0.4 * np.arange(m))
+        for ns, ov in cases:
+            P = ma.AdditiveSchwarzPreconditioner(csr, ns, ov)
+            ref = I.AdditiveSchwarzPreconditioner(S.indptr, S.indices, S.data, ns, ov)
+            st, rs = P.stats(), ref.stats()
+            assert st[:3] == rs[:3] and abs(st[3] - rs[3]) <= 1e-12, (ns, ov)
+            z = P.apply(r); zr = ref.apply(r)
+            assert np.abs(z - zr).max() <= 1e-12 * np.abs(zr).max(), (ns, ov)
+            P.close()
+        csr.close()
+    csr, S = _csr(_schwarz_test_matrix())
+    lin = ma.LinearOperator.csr(csr)
+    b = np.sin(np.arange(20)).astype(np.complex128)
+    P = ma.AdditiveSchwarzPreconditioner(csr, 4, 1)
+    assert (np.abs(P.apply(b)) < 100.0).all()
+    P.close()
+    P = ma.AdditiveSchwarzPreconditioner(csr, 4, 2)
+    nsub, mn, mx, avg = P.stats()
+    assert nsub == 4 and mn > 0 and mx >= mn and avg > 5.0
+    P.close()
+    for ov in (0, 1, 2):
+        P = ma.AdditiveSchwarzPreconditioner(csr, 4, ov)
+        x, info = ma.gmres_preconditioned(lin, P, b, restart=20, max_iterations=100, tol=1e-8)
+        assert info.converged and np.linalg.norm(S @ x - b) <= 1e-6 * np.linalg.norm(b)
+        P.close()
+    with pytest.raises(ma.MaError):
+        ma.AdditiveSchwarzPreconditioner(csr, 4, -1)
+    lin.close(); csr.close()
