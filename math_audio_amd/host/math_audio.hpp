@@ -559,6 +559,50 @@ class IluPreconditioner : public Preconditioner {
   IluPreconditioner() = default;
   ma_precond_t* h_ = nullptr;
 };
+// preconditioners/ilu_parallel.rs: IluColoringPreconditioner::from_csr (:52: ILU(0) with level-scheduled solves -- the device apply of
+// IluPreconditioner), IluFixedPointPreconditioner::from_csr(&matrix, iterations) / from_csr_default (:397, :492);
+// preconditioners/schwarz.rs: AdditiveSchwarzPreconditioner::from_csr(&matrix, num_subdomains, overlap) (:84), stats() (:148)
+class IluColoringPreconditioner : public Preconditioner {
+ public:
+  static IluColoringPreconditioner from_csr(const CsrMatrix& m) { IluColoringPreconditioner p; solver_check(ma_precond_create_ilu0(m.csr_handle(), &p.h_)); return p; }
+  IluColoringPreconditioner(IluColoringPreconditioner&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  ~IluColoringPreconditioner() override { if (h_) ma_precond_destroy(h_); }
+  ma_precond_t* handle() const override { return h_; }
+ private:
+  IluColoringPreconditioner() = default;
+  ma_precond_t* h_ = nullptr;
+};
+class IluFixedPointPreconditioner : public Preconditioner {
+ public:
+  static IluFixedPointPreconditioner from_csr(const CsrMatrix& m, size_t iterations) {
+    IluFixedPointPreconditioner p; solver_check(ma_precond_create_ilu_fixed_point(m.csr_handle(), (int32_t)iterations, &p.h_)); return p;
+  }
+  static IluFixedPointPreconditioner from_csr_default(const CsrMatrix& m) { return from_csr(m, 3); }
+  IluFixedPointPreconditioner(IluFixedPointPreconditioner&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  ~IluFixedPointPreconditioner() override { if (h_) ma_precond_destroy(h_); }
+  ma_precond_t* handle() const override { return h_; }
+ private:
+  IluFixedPointPreconditioner() = default;
+  ma_precond_t* h_ = nullptr;
+};
+struct SchwarzStats { size_t num_subdomains = 0, min_size = 0, max_size = 0; double avg_size = 0.0; };
+class AdditiveSchwarzPreconditioner : public Preconditioner {
+ public:
+  static AdditiveSchwarzPreconditioner from_csr(const CsrMatrix& m, size_t num_subdomains, size_t overlap) {
+    AdditiveSchwarzPreconditioner p; solver_check(ma_precond_create_schwarz(m.csr_handle(), (int32_t)num_subdomains, (int32_t)overlap, &p.h_)); return p;
+  }
+  AdditiveSchwarzPreconditioner(AdditiveSchwarzPreconditioner&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  ~AdditiveSchwarzPreconditioner() override { if (h_) ma_precond_destroy(h_); }
+  ma_precond_t* handle() const override { return h_; }
+  SchwarzStats stats() const {
+    int64_t a = 0, b = 0, c = 0; double d = 0.0;
+    solver_check(ma_precond_schwarz_stats(h_, &a, &b, &c, &d));
+    return SchwarzStats{(size_t)a, (size_t)b, (size_t)c, d};
+  }
+ private:
+  AdditiveSchwarzPreconditioner() = default;
+  ma_precond_t* h_ = nullptr;
+};
 
 // iterative/gmres_pipelined.rs:18-250: gmres_pipelined(operator, precond, b, x0, config); precond may be null (IdentityPreconditioner)
 inline GmresSolution gmres_pipelined(const LinearOperator& a, const Preconditioner* m, const std::vector<Complex64>& b, const std::vector<Complex64>* x0, const GmresConfig& c) {

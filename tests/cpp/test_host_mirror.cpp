@@ -195,6 +195,16 @@ static void test_amg_and_pipelined_gmres() {
   {                                                          // ilu.rs:177-224: the 3 x 3 tridiagonal system
     CsrMatrix t3 = CsrMatrix::from_dense({4, -1, 0, -1, 4, -1, 0, -1, 4}, 3, 3, 1e-15);
     auto ilu = IluPreconditioner::from_csr(t3);
+    {                                                      // ilu_parallel.rs / schwarz.rs through the mirror: each one preconditions GMRES to convergence
+      std::vector<Complex64> bb(t3.num_rows()); for (size_t q = 0; q < bb.size(); ++q) bb[q] = Complex64(std::sin((double)q), 0.25);
+      auto col = IluColoringPreconditioner::from_csr(t3);
+      auto fp = IluFixedPointPreconditioner::from_csr_default(t3);
+      auto sw = AdditiveSchwarzPreconditioner::from_csr(t3, 2, 1);
+      CHECK(sw.stats().num_subdomains == 2 && sw.stats().min_size > 0 && sw.stats().max_size >= sw.stats().min_size);
+      CHECK(gmres_preconditioned(t3, col, bb, GmresConfig{100, 20, 1e-10, 0}).converged);
+      CHECK(gmres_preconditioned(t3, fp, bb, GmresConfig{100, 20, 1e-10, 0}).converged);
+      CHECK(gmres_preconditioned(t3, sw, bb, GmresConfig{100, 20, 1e-10, 0}).converged);
+    }
     std::vector<Complex64> r3 = {{1, 0}, {2, 0}, {3, 0}};
     auto chk = t3.matvec(ilu.apply(r3));
     CHECK(std::abs(chk[0] - r3[0]) < 0.5 && std::abs(chk[1] - r3[1]) < 0.5 && std::abs(chk[2] - r3[2]) < 0.5);
