@@ -3,7 +3,10 @@
 // its order, so that the coarse sets are identical and the values equal to the last bit of every sum; the product path then applies
 // the cycle on the device (op_plan.hip). Nothing here is a fallback for a device step.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include "amg_setup.hpp"
 
 namespace ma {
@@ -21,7 +24,8 @@ struct Trip { int64_t r, c; c64 v; };
 HostCsr from_triplets(int64_t nr, int64_t nc, std::vector<Trip>& t) {
   HostCsr m; m.nr = nr; m.nc = nc; m.ptr.assign((size_t)nr + 1, 0);
   if (t.empty()) return m;
-  std::stable_sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+  auto before = [](const Trip& a, const Trip& b) { return a.r != b.r ? a.r < b.r : a.c < b.c; };
+  if (!std::is_sorted(t.begin(), t.end(), before)) std::stable_sort(t.begin(), t.end(), before);   // a stable sort of a sorted list is the list
   m.col.reserve(t.size()); m.val.reserve(t.size());
   int64_t pr = -1, pc = -1;
   for (const Trip& e : t) {
@@ -37,12 +41,19 @@ inline c64 get(const HostCsr& m, int64_t i, int64_t j) {                        
   return c64{0.0, 0.0};
 }
 
-// CsrMatrix::matmul (csr.rs:594-651)
-HostCsr matmul(const HostCsr& a, const HostCsr& b) {
-  if (a.nr == 0 || b.nc == 0 || a.val.empty() || b.val.empty()) { HostCsr m; m.nr = a.nr; m.nc = b.nc; m.ptr.assign((size_t)a.nr + 1, 0); return m; }
-  std::vector<Trip> trip; trip.reserve(a.val.size() * 4);
+// host threads for the row-parallel parts of the setup (MA_HOST_THREADS, default min(16, cores)): every row's arithmetic is the
+// sequential code's and the rows are put together in row order, so the result does not depend on the count
+int host_threads() {
+  const char* e = getenv("MA_HOST_THREADS");
+  int t = e ? atoi(e) : 0;
+  if (t <= 0) { t = (int)std::thread::hardware_concurrency(); if (t > 16) t = 16; }
+  return t < 1 ? 1 : t;
+}
+
+// CsrMatrix::matmul (csr.rs:594-651): the rows are independent, blocks of rows run on host threads
+void matmul_rows(const HostCsr& a, const HostCsr& b, int64_t i0, int64_t i1, std::vector<Trip>& trip) {
   std::vector<std::pair<int64_t, c64>> rd;
-  for (int64_t i = 0; i < a.nr; ++i) {
+  for (int64_t i = i0; i < i1; ++i) {
     rd.clear();
     for (int64_t p = a.ptr[(size_t)i]; p < a.ptr[(size_t)i + 1]; ++p) {
       const int64_t k = a.col[(size_t)p]; const c64 aik = a.val[(size_t)p];
@@ -57,6 +68,20 @@ HostCsr matmul(const HostCsr& a, const HostCsr& b) {
     }
     if (cnorm(cv) > 1e-15) trip.push_back({i, cj, cv});
   }
+}
+HostCsr matmul(const HostCsr& a, const HostCsr& b) {
+  if (a.nr == 0 || b.nc == 0 || a.val.empty() || b.val.empty()) { HostCsr m; m.nr = a.nr; m.nc = b.nc; m.ptr.assign((size_t)a.nr + 1, 0); return m; }
+  const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, a.nr / 4096));
+  std::vector<std::vector<Trip>> parts((size_t)T);
+  if (T == 1) matmul_rows(a, b, 0, a.nr, parts[0]);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { matmul_rows(a, b, a.nr * t / T, a.nr * (t + 1) / T, parts[(size_t)t]); });
+    for (auto& x : th) x.join();
+  }
+  size_t total = 0; for (const auto& v : parts) total += v.size();
+  std::vector<Trip> trip; trip.reserve(total);
+  for (auto& v : parts) { trip.insert(trip.end(), v.begin(), v.end()); std::vector<Trip>().swap(v); }
   return from_triplets(a.nr, b.nc, trip);
 }
 
@@ -201,19 +226,30 @@ int amg_setup_host(const HostCsr& A, const ma_amg_config_t& cfg, std::vector<Hos
   As.push_back(A);
   std::vector<int64_t> sp, sj, c2f;
   std::vector<char> pt;
+  const bool timing = getenv("MA_AMG_TIMING") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   for (int l = 0; l + 1 < cfg.max_levels; ++l) {
     const HostCsr& cur = As.back();
     const int64_t n = cur.nr;
     if (n <= (int64_t)cfg.coarse_size) break;
+    const auto t0 = now();
     strength(cur, cfg.strong_threshold, sp, sj);
+    const auto t1 = now();
     if (cfg.coarsening == 0) coarsen_rs(n, sp, sj, pt); else coarsen_pmis(n, sp, sj, pt);
     c2f.clear();
     for (int64_t i = 0; i < n; ++i) if (pt[(size_t)i] == COARSE) c2f.push_back(i);
     if (c2f.empty() || (int64_t)c2f.size() >= n) break;
+    const auto t2 = now();
     HostCsr P = build_interpolation(cur, sp, sj, pt, c2f, cfg);
+    const auto t3 = now();
     HostCsr R = transpose(P);
+    const auto t4 = now();
     HostCsr AP = matmul(cur, P);
+    const auto t5 = now();
     HostCsr Ac = matmul(R, AP);                                                               // galerkin_product, amg.rs:825-828
+    if (timing) fprintf(stderr, "[amg setup] level %d n %lld: strength %.0f coarsen %.0f interpolation %.0f transpose %.0f A*P %.0f R*(AP) %.0f ms\n", l, (long long)n,
+                        ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, now()));
     Ps.push_back(std::move(P)); Rs.push_back(std::move(R)); As.push_back(std::move(Ac));
   }
   double td = 0.0, tn = 0.0;                                                                  // compute_complexities, amg.rs:837-853
