@@ -41,15 +41,6 @@ inline c64 get(const HostCsr& m, int64_t i, int64_t j) {                        
   return c64{0.0, 0.0};
 }
 
-// host threads for the row-parallel parts of the setup (MA_HOST_THREADS, default min(16, cores)): every row's arithmetic is the
-// sequential code's and the rows are put together in row order, so the result does not depend on the count
-int host_threads() {
-  const char* e = getenv("MA_HOST_THREADS");
-  int t = e ? atoi(e) : 0;
-  if (t <= 0) { t = (int)std::thread::hardware_concurrency(); if (t > 16) t = 16; }
-  return t < 1 ? 1 : t;
-}
-
 // CsrMatrix::matmul (csr.rs:594-651): the rows are independent, blocks of rows run on host threads
 void matmul_rows(const HostCsr& a, const HostCsr& b, int64_t i0, int64_t i1, std::vector<Trip>& trip) {
   std::vector<std::pair<int64_t, c64>> rd;

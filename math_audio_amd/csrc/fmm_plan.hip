@@ -13,6 +13,7 @@
 // Meshes without evaluation elements, velocity-type boundary conditions (the coefficient of compute_near_block is the
 // velocity one whatever the panel's type), every panel in at most one cluster; anything else is MA_ERR_UNSUPPORTED.
 #include "fmm_plan.hpp"
+#include <chrono>
 #include "ma_device_math.hpp"
 #include "ma_tables.h"
 #include <vector>
@@ -613,6 +614,22 @@ static int slfmm_launch_down(const ma_slfmm* S, double sgn, dc* y, hipStream_t s
   return MA_OK;
 }
 
+// the element pair behind every near entry, block by block (row-major inside a block); the self term's slot gets a neighbouring
+// panel as a stand-in partner, its value is overwritten by slfmm_fix_diag_kernel
+__global__ __launch_bounds__(256) void slfmm_pairs_kernel(const int* __restrict__ eptr, const int* __restrict__ eidx, const int* __restrict__ bsrc,
+                                                          const int* __restrict__ bfld, const long long* __restrict__ boff, int np, int2* __restrict__ pairs) {
+  const int b = blockIdx.x;
+  const int a = bsrc[b], f = bfld[b];
+  const int a0 = eptr[a], ns = eptr[a + 1] - a0, f0 = eptr[f], nf = eptr[f + 1] - f0;
+  int2* out = pairs + boff[b];
+  for (long long idx = threadIdx.x; idx < (long long)ns * nf; idx += 256) {
+    const int i = (int)(idx / nf), j = (int)(idx % nf);
+    const int se = eidx[a0 + i]; int fe = eidx[f0 + j];
+    if (a == f && se == fe) fe = (se + 1) % np == se ? se : (se + 1) % np;
+    out[idx] = make_int2(se, fe);
+  }
+}
+
 static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st) {
   const int avg = S->nc > 0 ? (int)((S->h_eptr.empty() ? 0 : S->h_eptr.back()) / S->nc) : 0;
   int G = 8; while (G < 64 && G < avg) G <<= 1;
@@ -705,6 +722,10 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
     for (int q = cl->near_ptr[c]; q < cl->near_ptr[c + 1]; ++q) MA_REQUIRE(cl->near_idx && cl->near_idx[q] >= 0 && cl->near_idx[q] < nc, MA_ERR_INVALID, "near cluster index out of range");
     for (int q = cl->far_ptr[c]; q < cl->far_ptr[c + 1]; ++q) MA_REQUIRE(cl->far_idx && cl->far_idx[q] >= 0 && cl->far_idx[q] < nc, MA_ERR_INVALID, "far cluster index out of range");
   }
+  const bool timing = getenv("MA_FMM_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto tt0 = tnow();
   ma_slfmm* S = new (std::nothrow) ma_slfmm(); MA_REQUIRE(S, MA_ERR_NOMEM, "host allocation failed");
   S->device = plan->device; S->plan = plan; S->n = plan->nd; S->nc = nc; S->P = n_theta * n_phi; S->k = physics->wave_number; S->overlap = allow_overlap;
   auto fail = [&](int code) { slfmm_destroy(S); return code; };
@@ -743,41 +764,46 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   boff.push_back(tot);
   S->nbval = tot;
   if (tot >= 2000000000LL) { set_error("near field of %lld entries", tot); return fail(MA_ERR_UNSUPPORTED); }
-  std::vector<int2> pairs((size_t)std::max<long long>(tot, 1));
+  // the (source element, field element) pair of every near entry is written on the device (slfmm_pairs_kernel); the host keeps the
+  // positions of the self terms: entry (i, i) of every diagonal block (a cluster lists an element once)
   std::vector<long long> dpos; std::vector<int> dpanel;
   for (size_t b = 0; b < bsrc.size(); ++b) {
-    const int ci = bsrc[b], cj = bfld[b];
-    const int ns = eptr[(size_t)ci + 1] - eptr[(size_t)ci], nf = eptr[(size_t)cj + 1] - eptr[(size_t)cj];
-    for (int i = 0; i < ns; ++i)
-      for (int j = 0; j < nf; ++j) {
-        const int se = eidx[(size_t)eptr[(size_t)ci] + i], fe = eidx[(size_t)eptr[(size_t)cj] + j];
-        const long long pos = boff[b] + (long long)i * nf + j;
-        if (ci == cj && se == fe) { dpos.push_back(pos); dpanel.push_back(se); pairs[(size_t)pos] = make_int2(se, (se + 1) % np == se ? se : (se + 1) % np); }
-        else pairs[(size_t)pos] = make_int2(se, fe);
-      }
+    if (bsrc[b] != bfld[b]) continue;
+    const int ci = bsrc[b];
+    const int ns = eptr[(size_t)ci + 1] - eptr[(size_t)ci];
+    for (int i = 0; i < ns; ++i) { dpos.push_back(boff[b] + (long long)i * ns + i); dpanel.push_back(eidx[(size_t)eptr[(size_t)ci] + i]); }
   }
+  const auto tt1 = tnow();
   // ---- D entries (:663-721)
-  std::vector<std::vector<std::pair<int, c64>>> by_field((size_t)nc), by_source((size_t)nc);
+  // by source (the transpose apply): the far lists as they come; by field (the forward apply): the same pairs counted into rows, source
+  // ascending within a row (the order the reference's loop appends them in)
+  std::vector<int> fptr((size_t)nc + 1, 0), foth, tptr(cl->far_ptr, cl->far_ptr + nc + 1), toth; std::vector<c64> fval, tval;
   {
     const int order = std::max(n_terms, 2);
-    std::vector<double> hr, hi;
+    const size_t npairs = (size_t)cl->far_ptr[nc];
+    // one spherical Hankel evaluation per far pair: independent, on host threads, each into its own slot
+    tval.resize(npairs); if (npairs) toth.assign(cl->far_idx, cl->far_idx + npairs);
+    std::vector<int> bad((size_t)nc, -1);
+    host_parallel_for(nc, 16, [&](long long c0, long long c1) {
+      std::vector<double> hr, hi;
+      for (long long i = c0; i < c1; ++i)
+        for (int q = cl->far_ptr[i]; q < cl->far_ptr[i + 1]; ++q) {
+          const int j = cl->far_idx[q];
+          const double dx = cc[(size_t)3 * i] - cc[(size_t)3 * j], dy = cc[(size_t)3 * i + 1] - cc[(size_t)3 * j + 1], dz = cc[(size_t)3 * i + 2] - cc[(size_t)3 * j + 2];
+          const double r = std::sqrt(dx * dx + dy * dy + dz * dz);
+          if (!(r > 0.0)) { if (bad[(size_t)i] < 0) bad[(size_t)i] = j; continue; }
+          spherical_hankel_first_kind(order, S->k * r, 1.0, hr, hi);
+          tval[(size_t)q] = c64{-hi[0] * S->k, hr[0] * S->k};                      // h_0 * (i k)
+        }
+    });
+    for (int i = 0; i < nc; ++i) if (bad[(size_t)i] >= 0) { set_error("far clusters %d and %d share their centre", i, bad[(size_t)i]); return fail(MA_ERR_INVALID); }
+    for (size_t q = 0; q < npairs; ++q) fptr[(size_t)toth[q] + 1] += 1;
+    for (int c = 0; c < nc; ++c) fptr[(size_t)c + 1] += fptr[(size_t)c];
+    foth.resize(npairs); fval.resize(npairs);
+    std::vector<int> cur(fptr.begin(), fptr.end() - 1);
     for (int i = 0; i < nc; ++i)
-      for (int q = cl->far_ptr[i]; q < cl->far_ptr[i + 1]; ++q) {
-        const int j = cl->far_idx[q];
-        const double dx = cc[(size_t)3 * i] - cc[(size_t)3 * j], dy = cc[(size_t)3 * i + 1] - cc[(size_t)3 * j + 1], dz = cc[(size_t)3 * i + 2] - cc[(size_t)3 * j + 2];
-        const double r = std::sqrt(dx * dx + dy * dy + dz * dz);
-        if (!(r > 0.0)) { set_error("far clusters %d and %d share their centre", i, j); return fail(MA_ERR_INVALID); }
-        spherical_hankel_first_kind(order, S->k * r, 1.0, hr, hi);
-        const c64 d{-hi[0] * S->k, hr[0] * S->k};                      // h_0 * (i k)
-        by_field[(size_t)j].push_back({i, d}); by_source[(size_t)i].push_back({j, d});
-      }
+      for (int q = cl->far_ptr[i]; q < cl->far_ptr[i + 1]; ++q) { const int pos = cur[(size_t)toth[(size_t)q]]++; foth[(size_t)pos] = i; fval[(size_t)pos] = tval[(size_t)q]; }
   }
-  auto flatten = [&](const std::vector<std::vector<std::pair<int, c64>>>& L, std::vector<int>& ptr, std::vector<int>& oth, std::vector<c64>& val) {
-    ptr.assign(1, 0);
-    for (const auto& l : L) { for (const auto& e : l) { oth.push_back(e.first); val.push_back(e.second); } ptr.push_back((int)oth.size()); }
-  };
-  std::vector<int> fptr, foth, tptr, toth; std::vector<c64> fval, tval;
-  flatten(by_field, fptr, foth, fval); flatten(by_source, tptr, toth, tval);
   // ---- per-cluster views of the blocks: as source (rows of the block) or as field of an off-diagonal block (its transpose)
   std::vector<std::vector<SlfmmEntry>> views((size_t)nc);
   std::vector<long long> broff(bsrc.size()), bcoff(bsrc.size()); long long npart = 0, max_block = 0;
@@ -791,6 +817,7 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   }
   std::vector<int> cptr(1, 0); std::vector<SlfmmEntry> cent;
   for (const auto& v : views) { cent.insert(cent.end(), v.begin(), v.end()); cptr.push_back((int)cent.size()); }
+  const auto tt2 = tnow();
   int rc = MA_OK;
 #define UP(dst, src) if (!rc) rc = upload(&S->dst, src)
   UP(d_eptr, eptr); UP(d_eidx, eidx); UP(d_edof, edof); UP(d_cc, cc); UP(d_sc, sc); UP(d_sw, sw); UP(d_cptr, cptr); UP(d_cent, cent);
@@ -798,25 +825,32 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
 #undef UP
   if (!rc) rc = fmm_dense_from_lists(fptr, foth, fval, nc, &S->d_fdense);
   { const char* e = getenv("MA_FMM_NEAR_BLOCKS");           // =0: the per-cluster kernel (every off-diagonal block read from both sides)
+    S->nblocks = (int)bsrc.size(); S->max_block = max_block;
+    if (!rc) rc = upload(&S->d_bsrc, bsrc);
+    if (!rc) rc = upload(&S->d_bfld, bfld);
+    if (!rc) rc = upload(&S->d_boff, boff);
     if (!rc && !(e && atoi(e) == 0) && !bsrc.empty()) {
-      S->nblocks = (int)bsrc.size(); S->max_block = max_block;
-      rc = upload(&S->d_bsrc, bsrc); if (!rc) rc = upload(&S->d_bfld, bfld); if (!rc) rc = upload(&S->d_boff, boff);
       if (!rc) rc = upload(&S->d_broff, broff);
       if (!rc) rc = upload(&S->d_bcoff, bcoff);
       if (!rc && hipMalloc(&S->d_part, sizeof(c64) * (size_t)std::max(npart, 1LL)) != hipSuccess) { set_error("near-field partial sums"); rc = MA_ERR_NOMEM; }
     } }
-  if (!rc) rc = fmm_dense_from_lists(tptr, toth, tval, nc, &S->d_tdense);
+  if (!rc && free_term) rc = fmm_dense_from_lists(tptr, toth, tval, nc, &S->d_tdense);   // the multi-level operator's leaf (no free term) is never applied transposed
   if (rc) return fail(rc);
+  const auto tt3 = tnow();
   hipError_t e = hipMalloc(&S->d_bval, sizeof(c64) * (size_t)std::max<long long>(tot, 1));
   if (e == hipSuccess) e = hipMalloc(&S->d_up, sizeof(c64) * (size_t)nc * (size_t)P);
   if (e == hipSuccess) e = hipMalloc(&S->d_tr, sizeof(c64) * (size_t)nc * (size_t)P);
   int2* d_pairs = nullptr; long long* d_dpos = nullptr; int* d_dpanel = nullptr; c64* d_self = nullptr;
-  if (e == hipSuccess) e = hipMalloc(&d_pairs, sizeof(int2) * pairs.size());
-  if (e == hipSuccess) e = hipMemcpy(d_pairs, pairs.data(), sizeof(int2) * pairs.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&d_pairs, sizeof(int2) * (size_t)std::max<long long>(tot, 1));
+  if (e == hipSuccess && S->nblocks > 0) {
+    hipLaunchKernelGGL(slfmm_pairs_kernel, dim3((unsigned)S->nblocks), dim3(256), 0, nullptr, S->d_eptr, S->d_eidx, S->d_bsrc, S->d_bfld, S->d_boff, np, d_pairs);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipMalloc(&d_self, sizeof(c64) * (size_t)np);
   auto drop = [&]() { if (d_pairs) (void)hipFree(d_pairs); if (d_dpos) (void)hipFree(d_dpos); if (d_dpanel) (void)hipFree(d_dpanel); if (d_self) (void)hipFree(d_self); };
   if (e != hipSuccess) { set_error("SLFMM workspace: %s", hipGetErrorString(e)); drop(); return fail(MA_ERR_NOMEM); }
   rc = upload(&d_dpos, dpos); if (!rc) rc = upload(&d_dpanel, dpanel);
+  const auto tt4 = tnow();
   // coefficient of compute_near_block (:583-584): dg_dn gamma tau + d2g beta with beta = i h / k (types.rs:64-70), sign +1
   BemPhys ph;
   const double bim = physics->tau > 0.0 ? physics->harmonic_factor / physics->wave_number : 0.0;
@@ -839,6 +873,7 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   }
   if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("SLFMM near-field kernels failed"); rc = MA_ERR_HIP; }
   drop();
+  if (timing) fprintf(stderr, "[slfmm build] nc %d: lists+pairs %.0f, D %.0f, views %.0f, uploads+dense %.0f, alloc+pairs upload %.0f, kernels %.0f ms\n", nc, tms(tt0, tt1), tms(tt1, tt2), 0.0, tms(tt2, tt3), tms(tt3, tt4), tms(tt4, tnow()));
   if (rc) return fail(rc);
   *out = S;
   return MA_OK;
@@ -1185,25 +1220,40 @@ int mlfmm_create(ma_bem_plan* plan, const ma_cluster_tree* T, const ma_physics_t
       if (L.P > 1024) { set_error("level %d: %d sphere points", l, L.P); return fail(MA_ERR_UNSUPPORTED); }
       std::vector<double> cc((size_t)L.nc * 3), sc, sw;
       sphere_rule(lv.theta, lv.phi, sc, sw);
-      std::vector<std::vector<std::pair<int, c64>>> by_field((size_t)L.nc);
       std::vector<int> sptr(1, 0), sidx;
       const int order = std::max(lv.terms, 2);
-      std::vector<double> hr, hi;
+      // one spherical Hankel evaluation per far pair, on host threads, each into its own slot (skipped pairs keep the flag)
+      std::vector<std::vector<c64>> dv((size_t)L.nc); std::vector<std::vector<char>> dskip((size_t)L.nc);
+      host_parallel_for(L.nc, 16, [&](long long c0, long long c1) {
+        std::vector<double> hr, hi;
+        for (long long i = c0; i < c1; ++i) {
+          const HostCluster& q = lv.cl[(size_t)i];
+          dv[(size_t)i].resize(q.far.size()); dskip[(size_t)i].assign(q.far.size(), 0);
+          for (size_t t = 0; t < q.far.size(); ++t) {
+            const HostCluster& o = lv.cl[(size_t)q.far[t]];
+            const double dx = q.c[0] - o.c[0], dy = q.c[1] - o.c[1], dz = q.c[2] - o.c[2];
+            const double r = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (r < 1e-15) { dskip[(size_t)i][t] = 1; continue; }          // mlfmm.rs:826-828
+            spherical_hankel_first_kind(order, k * r, 1.0, hr, hi);
+            dv[(size_t)i][t] = c64{-hi[0] * k, hr[0] * k};
+          }
+        }
+      });
+      std::vector<int> fptr((size_t)L.nc + 1, 0), foth; std::vector<c64> fval;       // by field, source ascending within a row
       for (int i = 0; i < L.nc; ++i) {
         const HostCluster& q = lv.cl[(size_t)i];
         for (int d = 0; d < 3; ++d) cc[(size_t)3 * i + d] = q.c[d];
-        for (int j : q.far) {
-          const HostCluster& o = lv.cl[(size_t)j];
-          const double dx = q.c[0] - o.c[0], dy = q.c[1] - o.c[1], dz = q.c[2] - o.c[2];
-          const double r = std::sqrt(dx * dx + dy * dy + dz * dz);
-          if (r < 1e-15) continue;                                         // mlfmm.rs:826-828
-          spherical_hankel_first_kind(order, k * r, 1.0, hr, hi);
-          by_field[(size_t)j].push_back({i, c64{-hi[0] * k, hr[0] * k}});   // locals[field j] += d multipoles[source i]
-        }
+        for (size_t t = 0; t < q.far.size(); ++t) if (!dskip[(size_t)i][t]) fptr[(size_t)q.far[t] + 1] += 1;
         sidx.insert(sidx.end(), q.sons.begin(), q.sons.end()); sptr.push_back((int)sidx.size());
       }
-      std::vector<int> fptr(1, 0), foth; std::vector<c64> fval;
-      for (const auto& v : by_field) { for (const auto& e : v) { foth.push_back(e.first); fval.push_back(e.second); } fptr.push_back((int)foth.size()); }
+      for (int c = 0; c < L.nc; ++c) fptr[(size_t)c + 1] += fptr[(size_t)c];
+      foth.resize((size_t)fptr[(size_t)L.nc]); fval.resize(foth.size());
+      { std::vector<int> cur(fptr.begin(), fptr.end() - 1);
+        for (int i = 0; i < L.nc; ++i) {
+          const HostCluster& q = lv.cl[(size_t)i];
+          for (size_t t = 0; t < q.far.size(); ++t)
+            if (!dskip[(size_t)i][t]) { const int pos = cur[(size_t)q.far[t]]++; foth[(size_t)pos] = i; fval[(size_t)pos] = dv[(size_t)i][t]; }   // locals[field j] += d multipoles[source i]
+        } }
       int rc = upload(&L.d_cc, cc);
       if (!rc) rc = upload(&L.d_sc, sc);
       if (!rc) rc = upload(&L.d_sw, sw);

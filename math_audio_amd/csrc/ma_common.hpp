@@ -5,6 +5,10 @@
 #include <cstdarg>
 #include <cstring>
 #include <string>
+#include <cstdlib>
+#include <functional>
+#include <thread>
+#include <vector>
 #include "../../include/mathaudio_hip.h"
 
 namespace ma {
@@ -34,6 +38,23 @@ int use_device(int device);
 
 struct c64 { double re, im; };
 static_assert(sizeof(c64) == sizeof(ma_c64), "layout");
+
+// Host threads for setup work that is independent per item (MA_HOST_THREADS, default min(16, cores)). fn(begin, end) gets contiguous
+// blocks; callers keep per-item results in per-item slots, so what is computed does not depend on the count.
+inline int host_threads() {
+  const char* e = getenv("MA_HOST_THREADS");
+  int t = e ? atoi(e) : 0;
+  if (t <= 0) { t = (int)std::thread::hardware_concurrency(); if (t > 16) t = 16; }
+  return t < 1 ? 1 : t;
+}
+inline void host_parallel_for(long long n, long long min_per_thread, const std::function<void(long long, long long)>& fn) {
+  long long T = host_threads();
+  if (min_per_thread > 0 && n / min_per_thread < T) T = n / min_per_thread;
+  if (T <= 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  for (long long t = 0; t < T; ++t) th.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T); });
+  for (auto& x : th) x.join();
+}
 
 // HIP event pair helper for the optional per-phase timing.
 struct PhaseTimer {
