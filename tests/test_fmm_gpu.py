@@ -19,7 +19,8 @@ def _xvec(n):
     return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
 
 
-@pytest.mark.parametrize("sub,ka,cell,nt,nphi", [(2, 1.0, 0.07, 4, 8), (3, 3.0, 0.05, 6, 12), (2, 0.2, 10.0, 4, 8)])
+# sphere rules of 32, 72, 288 (more than one pass of 256 points in the upward pass, three translation passes of 128) and 6 points
+@pytest.mark.parametrize("sub,ka,cell,nt,nphi", [(2, 1.0, 0.07, 4, 8), (3, 3.0, 0.05, 6, 12), (2, 0.2, 10.0, 4, 8), (2, 2.0, 0.07, 12, 24), (2, 1.0, 0.07, 2, 3)])
 def test_slfmm_operator_matches_the_restatement(gpu, sub, ka, cell, nt, nphi):
     om = O.icosphere(RADIUS, sub)
     k = k_from_ka(ka)
