@@ -112,3 +112,24 @@ def test_operator_apply_is_linear_and_reproducible_at_size(gpu):
     y0 = op0.apply(x); yt0 = op0.apply_transpose(x)
     assert np.abs(y0 - y).max() <= 1e-12 * np.abs(y).max() and np.abs(yt0 - yt).max() <= 1e-12 * np.abs(yt).max()
     op0.close(); op.close()
+
+
+def test_slfmm_over_octree_leaves(gpu):
+    """The reference's own spatial partition (Octree::build + compute_interaction_lists, mesh/octree.rs, mirrored in
+    math_audio_amd/octree.py) as the clusters of build_slfmm_system: device operator against the restatement on the same lists."""
+    from math_audio_amd import octree as T
+    om = O.icosphere(RADIUS, 3)
+    k = k_from_ka(2.0)
+    tree = T.Octree.build(om.center, 40, 5)
+    tree.compute_interaction_lists(1.5)
+    cl = T.slfmm_clusters(tree)
+    assert cl.n == tree.stats().num_leaves > 8 and cl.far_ptr[-1] > 0
+    ref = O.Slfmm(om, cl, k, 6, 12, 5)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    op = ma.LinearOperator.slfmm(plan, cl, k, 6, 12, 5)
+    x = _xvec(om.n_elem)
+    y = op.apply(x); yr = ref.matvec(x)
+    assert np.abs(y - yr).max() <= 1e-10 * np.abs(yr).max()
+    yt = op.apply_transpose(x); ytr = ref.matvec(x, transpose=True)
+    assert np.abs(yt - ytr).max() <= 1e-10 * np.abs(ytr).max()
+    op.close(); plan.close()
