@@ -36,7 +36,7 @@ struct ma_slfmm {
   int* d_tptr = nullptr; int* d_toth = nullptr; c64* d_tval = nullptr;      // grouped by source cluster (transpose)
   c64* d_fdense = nullptr; c64* d_tdense = nullptr;                         // the same two as dense nc x nc matrices, when the lists are nearly full
   int* d_bsrc = nullptr; int* d_bfld = nullptr; long long* d_boff = nullptr; int nblocks = 0;   // the near blocks one by one
-  long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0;   // their partial sums (rows, columns)
+  long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0, max_width = 0;   // their partial sums (rows, columns)
   c64* d_up = nullptr; c64* d_tr = nullptr;
   c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=0: recomputed)
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
@@ -488,6 +488,72 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
     }
   }
 }
+// Large blocks (wider than one lane set): the same two products with the rows outside and the column chunks inside. A lane keeps
+// x[cols] of its NCH <= 8 chunks and their column sums in registers, a row is reduced over the lanes ONCE (not once per chunk) and
+// written once. One workgroup per block, the four wavefronts take rows w, w + 4, ...; their column sums meet in LDS in wavefront order.
+constexpr int FMM_NCH = 8;
+__global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ bsrc,
+                                                                     const int* __restrict__ bfld, const long long* __restrict__ boff,
+                                                                     const long long* __restrict__ broff, const long long* __restrict__ bcoff, int nblocks,
+                                                                     const dc* __restrict__ bval, const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
+  __shared__ dc cpart[4 * 64 * FMM_NCH];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int a = bsrc[b], f = bfld[b];
+  const int a0 = eptr[a], ns = eptr[a + 1] - a0, f0 = eptr[f], nf = eptr[f + 1] - f0;
+  const dc* B = bval + boff[b];
+  const bool both = a != f, self_t = !both && tmode != 0;
+  dc* prow = part + broff[b];
+  dc* pcol = both ? part + bcoff[b] : prow;
+  const int nch = (nf + 63) >> 6;                            // <= FMM_NCH (the launcher's choice)
+  dc xf[FMM_NCH]; double cr[FMM_NCH], ci[FMM_NCH];
+#pragma unroll
+  for (int ch = 0; ch < FMM_NCH; ++ch) {
+    const int j = ch * 64 + lane;
+    xf[ch] = (ch < nch && j < nf) ? x[edof[f0 + j]] : dc_make(0.0, 0.0);
+    cr[ch] = 0.0; ci[ch] = 0.0;
+  }
+  constexpr int U = 4;
+  for (int i0 = w; i0 < ns; i0 += 4 * U) {
+    dc xa[U]; double pr[U], pi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; xa[u] = x[edof[a0 + (i < ns ? i : i0)]]; pr[u] = 0.0; pi[u] = 0.0; }
+#pragma unroll
+    for (int ch = 0; ch < FMM_NCH; ++ch) {
+      if (ch < nch) {                                        // uniform
+        const int j = ch * 64 + lane;
+        const bool vj = j < nf;
+        dc bb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; bb[u] = B[(long long)(i < ns ? i : i0) * nf + (vj ? j : 0)]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (vj && i0 + 4 * u < ns) {
+            pr[u] += bb[u].re * xf[ch].re - bb[u].im * xf[ch].im; pi[u] += bb[u].re * xf[ch].im + bb[u].im * xf[ch].re;
+            cr[ch] += bb[u].re * xa[u].re - bb[u].im * xa[u].im; ci[ch] += bb[u].re * xa[u].im + bb[u].im * xa[u].re;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double sr = fmm_set_sum(pr[u], 64), si = fmm_set_sum(pi[u], 64);
+      const int i = i0 + 4 * u;
+      if (lane == 0 && i < ns && !self_t) prow[i] = dc_make(sr, si);
+    }
+  }
+  if (both || self_t) {                                      // uniform over the block
+#pragma unroll
+    for (int ch = 0; ch < FMM_NCH; ++ch) if (ch < nch) cpart[(w * FMM_NCH + ch) * 64 + lane] = dc_make(cr[ch], ci[ch]);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nf; j += 256) {
+      const int ch = j >> 6, l = j & 63;
+      double tr_ = 0.0, ti_ = 0.0;
+      for (int q = 0; q < 4; ++q) { tr_ += cpart[(q * FMM_NCH + ch) * 64 + l].re; ti_ += cpart[(q * FMM_NCH + ch) * 64 + l].im; }
+      pcol[j] = dc_make(tr_, ti_);
+    }
+  }
+}
 template <int WPC>
 __global__ __launch_bounds__(256) void slfmm_near_gather_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
                                                                 const SlfmmEntry* __restrict__ cent, const dc* __restrict__ part, dc* __restrict__ y,
@@ -532,7 +598,7 @@ __global__ __launch_bounds__(256) void slfmm_phase_table_kernel(BemGeom g, const
 __global__ __launch_bounds__(256) void slfmm_up_tab_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const dc* __restrict__ E, int P, double sgn,
                                                            const dc* __restrict__ x, dc* __restrict__ up) {
   __shared__ dc part[256];
-  constexpr int U = 4;
+  constexpr int U = 8;
   const int c = blockIdx.x, tid = threadIdx.x;
   const int e0 = eptr[c], n = eptr[c + 1] - e0;
   const int QG = P <= 256 ? 256 / P : 1;
@@ -567,7 +633,7 @@ __global__ __launch_bounds__(256) void slfmm_up_tab_kernel(const int* __restrict
 // y[dof_j] += sum_p (E.re, sgn E.im) tr[c][p]: a wavefront per element (four at a time), lanes over the sphere points
 __global__ __launch_bounds__(256) void slfmm_down_tab_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const dc* __restrict__ E, int P, double sgn,
                                                              const dc* __restrict__ tr, dc* __restrict__ y, int overlap) {
-  constexpr int U = 4;
+  constexpr int U = 8;
   const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e0 = eptr[c], n = eptr[c + 1] - e0;
   const dc* l = tr + (long long)c * P;
@@ -637,6 +703,9 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
     const dc* bv = reinterpret_cast<const dc*>(S->d_bval); dc* part = reinterpret_cast<dc*>(S->d_part);
     if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, dim3((unsigned)((S->nblocks + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
                                                    S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
+    else if (S->max_width <= 64 * FMM_NCH && !getenv("MA_FMM_WIDE_BLOCKS_OFF"))
+      hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+                         S->d_bcoff, S->nblocks, bv, x, part, tmode);
     else hipLaunchKernelGGL(slfmm_near_blocks_kernel<4>, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
                             S->d_bcoff, S->nblocks, bv, x, part, tmode);
     MA_HIP(hipGetLastError());
@@ -811,7 +880,7 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
     const long long ns = eptr[(size_t)bsrc[b] + 1] - eptr[(size_t)bsrc[b]], nf = eptr[(size_t)bfld[b] + 1] - eptr[(size_t)bfld[b]];
     broff[b] = npart; npart += ns;
     bcoff[b] = npart; if (bsrc[b] != bfld[b]) npart += nf;
-    max_block = std::max(max_block, ns * nf);
+    max_block = std::max(max_block, ns * nf); S->max_width = std::max(S->max_width, nf);
     views[(size_t)bsrc[b]].push_back({boff[b], broff[b], bfld[b], 0});
     if (bsrc[b] != bfld[b]) views[(size_t)bfld[b]].push_back({boff[b], bcoff[b], bsrc[b], 1});
   }
