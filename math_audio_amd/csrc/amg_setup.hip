@@ -41,9 +41,13 @@ inline c64 get(const HostCsr& m, int64_t i, int64_t j) {                        
   return c64{0.0, 0.0};
 }
 
-// CsrMatrix::matmul (csr.rs:594-651): the rows are independent, blocks of rows run on host threads
-void matmul_rows(const HostCsr& a, const HostCsr& b, int64_t i0, int64_t i1, std::vector<Trip>& trip) {
+// CsrMatrix::matmul (csr.rs:594-651): the rows are independent, blocks of rows run on host threads. Every row is formed as the
+// reference forms it (products in storage order, stable sort by column, sums in that order, norm <= 1e-15 dropped); its from_triplets
+// pass over the rows' triplets -- already in (row, column) order with one entry per position -- is the concatenation done here.
+struct RowBlock { std::vector<int64_t> cnt, col; std::vector<c64> val; };
+void matmul_rows(const HostCsr& a, const HostCsr& b, int64_t i0, int64_t i1, RowBlock& out) {
   std::vector<std::pair<int64_t, c64>> rd;
+  out.cnt.assign((size_t)(i1 - i0), 0);
   for (int64_t i = i0; i < i1; ++i) {
     rd.clear();
     for (int64_t p = a.ptr[(size_t)i]; p < a.ptr[(size_t)i + 1]; ++p) {
@@ -52,46 +56,78 @@ void matmul_rows(const HostCsr& a, const HostCsr& b, int64_t i0, int64_t i1, std
     }
     if (rd.empty()) continue;
     std::stable_sort(rd.begin(), rd.end(), [](const std::pair<int64_t, c64>& x, const std::pair<int64_t, c64>& y) { return x.first < y.first; });
+    const size_t before = out.col.size();
     int64_t cj = rd[0].first; c64 cv = rd[0].second;
     for (size_t e = 1; e < rd.size(); ++e) {
       if (rd[e].first == cj) cv = cadd(cv, rd[e].second);
-      else { if (cnorm(cv) > 1e-15) trip.push_back({i, cj, cv}); cj = rd[e].first; cv = rd[e].second; }
+      else { if (cnorm(cv) > 1e-15) { out.col.push_back(cj); out.val.push_back(cv); } cj = rd[e].first; cv = rd[e].second; }
     }
-    if (cnorm(cv) > 1e-15) trip.push_back({i, cj, cv});
+    if (cnorm(cv) > 1e-15) { out.col.push_back(cj); out.val.push_back(cv); }
+    out.cnt[(size_t)(i - i0)] = (int64_t)(out.col.size() - before);
   }
 }
 HostCsr matmul(const HostCsr& a, const HostCsr& b) {
-  if (a.nr == 0 || b.nc == 0 || a.val.empty() || b.val.empty()) { HostCsr m; m.nr = a.nr; m.nc = b.nc; m.ptr.assign((size_t)a.nr + 1, 0); return m; }
+  HostCsr m; m.nr = a.nr; m.nc = b.nc; m.ptr.assign((size_t)a.nr + 1, 0);
+  if (a.nr == 0 || b.nc == 0 || a.val.empty() || b.val.empty()) return m;
   const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, a.nr / 4096));
-  std::vector<std::vector<Trip>> parts((size_t)T);
+  std::vector<RowBlock> parts((size_t)T);
   if (T == 1) matmul_rows(a, b, 0, a.nr, parts[0]);
   else {
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { matmul_rows(a, b, a.nr * t / T, a.nr * (t + 1) / T, parts[(size_t)t]); });
     for (auto& x : th) x.join();
   }
-  size_t total = 0; for (const auto& v : parts) total += v.size();
-  std::vector<Trip> trip; trip.reserve(total);
-  for (auto& v : parts) { trip.insert(trip.end(), v.begin(), v.end()); std::vector<Trip>().swap(v); }
-  return from_triplets(a.nr, b.nc, trip);
+  std::vector<int64_t> base((size_t)T + 1, 0);
+  for (int t = 0; t < T; ++t) {
+    const int64_t i0 = a.nr * t / T;
+    for (size_t r = 0; r < parts[(size_t)t].cnt.size(); ++r) m.ptr[(size_t)i0 + r + 1] = parts[(size_t)t].cnt[r];
+    base[(size_t)t + 1] = base[(size_t)t] + (int64_t)parts[(size_t)t].col.size();
+  }
+  for (int64_t i = 0; i < a.nr; ++i) m.ptr[(size_t)i + 1] += m.ptr[(size_t)i];
+  m.col.resize((size_t)base[(size_t)T]); m.val.resize((size_t)base[(size_t)T]);
+  auto place = [&](int t) {
+    std::copy(parts[(size_t)t].col.begin(), parts[(size_t)t].col.end(), m.col.begin() + base[(size_t)t]);
+    std::copy(parts[(size_t)t].val.begin(), parts[(size_t)t].val.end(), m.val.begin() + base[(size_t)t]);
+  };
+  if (T == 1) place(0);
+  else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(place, t); for (auto& x : th) x.join(); }
+  return m;
 }
 
 HostCsr transpose(const HostCsr& m) {                                                       // amg.rs:810-822
-  std::vector<Trip> t; t.reserve(m.val.size());
-  for (int64_t i = 0; i < m.nr; ++i) for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) t.push_back({m.col[(size_t)q], i, m.val[(size_t)q]});
-  return from_triplets(m.nc, m.nr, t);
+  // from_triplets over (j, i, v) sorts by (j, i): with one entry per position -- what from_triplets itself hands over -- that is a
+  // counting transpose, row j filled in ascending i
+  HostCsr t; t.nr = m.nc; t.nc = m.nr; t.ptr.assign((size_t)m.nc + 1, 0); t.col.resize(m.val.size()); t.val.resize(m.val.size());
+  for (int64_t c : m.col) t.ptr[(size_t)c + 1] += 1;
+  for (int64_t j = 0; j < m.nc; ++j) t.ptr[(size_t)j + 1] += t.ptr[(size_t)j];
+  std::vector<int64_t> cur(t.ptr.begin(), t.ptr.end() - 1);
+  for (int64_t i = 0; i < m.nr; ++i)
+    for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) { const int64_t pos = cur[(size_t)m.col[(size_t)q]]++; t.col[(size_t)pos] = i; t.val[(size_t)pos] = m.val[(size_t)q]; }
+  return t;
 }
 
 // compute_strength_matrix (amg.rs:418-474), as CSR of column indices
 void strength(const HostCsr& m, double theta, std::vector<int64_t>& sp, std::vector<int64_t>& sj) {
-  sp.assign((size_t)m.nr + 1, 0); sj.clear();
-  for (int64_t i = 0; i < m.nr; ++i) {
-    double mx = 0.0;
-    for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) if (m.col[(size_t)q] != i) { const double nv = cnorm(m.val[(size_t)q]); if (nv > mx) mx = nv; }
-    const double thr = theta * mx;
-    for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) if (m.col[(size_t)q] != i && cnorm(m.val[(size_t)q]) >= thr) sj.push_back(m.col[(size_t)q]);
-    sp[(size_t)i + 1] = (int64_t)sj.size();
-  }
+  sp.assign((size_t)m.nr + 1, 0);
+  std::vector<char> strong(m.val.size(), 0);                 // per entry, rows on host threads; the lists are then read off in row order
+  host_parallel_for(m.nr, 8192, [&](long long r0, long long r1) {
+    for (int64_t i = r0; i < r1; ++i) {
+      double mx = 0.0;
+      for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) if (m.col[(size_t)q] != i) { const double nv = cnorm(m.val[(size_t)q]); if (nv > mx) mx = nv; }
+      const double thr = theta * mx;
+      int64_t cnt = 0;
+      for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) if (m.col[(size_t)q] != i && cnorm(m.val[(size_t)q]) >= thr) { strong[(size_t)q] = 1; ++cnt; }
+      sp[(size_t)i + 1] = cnt;
+    }
+  });
+  for (int64_t i = 0; i < m.nr; ++i) sp[(size_t)i + 1] += sp[(size_t)i];
+  sj.resize((size_t)sp[(size_t)m.nr]);
+  host_parallel_for(m.nr, 8192, [&](long long r0, long long r1) {
+    for (int64_t i = r0; i < r1; ++i) {
+      int64_t o = sp[(size_t)i];
+      for (int64_t q = m.ptr[(size_t)i]; q < m.ptr[(size_t)i + 1]; ++q) if (strong[(size_t)q]) sj[(size_t)o++] = m.col[(size_t)q];
+    }
+  });
 }
 
 enum : char { UNDECIDED = 0, COARSE = 1, FINE = 2 };
@@ -145,11 +181,14 @@ HostCsr build_interpolation(const HostCsr& m, const std::vector<int64_t>& sp, co
   const int64_t nf = m.nr;
   std::vector<int64_t> f2c((size_t)nf, -1);
   for (size_t c = 0; c < c2f.size(); ++c) f2c[(size_t)c2f[c]] = (int64_t)c;
-  std::vector<Trip> trip;
+  auto by_norm_desc = [](const std::pair<int64_t, c64>& a, const std::pair<int64_t, c64>& b) { return cnorm(a.second) > cnorm(b.second); };
+  // the rows are independent: blocks of rows on host threads, their triplets joined in row order
+  const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, nf / 8192));
+  std::vector<std::vector<Trip>> parts((size_t)T);
+  auto rows = [&](int64_t r0, int64_t r1, std::vector<Trip>& trip) {
   std::vector<int64_t> cn;
   std::vector<std::pair<int64_t, c64>> wts;
-  auto by_norm_desc = [](const std::pair<int64_t, c64>& a, const std::pair<int64_t, c64>& b) { return cnorm(a.second) > cnorm(b.second); };
-  for (int64_t i = 0; i < nf; ++i) {
+  for (int64_t i = r0; i < r1; ++i) {
     if (pt[(size_t)i] == COARSE) { trip.push_back({i, f2c[(size_t)i], c64{1.0, 0.0}}); continue; }
     if (pt[(size_t)i] != FINE) continue;
     const c64 aii = get(m, i, i);
@@ -206,6 +245,15 @@ HostCsr build_interpolation(const HostCsr& m, const std::vector<int64_t>& sp, co
     }
     for (const auto& e : wts) trip.push_back({i, e.first, e.second});
   }
+  };
+  if (T == 1) rows(0, nf, parts[0]);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { rows(nf * t / T, nf * (t + 1) / T, parts[(size_t)t]); });
+    for (auto& x : th) x.join();
+  }
+  std::vector<Trip> trip;
+  for (auto& v : parts) { trip.insert(trip.end(), v.begin(), v.end()); std::vector<Trip>().swap(v); }
   return from_triplets(nf, (int64_t)c2f.size(), trip);
 }
 
@@ -214,7 +262,7 @@ HostCsr build_interpolation(const HostCsr& m, const std::vector<int64_t>& sp, co
 int amg_setup_host(const HostCsr& A, const ma_amg_config_t& cfg, std::vector<HostCsr>& As, std::vector<HostCsr>& Ps, std::vector<HostCsr>& Rs,
                    double* grid_complexity, double* operator_complexity) {
   As.clear(); Ps.clear(); Rs.clear();
-  As.push_back(A);
+  As.push_back(A);   // (the caller's copy; level 0 is not uploaded again)
   std::vector<int64_t> sp, sj, c2f;
   std::vector<char> pt;
   const bool timing = getenv("MA_AMG_TIMING") != nullptr;

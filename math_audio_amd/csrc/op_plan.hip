@@ -648,11 +648,13 @@ int ma_precond_create_amg_from_csr(ma_csr_t* A, const ma_amg_config_t* cfg, ma_p
   rc = ma_csr_device(A, &dev); if (rc) return rc;
   MA_REQUIRE(nc == n && n > 0, MA_ERR_INVALID, "AMG needs a square, non-empty operator");
   HostCsr H; H.nr = n; H.nc = n; H.ptr.resize((size_t)n + 1); H.col.resize((size_t)nnz); H.val.resize((size_t)nnz);
-  { std::vector<int64_t> col((size_t)std::max<int64_t>(nnz, 1)); std::vector<ma_c64> v((size_t)std::max<int64_t>(nnz, 1));
-    rc = ma_csr_get(A, H.ptr.data(), col.data(), v.data()); if (rc) return rc;
-    for (int64_t q = 0; q < nnz; ++q) { H.col[(size_t)q] = col[(size_t)q]; H.val[(size_t)q] = c64{v[(size_t)q].re, v[(size_t)q].im}; } }
+  H.col.resize((size_t)std::max<int64_t>(nnz, 1)); H.val.resize((size_t)std::max<int64_t>(nnz, 1));
+  rc = ma_csr_get(A, H.ptr.data(), H.col.data(), reinterpret_cast<ma_c64*>(H.val.data())); if (rc) return rc;      // c64 and ma_c64 share their layout (ma_common.hpp)
+  H.col.resize((size_t)nnz); H.val.resize((size_t)nnz);
+  const auto t1 = std::chrono::steady_clock::now();
   std::vector<HostCsr> As, Ps, Rs; double gc = 1.0, oc = 1.0;
   rc = amg_setup_host(H, *cfg, As, Ps, Rs, &gc, &oc); if (rc) return rc;
+  const auto t2 = std::chrono::steady_clock::now();
   const size_t L = As.size();
   std::vector<ma_csr*> hA(L, nullptr), hP(L, nullptr), hR(L, nullptr), owned;
   hA[0] = A;
@@ -674,6 +676,8 @@ int ma_precond_create_amg_from_csr(ma_csr_t* A, const ma_amg_config_t* cfg, ma_p
   if (rc) { for (ma_csr* h : owned) (void)ma_csr_destroy(h); return rc; }
   M->amg_owned = owned; M->amg_gc = gc; M->amg_oc = oc;
   M->amg_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("MA_AMG_TIMING")) fprintf(stderr, "[amg setup] read back %.0f, hierarchy %.0f, uploads + level vectors %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                                       std::chrono::duration<double, std::milli>(t2 - t1).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
   *out = M; return MA_OK;
 }
 int ma_precond_amg_info(ma_precond_t* M, int32_t* num_levels, double* grid_complexity, double* operator_complexity, double* setup_time_ms) {
