@@ -321,6 +321,75 @@ __global__ __launch_bounds__(256) void csr_gs_persistent_kernel(CsrView A, const
     __syncthreads();
   }
 }
+// The same sweep with the device-wide barrier replaced by one flag per row: done[i] = the sweep's number once row i has its new value.
+// A row waits only for the rows it reads new values from (the earlier rows among its entries), so different parts of the matrix
+// run through their levels at their own pace and a hop costs one flag round trip instead of a barrier of every workgroup. The
+// rows come in level order, every level padded to whole wavefronts (four 16-lane row groups) so that no wavefront holds a row
+// together with one that waits for it; the grid is co-resident (one workgroup per CU), so the lowest unfinished level can always
+// run. Arithmetic per row as in csr_gs_level_kernel: bit-identical results. Only for patterns where "row i reads an old x_j"
+// implies "row j reads x_i" (structurally symmetric, or triangular factors): the caller checks. Every wait is bounded (2 s) and an
+// abandoned wait raises err[1], after which nobody waits any more.
+template <bool KM, int MODE>
+__global__ __launch_bounds__(256) void csr_gs_flags_kernel(CsrView A, const int* __restrict__ rows, long long npad, dc* x, const dc* __restrict__ b,
+                                                           unsigned* done, unsigned epoch, int backward, unsigned* err) {
+  constexpr int G = 16;
+  const int lg = threadIdx.x & (G - 1);
+  const long long group0 = ((long long)blockIdx.x * 256 + threadIdx.x) / G, ngroups = (long long)gridDim.x * (256 / G);
+  bool dead = false;
+  for (long long t = group0; t < npad; t += ngroups) {
+    const int i = rows[t];
+    double sr = 0.0, si = 0.0, dr = 0.0, di = 0.0, have = 0.0;
+    if (i >= 0) {
+      const long long beg = A.row_ptr[i], end = A.row_ptr[i + 1];
+      for (long long idx = beg + lg; idx < end; idx += G) {
+        double ar, ai;
+        if (KM) { const double kv = A.K[idx], mv = A.M[idx]; ar = kv - A.k2_re * mv; ai = -(A.k2_im * mv); }
+        else { const dc v = A.val[idx]; ar = v.re; ai = v.im; }
+        const int j = A.col[idx];
+        if (j == i) { dr += ar; di += ai; have = 1.0; continue; }
+        if ((backward ? j > i : j < i) && !dead) {
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          unsigned spins = 0;
+          // relaxed polls: an agent-scope ACQUIRE would invalidate the L2 at every poll (measured: 19 ms per sweep); the value read
+          // after the flag is itself a device-coherent load issued after the flag's value is known
+          while (__hip_atomic_load(done + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u) {
+              if (__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
+              if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; break; }
+            }
+          }
+        }
+        const dc xv = ld_coherent(x + j);
+        sr += ar * xv.re - ai * xv.im; si += ar * xv.im + ai * xv.re;
+      }
+    }
+    sr = group_sum<G>(sr); si = group_sum<G>(si); dr = group_sum<G>(dr); di = group_sum<G>(di); have = group_sum<G>(have);
+    if (lg != 0 || i < 0) continue;
+    if (MODE == 1 && have == 0.0) { dr = 1.0; di = 0.0; }
+    const double nd = hypot(dr, di);
+    if (!(MODE == 1 ? !(nd > 1e-15) : (nd < 1e-15))) {
+      const dc bb = b[i];
+      const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
+      if (MODE == 1) { const double ir = dr / ns, ii = -di / ns; st_coherent(x + i, dc_make(nr * ir - ni * ii, nr * ii + ni * ir)); }
+      else st_coherent(x + i, dc_make((nr * dr + ni * di) / ns, (ni * dr - nr * di) / ns));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    // the row's value has reached the coherence point (a RELEASE store would write the whole L2 back)
+    __hip_atomic_store(done + i, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // a skipped row is done too
+  }
+}
+int csr_launch_gs_flags(const CsrView& A, bool km, int mode, const int* rows_padded, long long npad, int grid, c64* x, const c64* b, unsigned* done, unsigned epoch,
+                        int backward, unsigned* err, hipStream_t st) {
+  if (npad <= 0) return MA_OK;
+  dc* xx = reinterpret_cast<dc*>(x); const dc* bb = reinterpret_cast<const dc*>(b);
+  dim3 g((unsigned)grid), block(256);
+  if (km) { if (mode) hipLaunchKernelGGL((csr_gs_flags_kernel<true, 1>), g, block, 0, st, A, rows_padded, npad, xx, bb, done, epoch, backward, err);
+            else hipLaunchKernelGGL((csr_gs_flags_kernel<true, 0>), g, block, 0, st, A, rows_padded, npad, xx, bb, done, epoch, backward, err); }
+  else { if (mode) hipLaunchKernelGGL((csr_gs_flags_kernel<false, 1>), g, block, 0, st, A, rows_padded, npad, xx, bb, done, epoch, backward, err);
+         else hipLaunchKernelGGL((csr_gs_flags_kernel<false, 0>), g, block, 0, st, A, rows_padded, npad, xx, bb, done, epoch, backward, err); }
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
 // returns the number of barrier arrivals the launch adds to bar[0] (the caller keeps the running total for `base`)
 int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* rows, const long long* lev_ptr, int nlev, int grid, c64* x, const c64* b,
                              unsigned* bar, unsigned base, unsigned gbase, hipStream_t st) {

@@ -290,9 +290,11 @@ def test_full_size_fem_box(gpu):
 
 
 def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
-    """The persistent sweep (one launch, a device-wide barrier per dependency level) against a launch per level: the same rows, the
-    same 16-lane reduction, so the iterates must agree bit for bit -- forward, backward, both modes, the fused K - k^2 M operator
-    and stored complex values, on a box with 46 levels and on an unsymmetric random pattern."""
+    """The three schedules of a sweep -- one persistent launch with a flag per row (the default where the pattern is structurally
+    symmetric or triangular), one persistent launch with a device-wide barrier per level, a launch per level -- handle the same rows
+    with the same 16-lane reduction, so the iterates must agree bit for bit: forward, backward, both modes, the fused K - k^2 M
+    operator and stored complex values, on a box with 46 levels; on an unsymmetric random pattern the flag schedule must step aside
+    (a row there may overwrite a value an earlier row still has to read) and the results still agree."""
     def _xvec(m):
         i = np.arange(m)
         return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
@@ -301,8 +303,9 @@ def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
     b = _xvec(n); x0 = 0.3 * _xvec(n)[::-1].copy()
     k = 1.3 + 0.2j
     outs = {}
-    for pers in ("1", "0"):
-        monkeypatch.setenv("MA_CSR_GS_PERSISTENT", pers)
+    for pers in ("1", "0", "flags"):
+        monkeypatch.setenv("MA_CSR_GS_PERSISTENT", "1" if pers == "1" else "0")
+        monkeypatch.setenv("MA_CSR_GS_FLAGS", "1" if pers == "flags" else "0")
         h = ma.CsrOperator(rp, ci, K=K, M=M); h.set_wavenumber(k)
         fwd, bwd = h.gauss_seidel_levels()
         assert fwd >= 8 and bwd >= 8
@@ -312,8 +315,8 @@ def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
         x3 = hc.fem_smooth(x0, b, kind=2, iterations=1)
         outs[pers] = (x1, x2, x3)
         h.close(); hc.close()
-    for a, c in zip(outs["1"], outs["0"]):
-        assert np.array_equal(a, c)
+    for a, c, f in zip(outs["1"], outs["0"], outs["flags"]):
+        assert np.array_equal(a, c) and np.array_equal(f, c)
     vals = O.helmholtz_values(K, M, k)
     ref = O.amg_sym_gauss_seidel(rp, ci, vals, x0, b, 2)
     assert np.abs(outs["1"][0] - ref).max() <= 1e-12 * np.abs(ref).max()
@@ -323,11 +326,12 @@ def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
     R.data = rng.standard_normal(R.nnz) + 1j * rng.standard_normal(R.nnz)
     R = (R + sp.diags(8.0 + rng.standard_normal(700))).tocsr(); R.sort_indices()
     bb = _xvec(700); res = {}
-    for pers in ("1", "0"):
-        monkeypatch.setenv("MA_CSR_GS_PERSISTENT", pers)
+    for pers in ("1", "0", "flags"):
+        monkeypatch.setenv("MA_CSR_GS_PERSISTENT", "1" if pers == "1" else "0")
+        monkeypatch.setenv("MA_CSR_GS_FLAGS", "1" if pers == "flags" else "0")
         h = ma.CsrOperator(R.indptr, R.indices, values=R.data)
         res[pers] = h.sym_gauss_seidel(np.zeros(700, dtype=complex), bb, 3)
         h.close()
-    assert np.array_equal(res["1"], res["0"])
+    assert np.array_equal(res["1"], res["0"]) and np.array_equal(res["flags"], res["0"])
     refu = O.amg_sym_gauss_seidel(R.indptr, R.indices, R.data, np.zeros(700, dtype=complex), bb, 3)
     assert np.abs(res["1"] - refu).max() <= 1e-12 * np.abs(refu).max()
