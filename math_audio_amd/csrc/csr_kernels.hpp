@@ -31,8 +31,8 @@ int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x,
 int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* rows, const long long* lev_ptr, int nlev, int grid, c64* x, const c64* b,
                              unsigned* bar, unsigned base, unsigned gbase, hipStream_t st);
 int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, int count, c64* x, const c64* b, hipStream_t st);
-int csr_launch_gs_flags(const CsrView& A, bool km, int mode, const int* rows_padded, long long npad, int grid, c64* x, const c64* b, unsigned* done, unsigned epoch,
-                        int backward, unsigned* err, hipStream_t st);
+int csr_launch_gs_flags(const CsrView& A, bool km, int mode, const int* rows_padded, long long npad, int grid, c64* x, c64* xn, const c64* b, int backward, unsigned* err,
+                        hipStream_t st);
 int csr_launch_diag(const CsrView& A, bool km, c64* dinv, double* l1, hipStream_t st);
 int csr_launch_assemble(long long nnz, const double* K, const double* M, double k2re, double k2im, int nb, const double* const* B, const double* cre, const double* cim,
                         c64* val, long long sell_tot, const int* sell_src, c64* sell_val, hipStream_t st);

@@ -36,9 +36,8 @@ struct ma_csr {
   // persistent sweep: the level offsets on the device, the barrier words {arrivals, error} and the arrivals issued so far
   long long* d_lev_ptr[2] = {nullptr, nullptr};
   unsigned* d_gs_bar = nullptr; unsigned gs_bar_count = 0, gs_grp_count = 0; int gs_grid = 0;
-  // flag-driven sweep: the rows in level order with every level padded to whole wavefronts (-1), one flag per row, the sweeps issued so far;
-  // usable in a direction when every old value a row reads belongs to a row that reads it back (structurally symmetric or triangular)
-  int* d_lev_rows_pad[2] = {nullptr, nullptr}; long long lev_npad[2] = {0, 0}; unsigned* d_gs_done = nullptr; unsigned gs_sweeps = 0; bool gs_flags_ok[2] = {false, false};
+  // value-as-flag sweep: the rows in level order with every level padded to whole wavefronts (-1), the second iterate array
+  int* d_lev_rows_pad[2] = {nullptr, nullptr}; long long lev_npad[2] = {0, 0}; c64* d_gs_xn = nullptr;
   CsrView view() const {
     CsrView v{};
     v.n = n; v.nnz = nnz; v.row_ptr = d_rowptr; v.col = d_col; v.val = reinterpret_cast<const dc*>(d_val); v.K = d_K; v.M = d_M;
@@ -67,7 +66,7 @@ void free_all(ma_csr* h) {
   for (long long* r : h->d_lev_ptr) if (r) (void)hipFree(r);
   if (h->d_gs_bar) (void)hipFree(h->d_gs_bar);
   for (int d = 0; d < 2; ++d) if (h->d_lev_rows_pad[d]) (void)hipFree(h->d_lev_rows_pad[d]);
-  if (h->d_gs_done) (void)hipFree(h->d_gs_done);
+  if (h->d_gs_xn) (void)hipFree(h->d_gs_xn);
   for (void* q : p) if (q) (void)hipFree(q);
 }
 int create_common(int64_t n, const int64_t* rowptr, const int64_t* col, int device, ma_csr** out, int64_t ncols = -1) {
@@ -535,23 +534,8 @@ static int build_levels(ma_csr* h) {
       MA_HIP(hipMalloc(&h->d_lev_rows_pad[dir], sizeof(int) * padded.size()));
       MA_HIP(hipMemcpy(h->d_lev_rows_pad[dir], padded.data(), sizeof(int) * padded.size(), hipMemcpyHostToDevice));
     }
-    // usable when every later row j that row i reads (an old value) stores (j, i) too: then j waits for i by its own entries
-    bool ok = true;
-    {
-      std::vector<int> sorted(col.begin(), col.begin() + (nnz > 0 ? nnz : 0));
-      for (long long i = 0; i < n; ++i) std::sort(sorted.begin() + rp[(size_t)i], sorted.begin() + rp[(size_t)i + 1]);
-      for (long long i = 0; i < n && ok; ++i)
-        for (long long idx = rp[(size_t)i]; idx < rp[(size_t)i + 1] && ok; ++idx) {
-          const long long j = col[(size_t)idx];
-          if (j < 0 || j >= n || j == i) continue;
-          const bool later = dir == 0 ? j > i : j < i;
-          if (later && !std::binary_search(sorted.begin() + rp[(size_t)j], sorted.begin() + rp[(size_t)j + 1], (int)i)) ok = false;
-        }
-    }
-    h->gs_flags_ok[dir] = ok;
   }
-  MA_HIP(hipMalloc(&h->d_gs_done, sizeof(unsigned) * (size_t)std::max<long long>(n, 1)));
-  MA_HIP(hipMemset(h->d_gs_done, 0, sizeof(unsigned) * (size_t)std::max<long long>(n, 1)));
+  MA_HIP(hipMalloc(&h->d_gs_xn, sizeof(c64) * (size_t)std::max<long long>(n, 1)));
   MA_HIP(hipMalloc(&h->d_gs_bar, 32 * 9 * sizeof(unsigned)));          // [0] arrivals of groups, [1] error, [32 (1 + g)] members of group g
   MA_HIP(hipMemset(h->d_gs_bar, 0, 32 * 9 * sizeof(unsigned)));
   MA_HIP(hipStreamSynchronize(nullptr));                  // (null-stream memset vs. non-blocking caller streams)
@@ -579,17 +563,13 @@ int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int m
   const char* epers = getenv("MA_CSR_GS_PERSISTENT");
   const bool persistent = epers && atoi(epers) != 0;
   const int nlev = (int)lp.size() - 1;
-  // Default where the pattern allows it (structurally symmetric, or a triangular factor): ONE persistent launch in which a row waits for
-  // the flags of the rows it reads new values from (csr_gs_flags_kernel). 10^6-DoF box, 298 levels per direction: 2.23 ms per symmetric
-  // sweep and 2.10 ms per ILU(0) apply against 2.95 / 2.97 ms for a launch per level (3.7 us per level hop against 4.9 us per
-  // dependent launch), bit-identical results (tools/gs_sweep_modes.py). MA_CSR_GS_FLAGS=0: the launches.
+  // Default: ONE persistent launch in which the new iterate goes to a second array that starts as a sentinel and a row polls the new
+  // values it needs until they have left the sentinel (csr_gs_flags_kernel). Bit-identical to the launches (tools/gs_sweep_modes.py).
+  // MA_CSR_GS_FLAGS=0: a launch per level.
   const char* eflags = getenv("MA_CSR_GS_FLAGS");
-  if (!(eflags && atoi(eflags) == 0) && !persistent && nlev >= 8 && h->gs_flags_ok[dir] && h->d_lev_rows_pad[dir]) {
-    h->gs_sweeps += 1;
-    if (h->gs_sweeps == 0) { MA_HIP(hipMemsetAsync(h->d_gs_done, 0, sizeof(unsigned) * (size_t)h->n, (hipStream_t)stream)); h->gs_sweeps = 1; }   // the counter came round
-    return csr_launch_gs_flags(v, h->fused_km(), mode, h->d_lev_rows_pad[dir], h->lev_npad[dir], h->gs_grid, (c64*)d_x, (const c64*)d_b, h->d_gs_done, h->gs_sweeps,
-                               backward ? 1 : 0, h->d_gs_bar, (hipStream_t)stream);
-  }
+  if (!(eflags && atoi(eflags) == 0) && !persistent && nlev >= 8 && h->d_lev_rows_pad[dir] && h->d_gs_xn)
+    return csr_launch_gs_flags(v, h->fused_km(), mode, h->d_lev_rows_pad[dir], h->lev_npad[dir], h->gs_grid, (c64*)d_x, h->d_gs_xn, (const c64*)d_b, backward ? 1 : 0,
+                               h->d_gs_bar, (hipStream_t)stream);
   if (persistent && nlev >= 8) {
     rc = csr_launch_gs_persistent(v, h->fused_km(), mode, h->d_lev_rows[dir], h->d_lev_ptr[dir], nlev, h->gs_grid, (c64*)d_x, (const c64*)d_b, h->d_gs_bar,
                                   h->gs_bar_count, h->gs_grp_count, (hipStream_t)stream);
