@@ -290,11 +290,10 @@ def test_full_size_fem_box(gpu):
 
 
 def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
-    """The three schedules of a sweep -- one persistent launch with a flag per row (the default where the pattern is structurally
-    symmetric or triangular), one persistent launch with a device-wide barrier per level, a launch per level -- handle the same rows
-    with the same 16-lane reduction, so the iterates must agree bit for bit: forward, backward, both modes, the fused K - k^2 M
-    operator and stored complex values, on a box with 46 levels; on an unsymmetric random pattern the flag schedule must step aside
-    (a row there may overwrite a value an earlier row still has to read) and the results still agree."""
+    """The three schedules of a sweep -- one persistent launch in which the new value is its own flag (the default), one persistent
+    launch with a device-wide barrier per level, a launch per level -- handle the same rows with the same 16-lane reduction, so the
+    iterates must agree bit for bit: forward, backward, both modes, the fused K - k^2 M operator and stored complex values, on a box
+    with 46 levels and on an unsymmetric random pattern."""
     def _xvec(m):
         i = np.arange(m)
         return np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
