@@ -334,3 +334,23 @@ def test_persistent_gauss_seidel_sweep_is_the_level_launches(gpu, monkeypatch):
     assert np.array_equal(res["1"], res["0"]) and np.array_equal(res["flags"], res["0"])
     refu = O.amg_sym_gauss_seidel(R.indptr, R.indices, R.data, np.zeros(700, dtype=complex), bb, 3)
     assert np.abs(res["1"] - refu).max() <= 1e-12 * np.abs(refu).max()
+
+
+def test_sweep_survives_the_sentinel_pattern_in_its_input(gpu):
+    """The default sweep marks "not there yet" with a NaN payload (0x7FFC0DE0DEADBEEF). Inputs that carry that very pattern -- or any
+    NaN -- must come out as NaNs where they propagate, not leave a row waiting: the writer never stores the sentinel itself."""
+    nodes, rp, ci, K, M = fem.helmholtz_box(10, 9, 8)
+    n = len(rp) - 1
+    h = ma.CsrOperator(rp, ci, K=K, M=M); h.set_wavenumber(1.1 + 0.1j)
+    assert min(h.gauss_seidel_levels()) >= 8
+    sentinel = np.frombuffer(np.array([0x7FFC0DE0DEADBEEF], dtype=np.uint64).tobytes(), dtype=np.float64)[0]
+    i = np.arange(n)
+    b = (np.sin(0.2 * i) + 1j * np.cos(0.1 * i)).astype(np.complex128)
+    x0 = (np.sin(0.1 * i) + 1j * np.cos(0.2 * i)).astype(np.complex128)
+    x0[5] = complex(sentinel, 1.0); x0[n // 2] = complex(2.0, sentinel); b[n - 3] = complex(sentinel, sentinel); b[7] = complex(np.nan, 0.0)
+    x = h.sym_gauss_seidel(x0, b, 2)
+    assert x.shape == (n,) and np.isnan(x).any()
+    ma.check(ma.lib().ma_csr_status(h.h))                    # no wait was abandoned
+    clean = h.sym_gauss_seidel(np.nan_to_num(x0, nan=0.5), np.nan_to_num(b, nan=0.25), 1)
+    assert np.isfinite(clean).all()
+    h.close()
