@@ -365,11 +365,180 @@ int op_launch_zgemv(long long n, const c64* A, const c64* x, c64* y, hipStream_t
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
+// One modified Gram-Schmidt step of GMRES (gmres.rs:178-196 / :344-362) as ONE launch: for i = 0..j: h_i = <v_i, w>, w -= h_i v_i;
+// then |w|. The separate kernels (two per inner product, one per update: 3 (j + 1) + 2 dependent launches per Krylov step) were
+// what a step cost on the sparse side. Here the workgroups keep their elements of w in registers, every inner product is reduced
+// exactly as dot_partial_kernel + dot_final_kernel reduce it (same element-to-thread map, same trees: bit-identical h_i), and
+// the workgroups exchange their partial sums through slots that start as a sentinel and are polled until both words have left it
+// (the value is its own flag, as in csr_gs_flags_kernel). Grid = the dot kernels' grid (<= 256 workgroups, one per CU:
+// co-resident); every wait is bounded (2 s) and an abandoned wait raises err[0], after which nobody waits.
+constexpr unsigned long long MGS_SENTINEL = 0x7FFC0DE0DEADBEEFull;
+constexpr int MGS_EMAX = 32;                                   // elements of w per thread (n <= 2^21 with 256 x 256 threads)
+__device__ __forceinline__ unsigned long long mgs_word(double v) {
+  const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+  return w == MGS_SENTINEL ? (w ^ 1ull) : w;
+}
+__global__ __launch_bounds__(256) void mgs_fill_kernel(long long nwords, unsigned long long* __restrict__ p) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < nwords) p[i] = MGS_SENTINEL;
+}
+template <int E>
+__global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* __restrict__ V, int j, dc* __restrict__ w, unsigned long long* slots /* (j + 2) x gridDim.x x 2 */,
+                                                        dc* __restrict__ scal_out /* h_0..h_j, then (|w|, 0) */, unsigned* err) {
+  __shared__ double sr[4], si[4], hb[2];
+  const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long long stride = (long long)nb * 256, i0 = (long long)b * 256 + tid;
+  dc wv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { const long long idx = i0 + e * stride; wv[e] = idx < n ? w[idx] : dc_make(0.0, 0.0); }
+  bool dead = false;
+  for (int step = 0; step <= j + 1; ++step) {
+    const bool last = step == j + 1;
+    const dc* v = V + (long long)step * n;
+    double ar = 0.0, ai = 0.0;
+    dc vv[E];
+    if (!last) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const long long idx = i0 + e * stride;
+        if (idx < n) { const dc a = v[idx]; vv[e] = a; const dc bb = wv[e]; ar += a.re * bb.re + a.im * bb.im; ai += a.re * bb.im - a.im * bb.re; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const long long idx = i0 + e * stride; if (idx < n) { const dc a = wv[e]; ar += a.re * a.re + a.im * a.im; } }
+    }
+    ar = wave_sum(ar); ai = wave_sum(ai);
+    if (lane == 0) { sr[wave] = ar; si[wave] = ai; }
+    __syncthreads();
+    unsigned long long* row = slots + (long long)step * nb * 2;
+    if (tid == 0) {
+      __hip_atomic_store(row + 2 * b, mgs_word((sr[0] + sr[1]) + (sr[2] + sr[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(row + 2 * b + 1, mgs_word((si[0] + si[1]) + (si[2] + si[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                            // sr / si are free again
+    // dot_final_kernel's reduction over the nb partial sums, done by every workgroup
+    double pr = 0.0, pi = 0.0;
+    if (tid < nb) {
+      unsigned long long wa = __hip_atomic_load(row + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), wb = __hip_atomic_load(row + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((wa == MGS_SENTINEL || wb == MGS_SENTINEL) && !dead) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        do {
+          __builtin_amdgcn_s_sleep(1);
+          wa = __hip_atomic_load(row + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wb = __hip_atomic_load(row + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((++spins & 1023u) == 0u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; break; }
+          }
+        } while (wa == MGS_SENTINEL || wb == MGS_SENTINEL);
+      }
+      pr += __longlong_as_double((long long)wa); pi += __longlong_as_double((long long)wb);
+    }
+    pr = wave_sum(pr); pi = wave_sum(pi);
+    if (lane == 0) { sr[wave] = pr; si[wave] = pi; }
+    __syncthreads();
+    if (tid == 0) {
+      const double r = (sr[0] + sr[1]) + (sr[2] + sr[3]), i2 = (si[0] + si[1]) + (si[2] + si[3]);
+      hb[0] = last ? __builtin_sqrt(r) : r; hb[1] = last ? 0.0 : i2;
+      if (b == 0) scal_out[step] = dc_make(hb[0], hb[1]);
+    }
+    __syncthreads();
+    if (!last) {                                                // w -= h v   (axpy_kernel with alpha = h, sgn = -1)
+      const double are = -1.0 * hb[0], aim = -1.0 * hb[1];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const long long idx = i0 + e * stride;
+        if (idx < n) { const dc xv = vv[e]; wv[e].re += are * xv.re - aim * xv.im; wv[e].im += are * xv.im + aim * xv.re; }
+      }
+    }
+    __syncthreads();                                            // hb is free again
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) { const long long idx = i0 + e * stride; if (idx < n) w[idx] = wv[e]; }
+}
+// returns MA_ERR_UNSUPPORTED when the vector is too long for the register-resident form (the caller then runs the separate kernels)
+int op_launch_gmres_mgs(long long n, const c64* V, int j, c64* w, void* slots, c64* scal_out, unsigned* err, hipStream_t st) {
+  int nb = (int)((n + 255) / 256); if (nb > RED_BLOCKS) nb = RED_BLOCKS; if (nb < 1) nb = 1;
+  const long long per = (n + (long long)nb * 256 - 1) / ((long long)nb * 256);
+  if (per > MGS_EMAX) return MA_ERR_UNSUPPORTED;
+  const long long nwords = (long long)(j + 2) * nb * 2;
+  hipLaunchKernelGGL(mgs_fill_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, nwords, reinterpret_cast<unsigned long long*>(slots));
+  const dc* Vd = reinterpret_cast<const dc*>(V); dc* wd = reinterpret_cast<dc*>(w); dc* sd = reinterpret_cast<dc*>(scal_out);
+  unsigned long long* sl = reinterpret_cast<unsigned long long*>(slots);
+  if (per <= 1) hipLaunchKernelGGL(gmres_mgs_kernel<1>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  else if (per <= 2) hipLaunchKernelGGL(gmres_mgs_kernel<2>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  else if (per <= 4) hipLaunchKernelGGL(gmres_mgs_kernel<4>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  else if (per <= 8) hipLaunchKernelGGL(gmres_mgs_kernel<8>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  else if (per <= 16) hipLaunchKernelGGL(gmres_mgs_kernel<16>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  else hipLaunchKernelGGL(gmres_mgs_kernel<32>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+int op_mgs_slot_bytes(int m) { return (int)sizeof(unsigned long long) * 2 * RED_BLOCKS * (m + 2); }
 int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st) {
   int nb = (int)((n + 255) / 256); if (nb > RED_BLOCKS) nb = RED_BLOCKS; if (nb < 1) nb = 1;
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, n, reinterpret_cast<const dc*>(x), reinterpret_cast<const dc*>(y), mode,
                      reinterpret_cast<dc*>(partial));
   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, nb, reinterpret_cast<const dc*>(partial), mode, reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+// `count` inner products <v_i, y> against one y (the classical Gram-Schmidt row of the pipelined GMRES) in two launches instead of
+// two per product: blockIdx.y selects the vector, every (vector, block) pair reduces exactly as dot_partial_kernel / dot_final_kernel
+// do, so each h_i is the separate kernels' bit for bit. partial: count x RED_BLOCKS entries.
+__global__ __launch_bounds__(256) void multi_dot_partial_kernel(long long n, const dc* __restrict__ V, const dc* __restrict__ y, dc* __restrict__ partial) {
+  __shared__ double sr[4], si[4];
+  const dc* x = V + (long long)blockIdx.y * n;
+  double ar = 0.0, ai = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const dc a = x[i]; const dc b = y[i];
+    ar += a.re * b.re + a.im * b.im; ai += a.re * b.im - a.im * b.re;
+  }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sr[wave] = ar; si[wave] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long long)blockIdx.y * RED_BLOCKS + blockIdx.x] = dc_make((sr[0] + sr[1]) + (sr[2] + sr[3]), (si[0] + si[1]) + (si[2] + si[3]));
+}
+__global__ __launch_bounds__(256) void multi_dot_final_kernel(int nb, const dc* __restrict__ partial, dc* __restrict__ out) {
+  __shared__ double sr[4], si[4];
+  const dc* p = partial + (long long)blockIdx.x * RED_BLOCKS;
+  double ar = 0.0, ai = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) { ar += p[i].re; ai += p[i].im; }
+  ar = wave_sum(ar); ai = wave_sum(ai);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sr[wave] = ar; si[wave] = ai; }
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = dc_make((sr[0] + sr[1]) + (sr[2] + sr[3]), (si[0] + si[1]) + (si[2] + si[3]));
+}
+int op_launch_multi_dot(long long n, const c64* V, int count, const c64* y, c64* partial /* count x 256 */, c64* out, hipStream_t st) {
+  if (count <= 0) return MA_OK;
+  int nb = (int)((n + 255) / 256); if (nb > RED_BLOCKS) nb = RED_BLOCKS; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(multi_dot_partial_kernel, dim3(nb, count), dim3(256), 0, st, n, reinterpret_cast<const dc*>(V), reinterpret_cast<const dc*>(y), reinterpret_cast<dc*>(partial));
+  hipLaunchKernelGGL(multi_dot_final_kernel, dim3(count), dim3(256), 0, st, nb, reinterpret_cast<const dc*>(partial), reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+// a -= sum_i h_i V_i and (when Z is given) b -= sum_i h_i Z_i, the updates applied in ascending i per element as the separate axpy
+// launches apply them (bit-identical), in one launch
+__global__ __launch_bounds__(256) void multi_axpy_kernel(long long n, int count, const dc* __restrict__ h, const dc* __restrict__ V, dc* __restrict__ a,
+                                                         const dc* __restrict__ Z, dc* __restrict__ b) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  dc av = a[idx], bv = Z ? b[idx] : dc_make(0.0, 0.0);
+  for (int i = 0; i < count; ++i) {
+    const double are = -1.0 * h[i].re, aim = -1.0 * h[i].im;
+    const dc xv = V[(long long)i * n + idx];
+    av.re += are * xv.re - aim * xv.im; av.im += are * xv.im + aim * xv.re;
+    if (Z) { const dc zv = Z[(long long)i * n + idx]; bv.re += are * zv.re - aim * zv.im; bv.im += are * zv.im + aim * zv.re; }
+  }
+  a[idx] = av;
+  if (Z) b[idx] = bv;
+}
+int op_launch_multi_axpy(long long n, int count, const c64* h_dev, const c64* V, c64* a, const c64* Z, c64* b, hipStream_t st) {
+  if (n <= 0 || count <= 0) return MA_OK;
+  hipLaunchKernelGGL(multi_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, count, reinterpret_cast<const dc*>(h_dev), reinterpret_cast<const dc*>(V),
+                     reinterpret_cast<dc*>(a), reinterpret_cast<const dc*>(Z), reinterpret_cast<dc*>(b));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

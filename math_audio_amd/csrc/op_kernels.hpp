@@ -15,6 +15,12 @@ int op_launch_cmul(long long n, const c64* a, const c64* x, c64* z, hipStream_t 
 // mode 0: out = conj(x).y ; mode 1: out = ||x||_2 (real part)
 int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st);
 int op_launch_axpy_dev(long long n, const c64* alpha_dev, double sgn, const c64* x, c64* y, hipStream_t st);
+// one modified Gram-Schmidt step (h_0..h_j, w updated, |w|) as one launch; MA_ERR_UNSUPPORTED when n is too long for it
+int op_launch_gmres_mgs(long long n, const c64* V, int j, c64* w, void* slots, c64* scal_out, unsigned* err, hipStream_t st);
+int op_mgs_slot_bytes(int m);
+// `count` inner products against one vector in two launches; a -= sum h_i V_i (and b -= sum h_i Z_i) in one
+int op_launch_multi_dot(long long n, const c64* V, int count, const c64* y, c64* partial /* count x 256 */, c64* out, hipStream_t st);
+int op_launch_multi_axpy(long long n, int count, const c64* h_dev, const c64* V, c64* a, const c64* Z, c64* b, hipStream_t st);
 int op_launch_axpy_host(long long n, double are, double aim, const c64* x, c64* y, hipStream_t st);
 int op_launch_axpby(long long n, double are, double aim, const c64* x, double bre, double bim, const c64* y, c64* out, hipStream_t st);
 int op_launch_tbem_matvec_t(const BemGeom& g, const BemPhys& ph, int row0, int row1, int nchunks, const c64* x, c64* partial,

@@ -927,8 +927,8 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
   MA_HIP(hipSetDevice(o->device));
   const long long n = o->n; const int m = restart;
   hipStream_t st = nullptr;
-  c64 *V = nullptr, *w = nullptr, *x = nullptr, *b = nullptr, *scal = nullptr, *partial = nullptr, *t = nullptr;
-  auto cleanup = [&]() { void* p[] = {V, w, x, b, scal, partial, t}; for (void* q : p) if (q) (void)hipFree(q); };
+  c64 *V = nullptr, *w = nullptr, *x = nullptr, *b = nullptr, *scal = nullptr, *partial = nullptr, *t = nullptr; void* mgs_slots = nullptr; unsigned* mgs_err = nullptr;
+  auto cleanup = [&]() { void* p[] = {V, w, x, b, scal, partial, t, mgs_slots, mgs_err}; for (void* q : p) if (q) (void)hipFree(q); };
 #define GM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_error("%s failed: %s", #call, hipGetErrorString(e_)); cleanup(); return MA_ERR_HIP; } } while (0)
 #define GM_RC(call) do { int rc_ = (call); if (rc_) { cleanup(); return rc_; } } while (0)
   GM_HIP(hipMalloc(&V, sizeof(c64) * (size_t)n * (size_t)(m + 1)));
@@ -938,6 +938,14 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
   GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 4)));
   GM_HIP(hipMalloc(&partial, sizeof(c64) * 256));
   GM_HIP(hipMalloc(&t, sizeof(c64) * (size_t)n));
+  // the Gram-Schmidt step as one launch (op_launch_gmres_mgs); MA_GMRES_FUSED_MGS=0: an inner product and an update kernel per basis vector
+  const char* efuse = getenv("MA_GMRES_FUSED_MGS");
+  bool fused_mgs = !(efuse && atoi(efuse) == 0);
+  if (fused_mgs) {
+    GM_HIP(hipMalloc(&mgs_slots, (size_t)op_mgs_slot_bytes(m)));
+    GM_HIP(hipMalloc(&mgs_err, sizeof(unsigned)));
+    GM_HIP(hipMemset(mgs_err, 0, sizeof(unsigned)));
+  }
   GM_HIP(hipMemcpy(b, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
   if (x0_host) GM_HIP(hipMemcpy(x, x0_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
   else GM_HIP(hipMemset(x, 0, sizeof(c64) * (size_t)n));
@@ -987,11 +995,20 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
       total += 1;
       if (Mp) { GM_RC(ma_op_apply_dev(o, V + (size_t)j * n, t, st)); GM_RC(ma_precond_apply_dev(Mp, t, w, st)); }   // w = M^-1 A v_j
       else GM_RC(ma_op_apply_dev(o, V + (size_t)j * n, w, st));
-      for (int i = 0; i <= j; ++i) {                                        // modified Gram-Schmidt, scalars stay on the device
-        GM_RC(op_launch_dot(n, V + (size_t)i * n, w, 0, partial, scal + 1 + i, st));
-        GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, V + (size_t)i * n, w, st));
+      bool stepped = false;
+      if (fused_mgs) {                                                      // modified Gram-Schmidt: h_0..h_j, w, |w| in one launch
+        const int frc = op_launch_gmres_mgs(n, V, j, w, mgs_slots, scal + 1, mgs_err, st);
+        if (frc == MA_OK) stepped = true;
+        else if (frc == MA_ERR_UNSUPPORTED) fused_mgs = false;              // vector too long for the register-resident form
+        else { cleanup(); return frc; }
       }
-      GM_RC(op_launch_dot(n, w, nullptr, 1, partial, scal + 2 + j, st));
+      if (!stepped) {
+        for (int i = 0; i <= j; ++i) {                                      // the same step as separate kernels, scalars stay on the device
+          GM_RC(op_launch_dot(n, V + (size_t)i * n, w, 0, partial, scal + 1 + i, st));
+          GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, V + (size_t)i * n, w, st));
+        }
+        GM_RC(op_launch_dot(n, w, nullptr, 1, partial, scal + 2 + j, st));
+      }
       GM_HIP(hipMemcpy(hcol.data(), scal + 1, sizeof(c64) * (size_t)(j + 2), hipMemcpyDeviceToHost));   // one sync per inner step
       for (int i = 0; i <= j; ++i) Hh(i, j) = hcol[i];
       const double wn = hcol[j + 1].real();
@@ -1030,6 +1047,7 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
     double rn = 0.0; GM_RC(norm_of(w, &rn));
     info->iterations = total; info->restarts = restarts; info->residual = rn / b_norm; info->converged = 0;
   }
+  if (mgs_err) { unsigned ew = 0; GM_HIP(hipMemcpy(&ew, mgs_err, sizeof(unsigned), hipMemcpyDeviceToHost)); if (ew) { set_error("a Gram-Schmidt step was abandoned at its exchange"); cleanup(); return MA_ERR_HIP; } }
   GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost));
   cleanup();
 #undef GM_HIP
@@ -1064,7 +1082,7 @@ static int gmres_pipelined_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_ho
   GM_HIP(hipMalloc(&Z, sizeof(c64) * (size_t)n * (size_t)(m + 1)));
   for (c64** p : {&x, &b, &t, &q, &vn}) GM_HIP(hipMalloc(p, sizeof(c64) * (size_t)n));
   GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 4)));
-  GM_HIP(hipMalloc(&partial, sizeof(c64) * 256)); GM_HIP(hipMalloc(&partial2, sizeof(c64) * 256));
+  GM_HIP(hipMalloc(&partial, sizeof(c64) * 256)); GM_HIP(hipMalloc(&partial2, sizeof(c64) * 256 * (size_t)(m + 1)));   // partial2: one row of 256 per basis vector (op_launch_multi_dot)
   GM_HIP(hipMemcpy(b, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
   if (x0_host) GM_HIP(hipMemcpy(x, x0_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
   else GM_HIP(hipMemset(x, 0, sizeof(c64) * (size_t)n));
@@ -1121,13 +1139,10 @@ static int gmres_pipelined_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_ho
       const c64* zj = Z + (size_t)j * n;
       GM_HIP(hipEventRecord(ev_z, st)); GM_HIP(hipStreamWaitEvent(s2, ev_z, 0));
       GM_RC(ma_op_apply_dev(o, zj, t, st)); GM_RC(precond(t, q));                                  // q = M^-1 A z_j        | concurrently
-      for (int i = 0; i <= j; ++i) GM_RC(op_launch_dot(n, V + (size_t)i * n, zj, 0, partial2, scal + 1 + i, s2));   // h_ij = <v_i, z_j> |
+      GM_RC(op_launch_multi_dot(n, V, j + 1, zj, partial2, scal + 1, s2));                        // h_ij = <v_i, z_j>, i <= j | (two launches)
       GM_HIP(hipEventRecord(ev_h, s2)); GM_HIP(hipStreamWaitEvent(st, ev_h, 0));
       GM_HIP(hipMemcpyAsync(vn, zj, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice, st));       // :129-136
-      for (int i = 0; i <= j; ++i) {
-        GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, V + (size_t)i * n, vn, st));
-        GM_RC(op_launch_axpy_dev(n, scal + 1 + i, -1.0, Z + (size_t)i * n, q, st));
-      }
+      GM_RC(op_launch_multi_axpy(n, j + 1, scal + 1, V, vn, Z, q, st));                           // vn -= h_ij v_i, q -= h_ij z_i (one launch)
       GM_RC(op_launch_dot(n, vn, nullptr, 1, partial, scal + 2 + j, st));                          // :139
       GM_HIP(hipMemcpy(hcol.data(), scal + 1, sizeof(c64) * (size_t)(j + 2), hipMemcpyDeviceToHost));
       for (int i = 0; i <= j; ++i) Hh(i, j) = hcol[i];
