@@ -975,9 +975,11 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
       y[i] = std::abs(Hh(i, i)) > 1e-30 ? sum * (1.0 / Hh(i, i)) : cplx(0.0, 0.0);
     }
   };
-  auto update_x = [&](int k) -> int {
-    for (int i = 0; i < k; ++i) { int rc = op_launch_axpy_host(n, y[i].real(), y[i].imag(), V + (size_t)i * n, x, st); if (rc) return rc; }
-    return MA_OK;
+  auto update_x = [&](int k) -> int {                        // x += sum_i y_i v_i in one launch: the coefficients go up negated (multi_axpy subtracts)
+    std::vector<c64> neg((size_t)std::max(k, 1));
+    for (int i = 0; i < k; ++i) neg[(size_t)i] = c64{-y[i].real(), -y[i].imag()};
+    MA_HIP(hipMemcpy(scal + 1, neg.data(), sizeof(c64) * (size_t)k, hipMemcpyHostToDevice));
+    return op_launch_multi_axpy(n, k, scal + 1, V, x, nullptr, nullptr, st);
   };
   int total = 0, restarts = 0; bool done = false;
   for (int outer = 0; outer < max_iterations && !done; ++outer) {
@@ -1119,9 +1121,11 @@ static int gmres_pipelined_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_ho
       y[i] = std::abs(Hh(i, i)) > 1e-30 ? sum * (1.0 / Hh(i, i)) : cplx(0.0, 0.0);
     }
   };
-  auto update_x = [&](int k) -> int {
-    for (int i = 0; i < k; ++i) { int rc = op_launch_axpy_host(n, y[i].real(), y[i].imag(), V + (size_t)i * n, x, st); if (rc) return rc; }
-    return MA_OK;
+  auto update_x = [&](int k) -> int {                        // x += sum_i y_i v_i in one launch: the coefficients go up negated (multi_axpy subtracts)
+    std::vector<c64> neg((size_t)std::max(k, 1));
+    for (int i = 0; i < k; ++i) neg[(size_t)i] = c64{-y[i].real(), -y[i].imag()};
+    MA_HIP(hipMemcpy(scal + 1, neg.data(), sizeof(c64) * (size_t)k, hipMemcpyHostToDevice));
+    return op_launch_multi_axpy(n, k, scal + 1, V, x, nullptr, nullptr, st);
   };
   int total = 0, restarts = 0; bool done = false;
   for (int outer = 0; outer < max_iterations && !done; ++outer) {
