@@ -252,9 +252,11 @@ int ma_csr_sym_gauss_seidel(ma_csr_t* h, ma_c64* x_inout, const ma_c64* b, int s
 int ma_csr_sym_gauss_seidel_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* stream);
 int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int mode, int backward, void* stream);
 int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward);   /* dependency levels per sweep (diagnostic) */
-/* MA_CSR_GS_PERSISTENT=1 runs a sweep as ONE persistent launch (a device-wide barrier per level instead of a kernel boundary; same
- * arithmetic, same results; measured slower than the launches, so off by default); ma_csr_status synchronises and reports
- * MA_ERR_HIP if such a sweep ever gave up at a barrier (bounded spin). */
+/* A sweep runs as ONE persistent launch: the new iterate goes to a second array of the handle that starts as a sentinel, a row polls
+ * the new values it depends on until they have left it, old values come from the untouched input (same arithmetic per row as a
+ * launch per dependency level: bit-identical results). MA_CSR_GS_FLAGS=0: a launch per level; MA_CSR_GS_PERSISTENT=1: one
+ * persistent launch with a device-wide barrier per level (measured slower). Every wait is bounded; ma_csr_status synchronises and
+ * reports MA_ERR_HIP if a sweep ever gave up waiting. A handle's sweeps must not run on two streams at once. */
 int ma_csr_status(ma_csr_t* h);
 
 /* math-fem geometric-multigrid smoothers on the COO HelmholtzMatrix (math-fem/src/assembly/helmholtz.rs:22-33,
