@@ -942,7 +942,7 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   }
   if (!rc && hipDeviceSynchronize() != hipSuccess) { set_error("SLFMM near-field kernels failed"); rc = MA_ERR_HIP; }
   drop();
-  if (timing) fprintf(stderr, "[slfmm build] nc %d: lists+pairs %.0f, D %.0f, views %.0f, uploads+dense %.0f, alloc+pairs upload %.0f, kernels %.0f ms\n", nc, tms(tt0, tt1), tms(tt1, tt2), 0.0, tms(tt2, tt3), tms(tt3, tt4), tms(tt4, tnow()));
+  if (timing) fprintf(stderr, "[slfmm build] nc %d: checks + block lists %.0f, translation factors + far lists %.0f, uploads + dense D %.0f, buffers + element pairs %.0f, near-field kernels %.0f ms\n", nc, tms(tt0, tt1), tms(tt1, tt2), tms(tt2, tt3), tms(tt3, tt4), tms(tt4, tnow()));
   if (rc) return fail(rc);
   *out = S;
   return MA_OK;
