@@ -1228,7 +1228,7 @@ static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_i
 #define KR_RC(call) do { int rc_ = (call); if (rc_) { cleanup(); return rc_; } } while (0)
   KR_HIP(hipMalloc(&buf, sizeof(c64) * (size_t)n * 9));
   KR_HIP(hipMalloc(&scal, sizeof(c64) * 4));
-  KR_HIP(hipMalloc(&partial, sizeof(c64) * 256));
+  KR_HIP(hipMalloc(&partial, sizeof(c64) * 256 * 2));
   c64 *x = buf, *r = buf + n, *r0 = buf + 2 * n, *p = buf + 3 * n, *v = buf + 4 * n, *sv = buf + 5 * n, *t = buf + 6 * n, *u = buf + 7 * n, *q = buf + 8 * n;
   KR_HIP(hipMemset(buf, 0, sizeof(c64) * (size_t)n * 9));
   KR_HIP(hipMemcpy(r, b_host, sizeof(c64) * (size_t)n, hipMemcpyHostToDevice));
@@ -1240,6 +1240,12 @@ static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_i
   auto norm = [&](const c64* a, double* out) -> int {
     int rc = op_launch_dot(n, a, nullptr, 1, partial, scal, st); if (rc) return rc;
     c64 h; MA_HIP(hipMemcpy(&h, scal, sizeof(c64), hipMemcpyDeviceToHost)); *out = h.re; return MA_OK;
+  };
+  // two inner products against one vector, <v0, y> and <v1, y> with v0, v1 adjacent in `buf`, in one exchange with the host (each reduced
+  // exactly as `dot` reduces it)
+  auto dot2 = [&](const c64* v01, const c64* yy, cplx* o0, cplx* o1) -> int {
+    int rc = op_launch_multi_dot(n, v01, 2, yy, partial, scal, st); if (rc) return rc;
+    c64 h[2]; MA_HIP(hipMemcpy(h, scal, 2 * sizeof(c64), hipMemcpyDeviceToHost)); *o0 = cplx(h[0].re, h[0].im); *o1 = cplx(h[1].re, h[1].im); return MA_OK;
   };
   auto axpby = [&](cplx a, const c64* xa, cplx bcoef, const c64* ya, c64* out) { return op_launch_axpby(n, a.real(), a.imag(), xa, bcoef.real(), bcoef.imag(), ya, out, st); };
   auto finish = [&](int iters, double res, bool conv) -> int {
@@ -1255,8 +1261,9 @@ static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_i
   const cplx one(1.0, 0.0);
   if (kind == 0) {                                                             // bicgstab.rs:46-182
     cplx rho = one, alpha = one, omega = one;
+    cplx rho_next; KR_RC(dot(r0, r, &rho_next));                               // <r0, r> of the coming iteration (later ones arrive with |r|)
     for (int it = 0; it < max_iterations; ++it) {
-      cplx rho_new; KR_RC(dot(r0, r, &rho_new));
+      const cplx rho_new = rho_next;
       if (std::abs(rho_new) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
       const cplx beta = (rho_new / rho) * (alpha / omega);
       rho = rho_new;
@@ -1270,14 +1277,15 @@ static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_i
       double s_norm; KR_RC(norm(sv, &s_norm));
       if (s_norm / b_norm < tol) { KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), p, x, st)); return finish(it + 1, s_norm / b_norm, true); }
       KR_RC(ma_op_apply_dev(o, sv, t, st));
-      cplx tt; KR_RC(dot(t, t, &tt));
+      cplx st_, tt; KR_RC(dot2(sv, t, &st_, &tt));                             // <s, t> and <t, t> together (s and t are adjacent); <t, s> = conj <s, t>
       if (std::abs(tt) < 1e-30) { KR_RC(norm(r, &rn)); return finish(it, rn / b_norm, false); }
-      cplx ts; KR_RC(dot(t, sv, &ts));
+      const cplx ts = std::conj(st_);
       omega = ts / tt;
       KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), p, x, st));     // x = x + alpha p + omega s
       KR_RC(op_launch_axpy_host(n, omega.real(), omega.imag(), sv, x, st));
       KR_RC(axpby(one, sv, -omega, t, r));                                     // r = s - omega t
-      KR_RC(norm(r, &rn));
+      cplx rr; KR_RC(dot2(r, r, &rr, &rho_next));                              // <r, r> and <r0, r> together (r and r0 are adjacent)
+      rn = std::sqrt(rr.real());
       const double rel = rn / b_norm;
       if (rel < tol) return finish(it + 1, rel, true);
       if (std::abs(omega) < 1e-30) return finish(it + 1, rel, false);
@@ -1299,10 +1307,10 @@ static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_i
       KR_RC(ma_op_apply_dev(o, sv, t, st));                                    // w = A (u + q)
       KR_RC(op_launch_axpy_host(n, alpha.real(), alpha.imag(), sv, x, st));
       KR_RC(op_launch_axpy_host(n, -alpha.real(), -alpha.imag(), t, r, st));
-      KR_RC(norm(r, &rn));
+      cplx rr, rho_new; KR_RC(dot2(r, r, &rr, &rho_new));                      // |r|^2 and <r0, r> together (r and r0 are adjacent)
+      rn = std::sqrt(rr.real());
       const double rel = rn / b_norm;
       if (rel < tol) return finish(it + 1, rel, true);
-      cplx rho_new; KR_RC(dot(r0, r, &rho_new));
       if (std::abs(rho) < 1e-30) return finish(it + 1, rel, false);
       const cplx beta = rho_new / rho;
       rho = rho_new;
