@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void mgs_fill_kernel(long long nwords, unsigne
 template <int E>
 __global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* __restrict__ V, int j, dc* __restrict__ w, unsigned long long* slots /* (j + 2) x gridDim.x x 2 */,
                                                         dc* __restrict__ scal_out /* h_0..h_j, then (|w|, 0) */, unsigned* err) {
-  __shared__ double sr[4], si[4], hb[2];
+  __shared__ double sr[4], si[4], tr[4], ti[4], hb[2][2];        // two sets of reduction slots and two h slots: a barrier less per phase
   const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const long long stride = (long long)nb * 256, i0 = (long long)b * 256 + tid;
   dc wv[E];
@@ -415,8 +415,7 @@ __global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* _
       __hip_atomic_store(row + 2 * b, mgs_word((sr[0] + sr[1]) + (sr[2] + sr[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(row + 2 * b + 1, mgs_word((si[0] + si[1]) + (si[2] + si[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                            // sr / si are free again
-    // dot_final_kernel's reduction over the nb partial sums, done by every workgroup
+    // dot_final_kernel's reduction over the nb partial sums, done by every workgroup (its own LDS slots: no barrier needed here)
     double pr = 0.0, pi = 0.0;
     if (tid < nb) {
       unsigned long long wa = __hip_atomic_load(row + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), wb = __hip_atomic_load(row + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -435,23 +434,23 @@ __global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* _
       pr += __longlong_as_double((long long)wa); pi += __longlong_as_double((long long)wb);
     }
     pr = wave_sum(pr); pi = wave_sum(pi);
-    if (lane == 0) { sr[wave] = pr; si[wave] = pi; }
+    if (lane == 0) { tr[wave] = pr; ti[wave] = pi; }
     __syncthreads();
+    const int hs = step & 1;
     if (tid == 0) {
-      const double r = (sr[0] + sr[1]) + (sr[2] + sr[3]), i2 = (si[0] + si[1]) + (si[2] + si[3]);
-      hb[0] = last ? __builtin_sqrt(r) : r; hb[1] = last ? 0.0 : i2;
-      if (b == 0) scal_out[step] = dc_make(hb[0], hb[1]);
+      const double r = (tr[0] + tr[1]) + (tr[2] + tr[3]), i2 = (ti[0] + ti[1]) + (ti[2] + ti[3]);
+      hb[hs][0] = last ? __builtin_sqrt(r) : r; hb[hs][1] = last ? 0.0 : i2;
+      if (b == 0) scal_out[step] = dc_make(hb[hs][0], hb[hs][1]);
     }
     __syncthreads();
     if (!last) {                                                // w -= h v   (axpy_kernel with alpha = h, sgn = -1)
-      const double are = -1.0 * hb[0], aim = -1.0 * hb[1];
+      const double are = -1.0 * hb[hs][0], aim = -1.0 * hb[hs][1];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const long long idx = i0 + e * stride;
         if (idx < n) { const dc xv = vv[e]; wv[e].re += are * xv.re - aim * xv.im; wv[e].im += are * xv.im + aim * xv.re; }
       }
     }
-    __syncthreads();                                            // hb is free again
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) { const long long idx = i0 + e * stride; if (idx < n) w[idx] = wv[e]; }
