@@ -24,7 +24,8 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
-// EPI: 0 y = A x; 1 r = b - A x; 2 Jacobi x_new = x + omega dinv (b - A x); 3 l1-Jacobi x_new = x + (b - A x) / l1
+// EPI: 0 y = A x; 1 r = b - A x; 2 Jacobi x_new = x + omega dinv (b - A x); 3 l1-Jacobi x_new = x + (b - A x) / l1;
+//      4 y = b + A x (the correction x + P e of the V-cycle in one pass; out may be b)
 template <int G, bool KM, int EPI>
 __global__ __launch_bounds__(256) void csr_rows_kernel(CsrView A, const dc* __restrict__ x, const dc* __restrict__ b,
                                                        dc* __restrict__ out, double omega) {
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(CsrView A, const dc* __re
   sr = group_sum<G>(sr); si = group_sum<G>(si);
   if (lane_in_group == 0) {
     if (EPI == 0) out[row] = dc_make(sr, si);
+    else if (EPI == 4) { const dc bb = b[row]; out[row] = dc_make(bb.re + sr, bb.im + si); }
     else {
       const dc bb = b[row];
       const double rr = bb.re - sr, ri = bb.im - si;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void sell_rows_kernel(CsrView A, const dc* __r
   }
   if (row >= A.n) return;
   if (EPI == 0) out[row] = dc_make(sr, si);
+  else if (EPI == 4) { const dc bb = b[row]; out[row] = dc_make(bb.re + sr, bb.im + si); }
   else {
     const dc bb = b[row];
     const double rr = bb.re - sr, ri = bb.im - si;
@@ -111,6 +114,7 @@ static int launch_sell2(const CsrView& A, int epi, const c64* x, const c64* b, c
     case 0: hipLaunchKernelGGL((sell_rows_kernel<KM, 0, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
     case 1: hipLaunchKernelGGL((sell_rows_kernel<KM, 1, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
     case 2: hipLaunchKernelGGL((sell_rows_kernel<KM, 2, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
+    case 4: hipLaunchKernelGGL((sell_rows_kernel<KM, 4, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
     default: hipLaunchKernelGGL((sell_rows_kernel<KM, 3, C16>), grid, block, 0, st, A, xx, bb, oo, omega); break;
   }
   MA_HIP(hipGetLastError());
@@ -150,6 +154,7 @@ static int launch_g(const CsrView& A, int epi, const c64* x, const c64* b, c64* 
     case 0: hipLaunchKernelGGL((csr_rows_kernel<G, KM, 0>), grid, block, 0, st, A, xx, bb, oo, omega); break;
     case 1: hipLaunchKernelGGL((csr_rows_kernel<G, KM, 1>), grid, block, 0, st, A, xx, bb, oo, omega); break;
     case 2: hipLaunchKernelGGL((csr_rows_kernel<G, KM, 2>), grid, block, 0, st, A, xx, bb, oo, omega); break;
+    case 4: hipLaunchKernelGGL((csr_rows_kernel<G, KM, 4>), grid, block, 0, st, A, xx, bb, oo, omega); break;
     default: hipLaunchKernelGGL((csr_rows_kernel<G, KM, 3>), grid, block, 0, st, A, xx, bb, oo, omega); break;
   }
   MA_HIP(hipGetLastError());
@@ -167,6 +172,30 @@ static int launch_km(const CsrView& A, int group, int epi, const c64* x, const c
   }
 }
 
+// the first Jacobi / l1-Jacobi sweep of an iterate that is zero: x_new = 0 + omega dinv (b - 0) resp. 0 + (b - 0) / l1, the EPI 2 / 3
+// epilogues with A x = 0 spelled out -- no pass over the matrix and no clearing of x beforehand
+__global__ __launch_bounds__(256) void csr_sweep_from_zero_kernel(long long n, const dc* __restrict__ dinv, const double* __restrict__ l1, const dc* __restrict__ b,
+                                                                  double omega, int l1mode, dc* __restrict__ out) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  const dc bb = b[row];
+  const double rr = bb.re - 0.0, ri = bb.im - 0.0;
+  if (!l1mode) {
+    const dc d = dinv[row];
+    const double wr = omega * d.re, wi = omega * d.im;
+    out[row] = dc_make(0.0 + (wr * rr - wi * ri), 0.0 + (wr * ri + wi * rr));
+  } else {
+    const double l = l1[row];
+    out[row] = dc_make(0.0 + rr / l, 0.0 + ri / l);
+  }
+}
+int csr_launch_sweep_from_zero(const CsrView& A, int l1mode, const c64* b, c64* out, double omega, hipStream_t st) {
+  if (A.n <= 0) return MA_OK;
+  hipLaunchKernelGGL(csr_sweep_from_zero_kernel, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A.n, A.dinv, A.l1, reinterpret_cast<const dc*>(b), omega, l1mode,
+                     reinterpret_cast<dc*>(out));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
 int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st) {
   if (A.n <= 0) return MA_OK;
   if (A.sell_ptr) return km ? launch_sell<true>(A, epi, x, b, out, omega, st) : launch_sell<false>(A, epi, x, b, out, omega, st);

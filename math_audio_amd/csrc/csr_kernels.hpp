@@ -30,6 +30,7 @@ struct CsrView {
 int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st);
 int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* rows, const long long* lev_ptr, int nlev, int grid, c64* x, const c64* b,
                              unsigned* bar, unsigned base, unsigned gbase, hipStream_t st);
+int csr_launch_sweep_from_zero(const CsrView& A, int l1mode, const c64* b, c64* out, double omega, hipStream_t st);
 int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, int count, c64* x, const c64* b, hipStream_t st);
 int csr_launch_gs_flags(const CsrView& A, bool km, int mode, const int* rows_padded, long long npad, int grid, c64* x, c64* xn, const c64* b, int backward, unsigned* err,
                         hipStream_t st);

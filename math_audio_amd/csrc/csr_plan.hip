@@ -329,28 +329,43 @@ int ma_csr_residual_dev(ma_csr_t* h, const void* d_x, const void* d_b, void* d_r
   MA_HIP(hipSetDevice(h->device));
   return csr_launch_rows(h->view(), h->fused_km(), h->group, 1, (const c64*)d_x, (const c64*)d_b, (c64*)d_r, 0.0, (hipStream_t)stream);
 }
-// `sweeps` Jacobi sweeps on d_x (in place from the caller's view; d_tmp is a scratch vector of n entries)
+// `sweeps` Jacobi sweeps on d_x (in place from the caller's view; d_tmp is a scratch vector of n entries). x_is_zero: the caller knows
+// the iterate is zero and has NOT cleared d_x: the first sweep is the diagonal scaling it then amounts to (no pass over the matrix)
+static int jacobi_sweeps(ma_csr* h, int epi, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, bool x_is_zero, hipStream_t st) {
+  int rc = ensure_diag(h, st);
+  c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
+  int s0 = 0;
+  if (x_is_zero && sweeps >= 1 && !rc) {
+    c64* first = (sweeps % 2 == 1) ? (c64*)d_x : (c64*)d_tmp;                   // so that the last sweep lands in d_x
+    rc = csr_launch_sweep_from_zero(h->view(), epi == 3 ? 1 : 0, (const c64*)d_b, first, omega, st);
+    cur = first; nxt = first == (c64*)d_x ? (c64*)d_tmp : (c64*)d_x; s0 = 1;
+  }
+  for (int s = s0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->fused_km(), h->group, epi, cur, (const c64*)d_b, nxt, omega, st); std::swap(cur, nxt); }
+  if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
+  return rc;
+}
 int ma_csr_jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream) {
   MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_jacobi_dev needs a square operator");
   MA_REQUIRE(h && d_x && d_b && d_tmp && sweeps >= 0, MA_ERR_INVALID, "bad argument");
   MA_HIP(hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)stream;
-  int rc = ensure_diag(h, st);
-  c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
-  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->fused_km(), h->group, 2, cur, (const c64*)d_b, nxt, omega, st); std::swap(cur, nxt); }
-  if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
-  return rc;
+  return jacobi_sweeps(h, 2, d_x, d_b, omega, sweeps, d_tmp, false, (hipStream_t)stream);
 }
 int ma_csr_l1jacobi_dev(ma_csr_t* h, void* d_x, const void* d_b, int sweeps, void* d_tmp, void* stream) {
   MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_l1jacobi_dev needs a square operator");
   MA_REQUIRE(h && d_x && d_b && d_tmp && sweeps >= 0, MA_ERR_INVALID, "bad argument");
   MA_HIP(hipSetDevice(h->device));
-  hipStream_t st = (hipStream_t)stream;
-  int rc = ensure_diag(h, st);
-  c64* cur = (c64*)d_x; c64* nxt = (c64*)d_tmp;
-  for (int s = 0; s < sweeps && !rc; ++s) { rc = csr_launch_rows(h->view(), h->fused_km(), h->group, 3, cur, (const c64*)d_b, nxt, 0.0, st); std::swap(cur, nxt); }
-  if (!rc && cur != (c64*)d_x) MA_HIP(hipMemcpyAsync(d_x, cur, sizeof(c64) * (size_t)h->n, hipMemcpyDeviceToDevice, st));
-  return rc;
+  return jacobi_sweeps(h, 3, d_x, d_b, 0.0, sweeps, d_tmp, false, (hipStream_t)stream);
+}
+// the V-cycle's forms (internal to the library): sweeps of an iterate known to be zero (d_x not cleared by the caller), and x += A e
+extern "C" int ma_csr_jacobi_from_zero_dev(ma_csr_t* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, int l1, void* stream) {
+  MA_REQUIRE(h && h->ncols == h->n && d_x && d_b && d_tmp && sweeps >= 1, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipSetDevice(h->device));
+  return jacobi_sweeps(h, l1 ? 3 : 2, d_x, d_b, l1 ? 0.0 : omega, sweeps, d_tmp, true, (hipStream_t)stream);
+}
+extern "C" int ma_csr_spmv_add_dev(ma_csr_t* h, const void* d_e, void* d_x_inout, void* stream) {
+  MA_REQUIRE(h && d_e && d_x_inout, MA_ERR_INVALID, "NULL argument");
+  MA_HIP(hipSetDevice(h->device));
+  return csr_launch_rows(h->view(), h->fused_km(), h->group, 4, (const c64*)d_e, (const c64*)d_x_inout, (c64*)d_x_inout, 0.0, (hipStream_t)stream);
 }
 
 // host-buffer forms: CsrMatrix::matvec(&x) -> y (csr.rs:240), smooth_jacobi / smooth_l1_jacobi (amg.rs:855-929)

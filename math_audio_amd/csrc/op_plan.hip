@@ -494,28 +494,37 @@ extern "C" int ma_csr_gauss_seidel_sweep_dev(ma_csr* h, void* d_x, const void* d
 // AmgPreconditioner::v_cycle (amg.rs:981-1065) on device vectors of level `level`: smoothers are the AMG sweeps of the CSR
 // handles (smooth_jacobi :855-884, smooth_l1_jacobi :887-929, smooth_sym_gauss_seidel :932-978), the coarsest level runs 20
 // Jacobi / 20 l1-Jacobi / 10 symmetric Gauss-Seidel sweeps (:986-1003), restriction and prolongation are SpMVs with the level's R and P.
-static int amg_smooth(ma_precond* M, AmgLevelDev& L, c64* x, const c64* b, int sweeps, hipStream_t st) {
+extern "C" int ma_csr_jacobi_from_zero_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, int l1, void* stream);
+extern "C" int ma_csr_spmv_add_dev(ma_csr* h, const void* d_e, void* d_x_inout, void* stream);
+// x_is_zero: the iterate is zero by construction and its array has not been cleared (Jacobi-type smoothers write the first sweep outright)
+static int amg_smooth(ma_precond* M, AmgLevelDev& L, c64* x, const c64* b, int sweeps, hipStream_t st, bool x_is_zero = false) {
   if (sweeps <= 0) return MA_OK;
+  if (x_is_zero && M->amg_smoother != 2) return ma_csr_jacobi_from_zero_dev(L.A, x, b, M->omega, sweeps, L.tmp, M->amg_smoother == 1 ? 1 : 0, st);
   if (M->amg_smoother == 1) return ma_csr_l1jacobi_dev(L.A, x, b, sweeps, L.tmp, st);
   if (M->amg_smoother == 2) return ma_csr_sym_gauss_seidel_dev(L.A, x, b, sweeps, st);
   return ma_csr_jacobi_dev(L.A, x, b, M->omega, sweeps, L.tmp, st);
 }
-static int amg_v_cycle(ma_precond* M, size_t level, c64* x, const c64* b, hipStream_t st) {
+// the sweeps a level runs first on its (zero) iterate: when they are Jacobi-type and there is at least one, the caller may leave the
+// iterate uncleared
+static bool amg_first_sweep_writes(const ma_precond* M, size_t level) {
+  const bool coarsest = level + 1 == M->lv.size() || !M->lv[level].P;
+  return M->amg_smoother != 2 && (coarsest ? 20 : M->amg_pre) >= 1;
+}
+static int amg_v_cycle(ma_precond* M, size_t level, c64* x, const c64* b, hipStream_t st, bool x_is_zero = false) {
   AmgLevelDev& L = M->lv[level];
   if (level + 1 == M->lv.size() || !L.P)
-    return amg_smooth(M, L, x, b, M->amg_smoother == 2 ? 10 : 20, st);
-  int rc = amg_smooth(M, L, x, b, M->amg_pre, st);
+    return amg_smooth(M, L, x, b, M->amg_smoother == 2 ? 10 : 20, st, x_is_zero);
+  int rc = amg_smooth(M, L, x, b, M->amg_pre, st, x_is_zero);
   if (!rc) rc = ma_csr_residual_dev(L.A, x, b, L.r, st);                       // r = b - A x
   AmgLevelDev& C = M->lv[level + 1];
   if (!rc) rc = ma_csr_spmv_dev(L.R, L.r, C.b, st);                            // r_c = R r
-  if (!rc && hipMemsetAsync(C.x, 0, sizeof(c64) * (size_t)C.n, st) != hipSuccess) { set_error("AMG: clearing the coarse correction failed"); rc = MA_ERR_HIP; }
-  if (!rc) rc = amg_v_cycle(M, level + 1, C.x, C.b, st);
-  if (!rc) rc = ma_csr_spmv_dev(L.P, C.x, L.r, st);                            // e = P e_c
-  if (!rc) rc = op_launch_axpby(L.n, 1.0, 0.0, x, 1.0, 0.0, L.r, x, st);      // x = x + e
+  const bool lazy = amg_first_sweep_writes(M, level + 1);                     // the coarse iterate starts at zero: cleared, or written by its first sweep
+  if (!rc && !lazy && hipMemsetAsync(C.x, 0, sizeof(c64) * (size_t)C.n, st) != hipSuccess) { set_error("AMG: clearing the coarse correction failed"); rc = MA_ERR_HIP; }
+  if (!rc) rc = amg_v_cycle(M, level + 1, C.x, C.b, st, lazy);
+  if (!rc) rc = ma_csr_spmv_add_dev(L.P, C.x, x, st);                          // x = x + P e_c in one pass
   if (!rc) rc = amg_smooth(M, L, x, b, M->amg_post, st);
   return rc;
 }
-
 int ma_precond_create_jacobi(ma_csr_t* csr, double omega, int32_t sweeps, ma_precond_t** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
   MA_REQUIRE(csr && sweeps >= 0, MA_ERR_INVALID, "bad argument");
