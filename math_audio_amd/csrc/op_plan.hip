@@ -891,17 +891,18 @@ int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stre
     if (!rc) rc = ma_csr_gauss_seidel_sweep_dev(M->ilu_u, d_z, M->d_tmp, 1, 1, stream);
     return rc;
   }
-  MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
+  const bool amg_lazy = M->kind == 5 && amg_first_sweep_writes(M, 0);          // z = 0 is then written by the cycle's first sweep
+  if (!amg_lazy) MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
   if (M->kind == 5) {                                    // AmgPreconditioner::apply, amg.rs:1068-1103: z = 0, then the cycle
     hipStream_t st = (hipStream_t)stream;
     c64* z = (c64*)d_z; const c64* r = (const c64*)d_r;
-    int rc = amg_v_cycle(M, 0, z, r, st);
+    int rc = amg_v_cycle(M, 0, z, r, st, amg_lazy);
     if (!rc && M->amg_cycle == 1) rc = amg_v_cycle(M, 0, z, r, st);             // W: the V-cycle twice (:1084-1087)
     if (!rc && M->amg_cycle == 2) {                                              // F: a second V-cycle on the residual (:1088-1094)
       c64* res = M->d_tmp; c64* corr = M->d_tmp + M->n;
       rc = ma_csr_residual_dev(M->lv[0].A, z, r, res, st);
-      if (!rc && hipMemsetAsync(corr, 0, sizeof(c64) * (size_t)M->n, st) != hipSuccess) { set_error("AMG: clearing the correction failed"); rc = MA_ERR_HIP; }
-      if (!rc) rc = amg_v_cycle(M, 0, corr, res, st);
+      if (!rc && !amg_lazy && hipMemsetAsync(corr, 0, sizeof(c64) * (size_t)M->n, st) != hipSuccess) { set_error("AMG: clearing the correction failed"); rc = MA_ERR_HIP; }
+      if (!rc) rc = amg_v_cycle(M, 0, corr, res, st, amg_lazy);
       if (!rc) rc = op_launch_axpby(M->n, 1.0, 0.0, z, 1.0, 0.0, corr, z, st);
     }
     return rc;
