@@ -291,6 +291,12 @@ def main():
     As = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
     xs_ = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
+    if lu.main_stream():
+        # the chip is split (MA_LU_CU_SPLIT): the plan's big updates run on a CU-masked stream, which is a blocking stream (the only
+        # kind hipExtStreamCreateWithCUMask makes) and would serialise against work on the NULL stream. The bench's own launches
+        # (assemblies) go onto that stream too: no extra hardware queue
+        stream = lu.main_stream()
+        torch.cuda.set_stream(torch.cuda.ExternalStream(stream, device=dev))
     asm_ms = np.zeros(3); lu_ms = np.zeros(8); upd = np.zeros(3)
     timing = False
 

@@ -381,6 +381,12 @@ class LuPlan:
         check(lib().ma_lu_plan_slot_stream(self.h, int(slot), C.byref(p)))
         return p.value
 
+    def main_stream(self):
+        """ma_lu_plan_main_stream: the CU-masked stream of the big updates (MA_LU_CU_SPLIT), or None."""
+        p = C.c_void_p()
+        check(lib().ma_lu_plan_main_stream(self.h, C.byref(p)))
+        return p.value
+
     def stage_reset(self, stream=0):
         check(lib().ma_lu_plan_stage_reset(self.h, C.c_void_p(stream)))
 

@@ -20,6 +20,7 @@
 #include <climits>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 namespace ma {
 
@@ -406,6 +407,219 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
     int rr = idx / nb, j = idx - rr * nb;
     A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
   }
+}
+
+// ------------------------------------------------------------------ panel factorisation with the rows in registers (round 3)
+// lane = row: a thread keeps its row's NB panel entries in registers for the whole panel (4 NB vector registers), the column
+// loop is unrolled so that every register index is static, and a workgroup of 256 threads holds 256 rows: a 10 000-row panel
+// is 40 workgroups instead of 233, so the per-column exchange is ONE flat sweep over <= 64 granules per lane (1.3-1.7 us on
+// idle CUs against 3.7 for the two-level gather over 233) and the rank-1 update is 4 FMAs per entry straight on registers
+// (no LDS traffic, no barrier between its parts). Rows never move during the panel: a thread tracks the POSITION its row
+// holds under LAPACK's sequence of interchanges (`mypos`: the pivot row of column c takes position k0 + c, the row that was
+// there takes the pivot's position) and writes its row to that position at the end, so the diagonal row needs no exchange
+// at all. Per column and workgroup: every wavefront reduces its candidate (top 32 bits of |re| + |im|, ties to the lowest
+// position -- the rule of lu_panel_kernel) with DPP; barrier; the wavefront that holds the workgroup's best row stages it
+// through LDS (one lane writes, 32 lanes read) and publishes it write-through, then the granule {value, tag, position};
+// wavefront 0 sweeps all granules (data = flag), fetches the winner's row into LDS; barrier; everybody eliminates.
+// The kernel is meant for CUs that no throughput kernel shares (CU-masked streams, lu_plan.hip): there its exchange runs
+// at the idle round trip (profiles/r03_cumask_probe.txt), and its registers (about 200 per lane, one wavefront per SIMD)
+// are why it is admitted one workgroup per CU.
+__device__ __forceinline__ unsigned wave_umin(unsigned v) { return ~wave_umax(~v); }
+
+// compile-time loop: f(integral_constant<int, I>) for I = I0 .. N-1. Every index into the row registers is a constant when the
+// code is generated (a runtime-indexed array of 4 NB registers would live in scratch memory: the unroller alone left it there)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv) {
+  __shared__ __attribute__((aligned(16))) dc s_urow[2][NB];   // pivot rows of the current and the previous column
+  __shared__ unsigned s_m[4];
+  __shared__ unsigned s_pos[4];
+  __shared__ int s_lane[4];
+  __shared__ int s_misc[4];                              // [0] pivot position, [1] fail, [2] poison seen at the start
+  constexpr unsigned NONE = 0xFFFFFFu;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, G = gridDim.x;
+  const int row0 = k0 + b * 256 + tid;
+  const bool valid = row0 < n;
+  int mypos = row0;
+  bool done = !valid;                                    // rows beyond n take no part
+  dc a[NB];
+  {
+    const dc* src = A + (size_t)(valid ? row0 : k0) * n + k0;
+    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = (valid && j < nbc) ? src[j] : dc_make(0.0, 0.0); });
+  }
+  if (tid == 0) { s_misc[1] = 0; s_misc[2] = (int)__hip_atomic_load(ws.timeout, RLX_AGENT); }
+  __syncthreads();
+  if (s_misc[2] != 0) {                                  // poisoned plan: identity pivots, nothing else (see lu_panel_kernel)
+    if (b == 0) for (int j = tid; j < nbc; j += 256) ipiv[k0 + j] = k0 + j;
+    return;
+  }
+#ifdef MA_PANEL_STAMPS
+  u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 stamp_t = __builtin_amdgcn_s_memrealtime();
+#define MA_RSTAMP(i) do { if (tid == 0) { u64 now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#else
+#define MA_RSTAMP(i) do { } while (0)
+#endif
+  // this wavefront's candidate of column c: top 32 bits of |re| + |im|, ties to the lowest position
+  auto candidate = [&](dc v) {
+    const double mag = cabs1(v);
+    const bool offer = !done && mag == mag;              // a NaN is never offered
+    const unsigned hi = offer ? (unsigned)((u64)__double_as_longlong(mag) >> 32) : 0u;
+    const unsigned m = wave_umax(hi);
+    const unsigned pk = (offer && hi == m) ? (unsigned)mypos : NONE;
+    const unsigned pmin = wave_umin(pk);
+    const u64 bm = __ballot(pk == pmin && pmin != NONE);
+    if (lane == 0) { s_m[wave] = m; s_pos[wave] = pmin; s_lane[wave] = bm ? (int)__builtin_ctzll(bm) : 0; }
+  };
+  candidate(a[0]);
+  __syncthreads();                                       // B1(0)
+  bool dead = false;                                     // uniform: an exchange was abandoned, the workgroup only falls through
+  dc lprev = dc_make(0.0, 0.0);                          // this row's multiplier of the previous column; its rank-1 update is still due on columns > c
+  bool upd_pending = false;                              // per lane: the previous column's update is due on this row
+  MA_RSTAMP(5);
+  static_for<0, NB>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (c < nbc && !dead) {
+    const int gc = k0 + c, buf = c & 1;
+    const unsigned want = (unsigned)(c + 1);
+    // ---- after B1(c): the workgroup's candidate; the wavefront that holds it sends the row off as it stands -- with the previous
+    // column's rank-1 update still due on the columns right of c (every receiver completes it on the row it fetches)
+    unsigned bmax = s_m[0], bpos = s_pos[0]; int bw = 0;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const unsigned mw = s_m[w], pw = s_pos[w];
+      if (pw != NONE && (bpos == NONE || mw > bmax || (mw == bmax && pw < bpos))) { bmax = mw; bpos = pw; bw = w; }
+    }
+    const bool sender = wave == bw;
+    if (sender && bpos != NONE && lane == s_lane[bw]) {
+      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
+      static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; st_sc1(dst + 2 * j, a[j].re); st_sc1(dst + 2 * j + 1, a[j].im); });
+    }
+    MA_RSTAMP(0);
+    // ---- the bulk of the previous column's rank-1 update, on registers; it overlaps the write-through of the row above
+    if constexpr (c > 0) {
+      if (upd_pending) {
+        const dc* up = s_urow[(c - 1) & 1];
+        dc u[NB];
+        static_for<c + 1, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; u[j] = up[j]; });
+        const double nlr = -lprev.re, nli = -lprev.im, lr = lprev.re, li = lprev.im;
+        static_for<c + 1, NB>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          a[j].re = __builtin_fma(li, u[j].im, __builtin_fma(nlr, u[j].re, a[j].re));
+          a[j].im = __builtin_fma(nli, u[j].re, __builtin_fma(nlr, u[j].im, a[j].im));
+        });
+      }
+    }
+    MA_RSTAMP(1);
+    if (sender) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row is out before the granule says so
+      if (lane == 0)
+        __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE,
+                           ((u64)(bpos != NONE ? bmax : 0u) << 32) | ((u64)want << 24) | (u64)bpos, RLX_AGENT);
+    }
+    // ---- wavefront 0: sweep every workgroup's granule until all carry this column's tag, reduce, fetch the winner's row
+    if (wave == 0) {
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      bool fail = gc == ws.test_abort_col && b == G - 1;   // test hook: this workgroup behaves as if its wait had expired
+      unsigned bhi = 0, bps = NONE; int bblk = -1;
+      const u64* gbase = ws.cand + (size_t)buf * ws.max_blocks * LU_GRANULE_STRIDE;
+      while (!fail) {
+        bool ok = true; bhi = 0; bps = NONE; bblk = -1;
+        for (int t = lane; t < G; t += 64) {
+          const u64 g = __hip_atomic_load(gbase + (size_t)t * LU_GRANULE_STRIDE, RLX_AGENT);
+          ok = ok && (((unsigned)(g >> 24) & 0xFFu) == want);
+          const unsigned h = (unsigned)(g >> 32), ps = (unsigned)g & NONE;
+          if (ps != NONE && (bps == NONE || h > bhi || (h == bhi && ps < bps))) { bhi = h; bps = ps; bblk = t; }
+        }
+        const unsigned ab = __hip_atomic_load(ws.timeout, RLX_AGENT);     // the plan's abort flag rides along
+        if (__all(ok)) break;
+        if (ab != 0u) { fail = true; break; }
+        __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;   // 4 s at 100 MHz: never hang
+      }
+      MA_RSTAMP(2);
+      const unsigned mh = wave_umax(bps != NONE ? bhi : 0u);
+      const unsigned pk = (bps != NONE && bhi == mh) ? bps : NONE;
+      const unsigned p = wave_umin(pk);
+      const u64 wm = __ballot(pk == p && p != NONE);
+      const int wb = wm ? __shfl(bblk, (int)__builtin_ctzll(wm), 64) : -1;
+      if (!fail) {
+        dc v = dc_make(0.0, 0.0);                        // no candidate anywhere: a zero pivot row, the column is skipped as singular
+        if (wb >= 0) {
+          const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX);
+          const int j = lane < NB ? lane : 0;
+          v = dc_make(ld_sc1(src + 2 * j), ld_sc1(src + 2 * j + 1));
+          if constexpr (c > 0) {
+            // the row was sent with the previous column's update due on the columns right of c: complete it (the sender's own copy
+            // goes through the same two fused multiply-adds per component in its registers)
+            const dc lp = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
+            const dc u = s_urow[(c - 1) & 1][j];
+            if (lane > c) {
+              v.re = __builtin_fma(lp.im, u.im, __builtin_fma(-lp.re, u.re, v.re));
+              v.im = __builtin_fma(-lp.im, u.re, __builtin_fma(-lp.re, u.im, v.im));
+            }
+          }
+        }
+        if (lane < NB) s_urow[buf][lane] = v;
+      }
+      if (lane == 0) {
+        if (fail) { __hip_atomic_store(ws.timeout, 1u, RLX_AGENT); s_misc[1] = 1; }
+        s_misc[0] = (wb >= 0 && p < (unsigned)n && p >= (unsigned)gc) ? (int)p : gc;
+      }
+    }
+    __syncthreads();                                     // B2(c): pivot row and position of column c are in LDS
+    MA_RSTAMP(3);
+    if (s_misc[1]) {                                     // uniform: the whole workgroup gives up; the columns it did not reach get
+      if (b == 0) for (int j = c + tid; j < nbc; j += 256) ipiv[k0 + j] = k0 + j;   // identity pivots (the plan is poisoned: MA_ERR_HIP)
+      dead = true;
+    } else {
+    const int p = s_misc[0];
+    const dc piv = s_urow[buf][c];
+    // lu.rs:106-110: a pivot column whose largest |z| is below 1e-30 is LuError::SingularMatrix; its elimination is skipped
+    const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
+    if (b == 0 && tid == 0) { ipiv[gc] = p; if (singular) atomicCAS(ws.info, 0, gc + 1); }
+    upd_pending = false;
+    if (!done) {
+      if (mypos == p) { done = true; mypos = gc; }       // this row is the pivot row: it rests at position k0 + c from now on
+      else {
+        if (mypos == gc) mypos = p;                      // the row that sat on the diagonal takes the pivot's place
+        if (!singular) {
+          const dc l = a[c] * crecip(piv);
+          a[c] = l;
+          lprev = l; upd_pending = true;
+          if constexpr (c + 1 < NB) {                    // the next column at once: its candidates go out before the rest of this update
+            const dc u = s_urow[buf][c + 1];
+            a[c + 1].re = __builtin_fma(l.im, u.im, __builtin_fma(-l.re, u.re, a[c + 1].re));
+            a[c + 1].im = __builtin_fma(-l.im, u.re, __builtin_fma(-l.re, u.im, a[c + 1].im));
+          }
+        }
+      }
+    }
+    if constexpr (c + 1 < NB) {
+      if (c + 1 < nbc) {
+        candidate(a[c + 1]);
+        __syncthreads();                                 // B1(c + 1)
+      }
+    }
+    MA_RSTAMP(4);
+    }
+    }
+  });
+  if (valid && !dead) {
+    dc* dst = A + (size_t)mypos * n + k0;
+    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if (j < nbc) dst[j] = a[j]; });
+  }
+#ifdef MA_PANEL_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MA_RSTAMP(6);
+  if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, stamp_acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ panel factorisation of several systems, a wavefront each
@@ -1451,14 +1665,15 @@ int lu_panel_configure() {
 // read from an aborted panel.
 namespace {
 constexpr int kSeqRing = 256;                          // launches remembered per device
-struct PanelLaunch { hipEvent_t ev = nullptr; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; int regs = 0; bool used = false; };
+struct PanelLaunch { hipEvent_t ev = nullptr; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; int regs = 0; int ncu = 0; bool used = false; };
 struct PanelSequencer {
   std::mutex mu;
   PanelLaunch ring[16][kSeqRing];
   bool made[16] = {};
   unsigned long long count[16] = {};
-  int regs[2] = {0, 0};      // vector registers per lane of lu_panel_kernel, lu_panel_wave_kernel
+  int regs[3] = {0, 0, 0};   // vector registers per lane of lu_panel_kernel, lu_panel_wave_kernel, lu_panel_reg_kernel
   int occ_checked_lds = 0;
+  bool occ_checked_reg = false;
 };
 PanelSequencer g_seq;
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -1478,14 +1693,14 @@ size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long
 int lu_panel_regs(int kind) {
   std::lock_guard<std::mutex> lock(g_seq.mu);
   if (g_seq.regs[0] == 0) {
-    const void* f[2] = {reinterpret_cast<const void*>(lu_panel_kernel), reinterpret_cast<const void*>(lu_panel_wave_kernel)};
-    for (int q = 0; q < 2; ++q) {
+    const void* f[3] = {reinterpret_cast<const void*>(lu_panel_kernel), reinterpret_cast<const void*>(lu_panel_wave_kernel), reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>)};
+    for (int q = 0; q < 3; ++q) {
       hipFuncAttributes fa;
       MA_HIP(hipFuncGetAttributes(&fa, f[q]));
       g_seq.regs[q] = fa.numRegs > 0 ? fa.numRegs : 128;
     }
   }
-  return g_seq.regs[kind == 1 ? 1 : 0];
+  return g_seq.regs[kind >= 0 && kind <= 2 ? kind : 0];
 }
 
 // MA_OK when a grid of nblk workgroups with this panel shape can be co-resident on ncu CUs on its own
@@ -1498,19 +1713,25 @@ int lu_panel_admissible(int nb, int rpb, int nblk, int ncu) {
   return MA_OK;
 }
 
-// admission + launch of either panel kernel: nsys = 1 -> lu_panel_kernel on (A[0], ws[0], ipiv[0]); nsys > 1 -> lu_panel_wave_kernel
-static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
+// LDS the register panel kernel declares (static: pivot row, staging row, a few words)
+static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 64; }
+
+// admission + launch of a panel kernel. kind 0: lu_panel_kernel on (A[0], ws[0], ipiv[0]); kind 1: lu_panel_wave_kernel over nsys
+// systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
+// CUs the stream may use (a CU-masked stream: the CUs of its mask).
+static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
   MA_REQUIRE(nsys >= 1 && nsys <= LU_GROUP_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
+  MA_REQUIRE(kind == 2 ? (nsys == 1 && rpb == 256 && nb >= 1 && nb <= LU_REG_NB) : (kind == (nsys == 1 ? 0 : 1)), MA_ERR_INVALID, "panel kernel kind %d with %d systems, %d rows per workgroup, %d columns", kind, nsys, rpb, nb);
   const LuPanelWs& ws = wss[0];
   MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
   MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,
              "panel grid (%d workgroups of %d rows from row %d) does not tile the %d rows", nblk, rpb, k0, n);
-  const int kind = nsys == 1 ? 0 : 1;                                    // lu_panel_kernel or lu_panel_wave_kernel
+  MA_REQUIRE(n < 0xFFFFFF, MA_ERR_UNSUPPORTED, "row positions travel in 24 bits of the exchange granule");
   const size_t sys_lds = (lu_panel_lds_bytes(nb, rpb) + 15) & ~(size_t)15;
-  const size_t lds = kind == 0 ? lu_panel_lds_bytes(nb, rpb) : sys_lds * (size_t)nsys;
+  const size_t lds = kind == 2 ? lu_panel_reg_lds() : (kind == 0 ? lu_panel_lds_bytes(nb, rpb) : sys_lds * (size_t)nsys);
   const int regs = lu_panel_regs(kind);
   {
     const int p = lu_panel_slots_per_cu(lds, regs);
@@ -1522,14 +1743,15 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
     for (int i = 0; i < kSeqRing; ++i) MA_HIP(hipEventCreateWithFlags(&g_seq.ring[dev][i].ev, hipEventDisableTiming));
     g_seq.made[dev] = true;
   }
-  if ((int)lds > g_seq.occ_checked_lds) {
+  if (kind == 2 ? !g_seq.occ_checked_reg : (int)lds > g_seq.occ_checked_lds) {
     // the runtime's own occupancy figure must not be below the slots the rule assumes (registers, waves, LDS granularity)
     int occ = 0;
     if (kind == 0) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
-    else MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_wave_kernel), 64 * nsys, lds));
+    else if (kind == 1) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_wave_kernel), 64 * nsys, lds));
+    else MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>), 256, 0));
     MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU at %zu B LDS is below the %d slots the admission rule assumes",
                occ, lds, lu_panel_slots_per_cu(lds, regs));
-    g_seq.occ_checked_lds = (int)lds;
+    if (kind == 2) g_seq.occ_checked_reg = true; else g_seq.occ_checked_lds = (int)lds;
   }
   // Admission. Streams are in order, so at most ONE panel kernel per stream runs at any time, and what may run beside this
   // launch is, per other stream, one of that stream's earlier launches (later launches do their own admission and count this
@@ -1538,7 +1760,9 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
   // waits for the LATEST launch of the stream whose latest launch is oldest (that stream then contributes nothing: all its
   // earlier launches are over when this kernel starts), and so on until the rest fits. For equal shapes on three lanes this
   // is "wait for the launch before the previous one"; the running set is always bounded by what its newest member computed,
-  // so the residency argument above applies to it.
+  // so the residency argument above applies to it. With CU-masked streams in the window the CUs counted are those of the
+  // SMALLEST set any member may use (grids on a mask share its CUs with every unmasked grid): a grid that needs more than
+  // that runs on its own, which the check above has already allowed.
   const unsigned long long i = g_seq.count[dev];
   PanelLaunch* ring = g_seq.ring[dev];
   PanelLaunch& me = ring[i % kSeqRing];
@@ -1550,25 +1774,25 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
     (void)hipGetLastError();
   }
   const unsigned long long oldest = i >= (unsigned long long)(kSeqRing - 1) ? i - (kSeqRing - 1) : 0ull;
-  struct Lane { hipStream_t st; unsigned long long latest; long long nblk; size_t lds; int regs; };
+  struct Lane { hipStream_t st; unsigned long long latest; long long nblk; size_t lds; int regs; int ncu; };
   Lane lanes[16]; int nlanes = 0;
   for (unsigned long long j = i; j-- > oldest;) {             // newest first: the first hit of a stream is its latest launch
     const PanelLaunch& L = ring[j % kSeqRing];
     if (!L.used || L.st == st) continue;
     int q = 0;
     while (q < nlanes && lanes[q].st != L.st) ++q;
-    if (q == nlanes) { if (nlanes == 16) continue; lanes[nlanes++] = {L.st, j, L.nblk, L.lds, L.regs}; }
-    else { if (L.nblk > lanes[q].nblk) lanes[q].nblk = L.nblk; if (L.lds > lanes[q].lds) lanes[q].lds = L.lds; if (L.regs > lanes[q].regs) lanes[q].regs = L.regs; }
+    if (q == nlanes) { if (nlanes == 16) continue; lanes[nlanes++] = {L.st, j, L.nblk, L.lds, L.regs, L.ncu}; }
+    else { if (L.nblk > lanes[q].nblk) lanes[q].nblk = L.nblk; if (L.lds > lanes[q].lds) lanes[q].lds = L.lds; if (L.regs > lanes[q].regs) lanes[q].regs = L.regs; if (L.ncu < lanes[q].ncu) lanes[q].ncu = L.ncu; }
   }
   bool pruned = false;
   for (;;) {
-    long long tot = nblk; size_t smax = lds; int rmax = regs; int victim = -1;
+    long long tot = nblk; size_t smax = lds; int rmax = regs; int cmin = ncu; int victim = -1;
     for (int q = 0; q < nlanes; ++q) {
       if (!lanes[q].st) continue;
-      tot += lanes[q].nblk; if (lanes[q].lds > smax) smax = lanes[q].lds; if (lanes[q].regs > rmax) rmax = lanes[q].regs;
+      tot += lanes[q].nblk; if (lanes[q].lds > smax) smax = lanes[q].lds; if (lanes[q].regs > rmax) rmax = lanes[q].regs; if (lanes[q].ncu < cmin) cmin = lanes[q].ncu;
       if (victim < 0 || lanes[q].latest < lanes[victim].latest) victim = q;
     }
-    if (victim < 0 || tot <= (long long)lu_panel_slots_per_cu(smax, rmax) * ncu) break;
+    if (victim < 0 || tot <= (long long)lu_panel_slots_per_cu(smax, rmax) * cmin) break;
     if (!pruned) {                                            // over capacity: forget the streams whose latest launch is over (idle lanes, plans of the past)
       pruned = true;
       for (int q = 0; q < nlanes; ++q) if (lanes[q].st && !pending(ring[lanes[q].latest % kSeqRing].ev)) lanes[q].st = nullptr;
@@ -1583,7 +1807,8 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
   if (clear_tags) for (int t = 0; t < nsys; ++t) MA_HIP(hipMemsetAsync(wss[t].cand, 0, lu_panel_granule_bytes(wss[t].max_blocks), st));
-  if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
+  if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0]);
+  else if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
   else {
     LuPanelBatch B;
     B.nsys = nsys;
@@ -1593,7 +1818,7 @@ static int launch_panel_any(int nsys, c64* const* As, int n, int k0, int nb, int
   }
   MA_HIP(hipGetLastError());
   MA_HIP(hipEventRecord(me.ev, st));
-  me.nblk = nblk; me.lds = lds; me.regs = regs; me.st = st; me.used = true;
+  me.nblk = nblk; me.lds = lds; me.regs = regs; me.ncu = ncu; me.st = st; me.used = true;
   g_seq.count[dev] = i + 1;
   return MA_OK;
 }
@@ -1607,11 +1832,21 @@ void lu_panel_forget_stream(int dev, hipStream_t st) {
 }
 
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
-  return launch_panel_any(1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
+  return launch_panel_any(0, 1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
+}
+// the register-resident panel kernel: 256 rows per workgroup, nb <= LU_REG_NB columns; ncu = the CUs `st` may use
+int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
+  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st);
+}
+// MA_OK when a register-panel grid of nblk workgroups can be co-resident on ncu CUs on its own
+int lu_panel_reg_admissible(int nblk, int ncu) {
+  const int p = lu_panel_slots_per_cu(lu_panel_reg_lds(), lu_panel_regs(2));
+  MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED, "register panel grid of %d workgroups cannot be co-resident on %d CUs (%d per CU)", nblk, ncu, p);
+  return MA_OK;
 }
 // the same panel of nsys systems (a lock-step batch) in one co-resident grid, a wavefront per system: lu_panel_wave_kernel
 int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
-  return launch_panel_any(nsys, As, n, k0, nb, rpb, nblk, ncu, wss, ipivs, clear_tags, st);
+  return launch_panel_any(1, nsys, As, n, k0, nb, rpb, nblk, ncu, wss, ipivs, clear_tags, st);
 }
 
 // Apply panel (k0, nb)'s interchanges to the columns [x0, x1) U [y0, y1) of A and to the nrhs right-hand sides.

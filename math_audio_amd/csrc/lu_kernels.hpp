@@ -3,6 +3,7 @@
 #include "ma_common.hpp"
 
 #define LU_NB_MAX 128
+#define LU_REG_NB 32            /* panel width of lu_panel_reg_kernel: a row's entries live in 4 * LU_REG_NB vector registers */
 #define LU_BATCH_MAX 8          /* systems (slots) a plan keeps resources for */
 #define LU_GROUP_MAX 4          /* systems one panel kernel factors together (a wavefront each) / lock-step batch size of the public API */
 
@@ -27,11 +28,13 @@ size_t lu_panel_lds_bytes(int nb, int rpb);
 size_t lu_panel_granule_bytes(int max_blocks);
 int lu_panel_configure();
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
+int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
+int lu_panel_reg_admissible(int nblk, int ncu);
 int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st);
 void lu_panel_forget_stream(int dev, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);
 int lu_panel_slots_per_cu(size_t lds, int regs);
-int lu_panel_regs(int kind);   /* 0 lu_panel_kernel, 1 lu_panel_wave_kernel */
+int lu_panel_regs(int kind);   /* 0 lu_panel_kernel, 1 lu_panel_wave_kernel, 2 lu_panel_reg_kernel */
 int lu_panel_admissible(int nb, int rpb, int nblk, int ncu);
 int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs, hipStream_t st);
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,

@@ -9,6 +9,12 @@
 using namespace ma;
 
 #define LU_LISTS_LEN (1 + 4 * LU_NB_MAX)
+#ifndef MA_LU_REG_PANEL_DEFAULT
+#define MA_LU_REG_PANEL_DEFAULT 0
+#endif
+#ifndef MA_LU_CU_SPLIT_DEFAULT
+#define MA_LU_CU_SPLIT_DEFAULT 0
+#endif
 #define LU_KB_MAX 8                         // panels per trailing update
 #define LU_LANE_TSTRIDE 512                   // the lane's interchanges touch at most (kb-1) panels' columns: 7 x 64 or 3 x 128
 
@@ -68,6 +74,21 @@ struct ma_lu_plan {
   // the other groups' trailing updates. 0 / 1: every slot on its own (the round-1 pipeline).
   int stage_group = 0;
   bool stage_lane_pending[LU_BATCH_MAX] = {};
+  // round 3: panels by lu_panel_reg_kernel (rows in registers, 32 columns, 256 rows per workgroup) when the tallest panel fits
+  // (MA_LU_REG_PANEL=0: the LDS-resident lu_panel_kernel), and in the staged schedule the chip split in two sets of CUs
+  // (MA_LU_CU_SPLIT=<P>, 0 = off): the panel kernels run on streams whose CU mask holds P CUs (P / 8 per XCD), the big trailing
+  // updates on a stream masked to the other ncu - P -- the exchange of a panel kernel then runs at its idle round trip instead of
+  // 2-3 x that beside update workgroups on the same CU (profiles/r03_cumask_probe.txt)
+  bool reg_panel = false;
+  int cu_split = 0;
+  int chain_mask = 0;                                     // MA_LU_CHAIN_MASK=1: the per-panel chain launches on streams masked to the update CUs too
+  int pan_mask = 0;                                       // MA_LU_PAN_MASK=1: the panel kernels on streams of their own, masked to the P panel CUs (0: only the big updates are masked
+                                                          // away from those CUs; every masked stream is one more hardware queue, and more than 4-5 busy queues cost more than they buy)
+  hipStream_t pan_streams[LU_BATCH_MAX] = {};             // mask A: panel kernels of slot m
+  hipStream_t chain_streams[LU_BATCH_MAX] = {};           // mask B (chain_mask) -- otherwise panel_streams[m] carries the chain
+  hipStream_t big_stream = nullptr;                       // mask B: the K = 256 updates of all slots
+  hipEvent_t ev_pan[LU_BATCH_MAX] = {}, ev_chain[LU_BATCH_MAX] = {};
+  int panel_cus() const { return cu_split > 0 ? cu_split : ncu; }
 };
 
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
@@ -170,6 +191,22 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (const char* eb = getenv("MA_LU_BATCH_NB")) { int v = atoi(eb); if (v >= 16 && v <= LU_NB_MAX && v % 16 == 0) P->batch_nb = v; }
   if (const char* eb = getenv("MA_LU_BATCH_LDS")) { int v = atoi(eb); if (v >= 16 && v <= 150) P->batch_lds = v * 1024; }
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
+  // the register panel kernel when the tallest panel's workgroups (256 rows each) are co-resident on the CUs its stream may use
+  {
+    int want_reg = MA_LU_REG_PANEL_DEFAULT, split = MA_LU_CU_SPLIT_DEFAULT;
+    if (const char* er = getenv("MA_LU_REG_PANEL")) want_reg = atoi(er);
+    if (const char* es = getenv("MA_LU_CU_SPLIT")) split = atoi(es);
+    if (const char* ec = getenv("MA_LU_CHAIN_MASK")) P->chain_mask = atoi(ec) != 0;
+    if (const char* ep = getenv("MA_LU_PAN_MASK")) P->pan_mask = atoi(ep) != 0;
+    if (split < 8 || split % 8 != 0 || split > ncu - 64 || ncu % 32 != 0 || !P->lookahead || !P->panel_overlap) split = 0;
+    P->cu_split = split;
+    if (!rc && want_reg && n <= 65535) {
+      const int nblk0 = (n + 255) / 256;
+      if (nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, (split && P->pan_mask) ? split : ncu) == MA_OK) P->reg_panel = true;
+      else if (split && P->pan_mask && nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, ncu) == MA_OK) { P->pan_mask = 0; P->reg_panel = true; }   // too tall for the panel CUs: panels anywhere
+    }
+    if (!P->reg_panel) P->pan_mask = 0;                   // the LDS-resident panel kernel's grid does not fit a small CU set: only the big updates are masked
+  }
   for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
   if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
   P->pws = P->pws_m[0];
@@ -178,7 +215,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     // that asks for more LDS per workgroup than the chip can hold at the grid's size is refused here, not at the first launch
     std::vector<int> k0s, nbs, rpbs, nblks;
     panel_schedule(P, k0s, nbs, rpbs, nblks);
-    for (size_t q = 0; q < k0s.size() && !rc; ++q)
+    for (size_t q = 0; q < k0s.size() && !rc && !P->reg_panel; ++q)
       if (q == 0 || rpbs[q] != rpbs[q - 1] || nbs[q] != nbs[q - 1] || nblks[q] > nblks[q - 1]) rc = lu_panel_admissible(nbs[q], rpbs[q], nblks[q], P->ncu);
     if (rc && (P->rpb_env || getenv("MA_LU_NB"))) rc = MA_ERR_INVALID;      // the text of the refusal is already in the error string
   }
@@ -201,6 +238,19 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_prep[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_lane[i], hipEventDisableTiming);
     if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&P->ev_bp, hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_pan[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_chain[i], hipEventDisableTiming);
+    if (e4 == hipSuccess && P->cu_split) {
+      // CU masks: bit i of the mask is CU (i / 8 mod 4 SEs ...) of XCD i mod 8 (tools/cumask_probe.hip): bits [0, P) are P / 8 CUs of
+      // every XCD. Masked streams are blocking streams (the only kind hipExtStreamCreateWithCUMask makes): a caller that drives the
+      // staged schedule from the NULL stream serialises against them -- use a non-blocking stream (bench.py, ma_bem_solve_sweep do)
+      const int words = ncu / 32;
+      std::vector<uint32_t> mA(words, 0u), mB(words, 0u);
+      for (int i = 0; i < ncu; ++i) (i < P->cu_split ? mA : mB)[i / 32] |= 1u << (i % 32);
+      for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess && P->pan_mask; ++i) e4 = hipExtStreamCreateWithCUMask(&P->pan_streams[i], words, mA.data());
+      for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess && P->chain_mask; ++i) e4 = hipExtStreamCreateWithCUMask(&P->chain_streams[i], words, mB.data());
+      if (e4 == hipSuccess) e4 = hipExtStreamCreateWithCUMask(&P->big_stream, words, mB.data());
+    }
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
   }
   if (rc) { ma_lu_plan_destroy(P); return rc; }
@@ -214,7 +264,9 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   // nothing of this plan may still be running when its streams and workspaces go (the panel sequencer keeps events that
   // were recorded on these streams)
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) (void)hipStreamSynchronize(P->panel_streams[i]); if (P->mid_streams[i]) (void)hipStreamSynchronize(P->mid_streams[i]); }
-  for (int i = 0; i < LU_BATCH_MAX; ++i) { lu_panel_forget_stream(P->device, P->panel_streams[i]); lu_panel_forget_stream(P->device, P->mid_streams[i]); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->pan_streams[i]) (void)hipStreamSynchronize(P->pan_streams[i]); if (P->chain_streams[i]) (void)hipStreamSynchronize(P->chain_streams[i]); }
+  if (P->big_stream) (void)hipStreamSynchronize(P->big_stream);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { lu_panel_forget_stream(P->device, P->panel_streams[i]); lu_panel_forget_stream(P->device, P->mid_streams[i]); lu_panel_forget_stream(P->device, P->pan_streams[i]); }
   lu_panel_forget_stream(P->device, P->panel_stream);
   for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
@@ -223,6 +275,9 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]);
     if (P->ev_prep[i]) (void)hipEventDestroy(P->ev_prep[i]); if (P->ev_mid[i]) (void)hipEventDestroy(P->ev_mid[i]); if (P->ev_big[i]) (void)hipEventDestroy(P->ev_big[i]); if (P->mid_streams[i]) (void)hipStreamDestroy(P->mid_streams[i]); }
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->pan_streams[i]) (void)hipStreamDestroy(P->pan_streams[i]); if (P->chain_streams[i]) (void)hipStreamDestroy(P->chain_streams[i]);
+    if (P->ev_pan[i]) (void)hipEventDestroy(P->ev_pan[i]); if (P->ev_chain[i]) (void)hipEventDestroy(P->ev_chain[i]); }
+  if (P->big_stream) (void)hipStreamDestroy(P->big_stream);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
     if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
@@ -265,6 +320,10 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 // panels of the factorisation: first column, width, rows per panel workgroup, workgroups
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks) {
   const int n = P->n;
+  if (P->reg_panel) {                                     // rows in registers: 256 rows per workgroup, LU_REG_NB columns per panel
+    for (int k0 = 0; k0 < n; k0 += LU_REG_NB) { k0s.push_back(k0); nbs.push_back(std::min(n - k0, LU_REG_NB)); rpbs.push_back(256); nblks.push_back((n - k0 + 255) / 256); }
+    return;
+  }
   for (int k0 = 0; k0 < n;) {
     int nb, rpb, nblk;
     // rows per panel workgroup: at most 47.5 KB of LDS, so that two systems' panel workgroups AND two trailing-update
@@ -290,6 +349,12 @@ static void panel_schedule_batched(const ma_lu_plan* P, int nsys, std::vector<in
     k0s.push_back(k0); nbs.push_back(nb); rpbs.push_back(rpb); nblks.push_back(nblk);
     k0 += nb;
   }
+}
+
+// one panel of system (A, ws, ipiv) on stream st: the kernel the plan's schedule was made for
+static int launch_panel(ma_lu_plan* P, c64* A, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st, bool masked) {
+  if (P->reg_panel) return lu_launch_panel_reg(A, P->n, k0, nb, nblk, masked ? P->panel_cus() : P->ncu, ws, ipiv, clear_tags, st);
+  return lu_launch_panel(A, P->n, k0, nb, rpb, nblk, P->ncu, ws, ipiv, clear_tags, st);
 }
 
 // panels per trailing update: K = kb * nb = 256 (tall systems factor in narrower panels -- 32 columns from 36 353 rows
@@ -372,7 +437,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     for (int q = blk_first(g); q < blk_last(g); ++q) {
       const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
       MA_MARK(t0, sp);
-      if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp))) return rc;
+      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp, false))) return rc;
       MA_MARK(t1, sp);
       interval(P, t0, t1, 0);
       // the panel's gather lists and inverted diagonal blocks: once, here; the main lane reuses them
@@ -559,7 +624,9 @@ struct Stage {
   int blk_first(int g) const { return g * kb; }
   int blk_last(int g) const { return std::min(Q, (g + 1) * kb); }
   int blk_end(int g) const { int q = blk_last(g) - 1; return k0s[q] + nbs[q]; }
-  hipStream_t lane_stream(int m) const { return P->panel_streams[m]; }
+  hipStream_t lane_stream(int m) const { return (P->cu_split && P->chain_mask) ? P->chain_streams[m] : P->panel_streams[m]; }
+  hipStream_t pan_stream(int m) const { return (P->cu_split && P->pan_mask) ? P->pan_streams[m] : lane_stream(m); }
+  hipStream_t big_stream() const { return P->cu_split ? P->big_stream : st; }
   int gemm(int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_) {
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
     P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;
@@ -571,10 +638,14 @@ struct Stage {
     const int e = blk_end(g);
     for (int q = blk_first(g); q < blk_last(g); ++q) {
       const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
-      MA_MARKD(t0, sp);
-      if ((rc = lu_launch_panel(A, n, k0, nb, rpbs[q], nblks[q], P->ncu, P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp))) return rc;
-      MA_MARKD(t1, sp);
+      // the panel kernel on the slot's panel stream (its own CUs when the chip is split), the rest of the chain on the lane stream
+      hipStream_t pp = pan_stream(m);
+      if (pp != sp) { MA_HIP(hipEventRecord(P->ev_chain[m], sp)); MA_HIP(hipStreamWaitEvent(pp, P->ev_chain[m], 0)); }
+      MA_MARKD(t0, pp);
+      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, pp, pp != sp))) return rc;
+      MA_MARKD(t1, pp);
       interval(P, t0, t1, 0);
+      if (pp != sp) { MA_HIP(hipEventRecord(P->ev_pan[m], pp)); MA_HIP(hipStreamWaitEvent(sp, P->ev_pan[m], 0)); }
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
@@ -673,12 +744,13 @@ struct Stage {
     const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
     if (nright <= 0) return MA_OK;
-    MA_HIP(hipStreamWaitEvent(st, P->ev_mid[m], 0));
-    MA_MARK(t5, st);
-    if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, st))) return rc;
-    MA_MARK(t6, st);
+    hipStream_t bs = big_stream();
+    MA_HIP(hipStreamWaitEvent(bs, P->ev_mid[m], 0));
+    MA_MARK(t5, bs);
+    if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, bs))) return rc;
+    MA_MARK(t6, bs);
     interval(P, t5, t6, 3);
-    MA_HIP(hipEventRecord(P->ev_big[m], st));
+    MA_HIP(hipEventRecord(P->ev_big[m], bs));
     return MA_OK;
   }
   int backsub(int m) {
@@ -728,7 +800,14 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
 // slot's next system there, beside the other slots' work, and pass the same stream to stage_begin)
 int ma_lu_plan_slot_stream(ma_lu_plan_t* P, int32_t slot, void** stream) {
   MA_REQUIRE(P && stream && slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "bad argument");
-  *stream = (void*)P->panel_streams[slot];
+  *stream = (void*)((P->cu_split && P->chain_mask) ? P->chain_streams[slot] : P->panel_streams[slot]);
+  return MA_OK;
+}
+// the stream the plan runs its big trailing updates on when the chip is split (MA_LU_CU_SPLIT): masked to the update CUs. A driver
+// that issues its own work between stage calls (assembly) may put it there instead of on a stream of its own; NULL when not split
+int ma_lu_plan_main_stream(ma_lu_plan_t* P, void** stream) {
+  MA_REQUIRE(P && stream, MA_ERR_INVALID, "bad argument");
+  *stream = (void*)(P->cu_split ? P->big_stream : nullptr);
   return MA_OK;
 }
 int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, int32_t nrhs, void* stream) {
@@ -745,6 +824,7 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
   MA_HIP(hipMemsetAsync(P->pws.info + slot, 0, sizeof(int), st));          // this slot's first-zero-pivot word
   MA_HIP(hipEventRecord(P->ev_prep[slot], st));
   MA_HIP(hipStreamWaitEvent(P->panel_streams[slot], P->ev_prep[slot], 0));
+  if (P->cu_split && P->chain_mask) MA_HIP(hipStreamWaitEvent(P->chain_streams[slot], P->ev_prep[slot], 0));
   if (P->stage_group >= 2) {                               // group mode: the first panels start when the whole group has begun (stage_begin_group)
     if (slot % P->stage_group != 0) { MA_HIP(hipEventRecord(P->ev_lane[slot], P->panel_streams[slot])); P->stage_lane_pending[slot] = true; }
     return MA_OK;
@@ -898,6 +978,8 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i])); if (P->mid_streams[i]) MA_HIP(hipStreamSynchronize(P->mid_streams[i])); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->pan_streams[i]) MA_HIP(hipStreamSynchronize(P->pan_streams[i])); if (P->chain_streams[i]) MA_HIP(hipStreamSynchronize(P->chain_streams[i])); }
+  if (P->big_stream) MA_HIP(hipStreamSynchronize(P->big_stream));
   int info[16];
   MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
   MA_REQUIRE(info[LU_BATCH_MAX] != 2, MA_ERR_HIP, "a panel left a pivot outside its range: the factorisation was abandoned (no rows were moved with it)");
@@ -913,6 +995,8 @@ int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipEventSynchronize(P->ev[P->ev_last]));
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->panel_streams[i]) MA_HIP(hipStreamSynchronize(P->panel_streams[i])); if (P->mid_streams[i]) MA_HIP(hipStreamSynchronize(P->mid_streams[i])); }
+  for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->pan_streams[i]) MA_HIP(hipStreamSynchronize(P->pan_streams[i])); if (P->chain_streams[i]) MA_HIP(hipStreamSynchronize(P->chain_streams[i])); }
+  if (P->big_stream) MA_HIP(hipStreamSynchronize(P->big_stream));
   for (int i = 0; i < 8; ++i) out8[i] = 0.0;
   for (const auto& v : P->iv) {
     float ms = 0.f;

@@ -54,3 +54,27 @@ def helmholtz_box(nx, ny, nz, lx=5.0, ly=4.0, lz=2.5):
     """The F1M family of SURVEY §8: box 5 x 4 x 2.5 m, (nx+1)(ny+1)(nz+1) nodes, 6 nx ny nz tets."""
     nodes, tets = box_mesh_tetrahedra(0.0, lx, 0.0, ly, 0.0, lz, nx, ny, nz)
     return (nodes,) + assemble_p1(nodes, tets)
+
+
+def boundary_nodes(tets):
+    """Nodes on faces that belong to exactly one tetrahedron (Mesh::detect_boundaries, math-fem/src/mesh/types.rs:357-401)."""
+    faces = np.concatenate([tets[:, [0, 1, 2]], tets[:, [0, 1, 3]], tets[:, [0, 2, 3]], tets[:, [1, 2, 3]]], axis=0)
+    faces = np.sort(faces, axis=1)
+    uniq, counts = np.unique(faces, axis=0, return_counts=True)
+    return np.unique(uniq[counts == 1].ravel())
+
+
+def apply_dirichlet_csr(row_ptr, col, values, rhs, nodes_idx, node_values):
+    """apply_dirichlet (math-fem/src/boundary/dirichlet.rs:72-175) on a CSR system: b_j -= A_ji g_i for free rows j, Dirichlet
+    rows become identity rows with b_i = g_i, Dirichlet columns are dropped. Returns (row_ptr, col, values, rhs) of the new system;
+    host plumbing in front of the device solve, like the generator above."""
+    n = len(row_ptr) - 1
+    A = sp.csr_matrix((np.asarray(values, dtype=np.complex128), np.asarray(col), np.asarray(row_ptr)), shape=(n, n))
+    g = np.zeros(n, dtype=np.complex128); g[nodes_idx] = node_values
+    fixed = np.zeros(n, dtype=bool); fixed[nodes_idx] = True
+    b = np.asarray(rhs, dtype=np.complex128) - A @ g                  # g is zero on the free nodes: only Dirichlet columns contribute
+    b[fixed] = g[fixed]
+    keep = sp.diags((~fixed).astype(np.float64))
+    B = (keep @ A @ keep + sp.diags(fixed.astype(np.complex128))).tocsr()
+    B.eliminate_zeros(); B.sort_indices()
+    return B.indptr.astype(np.int64), B.indices.astype(np.int64), B.data.astype(np.complex128), b
