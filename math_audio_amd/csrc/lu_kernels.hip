@@ -52,6 +52,23 @@ __device__ __forceinline__ dc crecip(dc z) {
   return dc_make(e / f, -1.0 / f);
 }
 
+// the same reciprocal with v_rcp_f64 + two Newton steps in place of the three IEEE divisions (about 600 cycles on the critical
+// path of every column of lu_panel_reg_kernel): within 2 ulp of crecip
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ dc crecip_fast(dc z) {
+  if (__builtin_fabs(z.im) < __builtin_fabs(z.re)) {
+    const double e = z.im * rcp_nr(z.re), g = rcp_nr(__builtin_fma(z.im, e, z.re));
+    return dc_make(g, -e * g);
+  }
+  const double e = z.re * rcp_nr(z.im), g = rcp_nr(__builtin_fma(z.re, e, z.im));
+  return dc_make(e * g, -g);
+}
+
 // better (value, row) candidate: larger value, ties -> lower row (izamax takes the first maximum)
 __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) { return v > bv || (v == bv && r < br); }
 
@@ -434,8 +451,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv, int* __restrict__ lists) {
   __shared__ __attribute__((aligned(16))) dc s_urow[2][NB];   // pivot rows of the current and the previous column
+  __shared__ __attribute__((aligned(16))) dc s_stage[NB];     // the row a workgroup sends: written by the lane that holds it, read by 32 lanes
   __shared__ unsigned s_m[4];
   __shared__ unsigned s_pos[4];
   __shared__ int s_lane[4];
@@ -453,19 +471,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const dc* src = A + (size_t)(valid ? row0 : k0) * n + k0;
     static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = (valid && j < nbc) ? src[j] : dc_make(0.0, 0.0); });
   }
-  if (tid == 0) { s_misc[1] = 0; s_misc[2] = (int)__hip_atomic_load(ws.timeout, RLX_AGENT); }
+  if (tid == 0) {
+    s_misc[1] = 0; s_misc[2] = (int)__hip_atomic_load(ws.timeout, RLX_AGENT);
+    // the panel's interchange list (what lu_perm_kernel folds from the pivots): rows end where `mypos` says, so every thread whose
+    // row moved appends (destination, source) itself. The count is cleared here, before this workgroup publishes anything: every
+    // other workgroup's first append comes after a sweep that saw this workgroup's first granule
+    if (b == 0 && lists) { __hip_atomic_store(lists, 0, RLX_AGENT); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  }
   __syncthreads();
   if (s_misc[2] != 0) {                                  // poisoned plan: identity pivots, nothing else (see lu_panel_kernel)
     if (b == 0) for (int j = tid; j < nbc; j += 256) ipiv[k0 + j] = k0 + j;
     return;
   }
 #ifdef MA_PANEL_STAMPS
+  // diagnostic build: [0] sender wave: B1 -> granule stored (ticks), [1] sender count, [2] wave 0: B1 -> sweep starts, [3] sweep time,
+  // [4] sweeps, [5] wave 0: B2 -> B1 of the next column, [6] columns x workgroups, [7] sender: B1 -> row stores issued
   u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  u64 stamp_t = __builtin_amdgcn_s_memrealtime();
-#define MA_RSTAMP(i) do { if (tid == 0) { u64 now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
-#else
-#define MA_RSTAMP(i) do { } while (0)
+  u64 stamp_b1 = __builtin_amdgcn_s_memrealtime(), stamp_b2 = stamp_b1;
+#define MA_NOW() __builtin_amdgcn_s_memrealtime()
 #endif
+#define MA_RSTAMP(i) do { } while (0)
   // this wavefront's candidate of column c: top 32 bits of |re| + |im|, ties to the lowest position
   auto candidate = [&](dc v) {
     const double mag = cabs1(v);
@@ -482,7 +507,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   bool dead = false;                                     // uniform: an exchange was abandoned, the workgroup only falls through
   dc lprev = dc_make(0.0, 0.0);                          // this row's multiplier of the previous column; its rank-1 update is still due on columns > c
   bool upd_pending = false;                              // per lane: the previous column's update is due on this row
-  MA_RSTAMP(5);
   static_for<0, NB>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     if (c < nbc && !dead) {
@@ -497,9 +521,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       if (pw != NONE && (bpos == NONE || mw > bmax || (mw == bmax && pw < bpos))) { bmax = mw; bpos = pw; bw = w; }
     }
     const bool sender = wave == bw;
-    if (sender && bpos != NONE && lane == s_lane[bw]) {
-      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
-      static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; st_sc1(dst + 2 * j, a[j].re); st_sc1(dst + 2 * j + 1, a[j].im); });
+#ifdef MA_PANEL_STAMPS
+    stamp_b1 = MA_NOW();
+#endif
+    if (sender && bpos != NONE) {
+      // one lane's row through LDS to 32 lanes: two coalesced write-through stores instead of 64 single-lane ones (each of those
+      // is a fabric write of its own: 2.0 us until every workgroup's granule was seen against 1.66 with the staging)
+      if (lane == s_lane[bw]) static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; s_stage[j] = a[j]; });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < NB) {
+        const dc v = s_stage[lane];
+        u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX) + 2 * lane;
+        st_sc1(dst, v.re); st_sc1(dst + 1, v.im);
+      }
+#ifdef MA_PANEL_STAMPS
+      if (lane == 0) stamp_acc[7] += MA_NOW() - stamp_b1;
+#endif
     }
     MA_RSTAMP(0);
     // ---- the bulk of the previous column's rank-1 update, on registers; it overlaps the write-through of the row above
@@ -516,53 +554,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         });
       }
     }
-    MA_RSTAMP(1);
     if (sender) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row is out before the granule says so
       if (lane == 0)
         __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE,
                            ((u64)(bpos != NONE ? bmax : 0u) << 32) | ((u64)want << 24) | (u64)bpos, RLX_AGENT);
+#ifdef MA_PANEL_STAMPS
+      if (lane == 0) { stamp_acc[0] += MA_NOW() - stamp_b1; stamp_acc[1] += 1; }
+#endif
     }
     // ---- wavefront 0: sweep every workgroup's granule until all carry this column's tag, reduce, fetch the winner's row
     if (wave == 0) {
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
+#ifdef MA_PANEL_STAMPS
+      if (lane == 0) { stamp_acc[2] += t0 - stamp_b1; stamp_acc[6] += 1; }
+#endif
       bool fail = gc == ws.test_abort_col && b == G - 1;   // test hook: this workgroup behaves as if its wait had expired
       unsigned bhi = 0, bps = NONE; int bblk = -1;
       const u64* gbase = ws.cand + (size_t)buf * ws.max_blocks * LU_GRANULE_STRIDE;
+      // The row of the best candidate SO FAR is fetched while the sweep is still waiting for the other workgroups (a granule that
+      // carries this column's tag is final, and its row was out before it): when the last granule arrives the winner's row is
+      // usually here already or on its way -- one dependent round trip less per column. hv / hl: the prefetched row (lane j: entry j)
+      // and the previous column's multiplier of that row; hb: whose it is (-1: none yet)
+      dc hv = dc_make(0.0, 0.0), hl = dc_make(0.0, 0.0); int hb = -1;
+      int wb = -1; unsigned p = NONE;
+      const int jl = lane < NB ? lane : 0;
+      auto fetch_row = [&](int blk) {
+        const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + blk) * (2 * LU_NB_MAX);
+        hv = dc_make(ld_sc1(src + 2 * jl), ld_sc1(src + 2 * jl + 1));
+        if constexpr (c > 0) hl = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
+        hb = blk;
+      };
       while (!fail) {
         bool ok = true; bhi = 0; bps = NONE; bblk = -1;
         for (int t = lane; t < G; t += 64) {
           const u64 g = __hip_atomic_load(gbase + (size_t)t * LU_GRANULE_STRIDE, RLX_AGENT);
-          ok = ok && (((unsigned)(g >> 24) & 0xFFu) == want);
+          const bool here = (((unsigned)(g >> 24) & 0xFFu) == want);
+          ok = ok && here;
           const unsigned h = (unsigned)(g >> 32), ps = (unsigned)g & NONE;
-          if (ps != NONE && (bps == NONE || h > bhi || (h == bhi && ps < bps))) { bhi = h; bps = ps; bblk = t; }
+          if (here && ps != NONE && (bps == NONE || h > bhi || (h == bhi && ps < bps))) { bhi = h; bps = ps; bblk = t; }
         }
         const unsigned ab = __hip_atomic_load(ws.timeout, RLX_AGENT);     // the plan's abort flag rides along
-        if (__all(ok)) break;
+        // best of the granules that have arrived
+        const unsigned mh = wave_umax(bps != NONE ? bhi : 0u);
+        const unsigned pk = (bps != NONE && bhi == mh) ? bps : NONE;
+        p = wave_umin(pk);
+        const u64 wm = __ballot(pk == p && p != NONE);
+        wb = wm ? __shfl(bblk, (int)__builtin_ctzll(wm), 64) : -1;
+        const bool all = __all(ok);
+#ifdef MA_PANEL_STAMPS
+        if (lane == 0) stamp_acc[4] += 1;
+#endif
+        if (wb >= 0 && wb != hb) fetch_row(wb);
+        if (all) break;
         if (ab != 0u) { fail = true; break; }
         __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;   // 4 s at 100 MHz: never hang
       }
-      MA_RSTAMP(2);
-      const unsigned mh = wave_umax(bps != NONE ? bhi : 0u);
-      const unsigned pk = (bps != NONE && bhi == mh) ? bps : NONE;
-      const unsigned p = wave_umin(pk);
-      const u64 wm = __ballot(pk == p && p != NONE);
-      const int wb = wm ? __shfl(bblk, (int)__builtin_ctzll(wm), 64) : -1;
+#ifdef MA_PANEL_STAMPS
+      if (lane == 0) stamp_acc[3] += MA_NOW() - t0;
+#endif
       if (!fail) {
         dc v = dc_make(0.0, 0.0);                        // no candidate anywhere: a zero pivot row, the column is skipped as singular
         if (wb >= 0) {
-          const u64* src = ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX);
-          const int j = lane < NB ? lane : 0;
-          v = dc_make(ld_sc1(src + 2 * j), ld_sc1(src + 2 * j + 1));
+          v = hv;
           if constexpr (c > 0) {
             // the row was sent with the previous column's update due on the columns right of c: complete it (the sender's own copy
             // goes through the same two fused multiply-adds per component in its registers)
-            const dc lp = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
-            const dc u = s_urow[(c - 1) & 1][j];
+            const dc u = s_urow[(c - 1) & 1][jl];
             if (lane > c) {
-              v.re = __builtin_fma(lp.im, u.im, __builtin_fma(-lp.re, u.re, v.re));
-              v.im = __builtin_fma(-lp.im, u.re, __builtin_fma(-lp.re, u.im, v.im));
+              v.re = __builtin_fma(hl.im, u.im, __builtin_fma(-hl.re, u.re, v.re));
+              v.im = __builtin_fma(-hl.im, u.re, __builtin_fma(-hl.re, u.im, v.im));
             }
           }
         }
@@ -574,7 +636,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       }
     }
     __syncthreads();                                     // B2(c): pivot row and position of column c are in LDS
-    MA_RSTAMP(3);
+#ifdef MA_PANEL_STAMPS
+    stamp_b2 = MA_NOW();
+#endif
     if (s_misc[1]) {                                     // uniform: the whole workgroup gives up; the columns it did not reach get
       if (b == 0) for (int j = c + tid; j < nbc; j += 256) ipiv[k0 + j] = k0 + j;   // identity pivots (the plan is poisoned: MA_ERR_HIP)
       dead = true;
@@ -590,7 +654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       else {
         if (mypos == gc) mypos = p;                      // the row that sat on the diagonal takes the pivot's place
         if (!singular) {
-          const dc l = a[c] * crecip(piv);
+          const dc l = a[c] * crecip_fast(piv);
           a[c] = l;
           lprev = l; upd_pending = true;
           if constexpr (c + 1 < NB) {                    // the next column at once: its candidates go out before the rest of this update
@@ -605,20 +669,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       if (c + 1 < nbc) {
         candidate(a[c + 1]);
         __syncthreads();                                 // B1(c + 1)
+#ifdef MA_PANEL_STAMPS
+        if (tid == 0) stamp_acc[5] += MA_NOW() - stamp_b2;
+#endif
       }
     }
-    MA_RSTAMP(4);
     }
     }
   });
   if (valid && !dead) {
     dc* dst = A + (size_t)mypos * n + k0;
     static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if (j < nbc) dst[j] = a[j]; });
+    if (lists && mypos != row0) {                        // "row mypos holds what row row0 held": at most 2 nbc entries over the whole grid
+      const int idx = atomicAdd(lists, 1);
+      if (idx < 2 * LU_NB_MAX) { lists[1 + idx] = mypos; lists[1 + 2 * LU_NB_MAX + idx] = row0; }
+    }
   }
 #ifdef MA_PANEL_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  MA_RSTAMP(6);
-  if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, stamp_acc[i]);
+  if (lane == 0) for (int i = 0; i < 8; ++i) if (stamp_acc[i]) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, stamp_acc[i]);
 #endif
 }
 
@@ -902,7 +970,9 @@ struct PermLds {
   };
 };
 
+template <bool WIDE>   // WIDE: called by a workgroup of more than 64 threads: threads >= 64 only meet the barriers
 __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, int nb, int d, dc* __restrict__ invd) {
+  const bool act = !WIDE || threadIdx.x < 64;
   // L = [A 0; C B] in 16 x 16 blocks:  L^-1 = [A^-1 0; -B^-1 C A^-1  B^-1].  Lanes 0-15 / 16-31 carry the columns of
   // A^-1 / B^-1 through a 16-row forward substitution (a quarter of the 32-row dependent chain); then lane (j, q)
   // forms rows 4q..4q+3 of column j of W = C A^-1 and of -B^-1 W.
@@ -910,14 +980,14 @@ __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, 
   const int lane = threadIdx.x, base = d * 32;
   const int m = min(32, nb - base);
 #pragma unroll 4
-  for (int idx = lane; idx < 1024; idx += 64) {
+  for (int idx = lane; act && idx < 1024; idx += 64) {
     const int i = idx >> 5, k = idx & 31;
     if (i < 16 && k >= 16) continue;
     const dc v = (i < m && k < i) ? T[(size_t)(base + i) * ldt + base + k] : dc_make(0.0, 0.0);
     if (i < 16) V.LA[i][k] = v; else if (k >= 16) V.LB[i - 16][k - 16] = v; else V.LC[i - 16][k] = v;
   }
   __syncthreads();
-  if (lane < 32) {
+  if (act && lane < 32) {
     // column j of A^-1 (lanes 0-15) / B^-1 (lanes 16-31): x_i = e_i - sum_{k<i} l_ik x_k, the x_k read back from this lane's
     // own column (registers are what this kernel must not need)
     const int j = lane & 15;
@@ -934,22 +1004,24 @@ __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, 
   }
   __syncthreads();
   {
-    const int j = lane & 15, q = lane >> 4;
+    const int j = lane & 15, q = (lane >> 4) & 3;
     dc w[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[r] = dc_make(0.0, 0.0);
 #pragma unroll 1
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; act && k < 16; ++k) {
       const dc a = (k >= j) ? V.XA[k][j] : dc_make(0.0, 0.0);          // A^-1 is lower triangular; above the diagonal XA was never written
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const dc c = V.LC[4 * q + r][k]; w[r].re += c.re * a.re - c.im * a.im; w[r].im += c.re * a.im + c.im * a.re; }
     }
     __syncthreads();                                      // LA is free now: W is parked there
+    if (act) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) V.LA[4 * q + r][j] = w[r];
+    }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; act && r < 4; ++r) {
       const int i = 4 * q + r;
       dc acc = dc_make(0.0, 0.0);
 #pragma unroll 2
@@ -962,7 +1034,7 @@ __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, 
   }
   __syncthreads();
 #pragma unroll 4
-  for (int idx = lane; idx < 1024; idx += 64) {
+  for (int idx = lane; act && idx < 1024; idx += 64) {
     const int i = idx >> 5, k = idx & 31;
     dc v = dc_make(0.0, 0.0);
     if (i < 16) { if (k <= i) v = V.XA[i][k]; }
@@ -976,7 +1048,7 @@ __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, 
 __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
                                                      const dc* __restrict__ T, int ldt, dc* __restrict__ invd, unsigned* __restrict__ poison) {
   __shared__ PermLds S;
-  if (blockIdx.x > 0) { lu_invert_diag32(S, T, ldt, nb, blockIdx.x - 1, invd); return; }
+  if (blockIdx.x > 0) { lu_invert_diag32<false>(S, T, ldt, nb, blockIdx.x - 1, invd); return; }
   // An aborted panel (the plan's poison word is set) has no valid pivots: no rows are moved. The same for a pivot outside
   // [k0 + c, n) -- which a completed panel never produces: the plan is poisoned (code 2) instead of acting on it.
   if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) { if (threadIdx.x == 0) lists[0] = 0; return; }
@@ -1059,6 +1131,84 @@ __global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A
     const dc v = tmp[(size_t)idx * tstride + q];
     if (q < nxy) { const int col = q < nx ? x0 + q : y0 + (q - nx); A[(size_t)d * n + col] = v; }
     else B[(size_t)(q - nxy) * n + d] = v;
+  }
+}
+
+// ------------------------------------------------------------------ one launch between two panels of a block column (round 3)
+// For the columns [x0, x0 + ncols) right of panel (k0, nb <= 32) -- the rest of its block column: the panel's row interchanges
+// and U = L11^-1 A[k0 : k0 + nb, columns], one workgroup per strip of 32 columns: the <= 2 nb moved rows of the strip are read
+// into registers (every read before any write), the rows that land below the panel are written, the panel rows' entries are put
+// together in LDS and go through a right-looking forward substitution with L11 (one barrier per row of L11: 32 x 32 entries per
+// strip need no matrix cores). The LAST workgroup inverts the diagonal block of L11 for the main lane's MFMA triangular solves,
+// beside the strips. Replaces four launches of the per-panel chain (lu_perm_kernel, gather, scatter, lu_trsm64_kernel).
+struct LaneStepLds {
+  union {
+    struct { dc B[32][33], L[32][33]; int dst[2 * LU_NB_MAX], src[2 * LU_NB_MAX]; } strip;
+    PermLds perm;
+  };
+};
+__global__ __launch_bounds__(256) void lu_lane_step_kernel(dc* __restrict__ A, int n, int k0, int nb, const int* __restrict__ lists, int x0, int ncols,
+                                                           dc* __restrict__ invd, const unsigned* __restrict__ poison) {
+  __shared__ LaneStepLds S;
+  const int tid = threadIdx.x;
+  const int nstrips = (ncols + 31) / 32;
+  if ((int)blockIdx.x >= nstrips) {                      // the extra workgroup: inverted diagonal block (identity-padded beyond nb)
+    lu_invert_diag32<true>(S.perm, A + (size_t)k0 * n + k0, n, nb, 0, invd);
+    return;
+  }
+  if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) return;      // an aborted panel has no valid pivots: no rows are moved
+  auto& V = S.strip;
+  int m = lists[0];
+  if (m < 0 || m > 2 * LU_NB_MAX) m = 0;
+  for (int i = tid; i < m; i += 256) { V.dst[i] = lists[1 + i]; V.src[i] = lists[1 + 2 * LU_NB_MAX + i]; }
+  const int c0 = x0 + 32 * (int)blockIdx.x;              // first column of the strip
+  const int wcols = min(32, x0 + ncols - c0);
+  // L11 (strictly lower part; the diagonal is 1) and the panel rows' entries as they stand
+  for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int i = idx >> 5, k = idx & 31;
+    V.L[i][k] = (i < nb && k < i) ? A[(size_t)(k0 + i) * n + k0 + k] : dc_make(0.0, 0.0);
+    V.B[i][k] = (i < nb && k < wcols) ? A[(size_t)(k0 + i) * n + c0 + k] : dc_make(0.0, 0.0);
+  }
+  __syncthreads();
+  // moved rows: element e = (list entry, column) -> registers
+  dc mv[8]; int md[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = tid + 256 * q, idx = e >> 5, col = e & 31;
+    md[q] = -1; mv[q] = dc_make(0.0, 0.0);
+    if (idx < m && col < wcols) {
+      const int sr = V.src[idx], ds = V.dst[idx];
+      if (sr >= 0 && sr < n && ds >= 0 && ds < n) { mv[q] = A[(size_t)sr * n + c0 + col]; md[q] = ds; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every read of the strip has returned ...
+  __syncthreads();                                       // ... in every thread, before the first write
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int col = (tid + 256 * q) & 31;
+    if (md[q] < 0) continue;
+    if (md[q] >= k0 && md[q] < k0 + nb) V.B[md[q] - k0][col] = mv[q];      // lands in the panel rows: joins the triangular solve
+    else A[(size_t)md[q] * n + c0 + col] = mv[q];
+  }
+  __syncthreads();
+  // right-looking forward substitution: row k is final once rows < k have been subtracted from it
+  {
+    const int col = tid & 31, r0 = tid >> 5;             // 8 rows at a time
+    for (int k = 0; k + 1 < nb; ++k) {
+      const dc xk = V.B[k][col];
+      for (int i = k + 1 + r0; i < nb; i += 8) {
+        const dc l = V.L[i][k];
+        dc v = V.B[i][col];
+        v.re = __builtin_fma(l.im, xk.im, __builtin_fma(-l.re, xk.re, v.re));
+        v.im = __builtin_fma(-l.im, xk.re, __builtin_fma(-l.re, xk.im, v.im));
+        V.B[i][col] = v;
+      }
+      __syncthreads();
+    }
+  }
+  for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int i = idx >> 5, k = idx & 31;
+    if (i < nb && k < wcols) A[(size_t)(k0 + i) * n + c0 + k] = V.B[i][k];
   }
 }
 
@@ -1719,7 +1869,8 @@ static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 6
 // admission + launch of a panel kernel. kind 0: lu_panel_kernel on (A[0], ws[0], ipiv[0]); kind 1: lu_panel_wave_kernel over nsys
 // systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
 // CUs the stream may use (a CU-masked stream: the CUs of its mask).
-static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
+static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st,
+                            int* reg_lists = nullptr) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
@@ -1807,7 +1958,7 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
   if (clear_tags) for (int t = 0; t < nsys; ++t) MA_HIP(hipMemsetAsync(wss[t].cand, 0, lu_panel_granule_bytes(wss[t].max_blocks), st));
-  if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0]);
+  if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0], reg_lists);
   else if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
   else {
     LuPanelBatch B;
@@ -1835,8 +1986,16 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   return launch_panel_any(0, 1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
 }
 // the register-resident panel kernel: 256 rows per workgroup, nb <= LU_REG_NB columns; ncu = the CUs `st` may use
-int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
-  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st);
+int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st) {
+  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st, lists);
+}
+// the step between two panels of a block column: interchanges + U = L11^-1 A12 on the columns [x0, x0 + ncols), and the inverted
+// diagonal block of L11 into invd (lists: what lu_launch_panel_reg wrote)
+int lu_launch_lane_step(c64* A, int n, int k0, int nb, const int* lists, int x0, int ncols, c64* invd, const unsigned* poison, hipStream_t st) {
+  MA_REQUIRE(nb >= 1 && nb <= 32 && k0 >= 0 && k0 + nb <= n && ncols >= 0 && x0 >= 0 && x0 + ncols <= n, MA_ERR_INVALID, "lane step outside the matrix");
+  hipLaunchKernelGGL(lu_lane_step_kernel, dim3((ncols + 31) / 32 + 1), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, lists, x0, ncols, reinterpret_cast<dc*>(invd), poison);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
 }
 // MA_OK when a register-panel grid of nblk workgroups can be co-resident on ncu CUs on its own
 int lu_panel_reg_admissible(int nblk, int ncu) {

@@ -200,6 +200,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (const char* ep = getenv("MA_LU_PAN_MASK")) P->pan_mask = atoi(ep) != 0;
     if (split < 8 || split % 8 != 0 || split > ncu - 64 || ncu % 32 != 0 || !P->lookahead || !P->panel_overlap) split = 0;
     P->cu_split = split;
+    if (P->batch_panel) want_reg = 0;                      // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
     if (!rc && want_reg && n <= 65535) {
       const int nblk0 = (n + 255) / 256;
       if (nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, (split && P->pan_mask) ? split : ncu) == MA_OK) P->reg_panel = true;
@@ -352,8 +353,8 @@ static void panel_schedule_batched(const ma_lu_plan* P, int nsys, std::vector<in
 }
 
 // one panel of system (A, ws, ipiv) on stream st: the kernel the plan's schedule was made for
-static int launch_panel(ma_lu_plan* P, c64* A, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st, bool masked) {
-  if (P->reg_panel) return lu_launch_panel_reg(A, P->n, k0, nb, nblk, masked ? P->panel_cus() : P->ncu, ws, ipiv, clear_tags, st);
+static int launch_panel(ma_lu_plan* P, c64* A, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, bool masked) {
+  if (P->reg_panel) return lu_launch_panel_reg(A, P->n, k0, nb, nblk, masked ? P->panel_cus() : P->ncu, ws, ipiv, lists, clear_tags, st);
   return lu_launch_panel(A, P->n, k0, nb, rpb, nblk, P->ncu, ws, ipiv, clear_tags, st);
 }
 
@@ -437,18 +438,21 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     for (int q = blk_first(g); q < blk_last(g); ++q) {
       const int k0 = k0s[q], nb = nbs[q], a1 = k0 + nb;
       MA_MARK(t0, sp);
-      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, sp, false))) return rc;
-      MA_MARK(t1, sp);
-      interval(P, t0, t1, 0);
       // the panel's gather lists and inverted diagonal blocks: once, here; the main lane reuses them
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
-      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
+      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], lists, q == 0 || nbs[q - 1] < 4, sp, false))) return rc;
+      MA_MARK(t1, sp);
+      interval(P, t0, t1, 0);
+      if (P->reg_panel) { if ((rc = lu_launch_lane_step(A, n, k0, nb, lists, a1, e - a1, invd, P->pws.timeout, sp))) return rc; }   // lists came from the panel kernel
+      else if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
       if (a1 < e) {
-        if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
-        const c64* T = A + (size_t)k0 * n + k0;
-        if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        if (!P->reg_panel) {
+          if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
+          const c64* T = A + (size_t)k0 * n + k0;
+          if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        }
         MA_MARK(t2, sp);
         if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
         MA_MARK(t3, sp);
@@ -642,17 +646,22 @@ struct Stage {
       hipStream_t pp = pan_stream(m);
       if (pp != sp) { MA_HIP(hipEventRecord(P->ev_chain[m], sp)); MA_HIP(hipStreamWaitEvent(pp, P->ev_chain[m], 0)); }
       MA_MARKD(t0, pp);
-      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], q == 0 || nbs[q - 1] < 4, pp, pp != sp))) return rc;
-      MA_MARKD(t1, pp);
-      interval(P, t0, t1, 0);
-      if (pp != sp) { MA_HIP(hipEventRecord(P->ev_pan[m], pp)); MA_HIP(hipStreamWaitEvent(sp, P->ev_pan[m], 0)); }
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
-      if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
+      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], lists, q == 0 || nbs[q - 1] < 4, pp, pp != sp))) return rc;
+      MA_MARKD(t1, pp);
+      interval(P, t0, t1, 0);
+      if (pp != sp) { MA_HIP(hipEventRecord(P->ev_pan[m], pp)); MA_HIP(hipStreamWaitEvent(sp, P->ev_pan[m], 0)); }
+      // register panel kernel: it wrote the interchange list itself, and ONE launch does the interchanges, U12 and the inverted
+      // diagonal block; otherwise: fold the pivots + invert, gather, scatter, U12
+      if (P->reg_panel) { if ((rc = lu_launch_lane_step(A, n, k0, nb, lists, a1, e - a1, invd, P->pws.timeout, sp))) return rc; }
+      else if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
       if (a1 < e) {
-        if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
-        if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        if (!P->reg_panel) {
+          if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
+          if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
+        }
         MA_MARK(t2, sp);
         if ((rc = gemm(n - a1, e - a1, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + a1, A + (size_t)a1 * n + a1, sp))) return rc;
         MA_MARK(t3, sp);
@@ -838,6 +847,7 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
 // always with equal block indices.
 int ma_lu_plan_stage_set_group(ma_lu_plan_t* P, int32_t group_size) {
   MA_REQUIRE(P && group_size >= 0 && group_size <= LU_GROUP_MAX, MA_ERR_INVALID, "group size must be 0..%d", LU_GROUP_MAX);
+  MA_REQUIRE(group_size < 2 || !P->reg_panel, MA_ERR_UNSUPPORTED, "slot groups share the LDS-resident panel kernel: not with MA_LU_REG_PANEL=1");
   if (group_size >= 2) {
     std::vector<int> k0s, nbs, rpbs, nblks;
     panel_schedule_batched(P, group_size, k0s, nbs, rpbs, nblks);

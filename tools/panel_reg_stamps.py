@@ -23,10 +23,13 @@ for it in range(2):
     assert lu.status(st) == 0
     t = lu.last_timing()
     L.ma_lu_plan_panel_stamps(lu.h, out.ctypes.data_as(C.c_void_p), 0)
-names = ["candidate + barrier", "publish (if wave 0 holds the best row)", "poll until all tagged", "reduce + fetch row + barrier", "eliminate", "load rows", "store rows", "-"]
-tot = out.sum() / 100.0
-print("register panel kernel, workgroup 0, thread 0: phase totals (us), n=%d" % n)
-for nm, v in zip(names, out):
-    print("  %-40s %10.1f us  %6.3f us/col" % (nm, v / 100.0, v / 100.0 / n))
-print("  total %.1f us = %.2f us/col; event-timed panel phase %.1f ms" % (tot, tot / n, t[0]))
+v = [float(x) for x in out]
+cols = max(v[6], 1.0); snd = max(v[1], 1.0)
+print("register panel kernel, all workgroups (lane 0 of the acting wavefront), n=%d: %d workgroup-columns" % (n, int(cols)))
+print("  sender: B1 -> row stores issued     %6.3f us" % (v[7] / snd / 100.0))
+print("  sender: B1 -> granule stored        %6.3f us" % (v[0] / snd / 100.0))
+print("  wave 0: B1 -> sweep starts          %6.3f us" % (v[2] / cols / 100.0))
+print("  wave 0: sweep until all tagged      %6.3f us  (%.2f sweeps per column)" % (v[3] / cols / 100.0, v[4] / cols))
+print("  wave 0: B2 -> B1 of the next column %6.3f us" % (v[5] / cols / 100.0))
+print("  event-timed panel phase %.1f ms = %.2f us per column" % (t[0], t[0] * 1e3 / n))
 print("res", float(torch.linalg.norm(A0 @ b - b0) / torch.linalg.norm(b0)))
