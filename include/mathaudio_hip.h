@@ -100,6 +100,11 @@ int ma_bem_plan_num_near_pairs(const ma_bem_plan_t* plan, int64_t* n);
 /* d_A (num_dofs^2 ma_c64) and d_rhs (num_dofs) are DEVICE pointers; work is enqueued on `stream`. */
 int ma_bem_plan_assemble_dev(ma_bem_plan_t* plan, const ma_physics_t* physics, double beta_re, double beta_im,
                              void* d_A, void* d_rhs, void* stream);
+/* build_tbem_system_with_beta (tbem.rs:96-222) for nf (1..16) wavenumbers of the plan's mesh in one call -- the next systems of a
+ * frequency sweep (room_simulator_bem.rs:329 walks the frequencies one by one): physics[f], beta[f] -> d_A[f], d_rhs[f] (device
+ * pointers, nf distinct matrices). The far pairs of up to three systems share one pass over the quadrature points. */
+int ma_bem_plan_assemble_multi_dev(ma_bem_plan_t* plan, int32_t nf, const ma_physics_t* physics, const double* beta_re, const double* beta_im,
+                                   void* const* d_A, void* const* d_rhs, void* stream);
 
 /* Incident field RHS.
  * Replaces: IncidentField::compute_rhs_with_beta(centers, normals, physics, beta)

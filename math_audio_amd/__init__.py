@@ -293,6 +293,14 @@ class BemPlan:
         check(lib().ma_bem_plan_assemble_dev(self.h, C.byref(ph), beta.real, beta.imag, C.c_void_p(d_A), C.c_void_p(d_rhs),
                                              C.c_void_p(stream)))
 
+    def assemble_multi_dev(self, ks, betas, d_As, d_rhss, stream=0, harmonic=1.0, tau=1.0):
+        """ma_bem_plan_assemble_multi_dev: the systems of several wavenumbers in one call (far pairs of up to three per pass)."""
+        nf = len(ks)
+        phs = (type(physics(1.0)) * nf)(*[physics(k, harmonic, tau) for k in ks])
+        br = (C.c_double * nf)(*[complex(b).real for b in betas]); bi = (C.c_double * nf)(*[complex(b).imag for b in betas])
+        pa = (C.c_void_p * nf)(*[int(a) for a in d_As]); pr = (C.c_void_p * nf)(*[int(r) for r in d_rhss])
+        check(lib().ma_bem_plan_assemble_multi_dev(self.h, nf, phs, br, bi, pa, pr, C.c_void_p(stream)))
+
     def incident_rhs_dev(self, k, beta, d_rhs, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=0,
                          harmonic=1.0, tau=1.0):
         ph = physics(k, harmonic, tau); beta = complex(beta); amp = complex(amp)

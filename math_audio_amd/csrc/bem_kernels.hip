@@ -113,7 +113,14 @@ __device__ __forceinline__ dc bm_coeff(const Acc4& s, int field_bc, const BemPhy
 
 // ------------------------------------------------------------------ K1: far pairs
 // grid.x: strips of 256 field panels, grid.y: strips of `rows_per_block` collocation rows.
-__global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block) {
+// NF systems of one mesh at NF wavenumbers in one pass (the systems a sweep keeps in flight): of the ~120 vector instructions of a
+// quadrature point, position, distance, reciprocal square root and the two normal projections (about 40) do not depend on the
+// wavenumber and are computed once; sin / cos and the kernel values (about 80) per system. VEL: every panel carries a velocity-type
+// condition -- assemble_tbem then reads only H and E (tbem.rs:311-330), so G and dG/dn_x are not accumulated (the per-lane
+// condition type keeps the compiler from dropping them on its own).
+struct FarMulti { BemPhys ph[3]; dc* A[3]; };
+template <int NF, bool VEL>
+__global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, FarMulti fm, int rows_per_block) {
   const int np = g.np;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int jj = j < np ? j : np - 1;
@@ -123,9 +130,11 @@ __global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, BemPhys ph, dc
   const double e2x = g.e2[0][jj], e2y = g.e2[1][jj], e2z = g.e2[2][jj];
   const double nyx = g.ny[0][jj], nyy = g.ny[1][jj], nyz = g.ny[2][jj];
   const double jw = g.jac[jj] * MA_INV4PI;
-  const int fbc = g.bc_type[jj];
+  const int fbc = VEL ? 0 : g.bc_type[jj];
   const long long col = g.dof[jj];
-  const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;   // wavruim, k^2 (regular.rs:44-45)
+  double kk[NF], k2[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) { kk[f] = fm.ph[f].k * fm.ph[f].harmonic; k2[f] = fm.ph[f].k * fm.ph[f].k; }   // wavruim, k^2 (regular.rs:44-45)
   const int i0 = blockIdx.y * rows_per_block;
   const int i1 = min(i0 + rows_per_block, np);
   for (int i = i0; i < i1; ++i) {
@@ -137,18 +146,51 @@ __global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, BemPhys ph, dc
     const double dny = d0x * nyx + d0y * nyy + d0z * nyz;             // (y - x) . n_y: constant over the flat panel
     const double dnx0 = d0x * nxx + d0y * nxy + d0z * nxz;            // (y - x) . n_x = dnx0 + xi e1.n_x + eta e2.n_x
     const double e1nx = e1x * nxx + e1y * nxy + e1z * nxz, e2nx = e2x * nxx + e2y * nxy + e2z * nxz;
-    Acc4 s;
-    s.g = s.h = s.ht = s.e = dc_make(0.0, 0.0);
+    Acc4 s[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) s[f].g = s[f].h = s[f].ht = s[f].e = dc_make(0.0, 0.0);
 #pragma unroll
     for (int q = 0; q < 13; ++q) {
       const double xi = c_tri13[q][0], eta = c_tri13[q][1], w = c_tri13[q][2];
-      double dx = __builtin_fma(eta, e2x, __builtin_fma(xi, e1x, d0x));
-      double dy = __builtin_fma(eta, e2y, __builtin_fma(xi, e1y, d0y));
-      double dz = __builtin_fma(eta, e2z, __builtin_fma(xi, e1z, d0z));
-      green_point_flat(dx, dy, dz, w * jw, k, k2, dny, __builtin_fma(eta, e2nx, __builtin_fma(xi, e1nx, dnx0)), m, s);
+      const double dx = __builtin_fma(eta, e2x, __builtin_fma(xi, e1x, d0x));
+      const double dy = __builtin_fma(eta, e2y, __builtin_fma(xi, e1y, d0y));
+      const double dz = __builtin_fma(eta, e2z, __builtin_fma(xi, e1z, d0z));
+      const double dnx = __builtin_fma(eta, e2nx, __builtin_fma(xi, e1nx, dnx0));
+      // green_point_flat, its wavenumber-free half once ...
+      const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+      if (!(r2 >= 1e-30)) continue;
+      double r, ri;
+      sqrt_rsqrt(r2, r, ri);
+      const double gsc = (w * jw) * ri;
+      const double a = dny * ri;
+      const double b = -(dnx * ri);
+      const double rq = a * b;
+      const double ri2 = ri * ri;
+      const double mri2 = m * ri2, rq3m = 3.0 * rq + m, ri23 = 3.0 * ri2;
+      // ... and the other half per system
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        double sn, cs;
+        sincos_bounded(kk[f] * r, sn, cs);
+        const double gre = cs * gsc, gim = sn * gsc;
+        const double bre = -(gre * ri) - gim * kk[f];
+        const double bim = gre * kk[f] - gim * ri;
+        const double fr = (ri23 - k2[f]) * rq + mri2;
+        const double fi = -(kk[f] * ri) * rq3m;
+        if (!VEL) {
+          s[f].g.re += gre; s[f].g.im += gim;
+          s[f].ht.re = __builtin_fma(bre, b, s[f].ht.re); s[f].ht.im = __builtin_fma(bim, b, s[f].ht.im);
+        }
+        s[f].h.re = __builtin_fma(bre, a, s[f].h.re); s[f].h.im = __builtin_fma(bim, a, s[f].h.im);
+        s[f].e.re += gre * fr - gim * fi;
+        s[f].e.im += gre * fi + gim * fr;
+      }
     }
-    dc coeff = bm_coeff(s, fbc, ph);
-    if (valid) A[(long long)g.dof[i] * g.nd + col] = coeff;
+    if (valid) {
+      const long long at = (long long)g.dof[i] * g.nd + col;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) fm.A[f][at] = bm_coeff(s[f], fbc, fm.ph[f]);
+    }
   }
 }
 
@@ -1284,14 +1326,22 @@ int bem_launch_near_list(const BemGeom& g, int pass, int* counts, const long lon
   return MA_OK;
 }
 
-int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) {
+int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st) {
+  MA_REQUIRE(nf >= 1 && nf <= 3, MA_ERR_INVALID, "1..3 systems per far pass");
   const int rpb = 32;
   dim3 grid((g.np + 255) / 256, (g.np + rpb - 1) / rpb), block(256);
-  hipLaunchKernelGGL(tbem_far_kernel, grid, block, 0, st, g, ph, reinterpret_cast<dc*>(A), rpb);
-  if (g.nquad > 0) hipLaunchKernelGGL(tbem_far_quad_kernel, dim3((g.nquad + 255) / 256, (g.np + rpb - 1) / rpb), block, 0, st, g, ph, reinterpret_cast<dc*>(A), rpb);
+  FarMulti fm{};
+  for (int f = 0; f < 3; ++f) { fm.ph[f] = phs[f < nf ? f : 0]; fm.A[f] = reinterpret_cast<dc*>(As[f < nf ? f : 0]); }
+  const bool vel = g.all_velocity != 0;
+  if (nf == 1) { if (vel) hipLaunchKernelGGL((tbem_far_kernel<1, true>), grid, block, 0, st, g, fm, rpb); else hipLaunchKernelGGL((tbem_far_kernel<1, false>), grid, block, 0, st, g, fm, rpb); }
+  else if (nf == 2) { if (vel) hipLaunchKernelGGL((tbem_far_kernel<2, true>), grid, block, 0, st, g, fm, rpb); else hipLaunchKernelGGL((tbem_far_kernel<2, false>), grid, block, 0, st, g, fm, rpb); }
+  else { if (vel) hipLaunchKernelGGL((tbem_far_kernel<3, true>), grid, block, 0, st, g, fm, rpb); else hipLaunchKernelGGL((tbem_far_kernel<3, false>), grid, block, 0, st, g, fm, rpb); }
+  if (g.nquad > 0) for (int f = 0; f < nf; ++f)
+    hipLaunchKernelGGL(tbem_far_quad_kernel, dim3((g.nquad + 255) / 256, (g.np + rpb - 1) / rpb), block, 0, st, g, phs[f], reinterpret_cast<dc*>(As[f]), rpb);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
+int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) { return bem_launch_far_multi(g, 1, &ph, &A, st); }
 
 int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st) {
   if (npairs <= 0) return MA_OK;

@@ -31,6 +31,8 @@ struct BemGeom {
   const unsigned char* ptype;
   const int* quad_ids;
   int nquad;
+  int all_velocity;       // every panel carries a velocity-type condition (bc_type 0: the rigid configurations): the far kernel then
+                          // needs neither the single-layer sum G nor dG/dn_x (assemble_tbem reads only H and E, tbem.rs:311-330)
 };
 
 // boundary values of the panels (BoundaryCondition::{Velocity,Pressure} payloads, types.rs:330-351): 4 slots per panel
@@ -49,6 +51,8 @@ struct BemPhys {
 int bem_upload_tables(const double tri13_scaled[13][3], const double* glx, const double* glw, const int glidx[21][2]);
 int bem_launch_near_list(const BemGeom& g, int pass, int* counts, const long long* offsets, int2* pairs, hipStream_t st);
 int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
+// nf (1..3) systems of the SAME mesh at different wavenumbers in one pass: the geometry of a quadrature point is computed once
+int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st);
 int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st);
 int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
 int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st);

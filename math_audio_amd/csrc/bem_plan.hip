@@ -1,6 +1,7 @@
 // bem_plan.hip — host side of the TBEM assembly: mesh validation, HBM layout, the per-mesh
 // near-pair plan, and the C-ABI entry points of include/mathaudio_hip.h for this row.
 #include "bem_kernels.hpp"
+#include <algorithm>
 #include "ma_tables.h"
 #include <vector>
 #include <cmath>
@@ -199,6 +200,8 @@ int ma_bem_plan_create(const ma_mesh_t* m, int device, ma_bem_plan_t** out) {
   g.ptype = (const unsigned char*)(base + bytes_d + stride * sizeof(int) + stride);
   g.quad_ids = (const int*)(base + bytes_d + stride * sizeof(int) + 2 * stride);
   g.nquad = (int)hquads.size();
+  g.all_velocity = 1;
+  for (int p = 0; p < np; ++p) if (hbc[p] != 0) g.all_velocity = 0;
 
   // constant tables (13-point rule scaled by 0.5 as triangle_quadrature does, gauss.rs:70)
   double t13[13][3];
@@ -329,6 +332,39 @@ int ma_bem_plan_assemble_dev(ma_bem_plan_t* P, const ma_physics_t* ph, double br
   if ((rc = bem_launch_near(P->geom, bp, P->d_pairs, P->npairs, A, st))) return rc;
   if (P->timing) MA_HIP(hipEventRecord(P->ev[2], st));
   if ((rc = bem_launch_self(P->geom, bp, A, st))) return rc;
+  if (P->timing) { MA_HIP(hipEventRecord(P->ev[3], st)); P->ev_valid = true; }
+  return MA_OK;
+}
+
+// The same mesh at nf wavenumbers (the next systems of a frequency sweep), each into its own matrix and right-hand side: the far
+// pairs of up to three systems go through ONE pass that computes every quadrature point's geometry (position, distance, the two
+// normal projections) once and only the wavenumber-dependent half (sin / cos, the kernel values) per system; near pairs and self
+// terms per system as in ma_bem_plan_assemble_dev. build_tbem_system_with_beta (tbem.rs:96-222) called nf times.
+int ma_bem_plan_assemble_multi_dev(ma_bem_plan_t* P, int32_t nf, const ma_physics_t* ph, const double* bre, const double* bim, void* const* dA, void* const* drhs, void* stream) {
+  MA_REQUIRE(P && ph && bre && bim && dA && drhs && nf >= 1 && nf <= 16, MA_ERR_INVALID, "bad argument");
+  BemPhys bp[16];
+  int rc;
+  for (int f = 0; f < nf; ++f) {
+    MA_REQUIRE(dA[f] && drhs[f], MA_ERR_INVALID, "system %d has a NULL pointer", f);
+    for (int o = 0; o < f; ++o) MA_REQUIRE(dA[o] != dA[f], MA_ERR_INVALID, "systems %d and %d alias", o, f);
+    if ((rc = ma_bem_make_phys(P, &ph[f], bre[f], bim[f], &bp[f]))) return rc;
+  }
+  MA_HIP(hipSetDevice(P->device));
+  hipStream_t st = (hipStream_t)stream;
+  for (int f = 0; f < nf; ++f) {
+    if (P->has_bc) { if ((rc = bem_launch_rhs_bc(P->geom, bp[f], P->bc, P->d_pairs, P->d_pair_off, P->npairs, P->d_rhs_scratch, (c64*)drhs[f], st))) return rc; }
+    else if ((rc = bem_launch_zero((c64*)drhs[f], P->nd, st))) return rc;
+  }
+  if (P->timing) MA_HIP(hipEventRecord(P->ev[0], st));
+  for (int f0 = 0; f0 < nf; f0 += 3) {
+    c64* As[3]; const int cnt = std::min(3, nf - f0);
+    for (int t = 0; t < cnt; ++t) As[t] = (c64*)dA[f0 + t];
+    if ((rc = bem_launch_far_multi(P->geom, cnt, bp + f0, As, st))) return rc;
+  }
+  if (P->timing) MA_HIP(hipEventRecord(P->ev[1], st));
+  for (int f = 0; f < nf; ++f) if ((rc = bem_launch_near(P->geom, bp[f], P->d_pairs, P->npairs, (c64*)dA[f], st))) return rc;
+  if (P->timing) MA_HIP(hipEventRecord(P->ev[2], st));
+  for (int f = 0; f < nf; ++f) if ((rc = bem_launch_self(P->geom, bp[f], (c64*)dA[f], st))) return rc;
   if (P->timing) { MA_HIP(hipEventRecord(P->ev[3], st)); P->ev_valid = true; }
   return MA_OK;
 }
