@@ -360,6 +360,14 @@ int ma_op_num_shards(const ma_op_t* op, int32_t* shards, int32_t* row_begin_or_n
 int ma_op_destroy(ma_op_t* op);
 int ma_op_num_rows(const ma_op_t* op, int64_t* n);
 int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);
+/* A LinearOperator (traits.rs:316-327) whose ROWS are spread over processes (one rank per GPU; SURVEY 8e.2, BASELINE config #5):
+ * `inner` = this rank's operator restricted to rows [row0, row1) (ma_op_create_tbem with a row range). After it has written its
+ * rows of y = A x, `gather(user, d_y, n, row0, row1, stream)` must complete d_y in place with the other ranks' rows, ordered on
+ * `stream` -- an all-gather on the caller's communicator (RCCL under torch.distributed's "nccl" backend); it returns 0 on
+ * success. The handle drives ma_gmres* like any other; apply_transpose / apply_hermitian are not defined for it. `inner` is
+ * not owned. */
+typedef int (*ma_gather_fn)(void* user, void* d_y, int64_t n, int64_t row0, int64_t row1, void* stream);
+int ma_op_create_gathered(ma_op_t* inner, int64_t row0, int64_t row1, ma_gather_fn gather, void* user, ma_op_t** out);
 int ma_op_apply_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
 /* apply_transpose (y = A^T x) and apply_hermitian (y = A^H x), traits.rs:326-358, for every operator kind. A matrix-free
  * operator created over a row block [row0, row1) returns that block's contribution to all entries of y (the blocks' results

@@ -652,6 +652,25 @@ class LinearOperator:
         return LinearOperator(h, plan)
 
     @staticmethod
+    def gathered(inner, row0, row1, gather):
+        """ma_op_create_gathered: `inner` owns rows [row0, row1) of y = A x; gather(d_y, n, row0, row1, stream) -> 0 completes y in
+        place with the other ranks' rows (an all-gather on the caller's communicator), ordered on `stream`."""
+        fn_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p)
+
+        def _cb(user, d_y, n, r0, r1, stream):
+            try:
+                return int(gather(int(d_y), int(n), int(r0), int(r1), int(stream or 0)))
+            except Exception as e:          # never unwind through the C frames
+                import sys
+                sys.stderr.write("gather callback failed: %r\n" % (e,))
+                return -1
+        cb = fn_t(_cb)
+        h = C.c_void_p()
+        lib().ma_op_create_gathered.argtypes = [C.c_void_p, C.c_int64, C.c_int64, fn_t, C.c_void_p, C.c_void_p]
+        check(lib().ma_op_create_gathered(inner.h, int(row0), int(row1), cb, None, C.byref(h)))
+        return LinearOperator(h, (inner, cb))
+
+    @staticmethod
     def tbem_multi(mesh, k, beta, devices, harmonic=1.0, tau=1.0):
         """ma_op_create_tbem_multi: the matrix-free operator row-sharded over `devices` (vectors live on devices[0])."""
         ph = physics(k, harmonic, tau); beta = complex(beta)

@@ -56,6 +56,9 @@ struct ma_op {
   ma_slfmm* fmm = nullptr;
   // kind 6: the multi-level operator (MlfmmSystem, assembly/mlfmm.rs)
   ma_mlfmm* mlfmm = nullptr;
+  // kind 8: one RANK's row block of an operator whose rows are spread over processes: `inner` (not owned) writes rows [row0, row1)
+  // of y, then the caller's exchange (an all-gather over the ranks' communicator: RCCL with the "nccl" backend) completes y
+  ma_op* inner = nullptr; ma_gather_fn gather = nullptr; void* gather_user = nullptr;
 };
 
 extern "C" int ma_op_destroy(ma_op_t* o);
@@ -294,6 +297,26 @@ int ma_op_num_shards(const ma_op_t* o, int32_t* shards, int32_t* row_begin_or_nu
   return MA_OK;
 }
 
+// LinearOperator over PROCESSES (SURVEY 8e.2, config #5 as the driver launches it: one rank per GPU): `inner` is this rank's
+// operator restricted to rows [row0, row1) (ma_op_create_tbem with a row range); after it has written its rows of y, `gather` must
+// complete y in place -- every other rank's rows -- ordered on `stream` (an all-gather on the ranks' communicator; the library
+// does not link a collective library itself: the communicator stays with the caller, behind `user`). The handle is an ordinary
+// ma_op_t: ma_gmres / ma_gmres_preconditioned / ma_gmres_pipelined drive it, every rank running the same iteration on the same
+// vectors. apply_transpose / apply_hermitian are not defined for it. `inner` is not owned and must outlive the handle.
+int ma_op_create_gathered(ma_op_t* inner, int64_t row0, int64_t row1, ma_gather_fn gather, void* user, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(inner && gather, MA_ERR_INVALID, "NULL argument");
+  MA_REQUIRE(row0 >= 0 && row0 <= row1 && row1 <= inner->n, MA_ERR_INVALID, "row block [%lld, %lld) outside 0..%lld", (long long)row0, (long long)row1, inner->n);
+  ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
+  o->kind = 8; o->device = inner->device; o->n = inner->n; o->inner = inner; o->gather = gather; o->gather_user = user;
+  o->row0 = (int)row0; o->row1 = (int)row1;
+  MA_HIP(hipSetDevice(o->device));
+  if (hipMalloc(&o->d_x, sizeof(c64) * (size_t)o->n) != hipSuccess || hipMalloc(&o->d_y, sizeof(c64) * (size_t)o->n) != hipSuccess) {
+    set_error("rank-sharded operator: staging vectors do not fit"); op_free(o); delete o; return MA_ERR_NOMEM;
+  }
+  *out = o;
+  return MA_OK;
+}
 int ma_op_destroy(ma_op_t* o) {
   if (!o) return MA_OK;
   (void)hipSetDevice(o->device);
@@ -349,6 +372,13 @@ int ma_op_apply_dev(ma_op_t* o, const void* d_x, void* d_y, void* stream) {
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(o->device));
   hipStream_t st = (hipStream_t)stream;
+  if (o->kind == 8) {                                    // this rank's rows, then the exchange that brings the other ranks' rows
+    int rc = ma_op_apply_dev(o->inner, d_x, d_y, stream);
+    if (rc) return rc;
+    rc = o->gather(o->gather_user, d_y, o->n, o->row0, o->row1, stream);
+    MA_REQUIRE(rc == 0, MA_ERR_HIP, "the row exchange of a rank-sharded operator failed (callback returned %d)", rc);
+    return MA_OK;
+  }
   if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, 0, st);
   if (o->kind == 4) return slfmm_apply(o->fmm, (const c64*)d_x, (c64*)d_y, 0, st);
   if (o->kind == 6) return mlfmm_apply(o->mlfmm, (const c64*)d_x, (c64*)d_y, st);
@@ -397,6 +427,7 @@ static int op_apply_t(ma_op_t* o, const void* d_x, void* d_y, bool herm, hipStre
   MA_REQUIRE(o && d_x && d_y, MA_ERR_INVALID, "NULL argument");
   MA_HIP(hipSetDevice(o->device));
   if (o->kind == 3) return op_apply_sharded(o, (const c64*)d_x, (c64*)d_y, herm ? 2 : 1, st);
+  MA_REQUIRE(o->kind != 8, MA_ERR_UNSUPPORTED, "the transposed apply of a rank-sharded operator needs a reduction over the ranks: not defined for it");
   MA_REQUIRE(o->kind != 6, MA_ERR_UNSUPPORTED, "MLFMM transpose not yet implemented (the reference's MlfmmOperator::apply_transpose is unimplemented!(), fmm_interface.rs:131-134)");
   if (o->kind == 4) {                                    // matvec_transpose (slfmm.rs:262-376); hermitian = conj(A^T conj(x)) (traits.rs:340-358)
     const c64* xin = (const c64*)d_x;
@@ -552,6 +583,7 @@ int ma_precond_create_sym_gauss_seidel(ma_csr_t* csr, int32_t sweeps, ma_precond
 int ma_precond_create_diagonal(ma_op_t* op, ma_precond_t** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
   MA_REQUIRE(op, MA_ERR_INVALID, "operator is NULL");
+  if (op->kind == 8) return ma_precond_create_diagonal(op->inner, out);             // every rank's plan holds every panel's self term
   if (op->kind == 1) return ma_precond_create_jacobi(op->csr, 1.0, 1, out);
   if (op->kind == 3) return ma_precond_create_diagonal(op->shards[0].op, out);    // the home shard's plan holds every panel
   MA_REQUIRE(op->kind != 6, MA_ERR_UNSUPPORTED, "diagonal preconditioner of the multi-level operator: the reference defines it for the single-level system only");

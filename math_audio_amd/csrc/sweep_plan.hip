@@ -65,13 +65,62 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
     if (!r) r = ma_bem_plan_incident_rhs_dev(plan, &ph, 0.0, bim, a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, dx[(size_t)s], st);
     return r;
   };
+  // Assembly AHEAD in the staged schedule: the systems of the next (up to three) frequencies in one ma_bem_plan_assemble_multi_dev
+  // call -- their far pairs share one pass over the quadrature points -- into spare matrices; a slot that begins a system swaps
+  // its matrix with the spare that holds it. Only when the spares fit comfortably (MA_SWEEP_ASM_AHEAD=1 switches it off).
+  int ahead = 3;
+  if (const char* ea = getenv("MA_SWEEP_ASM_AHEAD")) ahead = std::max(1, std::min(3, atoi(ea)));
+  if (ahead > n_mine) ahead = std::max(1, (int)n_mine);
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)ahead * 16.0 * (double)n * (double)n > 0.5 * (double)free_b) ahead = 1;
+  }
+  std::vector<void*> sA, sx; std::vector<int> holds;      // spare matrices / right-hand sides, and which of this device's frequencies each holds (-1: none)
+  if (ahead > 1) {
+    sA.assign((size_t)ahead, nullptr); sx.assign((size_t)ahead, nullptr); holds.assign((size_t)ahead, -1);
+    bool ok = true;
+    for (int q = 0; q < ahead && ok; ++q)
+      ok = hipMalloc(&sA[(size_t)q], sizeof(ma_c64) * (size_t)n * (size_t)n) == hipSuccess && hipMalloc(&sx[(size_t)q], sizeof(ma_c64) * (size_t)n) == hipSuccess;
+    if (!ok) { for (void* p : sA) if (p) (void)hipFree(p); for (void* p : sx) if (p) (void)hipFree(p); sA.clear(); sx.clear(); holds.clear(); ahead = 1; (void)hipGetLastError(); }
+  }
+  auto free_spares = [&]() { for (void* p : sA) if (p) (void)hipFree(p); for (void* p : sx) if (p) (void)hipFree(p); sA.clear(); sx.clear(); };
+  // system of this device's i-th frequency into slot s
+  auto take = [&](int i, int s) -> int {
+    if (ahead <= 1) return assemble(mine[(size_t)i], s);
+    int at = -1;
+    for (int q = 0; q < ahead; ++q) if (holds[(size_t)q] == i) at = q;
+    if (at < 0) {
+      ma_physics_t ph[3]; double br[3], bi[3]; void* pa[3]; void* pr[3]; int idx[3]; int cnt = 0;
+      for (int q = 0; q < ahead && i + cnt < n_mine; ++q) {
+        if (holds[(size_t)q] >= 0) continue;
+        const double freq = frequencies_hz[mine[(size_t)(i + cnt)]];
+        ph[cnt].wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;
+        ph[cnt].harmonic_factor = a.harmonic_factor; ph[cnt].tau = a.tau; ph[cnt].gamma = 1.0;
+        br[cnt] = 0.0; bi[cnt] = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / ph[cnt].wave_number : 0.0;
+        pa[cnt] = sA[(size_t)q]; pr[cnt] = sx[(size_t)q]; idx[cnt] = q; ++cnt;
+      }
+      int r = ma_bem_plan_assemble_multi_dev(plan, cnt, ph, br, bi, pa, pr, st);
+      for (int t = 0; t < cnt && !r; ++t) {
+        r = ma_bem_plan_incident_rhs_dev(plan, &ph[t], 0.0, bi[t], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, pr[t], st);
+        holds[(size_t)idx[t]] = i + t;
+      }
+      if (r) return r;
+      for (int q = 0; q < ahead; ++q) if (holds[(size_t)q] == i) at = q;
+      if (at < 0) { set_error("sweep: no spare system for frequency %d", i); return MA_ERR_INVALID; }
+    }
+    std::swap(dA[(size_t)s], sA[(size_t)at]); std::swap(dx[(size_t)s], sx[(size_t)at]);
+    holds[(size_t)at] = -1;
+    return MA_OK;
+  };
   int32_t G = 0;
   ma_c64* dX = nullptr; int32_t* dinfo = nullptr;
   const bool staged = ma_lu_plan_num_blocks(lu, &G) == MA_OK && G > 0 && ma_lu_plan_stage_reset(lu, st) == MA_OK;
+  if (!staged) { free_spares(); ahead = 1; }
   if (staged) {
     if (hipMalloc(&dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n) != hipSuccess || hipMalloc(&dinfo, sizeof(int32_t) * (size_t)n_mine) != hipSuccess) {
       if (dX) (void)hipFree(dX);
       set_error("sweep: the solutions of %d frequencies do not fit the device", n_mine);
+      free_spares();
       cleanup();
       return MA_ERR_NOMEM;
     }
@@ -86,7 +135,7 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
         if (i >= n_mine) continue;
         live = true;
         if (g == 0) {
-          rc = assemble(mine[(size_t)i], s);
+          rc = take(i, s);
           if (!rc) rc = ma_lu_plan_stage_begin(lu, s, dA[(size_t)s], dx[(size_t)s], 1, st);
         }
         sl[cnt] = s; bl[cnt] = g; ++cnt;
@@ -121,6 +170,7 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
     }
     if (rc) (void)hipDeviceSynchronize();                       // nothing may still be running on buffers that are about to go
     (void)hipFree(dX); (void)hipFree(dinfo);
+    free_spares();
     cleanup();
     return rc ? rc : worst;
   }

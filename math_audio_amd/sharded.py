@@ -4,9 +4,13 @@
 Every rank keeps the full x, owns a contiguous block of collocation ROWS of the operator, produces its slice of
 y = A x with the HIP operator kernels and the slices are exchanged with ONE all-gather per apply (RCCL over xGMI with
 the "nccl" backend; 16 B x N = 0.8 MB at 50k panels: latency-bound, no reduction, no atomics). The Krylov vectors
-are replicated: every rank runs the same restarted GMRES (math-solvers/src/iterative/gmres.rs:105-277, the same
-steps as the single-GPU `ma_gmres`) on identical data, so no other collective is needed and all ranks agree bit for
-bit. The vector arithmetic is torch tensor plumbing on the device; the operator apply is the product's kernel.
+are replicated: every rank runs the same restarted GMRES (math-solvers/src/iterative/gmres.rs:105-277) on identical data,
+so no other collective is needed and all ranks agree bit for bit.
+
+On a GPU the solver is the LIBRARY's device GMRES (`ma_gmres` / `ma_gmres_preconditioned`): the row block becomes an ordinary
+`ma_op_t` through `ma_op_create_gathered`, whose exchange callback runs the all-gather of this module on the communicator the
+caller holds (round 3; before that the iteration below ran as torch arithmetic with a host synchronisation per inner product).
+The torch iteration remains for operators without a library handle (the CPU rehearsal of the exchange with gloo).
 """
 import math
 import numpy as np
@@ -69,7 +73,49 @@ def tbem_sharded_operator(plan, k, beta, dist=None, device=None):
         y_block.copy_(y_full[r0:r1])
     so = ShardedOperator(n, local_apply, dist=dist, device=dev)
     so._keep = (op, y_full)
+    # the same row block as an ma_op_t of the library: its exchange callback is this module's all-gather
+    if op is not None:
+        so.lib_op = library_operator(so, op, n, r0, r1, dev)
     return so
+
+
+def library_operator(so, inner, n, r0, r1, dev):
+    """ma_op_create_gathered over `inner` (rows [r0, r1) of y): the callback all-gathers the ranks' blocks into d_y in place.
+    With the "nccl" backend (RCCL) the collective runs on device tensors; other backends (gloo) go through host staging."""
+    import torch
+    import math_audio_amd as ma
+    per, world, dist = so.per, so.world, so.dist
+    block = torch.zeros(per, dtype=torch.complex128, device=dev)
+    allb = torch.zeros(per * world, dtype=torch.complex128, device=dev)
+    on_device = dist is not None and dist.get_backend() == "nccl"
+
+    def gather(d_y, n_, row0, row1, stream):
+        if world == 1:
+            return 0
+        ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+        with torch.cuda.stream(ext):
+            y = _as_tensor(d_y, n_, dev)
+            block.zero_(); block[: row1 - row0].copy_(y[row0:row1])
+            if on_device:
+                dist.all_gather_into_tensor(torch.view_as_real(allb), torch.view_as_real(block))
+            else:
+                hb = torch.view_as_real(block).cpu(); ha = torch.empty(per * world, 2, dtype=torch.float64)
+                dist.all_gather_into_tensor(ha, hb)
+                torch.view_as_real(allb).copy_(ha)
+            y.copy_(allb[:n_])
+        return 0
+    lop = ma.LinearOperator.gathered(inner, r0, r1, gather)
+    lop._keep2 = (block, allb)
+    return lop
+
+
+def _as_tensor(ptr, n, dev):
+    """complex128 tensor view of n entries of device memory at `ptr` (no copy)."""
+    import torch
+
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (2 * n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+    return torch.view_as_complex(torch.as_tensor(_Arr(), device=dev).view(n, 2))
 
 
 def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
@@ -78,6 +124,11 @@ def gmres(op, b, x0=None, restart=30, max_iterations=100, tol=1e-6):
     out of restarts returns the true residual with converged = False. `op.apply(x)` is the only distributed step.
     Returns (x, info) with info = dict(iterations, restarts, converged, residual)."""
     import torch
+    if getattr(op, "lib_op", None) is not None:
+        # the library's device GMRES on the rank-sharded ma_op_t: same steps, vectors and scalars stay on the device
+        import math_audio_amd as ma
+        xh, info = ma.gmres(op.lib_op, b.cpu().numpy(), None if x0 is None else x0.cpu().numpy(), restart=restart, max_iterations=max_iterations, tol=tol)
+        return torch.tensor(xh, device=b.device), dict(iterations=info.iterations, restarts=info.restarts, converged=bool(info.converged), residual=info.residual)
     n = b.shape[0]
     x = torch.zeros(n, dtype=torch.complex128, device=b.device) if x0 is None else x0.clone()
     b_norm = float(torch.linalg.vector_norm(b))
