@@ -308,6 +308,49 @@ def config5_measure():
     return out
 
 
+def inlib_sweep(args):
+    """The sweep as ONE call into the library per phase (ma_bem_solve_sweep_multi_timed): frequency i of the list belongs to device
+    i mod N; device d therefore solves the frequencies the rank form gives rank d (freqs[(d + s N) mod 64], s = 0..steps-1).
+    Warm-up = one call with `warmup` frequencies per device; the timed call carries `steps` per device. value = all pairs / the
+    slowest device's sweep time (plan creation -- geometry upload, near list -- is per call and reported next to it)."""
+    import math_audio_amd as ma
+    from math_audio_amd import mesh as mm
+    N = args.gpus
+    devices = [int(t) for t in args.devices.split(",")] if args.devices else list(range(N))
+    if len(devices) != N:
+        raise SystemExit("bench.py --inlib: --devices lists %d devices, --gpus says %d" % (len(devices), N))
+    mesh = mm.generate_sphere_mesh(RADIUS, args.n_theta, args.n_phi)
+    n = mesh.n_elem
+    freqs = mm.log_space(100.0, 8000.0, 64)
+
+    def flist(first, count):
+        return [freqs[(d + (first + s_) * N) % len(freqs)] for s_ in range(count) for d in range(N)]
+    S = max(1, min(args.slots, 4))
+    if args.warmup > 0:
+        ma.solve_sweep_multi_timed(mesh, devices, flist(0, args.warmup), speed_of_sound=C_SOUND, beta_scale=4.0, slots=S)
+    t0 = time.perf_counter()
+    X, st, secs, setup, cnt = ma.solve_sweep_multi_timed(mesh, devices, flist(args.warmup, args.steps), speed_of_sound=C_SOUND, beta_scale=4.0, slots=S)
+    wall = time.perf_counter() - t0
+    if not np.all(st == 0):
+        raise SystemExit("a frequency of the sweep failed: status %s" % sorted(set(int(v) for v in st)))
+    if not np.all(np.isfinite(X.view(np.float64))):
+        raise SystemExit("non-finite solution")
+    if any(int(c) != args.steps for c in cnt):
+        raise SystemExit("device frequency counts %s, expected %d each" % (list(map(int, cnt)), args.steps))
+    elapsed = float(max(secs))
+    K = args.steps
+    out = {"metric": "bem_sweep_panel_pairs_per_s", "value": float(n) * n * K * N / elapsed, "unit": "panel-pairs/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
+           "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+           "config": {"workload": "S10 UV-sphere r=0.1 n_theta=%d n_phi=%d -> %d Tri3 panels; 64 log-spaced frequencies 100 Hz-8 kHz, frequency i on device i mod N; "
+                                  "one process, ma_bem_solve_sweep_multi (a host thread per device inside the library)" % (args.n_theta, args.n_phi, n),
+                      "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": S, "mode": "inlib", "devices": devices,
+                      "sharding": "frequency sweep, no data-path collective"},
+           "per_device_ms_per_step": [float(v) / K * 1e3 for v in secs], "per_device_frequencies": [int(c) for c in cnt],
+           "per_device_plan_setup_s": [float(v) for v in setup], "wall_s_of_the_call": wall,
+           "note": "value uses the slowest device's sweep time (solutions copied back to the host included); the call's wall time also holds each device's plan creation"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["bem", "fem"], default="bem", help="bem = the headline sweep (default); fem = CSR SpMV / smoother bandwidth")
@@ -319,6 +362,9 @@ def main():
     ap.add_argument("--n-phi", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--inlib", action="store_true", help="ONE process: ma_bem_solve_sweep_multi over --gpus N devices (a host thread per device inside the library: what a "
+                                                          "Rust caller gets) instead of one torch.distributed rank per GPU")
+    ap.add_argument("--devices", default="", help="--inlib: comma-separated device list instead of 0..N-1 (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1 allows repeats)")
     ap.add_argument("--no-extras", action="store_true", help="skip the passes after the timed region that put configs #4 (FEM SpMV / smoother) and #5 (50k-panel operators) into the line")
     ap.add_argument("--schedule", choices=["auto", "pipeline", "batch"], default="auto",
                     help="pipeline: slots at staggered block indices (staged plan API); batch: lock-step batches of --slots systems; "
@@ -332,6 +378,8 @@ def main():
         args.schedule = "pipeline" if args.steps >= 12 else "batch"
     if args.workload == "fem":
         return fem_workload(args)
+    if args.inlib:
+        return inlib_sweep(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks here, as child processes, BEFORE this process touches a GPU
         # (nothing GPU-related has been imported yet), and hand their status back. One rank per GPU over RCCL, rendezvous on
@@ -620,7 +668,14 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
+        mine = torch.tensor([elapsed, float(args.steps)], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank_ms = [float(v[0].item()) / args.steps * 1e3 for v in allv]
+        if any(int(v[1].item()) != args.steps for v in allv):
+            raise SystemExit("ranks disagree on the number of steps: %s" % [int(v[1].item()) for v in allv])
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -666,7 +721,8 @@ def main():
                                    "f -> rank f mod N; rigid BC, beta=4i/k, plane wave +z; step = TBEM assembly + incident RHS + dense complex LU "
                                    "solve (zgesv) of one frequency, device-resident" % (args.n_theta, args.n_phi, n),
                        "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": S, "schedule": args.schedule,
-                       "sharding": "frequency sweep, no data-path collective"},
+                       "sharding": "frequency sweep, no data-path collective", "mode": "ranks"},
+            "per_rank_ms_per_step": per_rank_ms, "per_rank_frequencies": [K] * world,
         }
         if timing:
             asm_t = asm_ms.sum() / K * 1e-3

@@ -150,6 +150,12 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
 int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz,
                              double speed_of_sound, double harmonic_factor, double tau, double beta_scale, int incident_kind,
                              const double* incident_vec3, double amp_re, double amp_im, int32_t slots, ma_c64* X_out, int32_t* status_or_null);
+/* The same with a per-device account (any of the three may be NULL): device_seconds[d] = wall time of device d's sweep,
+ * device_setup_seconds[d] = its plan creation (geometry upload, near-pair list), device_frequencies[d] = frequencies it solved. */
+int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz,
+                                   double speed_of_sound, double harmonic_factor, double tau, double beta_scale, int incident_kind,
+                                   const double* incident_vec3, double amp_re, double amp_im, int32_t slots, ma_c64* X_out, int32_t* status_or_null,
+                                   double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies);
 int ma_sweep_owner(int32_t frequency_index, int32_t ndev);      /* index into devices[] of the owner of a frequency */
 
 /* The same solve with the reference's own signature, lu_solve(&a, &b) -> x: inputs untouched, factors not copied back. */

@@ -85,6 +85,9 @@ def lib():
             "ma_lu_solve": [i32, vp, vp, vp],
             "ma_bem_solve_sweep": [vp, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
             "ma_bem_solve_sweep_multi": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
+            "ma_bem_solve_sweep_multi_timed": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp, vp, vp, vp],
+            "ma_bem_plan_assemble_multi_dev": [vp, i32, vp, vp, vp, vp, vp, vp],
+            "ma_lu_plan_main_stream": [vp, P(vp)],
             "ma_sweep_owner": [i32, i32],
             "ma_bem_plan_device": [vp, P(C.c_int)],
             "ma_lu_factorize": [i32, vp, P(vp)],
@@ -985,6 +988,20 @@ def solve_sweep_multi(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_
     if rc not in (MA_OK, MA_ERR_SINGULAR):
         check(rc)
     return X, st
+
+
+def solve_sweep_multi_timed(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, slots=3, harmonic=1.0, tau=1.0):
+    """ma_bem_solve_sweep_multi_timed: (X, status, device_seconds, device_setup_seconds, device_frequencies)."""
+    f = np.ascontiguousarray(frequencies_hz, dtype=np.float64); v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)
+    dv = np.ascontiguousarray(devices, dtype=np.int32)
+    nd = int((mesh.is_eval == 0).sum()) if mesh.is_eval is not None else mesh.n_elem
+    X = np.empty((len(f), nd), dtype=np.complex128); st = np.zeros(len(f), dtype=np.int32)
+    secs = np.zeros(len(dv)); setup = np.zeros(len(dv)); cnt = np.zeros(len(dv), dtype=np.int32)
+    rc = lib().ma_bem_solve_sweep_multi_timed(C.byref(mesh.c), _vp(dv), len(dv), len(f), _vp(f), float(speed_of_sound), float(harmonic), float(tau), float(beta_scale),
+                                              int(kind), _vp(v), amp.real, amp.imag, int(slots), _vp(X), _vp(st), _vp(secs), _vp(setup), _vp(cnt))
+    if rc not in (MA_OK, MA_ERR_SINGULAR):
+        check(rc)
+    return X, st, secs, setup, cnt
 
 
 class IluPreconditioner:

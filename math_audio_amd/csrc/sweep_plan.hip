@@ -14,6 +14,7 @@
 #include <cmath>
 #include <thread>
 #include <string>
+#include <chrono>
 
 using namespace ma;
 
@@ -216,9 +217,11 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
 // to device slot f mod ndev (room_simulator_bem.rs:329's loop dealt round-robin).
 int ma_sweep_owner(int32_t frequency_index, int32_t ndev) { return ndev > 0 ? frequency_index % ndev : 0; }
 
-int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
-                             double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
-                             int32_t slots, ma_c64* X_out, int32_t* status_or_null) {
+// the same with a per-device account for the caller (bench.py --inlib): device_seconds[d] = wall time of device d's sweep (its plan
+// creation excluded), device_setup_seconds[d] = its plan creation, device_frequencies[d] = frequencies it solved; any may be NULL
+int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
+                                   double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
+                                   int32_t slots, ma_c64* X_out, int32_t* status_or_null, double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies) {
   MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && n_freq > 0 && frequencies_hz && incident_vec3 && X_out, MA_ERR_INVALID, "bad argument");
   MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
   int count = 0;
@@ -236,16 +239,25 @@ int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int3
   auto work = [&](int d) {
     // one host thread per device: its own plans, stream and buffers; errors are thread-local and carried back as text
     ma_bem_plan_t* plan = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     int r = ma_bem_plan_create(mesh, devices[d], &plan);
+    const auto t1 = std::chrono::steady_clock::now();
     if (!r) r = sweep_on_plan_device(plan, n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null);
+    const auto t2 = std::chrono::steady_clock::now();
     if (r && r != MA_ERR_SINGULAR) texts[(size_t)d] = ma_last_error_string();
     if (plan) ma_bem_plan_destroy(plan);
     rcs[(size_t)d] = r;
+    if (device_setup_seconds) device_setup_seconds[d] = std::chrono::duration<double>(t1 - t0).count();
+    if (device_seconds) device_seconds[d] = std::chrono::duration<double>(t2 - t1).count();
+    if (device_frequencies) { int c = 0; for (int f = d; f < n_freq; f += ndev) ++c; device_frequencies[d] = c; }
   };
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;       // work(0) runs on the calling thread and selects devices[0]: the caller's device is restored below
   std::vector<std::thread> th;
   for (int d = 1; d < ndev; ++d) th.emplace_back(work, d);
   work(0);
   for (auto& t : th) t.join();
+  if (had) (void)hipSetDevice(prev);
   int worst = MA_OK;
   for (int d = 0; d < ndev; ++d) {
     if (rcs[(size_t)d] == MA_OK) continue;
@@ -254,6 +266,13 @@ int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int3
     return rcs[(size_t)d];
   }
   return worst;
+}
+
+int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
+                             double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
+                             int32_t slots, ma_c64* X_out, int32_t* status_or_null) {
+  return ma_bem_solve_sweep_multi_timed(mesh, devices, ndev, n_freq, frequencies_hz, speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3,
+                                        amp_re, amp_im, slots, X_out, status_or_null, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"
