@@ -13,6 +13,7 @@
 // col/val are one contiguous run; x is gathered through L2; the group reduces with DPP shuffles.
 // The Jacobi sweep is the same kernel with a fused epilogue x_new = x + w_i (b - A x)_i.
 #include "csr_kernels.hpp"
+#include "lu_kernels.hpp"
 #include "ma_device_math.hpp"
 
 namespace ma {
@@ -27,8 +28,8 @@ __device__ __forceinline__ double group_sum(double v) {
 // EPI: 0 y = A x; 1 r = b - A x; 2 Jacobi x_new = x + omega dinv (b - A x); 3 l1-Jacobi x_new = x + (b - A x) / l1;
 //      4 y = b + A x (the correction x + P e of the V-cycle in one pass; out may be b)
 template <int G, bool KM, int EPI>
-__global__ __launch_bounds__(256) void csr_rows_kernel(CsrView A, const dc* __restrict__ x, const dc* __restrict__ b,
-                                                       dc* __restrict__ out, double omega) {
+__global__ __launch_bounds__(256) void csr_rows_kernel(CsrView A, const dc* __restrict__ x, const dc* b /* EPI 4 is used in place: b == out */,
+                                                       dc* out, double omega) {
   const int lane_in_group = threadIdx.x & (G - 1);
   const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) / G;
   if (row >= A.n) return;                            // whole groups leave together (G divides 64)
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(CsrView A, const dc* __re
 // no cross-lane reduction is needed; rows of a structured FEM mesh have neighbouring columns, so the gather of x is
 // nearly coalesced too. Used when padding to the slice's longest row costs < 30 % (a P1 tet mesh: 4 %).
 template <bool KM, int EPI, bool C16>
-__global__ __launch_bounds__(256) void sell_rows_kernel(CsrView A, const dc* __restrict__ x, const dc* __restrict__ b,
-                                                        dc* __restrict__ out, double omega) {
+__global__ __launch_bounds__(256) void sell_rows_kernel(CsrView A, const dc* __restrict__ x, const dc* b /* EPI 4 is used in place: b == out */,
+                                                        dc* out, double omega) {
   const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long slice = row >> 6;
   const int lane = threadIdx.x & 63;
@@ -268,8 +269,15 @@ __global__ __launch_bounds__(256) void csr_gs_level_kernel(CsrView A, const int*
   }
   sr = group_sum<G>(sr); si = group_sum<G>(si); dr = group_sum<G>(dr); di = group_sum<G>(di); have = group_sum<G>(have);
   if (lg != 0) return;
-  if (MODE == 1 && have == 0.0) { dr = 1.0; di = 0.0; }
+  if (MODE >= 1 && have == 0.0) { dr = 1.0; di = 0.0; }
   const double nd = hypot(dr, di);
+  if (MODE == 2) {          // IluPreconditioner::apply's back substitution (ilu.rs:154-170): the sum always, the division only for |u_ii| > 1e-30
+    const dc bb = b[i];
+    const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
+    if (nd > 1e-30) { const double ir = dr / ns, ii = -di / ns; x[i] = dc_make(nr * ir - ni * ii, nr * ii + ni * ir); }
+    else x[i] = dc_make(nr, ni);
+    return;
+  }
   if (MODE == 1 ? !(nd > 1e-15) : (nd < 1e-15)) return;
   const dc bb = b[i];
   const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
@@ -332,6 +340,8 @@ __global__ __launch_bounds__(256) void csr_gs_persistent_kernel(CsrView A, const
     }
     if (L + 1 == nlev) break;                              // the kernel boundary orders the last level
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's x stores have reached the coherence point
+    __shared__ unsigned s_dead;
+    if (threadIdx.x == 0) s_dead = 0u;
     __syncthreads();
     if (threadIdx.x == 0) {
       // two-level arrival: 8 groups (workgroup b -> group b % 8 = its XCD under the round-robin placement) count their members on
@@ -342,12 +352,18 @@ __global__ __launch_bounds__(256) void csr_gs_persistent_kernel(CsrView A, const
       if ((old + 1u - gbase) == (unsigned)(L + 1) * gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned target = base + (unsigned)(L + 1) * ngrp;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      // a barrier that has failed once (this launch or an earlier one of this handle: the word is sticky until ma_csr_status) is not
+      // waited on again: with the arrival counters out of step every remaining level would spin for its full 2 s
+      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_dead = 1u;
+      unsigned spins = 0;
+      while (!s_dead && (int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // 2 s at 100 MHz
+        if ((++spins & 255u) == 0u && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_dead = 1u;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dead = 1u; }   // 2 s at 100 MHz
       }
     }
     __syncthreads();
+    if (s_dead) return;                                    // the whole workgroup leaves (ma_csr_status / the Krylov drivers report it)
   }
 }
 // The same sweep without a barrier and without flags: the new iterate is written to a second array xn that starts as a sentinel
@@ -370,7 +386,7 @@ __global__ __launch_bounds__(256) void csr_gs_fill_sentinel_kernel(long long n2,
 }
 template <bool KM, int MODE>
 __global__ __launch_bounds__(256) void csr_gs_flags_kernel(CsrView A, const int* __restrict__ rows, long long npad, const dc* __restrict__ x, dc* xn,
-                                                           const dc* __restrict__ b, int backward, unsigned* err) {
+                                                           const dc* __restrict__ b, int backward, unsigned* err, unsigned* gerr) {
   constexpr int G = 16;
   const int lg = threadIdx.x & (G - 1);
   const long long group0 = ((long long)blockIdx.x * 256 + threadIdx.x) / G, ngroups = (long long)gridDim.x * (256 / G);
@@ -398,7 +414,11 @@ __global__ __launch_bounds__(256) void csr_gs_flags_kernel(CsrView A, const int*
               wa = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wb = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if ((++spins & 1023u) == 0u) {
                 if (__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+                  __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (gerr) __hip_atomic_store(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // the device-wide word the Krylov drivers read
+                  dead = true; break;
+                }
               }
             } while (wa == GS_SENTINEL || wb == GS_SENTINEL);
           }
@@ -409,10 +429,15 @@ __global__ __launch_bounds__(256) void csr_gs_flags_kernel(CsrView A, const int*
     }
     sr = group_sum<G>(sr); si = group_sum<G>(si); dr = group_sum<G>(dr); di = group_sum<G>(di); have = group_sum<G>(have);
     if (lg != 0 || i < 0) continue;
-    if (MODE == 1 && have == 0.0) { dr = 1.0; di = 0.0; }
+    if (MODE >= 1 && have == 0.0) { dr = 1.0; di = 0.0; }
     const double nd = hypot(dr, di);
     dc out = x[i];                                            // a skipped row keeps its value
-    if (!(MODE == 1 ? !(nd > 1e-15) : (nd < 1e-15))) {
+    if (MODE == 2) {                                          // ilu.rs:154-170: the sum always, the division only for |u_ii| > 1e-30
+      const dc bb = b[i];
+      const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
+      if (nd > 1e-30) { const double ir = dr / ns, ii = -di / ns; out = dc_make(nr * ir - ni * ii, nr * ii + ni * ir); }
+      else out = dc_make(nr, ni);
+    } else if (!(MODE == 1 ? !(nd > 1e-15) : (nd < 1e-15))) {
       const dc bb = b[i];
       const double nr = bb.re - sr, ni = bb.im - si, ns = dr * dr + di * di;
       if (MODE == 1) { const double ir = dr / ns, ii = -di / ns; out = dc_make(nr * ir - ni * ii, nr * ii + ni * ir); }
@@ -428,13 +453,33 @@ int csr_launch_gs_flags(const CsrView& A, bool km, int mode, const int* rows_pad
                         hipStream_t st) {
   if (npad <= 0 || A.n <= 0) return MA_OK;
   const dc* xx = reinterpret_cast<const dc*>(x); dc* nn = reinterpret_cast<dc*>(xn); const dc* bb = reinterpret_cast<const dc*>(b);
+  // the sweep's workgroups wait for one another's rows: the launch goes through the same admission window as the LU panel kernels
+  // (registers of this instantiation from the runtime, once; the CUs of the device)
+  MA_REQUIRE(mode >= 0 && mode <= 2 && !(km && mode == 2), MA_ERR_INVALID, "sweep mode %d", mode);   // mode 2 (triangular solve) only on stored values
+  static int regs_of[5] = {0, 0, 0, 0, 0}; static int ncu_of[16] = {};
+  const int which = mode == 2 ? 4 : (km ? 2 : 0) + (mode ? 1 : 0);
+  int dev = 0; MA_HIP(hipGetDevice(&dev));
+  if (regs_of[which] == 0) {
+    const void* f = km ? (mode ? reinterpret_cast<const void*>(csr_gs_flags_kernel<true, 1>) : reinterpret_cast<const void*>(csr_gs_flags_kernel<true, 0>))
+                       : (mode == 2 ? reinterpret_cast<const void*>(csr_gs_flags_kernel<false, 2>)
+                                    : (mode ? reinterpret_cast<const void*>(csr_gs_flags_kernel<false, 1>) : reinterpret_cast<const void*>(csr_gs_flags_kernel<false, 0>)));
+    hipFuncAttributes fa; MA_HIP(hipFuncGetAttributes(&fa, f));
+    regs_of[which] = fa.numRegs > 0 ? fa.numRegs : 128;
+  }
+  if (dev >= 0 && dev < 16 && ncu_of[dev] == 0) { hipDeviceProp_t prop; MA_HIP(hipGetDeviceProperties(&prop, dev)); ncu_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+  const int ncu = (dev >= 0 && dev < 16) ? ncu_of[dev] : 256;
   hipLaunchKernelGGL(csr_gs_fill_sentinel_kernel, dim3((unsigned)((2 * A.n + 255) / 256)), dim3(256), 0, st, 2 * A.n, reinterpret_cast<unsigned long long*>(xn));
+  SpinLaunch guard;
+  { const int arc = guard.admit(st, grid, 0, regs_of[which], ncu); if (arc) return arc; }
+  unsigned* gerr = spin_error_word();
   dim3 g((unsigned)grid), block(256);
-  if (km) { if (mode) hipLaunchKernelGGL((csr_gs_flags_kernel<true, 1>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err);
-            else hipLaunchKernelGGL((csr_gs_flags_kernel<true, 0>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err); }
-  else { if (mode) hipLaunchKernelGGL((csr_gs_flags_kernel<false, 1>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err);
-         else hipLaunchKernelGGL((csr_gs_flags_kernel<false, 0>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err); }
+  if (km) { if (mode) hipLaunchKernelGGL((csr_gs_flags_kernel<true, 1>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err, gerr);
+            else hipLaunchKernelGGL((csr_gs_flags_kernel<true, 0>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err, gerr); }
+  else { if (mode == 2) hipLaunchKernelGGL((csr_gs_flags_kernel<false, 2>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err, gerr);
+         else if (mode) hipLaunchKernelGGL((csr_gs_flags_kernel<false, 1>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err, gerr);
+         else hipLaunchKernelGGL((csr_gs_flags_kernel<false, 0>), g, block, 0, st, A, rows_padded, npad, xx, nn, bb, backward, err, gerr); }
   MA_HIP(hipGetLastError());
+  { const int crc = guard.commit(); if (crc) return crc; }
   MA_HIP(hipMemcpyAsync(x, xn, sizeof(c64) * (size_t)A.n, hipMemcpyDeviceToDevice, st));
   return MA_OK;
 }
@@ -444,12 +489,17 @@ int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* row
   if (nlev <= 0) return MA_OK;
   dc* xx = reinterpret_cast<dc*>(x); const dc* bb = reinterpret_cast<const dc*>(b);
   dim3 g((unsigned)grid), block(256);
+  // a device-wide barrier per level: every workgroup must be resident -> the admission window of the spinning kernels
+  int dev = 0; MA_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop; MA_HIP(hipGetDeviceProperties(&prop, dev));
+  SpinLaunch guard;
+  { const int arc = guard.admit(st, grid, 0, 128, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256); if (arc) return arc; }
   if (km) { if (mode) hipLaunchKernelGGL((csr_gs_persistent_kernel<true, 1>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase);
             else hipLaunchKernelGGL((csr_gs_persistent_kernel<true, 0>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase); }
   else { if (mode) hipLaunchKernelGGL((csr_gs_persistent_kernel<false, 1>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase);
          else hipLaunchKernelGGL((csr_gs_persistent_kernel<false, 0>), g, block, 0, st, A, rows, lev_ptr, nlev, xx, bb, bar, base, gbase); }
   MA_HIP(hipGetLastError());
-  return MA_OK;
+  return guard.commit();
 }
 
 int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, int count, c64* x, const c64* b, hipStream_t st) {
@@ -458,7 +508,8 @@ int csr_launch_gs_level(const CsrView& A, bool km, int mode, const int* rows, in
   dc* xx = reinterpret_cast<dc*>(x); const dc* bb = reinterpret_cast<const dc*>(b);
   if (km) { if (mode) hipLaunchKernelGGL((csr_gs_level_kernel<true, 1>), grid, block, 0, st, A, rows, count, xx, bb);
             else hipLaunchKernelGGL((csr_gs_level_kernel<true, 0>), grid, block, 0, st, A, rows, count, xx, bb); }
-  else { if (mode) hipLaunchKernelGGL((csr_gs_level_kernel<false, 1>), grid, block, 0, st, A, rows, count, xx, bb);
+  else { if (mode == 2) hipLaunchKernelGGL((csr_gs_level_kernel<false, 2>), grid, block, 0, st, A, rows, count, xx, bb);
+         else if (mode) hipLaunchKernelGGL((csr_gs_level_kernel<false, 1>), grid, block, 0, st, A, rows, count, xx, bb);
          else hipLaunchKernelGGL((csr_gs_level_kernel<false, 0>), grid, block, 0, st, A, rows, count, xx, bb); }
   MA_HIP(hipGetLastError());
   return MA_OK;

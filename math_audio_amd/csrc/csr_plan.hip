@@ -1,5 +1,6 @@
 // csr_plan.hip — C-ABI of the sparse FEM side: CSR operator handles, SpMV, residual, Jacobi sweeps.
 #include "csr_kernels.hpp"
+#include "lu_kernels.hpp"
 #include "ma_device_math.hpp"
 #include <vector>
 #include <cstdlib>
@@ -564,7 +565,8 @@ static int build_levels(ma_csr* h) {
 // one sweep over all rows in index order (backward = 0) or reverse order (1); mode 0 = smoother.rs:71-117, 1 = amg.rs:932-978
 int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int mode, int backward, void* stream) {
   MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_gauss_seidel_sweep_dev needs a square operator");
-  MA_REQUIRE(h && d_x && d_b && (mode == 0 || mode == 1), MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(h && d_x && d_b && mode >= 0 && mode <= 2, MA_ERR_INVALID, "bad argument");   // 2: a triangular solve (ilu.rs:154-170), stored values only
+  MA_REQUIRE(mode != 2 || !h->fused_km(), MA_ERR_UNSUPPORTED, "the triangular-solve sweep runs on stored values");
   MA_HIP(hipSetDevice(h->device));
   int rc = build_levels(h);
   if (rc) return rc;
@@ -576,7 +578,7 @@ int ma_csr_gauss_seidel_sweep_dev(ma_csr_t* h, void* d_x, const void* d_b, int m
   // for the launches -- a dependent launch costs 4.9 us here, a barrier plus the level's cold coherent loads 5.7 us -- so the
   // launches stay the default; the results are bit-identical either way (tests/test_csr_gpu.py).
   const char* epers = getenv("MA_CSR_GS_PERSISTENT");
-  const bool persistent = epers && atoi(epers) != 0;
+  const bool persistent = epers && atoi(epers) != 0 && mode != 2;
   const int nlev = (int)lp.size() - 1;
   // Default: ONE persistent launch in which the new iterate goes to a second array that starts as a sentinel and a row polls the new
   // values it needs until they have left the sentinel (csr_gs_flags_kernel). Bit-identical to the launches (tools/gs_sweep_modes.py).
@@ -629,7 +631,13 @@ int ma_csr_status(ma_csr_t* h) {
   unsigned w[2] = {0, 0};
   MA_HIP(hipDeviceSynchronize());
   MA_HIP(hipMemcpy(w, h->d_gs_bar, sizeof(w), hipMemcpyDeviceToHost));
-  MA_REQUIRE(w[1] == 0, MA_ERR_HIP, "a Gauss-Seidel sweep was abandoned at its device-wide barrier");
+  if (w[1] != 0) {
+    // reported once: the handle's word and the device-wide one are cleared, later sweeps of the handle wait again
+    (void)hipMemset(h->d_gs_bar + 1, 0, sizeof(unsigned));
+    (void)spin_error_check("ma_csr_status");
+    set_error("a Gauss-Seidel sweep was abandoned at its exchange between workgroups");
+    return MA_ERR_HIP;
+  }
   return MA_OK;
 }
 // number of dependency levels of the forward / backward Gauss-Seidel schedule (diagnostics: launches per sweep)

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const dc* up = s_urow[(c - 1) & 1];
         dc u[NB];
         static_for<c + 1, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; u[j] = up[j]; });
-        const double nlr = -lprev.re, nli = -lprev.im, lr = lprev.re, li = lprev.im;
+        const double nlr = -lprev.re, nli = -lprev.im, li = lprev.im;
         static_for<c + 1, NB>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           a[j].re = __builtin_fma(li, u[j].im, __builtin_fma(nlr, u[j].re, a[j].re));
@@ -1863,57 +1863,36 @@ int lu_panel_admissible(int nb, int rpb, int nblk, int ncu) {
   return MA_OK;
 }
 
-// LDS the register panel kernel declares (static: pivot row, staging row, a few words)
-static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 64; }
-
-// admission + launch of a panel kernel. kind 0: lu_panel_kernel on (A[0], ws[0], ipiv[0]); kind 1: lu_panel_wave_kernel over nsys
-// systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
-// CUs the stream may use (a CU-masked stream: the CUs of its mask).
-static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st,
-                            int* reg_lists = nullptr) {
-  int dev = 0;
-  MA_HIP(hipGetDevice(&dev));
-  MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
-  MA_REQUIRE(nsys >= 1 && nsys <= LU_GROUP_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
-  MA_REQUIRE(kind == 2 ? (nsys == 1 && rpb == 256 && nb >= 1 && nb <= LU_REG_NB) : (kind == (nsys == 1 ? 0 : 1)), MA_ERR_INVALID, "panel kernel kind %d with %d systems, %d rows per workgroup, %d columns", kind, nsys, rpb, nb);
-  const LuPanelWs& ws = wss[0];
-  MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
-  MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,
-             "panel grid (%d workgroups of %d rows from row %d) does not tile the %d rows", nblk, rpb, k0, n);
-  MA_REQUIRE(n < 0xFFFFFF, MA_ERR_UNSUPPORTED, "row positions travel in 24 bits of the exchange granule");
-  const size_t sys_lds = (lu_panel_lds_bytes(nb, rpb) + 15) & ~(size_t)15;
-  const size_t lds = kind == 2 ? lu_panel_reg_lds() : (kind == 0 ? lu_panel_lds_bytes(nb, rpb) : sys_lds * (size_t)nsys);
-  const int regs = lu_panel_regs(kind);
+// ---- the admission window as a guard any SPINNING kernel of the library goes through (LU panels, the flag-driven Gauss-Seidel
+// sweep, the one-launch Gram-Schmidt step): admit() holds the sequencer until commit() has recorded the launch's event
+int SpinLaunch::admit(hipStream_t st_, int nblk_, size_t lds_, int regs_, int ncu_) {
+  int dev_ = 0;
+  MA_HIP(hipGetDevice(&dev_));
+  MA_REQUIRE(dev_ >= 0 && dev_ < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the sequencer table", dev_);
   {
-    const int p = lu_panel_slots_per_cu(lds, regs);
-    MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
-               "panel grid of %d workgroups x %zu B LDS (%d systems, %d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nsys, nb, rpb, ncu, p);
+    const int p = lu_panel_slots_per_cu(lds_ ? lds_ : 1, regs_);
+    MA_REQUIRE(p >= 1 && (long long)nblk_ <= (long long)p * ncu_, MA_ERR_UNSUPPORTED,
+               "a spinning grid of %d workgroups (%zu B LDS, %d registers) cannot be co-resident on %d CUs (%d per CU)", nblk_, lds_, regs_, ncu_, p);
   }
-  std::lock_guard<std::mutex> lock(g_seq.mu);
+  g_seq.mu.lock(); locked = true;
+  dev = dev_; st = st_; nblk = nblk_; lds = lds_ ? lds_ : 1; regs = regs_; ncu = ncu_;
   if (!g_seq.made[dev]) {
-    for (int i = 0; i < kSeqRing; ++i) MA_HIP(hipEventCreateWithFlags(&g_seq.ring[dev][i].ev, hipEventDisableTiming));
+    for (int i = 0; i < kSeqRing; ++i) {
+      const hipError_t e = hipEventCreateWithFlags(&g_seq.ring[dev][i].ev, hipEventDisableTiming);
+      if (e != hipSuccess) { set_error("sequencer events: %s", hipGetErrorString(e)); abandon(); return MA_ERR_HIP; }
+    }
     g_seq.made[dev] = true;
   }
-  if (kind == 2 ? !g_seq.occ_checked_reg : (int)lds > g_seq.occ_checked_lds) {
-    // the runtime's own occupancy figure must not be below the slots the rule assumes (registers, waves, LDS granularity)
-    int occ = 0;
-    if (kind == 0) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
-    else if (kind == 1) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_wave_kernel), 64 * nsys, lds));
-    else MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>), 256, 0));
-    MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU at %zu B LDS is below the %d slots the admission rule assumes",
-               occ, lds, lu_panel_slots_per_cu(lds, regs));
-    if (kind == 2) g_seq.occ_checked_reg = true; else g_seq.occ_checked_lds = (int)lds;
-  }
-  // Admission. Streams are in order, so at most ONE panel kernel per stream runs at any time, and what may run beside this
+  // Admission. Streams are in order, so at most ONE spinning kernel per stream runs at any time, and what may run beside this
   // launch is, per other stream, one of that stream's earlier launches (later launches do their own admission and count this
-  // one). Per other stream take the largest grid and LDS size among its launches of the last 256 panel launches; if this
-  // launch plus one such grid per stream fits p(s_max) x ncu workgroups, nothing has to be waited for. Otherwise the launch
-  // waits for the LATEST launch of the stream whose latest launch is oldest (that stream then contributes nothing: all its
-  // earlier launches are over when this kernel starts), and so on until the rest fits. For equal shapes on three lanes this
-  // is "wait for the launch before the previous one"; the running set is always bounded by what its newest member computed,
-  // so the residency argument above applies to it. With CU-masked streams in the window the CUs counted are those of the
-  // SMALLEST set any member may use (grids on a mask share its CUs with every unmasked grid): a grid that needs more than
-  // that runs on its own, which the check above has already allowed.
+  // one). Per other stream take the largest grid and LDS size among its launches of the last 256 launches; if this launch plus
+  // one such grid per stream fits p(s_max) x ncu workgroups, nothing has to be waited for. Otherwise the launch waits for the
+  // LATEST launch of the stream whose latest launch is oldest (that stream then contributes nothing: all its earlier launches are
+  // over when this kernel starts), and so on until the rest fits. For equal shapes on three lanes this is "wait for the launch
+  // before the previous one"; the running set is always bounded by what its newest member computed, so the residency argument
+  // above applies to it. With CU-masked streams in the window the CUs counted are those of the SMALLEST set any member may use
+  // (grids on a mask share its CUs with every unmasked grid): a grid that needs more than that runs on its own, which the check
+  // above has already allowed.
   const unsigned long long i = g_seq.count[dev];
   PanelLaunch* ring = g_seq.ring[dev];
   PanelLaunch& me = ring[i % kSeqRing];
@@ -1950,9 +1929,93 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
       continue;
     }
     const PanelLaunch& L = ring[lanes[victim].latest % kSeqRing];
-    if (pending(L.ev)) MA_HIP(hipStreamWaitEvent(st, L.ev, 0));
+    if (pending(L.ev)) {
+      const hipError_t e = hipStreamWaitEvent(st, L.ev, 0);
+      if (e != hipSuccess) { set_error("hipStreamWaitEvent failed: %s", hipGetErrorString(e)); abandon(); return MA_ERR_HIP; }
+    }
     lanes[victim].st = nullptr;                               // everything that stream launched before is over when this kernel starts
   }
+  return MA_OK;
+}
+int SpinLaunch::commit() {
+  if (!locked) return MA_OK;
+  const unsigned long long i = g_seq.count[dev];
+  PanelLaunch& me = g_seq.ring[dev][i % kSeqRing];
+  const hipError_t e = hipEventRecord(me.ev, st);
+  if (e == hipSuccess) { me.nblk = nblk; me.lds = lds; me.regs = regs; me.ncu = ncu; me.st = st; me.used = true; g_seq.count[dev] = i + 1; }
+  else set_error("hipEventRecord failed: %s", hipGetErrorString(e));
+  abandon();
+  return e == hipSuccess ? MA_OK : MA_ERR_HIP;
+}
+void SpinLaunch::abandon() { if (locked) { locked = false; g_seq.mu.unlock(); } }
+SpinLaunch::~SpinLaunch() { abandon(); }
+
+// device-wide "a spinning kernel gave up a wait" word: every such kernel raises it beside its own status word, every Krylov driver
+// reads (and clears) it once at its end -- a result computed across an abandoned wait is never returned with MA_OK
+namespace { unsigned* g_spin_err[16] = {}; std::mutex g_spin_err_mu; }
+unsigned* spin_error_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(g_spin_err_mu);
+  if (!g_spin_err[dev]) {
+    if (hipMalloc(&g_spin_err[dev], 64) != hipSuccess) { (void)hipGetLastError(); g_spin_err[dev] = nullptr; return nullptr; }
+    (void)hipMemset(g_spin_err[dev], 0, 64);
+    (void)hipDeviceSynchronize();
+  }
+  return g_spin_err[dev];
+}
+int spin_error_check(const char* what) {
+  unsigned* w = spin_error_word();
+  if (!w) return MA_OK;
+  unsigned v = 0;
+  MA_HIP(hipMemcpy(&v, w, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (!v) return MA_OK;
+  (void)hipMemset(w, 0, sizeof(unsigned));
+  set_error("%s: a kernel that exchanges between its workgroups abandoned a wait (its grid was not co-resident within 2 s); the result is not valid", what);
+  return MA_ERR_HIP;
+}
+
+// LDS the register panel kernel declares (static: pivot row, staging row, a few words)
+static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 64; }
+
+// admission + launch of a panel kernel. kind 0: lu_panel_kernel on (A[0], ws[0], ipiv[0]); kind 1: lu_panel_wave_kernel over nsys
+// systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
+// CUs the stream may use (a CU-masked stream: the CUs of its mask).
+static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st,
+                            int* reg_lists = nullptr) {
+  int dev = 0;
+  MA_HIP(hipGetDevice(&dev));
+  MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
+  MA_REQUIRE(nsys >= 1 && nsys <= LU_GROUP_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
+  MA_REQUIRE(kind == 2 ? (nsys == 1 && rpb == 256 && nb >= 1 && nb <= LU_REG_NB) : (kind == (nsys == 1 ? 0 : 1)), MA_ERR_INVALID, "panel kernel kind %d with %d systems, %d rows per workgroup, %d columns", kind, nsys, rpb, nb);
+  const LuPanelWs& ws = wss[0];
+  MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
+  MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,
+             "panel grid (%d workgroups of %d rows from row %d) does not tile the %d rows", nblk, rpb, k0, n);
+  MA_REQUIRE(n < 0xFFFFFF, MA_ERR_UNSUPPORTED, "row positions travel in 24 bits of the exchange granule");
+  const size_t sys_lds = (lu_panel_lds_bytes(nb, rpb) + 15) & ~(size_t)15;
+  const size_t lds = kind == 2 ? lu_panel_reg_lds() : (kind == 0 ? lu_panel_lds_bytes(nb, rpb) : sys_lds * (size_t)nsys);
+  const int regs = lu_panel_regs(kind);
+  {
+    const int p = lu_panel_slots_per_cu(lds, regs);
+    MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
+               "panel grid of %d workgroups x %zu B LDS (%d systems, %d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nsys, nb, rpb, ncu, p);
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_seq.mu);
+    if (kind == 2 ? !g_seq.occ_checked_reg : (int)lds > g_seq.occ_checked_lds) {
+      // the runtime's own occupancy figure must not be below the slots the rule assumes (registers, waves, LDS granularity)
+      int occ = 0;
+      if (kind == 0) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
+      else if (kind == 1) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_wave_kernel), 64 * nsys, lds));
+      else MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>), 256, 0));
+      MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU at %zu B LDS is below the %d slots the admission rule assumes",
+                 occ, lds, lu_panel_slots_per_cu(lds, regs));
+      if (kind == 2) g_seq.occ_checked_reg = true; else g_seq.occ_checked_lds = (int)lds;
+    }
+  }
+  SpinLaunch guard;
+  { const int arc = guard.admit(st, nblk, lds, regs, ncu); if (arc) return arc; }
   // Stale tags must not match. A workgroup rewrites its granule every column, so only columns 0 and 1 of a launch can
   // see the previous launch's granules, which carry that launch's last two tags (nb and nb - 1): they differ from the
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
@@ -1968,10 +2031,7 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
     hipLaunchKernelGGL(lu_panel_wave_kernel, dim3(nblk), dim3(64 * nsys), lds, st, B, n, k0, nb, rpb, (unsigned)sys_lds);
   }
   MA_HIP(hipGetLastError());
-  MA_HIP(hipEventRecord(me.ev, st));
-  me.nblk = nblk; me.lds = lds; me.regs = regs; me.ncu = ncu; me.st = st; me.used = true;
-  g_seq.count[dev] = i + 1;
-  return MA_OK;
+  return guard.commit();
 }
 
 // a stream is about to be destroyed (its work is over): the sequencer must not wait on, or query, events recorded on it

@@ -24,6 +24,21 @@ struct LuPanelWs {
   int test_abort_col;           // test hook (MA_LU_TEST_ABORT_COL): the last workgroup gives up at this global column; -1 = off
 };
 
+// Admission of a kernel whose workgroups wait for one another (all of them must be resident): see "Residency" in lu_kernels.hip.
+//   SpinLaunch g; if ((rc = g.admit(stream, workgroups, lds bytes, registers per lane, CUs the stream may use))) return rc;
+//   <launch>; return g.commit();
+// admit() refuses (MA_ERR_UNSUPPORTED) a grid that cannot be co-resident on its own, and makes the stream wait for older spinning
+// grids of other streams until everything in flight fits; the sequencer stays locked until commit() / destruction.
+struct SpinLaunch {
+  bool locked = false; int dev = 0; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; int regs = 0; int ncu = 0;
+  int admit(hipStream_t st, int nblk, size_t lds, int regs, int ncu);
+  int commit();
+  void abandon();
+  ~SpinLaunch();
+};
+unsigned* spin_error_word();            // device word raised by any spinning kernel that abandons a wait (NULL if it cannot be allocated)
+int spin_error_check(const char* what); // MA_ERR_HIP (and clears the word) if it is set; synchronous 4-byte copy
+
 size_t lu_panel_lds_bytes(int nb, int rpb);
 size_t lu_panel_granule_bytes(int max_blocks);
 int lu_panel_configure();

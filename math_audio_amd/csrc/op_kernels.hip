@@ -11,6 +11,8 @@
 //   dot / axpy / scale  inner_product (conj(x).y), axpy and vector_norm of blas_helpers.rs:21-73 with the
 //                       scalar kept on the device between the dot and the axpy of modified Gram-Schmidt.
 #include "op_kernels.hpp"
+#include "lu_kernels.hpp"
+#include <algorithm>
 #include "ma_device_math.hpp"
 
 namespace ma {
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(256) void mgs_fill_kernel(long long nwords, unsigne
 }
 template <int E>
 __global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* __restrict__ V, int j, dc* __restrict__ w, unsigned long long* slots /* (j + 2) x gridDim.x x 2 */,
-                                                        dc* __restrict__ scal_out /* h_0..h_j, then (|w|, 0) */, unsigned* err) {
+                                                        dc* __restrict__ scal_out /* h_0..h_j, (|w|, 0), then (1, 0) if a wait was abandoned else (0, 0) */, unsigned* err,
+                                                        unsigned* gerr) {
   __shared__ double sr[4], si[4], tr[4], ti[4], hb[2][2];        // two sets of reduction slots and two h slots: a barrier less per phase
   const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const long long stride = (long long)nb * 256, i0 = (long long)b * 256 + tid;
@@ -427,7 +430,11 @@ __global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* _
           wa = __hip_atomic_load(row + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wb = __hip_atomic_load(row + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((++spins & 1023u) == 0u) {
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dead = true; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+              __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (gerr) __hip_atomic_store(gerr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              dead = true; break;
+            }
           }
         } while (wa == MGS_SENTINEL || wb == MGS_SENTINEL);
       }
@@ -454,24 +461,51 @@ __global__ __launch_bounds__(256) void gmres_mgs_kernel(long long n, const dc* _
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) { const long long idx = i0 + e * stride; if (idx < n) w[idx] = wv[e]; }
+  // workgroup 0 waits for every workgroup's slots in every step: if any wait of this launch was abandoned, one of its threads knows
+  if (b == 0) {
+    const int any = __syncthreads_or(dead ? 1 : 0);
+    if (tid == 0) scal_out[j + 2] = dc_make(any ? 1.0 : 0.0, 0.0);
+  }
 }
-// returns MA_ERR_UNSUPPORTED when the vector is too long for the register-resident form (the caller then runs the separate kernels)
+// returns MA_ERR_UNSUPPORTED when the vector is too long for the register-resident form, or when the grid cannot be co-resident on
+// this device on its own (the caller then runs the separate kernels)
+template <int E> static const void* mgs_fn() { return reinterpret_cast<const void*>(gmres_mgs_kernel<E>); }
 int op_launch_gmres_mgs(long long n, const c64* V, int j, c64* w, void* slots, c64* scal_out, unsigned* err, hipStream_t st) {
   int nb = (int)((n + 255) / 256); if (nb > RED_BLOCKS) nb = RED_BLOCKS; if (nb < 1) nb = 1;
   const long long per = (n + (long long)nb * 256 - 1) / ((long long)nb * 256);
   if (per > MGS_EMAX) return MA_ERR_UNSUPPORTED;
+  const int ei = per <= 1 ? 0 : per <= 2 ? 1 : per <= 4 ? 2 : per <= 8 ? 3 : per <= 16 ? 4 : 5;
+  // Residency: the workgroups of this launch wait for one another. The grid is the dot kernels' grid (<= 256: the partial sums are
+  // then theirs bit for bit), so it must fit the device at the occupancy the runtime reports for this instantiation (registers:
+  // E = 32 keeps 2 x 32 complex values per lane) -- otherwise the separate kernels run -- and the launch goes through the admission
+  // window of the spinning kernels (lu_kernels.hip, "Residency"), which also keeps it apart from LU panel grids and flag-driven
+  // sweeps of other streams and host threads when they do not all fit.
+  static int regs_of[6] = {}, occ_of[6] = {}; static int ncu_of[16] = {};
+  int dev = 0; MA_HIP(hipGetDevice(&dev));
+  const void* fn = ei == 0 ? mgs_fn<1>() : ei == 1 ? mgs_fn<2>() : ei == 2 ? mgs_fn<4>() : ei == 3 ? mgs_fn<8>() : ei == 4 ? mgs_fn<16>() : mgs_fn<32>();
+  if (regs_of[ei] == 0) {
+    hipFuncAttributes fa; MA_HIP(hipFuncGetAttributes(&fa, fn));
+    int occ = 0; MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, 0));
+    occ_of[ei] = occ; regs_of[ei] = fa.numRegs > 0 ? fa.numRegs : 256;
+  }
+  if (dev >= 0 && dev < 16 && ncu_of[dev] == 0) { hipDeviceProp_t prop; MA_HIP(hipGetDeviceProperties(&prop, dev)); ncu_of[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+  const int ncu = (dev >= 0 && dev < 16) ? ncu_of[dev] : 256;
+  if (occ_of[ei] < 1 || (long long)nb > (long long)std::min(occ_of[ei], lu_panel_slots_per_cu(1, regs_of[ei])) * ncu) return MA_ERR_UNSUPPORTED;
   const long long nwords = (long long)(j + 2) * nb * 2;
   hipLaunchKernelGGL(mgs_fill_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, nwords, reinterpret_cast<unsigned long long*>(slots));
   const dc* Vd = reinterpret_cast<const dc*>(V); dc* wd = reinterpret_cast<dc*>(w); dc* sd = reinterpret_cast<dc*>(scal_out);
   unsigned long long* sl = reinterpret_cast<unsigned long long*>(slots);
-  if (per <= 1) hipLaunchKernelGGL(gmres_mgs_kernel<1>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
-  else if (per <= 2) hipLaunchKernelGGL(gmres_mgs_kernel<2>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
-  else if (per <= 4) hipLaunchKernelGGL(gmres_mgs_kernel<4>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
-  else if (per <= 8) hipLaunchKernelGGL(gmres_mgs_kernel<8>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
-  else if (per <= 16) hipLaunchKernelGGL(gmres_mgs_kernel<16>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
-  else hipLaunchKernelGGL(gmres_mgs_kernel<32>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err);
+  unsigned* gerr = spin_error_word();
+  SpinLaunch guard;
+  { const int arc = guard.admit(st, nb, 0, regs_of[ei], ncu); if (arc) return arc; }
+  if (ei == 0) hipLaunchKernelGGL(gmres_mgs_kernel<1>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err, gerr);
+  else if (ei == 1) hipLaunchKernelGGL(gmres_mgs_kernel<2>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err, gerr);
+  else if (ei == 2) hipLaunchKernelGGL(gmres_mgs_kernel<4>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err, gerr);
+  else if (ei == 3) hipLaunchKernelGGL(gmres_mgs_kernel<8>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err, gerr);
+  else if (ei == 4) hipLaunchKernelGGL(gmres_mgs_kernel<16>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err, gerr);
+  else hipLaunchKernelGGL(gmres_mgs_kernel<32>, dim3(nb), dim3(256), 0, st, n, Vd, j, wd, sl, sd, err, gerr);
   MA_HIP(hipGetLastError());
-  return MA_OK;
+  return guard.commit();
 }
 int op_mgs_slot_bytes(int m) { return (int)sizeof(unsigned long long) * 2 * RED_BLOCKS * (m + 2); }
 int op_launch_dot(long long n, const c64* x, const c64* y, int mode, c64* partial, c64* out, hipStream_t st) {

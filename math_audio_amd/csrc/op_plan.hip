@@ -1,6 +1,7 @@
 // op_plan.hip — the operator boundary (LinearOperator<Complex64>, math-solvers/src/traits.rs:316-327) and
 // restarted GMRES (math-solvers/src/iterative/gmres.rs:105-277) on the device.
 #include "op_kernels.hpp"
+#include "lu_kernels.hpp"
 #include "fmm_plan.hpp"
 #include "amg_setup.hpp"
 #include <chrono>
@@ -919,8 +920,10 @@ int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stre
   if (M->kind == 6) {                                    // IluPreconditioner::apply (ilu.rs:143-175): L y = r forward, U z = y backward
     // a forward sweep over a matrix without upper entries IS the forward substitution (and a backward sweep over one without lower
     // entries the backward substitution): the level-scheduled Gauss-Seidel sweeps of the two factors, amg.rs' form sum * diag.inv()
+    // U: mode 2 -- x_i = y_i - sum always, times u_ii^-1 only where |u_ii| > 1e-30 (ilu.rs:154-170): nothing of what the caller's
+    // d_z held before survives into the result
     int rc = ma_csr_gauss_seidel_sweep_dev(M->ilu_l, M->d_tmp, d_r, 1, 0, stream);
-    if (!rc) rc = ma_csr_gauss_seidel_sweep_dev(M->ilu_u, d_z, M->d_tmp, 1, 1, stream);
+    if (!rc) rc = ma_csr_gauss_seidel_sweep_dev(M->ilu_u, d_z, M->d_tmp, 2, 1, stream);
     return rc;
   }
   const bool amg_lazy = M->kind == 5 && amg_first_sweep_writes(M, 0);          // z = 0 is then written by the cycle's first sweep
@@ -955,6 +958,7 @@ int ma_precond_apply(ma_precond_t* M, const ma_c64* r_host, ma_c64* z_host) {
   if (!rc) rc = ma_precond_apply_dev(M, d_r, d_z, nullptr);
   if (!rc && hipMemcpy(z_host, d_z, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = MA_ERR_HIP;
   (void)hipFree(d_r); (void)hipFree(d_z);
+  if (!rc) rc = spin_error_check("ma_precond_apply");
   return rc;
 }
 
@@ -977,7 +981,7 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
   GM_HIP(hipMalloc(&w, sizeof(c64) * (size_t)n));
   GM_HIP(hipMalloc(&x, sizeof(c64) * (size_t)n));
   GM_HIP(hipMalloc(&b, sizeof(c64) * (size_t)n));
-  GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 4)));
+  GM_HIP(hipMalloc(&scal, sizeof(c64) * (size_t)(m + 5)));
   GM_HIP(hipMalloc(&partial, sizeof(c64) * 256));
   GM_HIP(hipMalloc(&t, sizeof(c64) * (size_t)n));
   // the Gram-Schmidt step as one launch (op_launch_gmres_mgs); MA_GMRES_FUSED_MGS=0: an inner product and an update kernel per basis vector
@@ -1002,7 +1006,7 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
   info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
   if (b_norm < 1e-15) { GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost)); cleanup(); return MA_OK; }
 
-  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2);
+  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 3);
   auto Hh = [&](int i, int j) -> cplx& { return H[(size_t)i * m + j]; };
   auto givens = [](cplx a, cplx bb, cplx* c, cplx* s) {
     if (std::abs(bb) < 1e-30) { *c = 1.0; *s = 0.0; return; }
@@ -1053,7 +1057,13 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
         }
         GM_RC(op_launch_dot(n, w, nullptr, 1, partial, scal + 2 + j, st));
       }
-      GM_HIP(hipMemcpy(hcol.data(), scal + 1, sizeof(c64) * (size_t)(j + 2), hipMemcpyDeviceToHost));   // one sync per inner step
+      GM_HIP(hipMemcpy(hcol.data(), scal + 1, sizeof(c64) * (size_t)(j + 2 + (stepped ? 1 : 0)), hipMemcpyDeviceToHost));   // one sync per inner step
+      if (stepped && hcol[j + 2].real() != 0.0) {            // the one-launch step gave up a wait (its flag rides behind |w|): stop at once
+        set_error("a Gram-Schmidt step was abandoned at its exchange (iteration %d)", total);
+        (void)spin_error_check("ma_gmres");                   // clears the device-wide word; the text above is what the caller reads
+        set_error("a Gram-Schmidt step was abandoned at its exchange (iteration %d)", total);
+        cleanup(); return MA_ERR_HIP;
+      }
       for (int i = 0; i <= j; ++i) Hh(i, j) = hcol[i];
       const double wn = hcol[j + 1].real();
       Hh(j + 1, j) = wn;
@@ -1092,6 +1102,9 @@ static int gmres_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_host, const 
     info->iterations = total; info->restarts = restarts; info->residual = rn / b_norm; info->converged = 0;
   }
   if (mgs_err) { unsigned ew = 0; GM_HIP(hipMemcpy(&ew, mgs_err, sizeof(unsigned), hipMemcpyDeviceToHost)); if (ew) { set_error("a Gram-Schmidt step was abandoned at its exchange"); cleanup(); return MA_ERR_HIP; } }
+  // a flag-driven sweep inside the preconditioner (symmetric Gauss-Seidel, ILU, Schwarz, AMG smoothers) that abandoned a wait left
+  // sentinel NaNs in its result: never return that with MA_OK
+  GM_RC(spin_error_check("ma_gmres"));
   GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost));
   cleanup();
 #undef GM_HIP
@@ -1148,7 +1161,7 @@ static int gmres_pipelined_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_ho
   info->iterations = 0; info->restarts = 0; info->converged = 1; info->residual = 0.0;
   if (b_norm < 1e-15) { GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost)); cleanup(); return MA_OK; }
 
-  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 2);
+  std::vector<cplx> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m), hcol(m + 3);
   auto Hh = [&](int i, int j) -> cplx& { return H[(size_t)i * m + j]; };
   auto givens = [](cplx a, cplx bb, cplx* c, cplx* s) {
     if (std::abs(bb) < 1e-30) { *c = 1.0; *s = 0.0; return; }
@@ -1230,6 +1243,7 @@ static int gmres_pipelined_impl(ma_op_t* o, ma_precond_t* Mp, const ma_c64* b_ho
     double rn = 0.0; GM_RC(norm_of(q, &rn));
     info->iterations = total; info->restarts = restarts; info->residual = rn / b_norm; info->converged = 0;
   }
+  GM_RC(spin_error_check("ma_gmres_pipelined"));            // a sweep of the preconditioner that abandoned a wait: never MA_OK
   GM_HIP(hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost));
   cleanup();
 #undef GM_HIP
@@ -1295,7 +1309,7 @@ static int krylov_impl(int kind, ma_op_t* o, const ma_c64* b_host, int32_t max_i
     hipError_t e = hipMemcpy(x_out, x, sizeof(c64) * (size_t)n, hipMemcpyDeviceToHost);
     cleanup();
     if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); return MA_ERR_HIP; }
-    return MA_OK;
+    return spin_error_check("Krylov solve");                // a sweep of a preconditioner that abandoned a wait: never MA_OK
   };
   double b_norm = 0.0, rn = 0.0;
   KR_RC(norm(r, &b_norm));
