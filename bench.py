@@ -754,7 +754,8 @@ def main():
                                "algorithmic_flops_per_step": gf}
             far_t = asm_ms[0] / K * 1e-3
             out["roofline_assembly"] = {"kernel": "tbem_far_kernel<%d, velocity-only> (far pairs of %d systems per pass)" % (ahead, ahead), "bound": "hbm", "achieved": 16.0 * n * n / far_t / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("ma::tbem_far_kernel"), "systems_per_pass": ahead,
+                                        "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("ma::tbem_far_kernel<%d, true>" % ahead) or pmc_traffic("ma::tbem_far_kernel"), "systems_per_pass": ahead,
+                                        "traffic_note": "bytes per LAUNCH: a launch writes the matrices of `systems_per_pass` systems (16 B x N^2 each)",
                                         "note": "16 B written per pair; the kernel is FP64-VALU/transcendental bound (SURVEY §8d): ~1.2 kflop per pair",
                                         "fp64_valu_tflops_equiv": 1.2e3 * n * n / far_t / 1e12}
             try:

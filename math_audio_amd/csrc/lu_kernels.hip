@@ -451,7 +451,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv, int* __restrict__ lists) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv, int* __restrict__ lists,
+                         dc* __restrict__ lrows, int lcol0) {
   __shared__ __attribute__((aligned(16))) dc s_urow[2][NB];   // pivot rows of the current and the previous column
   __shared__ __attribute__((aligned(16))) dc s_stage[NB];     // the row a workgroup sends: written by the lane that holds it, read by 32 lanes
   __shared__ unsigned s_m[4];
@@ -683,6 +684,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (lists && mypos != row0) {                        // "row mypos holds what row row0 held": at most 2 nbc entries over the whole grid
       const int idx = atomicAdd(lists, 1);
       if (idx < 2 * LU_NB_MAX) { lists[1 + idx] = mypos; lists[1 + 2 * LU_NB_MAX + idx] = row0; }
+    }
+    // right half of a 64-column panel (lu_plan.hip, pair form): the rows that became this half's pivot rows leave their entries of
+    // the LEFT half's columns [lcol0, lcol0 + 32) -- which nobody touches during this kernel -- in lrows[position - k0]: the block
+    // L10 the step after the panel solves with, read there instead of from rows another workgroup of that step is permuting
+    if (lrows && mypos >= k0 && mypos < k0 + nbc) {
+      const dc* lsrc = A + (size_t)row0 * n + lcol0;
+      dc* ldst = lrows + (size_t)(mypos - k0) * LU_REG_NB;
+      static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; ldst[j] = lsrc[j]; });
     }
   }
 #ifdef MA_PANEL_STAMPS
@@ -1045,10 +1054,9 @@ __device__ void lu_invert_diag32(PermLds& S, const dc* __restrict__ T, int ldt, 
 }
 
 
-__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
-                                                     const dc* __restrict__ T, int ldt, dc* __restrict__ invd, unsigned* __restrict__ poison) {
-  __shared__ PermLds S;
-  if (blockIdx.x > 0) { lu_invert_diag32<false>(S, T, ldt, nb, blockIdx.x - 1, invd); return; }
+// the panel's nb interchanges folded into (dst, src) row lists by ONE wavefront (threads >= 64 of a wider workgroup return at once)
+__device__ void lu_fold_pivots(PermLds& S, const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists, unsigned* __restrict__ poison) {
+  if (threadIdx.x >= 64) return;
   // An aborted panel (the plan's poison word is set) has no valid pivots: no rows are moved. The same for a pivot outside
   // [k0 + c, n) -- which a completed panel never produces: the plan is poisoned (code 2) instead of acting on it.
   if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) { if (threadIdx.x == 0) lists[0] = 0; return; }
@@ -1100,6 +1108,13 @@ __global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipi
     m += __popcll(bm);
   }
   if (lane == 0) lists[0] = m;
+}
+
+__global__ __launch_bounds__(64) void lu_perm_kernel(const int* __restrict__ ipiv, int n, int k0, int nb, int* __restrict__ lists /* [0]=m, dst[256], src[256] */,
+                                                     const dc* __restrict__ T, int ldt, dc* __restrict__ invd, unsigned* __restrict__ poison) {
+  __shared__ PermLds S;
+  if (blockIdx.x > 0) { lu_invert_diag32<false>(S, T, ldt, nb, blockIdx.x - 1, invd); return; }
+  lu_fold_pivots(S, ipiv, n, k0, nb, lists, poison);
 }
 
 // tmp[idx][q] = A[src[idx]][col(q)] over the column set [x0, x1) U [y0, y1) plus the nrhs RHS "columns"
@@ -1207,6 +1222,118 @@ __global__ __launch_bounds__(256) void lu_lane_step_kernel(dc* __restrict__ A, i
     }
   }
   for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int i = idx >> 5, k = idx & 31;
+    if (i < nb && k < wcols) A[(size_t)(k0 + i) * n + c0 + k] = V.B[i][k];
+  }
+}
+
+// The same step for a 64-column panel that was factored as TWO register half-panels (lu_plan.hip, launch_panel pair form): ONE launch
+// for what the 64-column chain did in six (the right half's interchanges on the left half's columns, lu_perm_kernel, gather,
+// scatter, lu_trsm64_kernel). Workgroups by role:
+//   [0, nstrips)   a strip of 32 columns of [x0, x0 + ncols): the left half's interchange list, then the right half's (each: every
+//                  read before any write; panel rows live in LDS), then U = L11^-1 B with the 64 x 64 L11 in three 32 x 32 pieces
+//                  that share one LDS buffer (solve, subtract L10 X0, solve);
+//   nstrips        the right half's interchanges on the left half's columns [k0, k0 + 32);
+//   nstrips + 1, 2 the inverted diagonal blocks of L11 for the main lane;
+//   nstrips + 3    the 64 pivots folded into the list the main lane applies left and right of the block.
+struct LaneStep2Lds {
+  union {
+    struct { dc B[64][33], L[32][33]; int dst[2][2 * LU_REG_NB], src[2][2 * LU_REG_NB]; int m[2]; } strip;
+    PermLds perm;
+  };
+};
+__global__ __launch_bounds__(256) void lu_lane_step2_kernel(dc* __restrict__ A, int n, int k0, int nb, const int* __restrict__ lists1, const int* __restrict__ lists2,
+                                                            int x0, int ncols, const int* __restrict__ ipiv, int* __restrict__ lists64, dc* __restrict__ invd,
+                                                            unsigned* __restrict__ poison, const dc* __restrict__ l10 /* rows 32.. of L11 x columns 0..31, row-major 32 wide */) {
+  __shared__ LaneStep2Lds S;
+  const int tid = threadIdx.x;
+  const int nstrips = (ncols + 31) / 32;
+  const int role = (int)blockIdx.x - nstrips;
+  if (role == 1 || role == 2) { if (32 * (role - 1) < nb) lu_invert_diag32<true>(S.perm, A + (size_t)k0 * n + k0, n, nb, role - 1, invd); return; }
+  if (role == 3) { lu_fold_pivots(S.perm, ipiv, n, k0, nb, lists64, poison); return; }
+  if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) return;      // an aborted panel has no valid pivots: no rows are moved
+  auto& V = S.strip;
+  const int h1 = min(nb, LU_REG_NB);
+  if (tid < 2) { int m = (tid == 0 ? lists1 : lists2)[0]; if (m < 0 || m > 2 * LU_REG_NB) m = 0; if (tid == 1 && nb <= LU_REG_NB) m = 0; V.m[tid] = m; }
+  __syncthreads();
+  for (int q = 0; q < 2; ++q) {
+    const int* ls = q == 0 ? lists1 : lists2;
+    for (int i = tid; i < V.m[q]; i += 256) { V.dst[q][i] = ls[1 + i]; V.src[q][i] = ls[1 + 2 * LU_NB_MAX + i]; }
+  }
+  const bool left = role == 0;                            // the left half's own columns: only the right half's interchanges, no solve
+  const int c0 = left ? k0 : x0 + 32 * (int)blockIdx.x;
+  const int wcols = left ? h1 : min(32, x0 + ncols - c0);
+  if (!left)
+    for (int idx = tid; idx < 64 * 32; idx += 256) {       // the panel rows' entries of the strip as they stand
+      const int i = idx >> 5, k = idx & 31;
+      V.B[i][k] = (i < nb && k < wcols) ? A[(size_t)(k0 + i) * n + c0 + k] : dc_make(0.0, 0.0);
+    }
+  __syncthreads();
+  // a row of the strip: from LDS if it is a panel row of a solving strip, else from the matrix
+  auto get = [&](int row, int col) -> dc { return (!left && row >= k0 && row < k0 + nb) ? V.B[row - k0][col] : A[(size_t)row * n + c0 + col]; };
+  auto put = [&](int row, int col, dc v) { if (!left && row >= k0 && row < k0 + nb) V.B[row - k0][col] = v; else A[(size_t)row * n + c0 + col] = v; };
+  for (int q = left ? 1 : 0; q < 2; ++q) {
+    const int m = V.m[q];
+    if (m == 0) continue;
+    dc mv[8]; int md[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int e = tid + 256 * t, idx = e >> 5, col = e & 31;
+      md[t] = -1; mv[t] = dc_make(0.0, 0.0);
+      if (idx < m && col < wcols) {
+        const int sr = V.src[q][idx], ds = V.dst[q][idx];
+        if (sr >= 0 && sr < n && ds >= 0 && ds < n) { mv[t] = get(sr, col); md[t] = ds; }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every read of the strip has returned ...
+    __syncthreads();                                       // ... in every thread, before the first write
+#pragma unroll
+    for (int t = 0; t < 8; ++t) if (md[t] >= 0) put(md[t], (tid + 256 * t) & 31, mv[t]);
+    __syncthreads();                                       // (workgroup-scope: the next list reads what this one wrote)
+  }
+  if (left) return;
+  // U = L11^-1 B, right-looking, 32 rows of L11 at a time through one LDS buffer
+  const int col = tid & 31, r0 = tid >> 5;
+  auto load_L = [&](int rb, int cb) {                      // rows [32 rb, +32) x columns [32 cb, +32) of L11 (strictly lower part when rb == cb)
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+      const int i = idx >> 5, k = idx & 31, gi = 32 * rb + i, gk = 32 * cb + k;
+      // block (1, 0) lies in the left half's columns, whose rows the `left` workgroup of THIS launch is permuting: it comes from the
+      // copy the right half's panel kernel left (its pivot rows' left-half entries)
+      V.L[i][k] = (gi < nb && gk < nb && gk < gi) ? ((rb == 1 && cb == 0) ? l10[(size_t)i * LU_REG_NB + k] : A[(size_t)(k0 + gi) * n + k0 + gk]) : dc_make(0.0, 0.0);
+    }
+    __syncthreads();
+  };
+  auto solve32 = [&](int rb) {                             // rows [32 rb, +32) of B against the diagonal block in V.L
+    const int rows = min(32, nb - 32 * rb);
+    for (int k = 0; k + 1 < rows; ++k) {
+      const dc xk = V.B[32 * rb + k][col];
+      for (int i = k + 1 + r0; i < rows; i += 8) {
+        const dc l = V.L[i][k];
+        dc v = V.B[32 * rb + i][col];
+        v.re = __builtin_fma(l.im, xk.im, __builtin_fma(-l.re, xk.re, v.re));
+        v.im = __builtin_fma(-l.im, xk.re, __builtin_fma(-l.re, xk.im, v.im));
+        V.B[32 * rb + i][col] = v;
+      }
+      __syncthreads();
+    }
+  };
+  load_L(0, 0); solve32(0);
+  if (nb > 32) {
+    load_L(1, 0);
+    for (int i = r0; i < nb - 32; i += 8) {                // B1 -= L10 X0
+      dc v = V.B[32 + i][col];
+      for (int k = 0; k < 32; ++k) {
+        const dc l = V.L[i][k], xk = V.B[k][col];
+        v.re = __builtin_fma(l.im, xk.im, __builtin_fma(-l.re, xk.re, v.re));
+        v.im = __builtin_fma(-l.im, xk.re, __builtin_fma(-l.re, xk.im, v.im));
+      }
+      V.B[32 + i][col] = v;
+    }
+    load_L(1, 1); solve32(1);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * 32; idx += 256) {
     const int i = idx >> 5, k = idx & 31;
     if (i < nb && k < wcols) A[(size_t)(k0 + i) * n + c0 + k] = V.B[i][k];
   }
@@ -1982,7 +2109,7 @@ static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 6
 // systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
 // CUs the stream may use (a CU-masked stream: the CUs of its mask).
 static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st,
-                            int* reg_lists = nullptr) {
+                            int* reg_lists = nullptr, c64* reg_lrows = nullptr, int reg_lcol0 = 0) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
@@ -2021,7 +2148,8 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
   if (clear_tags) for (int t = 0; t < nsys; ++t) MA_HIP(hipMemsetAsync(wss[t].cand, 0, lu_panel_granule_bytes(wss[t].max_blocks), st));
-  if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0], reg_lists);
+  if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0], reg_lists,
+                                    reinterpret_cast<dc*>(reg_lrows), reg_lcol0);
   else if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
   else {
     LuPanelBatch B;
@@ -2046,8 +2174,9 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   return launch_panel_any(0, 1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
 }
 // the register-resident panel kernel: 256 rows per workgroup, nb <= LU_REG_NB columns; ncu = the CUs `st` may use
-int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st) {
-  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st, lists);
+int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, c64* lrows, int lcol0) {
+  MA_REQUIRE(!lrows || (lcol0 >= 0 && lcol0 + LU_REG_NB <= k0), MA_ERR_INVALID, "left-half columns [%d, %d) not left of the panel at %d", lcol0, lcol0 + LU_REG_NB, k0);
+  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st, lists, lrows, lcol0);
 }
 // the step between two panels of a block column: interchanges + U = L11^-1 A12 on the columns [x0, x0 + ncols), and the inverted
 // diagonal block of L11 into invd (lists: what lu_launch_panel_reg wrote)
@@ -2123,6 +2252,17 @@ int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, 
   auto kern = (nb <= 64 && !wide_only) ? lu_trsm64_kernel : lu_trsm_mfma_kernel;
   hipLaunchKernelGGL(kern, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
                      reinterpret_cast<const dc*>(invd), reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// the step after a 64-column panel factored as two register half-panels: both halves' interchanges + U12 on [x0, x0 + ncols), the
+// right half's interchanges on the left half's columns, the inverted diagonal blocks and the folded 64-pivot list for the main lane
+int lu_launch_lane_step2(c64* A, int n, int k0, int nb, const int* lists1, const int* lists2, int x0, int ncols, const int* ipiv, int* lists64, c64* invd, unsigned* poison,
+                         const c64* l10, hipStream_t st) {
+  MA_REQUIRE(nb >= 1 && nb <= 2 * LU_REG_NB && k0 >= 0 && k0 + nb <= n && ncols >= 0 && x0 >= 0 && x0 + ncols <= n, MA_ERR_INVALID, "lane step outside the matrix");
+  hipLaunchKernelGGL(lu_lane_step2_kernel, dim3((ncols + 31) / 32 + 4), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, lists1, lists2, x0, ncols, ipiv, lists64,
+                     reinterpret_cast<dc*>(invd), poison, reinterpret_cast<const dc*>(l10));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -80,6 +80,9 @@ struct ma_lu_plan {
   // updates on a stream masked to the other ncu - P -- the exchange of a panel kernel then runs at its idle round trip instead of
   // 2-3 x that beside update workgroups on the same CU (profiles/r03_cumask_probe.txt)
   bool reg_panel = false;
+  bool reg_pair = false;                                  // MA_LU_REG_PANEL=2: the 64-column structure of round 2 (K = 64 in-block updates, 4 panels per block, the main lane's
+                                                          // per-panel work on 64 columns) with each 64-column panel factored as TWO register half-panels and the step between them
+  int* d_half_lists[LU_BATCH_MAX] = {}; c64* d_half_invd[LU_BATCH_MAX] = {}; c64* d_half_l10[LU_BATCH_MAX] = {};
   int cu_split = 0;
   int chain_mask = 0;                                     // MA_LU_CHAIN_MASK=1: the per-panel chain launches on streams masked to the update CUs too
   int pan_mask = 0;                                       // MA_LU_PAN_MASK=1: the panel kernels on streams of their own, masked to the P panel CUs (0: only the big updates are masked
@@ -125,6 +128,11 @@ int ma_lu_plan::ensure_batch(int nmat) {
     MA_HIP(hipMalloc(&d_lists[m], sizeof(int) * 2 * LU_KB_MAX * LU_LISTS_LEN));
     MA_HIP(hipMalloc(&d_invd[m], sizeof(c64) * 2 * LU_KB_MAX * LU_NB_MAX * 32));
     MA_HIP(hipMalloc(&d_tmp_l[m], sizeof(c64) * 2 * LU_NB_MAX * LU_LANE_TSTRIDE));
+    MA_HIP(hipMalloc(&d_half_lists[m], sizeof(int) * 2 * LU_LISTS_LEN));
+    MA_HIP(hipMemset(d_half_lists[m], 0, sizeof(int) * 2 * LU_LISTS_LEN));
+    MA_HIP(hipMalloc(&d_half_invd[m], sizeof(c64) * 32 * 32));
+    MA_HIP(hipMalloc(&d_half_l10[m], sizeof(c64) * 32 * 32));
+    MA_HIP(hipMemset(d_half_l10[m], 0, sizeof(c64) * 32 * 32));
     // the memset above runs on the null stream; the plan's lanes and the callers' streams may be non-blocking streams that do
     // not order themselves against it: without this wait it can land AFTER a panel kernel has written its pivots (seen as
     // "pivot outside its range" under two host threads)
@@ -203,8 +211,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (P->batch_panel) want_reg = 0;                      // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
     if (!rc && want_reg && n <= 65535) {
       const int nblk0 = (n + 255) / 256;
-      if (nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, (split && P->pan_mask) ? split : ncu) == MA_OK) P->reg_panel = true;
-      else if (split && P->pan_mask && nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, ncu) == MA_OK) { P->pan_mask = 0; P->reg_panel = true; }   // too tall for the panel CUs: panels anywhere
+      if (nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, (split && P->pan_mask) ? split : ncu) == MA_OK) { P->reg_panel = true; P->reg_pair = want_reg == 2; }
+      else if (split && P->pan_mask && nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, ncu) == MA_OK) { P->pan_mask = 0; P->reg_panel = true; P->reg_pair = want_reg == 2; }   // too tall for the panel CUs: panels anywhere
     }
     if (!P->reg_panel) P->pan_mask = 0;                   // the LDS-resident panel kernel's grid does not fit a small CU set: only the big updates are masked
   }
@@ -280,7 +288,7 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
     if (P->ev_pan[i]) (void)hipEventDestroy(P->ev_pan[i]); if (P->ev_chain[i]) (void)hipEventDestroy(P->ev_chain[i]); }
   if (P->big_stream) (void)hipStreamDestroy(P->big_stream);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
-    if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); }
+    if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); if (P->d_half_lists[i]) (void)hipFree(P->d_half_lists[i]); if (P->d_half_invd[i]) (void)hipFree(P->d_half_invd[i]); if (P->d_half_l10[i]) (void)hipFree(P->d_half_l10[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
   return MA_OK;
@@ -321,6 +329,10 @@ static void interval(ma_lu_plan* P, int a, int b, int phase) {
 // panels of the factorisation: first column, width, rows per panel workgroup, workgroups
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks) {
   const int n = P->n;
+  if (P->reg_panel && P->reg_pair) {                      // 64-column panels, each factored as two register half-panels (launch_panel_pair)
+    for (int k0 = 0; k0 < n; k0 += 2 * LU_REG_NB) { k0s.push_back(k0); nbs.push_back(std::min(n - k0, 2 * LU_REG_NB)); rpbs.push_back(256); nblks.push_back((n - k0 + 255) / 256); }
+    return;
+  }
   if (P->reg_panel) {                                     // rows in registers: 256 rows per workgroup, LU_REG_NB columns per panel
     for (int k0 = 0; k0 < n; k0 += LU_REG_NB) { k0s.push_back(k0); nbs.push_back(std::min(n - k0, LU_REG_NB)); rpbs.push_back(256); nblks.push_back((n - k0 + 255) / 256); }
     return;
@@ -353,7 +365,22 @@ static void panel_schedule_batched(const ma_lu_plan* P, int nsys, std::vector<in
 }
 
 // one panel of system (A, ws, ipiv) on stream st: the kernel the plan's schedule was made for
-static int launch_panel(ma_lu_plan* P, c64* A, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, bool masked) {
+static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, int nblk, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, bool masked) {
+  if (P->reg_panel && P->reg_pair) {
+    // a 64-column panel as two register half-panels: left half; its interchanges + U12 + rank-32 update on the right half's columns
+    // (lu_lane_step_kernel + one K = 32 update); right half. The pivots land in ipiv as one 64-column panel's: everything after
+    // this (lu_perm_kernel on 64 pivots, interchanges, U12, K = 64 updates, the main lane) is the 64-column schedule
+    const int n = P->n, cus = masked ? P->panel_cus() : P->ncu;
+    const int h1 = std::min(nb, LU_REG_NB), h2 = nb - h1;
+    int rc = lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st);
+    if (rc || h2 <= 0) return rc;
+    const int a1 = k0 + h1;
+    if ((rc = lu_launch_lane_step(A, n, k0, h1, P->d_half_lists[m], a1, h2, P->d_half_invd[m], P->pws.timeout, st))) return rc;
+    if ((rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m))) return rc;
+    // (the right half's interchanges on the LEFT half's columns -- part of the interchange itself inside a 64-column panel kernel --
+    // are the first job of lu_lane_step2_kernel, which every caller launches next)
+    return lu_launch_panel_reg(A, n, a1, h2, (n - a1 + 255) / 256, cus, ws, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, false, st, P->d_half_l10[m], k0);
+  }
   if (P->reg_panel) return lu_launch_panel_reg(A, P->n, k0, nb, nblk, masked ? P->panel_cus() : P->ncu, ws, ipiv, lists, clear_tags, st);
   return lu_launch_panel(A, P->n, k0, nb, rpb, nblk, P->ncu, ws, ipiv, clear_tags, st);
 }
@@ -442,13 +469,16 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
-      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], lists, q == 0 || nbs[q - 1] < 4, sp, false))) return rc;
+      if ((rc = launch_panel(P, m, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], lists, q == 0 || nbs[q - 1] < 4 || (P->reg_pair && nbs[q - 1] - LU_REG_NB < 4), sp, false))) return rc;
       MA_MARK(t1, sp);
       interval(P, t0, t1, 0);
-      if (P->reg_panel) { if ((rc = lu_launch_lane_step(A, n, k0, nb, lists, a1, e - a1, invd, P->pws.timeout, sp))) return rc; }   // lists came from the panel kernel
+      const bool fused_step = P->reg_panel;
+      if (P->reg_panel && P->reg_pair) {                    // both halves' interchanges + U12 + inverses + the folded 64-pivot list: one launch
+        if ((rc = lu_launch_lane_step2(A, n, k0, nb, P->d_half_lists[m], P->d_half_lists[m] + LU_LISTS_LEN, a1, e - a1, P->d_ipiv[m], lists, invd, P->pws.timeout, P->d_half_l10[m], sp))) return rc;
+      } else if (fused_step) { if ((rc = lu_launch_lane_step(A, n, k0, nb, lists, a1, e - a1, invd, P->pws.timeout, sp))) return rc; }   // lists came from the panel kernel
       else if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
       if (a1 < e) {
-        if (!P->reg_panel) {
+        if (!fused_step) {
           if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
           const c64* T = A + (size_t)k0 * n + k0;
           if ((rc = lu_launch_trsm_mfma(T, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
@@ -649,16 +679,19 @@ struct Stage {
       const int slot = (g & 1) * LU_KB_MAX + (q - blk_first(g));
       int* lists = P->d_lists[m] + (size_t)slot * LU_LISTS_LEN;
       c64* invd = P->d_invd[m] + (size_t)slot * LU_NB_MAX * 32;
-      if ((rc = launch_panel(P, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], lists, q == 0 || nbs[q - 1] < 4, pp, pp != sp))) return rc;
+      if ((rc = launch_panel(P, m, A, k0, nb, rpbs[q], nblks[q], P->pws_m[m], P->d_ipiv[m], lists, q == 0 || nbs[q - 1] < 4 || (P->reg_pair && nbs[q - 1] - LU_REG_NB < 4), pp, pp != sp))) return rc;
       MA_MARKD(t1, pp);
       interval(P, t0, t1, 0);
       if (pp != sp) { MA_HIP(hipEventRecord(P->ev_pan[m], pp)); MA_HIP(hipStreamWaitEvent(sp, P->ev_pan[m], 0)); }
       // register panel kernel: it wrote the interchange list itself, and ONE launch does the interchanges, U12 and the inverted
       // diagonal block; otherwise: fold the pivots + invert, gather, scatter, U12
-      if (P->reg_panel) { if ((rc = lu_launch_lane_step(A, n, k0, nb, lists, a1, e - a1, invd, P->pws.timeout, sp))) return rc; }
+      const bool fused_step = P->reg_panel;
+      if (P->reg_panel && P->reg_pair) {
+        if ((rc = lu_launch_lane_step2(A, n, k0, nb, P->d_half_lists[m], P->d_half_lists[m] + LU_LISTS_LEN, a1, e - a1, P->d_ipiv[m], lists, invd, P->pws.timeout, P->d_half_l10[m], sp))) return rc;
+      } else if (fused_step) { if ((rc = lu_launch_lane_step(A, n, k0, nb, lists, a1, e - a1, invd, P->pws.timeout, sp))) return rc; }
       else if ((rc = lu_launch_perm(A, n, k0, nb, P->d_ipiv[m], lists, invd, P->pws.timeout, sp))) return rc;
       if (a1 < e) {
-        if (!P->reg_panel) {
+        if (!fused_step) {
           if ((rc = lu_launch_row_moves(A, n, nb, lists, P->d_tmp_l[m], LU_LANE_TSTRIDE, a1, e, 0, 0, nullptr, 0, sp))) return rc;
           if ((rc = lu_launch_trsm_mfma(A + (size_t)k0 * n + k0, n, nb, invd, A + (size_t)k0 * n + a1, (size_t)n, e - a1, nullptr, 0, 0, sp))) return rc;
         }
