@@ -426,12 +426,14 @@ def main():
     As = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
     xs_ = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
     stream = torch.cuda.current_stream().cuda_stream
+    cu_split = 0
     if lu.main_stream():
         # the chip is split (MA_LU_CU_SPLIT): the plan's big updates run on a CU-masked stream, which is a blocking stream (the only
         # kind hipExtStreamCreateWithCUMask makes) and would serialise against work on the NULL stream. The bench's own launches
         # (assemblies) go onto that stream too: no extra hardware queue
         stream = lu.main_stream()
         torch.cuda.set_stream(torch.cuda.ExternalStream(stream, device=dev))
+        cu_split = int(os.environ.get("MA_LU_CU_SPLIT", "64"))
     asm_ms = np.zeros(3); lu_ms = np.zeros(8); upd = np.zeros(3)
     timing = False
 
@@ -751,7 +753,9 @@ def main():
                                "traffic_note": "HBM-side bytes per launch from a separate rocprofv3 --pmc pass (profiles/); the algorithmic C read+write "
                                                "is %.3g B per launch on average" % (upd[2] / K / n_gemm),
                                "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
-                               "algorithmic_flops_per_step": gf}
+                               "algorithmic_flops_per_step": gf,
+                               "cus_note": ("the K = 256 updates run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); "
+                                            "peak is the whole chip's" % (256 - cu_split, cu_split)) if cu_split else "updates on the whole chip"}
             far_t = asm_ms[0] / K * 1e-3
             out["roofline_assembly"] = {"kernel": "tbem_far_kernel<%d, velocity-only> (far pairs of %d systems per pass)" % (ahead, ahead), "bound": "hbm", "achieved": 16.0 * n * n / far_t / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("ma::tbem_far_kernel<%d, true>" % ahead) or pmc_traffic("ma::tbem_far_kernel"), "systems_per_pass": ahead,

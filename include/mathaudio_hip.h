@@ -192,10 +192,11 @@ int ma_lu_plan_reserve_events(ma_lu_plan_t* plan, int64_t count);   /* timing ev
 int ma_lu_plan_num_blocks(ma_lu_plan_t* plan, int32_t* blocks);
 int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
 int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);
-/* Round 3: with MA_LU_CU_SPLIT=<P> the plan runs the K = 256 trailing updates of the staged schedule on a stream whose CU mask
- * leaves P CUs (P / 8 per XCD) to the latency-bound panel kernels (no reference counterpart: a schedule detail behind lu_solve,
- * math-solvers/src/direct/lu.rs:142-153). *stream = that stream (the caller may issue its assemblies there), or NULL. */
-int ma_lu_plan_main_stream(ma_lu_plan_t* plan, void** stream);   /* the stream a slot's chain runs on */
+/* Round 3: a plan for 4 096..16 384 rows (or MA_LU_CU_SPLIT=<P>) runs its big trailing updates on a stream whose CU mask leaves
+ * P = 64 CUs (P / 8 per XCD) to the latency-bound panel kernels (no reference counterpart: a schedule detail behind lu_solve,
+ * math-solvers/src/direct/lu.rs:142-153). *stream = that stream, or NULL when the plan does not split the chip. A driver of the
+ * staged schedule passes it as ITS stream (assemblies included): one hardware queue less. */
+int ma_lu_plan_main_stream(ma_lu_plan_t* plan, void** stream);
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
 /* Groups of slots (up to 8 slots): with group_size 2..4 the slots [k g, (k+1) g) move in lock step and share ONE panel kernel per panel

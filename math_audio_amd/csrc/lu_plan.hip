@@ -9,11 +9,19 @@
 using namespace ma;
 
 #define LU_LISTS_LEN (1 + 4 * LU_NB_MAX)
-#ifndef MA_LU_REG_PANEL_DEFAULT
-#define MA_LU_REG_PANEL_DEFAULT 0
+// Round-3 default for systems of MA_LU_PAIR_MIN_N..MA_LU_PAIR_MAX_N rows (the sizes measured: 6 000 - 14 000 rows, every one faster
+// on the staged, the batched and the one-system path, profiles/r03_lu_panel_experiments.md): 64-column panels factored as two
+// register half-panels (MA_LU_REG_PANEL=2) and the big trailing updates kept off 64 of the 256 CUs (MA_LU_CU_SPLIT=64).
+// Outside that range, on a chip that is not 256 CUs, and for a plan tuned with the LDS family's switches (MA_LU_NB, MA_LU_RPB,
+// MA_LU_BATCH_PANEL), the round-2 schedule.
+#ifndef MA_LU_PAIR_MIN_N
+#define MA_LU_PAIR_MIN_N 4096
+#endif
+#ifndef MA_LU_PAIR_MAX_N
+#define MA_LU_PAIR_MAX_N 16384
 #endif
 #ifndef MA_LU_CU_SPLIT_DEFAULT
-#define MA_LU_CU_SPLIT_DEFAULT 0
+#define MA_LU_CU_SPLIT_DEFAULT 64
 #endif
 #define LU_KB_MAX 8                         // panels per trailing update
 #define LU_LANE_TSTRIDE 512                   // the lane's interchanges touch at most (kb-1) panels' columns: 7 x 64 or 3 x 128
@@ -79,6 +87,7 @@ struct ma_lu_plan {
   // (MA_LU_CU_SPLIT=<P>, 0 = off): the panel kernels run on streams whose CU mask holds P CUs (P / 8 per XCD), the big trailing
   // updates on a stream masked to the other ncu - P -- the exchange of a panel kernel then runs at its idle round trip instead of
   // 2-3 x that beside update workgroups on the same CU (profiles/r03_cumask_probe.txt)
+  bool reg_panel0 = false, reg_pair0 = false;             // what the plan was created with (slot groups switch a plan to the LDS family and back)
   bool reg_panel = false;
   bool reg_pair = false;                                  // MA_LU_REG_PANEL=2: the 64-column structure of round 2 (K = 64 in-block updates, 4 panels per block, the main lane's
                                                           // per-panel work on 64 columns) with each 64-column panel factored as TWO register half-panels and the step between them
@@ -92,6 +101,7 @@ struct ma_lu_plan {
   hipStream_t big_stream = nullptr;                       // mask B: the K = 256 updates of all slots
   hipEvent_t ev_pan[LU_BATCH_MAX] = {}, ev_chain[LU_BATCH_MAX] = {};
   int panel_cus() const { return cu_split > 0 ? cu_split : ncu; }
+  int admit_cus = 0;                                      // MA_LU_ADMIT_CUS: the CU count the admission window counts register panels against (0: what the launch may use)
 };
 
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
@@ -201,11 +211,14 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (const char* e3 = getenv("MA_LU_RPB")) { int v = atoi(e3); if (v >= 8 && v <= 256) { P->rpb_cap = v; P->rpb_env = true; } }
   // the register panel kernel when the tallest panel's workgroups (256 rows each) are co-resident on the CUs its stream may use
   {
-    int want_reg = MA_LU_REG_PANEL_DEFAULT, split = MA_LU_CU_SPLIT_DEFAULT;
+    const bool lds_tuned = P->rpb_env || getenv("MA_LU_NB") || P->batch_panel;
+    int want_reg = (n >= MA_LU_PAIR_MIN_N && n <= MA_LU_PAIR_MAX_N && ncu == 256 && !lds_tuned) ? 2 : 0;
     if (const char* er = getenv("MA_LU_REG_PANEL")) want_reg = atoi(er);
+    int split = want_reg == 2 ? MA_LU_CU_SPLIT_DEFAULT : 0;
     if (const char* es = getenv("MA_LU_CU_SPLIT")) split = atoi(es);
     if (const char* ec = getenv("MA_LU_CHAIN_MASK")) P->chain_mask = atoi(ec) != 0;
     if (const char* ep = getenv("MA_LU_PAN_MASK")) P->pan_mask = atoi(ep) != 0;
+    if (const char* ea = getenv("MA_LU_ADMIT_CUS")) { const int v = atoi(ea); if (v >= 20 && v <= ncu) P->admit_cus = v; }
     if (split < 8 || split % 8 != 0 || split > ncu - 64 || ncu % 32 != 0 || !P->lookahead || !P->panel_overlap) split = 0;
     P->cu_split = split;
     if (P->batch_panel) want_reg = 0;                      // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
@@ -215,6 +228,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
       else if (split && P->pan_mask && nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, ncu) == MA_OK) { P->pan_mask = 0; P->reg_panel = true; P->reg_pair = want_reg == 2; }   // too tall for the panel CUs: panels anywhere
     }
     if (!P->reg_panel) P->pan_mask = 0;                   // the LDS-resident panel kernel's grid does not fit a small CU set: only the big updates are masked
+    if (!P->reg_panel && !getenv("MA_LU_CU_SPLIT")) P->cu_split = 0;   // the default split comes with the register panels only
+    P->reg_panel0 = P->reg_panel; P->reg_pair0 = P->reg_pair;
   }
   for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
   if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
@@ -258,7 +273,12 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
       for (int i = 0; i < ncu; ++i) (i < P->cu_split ? mA : mB)[i / 32] |= 1u << (i % 32);
       for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess && P->pan_mask; ++i) e4 = hipExtStreamCreateWithCUMask(&P->pan_streams[i], words, mA.data());
       for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess && P->chain_mask; ++i) e4 = hipExtStreamCreateWithCUMask(&P->chain_streams[i], words, mB.data());
-      if (e4 == hipSuccess) e4 = hipExtStreamCreateWithCUMask(&P->big_stream, words, mB.data());
+      if (e4 == hipSuccess) {
+        e4 = hipExtStreamCreateWithCUMask(&P->big_stream, words, mB.data());
+        if (e4 != hipSuccess && !getenv("MA_LU_CU_SPLIT")) {   // the default split on a runtime that makes no masked streams: the whole chip for everything
+          (void)hipGetLastError(); e4 = hipSuccess; P->big_stream = nullptr; P->cu_split = 0;
+        }
+      }
     }
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }
   }
@@ -370,7 +390,7 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     // a 64-column panel as two register half-panels: left half; its interchanges + U12 + rank-32 update on the right half's columns
     // (lu_lane_step_kernel + one K = 32 update); right half. The pivots land in ipiv as one 64-column panel's: everything after
     // this (lu_perm_kernel on 64 pivots, interchanges, U12, K = 64 updates, the main lane) is the 64-column schedule
-    const int n = P->n, cus = masked ? P->panel_cus() : P->ncu;
+    const int n = P->n, cus = P->admit_cus > 0 ? P->admit_cus : (masked ? P->panel_cus() : P->ncu);
     const int h1 = std::min(nb, LU_REG_NB), h2 = nb - h1;
     int rc = lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st);
     if (rc || h2 <= 0) return rc;
@@ -880,7 +900,18 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
 // always with equal block indices.
 int ma_lu_plan_stage_set_group(ma_lu_plan_t* P, int32_t group_size) {
   MA_REQUIRE(P && group_size >= 0 && group_size <= LU_GROUP_MAX, MA_ERR_INVALID, "group size must be 0..%d", LU_GROUP_MAX);
-  MA_REQUIRE(group_size < 2 || !P->reg_panel, MA_ERR_UNSUPPORTED, "slot groups share the LDS-resident panel kernel: not with MA_LU_REG_PANEL=1");
+  // slot groups share ONE wavefront-per-system panel kernel, which is of the LDS family: a plan created with register panels
+  // factors with the LDS family while groups are set (a plan stays in one family per factorisation: the two pivot the same
+  // rows but round differently) and returns to its own with group_size < 2
+  if (group_size >= 2 && P->reg_panel0) {
+    P->reg_panel = false; P->reg_pair = false;
+    std::vector<int> k0s, nbs, rpbs, nblks;
+    panel_schedule(P, k0s, nbs, rpbs, nblks);
+    int rc = MA_OK;
+    for (size_t q = 0; q < k0s.size() && !rc; ++q)
+      if (q == 0 || rpbs[q] != rpbs[q - 1] || nbs[q] != nbs[q - 1] || nblks[q] > nblks[q - 1]) rc = lu_panel_admissible(nbs[q], rpbs[q], nblks[q], P->ncu);
+    if (rc) { P->reg_panel = P->reg_panel0; P->reg_pair = P->reg_pair0; return rc; }
+  } else if (group_size < 2) { P->reg_panel = P->reg_panel0; P->reg_pair = P->reg_pair0; }
   if (group_size >= 2) {
     std::vector<int> k0s, nbs, rpbs, nblks;
     panel_schedule_batched(P, group_size, k0s, nbs, rpbs, nblks);

@@ -45,10 +45,17 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
   if (slots > n_mine) slots = n_mine;
   ma_lu_plan_t* lu = nullptr;
   if ((rc = ma_lu_plan_create(n, device, &lu))) return rc;
+  // the sweep's own stream: the plan's big-update stream when the plan splits the chip (that stream is masked to the update CUs,
+  // and a stream more would be one hardware queue more: profiles/r03_lu_panel_experiments.md), a stream of its own otherwise
   hipStream_t st = nullptr;
-  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("sweep: stream creation failed"); ma_lu_plan_destroy(lu); return MA_ERR_HIP; }
+  bool own_stream = false;
+  { void* ms = nullptr; if (ma_lu_plan_main_stream(lu, &ms) == MA_OK && ms) st = (hipStream_t)ms; }
+  if (!st) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("sweep: stream creation failed"); ma_lu_plan_destroy(lu); return MA_ERR_HIP; }
+    own_stream = true;
+  }
   std::vector<void*> dA((size_t)slots, nullptr), dx((size_t)slots, nullptr);
-  auto cleanup = [&]() { for (void* p : dA) if (p) (void)hipFree(p); for (void* p : dx) if (p) (void)hipFree(p); ma_lu_plan_destroy(lu); (void)hipStreamDestroy(st); };
+  auto cleanup = [&]() { for (void* p : dA) if (p) (void)hipFree(p); for (void* p : dx) if (p) (void)hipFree(p); ma_lu_plan_destroy(lu); if (own_stream) (void)hipStreamDestroy(st); };
   for (int s = 0; s < slots; ++s)
     if (hipMalloc(&dA[(size_t)s], sizeof(ma_c64) * (size_t)n * (size_t)n) != hipSuccess || hipMalloc(&dx[(size_t)s], sizeof(ma_c64) * (size_t)n) != hipSuccess) {
       set_error("sweep: %d systems of %d x %d do not fit device %d", slots, n, n, device);
