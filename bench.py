@@ -505,7 +505,7 @@ def main():
         if gsz:
             return run_pipeline_groups(first, nsteps)
         G = lu.num_blocks()
-        spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or max(1, (G + slots) // (slots + 1))   # rounds between the starts of two slots (G/4 for 3 slots measured best: 59.9 vs 60.7 ms at G/3)
+        spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or lu.stage_spacing(slots)   # rounds between the starts of two slots (ma_lu_plan_stage_spacing: G/3 with the register pair panels, G/4 with the LDS panels)
         off = [s * spacing for s in range(slots)]
         lu.stage_reset(stream)
         asm_lane = os.environ.get("MA_BENCH_ASM_LANE", "0") != "0"

@@ -197,6 +197,9 @@ int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);
  * math-solvers/src/direct/lu.rs:142-153). *stream = that stream, or NULL when the plan does not split the chip. A driver of the
  * staged schedule passes it as ITS stream (assemblies included): one hardware queue less. */
 int ma_lu_plan_main_stream(ma_lu_plan_t* plan, void** stream);
+/* rounds between the starts of two of `slots` slots that the plan's kernels were measured best with (a driver of the staged
+ * schedule starts slot s at round s * spacing; ma_bem_solve_sweep and bench.py do) */
+int ma_lu_plan_stage_spacing(ma_lu_plan_t* plan, int32_t slots, int32_t* spacing);
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
 /* Groups of slots (up to 8 slots): with group_size 2..4 the slots [k g, (k+1) g) move in lock step and share ONE panel kernel per panel

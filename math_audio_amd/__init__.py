@@ -88,6 +88,7 @@ def lib():
             "ma_bem_solve_sweep_multi_timed": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp, vp, vp, vp],
             "ma_bem_plan_assemble_multi_dev": [vp, i32, vp, vp, vp, vp, vp, vp],
             "ma_lu_plan_main_stream": [vp, P(vp)],
+            "ma_lu_plan_stage_spacing": [vp, i32, P(i32)],
             "ma_sweep_owner": [i32, i32],
             "ma_bem_plan_device": [vp, P(C.c_int)],
             "ma_lu_factorize": [i32, vp, P(vp)],
@@ -397,6 +398,12 @@ class LuPlan:
         p = C.c_void_p()
         check(lib().ma_lu_plan_main_stream(self.h, C.byref(p)))
         return p.value
+
+    def stage_spacing(self, slots):
+        """ma_lu_plan_stage_spacing: rounds between the starts of two slots of the staged schedule."""
+        v = C.c_int32(0)
+        check(lib().ma_lu_plan_stage_spacing(self.h, int(slots), C.byref(v)))
+        return v.value
 
     def stage_reset(self, stream=0):
         check(lib().ma_lu_plan_stage_reset(self.h, C.c_void_p(stream)))

@@ -270,7 +270,10 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
       // staged schedule from the NULL stream serialises against them -- use a non-blocking stream (bench.py, ma_bem_solve_sweep do)
       const int words = ncu / 32;
       std::vector<uint32_t> mA(words, 0u), mB(words, 0u);
-      for (int i = 0; i < ncu; ++i) (i < P->cu_split ? mA : mB)[i / 32] |= 1u << (i % 32);
+      // MA_LU_SPLIT_SHAPE=xcd: the panel CUs as WHOLE XCDs (split / 32 of them) instead of split / 8 CUs of every XCD
+      const char* shp = getenv("MA_LU_SPLIT_SHAPE");
+      const bool by_xcd = shp && shp[0] == 'x' && P->cu_split % 32 == 0;
+      for (int i = 0; i < ncu; ++i) ((by_xcd ? (i % 8) < P->cu_split / 32 : i < P->cu_split) ? mA : mB)[i / 32] |= 1u << (i % 32);
       for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess && P->pan_mask; ++i) e4 = hipExtStreamCreateWithCUMask(&P->pan_streams[i], words, mA.data());
       for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess && P->chain_mask; ++i) e4 = hipExtStreamCreateWithCUMask(&P->chain_streams[i], words, mB.data());
       if (e4 == hipSuccess) {
@@ -412,7 +415,10 @@ static int effective_kb(const ma_lu_plan* P, const std::vector<int>& nbs) {
   const int nb0 = nbs.empty() ? P->want_nb : std::max(1, nbs[0]);
   int nbmax = 1;
   for (int v : nbs) nbmax = std::max(nbmax, v);             // panels widen again once the remaining rows fit (32 -> 64 columns)
-  int kb = P->kb_env ? P->kb : std::max(P->kb, 256 / nb0);
+  // register pair panels: 6 panels (K = 384) per update -- the update kernel's prologue and C read-modify-write are a fifth of a
+  // K = 256 tile's time, and the short chain of the pair panels leaves the lanes room for two more panels per block (51.4 ms per
+  // frequency against 52.3 at 4 and 51.5 at 8: profiles/r03_lu_panel_experiments.md)
+  int kb = P->kb_env ? P->kb : (P->reg_panel && P->reg_pair) ? 6 : std::max(P->kb, 256 / nb0);
   kb = std::max(1, std::min(kb, LU_KB_MAX));
   while (kb > 1 && (kb - 1) * nbmax > LU_LANE_TSTRIDE) --kb;
   return kb;
@@ -867,6 +873,18 @@ int ma_lu_plan_slot_stream(ma_lu_plan_t* P, int32_t slot, void** stream) {
 }
 // the stream the plan runs its big trailing updates on when the chip is split (MA_LU_CU_SPLIT): masked to the update CUs. A driver
 // that issues its own work between stage calls (assembly) may put it there instead of on a stream of its own; NULL when not split
+// rounds between the starts of two slots of the staged schedule. Round-2 kernels (LDS panels, 0.75 ms of chain per panel beside
+// the updates): G / (slots + 1), i.e. one quarter of a factorisation empty (59.9 ms against 60.7 at G / 3). Register pair panels
+// (0.5 ms of chain): G / slots -- the slots evenly spread, so that the sum of the updates of one round never falls far below the
+// chain of the slot that is closest to its end (50.8 ms against 51.4).
+int ma_lu_plan_stage_spacing(ma_lu_plan_t* P, int32_t slots, int32_t* spacing) {
+  MA_REQUIRE(P && spacing && slots >= 1, MA_ERR_INVALID, "bad argument");
+  int32_t G = 0;
+  int rc = ma_lu_plan_num_blocks(P, &G);
+  if (rc) return rc;
+  *spacing = (P->reg_panel && P->reg_pair) ? std::max(1, (G + slots / 2) / slots) : std::max(1, (G + slots) / (slots + 1));
+  return MA_OK;
+}
 int ma_lu_plan_main_stream(ma_lu_plan_t* P, void** stream) {
   MA_REQUIRE(P && stream, MA_ERR_INVALID, "bad argument");
   *stream = (void*)(P->cu_split ? P->big_stream : nullptr);

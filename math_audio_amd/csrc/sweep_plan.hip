@@ -133,7 +133,9 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
       return MA_ERR_NOMEM;
     }
     std::vector<int> off((size_t)slots);
-    for (int s = 0; s < slots; ++s) off[(size_t)s] = s * std::max(1, (G + slots) / (slots + 1));   // G/4 apart for 3 slots (measured best)
+    int32_t spacing = std::max(1, (G + slots) / (slots + 1));
+    (void)ma_lu_plan_stage_spacing(lu, slots, &spacing);                                          // what the plan's kernels were measured best with
+    for (int s = 0; s < slots; ++s) off[(size_t)s] = s * spacing;
     for (int r = 0; !rc; ++r) {
       int32_t sl[4], bl[4]; int cnt = 0; bool live = false;
       for (int s = 0; s < slots && !rc; ++s) {
