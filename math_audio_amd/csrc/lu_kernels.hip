@@ -1714,6 +1714,10 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
 // others' MFMA loops (with one 128 x 64 workgroup per CU the epilogue cost 22 % of the kernel); the sums Ar+Ai and Br+Bi are formed once per fragment load.
 #define Z3_BM 64
 #define Z3_BN 64
+#ifndef MA_ZGEMM_DMA_DEFAULT
+#define MA_ZGEMM_DMA_DEFAULT 1
+#endif
+#define Z3_STAGES 3                          // LDS stages of 16 KB: three workgroups of 48 KB share a CU
 
 #ifndef MA_ZGEMM_MAXWAVES
 #define MA_ZGEMM_MAXWAVES 2
@@ -1806,13 +1810,22 @@ __device__ __forceinline__ void zgemm3m_body(int M, int N, int K, const dc* __re
     }
   };
 
+  // Three LDS stages. The loads of stage st + 2 are issued at the top of iteration st and go to LDS at the top of iteration
+  // st + 1: a whole stage of matrix-core work (x the wavefronts sharing the SIMD) lies between a load and the first instruction
+  // that needs it, where the two-stage form waited for its loads at the END of the stage they were issued in (one stage is
+  // 0.65 us of MFMA time, an L2 miss under load 1-2 us). The staging registers are the same 16: free again once written to LDS.
+  // One barrier per stage as before: it publishes stage st + 1 (written an iteration ago by now) and fences the reuse of buffer
+  // st mod 3, which is written next at the top of iteration st + 2.
   const int nstage = (K + ZG_BK - 1) / ZG_BK;
   load_stage(0);
   store_stage(0);
+  if (nstage > 1) load_stage(ZG_BK);
   __syncthreads();
+  int buf = 0;
   for (int st = 0; st < nstage; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstage) load_stage((st + 1) * ZG_BK);
+    const int nxt = buf == Z3_STAGES - 1 ? 0 : buf + 1;
+    if (st + 1 < nstage) store_stage(nxt);
+    if (st + 2 < nstage) load_stage((st + 2) * ZG_BK);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int kk = ks * 4 + lk;
@@ -1831,25 +1844,36 @@ __device__ __forceinline__ void zgemm3m_body(int M, int N, int K, const dc* __re
           t3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[a], bs[b], t3[a][b], 0, 0, 0);
         }
     }
-    if (st + 1 < nstage) store_stage(buf ^ 1);
     __syncthreads();
+    buf = nxt;
   }
+  // C read-modify-write, eight entries of C in flight per lane: the loads of one half (a) of the wavefront's tile are issued
+  // back to back from clamped (always valid) addresses, without a branch between them, then combined and stored under the bounds
+  // test. (Written entry by entry -- load, wait, store, sixteen times -- the compiler kept that order, and the epilogue was sixteen
+  // memory round trips per tile: as long as the K = 256 main loop itself.)
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a) {
+    dc cv[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = min(m0 + wm * 32 + a * 16 + lk + 4 * r, M - 1);
+        const int gn = min(n0 + wn * 32 + b * 16 + li, N - 1);
+        cv[b][r] = C[(size_t)gm * ldc + gn];
+      }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gm = m0 + wm * 32 + a * 16 + lk + 4 * r;
         const int gn = n0 + wn * 32 + b * 16 + li;
-        if (gm < M && gn < N) {
-          dc* pc = C + (size_t)gm * ldc + gn;
-          dc c = *pc;
-          const double p1 = t1[a][b][r], p2 = t2[a][b][r];
-          c.re -= p1 - p2; c.im -= t3[a][b][r] - p1 - p2;
-          *pc = c;
-        }
+        const double p1 = t1[a][b][r], p2 = t2[a][b][r];
+        dc c = cv[b][r];
+        c.re -= p1 - p2; c.im -= t3[a][b][r] - p1 - p2;
+        if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = c;
       }
+  }
   if (DRAW) {
     __syncthreads();                                                        // the next tile's first stage overwrites the LDS buffers
     if (one_tile) {                                                         // one tile per workgroup (grid = tiles): leave, counting out
@@ -1861,16 +1885,160 @@ __device__ __forceinline__ void zgemm3m_body(int M, int N, int K, const dc* __re
 }
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
                                                              const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
-  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
-  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
+  __shared__ __attribute__((aligned(16))) dc As[Z3_STAGES][ZG_BK][Z3_BM];
+  __shared__ __attribute__((aligned(16))) dc Bs[Z3_STAGES][ZG_BK][Z3_BN];
   zgemm3m_body<false>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, As, Bs, nullptr);
 }
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_drawn_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
                                                              const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc, unsigned* __restrict__ ctr, int one_tile) {
-  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][Z3_BM];
-  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][Z3_BN];
+  __shared__ __attribute__((aligned(16))) dc As[Z3_STAGES][ZG_BK][Z3_BM];
+  __shared__ __attribute__((aligned(16))) dc Bs[Z3_STAGES][ZG_BK][Z3_BN];
   __shared__ int s_tile[2];
   zgemm3m_body<true>(M, N, K, A, lda, B, ldb, C, ldc, ctr, one_tile, As, Bs, s_tile);
+}
+
+// ------------------------------------------------------------------ C -= A * B, 3M form, operands by LDS-DMA
+// What the matrix cores lose in zgemm3m_sub_kernel is its LDS traffic (tools/mfma_loop_probe.hip, profiles/r03_mfma_loop_probe.txt:
+// the bare loop of 24 MFMAs per stage runs at 76 TFLOP/s of 77; with the fragment reads 72; with the four ds_write_b128 of the
+// register staging 63; with the four global loads 59 -- and three workgroups per CU hide none of it). This kernel halves that
+// traffic per MFMA and takes the staging out of the register file:
+//   - a wavefront computes 32 x 64 of C (2 x 4 MFMA tiles x 3 accumulators = 192 accumulation registers, in the AGPR half of the
+//     file; 6 fragment reads per 24 MFMAs instead of 4 per 12), WM x WN wavefronts a tile of 32 WM x 64 WN;
+//   - A and B tiles go global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write), three stages of 8 k, the
+//     DMAs of stage st + 2 issued at the top of iteration st and waited for (counted vmcnt) before the barrier that ends
+//     iteration st + 1 -- one raw s_barrier per stage, nothing drains early;
+//   - an LDS-DMA writes 64 lanes x 16 B CONTIGUOUSLY, so the layout that keeps the fragment reads conflict-free is made on the
+//     SOURCE side: lane l of the DMA for rows 8c .. 8c + 7 of the A tile fetches (row 8c + (l & 7), k = 2 (l >> 4) + ((l >> 3) & 1)):
+//     8 rows x 128 B per instruction, the same lines as a plain row-major load; an A fragment read of one ds_read_b128 lane group
+//     ({0-3, 12-15, 20-27}: 8 rows x 2 consecutive k) then touches 16 different 16-B slots mod 16. B rows are k-major as they are.
+// Edges: rows >= M and columns >= N are fetched from the last valid row / column (they only reach C entries that are not stored);
+// K must be a multiple of 8 (the launcher falls back to zgemm3m_sub_kernel otherwise).
+#define ZD_BK 8
+__device__ __forceinline__ void zd_glds16(const void* g, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+#define ZD_MFMA(acc, x, y) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y))
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void zgemm3m_dma_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda, const dc* __restrict__ B, size_t ldb,
+                                                                   dc* __restrict__ C, size_t ldc) {
+  constexpr int NW = WM * WN, TM = 32 * WM, TN = 64 * WN;
+  constexpr int ACH = TM / 8, BSEG = TN / 64, BCH = 8 * BSEG;        // 1-KiB pieces of one stage: 8 rows of A each / 64 columns of one k-row of B each
+  constexpr int CA = ACH / NW, CB = BCH / NW;                          // pieces per wavefront per stage
+  static_assert(ACH % NW == 0 && BCH % NW == 0, "pieces must divide among the wavefronts");
+  constexpr int STAGE = (TM + TN) * ZD_BK;                             // entries per stage: A part, then B part
+  extern __shared__ __attribute__((aligned(16))) dc zd_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 15, lk = lane >> 4;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)zd_lds;
+
+  // per-lane sources of this wavefront's pieces (advanced by one stage per issue)
+  const dc* pa[CA]; const dc* pb[CB];
+#pragma unroll
+  for (int j = 0; j < CA; ++j) {
+    const int c = wave * CA + j;
+    const int row = min(m0 + 8 * c + (lane & 7), M - 1);
+    pa[j] = A + (size_t)row * lda + (((lane >> 4) << 1) | ((lane >> 3) & 1));
+  }
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    const int q = wave * CB + j, k = q / BSEG, seg = q - k * BSEG;
+    const int col = min(n0 + seg * 64 + lane, N - 1);
+    pb[j] = B + (size_t)k * ldb + col;
+  }
+  auto issue = [&](int buf) {
+    const unsigned base = lds0 + (unsigned)(buf * STAGE * (int)sizeof(dc));
+#pragma unroll
+    for (int j = 0; j < CA; ++j) { zd_glds16(pa[j], base + (unsigned)((wave * CA + j) * 1024)); pa[j] += ZD_BK; }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) { zd_glds16(pb[j], base + (unsigned)(TM * ZD_BK * 16 + (wave * CB + j) * 1024)); pb[j] += (size_t)ZD_BK * ldb; }
+  };
+
+  v4d t1[2][4], t2[2][4], t3[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { t1[a][b] = (v4d){0, 0, 0, 0}; t2[a][b] = (v4d){0, 0, 0, 0}; t3[a][b] = (v4d){0, 0, 0, 0}; }
+
+  // fragment positions (entries inside a stage): A piece (m >> 3), slot (k >> 1) 16 + (k & 1) 8 + (m & 7); B piece k BSEG + (n >> 6), slot n & 63
+  int aoff[2][2], boff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int k = ks * 4 + lk;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { const int m = wm * 32 + a * 16 + li; aoff[ks][a] = (m >> 3) * 64 + (k >> 1) * 16 + (k & 1) * 8 + (m & 7); }
+    boff[ks] = TM * ZD_BK + (k * BSEG + wn) * 64 + li;
+  }
+
+  const int nstage = K / ZD_BK;
+  issue(0);
+  if (nstage > 1) issue(1);
+  if (nstage > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CA + CB) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int st = 0; st < nstage; ++st) {
+    const int nxt = buf == 2 ? 0 : buf + 1;
+    if (st + 2 < nstage) issue(nxt == 2 ? 0 : nxt + 1);
+    const dc* S = zd_lds + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      dc af[2], bf[4];
+      double as[2], bs[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = S[aoff[ks][a]];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = S[boff[ks] + b * 16];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) as[a] = af[a].re + af[a].im;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bs[b] = bf[b].re + bf[b].im;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          ZD_MFMA(t1[a][b], af[a].re, bf[b].re);
+          ZD_MFMA(t2[a][b], af[a].im, bf[b].im);
+          ZD_MFMA(t3[a][b], as[a], bs[b]);
+        }
+    }
+    // stage st + 1 has landed (the pieces of st + 2, issued above, may stay in flight); the barrier publishes it and fences buffer st mod 3
+    if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CA + CB) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    buf = nxt;
+  }
+
+  // C read-modify-write, eight entries in flight per lane: the loads of a quarter (a, two b) of the wavefront's tile are issued
+  // back to back from clamped (always valid) addresses, then combined and stored under the bounds test (sixteen at a time
+  // spilled 28 registers)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh) {
+      dc cv[2][4];
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gm = min(m0 + wm * 32 + a * 16 + lk + 4 * r, M - 1);
+          const int gn = min(n0 + wn * 64 + (bh * 2 + b2) * 16 + li, N - 1);
+          cv[b2][r] = C[(size_t)gm * ldc + gn];
+        }
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = bh * 2 + b2;
+          const int gm = m0 + wm * 32 + a * 16 + lk + 4 * r;
+          const int gn = n0 + wn * 64 + b * 16 + li;
+          const double p1 = t1[a][b][r], p2 = t2[a][b][r];
+          dc c = cv[b2][r];
+          c.re -= p1 - p2; c.im -= t3[a][b][r] - p1 - p2;
+          if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = c;
+        }
+    }
 }
 
 // thin-N variant for the right-hand sides (N = nrhs small): y[m] -= sum_k A[m][k] x[k]; one wave per row
@@ -1889,17 +2057,19 @@ __global__ __launch_bounds__(256) void zgemv_sub_kernel(int M, int K, const dc* 
 
 // MFMA f64 issue-rate probe: each wave runs `iters` x 16 independent v_mfma_f64_16x16x4_f64
 __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(double* out, int iters) {
-  v4d acc[16];
+  // 12 independent accumulators (what one k-step of the update kernel issues), the instruction written out so that the
+  // accumulators stay where they are (the builtin form moved them between the two register files every iteration: 34 TFLOP/s)
+  v4d acc[12];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0, 0, 0, 0};
+  for (int i = 0; i < 12; ++i) acc[i] = (v4d){0, 0, 0, 0};
   double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 12; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 12; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -2278,6 +2448,23 @@ int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb
 
 int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m) {
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
+  if (use_3m && K % ZD_BK == 0) {
+    static const int dma_mode = [] { const char* e = getenv("MA_ZGEMM_DMA"); return e ? atoi(e) : MA_ZGEMM_DMA_DEFAULT; }();
+    if (dma_mode == 1 || dma_mode == 2) {
+      static const bool configured = [] {
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16) == hipSuccess;
+        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * ZD_BK * 16) == hipSuccess;
+        return ok;
+      }();
+      MA_REQUIRE(configured, MA_ERR_HIP, "zgemm3m_dma_kernel: LDS size refused");
+      if (dma_mode == 1) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2>), dim3((N + 127) / 128, (M + 63) / 64), dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
+                                            reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc);
+      else hipLaunchKernelGGL((zgemm3m_dma_kernel<4, 2>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 3 * (128 + 128) * ZD_BK * 16, st, M, N, K,
+                              reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc);
+      MA_HIP(hipGetLastError());
+      return MA_OK;
+    }
+  }
   if (use_3m) {
     dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
     // large updates draw their tiles XCD by XCD (see the kernel): a ring of counter blocks per device, one block per launch,

@@ -1282,7 +1282,7 @@ int ma_probe_mfma_f64(int device, double* tflops) {
   MA_HIP(hipEventSynchronize(b));
   float ms = 0.f;
   MA_HIP(hipEventElapsedTime(&ms, a, b));
-  const double flops = (double)blocks * 4.0 * iters * 16.0 * (2.0 * 16 * 16 * 4);
+  const double flops = (double)blocks * 4.0 * iters * 12.0 * (2.0 * 16 * 16 * 4);
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
   return rc;
