@@ -476,26 +476,81 @@ def main():
 
     def take_system(step, slot, last_step):
         """the system of `step` into slot `slot` (assembled on `stream`)"""
+        if os.environ.get("MA_BENCH_NO_ASM_BOUND"):
+            # diagnostic, NOT a benchmark: three systems assembled once, every step copies one (0.65 ms) -- what the schedule would
+            # run at if the assemblies cost the caller's stream nothing
+            if not spare_A:
+                for q in range(3):
+                    spare_A.append(torch.empty(n * n, dtype=torch.complex128, device=dev)); spare_x.append(torch.empty(n, dtype=torch.complex128, device=dev))
+                    f = freqs[(rank + q * world) % len(freqs)]; k = mm.wave_number(f, C_SOUND); b = mm.burton_miller_beta_scaled(k, 4.0)
+                    plan.assemble_dev(k, b, spare_A[q].data_ptr(), spare_x[q].data_ptr(), stream=stream)
+                    plan.incident_rhs_dev(k, b, spare_x[q].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
+            As[slot].copy_(spare_A[step % 3]); xs_[slot].copy_(spare_x[step % 3])
+            return
         if ahead <= 1:
             return assemble_into(step, slot)
-        if not spare_A:
-            for _ in range(ahead):
-                spare_A.append(torch.empty(n * n, dtype=torch.complex128, device=dev)); spare_x.append(torch.empty(n, dtype=torch.complex128, device=dev))
-        if step not in ready:
-            free = [i for i in range(ahead) if i not in ready.values()]
-            steps_ = [s_ for s_ in range(step, min(step + len(free), last_step))]
-            ks_, bs_ = [], []
-            for s_ in steps_:
-                f = freqs[(rank + s_ * world) % len(freqs)]
-                k = mm.wave_number(f, C_SOUND); ks_.append(k); bs_.append(mm.burton_miller_beta_scaled(k, 4.0))
-            idx = free[:len(steps_)]
-            plan.assemble_multi_dev(ks_, bs_, [spare_A[i].data_ptr() for i in idx], [spare_x[i].data_ptr() for i in idx], stream=stream)
-            for s_, i, k, b in zip(steps_, idx, ks_, bs_):
-                plan.incident_rhs_dev(k, b, spare_x[i].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
-                ready[s_] = i
-        i = ready.pop(step)
-        As[slot], spare_A[i] = spare_A[i], As[slot]
-        xs_[slot], spare_x[i] = spare_x[i], xs_[slot]
+        if not sets:
+            for _ in range(2):
+                sets.append({"A": [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(ahead)],
+                             "x": [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(ahead)],
+                             "steps": [], "taken": set(), "part": 0, "ks": [], "bs": []})
+        have = [t for t in sets if step in t["steps"] and step not in t["taken"]]
+        if not have:                                             # (first use, or the driver jumped): assemble it and its successors now
+            t = next(t for t in sets if len(t["taken"]) == len(t["steps"]))
+            start_job(t, step, last_step)
+            have = [t]
+            other = sets[1] if t is sets[0] else sets[0]
+            if len(other["taken"]) == len(other["steps"]) and step + ahead < last_step:
+                start_job(other, step + ahead, last_step)      # the set after this one: in pieces, from now on
+        t = have[0]
+        while t["part"] < nparts:                                # not finished in the gaps: the rest now
+            issue_part(t)
+        i = t["steps"].index(step)
+        As[slot], t["A"][i] = t["A"][i], As[slot]
+        xs_[slot], t["x"][i] = t["x"][i], xs_[slot]
+        t["taken"].add(step)
+        if len(t["taken"]) == len(t["steps"]):                   # the set is free again: the systems after the other set's, in pieces
+            other = sets[1] if t is sets[0] else sets[0]
+            nxt = (max(other["steps"]) + 1) if other["steps"] and max(other["steps"]) >= step else step + 1
+            if nxt < last_step:
+                start_job(t, nxt, last_step)
+
+    # Assembly AHEAD, in PIECES: two sets of `ahead` spare systems. While the slots consume one set (a slot that begins a system
+    # swaps its matrix with the spare that holds it), the other set's systems are assembled by ma_bem_plan_assemble_multi_part_dev
+    # in `nparts` pieces of the far pairs' rows (the far pairs of the set's systems share one pass over the quadrature points),
+    # one piece per round in the rounds just before a slot begins -- where the sum of the three slots' updates is smallest and
+    # the caller's stream would wait for the slots' panel chains (DESIGN.md 4.3). Same work inside the timed region.
+    sets = []
+    ppp = max(1, int(os.environ.get("MA_BENCH_ASM_PIECES", "4")))   # pieces per period (= per begin of a slot)
+    nparts = ppp * ahead
+
+    def start_job(t, first_step, last_step):
+        t["steps"] = [s_ for s_ in range(first_step, min(first_step + ahead, last_step))]
+        t["taken"] = set(); t["part"] = 0; t["ks"] = []; t["bs"] = []
+        for s_ in t["steps"]:
+            f = freqs[(rank + s_ * world) % len(freqs)]
+            k = mm.wave_number(f, C_SOUND); t["ks"].append(k); t["bs"].append(mm.burton_miller_beta_scaled(k, 4.0))
+
+    def issue_part(t):
+        m = len(t["steps"])
+        plan.assemble_multi_part_dev(t["ks"], t["bs"], [a.data_ptr() for a in t["A"][:m]], [x.data_ptr() for x in t["x"][:m]], t["part"], nparts, stream=stream)
+        t["part"] += 1
+        if t["part"] == nparts:
+            for i in range(m):
+                plan.incident_rhs_dev(t["ks"][i], t["bs"][i], t["x"][i].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
+
+    def assembly_tick(r, spacing):
+        """after the updates of round r: one piece of the set being assembled, in the last `ppp` rounds before a slot begins"""
+        if ahead <= 1 or not sets:
+            return
+        if (r % spacing) < spacing - ppp:
+            return
+        for t in sets:
+            if t["steps"] and t["part"] < nparts and not t["taken"]:
+                issue_part(t)
+                return
+
+    host_round = [] if os.environ.get("MA_BENCH_HOST_ROUNDS") else None   # host seconds per stage_round call (diagnostic)
 
     def run_pipeline(first, nsteps):
         """The same frequencies through the staged schedule: slot s works on steps s, s + S, ... and starts a quarter of a
@@ -534,10 +589,16 @@ def main():
             if not live:
                 break
             if sl:
+                if host_round is not None:
+                    th = time.perf_counter()
                 lu.stage_round(sl, bl, stream)
+                if host_round is not None:
+                    host_round.append((time.perf_counter() - th, len(sl)))
             for s, g in zip(sl, bl):
                 if g == G - 1:
                     lu.stage_finish(s, lanes[s] if asm_lane else stream)
+            if not asm_lane:
+                assembly_tick(r, spacing)
             r += 1
         if timing:
             lu_ms[:] += lu.last_timing()
@@ -683,10 +744,22 @@ def main():
         elapsed = float(t.item())
     if lu.status(stream) != ma.MA_OK:
         raise SystemExit("solve failed: %s" % ma.lib().ma_last_error_string().decode())
+    if timing and args.schedule == "pipeline" and os.environ.get("MA_BENCH_DUMP_UPDATES"):
+        # diagnostic: where does the caller's stream wait? (start, end) of every big update of the timed region
+        lu.last_timing()
+        iv = lu.dump_intervals(3)
+        np.save(os.environ["MA_BENCH_DUMP_UPDATES"], iv)
+        gaps = iv[1:, 0] - iv[:-1, 1]
+        dur = iv[:, 1] - iv[:, 0]
+        span = iv[-1, 1] - iv[0, 0]
+        sys.stderr.write("big updates: %d, busy %.1f ms of %.1f ms (%.3f); gaps: total %.1f ms; > 0.05 ms: %d (%.1f ms); > 0.5 ms: %d (%.1f ms); > 2 ms: %d (%.1f ms)\n"
+                         % (len(iv), dur.sum(), span, dur.sum() / span, gaps.sum(), (gaps > 0.05).sum(), gaps[gaps > 0.05].sum(), (gaps > 0.5).sum(), gaps[gaps > 0.5].sum(),
+                            (gaps > 2).sum(), gaps[gaps > 2].sum()))
     if timing and args.schedule == "pipeline":
         # per-call assembly events would need a host synchronisation per system inside the pipeline: the assembly phases
         # are timed in a separate pass over the same frequencies, after the timed region
-        if ahead > 1 and spare_A:                  # as the timed region assembled them: `ahead` systems per call
+        if ahead > 1 and sets:                     # as the timed region assembled them: `ahead` systems per pass over the quadrature points
+            spare_A, spare_x = sets[0]["A"], sets[0]["x"]
             for i in range(0, args.steps, ahead):
                 steps_ = list(range(args.warmup + i, min(args.warmup + i + ahead, args.warmup + args.steps)))
                 ks_ = [mm.wave_number(freqs[(rank + s_ * world) % len(freqs)], C_SOUND) for s_ in steps_]
@@ -711,6 +784,10 @@ def main():
         if not np.all(np.isfinite(v.cpu().numpy().view(np.float64))):
             raise SystemExit("non-finite solution")
 
+    if rank == 0 and host_round:
+        hr = sorted(t for t, c in host_round if c == max(c2 for _, c2 in host_round))
+        sys.stderr.write("host time per full stage_round call: min %.3f ms, median %.3f ms, max %.3f ms over %d calls (%d rounds per system)\n"
+                         % (hr[0] * 1e3, hr[len(hr) // 2] * 1e3, hr[-1] * 1e3, len(hr), lu.num_blocks()))
     if rank == 0:
         K = args.steps
         sys.stderr.write("host enqueue %.1f ms per step of %.1f ms per step\n" % (t_enqueued * 1e3 / K, elapsed * 1e3 / K))

@@ -105,6 +105,11 @@ int ma_bem_plan_assemble_dev(ma_bem_plan_t* plan, const ma_physics_t* physics, d
  * pointers, nf distinct matrices). The far pairs of up to three systems share one pass over the quadrature points. */
 int ma_bem_plan_assemble_multi_dev(ma_bem_plan_t* plan, int32_t nf, const ma_physics_t* physics, const double* beta_re, const double* beta_im,
                                    void* const* d_A, void* const* d_rhs, void* stream);
+/* The same assembly in `nparts` pieces issued one at a time (part = 0 .. nparts - 1, in that order, all on one stream): every
+ * part a slice of the far pairs' rows, the first also the right-hand sides' preparation, the last also the near and self pairs.
+ * For a sweep that assembles ahead and feeds the parts to its stream where it would otherwise wait (sweep_plan.hip). */
+int ma_bem_plan_assemble_multi_part_dev(ma_bem_plan_t* plan, int32_t nf, const ma_physics_t* physics, const double* beta_re, const double* beta_im,
+                                        void* const* d_A, void* const* d_rhs, int32_t part, int32_t nparts, void* stream);
 
 /* Incident field RHS.
  * Replaces: IncidentField::compute_rhs_with_beta(centers, normals, physics, beta)
@@ -520,6 +525,7 @@ int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma
 int ma_probe_mfma_f64(int device, double* tflops);
 /* Diagnostics (tools/panel_cotenancy.py): `repeat` launches of the trailing-update kernel on device buffers (C[M][N] -= A[M][K] B[K][N],
  * tight leading dimensions) / of the matrix-core probe (d_out: 256 * blocks doubles) on `stream`, as background load. */
+int ma_lu_plan_dump_intervals(ma_lu_plan_t* plan, int32_t phase, double* out_pairs, int32_t capacity, int32_t* count);   /* diagnostic: (start, end) ms of the timed intervals of one phase */
 int ma_diag_zgemm_dev(int32_t M, int32_t N, int32_t K, const void* dA, const void* dB, void* dC, int32_t repeat, void* stream);
 int ma_diag_mfma_burn(void* d_out, int32_t blocks, int32_t iters, int32_t repeat, void* stream);
 

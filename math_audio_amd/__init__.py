@@ -87,8 +87,10 @@ def lib():
             "ma_bem_solve_sweep_multi": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
             "ma_bem_solve_sweep_multi_timed": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp, vp, vp, vp],
             "ma_bem_plan_assemble_multi_dev": [vp, i32, vp, vp, vp, vp, vp, vp],
+            "ma_bem_plan_assemble_multi_part_dev": [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp],
             "ma_lu_plan_main_stream": [vp, P(vp)],
             "ma_lu_plan_stage_spacing": [vp, i32, P(i32)],
+            "ma_lu_plan_dump_intervals": [vp, i32, vp, i32, P(i32)],
             "ma_sweep_owner": [i32, i32],
             "ma_bem_plan_device": [vp, P(C.c_int)],
             "ma_lu_factorize": [i32, vp, P(vp)],
@@ -305,6 +307,14 @@ class BemPlan:
         pa = (C.c_void_p * nf)(*[int(a) for a in d_As]); pr = (C.c_void_p * nf)(*[int(r) for r in d_rhss])
         check(lib().ma_bem_plan_assemble_multi_dev(self.h, nf, phs, br, bi, pa, pr, C.c_void_p(stream)))
 
+    def assemble_multi_part_dev(self, ks, betas, d_As, d_rhss, part, nparts, stream=0, harmonic=1.0, tau=1.0):
+        """ma_bem_plan_assemble_multi_part_dev: piece `part` of `nparts` of assemble_multi_dev (issue them in order on one stream)."""
+        nf = len(ks)
+        phs = (type(physics(1.0)) * nf)(*[physics(k, harmonic, tau) for k in ks])
+        br = (C.c_double * nf)(*[complex(b).real for b in betas]); bi = (C.c_double * nf)(*[complex(b).imag for b in betas])
+        pa = (C.c_void_p * nf)(*[int(a) for a in d_As]); pr = (C.c_void_p * nf)(*[int(r) for r in d_rhss])
+        check(lib().ma_bem_plan_assemble_multi_part_dev(self.h, nf, phs, br, bi, pa, pr, int(part), int(nparts), C.c_void_p(stream)))
+
     def incident_rhs_dev(self, k, beta, d_rhs, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=0,
                          harmonic=1.0, tau=1.0):
         ph = physics(k, harmonic, tau); beta = complex(beta); amp = complex(amp)
@@ -398,6 +408,13 @@ class LuPlan:
         p = C.c_void_p()
         check(lib().ma_lu_plan_main_stream(self.h, C.byref(p)))
         return p.value
+
+    def dump_intervals(self, phase, capacity=200000):
+        """ma_lu_plan_dump_intervals: (start, end) ms of the timed intervals of one phase of the last timed staged run."""
+        out = np.zeros((capacity, 2), dtype=np.float64)
+        c = C.c_int32(0)
+        check(lib().ma_lu_plan_dump_intervals(self.h, int(phase), _vp(out), int(capacity), C.byref(c)))
+        return out[:min(c.value, capacity)]
 
     def stage_spacing(self, slots):
         """ma_lu_plan_stage_spacing: rounds between the starts of two slots of the staged schedule."""

@@ -120,7 +120,7 @@ __device__ __forceinline__ dc bm_coeff(const Acc4& s, int field_bc, const BemPhy
 // condition type keeps the compiler from dropping them on its own).
 struct FarMulti { BemPhys ph[3]; dc* A[3]; };
 template <int NF, bool VEL>
-__global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, FarMulti fm, int rows_per_block) {
+__global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, FarMulti fm, int rows_per_block, int row_blk0) {
   const int np = g.np;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int jj = j < np ? j : np - 1;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void tbem_far_kernel(BemGeom g, FarMulti fm, i
   double kk[NF], k2[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) { kk[f] = fm.ph[f].k * fm.ph[f].harmonic; k2[f] = fm.ph[f].k * fm.ph[f].k; }   // wavruim, k^2 (regular.rs:44-45)
-  const int i0 = blockIdx.y * rows_per_block;
+  const int i0 = ((int)blockIdx.y + row_blk0) * rows_per_block;   // row_blk0: the first strip of a partial pass (ma_bem_plan_assemble_multi_part_dev)
   const int i1 = min(i0 + rows_per_block, np);
   for (int i = i0; i < i1; ++i) {
     // wave-uniform collocation data (scalar loads)
@@ -612,7 +612,7 @@ __device__ __forceinline__ double quad_sq_area(const BemGeom& g, int j) {
 
 // K1q: every pair whose field panel is a quad, un-subdivided rule of the order the distance asks for.
 // grid.x: strips of 256 quad panels (lane = panel), grid.y: strips of collocation rows.
-__global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block) {
+__global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys ph, dc* __restrict__ A, int rows_per_block, int row_blk0) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   const bool valid = q < g.nquad;
   const int j = g.quad_ids[valid ? q : 0];
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void tbem_far_quad_kernel(BemGeom g, BemPhys p
   const long long col = g.dof[j];
   const double k = ph.k * ph.harmonic, k2 = ph.k * ph.k;
   const double sq = quad_sq_area(g, j);
-  const int i0 = blockIdx.y * rows_per_block, i1 = min(i0 + rows_per_block, g.np);
+  const int i0 = ((int)blockIdx.y + row_blk0) * rows_per_block, i1 = min(i0 + rows_per_block, g.np);
   for (int i = i0; i < i1; ++i) {
     const dc a = quad_far_coeff(g, v, sq, fbc, i, ph, k, k2);
     if (valid) A[(long long)g.dof[i] * g.nd + col] = a;
@@ -1326,22 +1326,28 @@ int bem_launch_near_list(const BemGeom& g, int pass, int* counts, const long lon
   return MA_OK;
 }
 
-int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st) {
+int bem_far_row_strips(const BemGeom& g) { return (g.np + 31) / 32; }
+// strips [blk0, blk0 + nblk) of 32 collocation rows (nblk < 0: all of them)
+int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st, int blk0, int nblk) {
   MA_REQUIRE(nf >= 1 && nf <= 3, MA_ERR_INVALID, "1..3 systems per far pass");
   const int rpb = 32;
-  dim3 grid((g.np + 255) / 256, (g.np + rpb - 1) / rpb), block(256);
+  const int all = (g.np + rpb - 1) / rpb;
+  if (nblk < 0) { blk0 = 0; nblk = all; }
+  MA_REQUIRE(blk0 >= 0 && blk0 + nblk <= all, MA_ERR_INVALID, "row strips [%d, %d) of %d", blk0, blk0 + nblk, all);
+  if (nblk == 0) return MA_OK;
+  dim3 grid((g.np + 255) / 256, nblk), block(256);
   FarMulti fm{};
   for (int f = 0; f < 3; ++f) { fm.ph[f] = phs[f < nf ? f : 0]; fm.A[f] = reinterpret_cast<dc*>(As[f < nf ? f : 0]); }
   const bool vel = g.all_velocity != 0;
-  if (nf == 1) { if (vel) hipLaunchKernelGGL((tbem_far_kernel<1, true>), grid, block, 0, st, g, fm, rpb); else hipLaunchKernelGGL((tbem_far_kernel<1, false>), grid, block, 0, st, g, fm, rpb); }
-  else if (nf == 2) { if (vel) hipLaunchKernelGGL((tbem_far_kernel<2, true>), grid, block, 0, st, g, fm, rpb); else hipLaunchKernelGGL((tbem_far_kernel<2, false>), grid, block, 0, st, g, fm, rpb); }
-  else { if (vel) hipLaunchKernelGGL((tbem_far_kernel<3, true>), grid, block, 0, st, g, fm, rpb); else hipLaunchKernelGGL((tbem_far_kernel<3, false>), grid, block, 0, st, g, fm, rpb); }
+  if (nf == 1) { if (vel) hipLaunchKernelGGL((tbem_far_kernel<1, true>), grid, block, 0, st, g, fm, rpb, blk0); else hipLaunchKernelGGL((tbem_far_kernel<1, false>), grid, block, 0, st, g, fm, rpb, blk0); }
+  else if (nf == 2) { if (vel) hipLaunchKernelGGL((tbem_far_kernel<2, true>), grid, block, 0, st, g, fm, rpb, blk0); else hipLaunchKernelGGL((tbem_far_kernel<2, false>), grid, block, 0, st, g, fm, rpb, blk0); }
+  else { if (vel) hipLaunchKernelGGL((tbem_far_kernel<3, true>), grid, block, 0, st, g, fm, rpb, blk0); else hipLaunchKernelGGL((tbem_far_kernel<3, false>), grid, block, 0, st, g, fm, rpb, blk0); }
   if (g.nquad > 0) for (int f = 0; f < nf; ++f)
-    hipLaunchKernelGGL(tbem_far_quad_kernel, dim3((g.nquad + 255) / 256, (g.np + rpb - 1) / rpb), block, 0, st, g, phs[f], reinterpret_cast<dc*>(As[f]), rpb);
+    hipLaunchKernelGGL(tbem_far_quad_kernel, dim3((g.nquad + 255) / 256, nblk), block, 0, st, g, phs[f], reinterpret_cast<dc*>(As[f]), rpb, blk0);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
-int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) { return bem_launch_far_multi(g, 1, &ph, &A, st); }
+int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st) { return bem_launch_far_multi(g, 1, &ph, &A, st, 0, -1); }
 
 int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st) {
   if (npairs <= 0) return MA_OK;

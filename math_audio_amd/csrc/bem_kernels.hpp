@@ -52,7 +52,8 @@ int bem_upload_tables(const double tri13_scaled[13][3], const double* glx, const
 int bem_launch_near_list(const BemGeom& g, int pass, int* counts, const long long* offsets, int2* pairs, hipStream_t st);
 int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
 // nf (1..3) systems of the SAME mesh at different wavenumbers in one pass: the geometry of a quadrature point is computed once
-int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st);
+int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st, int blk0 = 0, int nblk = -1);
+int bem_far_row_strips(const BemGeom& g);
 int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st);
 int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
 int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st);

@@ -340,8 +340,14 @@ int ma_bem_plan_assemble_dev(ma_bem_plan_t* P, const ma_physics_t* ph, double br
 // pairs of up to three systems go through ONE pass that computes every quadrature point's geometry (position, distance, the two
 // normal projections) once and only the wavenumber-dependent half (sin / cos, the kernel values) per system; near pairs and self
 // terms per system as in ma_bem_plan_assemble_dev. build_tbem_system_with_beta (tbem.rs:96-222) called nf times.
-int ma_bem_plan_assemble_multi_dev(ma_bem_plan_t* P, int32_t nf, const ma_physics_t* ph, const double* bre, const double* bim, void* const* dA, void* const* drhs, void* stream) {
+// part `part` of `nparts` of the assembly of nf systems: every part a slice of the far pairs' row strips; part 0 also prepares the
+// right-hand sides, the last part also runs the near and self pairs (which overwrite far entries: they come after every far part
+// in stream order). nparts = 1 is the whole assembly. A driver that has the matrices' memory early (a sweep assembling ahead)
+// feeds the parts to its stream one at a time where that stream would otherwise wait (sweep_plan.hip, bench.py).
+static int assemble_multi_part(ma_bem_plan_t* P, int32_t nf, const ma_physics_t* ph, const double* bre, const double* bim, void* const* dA, void* const* drhs,
+                               int32_t part, int32_t nparts, void* stream) {
   MA_REQUIRE(P && ph && bre && bim && dA && drhs && nf >= 1 && nf <= 16, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, MA_ERR_INVALID, "part %d of %d", part, nparts);
   BemPhys bp[16];
   int rc;
   for (int f = 0; f < nf; ++f) {
@@ -351,22 +357,32 @@ int ma_bem_plan_assemble_multi_dev(ma_bem_plan_t* P, int32_t nf, const ma_physic
   }
   MA_HIP(hipSetDevice(P->device));
   hipStream_t st = (hipStream_t)stream;
-  for (int f = 0; f < nf; ++f) {
+  const bool first = part == 0, last = part == nparts - 1, whole = nparts == 1;
+  if (first) for (int f = 0; f < nf; ++f) {
     if (P->has_bc) { if ((rc = bem_launch_rhs_bc(P->geom, bp[f], P->bc, P->d_pairs, P->d_pair_off, P->npairs, P->d_rhs_scratch, (c64*)drhs[f], st))) return rc; }
     else if ((rc = bem_launch_zero((c64*)drhs[f], P->nd, st))) return rc;
   }
-  if (P->timing) MA_HIP(hipEventRecord(P->ev[0], st));
+  if (P->timing && whole) MA_HIP(hipEventRecord(P->ev[0], st));
+  const int strips = bem_far_row_strips(P->geom);
+  const int b0 = (int)((long long)strips * part / nparts), b1 = (int)((long long)strips * (part + 1) / nparts);
   for (int f0 = 0; f0 < nf; f0 += 3) {
     c64* As[3]; const int cnt = std::min(3, nf - f0);
     for (int t = 0; t < cnt; ++t) As[t] = (c64*)dA[f0 + t];
-    if ((rc = bem_launch_far_multi(P->geom, cnt, bp + f0, As, st))) return rc;
+    if ((rc = bem_launch_far_multi(P->geom, cnt, bp + f0, As, st, b0, b1 - b0))) return rc;
   }
-  if (P->timing) MA_HIP(hipEventRecord(P->ev[1], st));
-  for (int f = 0; f < nf; ++f) if ((rc = bem_launch_near(P->geom, bp[f], P->d_pairs, P->npairs, (c64*)dA[f], st))) return rc;
-  if (P->timing) MA_HIP(hipEventRecord(P->ev[2], st));
-  for (int f = 0; f < nf; ++f) if ((rc = bem_launch_self(P->geom, bp[f], (c64*)dA[f], st))) return rc;
-  if (P->timing) { MA_HIP(hipEventRecord(P->ev[3], st)); P->ev_valid = true; }
+  if (P->timing && whole) MA_HIP(hipEventRecord(P->ev[1], st));
+  if (last) for (int f = 0; f < nf; ++f) if ((rc = bem_launch_near(P->geom, bp[f], P->d_pairs, P->npairs, (c64*)dA[f], st))) return rc;
+  if (P->timing && whole) MA_HIP(hipEventRecord(P->ev[2], st));
+  if (last) for (int f = 0; f < nf; ++f) if ((rc = bem_launch_self(P->geom, bp[f], (c64*)dA[f], st))) return rc;
+  if (P->timing && whole) { MA_HIP(hipEventRecord(P->ev[3], st)); P->ev_valid = true; }
   return MA_OK;
+}
+int ma_bem_plan_assemble_multi_dev(ma_bem_plan_t* P, int32_t nf, const ma_physics_t* ph, const double* bre, const double* bim, void* const* dA, void* const* drhs, void* stream) {
+  return assemble_multi_part(P, nf, ph, bre, bim, dA, drhs, 0, 1, stream);
+}
+int ma_bem_plan_assemble_multi_part_dev(ma_bem_plan_t* P, int32_t nf, const ma_physics_t* ph, const double* bre, const double* bim, void* const* dA, void* const* drhs,
+                                        int32_t part, int32_t nparts, void* stream) {
+  return assemble_multi_part(P, nf, ph, bre, bim, dA, drhs, part, nparts, stream);
 }
 
 int ma_bem_plan_set_timing(ma_bem_plan_t* P, int enable) {

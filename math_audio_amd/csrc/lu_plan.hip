@@ -101,6 +101,7 @@ struct ma_lu_plan {
   hipStream_t big_stream = nullptr;                       // mask B: the K = 256 updates of all slots
   hipEvent_t ev_pan[LU_BATCH_MAX] = {}, ev_chain[LU_BATCH_MAX] = {};
   int panel_cus() const { return cu_split > 0 ? cu_split : ncu; }
+  int tail_rows = 0;                                      // staged schedule: blocks with at most this many rows left take their WHOLE trailing update on the slot's lane (see Stage::tail)
   int admit_cus = 0;                                      // MA_LU_ADMIT_CUS: the CU count the admission window counts register panels against (0: what the launch may use)
 };
 
@@ -219,6 +220,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (const char* ec = getenv("MA_LU_CHAIN_MASK")) P->chain_mask = atoi(ec) != 0;
     if (const char* ep = getenv("MA_LU_PAN_MASK")) P->pan_mask = atoi(ep) != 0;
     if (const char* ea = getenv("MA_LU_ADMIT_CUS")) { const int v = atoi(ea); if (v >= 20 && v <= ncu) P->admit_cus = v; }
+    if (const char* et = getenv("MA_LU_TAIL_ROWS")) { const int v = atoi(et); if (v >= 0) P->tail_rows = v; }
     if (split < 8 || split % 8 != 0 || split > ncu - 64 || ncu % 32 != 0 || !P->lookahead || !P->panel_overlap) split = 0;
     P->cu_split = split;
     if (P->batch_panel) want_reg = 0;                      // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
@@ -684,6 +686,11 @@ struct Stage {
   int blk_first(int g) const { return g * kb; }
   int blk_last(int g) const { return std::min(Q, (g + 1) * kb); }
   int blk_end(int g) const { int q = blk_last(g) - 1; return k0s[q] + nbs[q]; }
+  // Tail blocks: once few rows are left, a slot's big update is small and its latency-bound chain is what a round waits for (and,
+  // first in the round's order on the caller's stream, what the other slots' updates queue behind). From there on the slot's
+  // lane applies the whole trailing update of a block itself and the slot no longer touches the caller's stream: it finishes
+  // at its chain's pace, beside the rounds of the other slots.
+  bool tail(int g) const { return P->stage_group < 2 && g >= 0 && g < G && n - blk_end(g) <= P->tail_rows; }
   hipStream_t lane_stream(int m) const { return (P->cu_split && P->chain_mask) ? P->chain_streams[m] : P->panel_streams[m]; }
   hipStream_t pan_stream(int m) const { return (P->cu_split && P->pan_mask) ? P->pan_streams[m] : lane_stream(m); }
   hipStream_t big_stream() const { return P->cu_split ? P->big_stream : st; }
@@ -770,7 +777,7 @@ struct Stage {
     c64* A = P->cur_A[m]; c64* B = P->cur_B[m]; hipStream_t sm = lane_stream(m);
     const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
-    if (g > 0) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));               // block g-1's big update of this slot
+    if (g > 0 && !tail(g - 1)) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));   // block g-1's big update of this slot
     MA_MARKD(t0, sm);
     for (int q = blk_first(g); q < blk_last(g); ++q)
       if ((rc = lu_launch_row_moves(A, n, nbs[q], P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs, sm))) return rc;
@@ -796,7 +803,7 @@ struct Stage {
     }
     MA_MARK(t3, sm);
     const bool narrow = nright > 0 && g + 1 < G;
-    if (narrow && (rc = gemm(nright, enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, sm))) return rc;
+    if (narrow && (rc = gemm(nright, tail(g) ? nright : enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, sm))) return rc;
     MA_MARK(t4, sm);
     interval(P, t3, t4, 5);
     MA_HIP(hipEventRecord(P->ev_mid[m], sm));
@@ -811,7 +818,7 @@ struct Stage {
     c64* A = P->cur_A[m];
     const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
-    if (nright <= 0) return MA_OK;
+    if (nright <= 0 || tail(g)) return MA_OK;
     hipStream_t bs = big_stream();
     MA_HIP(hipStreamWaitEvent(bs, P->ev_mid[m], 0));
     MA_MARK(t5, bs);
@@ -1098,6 +1105,27 @@ int ma_lu_plan_last_timing(ma_lu_plan_t* P, double* out8) {
     else if (v.phase == 6) out8[6] = ms;
   }
   out8[5] = P->n_gemm_launch;
+  return MA_OK;
+}
+
+// Diagnostic: the timed intervals of one phase of the last call as (start, end) in ms after the call's first mark, in the order
+// they were enqueued (phase 3 = the big updates on the caller's stream: their gaps are that stream's waits). After last_timing.
+int ma_lu_plan_dump_intervals(ma_lu_plan_t* P, int32_t phase, double* out_pairs, int32_t capacity, int32_t* count) {
+  MA_REQUIRE(P && out_pairs && count && capacity >= 0, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(P->ev_valid && P->stage_first_mark >= 0, MA_ERR_INVALID, "no timed staged run on this plan");
+  MA_HIP(hipSetDevice(P->device));
+  int c = 0;
+  for (const auto& v : P->iv) {
+    if (v.phase != phase) continue;
+    if (c < capacity) {
+      float a = 0.f, b = 0.f;
+      MA_HIP(hipEventElapsedTime(&a, P->ev[P->stage_first_mark], P->ev[v.a]));
+      MA_HIP(hipEventElapsedTime(&b, P->ev[P->stage_first_mark], P->ev[v.b]));
+      out_pairs[2 * c] = a; out_pairs[2 * c + 1] = b;
+    }
+    ++c;
+  }
+  *count = c;
   return MA_OK;
 }
 

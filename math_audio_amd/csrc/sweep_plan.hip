@@ -73,51 +73,78 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
     if (!r) r = ma_bem_plan_incident_rhs_dev(plan, &ph, 0.0, bim, a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, dx[(size_t)s], st);
     return r;
   };
-  // Assembly AHEAD in the staged schedule: the systems of the next (up to three) frequencies in one ma_bem_plan_assemble_multi_dev
-  // call -- their far pairs share one pass over the quadrature points -- into spare matrices; a slot that begins a system swaps
-  // its matrix with the spare that holds it. Only when the spares fit comfortably (MA_SWEEP_ASM_AHEAD=1 switches it off).
+  // Assembly AHEAD, in PIECES, in the staged schedule. Two sets of (up to three) spare systems: while the slots consume one set --
+  // a slot that begins a system swaps its matrix with the spare that holds it -- the other set's systems are assembled by
+  // ma_bem_plan_assemble_multi_part_dev (their far pairs share one pass over the quadrature points) in pieces of the far pairs'
+  // rows, one piece per round in the rounds just before a slot begins: there the sum of the slots' updates is smallest and the
+  // stream would wait for the slots' panel chains. What has not been issued when a system is needed is issued then. Only when the
+  // spares fit comfortably (MA_SWEEP_ASM_AHEAD=1: every system assembled when its slot begins).
   int ahead = 3;
   if (const char* ea = getenv("MA_SWEEP_ASM_AHEAD")) ahead = std::max(1, std::min(3, atoi(ea)));
   if (ahead > n_mine) ahead = std::max(1, (int)n_mine);
+  int ppp = 4;                                                  // pieces per slot begin
+  if (const char* ep = getenv("MA_SWEEP_ASM_PIECES")) ppp = std::max(1, std::min(16, atoi(ep)));
   {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)ahead * 16.0 * (double)n * (double)n > 0.5 * (double)free_b) ahead = 1;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2.0 * (double)ahead * 16.0 * (double)n * (double)n > 0.5 * (double)free_b) ahead = 1;
   }
-  std::vector<void*> sA, sx; std::vector<int> holds;      // spare matrices / right-hand sides, and which of this device's frequencies each holds (-1: none)
+  struct AsmSet { void* A[3] = {}; void* x[3] = {}; int first = -1, cnt = 0, part = 0; unsigned taken = 0; ma_physics_t ph[3]; double br[3], bi[3]; };
+  AsmSet sets[2];
+  auto free_spares = [&]() { for (auto& t : sets) for (int q = 0; q < 3; ++q) { if (t.A[q]) (void)hipFree(t.A[q]); if (t.x[q]) (void)hipFree(t.x[q]); t.A[q] = t.x[q] = nullptr; } };
   if (ahead > 1) {
-    sA.assign((size_t)ahead, nullptr); sx.assign((size_t)ahead, nullptr); holds.assign((size_t)ahead, -1);
     bool ok = true;
-    for (int q = 0; q < ahead && ok; ++q)
-      ok = hipMalloc(&sA[(size_t)q], sizeof(ma_c64) * (size_t)n * (size_t)n) == hipSuccess && hipMalloc(&sx[(size_t)q], sizeof(ma_c64) * (size_t)n) == hipSuccess;
-    if (!ok) { for (void* p : sA) if (p) (void)hipFree(p); for (void* p : sx) if (p) (void)hipFree(p); sA.clear(); sx.clear(); holds.clear(); ahead = 1; (void)hipGetLastError(); }
+    for (auto& t : sets) for (int q = 0; q < ahead && ok; ++q)
+      ok = hipMalloc(&t.A[q], sizeof(ma_c64) * (size_t)n * (size_t)n) == hipSuccess && hipMalloc(&t.x[q], sizeof(ma_c64) * (size_t)n) == hipSuccess;
+    if (!ok) { free_spares(); ahead = 1; (void)hipGetLastError(); }
   }
-  auto free_spares = [&]() { for (void* p : sA) if (p) (void)hipFree(p); for (void* p : sx) if (p) (void)hipFree(p); sA.clear(); sx.clear(); };
+  const int nparts = ppp * ahead;
+  auto set_idle = [](const AsmSet& t) { return t.first < 0 || t.taken == (1u << t.cnt) - 1u; };
+  auto start_job = [&](AsmSet& t, int first_i) {
+    t.first = first_i; t.cnt = std::min(ahead, n_mine - first_i); t.part = 0; t.taken = 0;
+    for (int q = 0; q < t.cnt; ++q) {
+      const double freq = frequencies_hz[mine[(size_t)(first_i + q)]];
+      t.ph[q].wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;
+      t.ph[q].harmonic_factor = a.harmonic_factor; t.ph[q].tau = a.tau; t.ph[q].gamma = 1.0;
+      t.br[q] = 0.0; t.bi[q] = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / t.ph[q].wave_number : 0.0;
+    }
+  };
+  auto issue_part = [&](AsmSet& t) -> int {
+    int r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, st);
+    if (r) return r;
+    if (++t.part == nparts)
+      for (int q = 0; q < t.cnt && !r; ++q)
+        r = ma_bem_plan_incident_rhs_dev(plan, &t.ph[q], 0.0, t.bi[q], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, t.x[q], st);
+    return r;
+  };
   // system of this device's i-th frequency into slot s
   auto take = [&](int i, int s) -> int {
     if (ahead <= 1) return assemble(mine[(size_t)i], s);
-    int at = -1;
-    for (int q = 0; q < ahead; ++q) if (holds[(size_t)q] == i) at = q;
-    if (at < 0) {
-      ma_physics_t ph[3]; double br[3], bi[3]; void* pa[3]; void* pr[3]; int idx[3]; int cnt = 0;
-      for (int q = 0; q < ahead && i + cnt < n_mine; ++q) {
-        if (holds[(size_t)q] >= 0) continue;
-        const double freq = frequencies_hz[mine[(size_t)(i + cnt)]];
-        ph[cnt].wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;
-        ph[cnt].harmonic_factor = a.harmonic_factor; ph[cnt].tau = a.tau; ph[cnt].gamma = 1.0;
-        br[cnt] = 0.0; bi[cnt] = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / ph[cnt].wave_number : 0.0;
-        pa[cnt] = sA[(size_t)q]; pr[cnt] = sx[(size_t)q]; idx[cnt] = q; ++cnt;
-      }
-      int r = ma_bem_plan_assemble_multi_dev(plan, cnt, ph, br, bi, pa, pr, st);
-      for (int t = 0; t < cnt && !r; ++t) {
-        r = ma_bem_plan_incident_rhs_dev(plan, &ph[t], 0.0, bi[t], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, pr[t], st);
-        holds[(size_t)idx[t]] = i + t;
-      }
-      if (r) return r;
-      for (int q = 0; q < ahead; ++q) if (holds[(size_t)q] == i) at = q;
-      if (at < 0) { set_error("sweep: no spare system for frequency %d", i); return MA_ERR_INVALID; }
+    AsmSet* t = nullptr;
+    for (auto& c : sets) if (c.first >= 0 && i >= c.first && i < c.first + c.cnt && !(c.taken >> (i - c.first) & 1u)) t = &c;
+    if (!t) {
+      for (auto& c : sets) if (!t && set_idle(c)) t = &c;
+      if (!t) { set_error("sweep: no spare system for frequency %d", i); return MA_ERR_INVALID; }
+      start_job(*t, i);
+      AsmSet& o = t == &sets[0] ? sets[1] : sets[0];
+      if (set_idle(o) && i + ahead < n_mine) start_job(o, i + ahead);       // the set after this one: in pieces, from now on
     }
-    std::swap(dA[(size_t)s], sA[(size_t)at]); std::swap(dx[(size_t)s], sx[(size_t)at]);
-    holds[(size_t)at] = -1;
+    int r = MA_OK;
+    while (t->part < nparts && !r) r = issue_part(*t);                       // not finished in the gaps: the rest now
+    if (r) return r;
+    const int q = i - t->first;
+    std::swap(dA[(size_t)s], t->A[q]); std::swap(dx[(size_t)s], t->x[q]);
+    t->taken |= 1u << q;
+    if (set_idle(*t)) {                                                      // free again: the systems after the other set's
+      AsmSet& o = t == &sets[0] ? sets[1] : sets[0];
+      const int nxt = (o.first >= 0 && o.first + o.cnt - 1 >= i) ? o.first + o.cnt : i + 1;
+      if (nxt < n_mine) start_job(*t, nxt); else t->first = -1;
+    }
+    return MA_OK;
+  };
+  // after the updates of round r: one piece of the set being assembled, in the last ppp rounds before a slot begins
+  auto assembly_tick = [&](int r, int spacing) -> int {
+    if (ahead <= 1 || (r % spacing) < spacing - ppp) return MA_OK;
+    for (auto& t : sets) if (t.first >= 0 && t.part < nparts && t.taken == 0) return issue_part(t);
     return MA_OK;
   };
   int32_t G = 0;
@@ -159,6 +186,7 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
         if (!rc && hipMemcpyAsync(dX + (size_t)i * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
         if (!rc) rc = ma_lu_plan_stage_info_dev(lu, s, dinfo + i, st);
       }
+      if (!rc) rc = assembly_tick(r, spacing);
     }
     if (!rc) {
       int stt = ma_lu_plan_status(lu, st);                     // synchronises; an abandoned panel (poisoned plan) surfaces here
