@@ -52,6 +52,22 @@ def pmc_traffic(kernel):
     return best
 
 
+def big_update_line(n, G, seconds):
+    """the K = kb x 64 updates on the caller's stream alone (the launches on the look-ahead lanes are K = 32 / 64 and run beside
+    them): algorithmic flops of the staged schedule's big updates / their summed time"""
+    Q = (n + 63) // 64
+    kb = (Q + G - 1) // G
+    fl, cnt = 0.0, 0
+    for g in range(G):
+        a0 = g * kb * 64
+        e = min(n, a0 + kb * 64)
+        enext = min(n, e + kb * 64)
+        if n - e > 0 and n - enext > 0:
+            fl += 8.0 * (n - e) * (n - enext) * (e - a0); cnt += 1
+    return {"launches_per_step": cnt, "K": kb * 64, "algorithmic_flops_per_step": fl, "ms_per_step": seconds * 1e3,
+            "achieved": fl / seconds / 1e12, "unit": "TFLOP/s", "frac": fl / seconds / 1e12 / FP64_MFMA_PEAK_TF}
+
+
 def lu_flops(n):
     return (8.0 / 3.0) * n ** 3 + 8.0 * n ** 2          # SURVEY §8(a9): zgetrf + zgetrs, real flops
 
@@ -823,14 +839,16 @@ def main():
                     ph[key] = diag_ms[idx]
                 ph["note"] += "; pipeline schedule: lu_panel / lu_swaps / lu_trsm / lu_rhs_and_triangular and the assembly phases come from separate passes after the timed region, lu_zgemm* and lu_total from events inside it (lu_total spans the assemblies too)"
             ach = gf / gemm_t / 1e12
-            out["roofline"] = {"kernel": "zgemm3m_sub_kernel (LU trailing updates, v_mfma_f64_16x16x4_f64; every launch of the step)", "bound": "mfma", "achieved": ach,
-                               "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": pmc_traffic("ma::zgemm3m_sub_kernel"),
+            out["roofline"] = {"kernel": "zgemm3m_dma_kernel<2, 2> (LU trailing updates, v_mfma_f64_16x16x4_f64; every launch of the step)", "bound": "mfma", "achieved": ach,
+                               "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
+                               "traffic": pmc_traffic("ma::zgemm3m_dma_kernel<2, 2>") or pmc_traffic("ma::zgemm3m_sub_kernel"),
                                "raw_mfma_frac": 0.75 * ach / FP64_MFMA_PEAK_TF,
                                "raw_mfma_note": "achieved/frac count ALGORITHMIC flops (8 M N K per complex update); the 3M kernel issues 3 real products per complex product, i.e. 3/4 of them on the matrix cores",
                                "traffic_note": "HBM-side bytes per launch from a separate rocprofv3 --pmc pass (profiles/); the algorithmic C read+write "
                                                "is %.3g B per launch on average" % (upd[2] / K / n_gemm),
                                "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
                                "algorithmic_flops_per_step": gf,
+                               "big_updates": big_update_line(n, lu.num_blocks(), lu_ms[3] / K * 1e-3) if args.schedule == "pipeline" else None,
                                "cus_note": ("the K = 256 updates run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); "
                                             "peak is the whole chip's" % (256 - cu_split, cu_split)) if cu_split else "updates on the whole chip"}
             far_t = asm_ms[0] / K * 1e-3

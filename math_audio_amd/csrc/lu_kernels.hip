@@ -2448,8 +2448,10 @@ int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb
 
 int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m) {
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
-  if (use_3m && K % ZD_BK == 0) {
-    static const int dma_mode = [] { const char* e = getenv("MA_ZGEMM_DMA"); return e ? atoi(e) : MA_ZGEMM_DMA_DEFAULT; }();
+  const char* e_draw = getenv("MA_ZGEMM_XCD_TILES");                         // an explicit request for the drawn-tile kernel wins (read per launch: the tests switch both)
+  if (use_3m && K % ZD_BK == 0 && !(e_draw && atoi(e_draw) > 0)) {
+    const char* e_dma = getenv("MA_ZGEMM_DMA");
+    const int dma_mode = e_dma ? atoi(e_dma) : MA_ZGEMM_DMA_DEFAULT;
     if (dma_mode == 1 || dma_mode == 2) {
       static const bool configured = [] {
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16) == hipSuccess;

@@ -187,3 +187,31 @@ def test_multi_frequency_assembly_equals_the_single_one(gpu, nf):
         err = np.abs(Am - A_ref) / np.abs(A_ref).max(axis=1, keepdims=True)
         assert err[~mask].max() <= TOL_FAR and err[mask].max() <= TOL_NEAR
     plan.close()
+
+
+@pytest.mark.parametrize("nparts", [2, 5, 12])
+def test_assembly_in_pieces_is_the_whole_one(gpu, nparts):
+    """ma_bem_plan_assemble_multi_part_dev: the far pairs' rows in `nparts` slices (the first piece prepares the right-hand sides,
+    the last runs the near and self pairs): issued in order on one stream they leave exactly the bits of assemble_multi_dev."""
+    import torch
+    om = O.icosphere(RADIUS, 2)
+    mesh = to_ma_mesh(om)
+    n = om.n_elem
+    plan = ma.BemPlan(mesh)
+    dev = torch.device("cuda", 0)
+    ks = [k_from_ka(ka) for ka in (0.2, 1.0, 3.0)]
+    betas = [O.beta_scaled(k, 4.0) for k in ks]
+    whole = [torch.full((n * n,), 7.0 + 1j, dtype=torch.complex128, device=dev) for _ in ks]
+    wr = [torch.full((n,), 3.0, dtype=torch.complex128, device=dev) for _ in ks]
+    plan.assemble_multi_dev(ks, betas, [a.data_ptr() for a in whole], [r.data_ptr() for r in wr])
+    parts = [torch.full((n * n,), -5.0 + 2j, dtype=torch.complex128, device=dev) for _ in ks]
+    pr = [torch.full((n,), -1.0, dtype=torch.complex128, device=dev) for _ in ks]
+    for p in range(nparts):
+        plan.assemble_multi_part_dev(ks, betas, [a.data_ptr() for a in parts], [r.data_ptr() for r in pr], p, nparts)
+    torch.cuda.synchronize()
+    for a, b in zip(whole, parts):
+        assert torch.equal(a, b)
+    for a, b in zip(wr, pr):
+        assert torch.equal(a, b)
+    with pytest.raises(ma.MaError):
+        plan.assemble_multi_part_dev(ks, betas, [a.data_ptr() for a in parts], [r.data_ptr() for r in pr], nparts, nparts)

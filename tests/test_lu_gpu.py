@@ -31,6 +31,25 @@ def test_zgemm_sub_kernel(gpu, M, N, K):
     assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 128, 8), (65, 129, 16), (1, 1, 8), (300, 70, 384), (129, 1000, 24), (1000, 1000, 64)])
+def test_zgemm_dma_kernels_are_bitwise_the_register_staged_one(gpu, M, N, K):
+    """K a multiple of 8: the update runs in zgemm3m_dma_kernel (operands global -> LDS by LDS-DMA, 32 x 64 of C per wavefront);
+    MA_ZGEMM_DMA=0 is the register-staged zgemm3m_sub_kernel (the kernel for ragged K), =2 the 128 x 128-tile form. Every entry of C
+    accumulates the same products in the same order in all three: equal bits, ragged edges included (rows and columns beyond the
+    matrix are fetched from the last valid one and never stored)."""
+    rng = np.random.default_rng(M * 3 + N * 5 + K)
+    A = rng.standard_normal((M, K)) + 1j * rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
+    Cm = rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))
+    ref = Cm - A @ B
+    got = {}
+    for mode in (0, 1, 2):
+        with _with_env(MA_ZGEMM_DMA=mode):
+            got[mode] = ma.test_zgemm_sub(A, B, Cm)
+        assert np.abs(got[mode] - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
 @pytest.mark.parametrize("M,N,K,persist", [(700, 1100, 64, 0), (1300, 900, 256, 0), (515, 2100, 40, 1), (64, 64, 8, 0)])
 def test_zgemm_sub_kernel_drawing_its_tiles(gpu, M, N, K, persist):
     """Large updates draw their tiles XCD by XCD (8 x 8 blocks of tiles per XCD, counters per launch, stealing when an XCD runs
