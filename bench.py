@@ -849,12 +849,12 @@ def main():
                                "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
                                "algorithmic_flops_per_step": gf,
                                "big_updates": big_update_line(n, lu.num_blocks(), lu_ms[3] / K * 1e-3) if args.schedule == "pipeline" else None,
-                               "cus_note": ("the K = 256 updates run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); "
+                               "cus_note": ("the big updates (`big_updates`) run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); "
                                             "peak is the whole chip's" % (256 - cu_split, cu_split)) if cu_split else "updates on the whole chip"}
             far_t = asm_ms[0] / K * 1e-3
             out["roofline_assembly"] = {"kernel": "tbem_far_kernel<%d, velocity-only> (far pairs of %d systems per pass)" % (ahead, ahead), "bound": "hbm", "achieved": 16.0 * n * n / far_t / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("ma::tbem_far_kernel<%d, true>" % ahead) or pmc_traffic("ma::tbem_far_kernel"), "systems_per_pass": ahead,
-                                        "traffic_note": "bytes per LAUNCH: a launch writes the matrices of `systems_per_pass` systems (16 B x N^2 each)",
+                                        "traffic_note": "bytes per LAUNCH: a launch writes one piece (1 / %d of the rows) of the matrices of `systems_per_pass` systems (16 B x N^2 each)" % nparts,
                                         "note": "16 B written per pair; the kernel is FP64-VALU/transcendental bound (SURVEY §8d): ~1.2 kflop per pair",
                                         "fp64_valu_tflops_equiv": 1.2e3 * n * n / far_t / 1e12}
             try:
