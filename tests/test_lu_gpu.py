@@ -112,6 +112,43 @@ def test_lu_random_matches_lapack(gpu, n):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-13 * kappa
 
 
+@pytest.mark.parametrize("n", [33, 65, 66, 70, 97, 129, 130, 193, 777, 1500])
+def test_pair_panels_match_lapack(gpu, n):
+    """The schedule of the 4 096-16 384-row plans at small sizes (MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64): a 64-column panel as two
+    register half-panels, lu_lane_step_kernel between them, lu_lane_step2_kernel after them, ragged last panels and strips of 1, 2,
+    4, 6 columns (where the step kernel once read L10 from rows another workgroup was permuting). LAPACK's pivots, LAPACK's solution."""
+    import scipy.linalg as sla
+    A, b = _rand(n, 4000 + n)
+    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64):
+        x, piv = ma.zgesv(A, b, return_pivots=True)
+    _, piv_ref = sla.lu_factor(A)
+    assert np.array_equal(piv, piv_ref)
+    xr = np.linalg.solve(A, b)
+    res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
+    assert res <= 1e-14 * n
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-13 * (np.linalg.cond(A) if n <= 400 else 1e4)
+
+
+def test_default_schedule_of_a_4200_row_plan(gpu):
+    """4 096-16 384 rows: the plan splits the chip by default (ma_lu_plan_main_stream is the masked update stream) and factors with
+    the register pair panels and the LDS-DMA update kernel; pivots and solution against LAPACK at a size inside that range."""
+    import scipy.linalg as sla
+    n = 4200
+    A, b = _rand(n, 4200)
+    lu = ma.LuPlan(n)
+    assert lu.main_stream()
+    assert lu.stage_spacing(3) == (lu.num_blocks() + 1) // 3
+    lu.close()
+    x, piv = ma.zgesv(A, b, return_pivots=True)
+    _, piv_ref = sla.lu_factor(A)
+    assert np.array_equal(piv, piv_ref)
+    res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
+    assert res <= 1e-14 * n
+    small = ma.LuPlan(900)
+    assert not small.main_stream()                          # outside the range: the round-2 schedule on the whole chip
+    small.close()
+
+
 @pytest.mark.parametrize("n", [64, 300, 777])
 def test_lu_pivots_are_lapacks(gpu, n):
     """Partial pivoting picks LAPACK's rows (izamax on |re| + |im|, first maximum): on generic data, where no two candidates
@@ -230,15 +267,26 @@ def test_lu_factorize_then_solve_and_lu_solve(gpu, n):
     assert e.value.status == ma.MA_ERR_SINGULAR
 
 
-def test_staged_pipeline_is_bitwise_the_single_solve(gpu):
+_SCHEDULES = {"default": {}, "pair": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64}, "pair_tail": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64, "MA_LU_TAIL_ROWS": 400}}
+
+
+@pytest.mark.parametrize("sched", ["default", "pair", "pair_tail"])
+def test_staged_pipeline_is_bitwise_the_single_solve(gpu, sched):
     """The staged plan API (slots at their own block index, staggered by a fraction of a factorisation) runs the same kernels on
-    the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit."""
+    the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit. `pair`: the
+    schedule plans of 4 096-16 384 rows get by default (64-column panels as two register half-panels, the fused step kernels, the
+    big updates on a stream masked off 64 CUs, which the driver then uses as its own); `pair_tail`: with the last blocks' whole
+    updates on the lanes."""
     import torch
     n = 900
     dev = torch.device("cuda", 0)
     mats = [_rand(n, 300 + i) for i in range(7)]
-    lu = ma.LuPlan(n)
+    with _with_env(**_SCHEDULES[sched]):
+        lu = ma.LuPlan(n)
     st = torch.cuda.current_stream().cuda_stream
+    if sched != "default":
+        assert lu.main_stream()
+        st = lu.main_stream()
     singles = []
     for A, b in mats:
         dA = torch.tensor(A, device=dev).reshape(-1); db = torch.tensor(b, device=dev)
