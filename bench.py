@@ -391,7 +391,7 @@ def main():
                     help="pipeline schedule: slots in groups of this size share one panel kernel per panel and move in lock step (0 = every slot on its own)")
     args = ap.parse_args()
     if args.schedule == "auto":
-        args.schedule = "pipeline" if args.steps >= 12 else "batch"
+        args.schedule = "pipeline" if args.steps >= 6 else "batch"   # 6 / 9 / 12 / 20 steps: 54.6 / 52.5 / 51.5 / 50.1 ms staged against 56.2 / 56.8 / 57.0 / 57.8 in lock step (3 steps: 61.8 against 55.9)
     if args.workload == "fem":
         return fem_workload(args)
     if args.inlib:
