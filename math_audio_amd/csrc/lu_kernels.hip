@@ -2453,12 +2453,20 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
     const char* e_dma = getenv("MA_ZGEMM_DMA");
     const int dma_mode = e_dma ? atoi(e_dma) : MA_ZGEMM_DMA_DEFAULT;
     if (dma_mode == 1 || dma_mode == 2) {
-      static const bool configured = [] {
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16) == hipSuccess;
-        ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * ZD_BK * 16) == hipSuccess;
-        return ok;
-      }();
-      MA_REQUIRE(configured, MA_ERR_HIP, "zgemm3m_dma_kernel: LDS size refused");
+      // more than 64 KB of LDS per workgroup: the limit is raised per function AND per device (a process may drive several)
+      {
+        static std::mutex mu;
+        static bool done[16] = {};
+        int dev = 0;
+        MA_HIP(hipGetDevice(&dev));
+        MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the table", dev);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done[dev]) {
+          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
+          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * ZD_BK * 16));
+          done[dev] = true;
+        }
+      }
       if (dma_mode == 1) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2>), dim3((N + 127) / 128, (M + 63) / 64), dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
                                             reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc);
       else hipLaunchKernelGGL((zgemm3m_dma_kernel<4, 2>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 3 * (128 + 128) * ZD_BK * 16, st, M, N, K,
