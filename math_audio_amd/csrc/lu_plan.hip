@@ -101,6 +101,7 @@ struct ma_lu_plan {
   hipStream_t big_stream = nullptr;                       // mask B: the K = 256 updates of all slots
   hipEvent_t ev_pan[LU_BATCH_MAX] = {}, ev_chain[LU_BATCH_MAX] = {};
   int panel_cus() const { return cu_split > 0 ? cu_split : ncu; }
+  int share_pct = 0, share_min_rows = 0;                  // staged schedule: blocks with at least share_min_rows rows left give share_pct % of their big update's columns to the slot's lane (see Stage::lane_share)
   int tail_rows = 0;                                      // staged schedule: blocks with at most this many rows left take their WHOLE trailing update on the slot's lane (see Stage::tail)
   int admit_cus = 0;                                      // MA_LU_ADMIT_CUS: the CU count the admission window counts register panels against (0: what the launch may use)
 };
@@ -221,6 +222,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (const char* ep = getenv("MA_LU_PAN_MASK")) P->pan_mask = atoi(ep) != 0;
     if (const char* ea = getenv("MA_LU_ADMIT_CUS")) { const int v = atoi(ea); if (v >= 20 && v <= ncu) P->admit_cus = v; }
     if (const char* et = getenv("MA_LU_TAIL_ROWS")) { const int v = atoi(et); if (v >= 0) P->tail_rows = v; }
+    if (const char* et = getenv("MA_LU_LANE_SHARE")) { const int v = atoi(et); if (v >= 0 && v <= 90) P->share_pct = v; }
+    if (const char* et = getenv("MA_LU_LANE_SHARE_MIN_ROWS")) { const int v = atoi(et); if (v >= 0) P->share_min_rows = v; }
     if (split < 8 || split % 8 != 0 || split > ncu - 64 || ncu % 32 != 0 || !P->lookahead || !P->panel_overlap) split = 0;
     P->cu_split = split;
     if (P->batch_panel) want_reg = 0;                      // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
@@ -691,6 +694,16 @@ struct Stage {
   // lane applies the whole trailing update of a block itself and the slot no longer touches the caller's stream: it finishes
   // at its chain's pace, beside the rounds of the other slots.
   bool tail(int g) const { return P->stage_group < 2 && g >= 0 && g < G && n - blk_end(g) <= P->tail_rows; }
+  // The other end: while a slot's updates are big its lane has slack (a round lasts what the caller's stream needs for the three
+  // slots' updates, the chain is shorter), and the 64 CUs the updates keep off are mostly idle between panels: the lane takes the
+  // LAST columns of the block's big update (a multiple of 128: whole tiles), the caller's stream the rest.
+  int lane_share(int g) const {
+    if (P->share_pct <= 0 || P->stage_group >= 2 || tail(g) || g + 1 >= G) return 0;
+    const int nright = n - blk_end(g), big_cols = n - blk_end(g + 1);
+    if (nright < P->share_min_rows || big_cols <= 256) return 0;
+    int w = (int)((long long)big_cols * P->share_pct / 100) / 128 * 128;
+    return std::max(0, std::min(w, big_cols - 128));
+  }
   hipStream_t lane_stream(int m) const { return (P->cu_split && P->chain_mask) ? P->chain_streams[m] : P->panel_streams[m]; }
   hipStream_t pan_stream(int m) const { return (P->cu_split && P->pan_mask) ? P->pan_streams[m] : lane_stream(m); }
   hipStream_t big_stream() const { return P->cu_split ? P->big_stream : st; }
@@ -804,6 +817,10 @@ struct Stage {
     MA_MARK(t3, sm);
     const bool narrow = nright > 0 && g + 1 < G;
     if (narrow && (rc = gemm(nright, tail(g) ? nright : enext - e, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, sm))) return rc;
+    if (narrow && !tail(g)) {
+      const int w = lane_share(g);                           // columns [n - w, n) of the big update on the lane (before the next panels: the lane has the slack here)
+      if (w > 0 && (rc = gemm(nright, w, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + (n - w), A + (size_t)e * n + (n - w), sm))) return rc;
+    }
     MA_MARK(t4, sm);
     interval(P, t3, t4, 5);
     MA_HIP(hipEventRecord(P->ev_mid[m], sm));
@@ -822,7 +839,7 @@ struct Stage {
     hipStream_t bs = big_stream();
     MA_HIP(hipStreamWaitEvent(bs, P->ev_mid[m], 0));
     MA_MARK(t5, bs);
-    if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, bs))) return rc;
+    if ((rc = gemm(nright, n - enext - lane_share(g), e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, bs))) return rc;
     MA_MARK(t6, bs);
     interval(P, t5, t6, 3);
     MA_HIP(hipEventRecord(P->ev_big[m], bs));
