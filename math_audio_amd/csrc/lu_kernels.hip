@@ -13,7 +13,8 @@
 //   lu_trsm64_kernel   U12 = L11^-1 A12 as MFMA products with the inverted diagonal blocks, panels of <= 64 columns, 94
 //                      registers and 17 KB so that it runs beside a trailing update (lu_trsm_mfma_kernel: up to 128 columns);
 //   lu_trsv_kernel     the nb x nb triangular solves of the backward substitution, one wavefront each.
-//   zgemm3m_sub_kernel A22 -= L21 U12 on v_mfma_f64_16x16x4_f64, 3 real products per complex product, 64 x 64 tiles
+//   zgemm3m_dma_kernel A22 -= L21 U12 on v_mfma_f64_16x16x4_f64, 3 real products per complex product, 64 x 128 tiles, operands by LDS-DMA
+//   zgemm3m_sub_kernel the same with register staging and 64 x 64 tiles: K not a multiple of 8
 //                      (zgemm_sub_kernel: the 4-product form, 128 x 128 tiles).
 #include "lu_kernels.hpp"
 #include "ma_device_math.hpp"

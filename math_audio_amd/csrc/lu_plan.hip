@@ -82,11 +82,13 @@ struct ma_lu_plan {
   // the other groups' trailing updates. 0 / 1: every slot on its own (the round-1 pipeline).
   int stage_group = 0;
   bool stage_lane_pending[LU_BATCH_MAX] = {};
-  // round 3: panels by lu_panel_reg_kernel (rows in registers, 32 columns, 256 rows per workgroup) when the tallest panel fits
-  // (MA_LU_REG_PANEL=0: the LDS-resident lu_panel_kernel), and in the staged schedule the chip split in two sets of CUs
-  // (MA_LU_CU_SPLIT=<P>, 0 = off): the panel kernels run on streams whose CU mask holds P CUs (P / 8 per XCD), the big trailing
-  // updates on a stream masked to the other ncu - P -- the exchange of a panel kernel then runs at its idle round trip instead of
-  // 2-3 x that beside update workgroups on the same CU (profiles/r03_cumask_probe.txt)
+  // round 3 (the default for MA_LU_PAIR_MIN_N .. MA_LU_PAIR_MAX_N rows, see the top of this file): panels by lu_panel_reg_kernel
+  // (rows in registers, 32 columns, 256 rows per workgroup; MA_LU_REG_PANEL=0: the LDS-resident lu_panel_kernel) and the chip
+  // split in two sets of CUs (MA_LU_CU_SPLIT=<P>, 0 = off): the big trailing updates run on a stream masked to ncu - P CUs, so that
+  // the panel kernels' workgroups find the other P (P / 8 per XCD) free of update workgroups -- a panel kernel's exchange runs at
+  // its idle round trip there instead of 2-3 x that beside update workgroups on the same CU (profiles/r03_cumask_probe.txt).
+  // With MA_LU_PAN_MASK=1 the panel kernels run on streams masked to those P CUs themselves (measured: the extra hardware queues
+  // cost far more than the guarantee buys).
   bool reg_panel0 = false, reg_pair0 = false;             // what the plan was created with (slot groups switch a plan to the LDS family and back)
   bool reg_panel = false;
   bool reg_pair = false;                                  // MA_LU_REG_PANEL=2: the 64-column structure of round 2 (K = 64 in-block updates, 4 panels per block, the main lane's
