@@ -543,6 +543,7 @@ int ma_lu_plan_set_timing(ma_lu_plan_t* plan, int enable);   /* 0 off, 1 every p
 int ma_lu_plan_last_timing(ma_lu_plan_t* plan, double* out8);
 /* the update (zgemm) launches out[3]+out[7] cover: count, algorithmic flops (8 M N K) and C read+write bytes (32 M N) */
 int ma_lu_plan_last_update_stats(ma_lu_plan_t* plan, double* launches, double* flops, double* c_bytes);
+int ma_lu_plan_last_big_update_stats(ma_lu_plan_t* plan, double* launches, double* flops);   /* of those: the big trailing updates on the caller's stream (kernel zgemm3m_dma_kernel<2, 2, true>) */
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,7 @@ def lib():
             "ma_lu_plan_set_timing": [vp, C.c_int],
             "ma_lu_plan_last_timing": [vp, vp],
             "ma_lu_plan_last_update_stats": [vp, P(dbl), P(dbl), P(dbl)],
+            "ma_lu_plan_last_big_update_stats": [vp, P(dbl), P(dbl)],
             "ma_csr_create": [i64, vp, vp, vp, C.c_int, P(vp)],
             "ma_csr_create_helmholtz": [i64, vp, vp, vp, vp, C.c_int, P(vp)],
             "ma_csr_create_rect": [i64, i64, vp, vp, vp, C.c_int, P(vp)],
@@ -455,8 +456,14 @@ class LuPlan:
         check(lib().ma_lu_plan_last_timing(self.h, _vp(out)))
         return out
 
+    def last_big_update_stats(self):
+        """(launches, algorithmic flops) of the big trailing updates on the caller's stream in the last call."""
+        a, b = C.c_double(), C.c_double()
+        check(lib().ma_lu_plan_last_big_update_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def last_update_stats(self):
-        """(launches, algorithmic flops, algorithmic C bytes) of the caller-stream trailing updates of the last call."""
+        """(launches, algorithmic flops, algorithmic C bytes) of every update launch (caller's stream and lanes) of the last call."""
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         check(lib().ma_lu_plan_last_update_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value

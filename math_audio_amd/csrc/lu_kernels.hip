@@ -1921,9 +1921,11 @@ __device__ __forceinline__ void zd_glds16(const void* g, unsigned lds_dst) {
 }
 #define ZD_MFMA(acc, x, y) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y))
 
-template <int WM, int WN>
+// BIG: the same code as a kernel of its own for the big trailing updates on the caller's stream (K = panels-per-update x 64, nine
+// tenths of a factorisation's flops), so that a kernel trace tells them from the K = 32 / 64 in-block updates on the lanes.
+template <int WM, int WN, bool BIG>
 __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void zgemm3m_dma_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda, const dc* __restrict__ B, size_t ldb,
-                                                                   dc* __restrict__ C, size_t ldc) {
+                                                                   dc* __restrict__ C, size_t ldc, int xcd_order) {
   constexpr int NW = WM * WN, TM = 32 * WM, TN = 64 * WN;
   constexpr int ACH = TM / 8, BSEG = TN / 64, BCH = 8 * BSEG;        // 1-KiB pieces of one stage: 8 rows of A each / 64 columns of one k-row of B each
   constexpr int CA = ACH / NW, CB = BCH / NW;                          // pieces per wavefront per stage
@@ -1933,7 +1935,30 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void zgemm3m_dm
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
   const int li = lane & 15, lk = lane >> 4;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  // Tile of this workgroup. xcd_order (a one-dimensional grid of 8 ceil(tiles / 8) workgroups) deals the tiles out XCD by XCD: workgroup b goes to XCD b mod 8
+  // when the chip is free to place it so (a tendency, not a rule: every tile is computed exactly once whatever the placement),
+  // XCD x takes the x-th eighth of the tile sequence, and that sequence runs through blocks of 4 x 4 tiles, so that the ~50
+  // workgroups an XCD runs at a time share 4 row strips of A and 4 column strips of B per 16 tiles in its 4 MB of L2 instead of
+  // fetching 2 strips per tile over the fabric.
+  int m0, n0;
+  if (!xcd_order) { m0 = blockIdx.y * TM; n0 = blockIdx.x * TN; }
+  else {
+    const int gx = (N + TN - 1) / TN, gy = (M + TM - 1) / TM, T = gx * gy;
+    const int per = (T + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (t >= T) return;                                                   // (uniform: before any barrier)
+    const int bw = (gx + 3) >> 2;                                         // blocks of 4 x 4 tiles, block-row-major; the last column / row of blocks may be narrower
+    const int full_rows = gy >> 2;                                        // block rows with 4 tile rows
+    int ty, tx;
+    if (t < full_rows * 4 * gx) {
+      const int br = t / (4 * gx), r = t - br * 4 * gx;                   // block row, index inside it
+      const int full_cols = gx >> 2;
+      if (r < full_cols * 16) { const int bc = r >> 4, q = r & 15; ty = br * 4 + (q >> 2); tx = bc * 4 + (q & 3); }
+      else { const int q = r - full_cols * 16, w = gx - full_cols * 4; ty = br * 4 + q / w; tx = full_cols * 4 + q % w; }
+    } else { const int q = t - full_rows * 4 * gx; ty = full_rows * 4 + q / gx; tx = q % gx; }   // the last (short) block row: row-major
+    (void)bw;
+    m0 = ty * TM; n0 = tx * TN;
+  }
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)zd_lds;
 
   // per-lane sources of this wavefront's pieces (advanced by one stage per issue)
@@ -2447,7 +2472,7 @@ int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb
   return MA_OK;
 }
 
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m) {
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big) {
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
   const char* e_draw = getenv("MA_ZGEMM_XCD_TILES");                         // an explicit request for the drawn-tile kernel wins (read per launch: the tests switch both)
   if (use_3m && K % ZD_BK == 0 && !(e_draw && atoi(e_draw) > 0)) {
@@ -2463,15 +2488,23 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
         MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the table", dev);
         std::lock_guard<std::mutex> lock(mu);
         if (!done[dev]) {
-          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
-          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * ZD_BK * 16));
+          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
+          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
+          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * ZD_BK * 16));
           done[dev] = true;
         }
       }
-      if (dma_mode == 1) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2>), dim3((N + 127) / 128, (M + 63) / 64), dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
-                                            reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc);
-      else hipLaunchKernelGGL((zgemm3m_dma_kernel<4, 2>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 3 * (128 + 128) * ZD_BK * 16, st, M, N, K,
-                              reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc);
+      // big updates: a one-dimensional grid, tiles dealt out XCD by XCD in blocks of 4 x 4 (see the kernel); MA_ZGEMM_TILE_ORDER=0: plain
+      const char* e_ord = getenv("MA_ZGEMM_TILE_ORDER");
+      const bool xcd_order = (e_ord ? atoi(e_ord) != 0 : true) && (long long)((N + 127) / 128) * ((M + 63) / 64) >= 512;
+      const int T22 = ((N + 127) / 128) * ((M + 63) / 64);
+      const dim3 g22 = xcd_order ? dim3(8 * ((T22 + 7) / 8), 1) : dim3((N + 127) / 128, (M + 63) / 64);
+      if (dma_mode == 1 && big) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, true>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
+                                                   reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, xcd_order ? 1 : 0);
+      else if (dma_mode == 1) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, false>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
+                                                 reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, xcd_order ? 1 : 0);
+      else hipLaunchKernelGGL((zgemm3m_dma_kernel<4, 2, false>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 3 * (128 + 128) * ZD_BK * 16, st, M, N, K,
+                              reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, 0);
       MA_HIP(hipGetLastError());
       return MA_OK;
     }

@@ -61,6 +61,7 @@ struct ma_lu_plan {
   std::vector<Iv> iv;             // timed intervals of the last call
   int ev_last = -1;
   int n_gemm_launch = 0;
+  int n_big_launch = 0; double big_flops = 0.0;   // of those: the big trailing updates on the caller's stream (phase 3)
   bool ev_valid = false;
   hipStream_t panel_stream = nullptr;   // stream of the look-ahead lane (system 0)
   hipStream_t panel_streams[LU_BATCH_MAX] = {};   // [0] aliases panel_stream; one per system of a batch
@@ -460,7 +461,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   const int n = P->n;
   const int tstride = n + P->nrhs_max;
   int rc;
-  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->ev_valid = false; P->last_batch = nmat;
+  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->n_big_launch = 0; P->big_flops = 0.0; P->ev_valid = false; P->last_batch = nmat;
   MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
   MA_MARK(e_begin, st);
 
@@ -484,10 +485,11 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
   auto blk_first = [&](int g) { return g * kb; };
   auto blk_last = [&](int g) { return std::min(Q, (g + 1) * kb); };           // one past
   auto blk_end = [&](int g) { int q = blk_last(g) - 1; return k0s[q] + nbs[q]; };   // first column right of block g
-  auto gemm = [&](int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_) -> int {
+  auto gemm = [&](int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_, bool big_ = false) -> int {
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
     P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;   // every launch is timed: phase 3 (main lane) or 5 (look-ahead lanes)
-    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m);
+    if (big_) { P->n_big_launch++; P->big_flops += 8.0 * M_ * (double)N_ * K_; }
+    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_);
   };
 
   // the look-ahead lane: factor the block column of block g of system m
@@ -629,7 +631,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       if (split) MA_HIP(hipStreamWaitEvent(st, P->ev_mid[m], 0));
       MA_MARK(t5, st);
       if (la) {
-        if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, st))) return rc;
+        if ((rc = gemm(nright, n - enext, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, st, true))) return rc;
       } else {
         if ((rc = gemm(nright, nright, e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + e, A + (size_t)e * n + e, st))) return rc;
         if (g + 1 < G && (rc = lane(m, g + 1))) return rc;
@@ -709,10 +711,11 @@ struct Stage {
   hipStream_t lane_stream(int m) const { return (P->cu_split && P->chain_mask) ? P->chain_streams[m] : P->panel_streams[m]; }
   hipStream_t pan_stream(int m) const { return (P->cu_split && P->pan_mask) ? P->pan_streams[m] : lane_stream(m); }
   hipStream_t big_stream() const { return P->cu_split ? P->big_stream : st; }
-  int gemm(int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_) {
+  int gemm(int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_, bool big_ = false) {
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
     P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;
-    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m);
+    if (big_) { P->n_big_launch++; P->big_flops += 8.0 * M_ * (double)N_ * K_; }
+    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_);
   }
   // the look-ahead lane: factor the block column of block g of slot m
   int lane(int m, int g) {
@@ -841,7 +844,7 @@ struct Stage {
     hipStream_t bs = big_stream();
     MA_HIP(hipStreamWaitEvent(bs, P->ev_mid[m], 0));
     MA_MARK(t5, bs);
-    if ((rc = gemm(nright, n - enext - lane_share(g), e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, bs))) return rc;
+    if ((rc = gemm(nright, n - enext - lane_share(g), e - a0, A + (size_t)e * n + a0, A + (size_t)a0 * n + enext, A + (size_t)e * n + enext, bs, true))) return rc;
     MA_MARK(t6, bs);
     interval(P, t5, t6, 3);
     MA_HIP(hipEventRecord(P->ev_big[m], bs));
@@ -883,7 +886,7 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
   MA_HIP(hipSetDevice(P->device));
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->ev_valid = false; P->last_batch = 0;
+  P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->n_big_launch = 0; P->big_flops = 0.0; P->ev_valid = false; P->last_batch = 0;
   P->last_bp_nsys = 0;
   MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
   MA_MARK(e0, st);
@@ -1150,6 +1153,12 @@ int ma_lu_plan_dump_intervals(ma_lu_plan_t* P, int32_t phase, double* out_pairs,
 
 // Update (zgemm) launches of the last call, main lane and look-ahead lanes, all systems of the batch: count, algorithmic
 // flops (8 M N K each) and algorithmic C bytes (32 M N each). Their time is out8[3] + out8[7] of ma_lu_plan_last_timing.
+// the big trailing updates on the caller's stream alone (their time is out8[3] of ma_lu_plan_last_timing)
+int ma_lu_plan_last_big_update_stats(ma_lu_plan_t* P, double* launches, double* flops) {
+  MA_REQUIRE(P && launches && flops, MA_ERR_INVALID, "NULL argument");
+  *launches = P->n_big_launch; *flops = P->big_flops;
+  return MA_OK;
+}
 int ma_lu_plan_last_update_stats(ma_lu_plan_t* P, double* launches, double* flops, double* c_bytes) {
   MA_REQUIRE(P && launches && flops && c_bytes, MA_ERR_INVALID, "NULL argument");
   *launches = P->n_gemm_launch; *flops = P->gemm_flops; *c_bytes = P->gemm_cbytes;

@@ -31,7 +31,7 @@ def test_zgemm_sub_kernel(gpu, M, N, K):
     assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 128, 8), (65, 129, 16), (1, 1, 8), (300, 70, 384), (129, 1000, 24), (1000, 1000, 64)])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 8), (65, 129, 16), (1, 1, 8), (300, 70, 384), (129, 1000, 24), (1000, 1000, 64), (2100, 4100, 16), (40, 66000, 8)])
 def test_zgemm_dma_kernels_are_bitwise_the_register_staged_one(gpu, M, N, K):
     """K a multiple of 8: the update runs in zgemm3m_dma_kernel (operands global -> LDS by LDS-DMA, 32 x 64 of C per wavefront);
     MA_ZGEMM_DMA=0 is the register-staged zgemm3m_sub_kernel (the kernel for ragged K), =2 the 128 x 128-tile form. Every entry of C
@@ -48,6 +48,9 @@ def test_zgemm_dma_kernels_are_bitwise_the_register_staged_one(gpu, M, N, K):
             got[mode] = ma.test_zgemm_sub(A, B, Cm)
         assert np.abs(got[mode] - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    # from 512 tiles on the tiles are dealt out XCD by XCD in blocks of 4 x 4 (a one-dimensional grid): every tile once, the same bits
+    with _with_env(MA_ZGEMM_DMA=1, MA_ZGEMM_TILE_ORDER=0):
+        assert np.array_equal(ma.test_zgemm_sub(A, B, Cm), got[0])
 
 
 @pytest.mark.parametrize("M,N,K,persist", [(700, 1100, 64, 0), (1300, 900, 256, 0), (515, 2100, 40, 1), (64, 64, 8, 0)])
