@@ -8,6 +8,10 @@ One step = one frequency: TBEM assembly (far + near + self kernels) + incident R
 complex LU solve, everything resident in HBM (geometry and the near-pair plan are uploaded once
 before the timed region; nothing crosses PCIe inside it).
 
+The timed region is ONE call of the library's own frequency loop per rank -- ma_bem_sweep_run on a reusable handle
+(include/mathaudio_hip.h; the C-ABI entry a Rust caller binds in place of room_simulator_bem.rs:328-360) -- so the number of
+record comes from the boundary, not from orchestration in this file.
+
   python bench.py --gpus N --steps K --warmup W
       N > 1 without WORLD_SIZE in the environment: bench.py starts its own N ranks (one per GPU) with
       torch.distributed.run before anything touches a GPU, and exits with their status;
@@ -52,35 +56,8 @@ def pmc_traffic(kernel):
     return best
 
 
-def big_update_line(n, G, seconds):
-    """the K = kb x 64 updates on the caller's stream alone (the launches on the look-ahead lanes are K = 32 / 64 and run beside
-    them): algorithmic flops of the staged schedule's big updates / their summed time"""
-    Q = (n + 63) // 64
-    kb = (Q + G - 1) // G
-    fl, cnt = 0.0, 0
-    for g in range(G):
-        a0 = g * kb * 64
-        e = min(n, a0 + kb * 64)
-        enext = min(n, e + kb * 64)
-        if n - e > 0 and n - enext > 0:
-            fl += 8.0 * (n - e) * (n - enext) * (e - a0); cnt += 1
-    return {"launches_per_step": cnt, "K": kb * 64, "algorithmic_flops_per_step": fl, "ms_per_step": seconds * 1e3,
-            "achieved": fl / seconds / 1e12, "unit": "TFLOP/s", "frac": fl / seconds / 1e12 / FP64_MFMA_PEAK_TF}
-
-
 def lu_flops(n):
     return (8.0 / 3.0) * n ** 3 + 8.0 * n ** 2          # SURVEY §8(a9): zgetrf + zgetrs, real flops
-
-
-def gemm_flops(n, nb=128):
-    """Real flops of the trailing updates A22 -= L21 U12 of a right-looking LU with panel width nb."""
-    f, k0 = 0.0, 0
-    while k0 < n:
-        w = min(nb, n - k0)
-        r = n - k0 - w
-        f += 8.0 * w * r * r
-        k0 += w
-    return f
 
 
 def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
@@ -324,47 +301,60 @@ def config5_measure():
     return out
 
 
-def inlib_sweep(args):
-    """The sweep as ONE call into the library per phase (ma_bem_solve_sweep_multi_timed): frequency i of the list belongs to device
-    i mod N; device d therefore solves the frequencies the rank form gives rank d (freqs[(d + s N) mod 64], s = 0..steps-1).
-    Warm-up = one call with `warmup` frequencies per device; the timed call carries `steps` per device. value = all pairs / the
-    slowest device's sweep time (plan creation -- geometry upload, near list -- is per call and reported next to it)."""
+def inlib_multi(args):
+    """--inlib-multi: ONE process, ma_bem_solve_sweep_multi_timed over --gpus N devices (a host thread, BEM plan and sweep handle per
+    device inside the library: what a single Rust process gets on a node). Frequency i of the list belongs to device i mod N."""
     import math_audio_amd as ma
     from math_audio_amd import mesh as mm
     N = args.gpus
     devices = [int(t) for t in args.devices.split(",")] if args.devices else list(range(N))
     if len(devices) != N:
-        raise SystemExit("bench.py --inlib: --devices lists %d devices, --gpus says %d" % (len(devices), N))
+        raise SystemExit("bench.py --inlib-multi: --devices lists %d devices, --gpus says %d" % (len(devices), N))
     mesh = mm.generate_sphere_mesh(RADIUS, args.n_theta, args.n_phi)
     n = mesh.n_elem
     freqs = mm.log_space(100.0, 8000.0, 64)
 
     def flist(first, count):
         return [freqs[(d + (first + s_) * N) % len(freqs)] for s_ in range(count) for d in range(N)]
-    S = max(1, min(args.slots, 4))
     if args.warmup > 0:
-        ma.solve_sweep_multi_timed(mesh, devices, flist(0, args.warmup), speed_of_sound=C_SOUND, beta_scale=4.0, slots=S)
+        ma.solve_sweep_multi_timed(mesh, devices, flist(0, args.warmup), speed_of_sound=C_SOUND, beta_scale=4.0, slots=args.slots)
     t0 = time.perf_counter()
-    X, st, secs, setup, cnt = ma.solve_sweep_multi_timed(mesh, devices, flist(args.warmup, args.steps), speed_of_sound=C_SOUND, beta_scale=4.0, slots=S)
+    X, st, secs, setup, cnt = ma.solve_sweep_multi_timed(mesh, devices, flist(args.warmup, args.steps), speed_of_sound=C_SOUND, beta_scale=4.0, slots=args.slots)
     wall = time.perf_counter() - t0
-    if not np.all(st == 0):
-        raise SystemExit("a frequency of the sweep failed: status %s" % sorted(set(int(v) for v in st)))
-    if not np.all(np.isfinite(X.view(np.float64))):
-        raise SystemExit("non-finite solution")
-    if any(int(c) != args.steps for c in cnt):
-        raise SystemExit("device frequency counts %s, expected %d each" % (list(map(int, cnt)), args.steps))
-    elapsed = float(max(secs))
-    K = args.steps
-    out = {"metric": "bem_sweep_panel_pairs_per_s", "value": float(n) * n * K * N / elapsed, "unit": "panel-pairs/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
-           "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
-           "config": {"workload": "S10 UV-sphere r=0.1 n_theta=%d n_phi=%d -> %d Tri3 panels; 64 log-spaced frequencies 100 Hz-8 kHz, frequency i on device i mod N; "
-                                  "one process, ma_bem_solve_sweep_multi (a host thread per device inside the library)" % (args.n_theta, args.n_phi, n),
-                      "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": S, "mode": "inlib", "devices": devices,
-                      "sharding": "frequency sweep, no data-path collective"},
-           "per_device_ms_per_step": [float(v) / K * 1e3 for v in secs], "per_device_frequencies": [int(c) for c in cnt],
-           "per_device_plan_setup_s": [float(v) for v in setup], "wall_s_of_the_call": wall,
-           "note": "value uses the slowest device's sweep time (solutions copied back to the host included); the call's wall time also holds each device's plan creation"}
-    print(json.dumps(out))
+    if not np.all(st == 0) or not np.all(np.isfinite(X.view(np.float64))) or any(int(c) != args.steps for c in cnt):
+        raise SystemExit("the multi-device sweep failed: status %s, counts %s" % (sorted(set(int(v) for v in st)), list(map(int, cnt))))
+    elapsed, K = float(max(secs)), args.steps
+    print(json.dumps({"metric": "bem_sweep_panel_pairs_per_s", "value": float(n) * n * K * N / elapsed, "unit": "panel-pairs/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
+                      "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+                      "config": {"workload": workload_text(args, n), "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": args.slots,
+                                 "mode": "in-library, one process: ma_bem_solve_sweep_multi (a host thread per device)", "devices": devices,
+                                 "sharding": "frequency sweep, no data-path collective"},
+                      "per_device_ms_per_step": [float(v) / K * 1e3 for v in secs], "per_device_plan_setup_s": [float(v) for v in setup], "wall_s_of_the_call": wall,
+                      "note": "value uses the slowest device's run (solutions copied back included); plan + handle creation per device is in per_device_plan_setup_s"}))
+
+
+def workload_text(args, n):
+    return ("S10 UV-sphere r=0.1 n_theta=%d n_phi=%d -> %d Tri3 panels; 64 log-spaced frequencies 100 Hz-8 kHz sharded f -> rank f mod N; rigid BC, "
+            "beta=4i/k, plane wave +z; step = TBEM assembly + incident RHS + dense complex LU solve (zgesv) of one frequency, device-resident"
+            % (args.n_theta, args.n_phi, n))
+
+
+def residual_check(ma, mm, torch, plan, n, dev, freqs_run, X, count):
+    """After the timed region: the last `count` systems re-assembled on the single-system path (the factorisation destroyed the
+    sweep's copies) and ||A x - b|| / ||b|| of the sweep's solutions, in torch on the device. The checker, not the product."""
+    A = torch.empty(n * n, dtype=torch.complex128, device=dev); b = torch.empty(n, dtype=torch.complex128, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    worst, which = 0.0, []
+    for i in range(len(freqs_run) - count, len(freqs_run)):
+        k = mm.wave_number(freqs_run[i], C_SOUND); beta = mm.burton_miller_beta_scaled(k, 4.0)
+        plan.assemble_dev(k, beta, A.data_ptr(), b.data_ptr(), stream=st)
+        plan.incident_rhs_dev(k, beta, b.data_ptr(), accumulate=True, stream=st)
+        x = torch.from_numpy(X[i]).to(dev)
+        res = float(torch.linalg.norm(A.view(n, n) @ x - b) / torch.linalg.norm(b))
+        worst = max(worst, res); which.append(round(float(freqs_run[i]), 1))
+    del A
+    return {"max_rel_residual": worst, "frequencies_hz": which, "bound": 1e-10,
+            "note": "||A x - b|| / ||b|| of the sweep's last solutions against systems re-assembled by ma_bem_plan_assemble_dev after the timed region"}
 
 
 def main():
@@ -377,25 +367,19 @@ def main():
     ap.add_argument("--n-theta", type=int, default=51)
     ap.add_argument("--n-phi", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-timing", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--inlib", action="store_true", help="ONE process: ma_bem_solve_sweep_multi over --gpus N devices (a host thread per device inside the library: what a "
-                                                          "Rust caller gets) instead of one torch.distributed rank per GPU")
-    ap.add_argument("--devices", default="", help="--inlib: comma-separated device list instead of 0..N-1 (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1 allows repeats)")
+    ap.add_argument("--no-timing", action="store_true", help="no HIP events around the update launches and the assembly pieces inside the timed region")
     ap.add_argument("--no-extras", action="store_true", help="skip the passes after the timed region that put configs #4 (FEM SpMV / smoother) and #5 (50k-panel operators) into the line")
-    ap.add_argument("--schedule", choices=["auto", "pipeline", "batch"], default="auto",
-                    help="pipeline: slots at staggered block indices (staged plan API); batch: lock-step batches of --slots systems; "
-                         "auto: pipeline from 12 steps on (below that its fill and drain cost more than the lock step does)")
-    ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "3")),
-                    help="frequencies in flight per GPU (systems factored as one interleaved batch, 1..4; with --group-size g: a multiple of g, up to 8)")
-    ap.add_argument("--group-size", type=int, default=int(os.environ.get("MA_SWEEP_GROUP", "0")),
-                    help="pipeline schedule: slots in groups of this size share one panel kernel per panel and move in lock step (0 = every slot on its own)")
+    ap.add_argument("--no-check", action="store_true", help="skip the residual check of the last systems after the timed region")
+    ap.add_argument("--inlib-multi", action="store_true", help="ONE process: ma_bem_solve_sweep_multi over --gpus N devices (a host thread per device inside the library) "
+                                                                "instead of one torch.distributed rank per GPU")
+    ap.add_argument("--devices", default="", help="--inlib-multi: comma-separated device list instead of 0..N-1 (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1 allows repeats)")
+    ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "3")), help="frequencies in flight per GPU (1..4)")
+    ap.add_argument("--dump-updates", default="", help="diagnostic: save (start, end) ms of every big update of the timed run to this .npy and print the stream's gaps")
     args = ap.parse_args()
-    if args.schedule == "auto":
-        args.schedule = "pipeline" if args.steps >= 6 else "batch"   # 6 / 9 / 12 / 20 steps: 54.6 / 52.5 / 51.5 / 50.1 ms staged against 56.2 / 56.8 / 57.0 / 57.8 in lock step (3 steps: 61.8 against 55.9)
     if args.workload == "fem":
         return fem_workload(args)
-    if args.inlib:
-        return inlib_sweep(args)
+    if args.inlib_multi:
+        return inlib_multi(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks here, as child processes, BEFORE this process touches a GPU
         # (nothing GPU-related has been imported yet), and hand their status back. One rank per GPU over RCCL, rendezvous on
@@ -430,455 +414,122 @@ def main():
     mesh = mm.generate_sphere_mesh(RADIUS, args.n_theta, args.n_phi)
     n = mesh.n_elem
     freqs = mm.log_space(100.0, 8000.0, 64)
-    # Frequencies are independent, and 288 GB of HBM holds many 1.6 GB systems: S systems are kept in flight and
-    # factored as ONE interleaved batch, so one frequency's latency-bound panel factorisation (one chip-wide
-    # gather per column) runs underneath another's MFMA-bound trailing update. A step is still one frequency.
-    gsz = args.group_size if (args.group_size >= 2 and args.schedule == "pipeline") else 0
-    S = max(1, min(args.slots, args.steps, 8 if gsz else int(os.environ.get("MA_BENCH_MAX_SLOTS", "4"))))
-    if gsz:
-        S = max(gsz, (S // gsz) * gsz)
+    K, W = args.steps, args.warmup
+    S = max(1, min(args.slots, 4, K))
+    # rank r solves the list's points r, r + N, ...: its s-th step is point (r + s N) mod 64 (the list wraps for long runs)
+    mine = lambda first, count: [freqs[(rank + (first + s_) * world) % len(freqs)] for s_ in range(count)]
     plan = ma.BemPlan(mesh, device=local_rank)
-    lu = ma.LuPlan(n, device=local_rank)
-    As = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
-    xs_ = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
-    stream = torch.cuda.current_stream().cuda_stream
-    cu_split = 0
-    if lu.main_stream():
-        # the chip is split (MA_LU_CU_SPLIT): the plan's big updates run on a CU-masked stream, which is a blocking stream (the only
-        # kind hipExtStreamCreateWithCUMask makes) and would serialise against work on the NULL stream. The bench's own launches
-        # (assemblies) go onto that stream too: no extra hardware queue
-        stream = lu.main_stream()
-        torch.cuda.set_stream(torch.cuda.ExternalStream(stream, device=dev))
-        cu_split = int(os.environ.get("MA_LU_CU_SPLIT", "64"))
-    asm_ms = np.zeros(3); lu_ms = np.zeros(8); upd = np.zeros(3); bigupd = np.zeros(2)
-    timing = False
-
-    def batch(first_step, count):
-        """`count` (<= S) consecutive frequencies: assemble each, then one interleaved factor+solve."""
-        for i in range(count):
-            f = freqs[(rank + (first_step + i) * world) % len(freqs)]
-            k = mm.wave_number(f, C_SOUND)
-            beta = mm.burton_miller_beta_scaled(k, 4.0)
-            plan.assemble_dev(k, beta, As[i].data_ptr(), xs_[i].data_ptr(), stream=stream)
-            plan.incident_rhs_dev(k, beta, xs_[i].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
-            if timing:
-                asm_ms[:] += plan.last_timing()
-        lu.factor_solve_batch_dev([a.data_ptr() for a in As[:count]], [v.data_ptr() for v in xs_[:count]], 1, stream=stream)
-        if timing:
-            lu_ms[:] += lu.last_timing()
-            upd[:] += lu.last_update_stats(); bigupd[:] += lu.last_big_update_stats()
-
-    def run_batches(first, nsteps):
-        s = 0
-        while s < nsteps:
-            c = min(S, nsteps - s)
-            batch(first + s, c)
-            s += c
-
-    def assemble_into(step, slot, on=None):
-        on = stream if on is None else on
-        f = freqs[(rank + step * world) % len(freqs)]
-        k = mm.wave_number(f, C_SOUND)
-        beta = mm.burton_miller_beta_scaled(k, 4.0)
-        plan.assemble_dev(k, beta, As[slot].data_ptr(), xs_[slot].data_ptr(), stream=on)
-        plan.incident_rhs_dev(k, beta, xs_[slot].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=on)
-
-    # The pipeline assembles AHEAD: the systems of the next `ahead` steps in one call (ma_bem_plan_assemble_multi_dev: the far pairs
-    # of up to three systems share one pass over the quadrature points) into spare matrices; a slot that begins a system swaps its
-    # matrix with the spare that holds it. Same work inside the timed region, 1.6 GB more of HBM per system assembled ahead.
-    ahead = max(1, min(3, int(os.environ.get("MA_BENCH_ASM_AHEAD", "3"))))
-    spare_A, spare_x = [], []
-    ready = {}                                                   # step -> index of the spare that holds its system
-
-    def take_system(step, slot, last_step):
-        """the system of `step` into slot `slot` (assembled on `stream`)"""
-        if os.environ.get("MA_BENCH_NO_ASM_BOUND"):
-            # diagnostic, NOT a benchmark: three systems assembled once, every step copies one (0.65 ms) -- what the schedule would
-            # run at if the assemblies cost the caller's stream nothing
-            if not spare_A:
-                for q in range(3):
-                    spare_A.append(torch.empty(n * n, dtype=torch.complex128, device=dev)); spare_x.append(torch.empty(n, dtype=torch.complex128, device=dev))
-                    f = freqs[(rank + q * world) % len(freqs)]; k = mm.wave_number(f, C_SOUND); b = mm.burton_miller_beta_scaled(k, 4.0)
-                    plan.assemble_dev(k, b, spare_A[q].data_ptr(), spare_x[q].data_ptr(), stream=stream)
-                    plan.incident_rhs_dev(k, b, spare_x[q].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
-            As[slot].copy_(spare_A[step % 3]); xs_[slot].copy_(spare_x[step % 3])
-            return
-        if ahead <= 1:
-            return assemble_into(step, slot)
-        if not sets:
-            for _ in range(2):
-                sets.append({"A": [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(ahead)],
-                             "x": [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(ahead)],
-                             "steps": [], "taken": set(), "part": 0, "ks": [], "bs": []})
-        have = [t for t in sets if step in t["steps"] and step not in t["taken"]]
-        if not have:                                             # (first use, or the driver jumped): assemble it and its successors now
-            t = next(t for t in sets if len(t["taken"]) == len(t["steps"]))
-            start_job(t, step, last_step)
-            have = [t]
-            other = sets[1] if t is sets[0] else sets[0]
-            if len(other["taken"]) == len(other["steps"]) and step + ahead < last_step:
-                start_job(other, step + ahead, last_step)      # the set after this one: in pieces, from now on
-        t = have[0]
-        while t["part"] < nparts:                                # not finished in the gaps: the rest now
-            issue_part(t)
-        i = t["steps"].index(step)
-        As[slot], t["A"][i] = t["A"][i], As[slot]
-        xs_[slot], t["x"][i] = t["x"][i], xs_[slot]
-        t["taken"].add(step)
-        if len(t["taken"]) == len(t["steps"]):                   # the set is free again: the systems after the other set's, in pieces
-            other = sets[1] if t is sets[0] else sets[0]
-            nxt = (max(other["steps"]) + 1) if other["steps"] and max(other["steps"]) >= step else step + 1
-            if nxt < last_step:
-                start_job(t, nxt, last_step)
-
-    # Assembly AHEAD, in PIECES: two sets of `ahead` spare systems. While the slots consume one set (a slot that begins a system
-    # swaps its matrix with the spare that holds it), the other set's systems are assembled by ma_bem_plan_assemble_multi_part_dev
-    # in `nparts` pieces of the far pairs' rows (the far pairs of the set's systems share one pass over the quadrature points),
-    # one piece per round in the rounds just before a slot begins -- where the sum of the three slots' updates is smallest and
-    # the caller's stream would wait for the slots' panel chains (DESIGN.md 4.3). Same work inside the timed region.
-    sets = []
-    ppp = max(1, int(os.environ.get("MA_BENCH_ASM_PIECES", "4")))   # pieces per period (= per begin of a slot)
-    nparts = ppp * ahead
-
-    def start_job(t, first_step, last_step):
-        t["steps"] = [s_ for s_ in range(first_step, min(first_step + ahead, last_step))]
-        t["taken"] = set(); t["part"] = 0; t["ks"] = []; t["bs"] = []
-        for s_ in t["steps"]:
-            f = freqs[(rank + s_ * world) % len(freqs)]
-            k = mm.wave_number(f, C_SOUND); t["ks"].append(k); t["bs"].append(mm.burton_miller_beta_scaled(k, 4.0))
-
-    def issue_part(t):
-        m = len(t["steps"])
-        plan.assemble_multi_part_dev(t["ks"], t["bs"], [a.data_ptr() for a in t["A"][:m]], [x.data_ptr() for x in t["x"][:m]], t["part"], nparts, stream=stream)
-        t["part"] += 1
-        if t["part"] == nparts:
-            for i in range(m):
-                plan.incident_rhs_dev(t["ks"][i], t["bs"][i], t["x"][i].data_ptr(), kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, accumulate=True, stream=stream)
-
-    def assembly_tick(r, spacing):
-        """after the updates of round r: one piece of the set being assembled, in the last `ppp` rounds before a slot begins"""
-        if ahead <= 1 or not sets:
-            return
-        if (r % spacing) < spacing - ppp:
-            return
-        for t in sets:
-            if t["steps"] and t["part"] < nparts and not t["taken"]:
-                issue_part(t)
-                return
-
-    host_round = [] if os.environ.get("MA_BENCH_HOST_ROUNDS") else None   # host seconds per stage_round call (diagnostic)
-
-    def run_pipeline(first, nsteps):
-        """The same frequencies through the staged schedule: slot s works on steps s, s + S, ... and starts a quarter of a
-        factorisation after slot s - 1, so every round of block updates carries a bigger, a medium and a smaller one and no
-        slot's latency-bound panel chain is ever the only thing running. No host synchronisation inside."""
-        slots = max(1, min(S, nsteps))
-        if gsz:
-            return run_pipeline_groups(first, nsteps)
-        G = lu.num_blocks()
-        spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or lu.stage_spacing(slots)   # rounds between the starts of two slots (ma_lu_plan_stage_spacing: G/3 with the register pair panels, G/4 with the LDS panels)
-        off = [s * spacing for s in range(slots)]
-        lu.stage_reset(stream)
-        asm_lane = os.environ.get("MA_BENCH_ASM_LANE", "0") != "0"
-        lanes = [lu.slot_stream(s) for s in range(slots)]
-        r = 0
-        while True:
-            sl, bl, live = [], [], False
-            for s in range(slots):
-                lr = r - off[s]
-                if lr < 0:
-                    live = True
-                    continue
-                sysno, g = divmod(lr, G)
-                idx = s + slots * sysno
-                if idx >= nsteps:
-                    continue
-                live = True
-                own = lanes[s] if asm_lane else stream
-                if g == 0:
-                    if asm_lane:
-                        assemble_into(first + idx, s, own)
-                    else:
-                        take_system(first + idx, s, first + nsteps)
-                    lu.stage_begin(s, As[s].data_ptr(), xs_[s].data_ptr(), 1, own)
-                sl.append(s); bl.append(g)
-            if not live:
-                break
-            if sl:
-                if host_round is not None:
-                    th = time.perf_counter()
-                lu.stage_round(sl, bl, stream)
-                if host_round is not None:
-                    host_round.append((time.perf_counter() - th, len(sl)))
-            for s, g in zip(sl, bl):
-                if g == G - 1:
-                    lu.stage_finish(s, lanes[s] if asm_lane else stream)
-            if not asm_lane:
-                assembly_tick(r, spacing)
-            r += 1
-        if timing:
-            lu_ms[:] += lu.last_timing()
-            upd[:] += lu.last_update_stats(); bigupd[:] += lu.last_big_update_stats()
-
-    def run_pipeline_model(first, nsteps):
-        """The staged schedule WITHOUT rounds. The caller's stream carries the big updates (and the assemblies) of all slots in
-        ONE order; in rounds -- every slot one block per round -- a slot near the end of its factorisation (tiny update, 2 ms
-        of chain per block) waits each round for the updates of the slots near their start (2.5 ms of matrix-core work each).
-        Here the order comes from a small model of the pipeline (lane chain, per-panel work, update time ~ (rows left)^2): the
-        next job on the caller's stream is always the one that becomes ready first, so slots advance at their own pace."""
-        slots = max(1, min(S, nsteps))
-        G = lu.num_blocks()
-        lanes = [lu.slot_stream(s_) for s_ in range(slots)]
-        Lm = float(os.environ.get("MA_MODEL_LANE", "2.6")); Mm = float(os.environ.get("MA_MODEL_MWORK", "0.9"))
-        Bm = float(os.environ.get("MA_MODEL_BIG", "3.0")); Am = float(os.environ.get("MA_MODEL_ASM", "5.5")); Km = float(os.environ.get("MA_MODEL_BACK", "1.5"))
-        gap0 = float(os.environ.get("MA_MODEL_STAGGER", "0")) or (G * (Lm + Mm) + Am) / slots
-        blk = 256.0
-        def big_ms(g):
-            left = max(0.0, n - blk * (g + 1))
-            return Bm * (left / n) ** 2
-        lu.stage_reset(stream)
-        t_main = 0.0
-        # per slot: next job ("asm" or block index), when it becomes eligible, lane end time of the block, end of the previous big
-        sysno = [0] * slots; job = ["asm"] * slots; elig = [s_ * gap0 for s_ in range(slots)]
-        t_lane = [0.0] * slots; t_bigdone = [0.0] * slots
-        active = [s_ < nsteps for s_ in range(slots)]
-        while any(active):
-            s_ = min((i for i in range(slots) if active[i]), key=lambda i: elig[i])
-            idx = s_ + slots * sysno[s_]
-            if job[s_] == "asm":
-                start = max(t_main, elig[s_]); t_main = start + Am
-                assemble_into(first + idx, s_, stream)
-                lu.stage_begin(s_, As[s_].data_ptr(), xs_[s_].data_ptr(), 1, stream)
-                t_lane[s_] = t_main + Lm; t_bigdone[s_] = t_main
-                job[s_] = 0
-                elig[s_] = max(t_lane[s_], t_bigdone[s_]) + Mm          # t_mid of block 0
-            else:
-                g = job[s_]
-                t_mid = elig[s_]
-                start = max(t_main, t_mid); dur = big_ms(g); t_main = start + dur
-                lu.stage_round([s_], [g], stream)
-                t_bigdone[s_] = t_main if dur > 0 else t_mid
-                t_lane[s_] = t_mid + Lm
-                if g == G - 1:
-                    lu.stage_finish(s_, stream)
-                    sysno[s_] += 1
-                    job[s_] = "asm"; elig[s_] = t_mid + Km
-                    if s_ + slots * sysno[s_] >= nsteps:
-                        active[s_] = False
-                else:
-                    job[s_] = g + 1
-                    elig[s_] = max(t_lane[s_], t_bigdone[s_]) + Mm
-        if timing:
-            lu_ms[:] += lu.last_timing()
-            upd[:] += lu.last_update_stats(); bigupd[:] += lu.last_big_update_stats()
-
-    if gsz and (args.steps % gsz or args.warmup % gsz):
-        raise SystemExit("bench.py: with --group-size %d, --steps and --warmup must be multiples of it (no frequency may be skipped)" % gsz)
-
-    def run_pipeline_groups(first, nsteps):
-        """Groups of gsz slots in lock step (one panel kernel per panel for the whole group: a wavefront per system), the groups
-        staggered against each other: a group's latency-bound chain runs under the other groups' trailing updates."""
-        U = S // gsz
-        lu.stage_set_group(gsz)
-        G = lu.num_blocks()
-        spacing = int(os.environ.get("MA_STAGE_SPACING", "0")) or max(1, G // U)
-        off = [u * spacing for u in range(U)]
-        lu.stage_reset(stream)
-        r = 0
-        while True:
-            sl, bl, live = [], [], False
-            for u in range(U):
-                lr = r - off[u]
-                if lr < 0:
-                    live = True
-                    continue
-                sysno, g = divmod(lr, G)
-                base = (u + U * sysno) * gsz                 # first step index of this group's current systems
-                if base + gsz > nsteps:
-                    continue
-                live = True
-                if g == 0:
-                    for t in range(gsz):
-                        assemble_into(first + base + t, u * gsz + t)
-                        lu.stage_begin(u * gsz + t, As[u * gsz + t].data_ptr(), xs_[u * gsz + t].data_ptr(), 1, stream)
-                    lu.stage_begin_group(u * gsz, stream)
-                for t in range(gsz):
-                    sl.append(u * gsz + t); bl.append(g)
-            if not live:
-                break
-            if sl:
-                lu.stage_round(sl, bl, stream)
-            for s_, g in zip(sl, bl):
-                if g == G - 1:
-                    lu.stage_finish(s_, stream)
-            r += 1
-        if timing:
-            lu_ms[:] += lu.last_timing()
-            upd[:] += lu.last_update_stats(); bigupd[:] += lu.last_big_update_stats()
-
-    run = run_pipeline if args.schedule == "pipeline" else run_batches
-    if args.schedule == "pipeline" and not gsz and os.environ.get("MA_SWEEP_ORDER", "rounds") == "model":
-        run = run_pipeline_model
-
-    run(0, args.warmup)
-    torch.cuda.synchronize()
-    if lu.status(stream) != ma.MA_OK:
-        raise SystemExit("warm-up solve failed: %s" % ma.lib().ma_last_error_string().decode())
-
-    if os.environ.get("MA_BENCH_HOST_PROBE"):
-        # how fast can the host enqueue? three systems into empty queues on an idle device: no back-pressure yet
-        th = time.perf_counter()
-        run(args.warmup, min(S, 3))
-        th = time.perf_counter() - th
-        torch.cuda.synchronize()
-        sys.stderr.write("host probe: %.1f ms to enqueue %d systems into empty queues\n" % (th * 1e3, min(S, 3)))
+    # The library's frequency loop behind its reusable handle: LU plan, streams, S systems in flight, the spare systems of the
+    # assembly-ahead and the parked solutions are allocated HERE, once, outside the timed region (inputs resident in HBM).
+    sweep = ma.BemSweep(plan, max(K, W, 1), slots=S)
+    info = sweep.info()
+    lu = sweep.lu_plan()
+    if W > 0:
+        _, st_w = sweep.run(mine(0, W), speed_of_sound=C_SOUND, beta_scale=4.0)
+        if not np.all(st_w == 0):
+            raise SystemExit("warm-up sweep failed: status %s" % sorted(set(int(v) for v in st_w)))
     timing = not args.no_timing
-    plan.set_timing(timing); lu.set_timing(2 if (timing and args.schedule == "pipeline") else timing)
-    if timing and args.schedule == "pipeline":
-        lu.reserve_events(1800 * args.steps)       # the event pool must not grow inside the timed region
+    sweep.set_timing(timing)                        # events around the update launches and the assembly pieces; the pools are filled now, not inside the timed region
+    run_freqs = mine(W, K)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
-    t_enqueued = time.perf_counter() - t0            # host time to enqueue the timed steps (the device may still be running)
+    X, status = sweep.run(run_freqs, speed_of_sound=C_SOUND, beta_scale=4.0)      # exactly K steps; returns with the K solutions on the host
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    per_rank_ms = [elapsed / args.steps * 1e3]
+    elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / K * 1e3]
     if world > 1:
-        mine = torch.tensor([elapsed, float(args.steps)], dtype=torch.float64, device=dev)
-        allv = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allv, mine)
-        per_rank_ms = [float(v[0].item()) / args.steps * 1e3 for v in allv]
-        if any(int(v[1].item()) != args.steps for v in allv):
-            raise SystemExit("ranks disagree on the number of steps: %s" % [int(v[1].item()) for v in allv])
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        per_rank_ms = [float(v.item()) / K * 1e3 for v in allv]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if lu.status(stream) != ma.MA_OK:
-        raise SystemExit("solve failed: %s" % ma.lib().ma_last_error_string().decode())
-    if timing and args.schedule == "pipeline" and os.environ.get("MA_BENCH_DUMP_UPDATES"):
-        # diagnostic: where does the caller's stream wait? (start, end) of every big update of the timed region
-        lu.last_timing()
-        iv = lu.dump_intervals(3)
-        np.save(os.environ["MA_BENCH_DUMP_UPDATES"], iv)
-        gaps = iv[1:, 0] - iv[:-1, 1]
-        dur = iv[:, 1] - iv[:, 0]
-        span = iv[-1, 1] - iv[0, 0]
-        sys.stderr.write("big updates: %d, busy %.1f ms of %.1f ms (%.3f); gaps: total %.1f ms; > 0.05 ms: %d (%.1f ms); > 0.5 ms: %d (%.1f ms); > 2 ms: %d (%.1f ms)\n"
-                         % (len(iv), dur.sum(), span, dur.sum() / span, gaps.sum(), (gaps > 0.05).sum(), gaps[gaps > 0.05].sum(), (gaps > 0.5).sum(), gaps[gaps > 0.5].sum(),
-                            (gaps > 2).sum(), gaps[gaps > 2].sum()))
-    if timing and args.schedule == "pipeline":
-        # per-call assembly events would need a host synchronisation per system inside the pipeline: the assembly phases
-        # are timed in a separate pass over the same frequencies, after the timed region
-        if ahead > 1 and sets:                     # as the timed region assembled them: `ahead` systems per pass over the quadrature points
-            spare_A, spare_x = sets[0]["A"], sets[0]["x"]
-            for i in range(0, args.steps, ahead):
-                steps_ = list(range(args.warmup + i, min(args.warmup + i + ahead, args.warmup + args.steps)))
-                ks_ = [mm.wave_number(freqs[(rank + s_ * world) % len(freqs)], C_SOUND) for s_ in steps_]
-                plan.assemble_multi_dev(ks_, [mm.burton_miller_beta_scaled(k, 4.0) for k in ks_], [spare_A[q].data_ptr() for q in range(len(steps_))],
-                                        [spare_x[q].data_ptr() for q in range(len(steps_))], stream=stream)
-                asm_ms[:] += plan.last_timing()
-        else:
-            for i in range(args.steps):
-                assemble_into(args.warmup + i, 0)
-                asm_ms[:] += plan.last_timing()
-        # the other phases of the factorisation (panel, interchanges, U12, substitutions) are bracketed in one lock-step batch
-        # outside the timed region: inside it only the trailing-update launches carry events (every event sits on a
-        # latency-bound chain; all of them cost 2.4 ms per frequency)
-        keep = (lu_ms.copy(), upd.copy(), asm_ms.copy(), bigupd.copy())
-        lu_ms[:] = 0; upd[:] = 0
-        lu.set_timing(1)
-        batch(args.warmup, min(S, 4))
-        torch.cuda.synchronize()
-        diag_ms = lu_ms / min(S, 4)
-        lu_ms[:], upd[:], asm_ms[:], bigupd[:] = keep
-    for v in xs_:
-        if not np.all(np.isfinite(v.cpu().numpy().view(np.float64))):
-            raise SystemExit("non-finite solution")
-
-    if rank == 0 and host_round:
-        hr = sorted(t for t, c in host_round if c == max(c2 for _, c2 in host_round))
-        sys.stderr.write("host time per full stage_round call: min %.3f ms, median %.3f ms, max %.3f ms over %d calls (%d rounds per system)\n"
-                         % (hr[0] * 1e3, hr[len(hr) // 2] * 1e3, hr[-1] * 1e3, len(hr), lu.num_blocks()))
+    if not np.all(status == 0):
+        raise SystemExit("a frequency of the sweep failed: status %s (%s)" % (sorted(set(int(v) for v in status)), ma.lib().ma_last_error_string().decode()))
+    if not np.all(np.isfinite(X.view(np.float64))):
+        raise SystemExit("non-finite solution")
+    tm = sweep.last_timing()
     if rank == 0:
-        K = args.steps
-        sys.stderr.write("host enqueue %.1f ms per step of %.1f ms per step\n" % (t_enqueued * 1e3 / K, elapsed * 1e3 / K))
-        total_pairs = float(n) * n * K * world
         out = {
-            "metric": "bem_sweep_panel_pairs_per_s", "value": total_pairs / elapsed, "unit": "panel-pairs/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3,
+            "metric": "bem_sweep_panel_pairs_per_s", "value": float(n) * n * K * world / elapsed, "unit": "panel-pairs/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
-            "config": {"workload": "S10 UV-sphere r=0.1 n_theta=%d n_phi=%d -> %d Tri3 panels; 64 log-spaced frequencies 100 Hz-8 kHz sharded "
-                                   "f -> rank f mod N; rigid BC, beta=4i/k, plane wave +z; step = TBEM assembly + incident RHS + dense complex LU "
-                                   "solve (zgesv) of one frequency, device-resident" % (args.n_theta, args.n_phi, n),
-                       "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": S, "schedule": args.schedule,
-                       "sharding": "frequency sweep, no data-path collective", "mode": "ranks"},
+            "config": {"workload": workload_text(args, n), "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": info["slots"],
+                       "mode": "in-library: one ma_bem_sweep_run call per rank on a reusable ma_bem_sweep_t handle (the C-ABI frequency loop; staged pipeline = %s, "
+                               "%d blocks per factorisation, slots %d rounds apart, %d systems assembled ahead)" % (info["staged"], info["blocks"], info["spacing"], info["systems_ahead"]),
+                       "sharding": "frequency sweep, no data-path collective"},
             "per_rank_ms_per_step": per_rank_ms, "per_rank_frequencies": [K] * world,
+            "sweep_call": {"wall_s_inside_the_call": tm["wall_s"], "device_ms_first_to_last_event": tm["device_ms"],
+                           "note": "the timed region is the ma_bem_sweep_run call plus the bracket's synchronisations; solutions (K x N complex128) come back to the host inside it"},
         }
+        if timing and info["staged"]:
+            l8 = lu.last_timing()
+            n_all, f_all, _ = lu.last_update_stats()
+            t_all = (l8[3] + l8[7]) * 1e-3                         # every update launch: the big ones on the sweep's stream + the lanes' K = 32 / 64 / 384 ones
+            n_big, f_big, t_big = max(1, tm["big_update_launches"]), tm["big_update_flops"], tm["big_update_ms"] * 1e-3
+            asm_t = tm["assembly_ms"] * 1e-3
+            cu_split = 64 if lu.main_stream() else 0
+            if lu.main_stream() and os.environ.get("MA_LU_CU_SPLIT"):
+                cu_split = int(os.environ["MA_LU_CU_SPLIT"])
+            bach = f_big / t_big / 1e12
+            ach_all = f_all / t_all / 1e12
+            e2e = lu_flops(n) * K / elapsed / 1e12
+            out["roofline"] = {
+                "kernel": "zgemm3m_dma_kernel<2, 2, true> (the big LU trailing updates on the sweep's stream, K = 64 x panels per block, v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma", "achieved": bach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": bach / FP64_MFMA_PEAK_TF,
+                "traffic": pmc_traffic("ma::zgemm3m_dma_kernel<2, 2, true>") or pmc_traffic("ma::zgemm3m_sub_kernel"),
+                "launches_per_step": n_big / K, "avg_launch_ms": t_big / n_big * 1e3, "algorithmic_flops_per_launch": f_big / n_big,
+                "algorithmic_flops_per_step": f_big / K, "share_of_update_flops": f_big / f_all if f_all > 0 else None,
+                "raw_mfma_frac": 0.75 * bach / FP64_MFMA_PEAK_TF,
+                "raw_mfma_note": "achieved / frac count ALGORITHMIC flops (8 M N K per complex update); the 3M kernel issues 3 real products per complex product, i.e. 3/4 of them on the matrix cores",
+                "all_update_launches": {"achieved": ach_all, "unit": "TFLOP/s", "frac": ach_all / FP64_MFMA_PEAK_TF, "launches_per_step": n_all / K, "avg_launch_ms": t_all / max(1.0, n_all) * 1e3,
+                                        "algorithmic_flops_per_step": f_all / K,
+                                        "note": "every update launch (big ones + the lanes' K = 32 / 64 / 384 ones), each timed by its own events under co-tenancy: the basis of rounds 1-2"},
+                "end_to_end_frac": e2e / FP64_MFMA_PEAK_TF, "end_to_end_tflops": e2e,
+                "end_to_end_note": "((8/3) N^3 + 8 N^2) x steps / the timed region / peak: assembly, panels, waits and ramps included -- the figure that compares like for like across rounds",
+                "cus_note": ("the big updates run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); peak is the whole chip's"
+                             % (256 - cu_split, cu_split)) if cu_split else "updates on the whole chip"}
+            out["solve_gflops"] = lu_flops(n) * K / max(elapsed - asm_t, 1e-9) / 1e9
+            out["assembly_pairs_per_s"] = float(n) * n * K / asm_t if asm_t > 0 else None
+            out["phase_ms_per_step"] = {"assembly_in_the_timed_region": tm["assembly_ms"] / K, "assembly_pieces_per_step": tm["assembly_pieces"] / K,
+                                        "big_updates": tm["big_update_ms"] / K, "lane_updates": l8[7] / K, "stream_neither": (tm["device_ms"] - tm["assembly_ms"] - tm["big_update_ms"]) / K,
+                                        "note": "events on the sweep's stream INSIDE the timed region: assembly pieces (far pairs of up to 3 systems per pass, near, self, incident right-hand sides) and "
+                                                "big updates share that stream, so device_ms - assembly - big updates is what the stream spends waiting for the slots' chains, on parking copies and in ramps; "
+                                                "lane_updates run on the slots' streams beside it"}
+            # 16 B written per pair; the far kernel is FP64-VALU / transcendental bound. Work per pair: ~1.2 kflop alone; with three
+            # systems per pass the geometric third of a quadrature point's ~120 instructions is shared: ~93 per system -> ~0.93 kflop per pair
+            per_pair = 1.2e3 * (93.0 / 120.0) if info["systems_ahead"] >= 3 else 1.2e3
+            out["roofline_assembly"] = {"kernel": "tbem_far_kernel<%d, velocity-only> + near + self + incident RHS, as the timed region ran them (on the update stream's CUs, beside the lanes)" % max(1, info["systems_ahead"]),
+                                        "bound": "hbm", "achieved": 16.0 * n * n * K / asm_t / 1e9 if asm_t > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": 16.0 * n * n * K / asm_t / 1e9 / HBM_PEAK_GBS if asm_t > 0 else None,
+                                        "traffic": pmc_traffic("ma::tbem_far_kernel<3, true>") or pmc_traffic("ma::tbem_far_kernel"),
+                                        "fp64_valu_tflops_equiv": per_pair * n * n * K / asm_t / 1e12 if asm_t > 0 else None, "flops_per_pair_assumed": per_pair,
+                                        "note": "algorithmic bytes: 16 B per pair; FP64-VALU-bound, not HBM-bound (DESIGN 4)"}
+            if args.dump_updates:
+                iv = lu.dump_intervals(3)
+                np.save(args.dump_updates, iv)
+                gaps = iv[1:, 0] - iv[:-1, 1]; dur = iv[:, 1] - iv[:, 0]; span = iv[-1, 1] - iv[0, 0]
+                sys.stderr.write("big updates: %d, busy %.1f ms of %.1f ms (%.3f); gaps: total %.1f ms; > 0.5 ms: %d (%.1f ms); > 2 ms: %d (%.1f ms)\n"
+                                 % (len(iv), dur.sum(), span, dur.sum() / span, gaps.sum(), (gaps > 0.5).sum(), gaps[gaps > 0.5].sum(), (gaps > 2).sum(), gaps[gaps > 2].sum()))
+        sweep.close()                                   # 9 matrices of 1.6 GB go back before the checker and the extras allocate theirs
+        if not args.no_check:
+            out["check"] = residual_check(ma, mm, torch, plan, n, dev, run_freqs, X, min(S, K))
+            if not out["check"]["max_rel_residual"] <= 1e-10:
+                raise SystemExit("residual check failed: %r" % out["check"])
         if timing:
-            asm_t = asm_ms.sum() / K * 1e-3
-            gemm_t = (lu_ms[3] + lu_ms[7]) / K * 1e-3   # every zgemm launch: main lane + look-ahead lanes
-            lu_t = lu_ms[6] / K * 1e-3                 # whole factor+solve on the caller's stream (panel overlaps zgemm)
-            if args.schedule == "pipeline":            # the span also holds the assemblies, which share the caller's stream with the big updates
-                lu_t = max(lu_t - asm_t, 1e-9)
-            n_gemm = max(1.0, upd[0] / K)
-            gf = upd[1] / K
-            out["assembly_pairs_per_s"] = n * n / asm_t
-            out["solve_gflops"] = lu_flops(n) / lu_t / 1e9
-            out["phase_ms_per_step"] = {"assembly_far": asm_ms[0] / K, "assembly_near": asm_ms[1] / K, "assembly_self": asm_ms[2] / K,
-                                        "lu_panel": lu_ms[0] / K, "lu_swaps": lu_ms[1] / K, "lu_trsm": lu_ms[2] / K, "lu_zgemm": lu_ms[3] / K,
-                                        "lu_rhs_and_triangular": lu_ms[4] / K, "lu_zgemm_lookahead_lanes": lu_ms[7] / K, "lu_total": lu_ms[6] / K,
-                                        "note": "lu_panel and lu_zgemm_lookahead_lanes run on the look-ahead streams concurrently with the main lane; lu_panel intervals include queueing behind other systems' panels"}
-            if args.schedule == "pipeline":
-                ph = out["phase_ms_per_step"]
-                for key, idx in (("lu_panel", 0), ("lu_swaps", 1), ("lu_trsm", 2), ("lu_rhs_and_triangular", 4)):
-                    ph[key] = diag_ms[idx]
-                ph["note"] += "; pipeline schedule: lu_panel / lu_swaps / lu_trsm / lu_rhs_and_triangular and the assembly phases come from separate passes after the timed region, lu_zgemm* and lu_total from events inside it (lu_total spans the assemblies too)"
-            ach = gf / gemm_t / 1e12
-            all_launches = {"kernels": "zgemm3m_dma_kernel<2, 2, true> + <2, 2, false> (every update launch the library counts: the big updates on the caller's stream and the K = 64 in-block updates on the look-ahead lanes, all timed under co-tenancy)",
-                            "achieved": ach, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "launches_per_step": n_gemm, "avg_launch_ms": gemm_t / n_gemm * 1e3,
-                            "algorithmic_flops_per_step": gf, "raw_mfma_frac": 0.75 * ach / FP64_MFMA_PEAK_TF}
-            # the dominant kernel: the big trailing updates on the caller's stream (their own instantiation of the update kernel, so
-            # that the committed kernel statistics show them apart): nine tenths of a step's flops
-            n_big = max(1.0, bigupd[0] / K)
-            big_f = bigupd[1] / K
-            big_t = lu_ms[3] / K * 1e-3
-            if big_f <= 0.0:                                  # lock-step schedule on an old library: fall back to all launches
-                n_big, big_f, big_t = n_gemm, gf, gemm_t
-            bach = big_f / big_t / 1e12
-            out["roofline"] = {"kernel": "zgemm3m_dma_kernel<2, 2, true> (the big LU trailing updates on the caller's stream, K = %d, v_mfma_f64_16x16x4_f64)" % big_update_line(n, lu.num_blocks(), 1.0)["K"],
-                               "bound": "mfma", "achieved": bach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": bach / FP64_MFMA_PEAK_TF,
-                               "traffic": pmc_traffic("ma::zgemm3m_dma_kernel<2, 2, true>") or pmc_traffic("ma::zgemm3m_dma_kernel<2, 2>") or pmc_traffic("ma::zgemm3m_sub_kernel"),
-                               "raw_mfma_frac": 0.75 * bach / FP64_MFMA_PEAK_TF,
-                               "raw_mfma_note": "achieved/frac count ALGORITHMIC flops (8 M N K per complex update); the 3M kernel issues 3 real products per complex product, i.e. 3/4 of them on the matrix cores",
-                               "traffic_note": "HBM-side bytes per launch from a separate rocprofv3 --pmc pass (profiles/); the algorithmic C read+write is %.3g B per launch on average" % (32.0 * big_f / (8.0 * big_update_line(n, lu.num_blocks(), 1.0)["K"]) / n_big),
-                               "launches_per_step": n_big, "avg_launch_ms": big_t / n_big * 1e3,
-                               "algorithmic_flops_per_step": big_f, "share_of_update_flops": big_f / gf if gf > 0 else None,
-                               "all_update_launches": all_launches,
-                               "cus_note": ("these updates run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); "
-                                            "peak is the whole chip's" % (256 - cu_split, cu_split)) if cu_split else "updates on the whole chip"}
-            far_t = asm_ms[0] / K * 1e-3
-            out["roofline_assembly"] = {"kernel": "tbem_far_kernel<%d, velocity-only> (far pairs of %d systems per pass)" % (ahead, ahead), "bound": "hbm", "achieved": 16.0 * n * n / far_t / 1e9, "peak": HBM_PEAK_GBS,
-                                        "unit": "GB/s", "frac": 16.0 * n * n / far_t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("ma::tbem_far_kernel<%d, true>" % ahead) or pmc_traffic("ma::tbem_far_kernel"), "systems_per_pass": ahead,
-                                        "traffic_note": "bytes per LAUNCH: a launch writes one piece (1 / %d of the rows) of the matrices of `systems_per_pass` systems (16 B x N^2 each)" % nparts,
-                                        "note": "16 B written per pair; the kernel is FP64-VALU/transcendental bound (SURVEY §8d): ~1.2 kflop per pair",
-                                        "fp64_valu_tflops_equiv": 1.2e3 * n * n / far_t / 1e12}
             try:
-                out["mfma_f64_probe_tflops"] = ma.probe_mfma_f64(local_rank)
-            except Exception as e:      # diagnostics only
+                out["mfma_f64_probe_tflops"] = ma.probe_mfma_f64(local_rank)     # 3 x 6.5 ms of back-to-back v_mfma_f64_16x16x4_f64 on every CU (tools/mfma_peak_probe.py reads the same)
+            except Exception:                                                  # diagnostics only
                 out["mfma_f64_probe_tflops"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.n_theta, args.n_phi, freqs[32])
         if world == 1 and not args.no_extras and timing:
-            # BASELINE configs #4 and #5, after the timed region like the diagnostic passes above: the sweep's buffers are released first
-            torch.cuda.synchronize()
-            torch.cuda.set_stream(torch.cuda.default_stream(dev))
-            del As[:], xs_[:]
-            lu.close(); plan.close()
+            # BASELINE configs #4 and #5, after the timed region: the sweep's buffers have been released
+            plan.close()
             torch.cuda.empty_cache()
             try:
                 t0x = time.perf_counter()
@@ -892,6 +543,8 @@ def main():
             except Exception as e:      # the extras must not take the headline line with them
                 out["extras_error"] = repr(e)
         print(json.dumps(out))
+    else:
+        sweep.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -147,6 +147,36 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
                        double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, int32_t slots,
                        ma_c64* X_out, int32_t* status_or_null);
 
+/* The loop behind a reusable handle (round 4): what ma_bem_solve_sweep allocates per call -- the LU plan and its streams, the
+ * `slots` systems in flight, the spare systems of the assembly-ahead (2 x 3 more matrices when they fit), the parked solutions --
+ * is allocated once for up to max_frequencies frequencies per run and reused by every ma_bem_sweep_run. The reference's driver
+ * sweeps once per source (room_simulator_bem.rs:243-256 builds the mesh once, :328-360 loops over the frequencies; a Rust caller
+ * holds the handle in the struct that holds its mesh and implements Drop with ma_bem_sweep_destroy). The plan is borrowed.
+ * ma_bem_sweep_run: arguments as ma_bem_solve_sweep; X_out_or_null = NULL leaves the solutions on the device
+ * (ma_bem_sweep_solutions_dev: row i = the i-th frequency of the last run, valid until the next run). Runs of one handle must
+ * not overlap; handles of different plans / devices are independent (one host thread per device: ma_bem_solve_sweep_multi). */
+typedef struct ma_bem_sweep ma_bem_sweep_t;
+typedef struct ma_lu_plan ma_lu_plan_t;           /* workspace for device-resident solves of size n (ma_lu_plan_create below) */
+int ma_bem_sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep_t** out);
+int ma_bem_sweep_destroy(ma_bem_sweep_t* sweep);
+int ma_bem_sweep_run(ma_bem_sweep_t* sweep, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
+                     double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
+                     ma_c64* X_out_or_null, int32_t* status_or_null);
+int ma_bem_sweep_solutions_dev(ma_bem_sweep_t* sweep, void** d_X, int32_t* count);
+/* device-to-device copy on the current device, complete on return (for callers that mix the library's device pointers with their own buffers) */
+int ma_device_copy(void* d_dst, const void* d_src, int64_t bytes, void* stream);
+/* Measurement (bench.py; no reference counterpart): with timing on, HIP events bracket the run, every piece of assembly and every
+ * big trailing update ON THE STREAM THEY RUN ON. ma_bem_sweep_last_timing, out8 = { wall seconds of the last run (entry to
+ * solutions on the host), device ms between the run's first and last event, ms summed over the assembly pieces (incident
+ * right-hand sides included), pieces, ms summed over the big trailing updates, their launches, their algorithmic flops (8 M N K
+ * each), frequencies }. ma_bem_sweep_info: slots, blocks per factorisation, rounds between two slots' starts, systems assembled
+ * ahead (1 = none), 1 if the staged pipeline runs (any pointer may be NULL). The LU plan and the stream are borrowed. */
+int ma_bem_sweep_set_timing(ma_bem_sweep_t* sweep, int enable);
+int ma_bem_sweep_last_timing(ma_bem_sweep_t* sweep, double* out8);
+int ma_bem_sweep_info(ma_bem_sweep_t* sweep, int32_t* slots, int32_t* blocks, int32_t* spacing, int32_t* systems_ahead, int32_t* staged);
+int ma_bem_sweep_lu_plan(ma_bem_sweep_t* sweep, ma_lu_plan_t** plan);
+int ma_bem_sweep_stream(ma_bem_sweep_t* sweep, void** stream);
+
 /* The same loop over the GPUs of one node (BASELINE.json configs[2]): frequency f is solved on devices[f mod ndev]
  * (ma_sweep_owner), one host thread, BEM plan, LU plan and stream per device, no collective on the data path; X_out
  * (n_freq x num_dofs) and status_or_null are indexed by f as above. A Rust caller replaces the `for freq` loop of
@@ -171,7 +201,6 @@ int ma_lu_factorize(int32_t n, const ma_c64* A_rowmajor, ma_lu_factorization_t**
 int ma_lu_factorization_solve(ma_lu_factorization_t* f, const ma_c64* b, ma_c64* x);
 int ma_lu_factorization_destroy(ma_lu_factorization_t* f);
 
-typedef struct ma_lu_plan ma_lu_plan_t;           /* workspace for device-resident solves of size n */
 int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out);
 int ma_lu_plan_destroy(ma_lu_plan_t* plan);
 /* Factor d_A in place (row-major, device) and solve for nrhs right-hand sides stored as
@@ -214,6 +243,12 @@ int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slo
 int ma_lu_plan_stage_set_group(ma_lu_plan_t* plan, int32_t group_size);
 int ma_lu_plan_stage_begin_group(ma_lu_plan_t* plan, int32_t first_slot, void* stream);
 int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);
+/* The finish in three steps, for a driver that gives the slot its next system in other buffers (ma_bem_sweep_run): _defer right after the
+ * slot's last round (the factorisation is complete on `stream`: stage_info_dev may follow; nothing is launched), _issue later (the backward
+ * substitution goes onto the slot's lane behind what the lane has been given since), _wait (`stream` waits for it; x is in the system's b). */
+int ma_lu_plan_stage_finish_defer(ma_lu_plan_t* plan, int32_t slot, void* stream);
+int ma_lu_plan_stage_finish_issue(ma_lu_plan_t* plan, int32_t slot);
+int ma_lu_plan_stage_finish_wait(ma_lu_plan_t* plan, int32_t slot, void* stream);
 /* after stage_finish: the slot's status word (0, or 1 + the column of the first zero pivot) copied to a device int on `stream` */
 int ma_lu_plan_stage_info_dev(ma_lu_plan_t* plan, int32_t slot, int32_t* d_out, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);

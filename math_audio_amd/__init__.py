@@ -84,6 +84,16 @@ def lib():
             "ma_lu_plan_solve_dev": [vp, vp, vp, i32, vp],
             "ma_lu_solve": [i32, vp, vp, vp],
             "ma_bem_solve_sweep": [vp, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
+            "ma_bem_sweep_create": [vp, i32, i32, P(vp)],
+            "ma_bem_sweep_destroy": [vp],
+            "ma_device_copy": [vp, vp, i64, vp],
+            "ma_bem_sweep_run": [vp, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, vp, vp],
+            "ma_bem_sweep_solutions_dev": [vp, P(vp), P(i32)],
+            "ma_bem_sweep_set_timing": [vp, C.c_int],
+            "ma_bem_sweep_last_timing": [vp, vp],
+            "ma_bem_sweep_info": [vp, P(i32), P(i32), P(i32), P(i32), P(i32)],
+            "ma_bem_sweep_lu_plan": [vp, P(vp)],
+            "ma_bem_sweep_stream": [vp, P(vp)],
             "ma_bem_solve_sweep_multi": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp],
             "ma_bem_solve_sweep_multi_timed": [P(ma_mesh_t), vp, i32, i32, vp, dbl, dbl, dbl, dbl, C.c_int, vp, dbl, dbl, i32, vp, vp, vp, vp, vp],
             "ma_bem_plan_assemble_multi_dev": [vp, i32, vp, vp, vp, vp, vp, vp],
@@ -1000,6 +1010,74 @@ def solve_sweep(plan, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind
     if rc not in (MA_OK, MA_ERR_SINGULAR):
         check(rc)
     return X, st
+
+
+def memcpy_dtod(d_dst, d_src, nbytes, stream=0):
+    """ma_device_copy: device-to-device copy, complete on return."""
+    check(lib().ma_device_copy(C.c_void_p(d_dst), C.c_void_p(d_src), int(nbytes), C.c_void_p(stream)))
+
+
+class BemSweep:
+    """ma_bem_sweep_t: the frequency loop (room_simulator_bem.rs:328-360) behind a reusable handle -- LU plan, streams, the systems in
+    flight, the spares of the assembly-ahead and the parked solutions are allocated once. The plan is borrowed."""
+
+    def __init__(self, plan, max_frequencies, slots=3):
+        self.plan = plan; self.n = plan.num_dofs; self.h = C.c_void_p()
+        check(lib().ma_bem_sweep_create(plan.h, int(slots), int(max_frequencies), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ma_bem_sweep_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, harmonic=1.0, tau=1.0, to_host=True):
+        """ma_bem_sweep_run: (X[n_freq, n] or None with to_host=False, status[n_freq])."""
+        f = np.ascontiguousarray(frequencies_hz, dtype=np.float64); v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)
+        X = np.empty((len(f), self.n), dtype=np.complex128) if to_host else None
+        st = np.zeros(len(f), dtype=np.int32)
+        rc = lib().ma_bem_sweep_run(self.h, len(f), _vp(f), float(speed_of_sound), float(harmonic), float(tau), float(beta_scale), int(kind), _vp(v),
+                                    amp.real, amp.imag, _vp(X) if to_host else None, _vp(st))
+        if rc not in (MA_OK, MA_ERR_SINGULAR):
+            check(rc)
+        return X, st
+
+    def solutions_dev(self):
+        """(device pointer, count): the parked solutions of the last run, row i = its i-th frequency."""
+        p = C.c_void_p(); c = C.c_int32(0)
+        check(lib().ma_bem_sweep_solutions_dev(self.h, C.byref(p), C.byref(c)))
+        return p.value, c.value
+
+    def set_timing(self, enable=True):
+        check(lib().ma_bem_sweep_set_timing(self.h, 1 if enable else 0))
+
+    def last_timing(self):
+        o = np.zeros(8)
+        check(lib().ma_bem_sweep_last_timing(self.h, _vp(o)))
+        return {"wall_s": o[0], "device_ms": o[1], "assembly_ms": o[2], "assembly_pieces": int(o[3]), "big_update_ms": o[4], "big_update_launches": int(o[5]),
+                "big_update_flops": o[6], "frequencies": int(o[7])}
+
+    def info(self):
+        v = [C.c_int32(0) for _ in range(5)]
+        check(lib().ma_bem_sweep_info(self.h, *[C.byref(t) for t in v]))
+        return {"slots": v[0].value, "blocks": v[1].value, "spacing": v[2].value, "systems_ahead": v[3].value, "staged": bool(v[4].value)}
+
+    def lu_plan(self):
+        """The handle's LU plan (borrowed: do not close it) for the diagnostics of LuPlan."""
+        p = C.c_void_p()
+        check(lib().ma_bem_sweep_lu_plan(self.h, C.byref(p)))
+        lu = LuPlan.__new__(LuPlan); lu.n = self.n; lu.h = p; lu.close = lambda: None
+        return lu
+
+    def stream(self):
+        p = C.c_void_p()
+        check(lib().ma_bem_sweep_stream(self.h, C.byref(p)))
+        return p.value
 
 
 def sweep_owner(frequency_index, ndev):

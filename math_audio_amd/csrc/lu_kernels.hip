@@ -1150,6 +1150,66 @@ __global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A
   }
 }
 
+struct LuBlockPanels { int np; int k0[8]; int nb[8]; };   // a block's panels: first columns and widths
+
+// ------------------------------------------------------------------ a whole block's interchanges in one launch (round 4)
+// The main lane's per-panel gather + scatter (2 launches per panel, 12 per block of six) as ONE launch per block: the folded lists
+// of the block's `np` panels (lists + j * lstride: [0] = m <= 2 nb, dst[], src[]) applied one after the other to the columns
+// [x0, x1) U [y0, y1) and to the nrhs right-hand sides. Columns are independent, so a workgroup owns a strip of 32 columns and walks
+// the panels on its own: per panel every moved entry of the strip is read into registers (16 per thread: 128 rows x 32 columns over
+// 256 threads), then -- after a workgroup barrier, i.e. every read before any write -- written to its destination row; the next
+// panel's reads see these writes (one CU, workgroup scope). The last workgroup takes the right-hand sides (row stride 1, one
+// "column" per right-hand side). A poisoned plan moves nothing (the folded lists of an abandoned panel are empty anyway).
+// Columns of [x0, x1) that lie inside the block receive only the interchanges of the panels to their right (P.k0[j] > column).
+template <int NT>   // 8 NT = the most list entries a panel may have: 128 (panels of <= 64 columns: 16 registers of moved entries per thread) or 256
+__global__ __launch_bounds__(256) void lu_block_row_moves_kernel(dc* __restrict__ A, int n, const int* __restrict__ lists, int lstride, LuBlockPanels P, int x0, int x1, int y0, int y1,
+                                                                 dc* __restrict__ B, int nrhs, const unsigned* __restrict__ poison) {
+  __shared__ int s_dst[2 * LU_NB_MAX], s_src[2 * LU_NB_MAX];
+  __shared__ int s_m;
+  if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) return;
+  const int tid = threadIdx.x;
+  const int nx = x1 - x0, nxy = nx + (y1 - y0);
+  const int nstrips = (nxy + 31) / 32;
+  const bool rhs = (int)blockIdx.x >= nstrips;
+  if (rhs && nrhs <= 0) return;
+  // a strip never straddles the two column ranges' seam in a way that matters: column q of the set is x0 + q or y0 + (q - nx)
+  const int q0 = 32 * (int)blockIdx.x;
+  const int col_l = tid & 31;
+  const int qc = q0 + col_l;
+  const bool col_ok = rhs ? col_l < nrhs : qc < nxy;
+  const size_t coff = rhs ? (size_t)col_l * (size_t)n : (size_t)(qc < nx ? x0 + qc : y0 + (qc - nx));
+  const size_t rstride = rhs ? 1 : (size_t)n;
+  dc* base = rhs ? B : A;
+  const bool xpart = !rhs && q0 < nx;                       // (uniform: strips are 32 columns from x0, the panels' first columns multiples of 32 from x0 -- checked by the launcher)
+  for (int j = 0; j < P.np; ++j) {
+    // inside the block a panel's interchanges go to the columns LEFT of the panel only: its own columns were permuted by the panel
+    // kernel, the block's columns right of it by the lane's step kernel
+    if (xpart && x0 + q0 >= P.k0[j]) continue;
+    const int* ls = lists + (size_t)j * lstride;
+    if (tid == 0) { int m = ls[0]; if (m < 0 || m > 8 * NT) m = 0; s_m = m; }
+    __syncthreads();
+    const int m = s_m;
+    if (m == 0) { __syncthreads(); continue; }
+    for (int i = tid; i < m; i += 256) { s_dst[i] = ls[1 + i]; s_src[i] = ls[1 + 2 * LU_NB_MAX + i]; }
+    __syncthreads();
+    dc mv[NT]; int md[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int idx = (tid >> 5) + 8 * t;
+      md[t] = -1; mv[t] = dc_make(0.0, 0.0);
+      if (idx < m && col_ok) {
+        const int sr = s_src[idx], ds = s_dst[idx];
+        if (sr >= 0 && sr < n && ds >= 0 && ds < n) { mv[t] = base[(size_t)sr * rstride + coff]; md[t] = ds; }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every read of the strip has returned ...
+    __syncthreads();                                       // ... in every thread, before the first write
+#pragma unroll
+    for (int t = 0; t < NT; ++t) if (md[t] >= 0) base[(size_t)md[t] * rstride + coff] = mv[t];
+    __syncthreads();                                       // workgroup scope: the next panel's reads see these writes
+  }
+}
+
 // ------------------------------------------------------------------ one launch between two panels of a block column (round 3)
 // For the columns [x0, x0 + ncols) right of panel (k0, nb <= 32) -- the rest of its block column: the panel's row interchanges
 // and U = L11^-1 A[k0 : k0 + nb, columns], one workgroup per strip of 32 columns: the <= 2 nb moved rows of the strip are read
@@ -1550,6 +1610,138 @@ __global__ __launch_bounds__(128, 5) void lu_trsm64_kernel(const dc* __restrict_
     load_rows(0, 1);
     if (active) solve_pair(b2r, b2i, b3r, b3i);
     store_tile(2, b2r, b2i); store_tile(3, b3r, b3i);
+  }
+}
+
+// ------------------------------------------------------------------ a whole block row of U in one launch (round 4)
+// The main lane's work on block g right of the block -- per panel j: U_j = L_jj^-1 A[p_j rows, e:n) (lu_trsm64_kernel), the
+// right-hand side's rows, and A[a_{j+1}:e, e:n) -= L[a_{j+1}:e, p_j] U_j (a K = 64 update launch), 3 launches per panel, 18 per
+// block of six -- as ONE launch: columns are independent, so a wavefront owns 16 columns of [e, n) and takes them through the block's
+// np <= 8 panels LEFT-looking: for panel i it fetches its 64 x 16 piece B_i of A12 (four accumulator tiles), subtracts
+// L[p_i rows, p_j columns] X_j for the panels j < i it has already solved (X_j comes back from memory in the accumulator layout,
+// which IS the MFMA B-operand layout; L in 64 x 32 pieces through LDS as re / im planes), solves with the inverted 32 x 32
+// diagonal blocks exactly as lu_trsm64_kernel does, and stores. Four wavefronts (64 columns) share the LDS pieces. The last
+// workgroup does the same for the right-hand sides (row stride 1): the forward substitution rides along, the rows below the
+// block get theirs from one zgemv afterwards.
+#define TB_ROWS 64
+__global__ __launch_bounds__(256) void lu_block_trsm_kernel(const dc* __restrict__ A, int lda, LuBlockPanels P, const dc* __restrict__ invd, int invd_stride,
+                                                            dc* __restrict__ X, size_t xrs, size_t xcs, int nc, int nmain,
+                                                            dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
+  __shared__ __attribute__((aligned(16))) double Lre[TB_ROWS * TM_PITCH];
+  __shared__ __attribute__((aligned(16))) double Lim[TB_ROWS * TM_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const bool extra = (int)blockIdx.x >= nmain;
+  dc* Xp = extra ? X2 : X;                                   // row 0 = the block's first row (P.k0[0])
+  const size_t rs = extra ? x2rs : xrs, cs = extra ? x2cs : xcs;
+  const int ncols = extra ? nc2 : nc;
+  const int c0 = extra ? wave * 16 : ((int)blockIdx.x * 4 + wave) * 16;
+  const bool active = c0 < ncols;
+  const int col = c0 + li;
+  const bool colok = active && col < ncols;
+  const int a0 = P.k0[0];
+  const v4d zero = (v4d){0, 0, 0, 0};
+  // tile t (16 rows) of panel q's rows, this wavefront's 16 columns: register r of lane (li, lk) = row 16 t + lk + 4 r, column li
+  auto load_tile = [&](int q, int t, v4d& br, v4d& bi) {
+    br = zero; bi = zero;
+    if (colok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + lk + 4 * r;
+        if (row < P.nb[q]) { const dc v = Xp[(size_t)(P.k0[q] - a0 + row) * rs + (size_t)col * cs]; br[r] = v.re; bi[r] = v.im; }
+      }
+    }
+  };
+  auto store_tile = [&](int q, int t, const v4d& br, const v4d& bi) {
+    if (colok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * t + lk + 4 * r;
+        if (row < P.nb[q]) Xp[(size_t)(P.k0[q] - a0 + row) * rs + (size_t)col * cs] = dc_make(br[r], bi[r]);
+      }
+    }
+  };
+  // LDS <- `rows` x 32 entries: what 0: the inverted diagonal block `blk` of panel q; 1: L[p_q rows r0.., p_j columns c0j..c0j+31] (zero beyond the panels)
+  auto load_rows = [&](int what, int q, int blk, int j, int r0, int cj, int rows) {
+    __syncthreads();
+    for (int idx = tid; idx < rows * 32; idx += 256) {
+      const int rr = idx >> 5, c = idx & 31;
+      dc v;
+      if (what == 0) v = invd[(size_t)q * invd_stride + ((size_t)blk * 32 + rr) * 32 + c];
+      else v = (r0 + rr < P.nb[q] && cj + c < P.nb[j]) ? A[(size_t)(P.k0[q] + r0 + rr) * lda + P.k0[j] + cj + c] : dc_make(0.0, 0.0);
+      Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
+    }
+    __syncthreads();
+  };
+  // T -= L[LDS rows lr0 + li, 32 columns] (Xa; Xb)
+  auto update_tile = [&](int lr0, v4d& tr, v4d& ti, const v4d& xar, const v4d& xai, const v4d& xbr, const v4d& xbi) {
+    const int lr = lr0 + li;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double ar = Lre[lr * TM_PITCH + ks * 4 + lk], ai = Lim[lr * TM_PITCH + ks * 4 + lk];
+      const double xr = (ks < 4) ? xar[ks & 3] : xbr[ks & 3], xi = (ks < 4) ? xai[ks & 3] : xbi[ks & 3];
+      tr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xr, tr, 0, 0, 0);
+      ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xi, ti, 0, 0, 0);
+      tr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, xi, tr, 0, 0, 0);
+      ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, xr, ti, 0, 0, 0);
+    }
+  };
+  // (Ba; Bb) <- D (Ba; Bb) with the unit-lower-triangular inverse D in LDS rows 0..31 (lu_trsm64_kernel's solve_pair)
+  auto solve_pair = [&](v4d& ar_, v4d& ai_, v4d& br_, v4d& bi_) {
+    v4d x0r = zero, x0i = zero, x1r = zero, x1i = zero;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double ar = Lre[(16 + li) * TM_PITCH + ks * 4 + lk], ai = Lim[(16 + li) * TM_PITCH + ks * 4 + lk];
+      const double br = (ks < 4) ? ar_[ks & 3] : br_[ks & 3], bi = (ks < 4) ? ai_[ks & 3] : bi_[ks & 3];
+      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x1r, 0, 0, 0);
+      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x1i, 0, 0, 0);
+      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x1r, 0, 0, 0);
+      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x1i, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double ar = Lre[li * TM_PITCH + ks * 4 + lk], ai = Lim[li * TM_PITCH + ks * 4 + lk];
+      const double br = ar_[ks], bi = ai_[ks];
+      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x0r, 0, 0, 0);
+      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x0i, 0, 0, 0);
+      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x0r, 0, 0, 0);
+      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x0i, 0, 0, 0);
+    }
+    ar_ = x0r; ai_ = x0i; br_ = x1r; bi_ = x1i;
+  };
+  for (int i = 0; i < P.np; ++i) {
+    v4d b0r, b0i, b1r, b1i, b2r, b2i, b3r, b3i;
+    load_tile(i, 0, b0r, b0i); load_tile(i, 1, b1r, b1i); load_tile(i, 2, b2r, b2i); load_tile(i, 3, b3r, b3i);
+    const int nti = (P.nb[i] + 15) >> 4;
+    for (int j = 0; j < i; ++j) {
+      v4d x0r, x0i, x1r, x1i;
+#pragma unroll 1
+      for (int cb = 0; cb < 2; ++cb) {
+        if (32 * cb >= P.nb[j]) break;                     // (uniform)
+        // the solved rows of panel j came back from this wavefront's own stores: same lanes, same addresses
+        load_tile(j, 2 * cb, x0r, x0i); load_tile(j, 2 * cb + 1, x1r, x1i);
+        load_rows(1, i, 0, j, 0, 32 * cb, TB_ROWS);
+        if (active) {
+          update_tile(0, b0r, b0i, x0r, x0i, x1r, x1i);
+          if (nti > 1) update_tile(16, b1r, b1i, x0r, x0i, x1r, x1i);
+          if (nti > 2) update_tile(32, b2r, b2i, x0r, x0i, x1r, x1i);
+          if (nti > 3) update_tile(48, b3r, b3i, x0r, x0i, x1r, x1i);
+        }
+      }
+    }
+    load_rows(0, i, 0, 0, 0, 0, 32);
+    if (active) solve_pair(b0r, b0i, b1r, b1i);
+    if (P.nb[i] > 32) {
+      load_rows(1, i, 0, i, 32, 0, 32);                    // L10 of panel i: rows 32.., columns 0..31
+      if (active) {
+        update_tile(0, b2r, b2i, b0r, b0i, b1r, b1i);
+        if (nti > 3) update_tile(16, b3r, b3i, b0r, b0i, b1r, b1i);
+      }
+      load_rows(0, i, 1, 0, 0, 0, 32);
+      if (active) solve_pair(b2r, b2i, b3r, b3i);
+    }
+    store_tile(i, 0, b0r, b0i); store_tile(i, 1, b1r, b1i); store_tile(i, 2, b2r, b2i); store_tile(i, 3, b3r, b3i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next panels read these rows back
   }
 }
 
@@ -2139,16 +2331,25 @@ int lu_panel_configure() {
 namespace {
 constexpr int kSeqRing = 256;                          // launches remembered per device
 struct PanelLaunch { hipEvent_t ev = nullptr; hipStream_t st = nullptr; int nblk = 0; size_t lds = 0; int regs = 0; int ncu = 0; bool used = false; };
-struct PanelSequencer {
+// Locking rule: ONE mutex per device guards that device's ring and count (host threads driving different devices never meet:
+// ma_bem_solve_sweep_multi runs a thread per device, each launching ~300 panels per frequency); it is held from admit() to
+// commit() -- admission and the launch it admits are one step for the other threads of the SAME device -- but never across a
+// host wait: when the host is a whole ring ahead of the device, admit() drops the lock, waits for the old launch's event and
+// looks again. The kernels' register counts and the occupancy checks (process-wide facts) sit behind a small mutex of their own.
+struct DeviceSequencer {
   std::mutex mu;
-  PanelLaunch ring[16][kSeqRing];
-  bool made[16] = {};
-  unsigned long long count[16] = {};
+  PanelLaunch ring[kSeqRing];
+  bool made = false;
+  unsigned long long count = 0;
+};
+DeviceSequencer g_seq_dev[16];
+struct KernelFacts {
+  std::mutex mu;
   int regs[3] = {0, 0, 0};   // vector registers per lane of lu_panel_kernel, lu_panel_wave_kernel, lu_panel_reg_kernel
   int occ_checked_lds = 0;
   bool occ_checked_reg = false;
 };
-PanelSequencer g_seq;
+KernelFacts g_seq;
 constexpr size_t kLdsPerCu = 160 * 1024;
 }  // namespace
 
@@ -2197,14 +2398,15 @@ int SpinLaunch::admit(hipStream_t st_, int nblk_, size_t lds_, int regs_, int nc
     MA_REQUIRE(p >= 1 && (long long)nblk_ <= (long long)p * ncu_, MA_ERR_UNSUPPORTED,
                "a spinning grid of %d workgroups (%zu B LDS, %d registers) cannot be co-resident on %d CUs (%d per CU)", nblk_, lds_, regs_, ncu_, p);
   }
-  g_seq.mu.lock(); locked = true;
+  DeviceSequencer& D = g_seq_dev[dev_];
+  D.mu.lock(); locked = true;
   dev = dev_; st = st_; nblk = nblk_; lds = lds_ ? lds_ : 1; regs = regs_; ncu = ncu_;
-  if (!g_seq.made[dev]) {
+  if (!D.made) {
     for (int i = 0; i < kSeqRing; ++i) {
-      const hipError_t e = hipEventCreateWithFlags(&g_seq.ring[dev][i].ev, hipEventDisableTiming);
+      const hipError_t e = hipEventCreateWithFlags(&D.ring[i].ev, hipEventDisableTiming);
       if (e != hipSuccess) { set_error("sequencer events: %s", hipGetErrorString(e)); abandon(); return MA_ERR_HIP; }
     }
-    g_seq.made[dev] = true;
+    D.made = true;
   }
   // Admission. Streams are in order, so at most ONE spinning kernel per stream runs at any time, and what may run beside this
   // launch is, per other stream, one of that stream's earlier launches (later launches do their own admission and count this
@@ -2216,16 +2418,22 @@ int SpinLaunch::admit(hipStream_t st_, int nblk_, size_t lds_, int regs_, int nc
   // above applies to it. With CU-masked streams in the window the CUs counted are those of the SMALLEST set any member may use
   // (grids on a mask share its CUs with every unmasked grid): a grid that needs more than that runs on its own, which the check
   // above has already allowed.
-  const unsigned long long i = g_seq.count[dev];
-  PanelLaunch* ring = g_seq.ring[dev];
-  PanelLaunch& me = ring[i % kSeqRing];
+  PanelLaunch* ring = D.ring;
   // an event counts as pending only while the runtime says "not ready": anything else (success, or an error because the
   // stream it was recorded on has been destroyed since -- plans come and go, the table is per device) means its work is over
   auto pending = [](hipEvent_t ev) { const hipError_t q = hipEventQuery(ev); (void)hipGetLastError(); return q == hipErrorNotReady; };
-  if (me.used && pending(me.ev)) {                            // launch i - 256 not finished yet: the host is that far ahead
-    (void)hipEventSynchronize(me.ev);
+  // launch i - 256 not finished yet: the host is that far ahead of the device. The wait happens WITHOUT the lock (the ring's
+  // events live as long as the process; another thread of this device may launch meanwhile, so the slot is looked up again)
+  for (;;) {
+    PanelLaunch& slot = ring[D.count % kSeqRing];
+    if (!(slot.used && pending(slot.ev))) break;
+    const hipEvent_t ev = slot.ev;
+    D.mu.unlock();
+    (void)hipEventSynchronize(ev);
     (void)hipGetLastError();
+    D.mu.lock();
   }
+  const unsigned long long i = D.count;
   const unsigned long long oldest = i >= (unsigned long long)(kSeqRing - 1) ? i - (kSeqRing - 1) : 0ull;
   struct Lane { hipStream_t st; unsigned long long latest; long long nblk; size_t lds; int regs; int ncu; };
   Lane lanes[16]; int nlanes = 0;
@@ -2262,15 +2470,16 @@ int SpinLaunch::admit(hipStream_t st_, int nblk_, size_t lds_, int regs_, int nc
 }
 int SpinLaunch::commit() {
   if (!locked) return MA_OK;
-  const unsigned long long i = g_seq.count[dev];
-  PanelLaunch& me = g_seq.ring[dev][i % kSeqRing];
+  DeviceSequencer& D = g_seq_dev[dev];
+  const unsigned long long i = D.count;
+  PanelLaunch& me = D.ring[i % kSeqRing];
   const hipError_t e = hipEventRecord(me.ev, st);
-  if (e == hipSuccess) { me.nblk = nblk; me.lds = lds; me.regs = regs; me.ncu = ncu; me.st = st; me.used = true; g_seq.count[dev] = i + 1; }
+  if (e == hipSuccess) { me.nblk = nblk; me.lds = lds; me.regs = regs; me.ncu = ncu; me.st = st; me.used = true; D.count = i + 1; }
   else set_error("hipEventRecord failed: %s", hipGetErrorString(e));
   abandon();
   return e == hipSuccess ? MA_OK : MA_ERR_HIP;
 }
-void SpinLaunch::abandon() { if (locked) { locked = false; g_seq.mu.unlock(); } }
+void SpinLaunch::abandon() { if (locked) { locked = false; g_seq_dev[dev].mu.unlock(); } }
 SpinLaunch::~SpinLaunch() { abandon(); }
 
 // device-wide "a spinning kernel gave up a wait" word: every such kernel raises it beside its own status word, every Krylov driver
@@ -2361,9 +2570,10 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
 // a stream is about to be destroyed (its work is over): the sequencer must not wait on, or query, events recorded on it
 void lu_panel_forget_stream(int dev, hipStream_t st) {
   if (dev < 0 || dev >= 16 || !st) return;
-  std::lock_guard<std::mutex> lock(g_seq.mu);
-  if (!g_seq.made[dev]) return;
-  for (int i = 0; i < kSeqRing; ++i) if (g_seq.ring[dev][i].used && g_seq.ring[dev][i].st == st) { g_seq.ring[dev][i].used = false; g_seq.ring[dev][i].st = nullptr; }
+  DeviceSequencer& D = g_seq_dev[dev];
+  std::lock_guard<std::mutex> lock(D.mu);
+  if (!D.made) return;
+  for (int i = 0; i < kSeqRing; ++i) if (D.ring[i].used && D.ring[i].st == st) { D.ring[i].used = false; D.ring[i].st = nullptr; }
 }
 
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
@@ -2421,6 +2631,25 @@ int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int t
   return MA_OK;
 }
 
+// the folded lists of a block's np panels (lists + j * lstride) applied in order to the columns [x0, x1) U [y0, y1) and the right-hand
+// sides: one launch (lu_block_row_moves_kernel). Panel j's list goes to a column c of [x0, x1) only if c < k0s[j].
+int lu_launch_block_row_moves(c64* A, int n, const int* lists, int lstride, int np, const int* k0s, const int* nbs, int x0, int x1, int y0, int y1, c64* B, int nrhs, const unsigned* poison, hipStream_t st) {
+  const int ncol = (x1 - x0) + (y1 - y0);
+  if (np <= 0 || (ncol <= 0 && nrhs <= 0)) return MA_OK;
+  MA_REQUIRE(np <= 8 && nrhs <= 32 && x0 <= x1 && y0 <= y1, MA_ERR_INVALID, "block row moves: bad shape");
+  LuBlockPanels P;
+  P.np = np;
+  int nb_max = 1;
+  for (int q = 0; q < 8; ++q) { P.k0[q] = q < np ? k0s[q] : 0; P.nb[q] = q < np ? nbs[q] : 0; if (q < np && nbs[q] > nb_max) nb_max = nbs[q]; }
+  for (int q = 0; q < np; ++q) MA_REQUIRE(nbs[q] >= 1 && nbs[q] <= LU_NB_MAX && (k0s[q] - x0) % 32 == 0, MA_ERR_INVALID, "block row moves: panel %d (%d columns from %d)", q, nbs[q], k0s[q]);
+  MA_REQUIRE((x1 - x0) % 32 == 0 || y1 == y0, MA_ERR_INVALID, "block row moves: the left range must be whole strips");
+  const int grid = (ncol + 31) / 32 + (nrhs > 0 ? 1 : 0);
+  if (nb_max <= 64) hipLaunchKernelGGL(lu_block_row_moves_kernel<16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, lists, lstride, P, x0, x1, y0, y1, reinterpret_cast<dc*>(B), nrhs, poison);
+  else hipLaunchKernelGGL(lu_block_row_moves_kernel<32>, dim3(grid), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, lists, lstride, P, x0, x1, y0, y1, reinterpret_cast<dc*>(B), nrhs, poison);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
                     c64* invd, unsigned* poison, hipStream_t st) {
   int rc = lu_launch_perm(A, n, k0, nb, ipiv, lists, invd, poison, st);
@@ -2463,6 +2692,23 @@ int lu_launch_lane_step2(c64* A, int n, int k0, int nb, const int* lists1, const
   return MA_OK;
 }
 
+// U12 of a whole block (np <= 8 panels of <= 64 columns each, first columns k0s[], widths nbs[]) on the columns X (row 0 = the block's
+// first row) and the nrhs right-hand sides: in-block updates included (lu_block_trsm_kernel). invd: the panels' inverted diagonal blocks,
+// invd_stride entries apart.
+int lu_launch_block_trsm(const c64* A, int n, int np, const int* k0s, const int* nbs, const c64* invd, int invd_stride, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st) {
+  if (np <= 0 || (ncols <= 0 && nrhs <= 0)) return MA_OK;
+  MA_REQUIRE(np <= 8 && nrhs <= 32, MA_ERR_DIM, "block trsm: %d panels / %d right-hand sides beyond the kernel's limits", np, nrhs);
+  LuBlockPanels P;
+  P.np = np;
+  for (int q = 0; q < 8; ++q) { P.k0[q] = q < np ? k0s[q] : 0; P.nb[q] = q < np ? nbs[q] : 0; }
+  for (int q = 0; q < np; ++q) MA_REQUIRE(nbs[q] >= 1 && nbs[q] <= 64 && (q == 0 || k0s[q] == k0s[q - 1] + nbs[q - 1]), MA_ERR_DIM, "block trsm: panel %d (%d columns from %d)", q, nbs[q], k0s[q]);
+  const int nmain = ncols > 0 ? (ncols + 63) / 64 : 0;
+  hipLaunchKernelGGL(lu_block_trsm_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(256), 0, st, reinterpret_cast<const dc*>(A), n, P, reinterpret_cast<const dc*>(invd), invd_stride,
+                     reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 // nrhs vectors b_r = B + r*ldb (nb entries each): b_r <- T^-1 b_r
 int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st) {
   if (nrhs <= 0 || nb <= 0) return MA_OK;
@@ -2472,12 +2718,24 @@ int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb
   return MA_OK;
 }
 
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big) {
+ZgemmMode zgemm_mode_from_env() {
+  ZgemmMode m;
+  if (const char* e = getenv("MA_ZGEMM_DMA")) m.dma = atoi(e);
+  if (const char* e = getenv("MA_ZGEMM_TILE_ORDER")) m.tile_order = atoi(e) != 0;
+  if (const char* e = getenv("MA_ZGEMM_XCD_TILES")) m.xcd_min_tiles = atoi(e);
+  if (const char* e = getenv("MA_ZGEMM_XCD_PERSIST")) m.persist = atoi(e) != 0;
+  return m;
+}
+
+// `mode`: which kernel family runs the update. A plan resolves the switches ONCE, when it is created, and hands the same mode to
+// every launch of its factorisations (the bitwise guarantees between schedules assume one family per factorisation, and getenv
+// per launch raced with the tests' setenv under several host threads); NULL = the process-wide mode, read at its first use.
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big, const ZgemmMode* mode) {
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
-  const char* e_draw = getenv("MA_ZGEMM_XCD_TILES");                         // an explicit request for the drawn-tile kernel wins (read per launch: the tests switch both)
-  if (use_3m && K % ZD_BK == 0 && !(e_draw && atoi(e_draw) > 0)) {
-    const char* e_dma = getenv("MA_ZGEMM_DMA");
-    const int dma_mode = e_dma ? atoi(e_dma) : MA_ZGEMM_DMA_DEFAULT;
+  static const ZgemmMode process_mode = zgemm_mode_from_env();
+  const ZgemmMode& zm = mode ? *mode : process_mode;
+  if (use_3m && K % ZD_BK == 0 && zm.xcd_min_tiles <= 0) {               // an explicit request for the drawn-tile kernel wins
+    const int dma_mode = zm.dma;
     if (dma_mode == 1 || dma_mode == 2) {
       // more than 64 KB of LDS per workgroup: the limit is raised per function AND per device (a process may drive several)
       {
@@ -2495,8 +2753,7 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
         }
       }
       // big updates: a one-dimensional grid, tiles dealt out XCD by XCD in blocks of 4 x 4 (see the kernel); MA_ZGEMM_TILE_ORDER=0: plain
-      const char* e_ord = getenv("MA_ZGEMM_TILE_ORDER");
-      const bool xcd_order = (e_ord ? atoi(e_ord) != 0 : true) && (long long)((N + 127) / 128) * ((M + 63) / 64) >= 512;
+      const bool xcd_order = zm.tile_order && (long long)((N + 127) / 128) * ((M + 63) / 64) >= 512;
       const int T22 = ((N + 127) / 128) * ((M + 63) / 64);
       const dim3 g22 = xcd_order ? dim3(8 * ((T22 + 7) / 8), 1) : dim3((N + 127) / 128, (M + 63) / 64);
       if (dma_mode == 1 && big) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, true>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
@@ -2513,8 +2770,7 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
     dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
     // large updates draw their tiles XCD by XCD (see the kernel): a ring of counter blocks per device, one block per launch,
     // zeroed at allocation and again by the last workgroup of the launch that used it
-    const char* e_xcd = getenv("MA_ZGEMM_XCD_TILES");                       // read per launch: the tests switch it
-    const int xcd_min_tiles = e_xcd ? atoi(e_xcd) : 0;                      // off unless asked for: it halves the fabric traffic and buys no time
+    const int xcd_min_tiles = zm.xcd_min_tiles;                             // off unless asked for: it halves the fabric traffic and buys no time
     unsigned* ctr = nullptr;
     unsigned grid_draw = 0;
     if (xcd_min_tiles > 0 && (long long)g3.x * g3.y >= xcd_min_tiles) {
@@ -2538,8 +2794,7 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
         grid_draw = (unsigned)std::min<long long>((long long)g3.x * g3.y, 2LL * ncu[dev]);
       }
     }
-    const char* e_per = getenv("MA_ZGEMM_XCD_PERSIST");
-    const bool one_tile = !(e_per && atoi(e_per) != 0);
+    const bool one_tile = !zm.persist;
     if (ctr && one_tile) hipLaunchKernelGGL(zgemm3m_sub_drawn_kernel, dim3(g3.x * g3.y), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
                                 reinterpret_cast<dc*>(C), ldc, ctr, 1);
     else if (ctr) hipLaunchKernelGGL(zgemm3m_sub_drawn_kernel, dim3(grid_draw), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,

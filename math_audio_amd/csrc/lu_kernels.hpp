@@ -56,12 +56,18 @@ int lu_panel_slots_per_cu(size_t lds, int regs);
 int lu_panel_regs(int kind);   /* 0 lu_panel_kernel, 1 lu_panel_wave_kernel, 2 lu_panel_reg_kernel */
 int lu_panel_admissible(int nb, int rpb, int nblk, int ncu);
 int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs, hipStream_t st);
+int lu_launch_block_row_moves(c64* A, int n, const int* lists, int lstride, int np, const int* k0s, const int* nbs, int x0, int x1, int y0, int y1, c64* B, int nrhs, const unsigned* poison, hipStream_t st);
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
                     c64* invd, unsigned* poison, hipStream_t st);
 int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st);
+int lu_launch_block_trsm(const c64* A, int n, int np, const int* k0s, const int* nbs, const c64* invd, int invd_stride, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st);
 int lu_trsm_configure();
 int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st);
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big = false);   // big: the trailing update on the caller's stream (its own kernel instantiation)
+// which kernel family runs C -= A B (MA_ZGEMM_DMA / _TILE_ORDER / _XCD_TILES / _XCD_PERSIST): resolved once per plan, never per launch
+struct ZgemmMode { int dma = 1; bool tile_order = true; int xcd_min_tiles = 0; bool persist = false; };
+ZgemmMode zgemm_mode_from_env();
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big = false,
+                        const ZgemmMode* mode = nullptr);   // big: the trailing update on the caller's stream (its own kernel instantiation); mode NULL: the process-wide one
 int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st);
 int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st);
 

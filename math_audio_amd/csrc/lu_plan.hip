@@ -50,6 +50,10 @@ struct ma_lu_plan {
   c64* cur_A[LU_BATCH_MAX] = {}; c64* cur_B[LU_BATCH_MAX] = {}; int cur_nrhs = 0;
   hipEvent_t ev_prep[LU_BATCH_MAX] = {};
   int stage_first_mark = -1;
+  // deferred finish (ma_lu_plan_stage_finish_defer / _issue / _wait): the system a slot has factored, whose backward substitution is
+  // issued later -- behind the first block columns of the slot's NEXT system, where the lane has slack -- and waited for later still
+  c64* fin_A[LU_BATCH_MAX] = {}; c64* fin_B[LU_BATCH_MAX] = {}; int fin_nrhs[LU_BATCH_MAX] = {}; int fin_state[LU_BATCH_MAX] = {};   // 0 none, 1 deferred, 2 issued
+  hipEvent_t ev_fin[LU_BATCH_MAX] = {};
   hipEvent_t ev_start = nullptr, ev_panel[LU_BATCH_MAX] = {}, ev_narrow[LU_BATCH_MAX] = {}, ev_mid[LU_BATCH_MAX] = {}, ev_big[LU_BATCH_MAX] = {};
   int ensure_batch(int nmat);
   int nrhs_max = 4;
@@ -70,6 +74,9 @@ struct ma_lu_plan {
   int midlane = 1;                // 1: on the system's look-ahead stream, 2: on a third stream per system, 0: on the caller's stream
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
   int want_nb = 64;               // panel width (MA_LU_NB): 64 columns keep two systems' panels co-resident from the first column of a 10k system
+  bool block_step = false;        // round 4: the main lane's per-panel launches of a block (12 gathers / scatters, 6 trsm, 6 zgemv, 5 in-block updates) as
+                                  // lu_block_row_moves_kernel + lu_block_trsm_kernel + one zgemv (MA_LU_BLOCK_STEP; default with the register pair panels)
+  ZgemmMode zmode;                // the update kernel family, resolved from the MA_ZGEMM_* switches when the plan is created
   bool use_3m = true;             // 3-product complex zgemm in the trailing update (MA_ZGEMM_3M=0 selects the 4-product form)
   bool rpb_env = false;           // MA_LU_RPB given
   int rpb_cap = 44;               // rows per panel workgroup when MA_LU_RPB is given
@@ -206,6 +213,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   if (!rc) rc = lu_trsm_configure();
   if (const char* e1 = getenv("MA_LU_NB")) { int v = atoi(e1); if (v >= 16 && v <= LU_NB_MAX && v % 16 == 0) P->want_nb = v; }
   if (const char* e0 = getenv("MA_ZGEMM_3M")) P->use_3m = atoi(e0) != 0;
+  P->zmode = zgemm_mode_from_env();
   if (const char* e2 = getenv("MA_LU_LOOKAHEAD")) P->lookahead = atoi(e2) != 0;
   if (const char* e6 = getenv("MA_LU_KB")) { int v = atoi(e6); if (v >= 1 && v <= LU_KB_MAX) { P->kb = v; P->kb_env = true; } }
   if (const char* e5 = getenv("MA_LU_PANEL_OVERLAP")) P->panel_overlap = atoi(e5) != 0;
@@ -238,6 +246,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (!P->reg_panel) P->pan_mask = 0;                   // the LDS-resident panel kernel's grid does not fit a small CU set: only the big updates are masked
     if (!P->reg_panel && !getenv("MA_LU_CU_SPLIT")) P->cu_split = 0;   // the default split comes with the register panels only
     P->reg_panel0 = P->reg_panel; P->reg_pair0 = P->reg_pair;
+    P->block_step = P->reg_panel && P->reg_pair;
+    if (const char* eb = getenv("MA_LU_BLOCK_STEP")) P->block_step = atoi(eb) != 0;
   }
   for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
   if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
@@ -269,6 +279,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_big[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_prep[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_lane[i], hipEventDisableTiming);
+    for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_fin[i], hipEventDisableTiming);
     if (e4 == hipSuccess) e4 = hipEventCreateWithFlags(&P->ev_bp, hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_pan[i], hipEventDisableTiming);
     for (int i = 0; i < LU_BATCH_MAX && e4 == hipSuccess; ++i) e4 = hipEventCreateWithFlags(&P->ev_chain[i], hipEventDisableTiming);
@@ -312,6 +323,7 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (P->ev_start) (void)hipEventDestroy(P->ev_start);
   if (P->ev_bp) (void)hipEventDestroy(P->ev_bp);
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->ev_lane[i]) (void)hipEventDestroy(P->ev_lane[i]);
+  for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->ev_fin[i]) (void)hipEventDestroy(P->ev_fin[i]);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->ev_panel[i]) (void)hipEventDestroy(P->ev_panel[i]); if (P->ev_narrow[i]) (void)hipEventDestroy(P->ev_narrow[i]);
     if (P->ev_prep[i]) (void)hipEventDestroy(P->ev_prep[i]); if (P->ev_mid[i]) (void)hipEventDestroy(P->ev_mid[i]); if (P->ev_big[i]) (void)hipEventDestroy(P->ev_big[i]); if (P->mid_streams[i]) (void)hipStreamDestroy(P->mid_streams[i]); }
   for (int i = 0; i < LU_BATCH_MAX; ++i) if (P->panel_streams[i]) (void)hipStreamDestroy(P->panel_streams[i]);
@@ -407,7 +419,7 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     if (rc || h2 <= 0) return rc;
     const int a1 = k0 + h1;
     if ((rc = lu_launch_lane_step(A, n, k0, h1, P->d_half_lists[m], a1, h2, P->d_half_invd[m], P->pws.timeout, st))) return rc;
-    if ((rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m))) return rc;
+    if ((rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m, false, &P->zmode))) return rc;
     // (the right half's interchanges on the LEFT half's columns -- part of the interchange itself inside a 64-column panel kernel --
     // are the first job of lu_lane_step2_kernel, which every caller launches next)
     return lu_launch_panel_reg(A, n, a1, h2, (n - a1 + 255) / 256, cus, ws, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, false, st, P->d_half_l10[m], k0);
@@ -430,6 +442,26 @@ static int effective_kb(const ma_lu_plan* P, const std::vector<int>& nbs) {
   kb = std::max(1, std::min(kb, LU_KB_MAX));
   while (kb > 1 && (kb - 1) * nbmax > LU_LANE_TSTRIDE) --kb;
   return kb;
+}
+
+// The main lane's work on block [q0, q1) right of the block and on the right-hand sides, as three launches (round 4): every panel's
+// interchanges on the columns left of it and right of the block, U12 of the whole block row with its in-block updates and the
+// right-hand sides' forward substitution, and the right-hand sides' rows below the block. Only for panels of <= 64 columns.
+static bool block_step_ok(const ma_lu_plan* P, const std::vector<int>& nbs, int q0, int q1) {
+  if (!P->block_step || q1 - q0 > 8 || q1 <= q0) return false;
+  for (int q = q0; q < q1; ++q) if (nbs[q] > 64) return false;
+  return true;
+}
+static int block_main(ma_lu_plan* P, int m, c64* A, c64* B, int nrhs, int g, const std::vector<int>& k0s, const std::vector<int>& nbs, int q0, int q1, int e, hipStream_t sm) {
+  const int n = P->n, np = q1 - q0, a0 = k0s[q0], nright = n - e;
+  const int* lists = P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX) * LU_LISTS_LEN;
+  const c64* invd = P->d_invd[m] + (size_t)((g & 1) * LU_KB_MAX) * LU_NB_MAX * 32;
+  int rc = lu_launch_block_row_moves(A, n, lists, LU_LISTS_LEN, np, &k0s[q0], &nbs[q0], 0, k0s[q1 - 1], e, n, B, nrhs, P->pws.timeout, sm);
+  if (rc) return rc;
+  if ((rc = lu_launch_block_trsm(A, n, np, &k0s[q0], &nbs[q0], invd, LU_NB_MAX * 32, A + (size_t)a0 * n + e, (size_t)n, nright, nrhs ? B + a0 : nullptr, (size_t)n, nrhs, sm))) return rc;
+  for (int r = 0; r < nrhs && nright > 0; ++r)
+    if ((rc = lu_launch_zgemv_sub(nright, e - a0, A + (size_t)e * n + a0, (size_t)n, B + (size_t)r * n + a0, B + (size_t)r * n + e, sm))) return rc;
+  return MA_OK;
 }
 
 // Factor the matrices in place and solve for nrhs right-hand sides each (d_B[nrhs][n]); everything asynchronous.
@@ -489,7 +521,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
     P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;   // every launch is timed: phase 3 (main lane) or 5 (look-ahead lanes)
     if (big_) { P->n_big_launch++; P->big_flops += 8.0 * M_ * (double)N_ * K_; }
-    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_);
+    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_, &P->zmode);
   };
 
   // the look-ahead lane: factor the block column of block g of system m
@@ -591,6 +623,12 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
       if (la) MA_HIP(hipStreamWaitEvent(sm, P->ev_panel[m], 0));
       if (split && g > 0) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));     // block g-1's big update of this system
       MA_MARK(t0, sm);
+      const bool bstep = !bp && block_step_ok(P, nbs, blk_first(g), blk_last(g));
+      if (bstep) {
+        if ((rc = block_main(P, m, A, B, nrhs, g, k0s, nbs, blk_first(g), blk_last(g), e, sm))) return rc;
+        MA_MARK(tb, sm);
+        interval(P, t0, tb, 2);
+      } else {
       for (int q = blk_first(g); q < blk_last(g); ++q)
         if ((rc = lu_launch_row_moves(A, n, nbs[q], P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs, sm))) return rc;
       MA_MARK(t1, sm);
@@ -610,6 +648,7 @@ static int factor_solve_batch(ma_lu_plan* P, int nmat, c64* const* As, c64* cons
         if (a1 < e && (rc = gemm(e - a1, nright, nb, A + (size_t)a1 * n + k0, A + (size_t)k0 * n + e, A + (size_t)a1 * n + e, sm))) return rc;
         MA_MARK(u3, sm);
         interval(P, u2, u3, split ? 5 : 3);
+      }
       }
       MA_MARK(t3, sm);
       const bool narrow = la && nright > 0 && g + 1 < G;
@@ -715,7 +754,7 @@ struct Stage {
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
     P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;
     if (big_) { P->n_big_launch++; P->big_flops += 8.0 * M_ * (double)N_ * K_; }
-    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_);
+    return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_, &P->zmode);
   }
   // the look-ahead lane: factor the block column of block g of slot m
   int lane(int m, int g) {
@@ -797,6 +836,11 @@ struct Stage {
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
     if (g > 0 && !tail(g - 1)) MA_HIP(hipStreamWaitEvent(sm, P->ev_big[m], 0));   // block g-1's big update of this slot
     MA_MARKD(t0, sm);
+    if (P->stage_group < 2 && block_step_ok(P, nbs, blk_first(g), blk_last(g))) {
+      if ((rc = block_main(P, m, A, B, nrhs, g, k0s, nbs, blk_first(g), blk_last(g), e, sm))) return rc;
+      MA_MARKD(tb, sm);
+      interval(P, t0, tb, 2);
+    } else {
     for (int q = blk_first(g); q < blk_last(g); ++q)
       if ((rc = lu_launch_row_moves(A, n, nbs[q], P->d_lists[m] + (size_t)((g & 1) * LU_KB_MAX + q - blk_first(g)) * LU_LISTS_LEN, P->d_tmp[m], tstride, 0, k0s[q], e, n, B, nrhs, sm))) return rc;
     MA_MARKD(t1, sm);
@@ -818,6 +862,7 @@ struct Stage {
         MA_MARK(v1, sm);
         interval(P, v0, v1, 5);
       }
+    }
     }
     MA_MARK(t3, sm);
     const bool narrow = nright > 0 && g + 1 < G;
@@ -850,24 +895,32 @@ struct Stage {
     MA_HIP(hipEventRecord(P->ev_big[m], bs));
     return MA_OK;
   }
-  int backsub(int m) {
-    c64* A = P->cur_A[m]; c64* B = P->cur_B[m]; hipStream_t sb = lane_stream(m);
+  // backward substitution of the system (A, B) that slot m has factored, on the slot's lane stream
+  int backsub_issue(int m, c64* A, c64* B, int nrhs_) {
+    hipStream_t sb = lane_stream(m);
     MA_MARKD(t7, sb);
-    for (int q = Q - 1; q >= 0 && nrhs > 0; --q) {
+    for (int q = Q - 1; q >= 0 && nrhs_ > 0; --q) {
       const int k0 = k0s[q], nb = nbs[q];
-      if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs, sb))) return rc;
-      for (int r = 0; r < nrhs && k0 > 0; ++r)
+      if ((rc = lu_launch_trsv(true, A + (size_t)k0 * n + k0, n, nb, B + k0, (size_t)n, nrhs_, sb))) return rc;
+      for (int r = 0; r < nrhs_ && k0 > 0; ++r)
         if ((rc = lu_launch_zgemv_sub(k0, nb, A + k0, (size_t)n, B + (size_t)r * n + k0, B + (size_t)r * n, sb))) return rc;
     }
     MA_MARKD(t8, sb);
     interval(P, t7, t8, 4);
-    MA_HIP(hipEventRecord(P->ev_panel[m], sb));
-    MA_HIP(hipStreamWaitEvent(st, P->ev_panel[m], 0));
+    return MA_OK;
+  }
+  int backsub_end(int m, hipEvent_t ev) {                  // `st` waits for what was recorded on the lane; the run's last mark
+    MA_HIP(hipStreamWaitEvent(st, ev, 0));
     MA_MARK(e_end, st);
     interval(P, P->stage_first_mark, e_end, 6);
     P->ev_last = e_end;
     if (P->timing) P->ev_valid = true;
     return MA_OK;
+  }
+  int backsub(int m) {
+    if ((rc = backsub_issue(m, P->cur_A[m], P->cur_B[m], nrhs))) return rc;
+    MA_HIP(hipEventRecord(P->ev_panel[m], lane_stream(m)));
+    return backsub_end(m, P->ev_panel[m]);
   }
 };
 }  // namespace
@@ -888,6 +941,7 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
   int rc;
   P->ev_used = 0; P->iv.clear(); P->n_gemm_launch = 0; P->gemm_flops = 0.0; P->gemm_cbytes = 0.0; P->n_big_launch = 0; P->big_flops = 0.0; P->ev_valid = false; P->last_batch = 0;
   P->last_bp_nsys = 0;
+  for (int i = 0; i < LU_BATCH_MAX; ++i) P->fin_state[i] = 0;
   MA_HIP(hipMemsetAsync(P->pws.info, 0, 64, st));
   MA_MARK(e0, st);
   P->stage_first_mark = e0;
@@ -1026,6 +1080,38 @@ int ma_lu_plan_stage_finish(ma_lu_plan_t* P, int32_t slot, void* stream) {
   MA_HIP(hipSetDevice(P->device));
   Stage S(P, (hipStream_t)stream);
   return S.backsub(slot);
+}
+// The finish in three steps, for a driver that hands the slot its next system in OTHER buffers (ma_bem_sweep_run swaps in a spare):
+// _defer after the slot's last round: the factorisation of the slot's system is complete on `stream` (its status word may be copied),
+// nothing is launched; _issue: the backward substitution goes onto the slot's lane stream behind whatever the lane has been given
+// since -- the first block columns of the next system, after which the lane waits for that system's largest update anyway;
+// _wait: `stream` waits for it (x is in the system's b). The 2 x 157 short launches of a 10 000-row backward substitution (6 ms on
+// the lane) thus leave the path between a slot's last block and its next system's first panels.
+int ma_lu_plan_stage_finish_defer(ma_lu_plan_t* P, int32_t slot, void* stream) {
+  MA_REQUIRE(P && slot >= 0 && slot < LU_BATCH_MAX && P->cur_A[slot], MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(P->stage_group < 2, MA_ERR_UNSUPPORTED, "deferred finish with slot groups");
+  MA_REQUIRE(P->fin_state[slot] == 0, MA_ERR_INVALID, "slot %d already has a deferred finish", slot);
+  MA_HIP(hipSetDevice(P->device));
+  P->fin_A[slot] = P->cur_A[slot]; P->fin_B[slot] = P->cur_B[slot]; P->fin_nrhs[slot] = P->cur_nrhs; P->fin_state[slot] = 1;
+  MA_HIP(hipStreamWaitEvent((hipStream_t)stream, P->ev_mid[slot], 0));      // the last block's work on the lane: every panel of the system is done
+  return MA_OK;
+}
+int ma_lu_plan_stage_finish_issue(ma_lu_plan_t* P, int32_t slot) {
+  MA_REQUIRE(P && slot >= 0 && slot < LU_BATCH_MAX && P->fin_state[slot] == 1, MA_ERR_INVALID, "slot %d has no deferred finish to issue", slot);
+  MA_HIP(hipSetDevice(P->device));
+  Stage S(P, nullptr);
+  int rc = S.backsub_issue(slot, P->fin_A[slot], P->fin_B[slot], P->fin_nrhs[slot]);
+  if (rc) return rc;
+  MA_HIP(hipEventRecord(P->ev_fin[slot], S.lane_stream(slot)));
+  P->fin_state[slot] = 2;
+  return MA_OK;
+}
+int ma_lu_plan_stage_finish_wait(ma_lu_plan_t* P, int32_t slot, void* stream) {
+  MA_REQUIRE(P && slot >= 0 && slot < LU_BATCH_MAX && P->fin_state[slot] == 2, MA_ERR_INVALID, "slot %d has no issued finish to wait for", slot);
+  MA_HIP(hipSetDevice(P->device));
+  Stage S(P, (hipStream_t)stream);
+  P->fin_state[slot] = 0;
+  return S.backsub_end(slot, P->ev_fin[slot]);
 }
 }  // extern "C"
 
@@ -1277,7 +1363,8 @@ int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma
   MA_HIP(hipMemcpy(dA, A, sizeof(c64) * (size_t)M * K, hipMemcpyHostToDevice));
   MA_HIP(hipMemcpy(dB, B, sizeof(c64) * (size_t)K * N, hipMemcpyHostToDevice));
   MA_HIP(hipMemcpy(dC, C, sizeof(c64) * (size_t)M * N, hipMemcpyHostToDevice));
-  { bool m3 = true; if (const char* e0 = getenv("MA_ZGEMM_3M")) m3 = atoi(e0) != 0; rc = lu_launch_zgemm_sub(M, N, K, dA, (size_t)K, dB, (size_t)N, dC, (size_t)N, nullptr, m3); }
+  { bool m3 = true; if (const char* e0 = getenv("MA_ZGEMM_3M")) m3 = atoi(e0) != 0; const ZgemmMode zm = zgemm_mode_from_env();   /* test hook: the switches as they are NOW */
+    rc = lu_launch_zgemm_sub(M, N, K, dA, (size_t)K, dB, (size_t)N, dC, (size_t)N, nullptr, m3, false, &zm); }
   if (!rc) { hipError_t e = hipMemcpy(C, dC, sizeof(c64) * (size_t)M * N, hipMemcpyDeviceToHost); if (e != hipSuccess) { set_error("copy back: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; } }
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
   return rc;
@@ -1326,19 +1413,19 @@ int ma_probe_mfma_f64(int device, double* tflops) {
   if (rc) return rc;
   hipDeviceProp_t prop;
   MA_HIP(hipGetDeviceProperties(&prop, device));
-  const int blocks = prop.multiProcessorCount * 2, iters = 4000;
+  const int blocks = prop.multiProcessorCount * 2, iters = 20000;   // 6.5 ms per launch: the ramp of a 1.3 ms launch read 69 TFLOP/s where tools/mfma_peak_probe.py reads 77
   double* d = nullptr;
   MA_HIP(hipMalloc(&d, sizeof(double) * 256 * (size_t)blocks));
   hipEvent_t a, b;
   MA_HIP(hipEventCreate(&a)); MA_HIP(hipEventCreate(&b));
-  rc = lu_launch_mfma_probe(d, blocks, 200, nullptr);   // warm-up
+  rc = lu_launch_mfma_probe(d, blocks, 2000, nullptr);   // warm-up (clocks)
   MA_HIP(hipEventRecord(a, nullptr));
-  if (!rc) rc = lu_launch_mfma_probe(d, blocks, iters, nullptr);
+  for (int q = 0; q < 3 && !rc; ++q) rc = lu_launch_mfma_probe(d, blocks, iters, nullptr);
   MA_HIP(hipEventRecord(b, nullptr));
   MA_HIP(hipEventSynchronize(b));
   float ms = 0.f;
   MA_HIP(hipEventElapsedTime(&ms, a, b));
-  const double flops = (double)blocks * 4.0 * iters * 12.0 * (2.0 * 16 * 16 * 4);
+  const double flops = 3.0 * (double)blocks * 4.0 * iters * 12.0 * (2.0 * 16 * 16 * 4);
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
   return rc;

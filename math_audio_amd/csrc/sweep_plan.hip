@@ -2,12 +2,17 @@
 // (math-bem/bin/room_simulator_bem.rs:329-360 and BemSolver::solve, bem_solver.rs:355-480: per frequency
 // PhysicsParams::new, beta = burton_miller_beta_scaled, build_tbem_system_with_beta, compute_rhs_with_beta, lu_solve).
 // Built on the public entry points only: the systems go through the staged plan API as a pipeline -- `slots` of them in
-// HBM at a time, slot s a quarter of a factorisation behind slot s-1 (see ma_lu_plan_stage_*) -- without a host
+// HBM at a time, slot s a third of a factorisation behind slot s-1 (see ma_lu_plan_stage_*) -- without a host
 // synchronisation inside; the solutions are parked on the device and travel back once at the end.
 //
+// Round 4: the loop lives behind a HANDLE (ma_bem_sweep_t): LU plan, stream, the slots' systems, the spare systems of the
+// assembly-ahead and the parked solutions are allocated once and reused by every run, so a caller that sweeps again and again
+// (room_simulator_bem.rs runs one sweep per source position) pays no hipMalloc of 6-9 matrices of 1.6 GB per call, and
+// bench.py times exactly this entry. ma_bem_solve_sweep is create + run + destroy.
+//
 // Multi-GPU: frequencies are independent, so ma_bem_solve_sweep_multi gives device d the
-// frequencies f = d, d + ndev, ... : one host thread per device, each with its own BEM plan, LU plan, stream and buffers on
-// ITS device; no data-path collective, the solutions land in the caller's X_out rows directly.
+// frequencies f = d, d + ndev, ... : one host thread per device, each with its own BEM plan, sweep handle, LU plan, stream and
+// buffers on ITS device; no data-path collective, the solutions land in the caller's X_out rows directly.
 #include "ma_common.hpp"
 #include <vector>
 #include <algorithm>
@@ -15,115 +20,215 @@
 #include <thread>
 #include <string>
 #include <chrono>
+#include <new>
 
 using namespace ma;
 
 namespace {
-
 struct SweepArgs {
-  double speed_of_sound, harmonic_factor, tau, beta_scale; int incident_kind; const double* incident_vec3; double amp_re, amp_im; int32_t slots;
+  double speed_of_sound, harmonic_factor, tau, beta_scale; int incident_kind; const double* incident_vec3; double amp_re, amp_im;
+};
+struct AsmSet { void* A[3] = {}; void* x[3] = {}; int first = -1, cnt = 0, part = 0; unsigned taken = 0; ma_physics_t ph[3]; double br[3], bi[3]; };
+}  // namespace
+
+struct ma_bem_sweep {
+  ma_bem_plan_t* plan = nullptr; int device = 0; int32_t n = 0; int32_t slots = 3; int32_t cap = 0;
+  ma_lu_plan_t* lu = nullptr; hipStream_t st = nullptr; bool own_stream = false;
+  std::vector<void*> dA, dx;
+  int ahead = 1, ppp = 4;
+  AsmSet sets[2];
+  int32_t G = 0, spacing = 1; bool staged = false;
+  ma_c64* dX = nullptr; int32_t* dinfo = nullptr;
+  // timing of the last run (ma_bem_sweep_set_timing): events around the run and around every piece of assembly, on the sweep's stream
+  bool timing = false;
+  hipEvent_t ev_run[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_asm; size_t ev_asm_used = 0;
+  double last_wall_s = 0.0, last_device_ms = 0.0, last_asm_ms = 0.0; int last_asm_pieces = 0, last_n = 0;
+  bool have_last = false;
+
+  void free_spares() { for (auto& t : sets) for (int q = 0; q < 3; ++q) { if (t.A[q]) (void)hipFree(t.A[q]); if (t.x[q]) (void)hipFree(t.x[q]); t.A[q] = t.x[q] = nullptr; } }
+  void release() {
+    (void)hipSetDevice(device);
+    if (st) (void)hipStreamSynchronize(st);
+    for (void* p : dA) if (p) (void)hipFree(p);
+    for (void* p : dx) if (p) (void)hipFree(p);
+    dA.clear(); dx.clear();
+    free_spares();
+    if (dX) (void)hipFree(dX);
+    if (dinfo) (void)hipFree(dinfo);
+    dX = nullptr; dinfo = nullptr;
+    for (hipEvent_t e : ev_asm) (void)hipEventDestroy(e);
+    ev_asm.clear();
+    for (auto& e : ev_run) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (lu) ma_lu_plan_destroy(lu);
+    lu = nullptr;
+    if (own_stream && st) (void)hipStreamDestroy(st);
+    st = nullptr;
+  }
+  int asm_mark() {                                         // one event on the sweep's stream, from the pool
+    if (!timing) return MA_OK;
+    if (ev_asm_used >= ev_asm.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); ev_asm.push_back(e); }
+    MA_HIP(hipEventRecord(ev_asm[ev_asm_used++], st));
+    return MA_OK;
+  }
 };
 
-// frequencies first, first + stride, ... of frequencies_hz[0..n_freq) on the plan's own device; X_out / status are indexed by
-// the GLOBAL frequency index
-int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* frequencies_hz, int32_t first, int32_t stride, const SweepArgs& a,
-                         ma_c64* X_out, int32_t* status_or_null) {
+namespace {
+
+int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep** out) {
+  *out = nullptr;
   int32_t n = 0;
   int rc = ma_bem_plan_num_dofs(plan, &n);
   if (rc) return rc;
   int device = 0;
   if ((rc = ma_bem_plan_device(plan, &device))) return rc;
-  // everything this call allocates lives on the PLAN's device, whatever device the calling thread had selected
+  // everything the handle allocates lives on the PLAN's device, whatever device the calling thread had selected
   MA_HIP(hipSetDevice(device));
-  std::vector<int> mine;
-  for (int f = first; f < n_freq; f += stride) mine.push_back(f);
-  const int n_mine = (int)mine.size();
-  if (n_mine == 0) return MA_OK;
-  int32_t slots = a.slots;
+  ma_bem_sweep* S = new (std::nothrow) ma_bem_sweep();
+  MA_REQUIRE(S, MA_ERR_NOMEM, "host allocation failed");
+  S->plan = plan; S->device = device; S->n = n; S->cap = max_frequencies;
   if (slots < 1) slots = 3;
   if (slots > 4) slots = 4;
-  if (slots > n_mine) slots = n_mine;
-  ma_lu_plan_t* lu = nullptr;
-  if ((rc = ma_lu_plan_create(n, device, &lu))) return rc;
+  if (slots > max_frequencies) slots = max_frequencies;
+  S->slots = slots;
+  auto fail = [&](int code) { S->release(); delete S; return code; };
+  if ((rc = ma_lu_plan_create(n, device, &S->lu))) return fail(rc);
   // the sweep's own stream: the plan's big-update stream when the plan splits the chip (that stream is masked to the update CUs,
   // and a stream more would be one hardware queue more: profiles/r03_lu_panel_experiments.md), a stream of its own otherwise
-  hipStream_t st = nullptr;
-  bool own_stream = false;
-  { void* ms = nullptr; if (ma_lu_plan_main_stream(lu, &ms) == MA_OK && ms) st = (hipStream_t)ms; }
-  if (!st) {
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_error("sweep: stream creation failed"); ma_lu_plan_destroy(lu); return MA_ERR_HIP; }
-    own_stream = true;
+  { void* ms = nullptr; if (ma_lu_plan_main_stream(S->lu, &ms) == MA_OK && ms) S->st = (hipStream_t)ms; }
+  if (!S->st) {
+    if (hipStreamCreateWithFlags(&S->st, hipStreamNonBlocking) != hipSuccess) { set_error("sweep: stream creation failed"); return fail(MA_ERR_HIP); }
+    S->own_stream = true;
   }
-  std::vector<void*> dA((size_t)slots, nullptr), dx((size_t)slots, nullptr);
-  auto cleanup = [&]() { for (void* p : dA) if (p) (void)hipFree(p); for (void* p : dx) if (p) (void)hipFree(p); ma_lu_plan_destroy(lu); if (own_stream) (void)hipStreamDestroy(st); };
+  S->dA.assign((size_t)slots, nullptr); S->dx.assign((size_t)slots, nullptr);
   for (int s = 0; s < slots; ++s)
-    if (hipMalloc(&dA[(size_t)s], sizeof(ma_c64) * (size_t)n * (size_t)n) != hipSuccess || hipMalloc(&dx[(size_t)s], sizeof(ma_c64) * (size_t)n) != hipSuccess) {
+    if (hipMalloc(&S->dA[(size_t)s], sizeof(ma_c64) * (size_t)n * (size_t)n) != hipSuccess || hipMalloc(&S->dx[(size_t)s], sizeof(ma_c64) * (size_t)n) != hipSuccess) {
       set_error("sweep: %d systems of %d x %d do not fit device %d", slots, n, n, device);
-      cleanup();
-      return MA_ERR_NOMEM;
+      return fail(MA_ERR_NOMEM);
     }
-  int worst = MA_OK;
-  auto assemble = [&](int f, int s) -> int {
-    const double freq = frequencies_hz[f];
-    ma_physics_t ph;
-    ph.wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;     // PhysicsParams::new, types.rs:39-58
-    ph.harmonic_factor = a.harmonic_factor; ph.tau = a.tau; ph.gamma = 1.0;
-    const double bim = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / ph.wave_number : 0.0;   // burton_miller_beta_scaled, types.rs:144-150
-    int r = ma_bem_plan_assemble_dev(plan, &ph, 0.0, bim, dA[(size_t)s], dx[(size_t)s], st);
-    if (!r) r = ma_bem_plan_incident_rhs_dev(plan, &ph, 0.0, bim, a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, dx[(size_t)s], st);
-    return r;
-  };
+  S->staged = ma_lu_plan_num_blocks(S->lu, &S->G) == MA_OK && S->G > 0 && ma_lu_plan_stage_reset(S->lu, S->st) == MA_OK;
+  if (S->staged) {
+    S->spacing = std::max(1, (S->G + slots) / (slots + 1));
+    (void)ma_lu_plan_stage_spacing(S->lu, slots, &S->spacing);                                   // what the plan's kernels were measured best with
+  }
   // Assembly AHEAD, in PIECES, in the staged schedule. Two sets of (up to three) spare systems: while the slots consume one set --
   // a slot that begins a system swaps its matrix with the spare that holds it -- the other set's systems are assembled by
   // ma_bem_plan_assemble_multi_part_dev (their far pairs share one pass over the quadrature points) in pieces of the far pairs'
   // rows, one piece per round in the rounds just before a slot begins: there the sum of the slots' updates is smallest and the
   // stream would wait for the slots' panel chains. What has not been issued when a system is needed is issued then. Only when the
-  // spares fit comfortably (MA_SWEEP_ASM_AHEAD=1: every system assembled when its slot begins).
+  // spares fit comfortably (MA_SWEEP_ASM_AHEAD=1: every system assembled when its slot begins) and when the slots take their
+  // systems in the order of the frequencies: slot s begins its j-th system at round s * spacing + j * G, which is monotone in the
+  // frequency index only while (slots - 1) * spacing < G -- a plan of one or two blocks (a few hundred rows) starts several slots
+  // in one round and a later frequency before an earlier one; there every system is assembled when its slot begins.
   int ahead = 3;
   if (const char* ea = getenv("MA_SWEEP_ASM_AHEAD")) ahead = std::max(1, std::min(3, atoi(ea)));
-  if (ahead > n_mine) ahead = std::max(1, (int)n_mine);
-  int ppp = 4;                                                  // pieces per slot begin
-  if (const char* ep = getenv("MA_SWEEP_ASM_PIECES")) ppp = std::max(1, std::min(16, atoi(ep)));
+  if (ahead > max_frequencies) ahead = std::max(1, (int)max_frequencies);
+  if (const char* ep = getenv("MA_SWEEP_ASM_PIECES")) S->ppp = std::max(1, std::min(16, atoi(ep)));
+  if (!S->staged || (slots - 1) * S->spacing >= S->G) ahead = 1;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2.0 * (double)ahead * 16.0 * (double)n * (double)n > 0.5 * (double)free_b) ahead = 1;
   }
-  struct AsmSet { void* A[3] = {}; void* x[3] = {}; int first = -1, cnt = 0, part = 0; unsigned taken = 0; ma_physics_t ph[3]; double br[3], bi[3]; };
-  AsmSet sets[2];
-  auto free_spares = [&]() { for (auto& t : sets) for (int q = 0; q < 3; ++q) { if (t.A[q]) (void)hipFree(t.A[q]); if (t.x[q]) (void)hipFree(t.x[q]); t.A[q] = t.x[q] = nullptr; } };
   if (ahead > 1) {
     bool ok = true;
-    for (auto& t : sets) for (int q = 0; q < ahead && ok; ++q)
+    for (auto& t : S->sets) for (int q = 0; q < ahead && ok; ++q)
       ok = hipMalloc(&t.A[q], sizeof(ma_c64) * (size_t)n * (size_t)n) == hipSuccess && hipMalloc(&t.x[q], sizeof(ma_c64) * (size_t)n) == hipSuccess;
-    if (!ok) { free_spares(); ahead = 1; (void)hipGetLastError(); }
+    if (!ok) { S->free_spares(); ahead = 1; (void)hipGetLastError(); }
   }
+  S->ahead = ahead;
+  if (S->staged) {
+    if (hipMalloc(&S->dX, sizeof(ma_c64) * (size_t)max_frequencies * (size_t)n) != hipSuccess || hipMalloc(&S->dinfo, sizeof(int32_t) * (size_t)max_frequencies) != hipSuccess) {
+      set_error("sweep: the solutions of %d frequencies do not fit the device", max_frequencies);
+      return fail(MA_ERR_NOMEM);
+    }
+  }
+  if (hipEventCreate(&S->ev_run[0]) != hipSuccess || hipEventCreate(&S->ev_run[1]) != hipSuccess) { set_error("sweep: event creation failed"); return fail(MA_ERR_HIP); }
+  *out = S;
+  return MA_OK;
+}
+
+// frequencies first, first + stride, ... of frequencies_hz[0..n_freq) on the handle's device; X_out / status are indexed by
+// the GLOBAL frequency index (X_out may be NULL: the solutions stay parked on the device, ma_bem_sweep_solutions_dev)
+int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int32_t first, int32_t stride, const SweepArgs& a, ma_c64* X_out, int32_t* status_or_null) {
+  const auto wall0 = std::chrono::steady_clock::now();
+  MA_HIP(hipSetDevice(S->device));
+  ma_bem_plan_t* plan = S->plan; ma_lu_plan_t* lu = S->lu; hipStream_t st = S->st;
+  const int32_t n = S->n;
+  std::vector<int> mine;
+  for (int f = first; f < n_freq; f += stride) mine.push_back(f);
+  const int n_mine = (int)mine.size();
+  S->have_last = false;
+  if (n_mine == 0) return MA_OK;
+  MA_REQUIRE(n_mine <= S->cap, MA_ERR_INVALID, "sweep: %d frequencies for a handle created for %d", n_mine, S->cap);
+  MA_REQUIRE(X_out || S->staged, MA_ERR_INVALID, "sweep: without the staged schedule the solutions are not parked on the device; pass X_out");
+  const int32_t slots = std::min<int32_t>(S->slots, n_mine);
+  std::vector<void*>& dA = S->dA; std::vector<void*>& dx = S->dx;
+  int rc = MA_OK, worst = MA_OK;
+  S->ev_asm_used = 0;
+  auto physics_of = [&](int f, ma_physics_t* ph, double* bim) {
+    const double freq = frequencies_hz[f];
+    ph->wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;     // PhysicsParams::new, types.rs:39-58
+    ph->harmonic_factor = a.harmonic_factor; ph->tau = a.tau; ph->gamma = 1.0;
+    *bim = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / ph->wave_number : 0.0;   // burton_miller_beta_scaled, types.rs:144-150
+  };
+  auto assemble = [&](int f, int s) -> int {
+    ma_physics_t ph; double bim;
+    physics_of(f, &ph, &bim);
+    int r = S->asm_mark();
+    if (!r) r = ma_bem_plan_assemble_dev(plan, &ph, 0.0, bim, dA[(size_t)s], dx[(size_t)s], st);
+    if (!r) r = ma_bem_plan_incident_rhs_dev(plan, &ph, 0.0, bim, a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, dx[(size_t)s], st);
+    if (!r) r = S->asm_mark();
+    return r;
+  };
+  const int ahead = std::min(S->ahead, std::max(1, n_mine));
+  const int ppp = S->ppp;
   const int nparts = ppp * ahead;
+  AsmSet* sets = S->sets;
+  for (int q = 0; q < 2; ++q) { sets[q].first = -1; sets[q].cnt = 0; sets[q].part = 0; sets[q].taken = 0; }
   auto set_idle = [](const AsmSet& t) { return t.first < 0 || t.taken == (1u << t.cnt) - 1u; };
   auto start_job = [&](AsmSet& t, int first_i) {
     t.first = first_i; t.cnt = std::min(ahead, n_mine - first_i); t.part = 0; t.taken = 0;
-    for (int q = 0; q < t.cnt; ++q) {
-      const double freq = frequencies_hz[mine[(size_t)(first_i + q)]];
-      t.ph[q].wave_number = 2.0 * 3.14159265358979323846 * freq / a.speed_of_sound;
-      t.ph[q].harmonic_factor = a.harmonic_factor; t.ph[q].tau = a.tau; t.ph[q].gamma = 1.0;
-      t.br[q] = 0.0; t.bi[q] = a.tau > 0.0 ? a.harmonic_factor * a.beta_scale / t.ph[q].wave_number : 0.0;
-    }
+    for (int q = 0; q < t.cnt; ++q) { physics_of(mine[(size_t)(first_i + q)], &t.ph[q], &t.bi[q]); t.br[q] = 0.0; }
   };
+  // Deferred finishes (ma_lu_plan_stage_finish_defer / _issue / _wait): with spares, a slot's next system arrives in OTHER buffers, so
+  // the backward substitution of the one it has just factored need not sit between its last block and the next system's first
+  // panels (314 short launches, 6 ms on the lane): it is issued behind the next system's first two block columns -- that system's
+  // first update is its largest, the lane waits for it anyway -- and the stream waits for it two rounds later, before the solution
+  // is parked and before any assembly may write the buffers again.
+  struct Pend { int stage = 0; int i = -1; void* x = nullptr; int round = 0; };
+  Pend pend[4];
+  const bool defer_ok = [&] { const char* e = getenv("MA_SWEEP_DEFER_FINISH"); return !(e && atoi(e) == 0); }();
+  auto collect = [&](int s) -> int {
+    Pend& p = pend[s];
+    int r = MA_OK;
+    if (p.stage == 1) { r = ma_lu_plan_stage_finish_issue(lu, s); if (!r) p.stage = 2; }
+    if (!r && p.stage == 2) {
+      r = ma_lu_plan_stage_finish_wait(lu, s, st);
+      if (!r && hipMemcpyAsync(S->dX + (size_t)p.i * (size_t)n, p.x, sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); r = MA_ERR_HIP; }
+      p.stage = 0;
+    }
+    return r;
+  };
+  auto collect_all = [&]() -> int { int r = MA_OK; for (int s = 0; s < 4 && !r; ++s) if (pend[s].stage) r = collect(s); return r; };
   auto issue_part = [&](AsmSet& t) -> int {
-    int r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, st);
+    int r = collect_all();                                                  // no assembly writes a buffer whose backward substitution is still out
+    if (!r) r = S->asm_mark();
+    if (!r) r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, st);
     if (r) return r;
     if (++t.part == nparts)
       for (int q = 0; q < t.cnt && !r; ++q)
         r = ma_bem_plan_incident_rhs_dev(plan, &t.ph[q], 0.0, t.bi[q], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, t.x[q], st);
+    if (!r) r = S->asm_mark();
     return r;
   };
   // system of this device's i-th frequency into slot s
   auto take = [&](int i, int s) -> int {
     if (ahead <= 1) return assemble(mine[(size_t)i], s);
     AsmSet* t = nullptr;
-    for (auto& c : sets) if (c.first >= 0 && i >= c.first && i < c.first + c.cnt && !(c.taken >> (i - c.first) & 1u)) t = &c;
+    for (int c = 0; c < 2; ++c) if (sets[c].first >= 0 && i >= sets[c].first && i < sets[c].first + sets[c].cnt && !(sets[c].taken >> (i - sets[c].first) & 1u)) t = &sets[c];
     if (!t) {
-      for (auto& c : sets) if (!t && set_idle(c)) t = &c;
-      if (!t) { set_error("sweep: no spare system for frequency %d", i); return MA_ERR_INVALID; }
+      for (int c = 0; c < 2; ++c) if (!t && set_idle(sets[c])) t = &sets[c];
+      if (!t) return assemble(mine[(size_t)i], s);                           // neither set holds it and neither is free: this one directly (the order of a tiny plan)
       start_job(*t, i);
       AsmSet& o = t == &sets[0] ? sets[1] : sets[0];
       if (set_idle(o) && i + ahead < n_mine) start_job(o, i + ahead);       // the set after this one: in pieces, from now on
@@ -144,25 +249,21 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
   // after the updates of round r: one piece of the set being assembled, in the last ppp rounds before a slot begins
   auto assembly_tick = [&](int r, int spacing) -> int {
     if (ahead <= 1 || (r % spacing) < spacing - ppp) return MA_OK;
-    for (auto& t : sets) if (t.first >= 0 && t.part < nparts && t.taken == 0) return issue_part(t);
+    for (int c = 0; c < 2; ++c) if (sets[c].first >= 0 && sets[c].part < nparts && sets[c].taken == 0) return issue_part(sets[c]);
     return MA_OK;
   };
-  int32_t G = 0;
-  ma_c64* dX = nullptr; int32_t* dinfo = nullptr;
-  const bool staged = ma_lu_plan_num_blocks(lu, &G) == MA_OK && G > 0 && ma_lu_plan_stage_reset(lu, st) == MA_OK;
-  if (!staged) { free_spares(); ahead = 1; }
-  if (staged) {
-    if (hipMalloc(&dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n) != hipSuccess || hipMalloc(&dinfo, sizeof(int32_t) * (size_t)n_mine) != hipSuccess) {
-      if (dX) (void)hipFree(dX);
-      set_error("sweep: the solutions of %d frequencies do not fit the device", n_mine);
-      free_spares();
-      cleanup();
-      return MA_ERR_NOMEM;
-    }
+  if (S->staged) {
+    const int32_t G = S->G;
+    ma_c64* dX = S->dX; int32_t* dinfo = S->dinfo;
+    rc = ma_lu_plan_stage_reset(lu, st);
+    if (!rc && S->timing && hipEventRecord(S->ev_run[0], st) != hipSuccess) { set_error("sweep: event record failed"); rc = MA_ERR_HIP; }
     std::vector<int> off((size_t)slots);
     int32_t spacing = std::max(1, (G + slots) / (slots + 1));
-    (void)ma_lu_plan_stage_spacing(lu, slots, &spacing);                                          // what the plan's kernels were measured best with
+    (void)ma_lu_plan_stage_spacing(lu, slots, &spacing);
+    if (const char* es = getenv("MA_STAGE_SPACING")) { const int v = atoi(es); if (v >= 1) spacing = v; }   // diagnostic
     for (int s = 0; s < slots; ++s) off[(size_t)s] = s * spacing;
+    int issue_g = 1;                                             // the block of the NEXT system after whose round a deferred backward substitution is issued
+    if (const char* eg = getenv("MA_SWEEP_DEFER_BLOCK")) issue_g = std::max(0, std::min(4, atoi(eg)));
     for (int r = 0; !rc; ++r) {
       int32_t sl[4], bl[4]; int cnt = 0; bool live = false;
       for (int s = 0; s < slots && !rc; ++s) {
@@ -180,25 +281,36 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
       if (!live || rc) break;
       if (cnt) rc = ma_lu_plan_stage_round(lu, cnt, sl, bl, st);
       for (int q = 0; q < cnt && !rc; ++q) {
-        if (bl[q] != G - 1) continue;
         const int s = sl[q], i = s + slots * ((r - off[(size_t)s]) / G);
-        rc = ma_lu_plan_stage_finish(lu, s, st);
-        if (!rc && hipMemcpyAsync(dX + (size_t)i * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
+        if (bl[q] == issue_g && pend[s].stage == 1) { rc = ma_lu_plan_stage_finish_issue(lu, s); pend[s].stage = 2; pend[s].round = r; }
+        if (bl[q] != G - 1 || rc) continue;
+        if (defer_ok && ahead > 1 && i + slots < n_mine && G > issue_g + 2) {   // the slot has a next system, which arrives in other buffers
+          if (pend[s].stage) rc = collect(s);
+          if (!rc) rc = ma_lu_plan_stage_finish_defer(lu, s, st);
+          if (!rc) { pend[s].stage = 1; pend[s].i = i; pend[s].x = dx[(size_t)s]; pend[s].round = r; }
+        } else {
+          rc = ma_lu_plan_stage_finish(lu, s, st);
+          if (!rc && hipMemcpyAsync(dX + (size_t)i * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
+        }
         if (!rc) rc = ma_lu_plan_stage_info_dev(lu, s, dinfo + i, st);
       }
+      for (int s = 0; s < slots && !rc; ++s) if (pend[s].stage == 2 && r >= pend[s].round + 2) rc = collect(s);
       if (!rc) rc = assembly_tick(r, spacing);
     }
+    if (!rc) rc = collect_all();
+    if (!rc && S->timing && hipEventRecord(S->ev_run[1], st) != hipSuccess) { set_error("sweep: event record failed"); rc = MA_ERR_HIP; }
     if (!rc) {
       int stt = ma_lu_plan_status(lu, st);                     // synchronises; an abandoned panel (poisoned plan) surfaces here
       if (stt != MA_OK && stt != MA_ERR_SINGULAR) rc = stt;
     }
     if (!rc) {
       std::vector<int32_t> hinfo((size_t)n_mine);
-      std::vector<ma_c64> hX;
       hipError_t e = hipMemcpy(hinfo.data(), dinfo, sizeof(int32_t) * (size_t)n_mine, hipMemcpyDeviceToHost);
-      if (stride == 1 && first == 0) { if (e == hipSuccess) e = hipMemcpy(X_out, dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n, hipMemcpyDeviceToHost); }
-      else for (int i = 0; i < n_mine && e == hipSuccess; ++i)
-        e = hipMemcpy(X_out + (size_t)mine[(size_t)i] * (size_t)n, dX + (size_t)i * (size_t)n, sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToHost);
+      if (X_out) {
+        if (stride == 1 && first == 0) { if (e == hipSuccess) e = hipMemcpy(X_out, dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n, hipMemcpyDeviceToHost); }
+        else for (int i = 0; i < n_mine && e == hipSuccess; ++i)
+          e = hipMemcpy(X_out + (size_t)mine[(size_t)i] * (size_t)n, dX + (size_t)i * (size_t)n, sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToHost);
+      }
       if (e != hipSuccess) { set_error("sweep: copy back failed: %s", hipGetErrorString(e)); rc = MA_ERR_HIP; }
       for (int i = 0; i < n_mine && !rc; ++i) {
         const int sf = hinfo[(size_t)i] ? MA_ERR_SINGULAR : MA_OK;
@@ -206,10 +318,19 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
         if (sf != MA_OK) worst = sf;
       }
     }
-    if (rc) (void)hipDeviceSynchronize();                       // nothing may still be running on buffers that are about to go
-    (void)hipFree(dX); (void)hipFree(dinfo);
-    free_spares();
-    cleanup();
+    if (rc) (void)hipDeviceSynchronize();                       // nothing may still be running on buffers that the caller may free next
+    if (!rc) {
+      S->last_wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+      S->last_n = n_mine; S->last_device_ms = 0.0; S->last_asm_ms = 0.0; S->last_asm_pieces = 0;
+      if (S->timing) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, S->ev_run[0], S->ev_run[1]) == hipSuccess) S->last_device_ms = ms;
+        for (size_t q = 0; q + 1 < S->ev_asm_used; q += 2)
+          if (hipEventElapsedTime(&ms, S->ev_asm[q], S->ev_asm[q + 1]) == hipSuccess) { S->last_asm_ms += ms; ++S->last_asm_pieces; }
+        (void)hipGetLastError();
+      }
+      S->have_last = true;
+    }
     return rc ? rc : worst;
   }
   // look-ahead lanes switched off (MA_LU_LOOKAHEAD=0 / MA_LU_PANEL_OVERLAP=0): lock-step batches
@@ -229,24 +350,131 @@ int sweep_on_plan_device(ma_bem_plan_t* plan, int32_t n_freq, const double* freq
     if (stt != MA_OK) worst = stt;
   }
   if (rc) (void)hipDeviceSynchronize();
-  cleanup();
+  if (!rc) { S->last_wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); S->last_n = n_mine; S->have_last = true; }
   return rc ? rc : worst;
+}
+
+int check_args(int32_t n_freq, const double* frequencies_hz, double speed_of_sound, const double* incident_vec3) {
+  MA_REQUIRE(n_freq > 0 && frequencies_hz && incident_vec3, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
+  return MA_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
+int ma_bem_sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep_t** out) {
+  MA_REQUIRE(plan && out && max_frequencies > 0, MA_ERR_INVALID, "bad argument");
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  const int rc = sweep_create(plan, slots, max_frequencies, out);
+  if (had) (void)hipSetDevice(prev);
+  return rc;
+}
+
+int ma_bem_sweep_destroy(ma_bem_sweep_t* sweep) {
+  if (!sweep) return MA_OK;
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  sweep->release();
+  delete sweep;
+  if (had) (void)hipSetDevice(prev);
+  return MA_OK;
+}
+
+int ma_bem_sweep_run(ma_bem_sweep_t* sweep, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau, double beta_scale,
+                     int incident_kind, const double* incident_vec3, double amp_re, double amp_im, ma_c64* X_out_or_null, int32_t* status_or_null) {
+  MA_REQUIRE(sweep, MA_ERR_INVALID, "NULL sweep");
+  int rc = check_args(n_freq, frequencies_hz, speed_of_sound, incident_vec3);
+  if (rc) return rc;
+  const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im};
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  rc = sweep_run(sweep, n_freq, frequencies_hz, 0, 1, a, X_out_or_null, status_or_null);
+  if (had) (void)hipSetDevice(prev);                            // the caller's current device is left as it was
+  return rc;
+}
+
+int ma_bem_sweep_set_timing(ma_bem_sweep_t* sweep, int enable) {
+  MA_REQUIRE(sweep, MA_ERR_INVALID, "NULL sweep");
+  sweep->timing = enable != 0;
+  int rc = ma_lu_plan_set_timing(sweep->lu, enable ? 2 : 0);     // 2: only the trailing-update launches are bracketed by events
+  if (!rc && enable) {
+    int prev = -1;
+    const bool had = hipGetDevice(&prev) == hipSuccess;
+    (void)hipSetDevice(sweep->device);
+    rc = ma_lu_plan_reserve_events(sweep->lu, (int64_t)sweep->cap * 1400 + 64);
+    while (!rc && sweep->ev_asm.size() < (size_t)sweep->cap * 16 + 16) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { set_error("sweep: event creation failed"); rc = MA_ERR_HIP; } else sweep->ev_asm.push_back(e); }
+    if (had) (void)hipSetDevice(prev);
+  }
+  return rc;
+}
+
+int ma_bem_sweep_last_timing(ma_bem_sweep_t* sweep, double* out8) {
+  MA_REQUIRE(sweep && out8, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(sweep->have_last, MA_ERR_INVALID, "no completed run on this sweep handle");
+  for (int i = 0; i < 8; ++i) out8[i] = 0.0;
+  out8[0] = sweep->last_wall_s; out8[1] = sweep->last_device_ms; out8[2] = sweep->last_asm_ms; out8[3] = sweep->last_asm_pieces; out8[7] = sweep->last_n;
+  if (sweep->timing && sweep->staged) {
+    double t8[8];
+    int rc = ma_lu_plan_last_timing(sweep->lu, t8);
+    if (rc) return rc;
+    out8[4] = t8[3];                                             // ms summed over the big trailing updates (events around every launch)
+    double launches = 0.0, flops = 0.0;
+    if ((rc = ma_lu_plan_last_big_update_stats(sweep->lu, &launches, &flops))) return rc;
+    out8[5] = launches; out8[6] = flops;
+  }
+  return MA_OK;
+}
+
+int ma_bem_sweep_lu_plan(ma_bem_sweep_t* sweep, ma_lu_plan_t** plan) {
+  MA_REQUIRE(sweep && plan, MA_ERR_INVALID, "bad argument");
+  *plan = sweep->lu;
+  return MA_OK;
+}
+
+int ma_bem_sweep_stream(ma_bem_sweep_t* sweep, void** stream) {
+  MA_REQUIRE(sweep && stream, MA_ERR_INVALID, "bad argument");
+  *stream = (void*)sweep->st;
+  return MA_OK;
+}
+
+int ma_bem_sweep_info(ma_bem_sweep_t* sweep, int32_t* slots, int32_t* blocks, int32_t* spacing, int32_t* systems_ahead, int32_t* staged) {
+  MA_REQUIRE(sweep, MA_ERR_INVALID, "NULL sweep");
+  if (slots) *slots = sweep->slots;
+  if (blocks) *blocks = sweep->G;
+  if (spacing) *spacing = sweep->spacing;
+  if (systems_ahead) *systems_ahead = sweep->ahead;
+  if (staged) *staged = sweep->staged ? 1 : 0;
+  return MA_OK;
+}
+
+int ma_bem_sweep_solutions_dev(ma_bem_sweep_t* sweep, void** d_X, int32_t* count) {
+  MA_REQUIRE(sweep && d_X && count, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(sweep->have_last && sweep->staged, MA_ERR_INVALID, "no parked solutions on this sweep handle");
+  *d_X = (void*)sweep->dX; *count = sweep->last_n;
+  return MA_OK;
+}
+
+// plumbing for callers that hold device pointers of the library (the parked solutions) and buffers of their own
+int ma_device_copy(void* d_dst, const void* d_src, int64_t bytes, void* stream) {
+  MA_REQUIRE(d_dst && d_src && bytes >= 0, MA_ERR_INVALID, "bad argument");
+  MA_HIP(hipMemcpyAsync(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  MA_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return MA_OK;
+}
+
 int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
                        double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, int32_t slots,
                        ma_c64* X_out, int32_t* status_or_null) {
-  MA_REQUIRE(plan && n_freq > 0 && frequencies_hz && incident_vec3 && X_out, MA_ERR_INVALID, "bad argument");
-  MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
-  const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im, slots};
-  int prev = -1;
-  const bool had = hipGetDevice(&prev) == hipSuccess;
-  const int rc = sweep_on_plan_device(plan, n_freq, frequencies_hz, 0, 1, a, X_out, status_or_null);
-  if (had) (void)hipSetDevice(prev);                            // the caller's current device is left as it was
+  MA_REQUIRE(plan && X_out, MA_ERR_INVALID, "bad argument");
+  int rc = check_args(n_freq, frequencies_hz, speed_of_sound, incident_vec3);
+  if (rc) return rc;
+  ma_bem_sweep_t* S = nullptr;
+  if ((rc = ma_bem_sweep_create(plan, slots, n_freq, &S))) return rc;
+  rc = ma_bem_sweep_run(S, n_freq, frequencies_hz, speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im, X_out, status_or_null);
+  ma_bem_sweep_destroy(S);
   return rc;
 }
 
@@ -254,15 +482,16 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
 // to device slot f mod ndev (room_simulator_bem.rs:329's loop dealt round-robin).
 int ma_sweep_owner(int32_t frequency_index, int32_t ndev) { return ndev > 0 ? frequency_index % ndev : 0; }
 
-// the same with a per-device account for the caller (bench.py --inlib): device_seconds[d] = wall time of device d's sweep (its plan
-// creation excluded), device_setup_seconds[d] = its plan creation, device_frequencies[d] = frequencies it solved; any may be NULL
+// the same with a per-device account for the caller: device_seconds[d] = wall time of device d's sweep run (plan and handle
+// creation excluded), device_setup_seconds[d] = its plan + handle creation, device_frequencies[d] = frequencies it solved; any may be NULL
 int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
                                    double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
                                    int32_t slots, ma_c64* X_out, int32_t* status_or_null, double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies) {
-  MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && n_freq > 0 && frequencies_hz && incident_vec3 && X_out, MA_ERR_INVALID, "bad argument");
-  MA_REQUIRE(speed_of_sound > 0.0, MA_ERR_INVALID, "speed of sound must be positive");
+  MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && X_out, MA_ERR_INVALID, "bad argument");
+  int rc = check_args(n_freq, frequencies_hz, speed_of_sound, incident_vec3);
+  if (rc) return rc;
   int count = 0;
-  int rc = ma_device_count(&count);
+  rc = ma_device_count(&count);
   if (rc) return rc;
   MA_REQUIRE(count > 0, MA_ERR_NO_DEVICE, "no gfx950 device visible");
   for (int d = 0; d < ndev; ++d) {
@@ -270,23 +499,26 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
     // (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1: several host threads on one GPU, so that a one-GPU box exercises the sharding)
     for (int o = 0; o < d; ++o) MA_REQUIRE(devices[o] != devices[d] || getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES"), MA_ERR_INVALID, "device %d listed twice", devices[d]);
   }
-  const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im, slots};
+  const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im};
   std::vector<int> rcs((size_t)ndev, MA_OK);
   std::vector<std::string> texts((size_t)ndev);
   auto work = [&](int d) {
     // one host thread per device: its own plans, stream and buffers; errors are thread-local and carried back as text
-    ma_bem_plan_t* plan = nullptr;
+    ma_bem_plan_t* plan = nullptr; ma_bem_sweep* S = nullptr;
+    int c = 0; for (int f = d; f < n_freq; f += ndev) ++c;
     const auto t0 = std::chrono::steady_clock::now();
-    int r = ma_bem_plan_create(mesh, devices[d], &plan);
+    int r = c > 0 ? ma_bem_plan_create(mesh, devices[d], &plan) : MA_OK;
+    if (!r && c > 0) r = sweep_create(plan, slots, c, &S);
     const auto t1 = std::chrono::steady_clock::now();
-    if (!r) r = sweep_on_plan_device(plan, n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null);
+    if (!r && c > 0) r = sweep_run(S, n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null);
     const auto t2 = std::chrono::steady_clock::now();
     if (r && r != MA_ERR_SINGULAR) texts[(size_t)d] = ma_last_error_string();
+    if (S) { S->release(); delete S; }
     if (plan) ma_bem_plan_destroy(plan);
     rcs[(size_t)d] = r;
     if (device_setup_seconds) device_setup_seconds[d] = std::chrono::duration<double>(t1 - t0).count();
     if (device_seconds) device_seconds[d] = std::chrono::duration<double>(t2 - t1).count();
-    if (device_frequencies) { int c = 0; for (int f = d; f < n_freq; f += ndev) ++c; device_frequencies[d] = c; }
+    if (device_frequencies) device_frequencies[d] = c;
   };
   int prev = -1;
   const bool had = hipGetDevice(&prev) == hipSuccess;       // work(0) runs on the calling thread and selects devices[0]: the caller's device is restored below
