@@ -229,7 +229,9 @@ int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);
 /* Round 3: a plan for 4 096..16 384 rows (or MA_LU_CU_SPLIT=<P>) runs its big trailing updates on a stream whose CU mask leaves
  * P = 64 CUs (P / 8 per XCD) to the latency-bound panel kernels (no reference counterpart: a schedule detail behind lu_solve,
  * math-solvers/src/direct/lu.rs:142-153). *stream = that stream, or NULL when the plan does not split the chip. A driver of the
- * staged schedule passes it as ITS stream (assemblies included): one hardware queue less. */
+ * staged schedule passes it as ITS stream (assemblies included): one hardware queue less. The masked stream is a blocking stream (the
+ * only kind the runtime makes with a CU mask): stage_reset / stage_begin refuse the NULL stream on such a plan (MA_ERR_INVALID) -- work on
+ * the NULL stream would serialise against every big update. */
 int ma_lu_plan_main_stream(ma_lu_plan_t* plan, void** stream);
 /* rounds between the starts of two of `slots` slots that the plan's kernels were measured best with (a driver of the staged
  * schedule starts slot s at round s * spacing; ma_bem_solve_sweep and bench.py do) */
@@ -418,6 +420,17 @@ int ma_op_apply(ma_op_t* op, const ma_c64* x, ma_c64* y);
  * not owned. */
 typedef int (*ma_gather_fn)(void* user, void* d_y, int64_t n, int64_t row0, int64_t row1, void* stream);
 int ma_op_create_gathered(ma_op_t* inner, int64_t row0, int64_t row1, ma_gather_fn gather, void* user, ma_op_t** out);
+/* The same with the exchange INSIDE the library (north_star: RCCL over xGMI for the block exchange; traits.rs:316-327 `apply`): rank `rank` of
+ * `nranks` owns rows [rank * per, min(n, (rank + 1) * per)), per = ceil(n / nranks), and every apply ends with one ncclAllGather of `per`
+ * rows per rank on the apply's stream -- no callback, nothing for a Rust host to glue. nccl_comm is an ncclComm_t of the librccl the
+ * process holds (the library binds librccl at first use with dlopen and so shares the copy already loaded); ma_rccl_get_unique_id /
+ * ma_rccl_comm_create / ma_rccl_comm_destroy wrap ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy of that same copy for hosts
+ * without an RCCL binding of their own (the 128-byte id travels from rank 0 to the others by the host's own means).
+ * Every rank must take the same decisions (same iteration counts): the collective has no timeout. Unmeasured on > 1 GPU. */
+int ma_op_create_gathered_rccl(ma_op_t* inner, void* nccl_comm, int32_t nranks, int32_t rank, ma_op_t** out);
+int ma_rccl_get_unique_id(void* id128);
+int ma_rccl_comm_create(int32_t nranks, int32_t rank, const void* id128, int device, void** comm);
+int ma_rccl_comm_destroy(void* comm);
 int ma_op_apply_dev(ma_op_t* op, const void* d_x, void* d_y, void* stream);
 /* apply_transpose (y = A^T x) and apply_hermitian (y = A^H x), traits.rs:326-358, for every operator kind. A matrix-free
  * operator created over a row block [row0, row1) returns that block's contribution to all entries of y (the blocks' results

@@ -715,6 +715,15 @@ class LinearOperator:
         return LinearOperator(h, (inner, cb))
 
     @staticmethod
+    def gathered_rccl(inner, comm, nranks, rank):
+        """ma_op_create_gathered_rccl: the row exchange as ncclAllGather INSIDE the library (rank `rank` of `nranks` owns rows
+        [rank * per, (rank + 1) * per), per = ceil(n / nranks)); `comm` is an RcclComm (or a raw ncclComm_t of the process's librccl)."""
+        h = C.c_void_p()
+        lib().ma_op_create_gathered_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        check(lib().ma_op_create_gathered_rccl(inner.h, C.c_void_p(comm.h.value if hasattr(comm, "h") else int(comm)), int(nranks), int(rank), C.byref(h)))
+        return LinearOperator(h, (inner, comm))
+
+    @staticmethod
     def tbem_multi(mesh, k, beta, devices, harmonic=1.0, tau=1.0):
         """ma_op_create_tbem_multi: the matrix-free operator row-sharded over `devices` (vectors live on devices[0])."""
         ph = physics(k, harmonic, tau); beta = complex(beta)
@@ -1010,6 +1019,30 @@ def solve_sweep(plan, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind
     if rc not in (MA_OK, MA_ERR_SINGULAR):
         check(rc)
     return X, st
+
+
+def rccl_unique_id():
+    """ma_rccl_get_unique_id: 128 bytes made on rank 0 and handed to every rank of the communicator by the host's own means."""
+    buf = (C.c_ubyte * 128)()
+    lib().ma_rccl_get_unique_id.argtypes = [C.c_void_p]
+    check(lib().ma_rccl_get_unique_id(buf))
+    return bytes(buf)
+
+
+class RcclComm:
+    """ma_rccl_comm_create / _destroy: an ncclComm_t of the librccl the library bound (the copy the process already holds, if any)."""
+
+    def __init__(self, nranks, rank, unique_id, device=0):
+        self.h = C.c_void_p(); self.nranks = nranks; self.rank = rank
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        lib().ma_rccl_comm_create.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_void_p]
+        check(lib().ma_rccl_comm_create(int(nranks), int(rank), buf, int(device), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().ma_rccl_comm_destroy.argtypes = [C.c_void_p]
+            lib().ma_rccl_comm_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def memcpy_dtod(d_dst, d_src, nbytes, stream=0):

@@ -40,6 +40,10 @@ struct ma_slfmm {
   c64* d_up = nullptr; c64* d_tr = nullptr;
   c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=0: recomputed)
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
+  // round 4: the near blocks' first pass runs on a second stream beside the far chain (up -> translate -> down), whose result goes to
+  // d_yfar and is added by the near field's second pass -- the apply costs max(near, far) + one short pass instead of their sum
+  // (MA_FMM_OVERLAP=0: one stream, the round-2 order). Created on first use.
+  hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_near = nullptr; c64* d_yfar = nullptr; int overlap_streams = -1;
   // host copies for extract_near_field_matrix
   std::vector<int> h_eptr, h_edof, h_bsrc, h_bfld; std::vector<long long> h_boff;
 };
@@ -383,6 +387,87 @@ static int fmm_launch_translate(const int* fptr, const int* foth, const c64* fva
   return MA_OK;
 }
 
+// The translations of SEVERAL levels of a tree in one launch (round 4): they are independent of one another once every level's
+// multipoles stand, and each alone fills a fraction of the chip (a top level has a handful of clusters); the same workgroup body as
+// fmm_translate_dense_kernel<KS, 2>, the level picked from the block index.
+struct FmmLevels { int nl; int first[9]; int rows[8]; int nc[8]; int P[8]; const dc* DT[8]; const dc* up[8]; dc* tr[8]; };
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void fmm_translate_levels_kernel(FmmLevels V) {
+  constexpr int NT = 2;
+  __shared__ dc part[16 * 16 * NT];
+  int l = 0;
+  while (l + 1 < V.nl && (int)blockIdx.x >= V.first[l + 1]) ++l;
+  const int rem = (int)blockIdx.x - V.first[l];
+  const int nc = V.nc[l], P = V.P[l];
+  const dc* __restrict__ DT = V.DT[l]; const dc* __restrict__ up = V.up[l]; dc* __restrict__ tr = V.tr[l];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int c0 = (rem % V.rows[l]) * 16;
+  const int pb = (rem / V.rows[l]) * (16 * NT);
+  const int npts = P - pb < 16 * NT ? P - pb : 16 * NT;
+  const int nt = (npts + 15) / 16;
+  const int steps = (nc + 3) / 4, per = (steps + KS - 1) / KS;
+  const int kb = w * per, ke = kb + per < steps ? kb + per : steps;
+  const dc* acol = DT + (c0 + lr < nc ? c0 + lr : nc - 1);
+  fmm_v4d cr[NT], ci[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { cr[t] = (fmm_v4d){0, 0, 0, 0}; ci[t] = cr[t]; }
+  dc a, bv[NT], an, bn[NT];
+  auto fetch = [&](int ks, dc& fa, dc* fb) {
+    const int sidx = ks * 4 + lk;
+    const int sc = sidx < nc ? sidx : nc - 1;
+    fa = acol[(long long)sc * nc];
+    if (sidx >= nc) fa = dc_make(0.0, 0.0);
+    const dc* urow = up + (long long)sc * P + pb;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) { const int col = 16 * t + lr; fb[t] = urow[col < npts ? col : npts - 1]; }
+  };
+  if (kb < ke) fetch(kb, a, bv);
+  for (int ks = kb; ks < ke; ++ks) {
+    if (ks + 1 < ke) fetch(ks + 1, an, bn);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt) {
+        cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].re, cr[t], 0, 0, 0);
+        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].im, ci[t], 0, 0, 0);
+        cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, bv[t].im, cr[t], 0, 0, 0);
+        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, bv[t].re, ci[t], 0, 0, 0);
+      }
+    a = an;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv[t] = bn[t];
+  }
+  for (int q = 0; q < KS; ++q) {                            // parts are added in wavefront order, as in the one-level kernel: the same bits
+    if (w == q) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t < nt) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            dc* o = part + (lk + 4 * g) * (16 * NT) + 16 * t + lr;
+            if (q == 0) *o = dc_make(cr[t][g], ci[t][g]);
+            else { o->re += cr[t][g]; o->im += ci[t][g]; }
+          }
+        }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < 16 * npts; idx += 64 * KS) {
+    const int r = idx / npts, j = idx % npts;
+    if (c0 + r < nc) tr[(long long)(c0 + r) * P + pb + j] = part[r * (16 * NT) + j];
+  }
+}
+// would fmm_launch_translate take the <KS, 2> dense kernel for this level? (those are the levels the batched launch can carry)
+static bool fmm_translate_batchable(const c64* dense, int nc, int P) { return dense && ((nc + 15) / 16) * ((P + 127) / 128) < 1024; }
+static int fmm_launch_translate_levels(const FmmLevels& V, hipStream_t st) {
+  if (V.nl <= 0) return MA_OK;
+  hipLaunchKernelGGL(fmm_translate_levels_kernel<8>, dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
 // dense nc x nc form (stored by source) of pair lists grouped by receiving cluster; nullptr (lists stay in use) when fewer than a quarter of the pairs exist or when
 // MA_FMM_DENSE_TRANSLATE=0 asks for the lists
 static int fmm_dense_from_lists(const std::vector<int>& ptr, const std::vector<int>& oth, const std::vector<c64>& val, int nc, c64** d_out) {
@@ -557,7 +642,7 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
 template <int WPC>
 __global__ __launch_bounds__(256) void slfmm_near_gather_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
                                                                 const SlfmmEntry* __restrict__ cent, const dc* __restrict__ part, dc* __restrict__ y,
-                                                                int overlap, int nclusters) {
+                                                                int overlap, int nclusters, const dc* __restrict__ yfar /* NULL, or the far field's share per dof (no overlap) */) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * (4 / WPC) + wave / WPC, w = wave % WPC;
   if (c >= nclusters) return;
@@ -574,6 +659,7 @@ __global__ __launch_bounds__(256) void slfmm_near_gather_kernel(const int* __res
     }
     dc* o = y + edof[e0 + i];
     if (overlap) { atomicAdd(&o->re, sr); atomicAdd(&o->im, si); }         // the dof is a row of several clusters
+    else if (yfar) { const dc f = yfar[edof[e0 + i]]; *o = dc_make(sr + f.re, si + f.im); }   // near, then + far: the sum the one-stream order forms
     else *o = dc_make(sr, si);
   }
 }
@@ -632,7 +718,7 @@ __global__ __launch_bounds__(256) void slfmm_up_tab_kernel(const int* __restrict
 }
 // y[dof_j] += sum_p (E.re, sgn E.im) tr[c][p]: a wavefront per element (four at a time), lanes over the sphere points
 __global__ __launch_bounds__(256) void slfmm_down_tab_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const dc* __restrict__ E, int P, double sgn,
-                                                             const dc* __restrict__ tr, dc* __restrict__ y, int overlap) {
+                                                             const dc* __restrict__ tr, dc* __restrict__ y, int overlap /* 1: atomic adds; 2: plain stores (y is the far field's own buffer) */) {
   constexpr int U = 8;
   const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e0 = eptr[c], n = eptr[c + 1] - e0;
@@ -657,7 +743,8 @@ __global__ __launch_bounds__(256) void slfmm_down_tab_kernel(const int* __restri
       const double a = fmm_set_sum(sr[u], 64), b = fmm_set_sum(si[u], 64);
       if (lane == 0 && j0 + u < n) {
         dc* o = y + edof[e0 + j0 + u];
-        if (overlap) { atomicAdd(&o->re, a); atomicAdd(&o->im, b); }
+        if (overlap == 1) { atomicAdd(&o->re, a); atomicAdd(&o->im, b); }
+        else if (overlap == 2) *o = dc_make(a, b);
         else { o->re += a; o->im += b; }
       }
     }
@@ -671,9 +758,9 @@ static int slfmm_launch_up(const ma_slfmm* S, double sgn, const dc* x, hipStream
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
-static int slfmm_launch_down(const ma_slfmm* S, double sgn, dc* y, hipStream_t st) {
+static int slfmm_launch_down(const ma_slfmm* S, double sgn, dc* y, hipStream_t st, bool store = false) {
   if (S->d_phase) hipLaunchKernelGGL(slfmm_down_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn,
-                                     reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
+                                     reinterpret_cast<const dc*>(S->d_tr), y, store ? 2 : (S->overlap ? 1 : 0));
   else hipLaunchKernelGGL(slfmm_down_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn,
                           reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
   MA_HIP(hipGetLastError());
@@ -696,12 +783,15 @@ __global__ __launch_bounds__(256) void slfmm_pairs_kernel(const int* __restrict_
   }
 }
 
-static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st) {
+// pass 0: both passes of the near field on `st`; 1: the blocks' products only (-> the partial sums); 2: the per-cluster pass only
+// (partial sums -> y, plus yfar when given)
+static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st, int pass = 0, const dc* yfar = nullptr) {
   const int avg = S->nc > 0 ? (int)((S->h_eptr.empty() ? 0 : S->h_eptr.back()) / S->nc) : 0;
   int G = 8; while (G < 64 && G < avg) G <<= 1;
   if (S->d_part) {
     const dc* bv = reinterpret_cast<const dc*>(S->d_bval); dc* part = reinterpret_cast<dc*>(S->d_part);
-    if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, dim3((unsigned)((S->nblocks + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
+    if (pass == 2) { /* second pass only */ }
+    else if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, dim3((unsigned)((S->nblocks + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
                                                    S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
     else if (S->max_width <= 64 * FMM_NCH && !getenv("MA_FMM_WIDE_BLOCKS_OFF"))
       hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
@@ -709,12 +799,14 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
     else hipLaunchKernelGGL(slfmm_near_blocks_kernel<4>, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
                             S->d_bcoff, S->nblocks, bv, x, part, tmode);
     MA_HIP(hipGetLastError());
+    if (pass == 1) return MA_OK;
     if (avg <= 48) hipLaunchKernelGGL(slfmm_near_gather_kernel<1>, dim3((unsigned)((S->nc + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, part, y,
-                                      S->overlap ? 1 : 0, S->nc);
-    else hipLaunchKernelGGL(slfmm_near_gather_kernel<4>, dim3((unsigned)S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, part, y, S->overlap ? 1 : 0, S->nc);
+                                      S->overlap ? 1 : 0, S->nc, yfar);
+    else hipLaunchKernelGGL(slfmm_near_gather_kernel<4>, dim3((unsigned)S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent, part, y, S->overlap ? 1 : 0, S->nc, yfar);
     MA_HIP(hipGetLastError());
     return MA_OK;
   }
+  MA_REQUIRE(pass == 0, MA_ERR_INVALID, "the near field without stored block sums has one pass");
   if (avg <= 48) hipLaunchKernelGGL(slfmm_near_kernel<1>, dim3((unsigned)((S->nc + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent,
                                     reinterpret_cast<const dc*>(S->d_bval), x, y, tmode, S->overlap ? 1 : 0, S->nc, G);
   else hipLaunchKernelGGL(slfmm_near_kernel<4>, dim3((unsigned)S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_cptr, S->d_cent,
@@ -752,6 +844,10 @@ void slfmm_destroy(ma_slfmm* S) {
   void* p[] = {S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->d_bval, S->d_cptr, S->d_cent, S->d_fptr, S->d_foth, S->d_fval, S->d_tptr, S->d_toth,
                S->d_tval, S->d_up, S->d_tr, S->d_fdense, S->d_tdense, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff, S->d_bcoff, S->d_part, S->d_phase};
   for (void* q : p) if (q) (void)hipFree(q);
+  if (S->d_yfar) (void)hipFree(S->d_yfar);
+  if (S->st2) { (void)hipStreamSynchronize(S->st2); (void)hipStreamDestroy(S->st2); }
+  if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
+  if (S->ev_near) (void)hipEventDestroy(S->ev_near);
   delete S;
 }
 
@@ -948,10 +1044,54 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   return MA_OK;
 }
 
+// the second stream, its events and the far field's own result vector: made at the first apply that wants them
+static bool slfmm_overlap_ready(ma_slfmm* S) {
+  if (S->overlap_streams < 0) {
+    const char* e = getenv("MA_FMM_OVERLAP");
+    S->overlap_streams = 0;
+    if (!(e && atoi(e) == 0) && S->d_part && S->d_phase) {
+      bool ok = hipStreamCreateWithFlags(&S->st2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&S->ev_near, hipEventDisableTiming) == hipSuccess && hipMalloc(&S->d_yfar, sizeof(c64) * (size_t)S->n) == hipSuccess;
+      if (ok) S->overlap_streams = 1; else (void)hipGetLastError();
+    }
+  }
+  return S->overlap_streams == 1;
+}
+// fork: the near blocks' products on the second stream, ordered after what `st` holds so far (x is ready, y is cleared)
+static int slfmm_fork_near(ma_slfmm* S, const dc* x, int tmode, hipStream_t st) {
+  MA_HIP(hipEventRecord(S->ev_fork, st));
+  MA_HIP(hipStreamWaitEvent(S->st2, S->ev_fork, 0));
+  int rc = slfmm_launch_near(S, x, nullptr, tmode, S->st2, 1);
+  if (rc) return rc;
+  MA_HIP(hipEventRecord(S->ev_near, S->st2));
+  return MA_OK;
+}
+// join: `st` (which has the far field in d_yfar, or will add it to y itself when elements sit in several clusters) takes the near
+// field's second pass
+static int slfmm_join_near(ma_slfmm* S, dc* y, double s_dn, hipStream_t st) {
+  MA_HIP(hipStreamWaitEvent(st, S->ev_near, 0));
+  if (S->overlap) {                                            // atomic adds into the cleared y: near sums, then the far field
+    int rc = slfmm_launch_near(S, nullptr, y, 0, st, 2);
+    if (!rc) rc = slfmm_launch_down(S, s_dn, y, st);
+    return rc;
+  }
+  return slfmm_launch_near(S, nullptr, y, 0, st, 2, reinterpret_cast<const dc*>(S->d_yfar));
+}
+
 int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_t st) {
   MA_HIP(hipSetDevice(S->device));
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));        // dofs outside every cluster receive nothing
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
+  if (slfmm_overlap_ready(S)) {
+    const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
+    int rc = slfmm_fork_near(S, x, transpose, st);
+    if (!rc) rc = slfmm_launch_up(S, s_up, x, st);
+    if (!rc) rc = fmm_launch_translate(transpose ? S->d_tptr : S->d_fptr, transpose ? S->d_toth : S->d_foth, transpose ? S->d_tval : S->d_fval,
+                                       transpose ? S->d_tdense : S->d_fdense, S->nc, S->P, S->d_up, S->d_tr, st);
+    if (!rc && !S->overlap) rc = slfmm_launch_down(S, s_dn, reinterpret_cast<dc*>(S->d_yfar), st, true);
+    if (!rc) rc = slfmm_join_near(S, y, s_dn, st);
+    return rc;
+  }
   { int rc = slfmm_launch_near(S, x, y, transpose, st); if (rc) return rc; }
   // far field: forward T (e^-), D grouped by field, S (e^+); transpose S^T (e^+), D grouped by source, T^T (e^-)
   const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
@@ -1346,7 +1486,10 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   ma_slfmm* F = S->leaf;
   MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
-  { int rc = slfmm_launch_near(F, x, y, 0, st); if (rc) return rc; }
+  // round 4: with a far field, the near blocks' products run on the leaf operator's second stream beside the whole far chain
+  const bool two = S->far_field && slfmm_overlap_ready(F);
+  if (two) { int rc = slfmm_fork_near(F, x, 0, st); if (rc) return rc; }
+  else { int rc = slfmm_launch_near(F, x, y, 0, st); if (rc) return rc; }
   if (!S->far_field) return MA_OK;
   // upward pass: leaf multipoles, then level by level to the top level that has far pairs
   { int rc = slfmm_launch_up(F, -1.0, x, st); if (rc) return rc; }
@@ -1360,12 +1503,25 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     hipLaunchKernelGGL(mlfmm_m2m_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, Mc, reinterpret_cast<dc*>(L.d_M));
     MA_HIP(hipGetLastError());
   }
-  // translation at every level
+  // translation at every level: the levels whose dense D takes the small-tile kernel travel in ONE launch (MA_FMM_BATCH_LEVELS=0: a launch per level)
+  static const bool batch_levels = [] { const char* e = getenv("MA_FMM_BATCH_LEVELS"); return !(e && atoi(e) == 0); }();
+  FmmLevels V; V.nl = 0; V.first[0] = 0;
+  auto add_or_launch = [&](const int* fptr, const int* foth, const c64* fval, const c64* dense, int nc, int P, const c64* up, c64* tr) -> int {
+    if (batch_levels && V.nl < 8 && fmm_translate_batchable(dense, nc, P)) {
+      const int q = V.nl++;
+      V.rows[q] = (nc + 15) / 16; V.nc[q] = nc; V.P[q] = P;
+      V.DT[q] = reinterpret_cast<const dc*>(dense); V.up[q] = reinterpret_cast<const dc*>(up); V.tr[q] = reinterpret_cast<dc*>(tr);
+      V.first[q + 1] = V.first[q] + V.rows[q] * ((P + 31) / 32);
+      return MA_OK;
+    }
+    return fmm_launch_translate(fptr, foth, fval, dense, nc, P, up, tr, st);
+  };
   for (int l = 0; l < nu; ++l) {
     MlLevel& L = S->up[(size_t)l];
-    { int rc = fmm_launch_translate(L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.nc, L.P, L.d_M, L.d_L, st); if (rc) return rc; }
+    { int rc = add_or_launch(L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.nc, L.P, L.d_M, L.d_L); if (rc) return rc; }
   }
-  { int rc = fmm_launch_translate(F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr, st); if (rc) return rc; }
+  { int rc = add_or_launch(F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr); if (rc) return rc; }
+  { int rc = fmm_launch_translate_levels(V, st); if (rc) return rc; }
   // downward pass
   for (int l = 0; l < nu; ++l) {
     MlLevel& L = S->up[(size_t)l];
@@ -1375,6 +1531,12 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     dc* Lc = reinterpret_cast<dc*>(below_is_leaf ? F->d_tr : S->up[(size_t)l + 1].d_L);
     hipLaunchKernelGGL(mlfmm_l2l_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, reinterpret_cast<const dc*>(L.d_L), Lc);
     MA_HIP(hipGetLastError());
+  }
+  if (two) {
+    // the far field's share per dof into the leaf operator's own vector (elements in one cluster each), then the near field's second
+    // pass adds the two; with overlapping leaves both accumulate into the cleared y with atomics, as before
+    if (!F->overlap) { int rc = slfmm_launch_down(F, 1.0, reinterpret_cast<dc*>(F->d_yfar), st, true); if (rc) return rc; }
+    return slfmm_join_near(F, y, 1.0, st);
   }
   { int rc = slfmm_launch_down(F, 1.0, y, st); if (rc) return rc; }
   return MA_OK;

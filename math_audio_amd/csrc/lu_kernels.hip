@@ -1235,7 +1235,10 @@ __global__ __launch_bounds__(256) void lu_lane_step_kernel(dc* __restrict__ A, i
   if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) return;      // an aborted panel has no valid pivots: no rows are moved
   auto& V = S.strip;
   int m = lists[0];
-  if (m < 0 || m > 2 * LU_NB_MAX) m = 0;
+  // a list longer than the 2 nb entries a panel of nb columns can produce (the register stash below holds 64) is a corrupted or stale
+  // list: the panel counts as abandoned -- the plan is poisoned (MA_ERR_HIP at ma_lu_plan_status) and no rows move, as lu_fold_pivots
+  // does for a pivot outside its range
+  if (m < 0 || m > 2 * nb) { if (tid == 0 && poison) __hip_atomic_store(const_cast<unsigned*>(poison), 2u, RLX_AGENT); return; }
   for (int i = tid; i < m; i += 256) { V.dst[i] = lists[1 + i]; V.src[i] = lists[1 + 2 * LU_NB_MAX + i]; }
   const int c0 = x0 + 32 * (int)blockIdx.x;              // first column of the strip
   const int wcols = min(32, x0 + ncols - c0);
@@ -1315,8 +1318,15 @@ __global__ __launch_bounds__(256) void lu_lane_step2_kernel(dc* __restrict__ A, 
   if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) return;      // an aborted panel has no valid pivots: no rows are moved
   auto& V = S.strip;
   const int h1 = min(nb, LU_REG_NB);
-  if (tid < 2) { int m = (tid == 0 ? lists1 : lists2)[0]; if (m < 0 || m > 2 * LU_REG_NB) m = 0; if (tid == 1 && nb <= LU_REG_NB) m = 0; V.m[tid] = m; }
+  if (tid < 2) {
+    int m = (tid == 0 ? lists1 : lists2)[0];
+    if (tid == 1 && nb <= LU_REG_NB) m = 0;
+    // (as in lu_lane_step_kernel: a list beyond what a half-panel can produce poisons the plan and moves no rows)
+    if (m < 0 || m > 2 * LU_REG_NB) { m = -1; if (poison) __hip_atomic_store(poison, 2u, RLX_AGENT); }
+    V.m[tid] = m;
+  }
   __syncthreads();
+  if (V.m[0] < 0 || V.m[1] < 0) return;
   for (int q = 0; q < 2; ++q) {
     const int* ls = q == 0 ? lists1 : lists2;
     for (int i = tid; i < V.m[q]; i += 256) { V.dst[q][i] = ls[1 + i]; V.src[q][i] = ls[1 + 2 * LU_NB_MAX + i]; }

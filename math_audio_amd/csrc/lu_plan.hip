@@ -246,8 +246,11 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (!P->reg_panel) P->pan_mask = 0;                   // the LDS-resident panel kernel's grid does not fit a small CU set: only the big updates are masked
     if (!P->reg_panel && !getenv("MA_LU_CU_SPLIT")) P->cu_split = 0;   // the default split comes with the register panels only
     P->reg_panel0 = P->reg_panel; P->reg_pair0 = P->reg_pair;
-    P->block_step = P->reg_panel && P->reg_pair;
-    if (const char* eb = getenv("MA_LU_BLOCK_STEP")) P->block_step = atoi(eb) != 0;
+    // measured (profiles/r04_lu_schedule_experiments.md): three launches per block instead of 31 shorten every slot's chain (the stream's
+    // waits 4.3 -> 3.8 ms per frequency) but the fused kernel's 157 four-wavefront workgroups cost the big updates what the chain gains
+    // (49.5 against 49.3 ms per frequency; 51.8 against 48.6 with eight panels per block): built, tested, off by default
+    P->block_step = false;
+    if (const char* eb = getenv("MA_LU_BLOCK_STEP")) P->block_step = atoi(eb) != 0 && P->reg_panel && P->reg_pair;
   }
   for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
   if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
@@ -419,7 +422,8 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     if (rc || h2 <= 0) return rc;
     const int a1 = k0 + h1;
     if ((rc = lu_launch_lane_step(A, n, k0, h1, P->d_half_lists[m], a1, h2, P->d_half_invd[m], P->pws.timeout, st))) return rc;
-    if ((rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m, false, &P->zmode))) return rc;
+    static const int skip_k32 = [] { const char* e = getenv("MA_DIAG_SKIP_LANE_GEMM"); return e ? atoi(e) : 0; }();   // diagnostic only (wrong results)
+    if (skip_k32 < 32 && (rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m, false, &P->zmode))) return rc;
     // (the right half's interchanges on the LEFT half's columns -- part of the interchange itself inside a 64-column panel kernel --
     // are the first job of lu_lane_step2_kernel, which every caller launches next)
     return lu_launch_panel_reg(A, n, a1, h2, (n - a1 + 255) / 256, cus, ws, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, false, st, P->d_half_l10[m], k0);
@@ -752,6 +756,9 @@ struct Stage {
   hipStream_t big_stream() const { return P->cu_split ? P->big_stream : st; }
   int gemm(int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_, bool big_ = false) {
     if (M_ <= 0 || N_ <= 0 || K_ <= 0) return MA_OK;
+    // DIAGNOSTIC ONLY (wrong results): what the lanes' small updates cost the step -- MA_DIAG_SKIP_LANE_GEMM=<max K> drops them
+    static const int skip_k = [] { const char* e = getenv("MA_DIAG_SKIP_LANE_GEMM"); return e ? atoi(e) : 0; }();
+    if (!big_ && skip_k > 0 && K_ <= skip_k) return MA_OK;
     P->n_gemm_launch++; P->gemm_flops += 8.0 * M_ * (double)N_ * K_; P->gemm_cbytes += 32.0 * M_ * (double)N_;
     if (big_) { P->n_big_launch++; P->big_flops += 8.0 * M_ * (double)N_ * K_; }
     return lu_launch_zgemm_sub(M_, N_, K_, a, (size_t)n, b_, (size_t)n, c, (size_t)n, s_, P->use_3m, big_, &P->zmode);
@@ -936,6 +943,9 @@ int ma_lu_plan_num_blocks(ma_lu_plan_t* P, int32_t* blocks) {
 int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
   MA_REQUIRE(P, MA_ERR_INVALID, "NULL plan");
   MA_REQUIRE(P->lookahead && P->panel_overlap, MA_ERR_UNSUPPORTED, "the staged schedule needs the look-ahead lanes (MA_LU_LOOKAHEAD / MA_LU_PANEL_OVERLAP)");
+  // a plan that splits the chip runs its big updates on a CU-masked stream, which is a BLOCKING stream: a driver on the NULL stream would
+  // serialise against it at every launch and lose the lanes' overlap without any error
+  MA_REQUIRE(!(P->cu_split && stream == nullptr), MA_ERR_INVALID, "this plan splits the chip: drive its staged schedule from ma_lu_plan_main_stream (or any non-blocking stream), not from the NULL stream");
   MA_HIP(hipSetDevice(P->device));
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -978,6 +988,7 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
   MA_REQUIRE(slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "slot %d outside 0..%d", slot, LU_BATCH_MAX - 1);
   MA_REQUIRE(nrhs >= 0 && nrhs <= P->nrhs_max && (nrhs == 0 || dB), MA_ERR_DIM, "nrhs must be 0..%d", P->nrhs_max);
   MA_REQUIRE(P->lookahead && P->panel_overlap, MA_ERR_UNSUPPORTED, "the staged schedule needs the look-ahead lanes");
+  MA_REQUIRE(!(P->cu_split && stream == nullptr), MA_ERR_INVALID, "this plan splits the chip: drive its staged schedule from ma_lu_plan_main_stream (or any non-blocking stream), not from the NULL stream");
   MA_HIP(hipSetDevice(P->device));
   int rc = P->ensure_batch(slot + 1);
   if (rc) return rc;

@@ -12,6 +12,9 @@
 #include <complex>
 #include <new>
 #include <cmath>
+#include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types and prototypes only: the library is bound at first use (dlopen), not at link time
 
 using namespace ma;
 typedef std::complex<double> cplx;
@@ -61,6 +64,7 @@ struct ma_op {
   // kind 8: one RANK's row block of an operator whose rows are spread over processes: `inner` (not owned) writes rows [row0, row1)
   // of y, then the caller's exchange (an all-gather over the ranks' communicator: RCCL with the "nccl" backend) completes y
   ma_op* inner = nullptr; ma_gather_fn gather = nullptr; void* gather_user = nullptr;
+  void (*gather_free)(void*) = nullptr;   // set when the library owns gather_user (ma_op_create_gathered_rccl)
 };
 
 extern "C" int ma_op_destroy(ma_op_t* o);
@@ -85,6 +89,7 @@ void op_free(ma_op* o) {
   void* p[] = {o->d_corr, o->d_diag, o->d_partial, o->d_x, o->d_y, o->d_tpart, o->d_cx, o->d_t_off, o->d_t_idx, o->d_tpartial};
   for (void* q : p) if (q) (void)hipFree(q);
   if (o->csr_t) (void)ma_csr_destroy(o->csr_t);
+  if (o->gather_free && o->gather_user) { o->gather_free(o->gather_user); o->gather_user = nullptr; }
 }
 int op_stage(ma_op* o) {
   MA_HIP(hipMalloc(&o->d_x, sizeof(c64) * (size_t)o->n));
@@ -319,6 +324,114 @@ int ma_op_create_gathered(ma_op_t* inner, int64_t row0, int64_t row1, ma_gather_
   *out = o;
   return MA_OK;
 }
+// ---- RCCL inside the library (round 4; north_star: "RCCL over xGMI only for the block reductions"): the row exchange of a rank-sharded
+// operator as ncclAllGather on the operator's stream, so that a host that keeps one rank per GPU needs no callback per apply. librccl is
+// bound at first use with dlopen -- in a process that already holds a copy (torch.distributed's "nccl" backend brings its own) the
+// loader hands back THAT copy, so a communicator and the collective always come from one library instance; a process that never
+// shards rows never loads it. Communicators are made through ma_rccl_comm_create or by the caller with the same librccl.
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) { api.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (api.h) break; }
+    if (!api.h) return;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+  });
+  return &api;
+}
+#define MA_RCCL(call)                                                                                        \
+  do {                                                                                                       \
+    ncclResult_t r_ = (call);                                                                                \
+    if (r_ != ncclSuccess) { set_error("%s failed: %s", #call, R->GetErrorString(r_)); return MA_ERR_HIP; }  \
+  } while (0)
+struct RcclGather { ncclComm_t comm; int nranks, rank; long long per; c64* stage; int device; };
+void rccl_gather_free(void* u) {
+  RcclGather* g = (RcclGather*)u;
+  if (g->stage) { (void)hipSetDevice(g->device); (void)hipFree(g->stage); }
+  delete g;
+}
+// ma_gather_fn: this rank's rows of y -> its block of the staging vector (equal blocks of `per` rows, the last one padded),
+// ncclAllGather in place, the first n entries back into y; all on `stream`
+int rccl_gather_cb(void* user, void* d_y, int64_t n, int64_t row0, int64_t row1, void* stream) {
+  RcclGather* g = (RcclGather*)user;
+  RcclApi* R = rccl_api();
+  hipStream_t st = (hipStream_t)stream;
+  c64* y = (c64*)d_y; c64* mine = g->stage + (size_t)g->rank * (size_t)g->per;
+  if (row1 - row0 < g->per && hipMemsetAsync(mine, 0, sizeof(c64) * (size_t)g->per, st) != hipSuccess) return -2;
+  if (row1 > row0 && hipMemcpyAsync(mine, y + row0, sizeof(c64) * (size_t)(row1 - row0), hipMemcpyDeviceToDevice, st) != hipSuccess) return -3;
+  const ncclResult_t r = R->AllGather(mine, g->stage, 2 * (size_t)g->per, ncclDouble, g->comm, st);
+  if (r != ncclSuccess) { set_error("ncclAllGather failed: %s", R->GetErrorString(r)); return -4; }
+  if (hipMemcpyAsync(y, g->stage, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return -5;
+  return 0;
+}
+}  // namespace
+
+int ma_rccl_get_unique_id(void* id128) {
+  MA_REQUIRE(id128, MA_ERR_INVALID, "NULL argument");
+  RcclApi* R = rccl_api();
+  MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  MA_RCCL(R->GetUniqueId((ncclUniqueId*)id128));
+  return MA_OK;
+}
+int ma_rccl_comm_create(int32_t nranks, int32_t rank, const void* id128, int device, void** comm) {
+  MA_REQUIRE(comm && id128 && nranks >= 1 && rank >= 0 && rank < nranks, MA_ERR_INVALID, "bad argument");
+  *comm = nullptr;
+  RcclApi* R = rccl_api();
+  MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded");
+  int rc = use_device(device);
+  if (rc) return rc;
+  ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  MA_RCCL(R->CommInitRank(&c, nranks, id, rank));
+  *comm = (void*)c;
+  return MA_OK;
+}
+int ma_rccl_comm_destroy(void* comm) {
+  if (!comm) return MA_OK;
+  RcclApi* R = rccl_api();
+  MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded");
+  MA_RCCL(R->CommDestroy((ncclComm_t)comm));
+  return MA_OK;
+}
+// ma_op_create_gathered with the exchange inside the library: rank `rank` of `nranks` holds rows [rank * per, min(n, (rank + 1) * per)),
+// per = ceil(n / nranks) (the row_block rule of sharded.py and of ma_op_create_tbem_multi), and every apply ends with one
+// ncclAllGather of per rows per rank on the apply's stream. `inner` is not owned; the communicator stays the caller's.
+int ma_op_create_gathered_rccl(ma_op_t* inner, void* nccl_comm, int32_t nranks, int32_t rank, ma_op_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL"); *out = nullptr;
+  MA_REQUIRE(inner && nccl_comm && nranks >= 1 && rank >= 0 && rank < nranks, MA_ERR_INVALID, "bad argument");
+  RcclApi* R = rccl_api();
+  MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded");
+  const long long n = inner->n, per = (n + nranks - 1) / nranks;
+  const long long row0 = std::min(n, (long long)rank * per), row1 = std::min(n, row0 + per);
+  MA_REQUIRE(inner->kind != 2 || (inner->row0 == row0 && inner->row1 == row1), MA_ERR_INVALID,
+             "rank %d of %d owns rows [%lld, %lld); the inner operator was created for [%d, %d)", rank, nranks, row0, row1, inner->row0, inner->row1);
+  RcclGather* g = new (std::nothrow) RcclGather{(ncclComm_t)nccl_comm, nranks, rank, per, nullptr, inner->device};
+  MA_REQUIRE(g, MA_ERR_NOMEM, "host allocation failed");
+  (void)hipSetDevice(inner->device);
+  if (hipMalloc(&g->stage, sizeof(c64) * (size_t)per * (size_t)nranks) != hipSuccess) { delete g; set_error("rank-sharded operator: the gather's staging vector does not fit"); return MA_ERR_NOMEM; }
+  int rc = ma_op_create_gathered(inner, row0, row1, rccl_gather_cb, g, out);
+  if (rc) { rccl_gather_free(g); return rc; }
+  (*out)->gather_free = rccl_gather_free;
+  return MA_OK;
+}
+
 int ma_op_destroy(ma_op_t* o) {
   if (!o) return MA_OK;
   (void)hipSetDevice(o->device);

@@ -132,6 +132,47 @@ def test_pair_panels_match_lapack(gpu, n):
     assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-13 * (np.linalg.cond(A) if n <= 400 else 1e4)
 
 
+@pytest.mark.parametrize("n", [66, 130, 450, 777, 1500, 2100])
+def test_block_step_matches_lapack(gpu, n):
+    """MA_LU_BLOCK_STEP=1 (round 4; built, measured neutral, off by default): the main lane's per-panel launches of a block of six
+    64-column panels -- 12 gathers / scatters, 6 triangular solves, 6 zgemv, 5 in-block updates -- as lu_block_row_moves_kernel (every
+    panel's interchanges on a strip of columns, panel after panel) + lu_block_trsm_kernel (U12 of the whole block row left-looking on
+    the matrix cores, the right-hand side riding along) + one zgemv: LAPACK's pivots and solution; ragged last panels and blocks."""
+    import scipy.linalg as sla
+    A, b = _rand(n, 5000 + n)
+    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64, MA_LU_BLOCK_STEP=1):
+        x, piv = ma.zgesv(A, b, return_pivots=True)
+        F = ma.LuFactorization(A)                            # the stored factors serve later right-hand sides (the row order of L is LAPACK's)
+        x2 = F.solve(2.0 * b)
+        F.close()
+    _, piv_ref = sla.lu_factor(A)
+    assert np.array_equal(piv, piv_ref)
+    xr = np.linalg.solve(A, b)
+    res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
+    assert res <= 1e-14 * n
+    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-13 * (np.linalg.cond(A) if n <= 400 else 1e4)
+    assert np.linalg.norm(x2 - 2.0 * xr) / np.linalg.norm(xr) <= 1e-12 * (np.linalg.cond(A) if n <= 400 else 1e4)
+
+
+def test_split_plan_refuses_the_null_stream_for_its_staged_schedule(gpu):
+    """ADVICE r3: a plan that splits the chip runs its big updates on a CU-masked stream, which the runtime makes as a BLOCKING stream;
+    a driver on the NULL stream would serialise against every update and silently lose the lanes' overlap: stage_reset / stage_begin
+    say so (MA_ERR_INVALID) instead."""
+    import torch
+    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64):
+        lu = ma.LuPlan(900)
+    assert lu.main_stream()
+    with pytest.raises(ma.MaError) as e:
+        lu.stage_reset(0)
+    assert e.value.status == ma.MA_ERR_INVALID
+    A = torch.zeros(900 * 900, dtype=torch.complex128, device="cuda"); b = torch.zeros(900, dtype=torch.complex128, device="cuda")
+    with pytest.raises(ma.MaError) as e:
+        lu.stage_begin(0, A.data_ptr(), b.data_ptr(), 1, 0)
+    assert e.value.status == ma.MA_ERR_INVALID
+    lu.stage_reset(lu.main_stream())                         # the plan's own stream is fine
+    lu.close()
+
+
 def test_default_schedule_of_a_4200_row_plan(gpu):
     """4 096-16 384 rows: the plan splits the chip by default (ma_lu_plan_main_stream is the masked update stream) and factors with
     the register pair panels and the LDS-DMA update kernel; pivots and solution against LAPACK at a size inside that range."""
@@ -270,10 +311,11 @@ def test_lu_factorize_then_solve_and_lu_solve(gpu, n):
     assert e.value.status == ma.MA_ERR_SINGULAR
 
 
-_SCHEDULES = {"default": {}, "pair": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64}, "pair_tail": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64, "MA_LU_TAIL_ROWS": 400}}
+_SCHEDULES = {"default": {}, "pair": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64}, "pair_tail": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64, "MA_LU_TAIL_ROWS": 400},
+              "pair_block": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64, "MA_LU_BLOCK_STEP": 1}}
 
 
-@pytest.mark.parametrize("sched", ["default", "pair", "pair_tail"])
+@pytest.mark.parametrize("sched", ["default", "pair", "pair_tail", "pair_block"])
 def test_staged_pipeline_is_bitwise_the_single_solve(gpu, sched):
     """The staged plan API (slots at their own block index, staggered by a fraction of a factorisation) runs the same kernels on
     the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit. `pair`: the

@@ -63,3 +63,39 @@ def test_two_ranks_one_gpu_library_gmres(gpu):
             if p.is_alive():
                 p.kill()
     assert len(res) == 2 and all(r[1] for r in res), res
+
+
+def test_rccl_gather_inside_the_library_world_of_one(gpu):
+    """ma_op_create_gathered_rccl: the row exchange of a rank-sharded operator as ncclAllGather inside the library,
+    on a communicator made through ma_rccl_get_unique_id / ma_rccl_comm_create. One GPU gives a world of one (RCCL refuses two ranks
+    on one device): the block is the whole operator, the collective runs on the apply's stream, and GMRES over the handle must be
+    the plain operator's iteration. The row-block rule (per = ceil(n / nranks)) is checked against sharded.row_block.
+    UNMEASURED on more than one GPU."""
+    import oracle_lib as O
+    import math_audio_amd as ma
+    from math_audio_amd import sharded
+    from helpers import to_ma_mesh, k_from_ka, RADIUS
+    om = O.icosphere(RADIUS, 2)
+    n = om.n_elem
+    k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    uid = ma.rccl_unique_id()
+    assert len(uid) == 128
+    comm = ma.RcclComm(1, 0, uid, device=0)
+    inner = ma.LinearOperator.tbem(plan, k, beta, rows=sharded.row_block(n, 0, 1))
+    gop = ma.LinearOperator.gathered_rccl(inner, comm, 1, 0)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    assert np.array_equal(gop.apply(x), inner.apply(x))
+    b = ma.incident_rhs(om.center, om.normal, k, beta)
+    xg, ig = ma.gmres(gop, b, restart=30, max_iterations=10, tol=1e-8)
+    xr, ir = ma.gmres(inner, b, restart=30, max_iterations=10, tol=1e-8)
+    assert ig.converged == 1 and ig.iterations == ir.iterations and np.array_equal(xg, xr)
+    # a row block that is not this rank's is refused
+    wrong = ma.LinearOperator.tbem(plan, k, beta, rows=(0, n // 2))
+    with pytest.raises(ma.MaError) as e:
+        ma.LinearOperator.gathered_rccl(wrong, comm, 1, 0)
+    assert e.value.status == ma.MA_ERR_INVALID
+    for o in (gop, inner, wrong):
+        o.close()
+    comm.close(); plan.close()
