@@ -233,6 +233,8 @@ int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);
  * only kind the runtime makes with a CU mask): stage_reset / stage_begin refuse the NULL stream on such a plan (MA_ERR_INVALID) -- work on
  * the NULL stream would serialise against every big update. */
 int ma_lu_plan_main_stream(ma_lu_plan_t* plan, void** stream);
+/* CUs the plan leaves to its panel kernels (0: the chip is not split) and the chip's CU count */
+int ma_lu_plan_cu_split(ma_lu_plan_t* plan, int32_t* panel_cus, int32_t* total_cus);
 /* rounds between the starts of two of `slots` slots that the plan's kernels were measured best with (a driver of the staged
  * schedule starts slot s at round s * spacing; ma_bem_solve_sweep and bench.py do) */
 int ma_lu_plan_stage_spacing(ma_lu_plan_t* plan, int32_t slots, int32_t* spacing);

@@ -36,7 +36,7 @@ struct ma_slfmm {
   int* d_tptr = nullptr; int* d_toth = nullptr; c64* d_tval = nullptr;      // grouped by source cluster (transpose)
   c64* d_fdense = nullptr; c64* d_tdense = nullptr;                         // the same two as dense nc x nc matrices, when the lists are nearly full
   int* d_bsrc = nullptr; int* d_bfld = nullptr; long long* d_boff = nullptr; int nblocks = 0;   // the near blocks one by one
-  long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0, max_width = 0;   // their partial sums (rows, columns)
+  long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0, max_width = 0, max_rows = 0;   // their partial sums (rows, columns)
   c64* d_up = nullptr; c64* d_tr = nullptr;
   c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=0: recomputed)
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
@@ -391,9 +391,8 @@ static int fmm_launch_translate(const int* fptr, const int* foth, const c64* fva
 // multipoles stand, and each alone fills a fraction of the chip (a top level has a handful of clusters); the same workgroup body as
 // fmm_translate_dense_kernel<KS, 2>, the level picked from the block index.
 struct FmmLevels { int nl; int first[9]; int rows[8]; int nc[8]; int P[8]; const dc* DT[8]; const dc* up[8]; dc* tr[8]; };
-template <int KS>
+template <int KS, int NT>
 __global__ __launch_bounds__(64 * KS) void fmm_translate_levels_kernel(FmmLevels V) {
-  constexpr int NT = 2;
   __shared__ dc part[16 * 16 * NT];
   int l = 0;
   while (l + 1 < V.nl && (int)blockIdx.x >= V.first[l + 1]) ++l;
@@ -461,9 +460,19 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_levels_kernel(FmmLevels
 }
 // would fmm_launch_translate take the <KS, 2> dense kernel for this level? (those are the levels the batched launch can carry)
 static bool fmm_translate_batchable(const c64* dense, int nc, int P) { return dense && ((nc + 15) / 16) * ((P + 127) / 128) < 1024; }
-static int fmm_launch_translate_levels(const FmmLevels& V, hipStream_t st) {
+// points per workgroup of the batched launch: 16 NT with NT = 2 / 5 / 8 by the sphere rule of the level that carries the most work (the
+// last one listed: the leaves): P = 72 (6 x 12 points) fits NT = 5, so D is read once per level instead of three times
+static int fmm_levels_nt(int P) {
+  static const int forced = [] { const char* e = getenv("MA_FMM_LEVELS_NT"); return e ? atoi(e) : 0; }();
+  if (forced == 2 || forced == 5 || forced == 8) return forced;
+  (void)P;
+  return 2;                                                  // measured: 32 points per workgroup (221 us on the 50k tree) beat 80 (249 us): more workgroups, the D rows come from L2
+}
+static int fmm_launch_translate_levels(const FmmLevels& V, int nt, hipStream_t st) {
   if (V.nl <= 0) return MA_OK;
-  hipLaunchKernelGGL(fmm_translate_levels_kernel<8>, dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
+  if (nt == 2) hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 2>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
+  else if (nt == 5) hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 5>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
+  else hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 8>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }
@@ -514,9 +523,10 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
                                                                 const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
   __shared__ dc cpart[WPB == 1 ? 1 : 4 * 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = WPB == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
   const int w = WPB == 1 ? 0 : wave;
-  if (b >= nblocks) return;                                  // WPB == 1: no barrier below; WPB == 4: the whole workgroup leaves
+  // grid-stride over the blocks (round 4): the launch may be capped at a few workgroups per CU, so that the kernels of the far
+  // chain on the other stream find free slots beside it (uncapped, its tens of thousands of workgroups kept them waiting)
+  for (int b = WPB == 1 ? blockIdx.x * 4 + wave : blockIdx.x; b < nblocks; b += WPB == 1 ? gridDim.x * 4 : gridDim.x) {   // WPB == 4: uniform over the workgroup
   const int a = bsrc[b], f = bfld[b];
   const int a0 = eptr[a], ns = eptr[a + 1] - a0, f0 = eptr[f], nf = eptr[f + 1] - f0;
   const dc* B = bval + boff[b];
@@ -572,50 +582,75 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
       }
     }
   }
+  }
 }
 // Large blocks (wider than one lane set): the same two products with the rows outside and the column chunks inside. A lane keeps
 // x[cols] of its NCH <= 8 chunks and their column sums in registers, a row is reduced over the lanes ONCE (not once per chunk) and
 // written once. One workgroup per block, the four wavefronts take rows w, w + 4, ...; their column sums meet in LDS in wavefront order.
 constexpr int FMM_NCH = 8;
+constexpr int FMM_WIDE_ROWS = 512;                            // rows of a block whose x entries are staged in LDS (taller blocks read x per row)
+template <int NCH>   // column chunks of 64 a lane may hold: 2 / 4 (next rows prefetched) / 8
 __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ bsrc,
                                                                      const int* __restrict__ bfld, const long long* __restrict__ boff,
                                                                      const long long* __restrict__ broff, const long long* __restrict__ bcoff, int nblocks,
                                                                      const dc* __restrict__ bval, const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
-  __shared__ dc cpart[4 * 64 * FMM_NCH];
+  __shared__ dc cpart[4 * 64 * NCH];
+  constexpr bool PIPE = NCH <= 4;
+  __shared__ dc xrow[FMM_WIDE_ROWS];                          // round 4: x of the block's rows, gathered once (the row loop then holds block loads only)
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x;
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {    // grid-stride (see slfmm_near_blocks_kernel)
   const int a = bsrc[b], f = bfld[b];
   const int a0 = eptr[a], ns = eptr[a + 1] - a0, f0 = eptr[f], nf = eptr[f + 1] - f0;
   const dc* B = bval + boff[b];
   const bool both = a != f, self_t = !both && tmode != 0;
   dc* prow = part + broff[b];
   dc* pcol = both ? part + bcoff[b] : prow;
-  const int nch = (nf + 63) >> 6;                            // <= FMM_NCH (the launcher's choice)
-  dc xf[FMM_NCH]; double cr[FMM_NCH], ci[FMM_NCH];
+  const int nch = (nf + 63) >> 6;                            // <= NCH (the launcher's choice)
+  const bool staged = ns <= FMM_WIDE_ROWS;
+  if (staged) for (int i = threadIdx.x; i < ns; i += 256) xrow[i] = x[edof[a0 + i]];
+  dc xf[NCH]; double cr[NCH], ci[NCH];
 #pragma unroll
-  for (int ch = 0; ch < FMM_NCH; ++ch) {
+  for (int ch = 0; ch < NCH; ++ch) {
     const int j = ch * 64 + lane;
     xf[ch] = (ch < nch && j < nf) ? x[edof[f0 + j]] : dc_make(0.0, 0.0);
     cr[ch] = 0.0; ci[ch] = 0.0;
   }
+  __syncthreads();
   constexpr int U = 4;
+  // the next rows' entries are fetched while this iteration's products run (two sets of U x nch loads in flight per lane)
+  dc bb[PIPE ? NCH : 1][U], bn[PIPE ? NCH : 1][U];
+  auto fetch = [&](int i0, dc (*dst)[U]) {
+#pragma unroll
+    for (int ch = 0; ch < (PIPE ? NCH : 1); ++ch)
+      if (ch < nch) {
+        const int j = ch * 64 + lane;
+        const int jc = j < nf ? j : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; dst[ch][u] = B[(long long)(i < ns ? i : i0) * nf + jc]; }
+      }
+  };
+  if (PIPE && w < ns) fetch(w, bb);
   for (int i0 = w; i0 < ns; i0 += 4 * U) {
+    const bool more = PIPE && i0 + 4 * U < ns;
+    if constexpr (PIPE) { if (more) fetch(i0 + 4 * U, bn); }
     dc xa[U]; double pr[U], pi[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; xa[u] = x[edof[a0 + (i < ns ? i : i0)]]; pr[u] = 0.0; pi[u] = 0.0; }
+    for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; const int ii = i < ns ? i : i0; xa[u] = staged ? xrow[ii] : x[edof[a0 + ii]]; pr[u] = 0.0; pi[u] = 0.0; }
 #pragma unroll
-    for (int ch = 0; ch < FMM_NCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
       if (ch < nch) {                                        // uniform
         const int j = ch * 64 + lane;
         const bool vj = j < nf;
-        dc bb[U];
+        if constexpr (!PIPE) {                               // many chunks: this chunk's U loads only (the whole row set would take every register)
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; bb[u] = B[(long long)(i < ns ? i : i0) * nf + (vj ? j : 0)]; }
+          for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; bb[0][u] = B[(long long)(i < ns ? i : i0) * nf + (vj ? j : 0)]; }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (vj && i0 + 4 * u < ns) {
-            pr[u] += bb[u].re * xf[ch].re - bb[u].im * xf[ch].im; pi[u] += bb[u].re * xf[ch].im + bb[u].im * xf[ch].re;
-            cr[ch] += bb[u].re * xa[u].re - bb[u].im * xa[u].im; ci[ch] += bb[u].re * xa[u].im + bb[u].im * xa[u].re;
+            const dc v = bb[PIPE ? ch : 0][u];
+            pr[u] += v.re * xf[ch].re - v.im * xf[ch].im; pi[u] += v.re * xf[ch].im + v.im * xf[ch].re;
+            cr[ch] += v.re * xa[u].re - v.im * xa[u].im; ci[ch] += v.re * xa[u].im + v.im * xa[u].re;
           }
         }
       }
@@ -626,19 +661,32 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
       const int i = i0 + 4 * u;
       if (lane == 0 && i < ns && !self_t) prow[i] = dc_make(sr, si);
     }
+    if constexpr (PIPE) {
+      if (more) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+          for (int u = 0; u < U; ++u) bb[ch][u] = bn[ch][u];
+      }
+    }
   }
   if (both || self_t) {                                      // uniform over the block
 #pragma unroll
-    for (int ch = 0; ch < FMM_NCH; ++ch) if (ch < nch) cpart[(w * FMM_NCH + ch) * 64 + lane] = dc_make(cr[ch], ci[ch]);
+    for (int ch = 0; ch < NCH; ++ch) if (ch < nch) cpart[(w * NCH + ch) * 64 + lane] = dc_make(cr[ch], ci[ch]);
     __syncthreads();
     for (int j = threadIdx.x; j < nf; j += 256) {
       const int ch = j >> 6, l = j & 63;
       double tr_ = 0.0, ti_ = 0.0;
-      for (int q = 0; q < 4; ++q) { tr_ += cpart[(q * FMM_NCH + ch) * 64 + l].re; ti_ += cpart[(q * FMM_NCH + ch) * 64 + l].im; }
+      for (int q = 0; q < 4; ++q) { tr_ += cpart[(q * NCH + ch) * 64 + l].re; ti_ += cpart[(q * NCH + ch) * 64 + l].im; }
       pcol[j] = dc_make(tr_, ti_);
     }
   }
+  __syncthreads();                                           // cpart and xrow are reused by the workgroup's next block
+  }
 }
+// (Round 4, measured and removed: the wide blocks CHUNK-major -- one chunk's x and column sum per lane, the rows' sums waiting in LDS
+// between chunks, 86 registers instead of 196 and twice the wavefronts per SIMD -- takes 233 us where the kernel above takes 160 on the
+// 50k box: a row reduced over the lanes once per chunk costs more than the occupancy buys. profiles/r04_fmm_apply.md)
 template <int WPC>
 __global__ __launch_bounds__(256) void slfmm_near_gather_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ cptr,
                                                                 const SlfmmEntry* __restrict__ cent, const dc* __restrict__ part, dc* __restrict__ y,
@@ -790,13 +838,23 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
   int G = 8; while (G < 64 && G < avg) G <<= 1;
   if (S->d_part) {
     const dc* bv = reinterpret_cast<const dc*>(S->d_bval); dc* part = reinterpret_cast<dc*>(S->d_part);
+    // beside the far chain (pass 1 on the second stream) the grid MAY be capped at MA_FMM_NEAR_WGS_PER_CU workgroups per CU (measured:
+    // every cap from 1 to 8 loses -- the near pass slows by more than the far chain gains; uncapped by default)
+    static const int cap_per_cu = [] { const char* e = getenv("MA_FMM_NEAR_WGS_PER_CU"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+    const unsigned cap = (pass == 1 && cap_per_cu > 0) ? (unsigned)(256 * cap_per_cu) : 0xFFFFFFFFu;
+    auto grid = [&](long long want) { return dim3((unsigned)std::min<long long>(want, (long long)cap)); };
     if (pass == 2) { /* second pass only */ }
-    else if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, dim3((unsigned)((S->nblocks + 3) / 4)), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
+    else if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, grid((S->nblocks + 3) / 4), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
                                                    S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
-    else if (S->max_width <= 64 * FMM_NCH && !getenv("MA_FMM_WIDE_BLOCKS_OFF"))
-      hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
-                         S->d_bcoff, S->nblocks, bv, x, part, tmode);
-    else hipLaunchKernelGGL(slfmm_near_blocks_kernel<4>, dim3((unsigned)S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+    else if (S->max_width <= 64 * FMM_NCH && !getenv("MA_FMM_WIDE_BLOCKS_OFF")) {
+      if (S->max_width <= 128) hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<2>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+                                                  S->d_bcoff, S->nblocks, bv, x, part, tmode);
+      else if (S->max_width <= 256) hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<4>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+                                                       S->d_bcoff, S->nblocks, bv, x, part, tmode);
+      else hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<8>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+                              S->d_bcoff, S->nblocks, bv, x, part, tmode);
+    }
+    else hipLaunchKernelGGL(slfmm_near_blocks_kernel<4>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
                             S->d_bcoff, S->nblocks, bv, x, part, tmode);
     MA_HIP(hipGetLastError());
     if (pass == 1) return MA_OK;
@@ -976,7 +1034,7 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
     const long long ns = eptr[(size_t)bsrc[b] + 1] - eptr[(size_t)bsrc[b]], nf = eptr[(size_t)bfld[b] + 1] - eptr[(size_t)bfld[b]];
     broff[b] = npart; npart += ns;
     bcoff[b] = npart; if (bsrc[b] != bfld[b]) npart += nf;
-    max_block = std::max(max_block, ns * nf); S->max_width = std::max(S->max_width, nf);
+    max_block = std::max(max_block, ns * nf); S->max_width = std::max(S->max_width, nf); S->max_rows = std::max(S->max_rows, ns);
     views[(size_t)bsrc[b]].push_back({boff[b], broff[b], bfld[b], 0});
     if (bsrc[b] != bfld[b]) views[(size_t)bfld[b]].push_back({boff[b], bcoff[b], bsrc[b], 1});
   }
@@ -1050,7 +1108,11 @@ static bool slfmm_overlap_ready(ma_slfmm* S) {
     const char* e = getenv("MA_FMM_OVERLAP");
     S->overlap_streams = 0;
     if (!(e && atoi(e) == 0) && S->d_part && S->d_phase) {
-      bool ok = hipStreamCreateWithFlags(&S->st2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess &&
+      // the near blocks' stream at the LOWEST priority: its tens of thousands of short workgroups otherwise keep the far chain's few
+      // kernels waiting for slots (the first upward-pass kernel took 350 us instead of 15 beside them)
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      bool ok = hipStreamCreateWithPriority(&S->st2, hipStreamNonBlocking, lo) == hipSuccess && hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&S->ev_near, hipEventDisableTiming) == hipSuccess && hipMalloc(&S->d_yfar, sizeof(c64) * (size_t)S->n) == hipSuccess;
       if (ok) S->overlap_streams = 1; else (void)hipGetLastError();
     }
@@ -1506,12 +1568,13 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   // translation at every level: the levels whose dense D takes the small-tile kernel travel in ONE launch (MA_FMM_BATCH_LEVELS=0: a launch per level)
   static const bool batch_levels = [] { const char* e = getenv("MA_FMM_BATCH_LEVELS"); return !(e && atoi(e) == 0); }();
   FmmLevels V; V.nl = 0; V.first[0] = 0;
+  const int nt = fmm_levels_nt(F->P);
   auto add_or_launch = [&](const int* fptr, const int* foth, const c64* fval, const c64* dense, int nc, int P, const c64* up, c64* tr) -> int {
     if (batch_levels && V.nl < 8 && fmm_translate_batchable(dense, nc, P)) {
       const int q = V.nl++;
       V.rows[q] = (nc + 15) / 16; V.nc[q] = nc; V.P[q] = P;
       V.DT[q] = reinterpret_cast<const dc*>(dense); V.up[q] = reinterpret_cast<const dc*>(up); V.tr[q] = reinterpret_cast<dc*>(tr);
-      V.first[q + 1] = V.first[q] + V.rows[q] * ((P + 31) / 32);
+      V.first[q + 1] = V.first[q] + V.rows[q] * ((P + 16 * nt - 1) / (16 * nt));
       return MA_OK;
     }
     return fmm_launch_translate(fptr, foth, fval, dense, nc, P, up, tr, st);
@@ -1521,7 +1584,7 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     { int rc = add_or_launch(L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.nc, L.P, L.d_M, L.d_L); if (rc) return rc; }
   }
   { int rc = add_or_launch(F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr); if (rc) return rc; }
-  { int rc = fmm_launch_translate_levels(V, st); if (rc) return rc; }
+  { int rc = fmm_launch_translate_levels(V, nt, st); if (rc) return rc; }
   // downward pass
   for (int l = 0; l < nu; ++l) {
     MlLevel& L = S->up[(size_t)l];

@@ -567,6 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     // ---- wavefront 0: sweep every workgroup's granule until all carry this column's tag, reduce, fetch the winner's row
     if (wave == 0) {
+      for (int q = 0; q < ws.diag_sleep; ++q) __builtin_amdgcn_s_sleep(8);   // diagnostic only (0 in production): 512 cycles each
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
 #ifdef MA_PANEL_STAMPS
       if (lane == 0) { stamp_acc[2] += t0 - stamp_b1; stamp_acc[6] += 1; }

@@ -22,6 +22,8 @@ struct LuPanelWs {
   unsigned long long* diagrow;  // [2][2*LU_NB_MAX]            current diagonal row of the panel
   int max_blocks;
   int test_abort_col;           // test hook (MA_LU_TEST_ABORT_COL): the last workgroup gives up at this global column; -1 = off
+  int diag_sleep;               // diagnostic (MA_DIAG_PANEL_SLEEP=<q>): q x 0.21 us added to every column of the register panel kernel -- the
+                                // slope of the sweep's step time against the panel's time per column (profiles/r04_lu_schedule_experiments.md)
 };
 
 // Admission of a kernel whose workgroups wait for one another (all of them must be resident): see "Residency" in lu_kernels.hip.

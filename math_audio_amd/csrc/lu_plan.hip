@@ -252,7 +252,8 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     P->block_step = false;
     if (const char* eb = getenv("MA_LU_BLOCK_STEP")) P->block_step = atoi(eb) != 0 && P->reg_panel && P->reg_pair;
   }
-  for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = -1;
+  for (int m = 0; m < LU_BATCH_MAX; ++m) { P->pws_m[m].test_abort_col = -1; P->pws_m[m].diag_sleep = 0; }
+  if (const char* ed = getenv("MA_DIAG_PANEL_SLEEP")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].diag_sleep = std::max(0, std::min(64, atoi(ed)));
   if (const char* e9 = getenv("MA_LU_TEST_ABORT_COL")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].test_abort_col = atoi(e9);
   P->pws = P->pws_m[0];
   if (!rc) {
@@ -976,6 +977,12 @@ int ma_lu_plan_stage_spacing(ma_lu_plan_t* P, int32_t slots, int32_t* spacing) {
   int rc = ma_lu_plan_num_blocks(P, &G);
   if (rc) return rc;
   *spacing = (P->reg_panel && P->reg_pair) ? std::max(1, (G + slots / 2) / slots) : std::max(1, (G + slots) / (slots + 1));
+  return MA_OK;
+}
+// how the plan splits the chip: CUs left to the panel kernels (0: no split; the mask's bits [0, panel_cus): panel_cus / 8 CUs of every XCD) and the chip's CUs
+int ma_lu_plan_cu_split(ma_lu_plan_t* P, int32_t* panel_cus, int32_t* total_cus) {
+  MA_REQUIRE(P && panel_cus && total_cus, MA_ERR_INVALID, "bad argument");
+  *panel_cus = P->cu_split; *total_cus = P->ncu;
   return MA_OK;
 }
 int ma_lu_plan_main_stream(ma_lu_plan_t* P, void** stream) {

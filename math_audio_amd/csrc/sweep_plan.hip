@@ -39,6 +39,11 @@ struct ma_bem_sweep {
   AsmSet sets[2];
   int32_t G = 0, spacing = 1; bool staged = false;
   ma_c64* dX = nullptr; int32_t* dinfo = nullptr;
+  // MA_SWEEP_ASM_STREAM (experiment, off by default): the assembly-ahead on a stream of its own -- 1: masked to the CUs the LU plan
+  // leaves to its panel kernels (their vector ALUs idle while a panel waits for its exchange; the far-pair kernel is ALU-bound and
+  // writes 16 bytes per 1.2 kflop), 2: unmasked. A whole set (three systems) is issued when its spares become free; the slot that
+  // takes a system makes the sweep's stream wait for the set's event.
+  hipStream_t asm_st = nullptr; hipEvent_t ev_gate = nullptr, ev_set[2] = {nullptr, nullptr};
   // timing of the last run (ma_bem_sweep_set_timing): events around the run and around every piece of assembly, on the sweep's stream
   bool timing = false;
   hipEvent_t ev_run[2] = {nullptr, nullptr};
@@ -60,15 +65,19 @@ struct ma_bem_sweep {
     for (hipEvent_t e : ev_asm) (void)hipEventDestroy(e);
     ev_asm.clear();
     for (auto& e : ev_run) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    if (asm_st) { (void)hipStreamSynchronize(asm_st); (void)hipStreamDestroy(asm_st); asm_st = nullptr; }
+    if (ev_gate) (void)hipEventDestroy(ev_gate);
+    for (auto& e : ev_set) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    ev_gate = nullptr;
     if (lu) ma_lu_plan_destroy(lu);
     lu = nullptr;
     if (own_stream && st) (void)hipStreamDestroy(st);
     st = nullptr;
   }
-  int asm_mark() {                                         // one event on the sweep's stream, from the pool
+  int asm_mark(hipStream_t on = nullptr) {                 // one event on the stream the assembly runs on, from the pool
     if (!timing) return MA_OK;
     if (ev_asm_used >= ev_asm.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); ev_asm.push_back(e); }
-    MA_HIP(hipEventRecord(ev_asm[ev_asm_used++], st));
+    MA_HIP(hipEventRecord(ev_asm[ev_asm_used++], on ? on : st));
     return MA_OK;
   }
 };
@@ -136,6 +145,21 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma
     if (!ok) { S->free_spares(); ahead = 1; (void)hipGetLastError(); }
   }
   S->ahead = ahead;
+  if (const char* ea = getenv("MA_SWEEP_ASM_STREAM")) {
+    const int mode = atoi(ea);
+    int32_t pcus = 0, ncus = 0;
+    if (mode > 0 && ahead > 1 && ma_lu_plan_cu_split(S->lu, &pcus, &ncus) == MA_OK) {
+      hipError_t e = hipSuccess;
+      if (mode == 1 && pcus > 0 && ncus % 32 == 0) {
+        std::vector<uint32_t> mask((size_t)ncus / 32, 0u);
+        for (int i = 0; i < pcus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+        e = hipExtStreamCreateWithCUMask(&S->asm_st, (uint32_t)mask.size(), mask.data());
+      } else e = hipStreamCreateWithFlags(&S->asm_st, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_gate, hipEventDisableTiming);
+      for (int q = 0; q < 2 && e == hipSuccess; ++q) e = hipEventCreateWithFlags(&S->ev_set[q], hipEventDisableTiming);
+      if (e != hipSuccess) { set_error("sweep: the assembly stream could not be made: %s", hipGetErrorString(e)); return fail(MA_ERR_HIP); }
+    }
+  }
   if (S->staged) {
     if (hipMalloc(&S->dX, sizeof(ma_c64) * (size_t)max_frequencies * (size_t)n) != hipSuccess || hipMalloc(&S->dinfo, sizeof(int32_t) * (size_t)max_frequencies) != hipSuccess) {
       set_error("sweep: the solutions of %d frequencies do not fit the device", max_frequencies);
@@ -186,8 +210,8 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
   AsmSet* sets = S->sets;
   for (int q = 0; q < 2; ++q) { sets[q].first = -1; sets[q].cnt = 0; sets[q].part = 0; sets[q].taken = 0; }
   auto set_idle = [](const AsmSet& t) { return t.first < 0 || t.taken == (1u << t.cnt) - 1u; };
-  auto start_job = [&](AsmSet& t, int first_i) {
-    t.first = first_i; t.cnt = std::min(ahead, n_mine - first_i); t.part = 0; t.taken = 0;
+  auto start_job = [&](AsmSet& t, int first_i, int max_cnt = 3) {
+    t.first = first_i; t.cnt = std::min(std::min(ahead, max_cnt), n_mine - first_i); t.part = 0; t.taken = 0;
     for (int q = 0; q < t.cnt; ++q) { physics_of(mine[(size_t)(first_i + q)], &t.ph[q], &t.bi[q]); t.br[q] = 0.0; }
   };
   // Deferred finishes (ma_lu_plan_stage_finish_defer / _issue / _wait): with spares, a slot's next system arrives in OTHER buffers, so
@@ -212,15 +236,21 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     return r;
   };
   auto collect_all = [&]() -> int { int r = MA_OK; for (int s = 0; s < 4 && !r; ++s) if (pend[s].stage) r = collect(s); return r; };
+  hipStream_t ast = S->asm_st ? S->asm_st : st;               // where the assembly-ahead runs
   auto issue_part = [&](AsmSet& t) -> int {
     int r = collect_all();                                                  // no assembly writes a buffer whose backward substitution is still out
-    if (!r) r = S->asm_mark();
-    if (!r) r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, st);
+    if (!r && S->asm_st && t.part == 0) {                                  // the spares are free from HERE on the sweep's stream: the assembly stream starts behind that point
+      if (hipEventRecord(S->ev_gate, st) != hipSuccess || hipStreamWaitEvent(S->asm_st, S->ev_gate, 0) != hipSuccess) { set_error("sweep: assembly stream gate failed"); r = MA_ERR_HIP; }
+    }
+    if (!r) r = S->asm_mark(ast);
+    if (!r) r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, ast);
     if (r) return r;
-    if (++t.part == nparts)
+    if (++t.part == nparts) {
       for (int q = 0; q < t.cnt && !r; ++q)
-        r = ma_bem_plan_incident_rhs_dev(plan, &t.ph[q], 0.0, t.bi[q], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, t.x[q], st);
-    if (!r) r = S->asm_mark();
+        r = ma_bem_plan_incident_rhs_dev(plan, &t.ph[q], 0.0, t.bi[q], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, t.x[q], ast);
+      if (!r && S->asm_st && hipEventRecord(S->ev_set[&t == &sets[0] ? 0 : 1], S->asm_st) != hipSuccess) { set_error("sweep: assembly stream event failed"); r = MA_ERR_HIP; }
+    }
+    if (!r) r = S->asm_mark(ast);
     return r;
   };
   // system of this device's i-th frequency into slot s
@@ -231,12 +261,17 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     if (!t) {
       for (int c = 0; c < 2; ++c) if (!t && set_idle(sets[c])) t = &sets[c];
       if (!t) return assemble(mine[(size_t)i], s);                           // neither set holds it and neither is free: this one directly (the order of a tiny plan)
-      start_job(*t, i);
+      // MA_SWEEP_FIRST_ALONE=1: the run's FIRST system travels alone, so that the first slot's panels start after one system's assembly
+      // instead of three's (measured: 50.35-50.55 against 50.17-50.36 ms over 20 steps -- the lone pass loses the shared geometry; off)
+      static const bool first_alone = [] { const char* e = getenv("MA_SWEEP_FIRST_ALONE"); return e && atoi(e) != 0; }();
+      const int c0 = (i == 0 && first_alone) ? 1 : 3;
+      start_job(*t, i, c0);
       AsmSet& o = t == &sets[0] ? sets[1] : sets[0];
-      if (set_idle(o) && i + ahead < n_mine) start_job(o, i + ahead);       // the set after this one: in pieces, from now on
+      if (set_idle(o) && i + t->cnt < n_mine) start_job(o, i + t->cnt);     // the set after this one: in pieces, from now on
     }
     int r = MA_OK;
     while (t->part < nparts && !r) r = issue_part(*t);                       // not finished in the gaps: the rest now
+    if (!r && S->asm_st && hipStreamWaitEvent(st, S->ev_set[t == &sets[0] ? 0 : 1], 0) != hipSuccess) { set_error("sweep: waiting for the assembly stream failed"); r = MA_ERR_HIP; }
     if (r) return r;
     const int q = i - t->first;
     std::swap(dA[(size_t)s], t->A[q]); std::swap(dx[(size_t)s], t->x[q]);
@@ -250,9 +285,14 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
   };
   // after the updates of round r: one piece of the set being assembled, in the last ppp rounds before a slot begins
   auto assembly_tick = [&](int r, int spacing) -> int {
+    if (ahead > 1 && S->asm_st) {                                          // a stream of its own paces itself: everything that is free goes out now
+      for (int c = 0; c < 2; ++c) while (sets[c].first >= 0 && sets[c].part < nparts && sets[c].taken == 0) { int q = issue_part(sets[c]); if (q) return q; }
+      return MA_OK;
+    }
     if (ahead <= 1 || (r % spacing) < spacing - ppp) return MA_OK;
-    for (int c = 0; c < 2; ++c) if (sets[c].first >= 0 && sets[c].part < nparts && sets[c].taken == 0) return issue_part(sets[c]);
-    return MA_OK;
+    AsmSet* pick = nullptr;                                                  // the unfinished set that is needed first
+    for (int c = 0; c < 2; ++c) if (sets[c].first >= 0 && sets[c].part < nparts && sets[c].taken == 0 && (!pick || sets[c].first < pick->first)) pick = &sets[c];
+    return pick ? issue_part(*pick) : MA_OK;
   };
   if (S->staged) {
     const int32_t G = S->G;
