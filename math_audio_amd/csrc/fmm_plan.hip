@@ -1112,6 +1112,7 @@ static bool slfmm_overlap_ready(ma_slfmm* S) {
       // kernels waiting for slots (the first upward-pass kernel took 350 us instead of 15 beside them)
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      { const char* ep = getenv("MA_FMM_NEAR_PRIO"); if (!(ep && atoi(ep) < 0)) lo = 0; }   // normal priority unless asked (-1: lowest)
       bool ok = hipStreamCreateWithPriority(&S->st2, hipStreamNonBlocking, lo) == hipSuccess && hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&S->ev_near, hipEventDisableTiming) == hipSuccess && hipMalloc(&S->d_yfar, sizeof(c64) * (size_t)S->n) == hipSuccess;
       if (ok) S->overlap_streams = 1; else (void)hipGetLastError();
