@@ -38,7 +38,8 @@ struct ma_slfmm {
   int* d_bsrc = nullptr; int* d_bfld = nullptr; long long* d_boff = nullptr; int nblocks = 0;   // the near blocks one by one
   long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0, max_width = 0, max_rows = 0;   // their partial sums (rows, columns)
   c64* d_up = nullptr; c64* d_tr = nullptr;
-  c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=0: recomputed)
+  c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=1; 0: recomputed with libm)
+  bool fast_phases = false;        // round 4 (the default, MA_FMM_STORE_PHASES=2): recomputed with the bounded-argument sin / cos, no table
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
   // round 4: the near blocks' first pass runs on a second stream beside the far chain (up -> translate -> down), whose result goes to
   // d_yfar and is added by the near field's second pass -- the apply costs max(near, far) + one short pass instead of their sum
@@ -798,8 +799,110 @@ __global__ __launch_bounds__(256) void slfmm_down_tab_kernel(const int* __restri
     }
   }
 }
+// Round 4: the phases RECOMPUTED, fast. The stored table costs 16 B per (element, sphere point) and pass -- 103 MB per pass on the 50k
+// box, beside a near field that is memory-bound already -- while the phase itself is 3 FMAs, one multiplication and a sin / cos of a
+// SMALL argument (|k s.(x - C)| <= k x cluster radius): sincos_bounded (ma_device_math.hpp: two-FMA Cody-Waite + the fdlibm kernels, no
+// library fall-back) takes ~35 FP64 instructions where libm's sincos -- which the first version of these passes called, and lost to the
+// table -- takes hundreds. The cluster's element offsets (and x, or the local expansion) are staged in LDS once per workgroup.
+// MA_FMM_STORE_PHASES: 2 (default) these kernels, no table; 1 the table; 0 the libm form.
+constexpr int FMM_FAST_ELEMS = 512;                          // elements of a cluster staged per pass (larger clusters walk in chunks)
+// up[c][p] = w_p sum_j exp(i sgn k s_p.(x_j - C)) x[dof_j]: thread sets split the elements, their parts are added in set order
+__global__ __launch_bounds__(256) void slfmm_up_fast_kernel(BemGeom g, const int* __restrict__ eptr, const int* __restrict__ eidx, const int* __restrict__ edof,
+                                                            const double* __restrict__ cc, const double* __restrict__ sc, const double* __restrict__ sw,
+                                                            int P, double k, double sgn, const dc* __restrict__ x, dc* __restrict__ up) {
+  __shared__ double ex[FMM_FAST_ELEMS], ey[FMM_FAST_ELEMS], ez[FMM_FAST_ELEMS];
+  __shared__ dc xv[FMM_FAST_ELEMS];
+  __shared__ dc part[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int e0 = eptr[c], n = eptr[c + 1] - e0;
+  const double Cx = cc[3 * c], Cy = cc[3 * c + 1], Cz = cc[3 * c + 2];
+  const int QG = P <= 256 ? 256 / P : 1;                     // thread sets over the elements (P sphere points each)
+  for (int pb = 0; pb < P; pb += 256) {
+    const int qg = P <= 256 ? tid / P : 0, p = pb + (P <= 256 ? tid % P : tid);
+    const bool act = qg < QG && p < P;
+    const double sx = act ? k * sc[3 * p] : 0.0, sy = act ? k * sc[3 * p + 1] : 0.0, sz = act ? k * sc[3 * p + 2] : 0.0;
+    double sr = 0.0, si = 0.0;
+    for (int j0 = 0; j0 < n; j0 += FMM_FAST_ELEMS) {
+      const int m = min(FMM_FAST_ELEMS, n - j0);
+      __syncthreads();
+      for (int j = tid; j < m; j += 256) {
+        const int e = eidx[e0 + j0 + j];
+        ex[j] = g.c[0][e] - Cx; ey[j] = g.c[1][e] - Cy; ez[j] = g.c[2][e] - Cz; xv[j] = x[edof[e0 + j0 + j]];
+      }
+      __syncthreads();
+      if (act)
+        for (int j = qg; j < m; j += QG) {
+          double sn, cs;
+          sincos_bounded(__builtin_fma(sx, ex[j], __builtin_fma(sy, ey[j], sz * ez[j])), sn, cs);
+          const double ei = sgn * sn;
+          const dc v = xv[j];
+          sr += cs * v.re - ei * v.im; si += cs * v.im + ei * v.re;
+        }
+    }
+    if (P > 256) { if (p < P) { const double w = sw[p]; up[(long long)c * P + p] = dc_make(w * sr, w * si); } continue; }
+    __syncthreads();
+    part[tid] = dc_make(sr, si);
+    __syncthreads();
+    if (tid < P) {
+      double tr_ = 0.0, ti_ = 0.0;
+      for (int q = 0; q < QG; ++q) { tr_ += part[q * P + tid].re; ti_ += part[q * P + tid].im; }
+      const double w = sw[tid];
+      up[(long long)c * P + tid] = dc_make(w * tr_, w * ti_);
+    }
+  }
+}
+// y[dof_j] (+)= sum_p w_p exp(i sgn k s_p.(x_j - C)) tr[c][p]: a wavefront per element (four at a time), lanes over the sphere points, the
+// cluster's local expansion and sphere rule in LDS; mode 0 add, 1 atomic add (overlapping leaves), 2 store (y = the far field's own vector)
+constexpr int FMM_FAST_PTS = 1024;
+__global__ __launch_bounds__(256) void slfmm_down_fast_kernel(BemGeom g, const int* __restrict__ eptr, const int* __restrict__ eidx, const int* __restrict__ edof,
+                                                              const double* __restrict__ cc, const double* __restrict__ sc, const double* __restrict__ sw,
+                                                              int P, double k, double sgn, const dc* __restrict__ tr, dc* __restrict__ y, int mode) {
+  __shared__ double px[FMM_FAST_PTS], py[FMM_FAST_PTS], pz[FMM_FAST_PTS];
+  __shared__ dc lw[FMM_FAST_PTS];                              // w_p tr[c][p]
+  const int c = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int e0 = eptr[c], n = eptr[c + 1] - e0;
+  const double Cx = cc[3 * c], Cy = cc[3 * c + 1], Cz = cc[3 * c + 2];
+  for (int p = tid; p < P; p += 256) {                         // P <= FMM_FAST_PTS (the launcher's choice)
+    px[p] = k * sc[3 * p]; py[p] = k * sc[3 * p + 1]; pz[p] = k * sc[3 * p + 2];
+    const dc l = tr[(long long)c * P + p]; const double w = sw[p];
+    lw[p] = dc_make(w * l.re, w * l.im);
+  }
+  __syncthreads();
+  constexpr int U = 4;
+  for (int j0 = wave * U; j0 < n; j0 += 4 * U) {
+    double dx[U], dy[U], dz[U], sr[U], si[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = eidx[e0 + (j0 + u < n ? j0 + u : j0)];
+      dx[u] = g.c[0][e] - Cx; dy[u] = g.c[1][e] - Cy; dz[u] = g.c[2][e] - Cz; sr[u] = 0.0; si[u] = 0.0;
+    }
+    for (int p = lane; p < P; p += 64) {
+      const double ax = px[p], ay = py[p], az = pz[p];
+      const dc l = lw[p];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        double sn, cs;
+        sincos_bounded(__builtin_fma(ax, dx[u], __builtin_fma(ay, dy[u], az * dz[u])), sn, cs);
+        const double ei = sgn * sn;
+        sr[u] += cs * l.re - ei * l.im; si[u] += cs * l.im + ei * l.re;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double a = fmm_set_sum(sr[u], 64), b = fmm_set_sum(si[u], 64);
+      if (lane == 0 && j0 + u < n) {
+        dc* o = y + edof[e0 + j0 + u];
+        if (mode == 1) { atomicAdd(&o->re, a); atomicAdd(&o->im, b); }
+        else if (mode == 2) *o = dc_make(a, b);
+        else { o->re += a; o->im += b; }
+      }
+    }
+  }
+}
 static int slfmm_launch_up(const ma_slfmm* S, double sgn, const dc* x, hipStream_t st) {
-  if (S->d_phase) hipLaunchKernelGGL(slfmm_up_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn, x,
+  if (S->fast_phases) hipLaunchKernelGGL(slfmm_up_fast_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn, x,
+                                         reinterpret_cast<dc*>(S->d_up));
+  else if (S->d_phase) hipLaunchKernelGGL(slfmm_up_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn, x,
                                      reinterpret_cast<dc*>(S->d_up));
   else hipLaunchKernelGGL(slfmm_up_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn, x,
                           reinterpret_cast<dc*>(S->d_up));
@@ -807,7 +910,9 @@ static int slfmm_launch_up(const ma_slfmm* S, double sgn, const dc* x, hipStream
   return MA_OK;
 }
 static int slfmm_launch_down(const ma_slfmm* S, double sgn, dc* y, hipStream_t st, bool store = false) {
-  if (S->d_phase) hipLaunchKernelGGL(slfmm_down_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn,
+  if (S->fast_phases) hipLaunchKernelGGL(slfmm_down_fast_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn,
+                                         reinterpret_cast<const dc*>(S->d_tr), y, store ? 2 : (S->overlap ? 1 : 0));
+  else if (S->d_phase) hipLaunchKernelGGL(slfmm_down_tab_kernel, dim3(S->nc), dim3(256), 0, st, S->d_eptr, S->d_edof, reinterpret_cast<const dc*>(S->d_phase), S->P, sgn,
                                      reinterpret_cast<const dc*>(S->d_tr), y, store ? 2 : (S->overlap ? 1 : 0));
   else hipLaunchKernelGGL(slfmm_down_kernel, dim3(S->nc), dim3(256), 0, st, S->plan->geom, S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->P, S->k, sgn,
                           reinterpret_cast<const dc*>(S->d_tr), y, S->overlap ? 1 : 0);
@@ -1088,7 +1193,10 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   }
   { const char* ev = getenv("MA_FMM_STORE_PHASES");
     const size_t listed = (size_t)eptr.back();
-    if (!rc && !(ev && atoi(ev) == 0) && listed > 0 && hipMalloc(&S->d_phase, sizeof(c64) * listed * (size_t)P) == hipSuccess) {
+    const int mode = ev ? atoi(ev) : 2;
+    // the fast form's arguments are k x an element-to-centre distance (far below the 2^30 its reduction allows); P must fit its LDS arrays
+    if (mode == 2 && P <= FMM_FAST_PTS) S->fast_phases = true;
+    if (!rc && mode == 1 && listed > 0 && hipMalloc(&S->d_phase, sizeof(c64) * listed * (size_t)P) == hipSuccess) {
       hipLaunchKernelGGL(slfmm_phase_table_kernel, dim3(nc), dim3(256), 0, nullptr, plan->geom, S->d_eptr, S->d_eidx, S->d_cc, S->d_sc, S->d_sw, P, S->k,
                          reinterpret_cast<dc*>(S->d_phase));
       if (hipGetLastError() != hipSuccess) { set_error("SLFMM phase table kernel failed"); rc = MA_ERR_HIP; }
@@ -1107,7 +1215,7 @@ static bool slfmm_overlap_ready(ma_slfmm* S) {
   if (S->overlap_streams < 0) {
     const char* e = getenv("MA_FMM_OVERLAP");
     S->overlap_streams = 0;
-    if (!(e && atoi(e) == 0) && S->d_part && S->d_phase) {
+    if (!(e && atoi(e) == 0) && S->d_part && (S->d_phase || S->fast_phases)) {
       // the near blocks' stream at the LOWEST priority: its tens of thousands of short workgroups otherwise keep the far chain's few
       // kernels waiting for slots (the first upward-pass kernel took 350 us instead of 15 beside them)
       int lo = 0, hi = 0;
@@ -1383,7 +1491,7 @@ __global__ __launch_bounds__(256) void mlfmm_m2m_kernel(const int* __restrict__ 
       const int p = tid + 256 * u;
       if (p < P) {
         const double sd = sc[3 * p] * dx + sc[3 * p + 1] * dy + sc[3 * p + 2] * dz;
-        double sn, cs; sincos(k * sd, &sn, &cs);
+        double sn, cs; sincos_bounded(k * sd, sn, cs);   // |k s.(c_son - c_C)| <= k x the father's radius
         ar[u] += cs * mr + sn * mi; ai[u] += cs * mi - sn * mr;          // e^{-i t} (mr + i mi)
       }
     }
@@ -1404,7 +1512,7 @@ __global__ __launch_bounds__(256) void mlfmm_l2l_kernel(const int* __restrict__ 
     double sr = 0.0, si = 0.0;
     for (int p = tid; p < P; p += 256) {
       const double sd = sc[3 * p] * dx + sc[3 * p + 1] * dy + sc[3 * p + 2] * dz;
-      double sn, cs; sincos(k * sd, &sn, &cs);
+      double sn, cs; sincos_bounded(k * sd, sn, cs);   // |k s.(c_son - c_C)| <= k x the father's radius
       const dc l = L[(long long)c * P + p]; const double w = sw[p];
       sr += w * (cs * l.re - sn * l.im); si += w * (cs * l.im + sn * l.re);
     }
