@@ -2830,6 +2830,50 @@ int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c6
   return MA_OK;
 }
 
+// ---- does a CU-masked stream do what the plan assumes? (round 4: the mask's bit layout was taken from tools/cumask_probe.hip and never
+// checked at run time.) A census: 4096 one-wavefront workgroups that each stay ~20 us record the (XCC, SE, SH, CU) they run on; the stream
+// must have used exactly `expect_cus` different CUs, the same number in each of the 8 XCDs. Once per (device, expectation).
+__global__ __launch_bounds__(64) void lu_cu_census_kernel(unsigned* __restrict__ out, int spin_ticks) {
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const u64 t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (u64)spin_ticks) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) out[blockIdx.x] = ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);     // cu_id[11:8], sh_id[12], se_id[15:13] of HW_ID
+}
+int lu_cumask_selfcheck(hipStream_t masked, int expect_cus, bool* ok) {
+  *ok = false;
+  int dev = 0;
+  MA_HIP(hipGetDevice(&dev));
+  static std::mutex mu;
+  static std::vector<std::pair<long long, bool>> seen;
+  const long long key = (long long)dev * 100000 + expect_cus;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& e : seen) if (e.first == key) { *ok = e.second; return MA_OK; }
+  }
+  constexpr int NB = 4096;
+  unsigned* d = nullptr;
+  MA_HIP(hipMalloc(&d, sizeof(unsigned) * NB));
+  hipLaunchKernelGGL(lu_cu_census_kernel, dim3(NB), dim3(64), 0, masked, d, 2000);          // 20 us at 100 MHz
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(masked);
+  std::vector<unsigned> h(NB);
+  if (e == hipSuccess) e = hipMemcpy(h.data(), d, sizeof(unsigned) * NB, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { set_error("CU-mask census failed: %s", hipGetErrorString(e)); return MA_ERR_HIP; }
+  std::sort(h.begin(), h.end());
+  h.erase(std::unique(h.begin(), h.end()), h.end());
+  int per_xcc[16] = {};
+  for (unsigned v : h) per_xcc[(v >> 8) & 0xf] += 1;
+  bool good = (int)h.size() == expect_cus && expect_cus % 8 == 0;
+  for (int x = 0; x < 8 && good; ++x) good = per_xcc[x] == expect_cus / 8;
+  std::lock_guard<std::mutex> lock(mu);
+  seen.push_back({key, good});
+  *ok = good;
+  return MA_OK;
+}
+
 int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st) {
   hipLaunchKernelGGL(mfma_f64_probe_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
   MA_HIP(hipGetLastError());

@@ -72,5 +72,6 @@ int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64
                         const ZgemmMode* mode = nullptr);   // big: the trailing update on the caller's stream (its own kernel instantiation); mode NULL: the process-wide one
 int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st);
 int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st);
+int lu_cumask_selfcheck(hipStream_t masked, int expect_cus, bool* ok);   // the masked stream uses exactly expect_cus CUs, spread evenly over the 8 XCDs
 
 }  // namespace ma

@@ -304,6 +304,19 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
         if (e4 != hipSuccess && !getenv("MA_LU_CU_SPLIT")) {   // the default split on a runtime that makes no masked streams: the whole chip for everything
           (void)hipGetLastError(); e4 = hipSuccess; P->big_stream = nullptr; P->cu_split = 0;
         }
+        // the mask's bit layout (bit i = XCD i mod 8, ...) is what tools/cumask_probe.hip found on an SPX MI355X; a census on the new
+        // stream says whether THIS device agrees: ncu - split CUs in use, the same number in every XCD. If not (another partition
+        // mode, another part), the plan runs its updates on the whole chip -- the round-2 placement, slower, never wrong.
+        if (e4 == hipSuccess && P->big_stream && !by_xcd) {
+          bool mask_ok = false;
+          rc = lu_cumask_selfcheck(P->big_stream, ncu - P->cu_split, &mask_ok);
+          if (!rc && !mask_ok) {
+            (void)hipStreamDestroy(P->big_stream); P->big_stream = nullptr; P->cu_split = 0;
+            for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->pan_streams[i]) { (void)hipStreamDestroy(P->pan_streams[i]); P->pan_streams[i] = nullptr; }
+                                                     if (P->chain_streams[i]) { (void)hipStreamDestroy(P->chain_streams[i]); P->chain_streams[i] = nullptr; } }
+            P->pan_mask = 0; P->chain_mask = 0;
+          }
+        }
       }
     }
     if (e4 != hipSuccess) { set_error("stream/event creation failed: %s", hipGetErrorString(e4)); rc = MA_ERR_HIP; }

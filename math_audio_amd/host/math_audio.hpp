@@ -9,7 +9,7 @@
 //            gmres / gmres_with_guess / gmres_preconditioned   (math-solvers/src/{sparse/csr,traits,iterative/gmres,preconditioners/diagonal}.rs)
 //   math_solvers::AmgPreconditioner (V/W/F cycle over a hierarchy the caller built) / gmres_pipelined   (preconditioners/amg.rs, iterative/gmres_pipelined.rs)
 //   math_bem::Cluster / SlfmmSystem (build_slfmm_system + its LinearOperator) / ClusterTree + MlfmmSystem (build_cluster_tree, build_mlfmm_system) / TbemOperator (matrix-free, one or several GPUs) /
-//            solve_frequency_sweep (the `for freq` loop of bin/room_simulator_bem.rs:329 as one call, one or several GPUs)
+//            solve_frequency_sweep (the `for freq` loop of bin/room_simulator_bem.rs:329 as one call, one or several GPUs) / FrequencySweep (the same behind a reusable handle)
 // Header-only; links against libmathaudio_hip.so. No CPU fallback: errors come back as exceptions or
 // Result values carrying the C status code.
 #pragma once
@@ -848,5 +848,40 @@ inline std::vector<std::vector<Complex64>> solve_frequency_sweep(const std::vect
   for (size_t f = 0; f < nf; ++f) out[f].assign(X.begin() + (std::ptrdiff_t)(f * n), X.begin() + (std::ptrdiff_t)((f + 1) * n));
   return out;
 }
+
+// The same loop behind a handle that a driver keeps beside its mesh (round 4; ma_bem_sweep_t): the device plan of the mesh, the LU plan,
+// its streams, the systems in flight, the spares of the assembly-ahead and the parked solutions are made ONCE; every solve() is one
+// ma_bem_sweep_run. room_simulator_bem.rs:243-256 builds the mesh once, :328-360 walks the frequencies -- once per source position.
+class FrequencySweep {
+ public:
+  FrequencySweep(const std::vector<Element>& elements, const std::vector<double>& nodes, size_t max_frequencies, int device = 0, int slots = 3) {
+    detail::Flat F; detail::flatten(elements, nodes, F);
+    n_ = (size_t)F.c.n_elem;
+    int rc = ma_bem_plan_create(&F.c, device, &plan_);
+    if (rc == MA_OK) rc = ma_bem_sweep_create(plan_, slots, (int32_t)max_frequencies, &sweep_);
+    if (rc != MA_OK) { const std::string msg = ma_last_error_string(); release(); throw BemError(rc, msg); }
+  }
+  FrequencySweep(const FrequencySweep&) = delete;
+  FrequencySweep& operator=(const FrequencySweep&) = delete;
+  ~FrequencySweep() { release(); }
+  size_t num_dofs() const { return n_; }
+  // surface solutions, one vector per frequency; status[f] is MA_OK or MA_ERR_SINGULAR
+  std::vector<std::vector<Complex64>> solve(const std::vector<double>& frequencies_hz, double speed_of_sound, double beta_scale, const IncidentField& incident,
+                                            std::vector<int32_t>* status = nullptr, double harmonic_factor = 1.0, double tau = 1.0) {
+    const size_t nf = frequencies_hz.size();
+    std::vector<Complex64> X(nf * n_);
+    std::vector<int32_t> st(nf, 0);
+    const int rc = ma_bem_sweep_run(sweep_, (int32_t)nf, frequencies_hz.data(), speed_of_sound, harmonic_factor, tau, beta_scale, incident.kind, incident.v,
+                                    incident.amp.real(), incident.amp.imag(), reinterpret_cast<ma_c64*>(X.data()), st.data());
+    if (rc != MA_OK && rc != MA_ERR_SINGULAR) throw BemError(rc, ma_last_error_string());
+    if (status) *status = st;
+    std::vector<std::vector<Complex64>> out(nf);
+    for (size_t f = 0; f < nf; ++f) out[f].assign(X.begin() + (std::ptrdiff_t)(f * n_), X.begin() + (std::ptrdiff_t)((f + 1) * n_));
+    return out;
+  }
+ private:
+  void release() { if (sweep_) ma_bem_sweep_destroy(sweep_); if (plan_) ma_bem_plan_destroy(plan_); sweep_ = nullptr; plan_ = nullptr; }
+  size_t n_ = 0; ma_bem_plan_t* plan_ = nullptr; ma_bem_sweep_t* sweep_ = nullptr;
+};
 
 }  // namespace math_bem

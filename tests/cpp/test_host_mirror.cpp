@@ -338,6 +338,24 @@ static void test_mesh_operators_and_sweep() {
     auto ref = math_solvers::lu_solve(sf.matrix, n, n, rhs);
     CHECK(ref.is_ok() && status[f] == MA_OK && diff(sols[f], ref.value) < 1e-9 * norm(ref.value));
   }
+  // round 4: the loop behind a handle that lives beside the mesh (ma_bem_sweep_t): two sweeps through ONE handle, the second shorter.
+  // The same frequencies through the one-call form: the same bits (same kernels on the same data); a sweep with another number of
+  // slots may assemble one, two or three systems per pass over the quadrature points, which moves the last bits of the far entries
+  {
+    FrequencySweep sw(mesh.elements, mesh.nodes, 4);
+    CHECK(sw.num_dofs() == n);
+    const std::vector<double> f4 = {300.0, 700.0, 1100.0, 250.0};
+    std::vector<int32_t> st4;
+    auto s4 = sw.solve(f4, c0, 4.0, IncidentField::plane_wave_z(), &st4);
+    auto s4_ref = solve_frequency_sweep(mesh.elements, mesh.nodes, f4, c0, 4.0, IncidentField::plane_wave_z(), {0});
+    for (size_t f = 0; f < f4.size(); ++f) CHECK(st4[f] == MA_OK && s4[f] == s4_ref[f]);
+    CHECK(diff(s4[0], sols[0]) < 1e-12 * norm(sols[0]) && diff(s4[1], sols[1]) < 1e-12 * norm(sols[1]));
+    auto s2 = sw.solve(freqs, c0, 4.0, IncidentField::plane_wave_z());
+    CHECK(s2.size() == 2 && s2[0] == s4[0] && s2[1] == s4[1]);          // the same handle, the same systems: the same bits
+    bool threw = false;
+    try { sw.solve({100.0, 200.0, 300.0, 400.0, 500.0}, c0, 4.0, IncidentField::plane_wave_z()); } catch (const BemError& e) { threw = e.status == MA_ERR_INVALID; }
+    CHECK(threw);                                            // more frequencies than the handle was made for
+  }
 }
 
 int main() {
