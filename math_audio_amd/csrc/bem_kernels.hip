@@ -420,6 +420,88 @@ __global__ __launch_bounds__(256) void tbem_near_kernel(BemGeom g, BemPhys ph, c
   }
 }
 
+// The near pairs of NF systems of one mesh in one pass (round 4): the sub-triangle leaves of a pair (generate_subelements,
+// singular.rs:497-660) depend on the geometry alone, and so do position, distance, reciprocal square root and the two normal
+// projections of every quadrature point; sin / cos and the kernel values are per system. Per system the operations and their order
+// are those of tbem_near_kernel<0> (green_point); the compiler contracts them into FMAs on its own terms in either kernel, so the entries
+// agree to rounding (1e-13 of the row scale, test_multi_frequency_assembly_equals_the_single_one), not bit for bit.
+template <int NF>
+__global__ __launch_bounds__(256) void tbem_near_multi_kernel(BemGeom g, FarMulti fm, const int2* __restrict__ pairs, long long npairs) {
+  __shared__ double s_leaf[4][MA_MAX_LEAVES][6];
+  __shared__ double s_next[4][MA_MAX_NSE][6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long pid = (long long)blockIdx.x * 4 + wave;
+  if (pid >= npairs) return;                         // whole wave leaves; no block barrier below
+  const int2 pr = pairs[pid];
+  const int i = pr.x, j = pr.y;
+  if (g.nquad > 0 && g.ptype[j] == 4) return;        // Quad4 field panel: tbem_near_quad_kernel, per system
+  const double cx = g.c[0][i], cy = g.c[1][i], cz = g.c[2][i];
+  const double nxx = g.nx[0][i], nxy = g.nx[1][i], nxz = g.nx[2][i];
+  double v[9] = {g.p0[0][j], g.p0[1][j], g.p0[2][j], g.p1[0][j], g.p1[1][j], g.p1[2][j], g.p2[0][j], g.p2[1][j], g.p2[2][j]};
+  const double area = g.area[j];
+  const int nleaf = near_build_leaves(v, area, cx, cy, cz, wave, lane, s_leaf, s_next);
+  const double e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
+  const double e2x = v[6] - v[0], e2y = v[7] - v[1], e2z = v[8] - v[2];
+  const double nyx = g.ny[0][j], nyy = g.ny[1][j], nyz = g.ny[2][j];
+  const double jw = g.jac[j] * MA_INV4PI;
+  const double d0x = v[0] - cx, d0y = v[1] - cy, d0z = v[2] - cz;
+  const double m = nxx * nyx + nxy * nyy + nxz * nyz;
+  double kk[NF], kk2[NF];
+  Acc4 s[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) { kk[f] = fm.ph[f].k * fm.ph[f].harmonic; kk2[f] = fm.ph[f].k * fm.ph[f].k; s[f].g = s[f].h = s[f].ht = s[f].e = dc_make(0.0, 0.0); }
+  const int ntask = nleaf * 13;
+  for (int t = lane; t < ntask; t += 64) {
+    const int lf = t / 13, q = t - lf * 13;
+    const double* L = s_leaf[wave][lf];
+    const double a0 = L[0], b0 = L[1], a1 = L[2], b1 = L[3], a2 = L[4], b2 = L[5];
+    const double xi = c_tri13[q][0], eta = c_tri13[q][1], w = c_tri13[q][2];
+    const double l0 = 1.0 - xi - eta;
+    const double xio = a0 * l0 + a1 * xi + a2 * eta;
+    const double eto = b0 * l0 + b1 * xi + b2 * eta;
+    const double det = __builtin_fabs((a1 - a0) * (b2 - b0) - (a2 - a0) * (b1 - b0));
+    const double dx = __builtin_fma(eto, e2x, __builtin_fma(xio, e1x, d0x));
+    const double dy = __builtin_fma(eto, e2y, __builtin_fma(xio, e1y, d0y));
+    const double dz = __builtin_fma(eto, e2z, __builtin_fma(xio, e1z, d0z));
+    // green_point, its wavenumber-free half once ...
+    const double r2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+    if (!(r2 >= 1e-30)) continue;
+    double r, ri;
+    sqrt_rsqrt(r2, r, ri);
+    const double gsc = (w * det * jw) * ri;
+    const double a = (dx * nyx + dy * nyy + dz * nyz) * ri;
+    const double b = -((dx * nxx + dy * nxy + dz * nxz) * ri);
+    const double rq = a * b, ri2 = ri * ri;
+    // ... and the rest per system
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const double k = kk[f];
+      double sn, cs;
+      sincos_bounded(k * r, sn, cs);
+      const double gre = cs * gsc, gim = sn * gsc;
+      const double bre = -(gre * ri) - gim * k;
+      const double bim = gre * k - gim * ri;
+      const double fr = (3.0 * ri2 - kk2[f]) * rq + m * ri2;
+      const double fi = -(k * ri) * (3.0 * rq + m);
+      Acc4& acc = s[f];
+      acc.g.re += gre; acc.g.im += gim;
+      acc.h.re = __builtin_fma(bre, a, acc.h.re); acc.h.im = __builtin_fma(bim, a, acc.h.im);
+      acc.ht.re = __builtin_fma(bre, b, acc.ht.re); acc.ht.im = __builtin_fma(bim, b, acc.ht.im);
+      acc.e.re += gre * fr - gim * fi;
+      acc.e.im += gre * fi + gim * fr;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    Acc4& a = s[f];
+    a.g.re = wave_sum(a.g.re); a.g.im = wave_sum(a.g.im);
+    a.h.re = wave_sum(a.h.re); a.h.im = wave_sum(a.h.im);
+    a.ht.re = wave_sum(a.ht.re); a.ht.im = wave_sum(a.ht.im);
+    a.e.re = wave_sum(a.e.re); a.e.im = wave_sum(a.e.im);
+    if (lane == 0) fm.A[f][(long long)g.dof[i] * g.nd + g.dof[j]] = bm_coeff(a, g.bc_type[j], fm.ph[f]);
+  }
+}
+
 // ------------------------------------------------------------------ K3: self terms
 // singular_integration_with_params (singular.rs:154-394) for Tri3, QuadratureParams::for_ka (:48-82)
 // from ka = k x mean edge length (:730-745). One wavefront per panel; the flattened point list
@@ -1354,6 +1436,22 @@ int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long
   dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
   hipLaunchKernelGGL(tbem_near_kernel<0>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
   if (g.nquad > 0) hipLaunchKernelGGL(tbem_near_quad_kernel<0>, grid, block, 0, st, g, ph, pairs, npairs, reinterpret_cast<dc*>(A));
+  MA_HIP(hipGetLastError());
+  return MA_OK;
+}
+
+// the near pairs of cnt <= 3 systems of one mesh: one pass over the leaves and the quadrature points' geometry (Tri3 field panels);
+// Quad4 field panels per system as before
+int bem_launch_near_multi(const BemGeom& g, int cnt, const BemPhys* ph, c64* const* As, const int2* pairs, long long npairs, hipStream_t st) {
+  if (npairs <= 0 || cnt <= 0) return MA_OK;
+  MA_REQUIRE(cnt <= 3, MA_ERR_INVALID, "at most three systems per pass");
+  if (cnt == 1) return bem_launch_near(g, ph[0], pairs, npairs, As[0], st);
+  FarMulti fm;
+  for (int f = 0; f < 3; ++f) { fm.ph[f] = ph[f < cnt ? f : 0]; fm.A[f] = reinterpret_cast<dc*>(As[f < cnt ? f : 0]); }
+  dim3 grid((unsigned)((npairs + 3) / 4)), block(256);
+  if (cnt == 2) hipLaunchKernelGGL(tbem_near_multi_kernel<2>, grid, block, 0, st, g, fm, pairs, npairs);
+  else hipLaunchKernelGGL(tbem_near_multi_kernel<3>, grid, block, 0, st, g, fm, pairs, npairs);
+  if (g.nquad > 0) for (int f = 0; f < cnt; ++f) hipLaunchKernelGGL(tbem_near_quad_kernel<0>, grid, block, 0, st, g, ph[f], pairs, npairs, reinterpret_cast<dc*>(As[f]));
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -55,6 +55,7 @@ int bem_launch_far(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
 int bem_launch_far_multi(const BemGeom& g, int nf, const BemPhys* phs, c64* const* As, hipStream_t st, int blk0 = 0, int nblk = -1);
 int bem_far_row_strips(const BemGeom& g);
 int bem_launch_near(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* A, hipStream_t st);
+int bem_launch_near_multi(const BemGeom& g, int cnt, const BemPhys* ph, c64* const* As, const int2* pairs, long long npairs, hipStream_t st);
 int bem_launch_self(const BemGeom& g, const BemPhys& ph, c64* A, hipStream_t st);
 int bem_launch_probe_pairs(const BemGeom& g, const BemPhys& ph, const int2* pairs, long long npairs, c64* out5, hipStream_t st);
 int bem_launch_probe_self(const BemGeom& g, const BemPhys& ph, c64* out5, hipStream_t st);

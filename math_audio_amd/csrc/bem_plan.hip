@@ -371,7 +371,15 @@ static int assemble_multi_part(ma_bem_plan_t* P, int32_t nf, const ma_physics_t*
     if ((rc = bem_launch_far_multi(P->geom, cnt, bp + f0, As, st, b0, b1 - b0))) return rc;
   }
   if (P->timing && whole) MA_HIP(hipEventRecord(P->ev[1], st));
-  if (last) for (int f = 0; f < nf; ++f) if ((rc = bem_launch_near(P->geom, bp[f], P->d_pairs, P->npairs, (c64*)dA[f], st))) return rc;
+  // the near pairs likewise three systems per pass (round 4: the leaves and the points' geometry are the mesh's); MA_BEM_NEAR_MULTI=0: a launch per system
+  static const bool near_multi = [] { const char* e = getenv("MA_BEM_NEAR_MULTI"); return !(e && atoi(e) == 0); }();
+  if (last && near_multi)
+    for (int f0 = 0; f0 < nf; f0 += 3) {
+      c64* As[3]; const int cnt = std::min(3, nf - f0);
+      for (int t = 0; t < cnt; ++t) As[t] = (c64*)dA[f0 + t];
+      if ((rc = bem_launch_near_multi(P->geom, cnt, bp + f0, As, P->d_pairs, P->npairs, st))) return rc;
+    }
+  if (last && !near_multi) for (int f = 0; f < nf; ++f) if ((rc = bem_launch_near(P->geom, bp[f], P->d_pairs, P->npairs, (c64*)dA[f], st))) return rc;
   if (P->timing && whole) MA_HIP(hipEventRecord(P->ev[2], st));
   if (last) for (int f = 0; f < nf; ++f) if ((rc = bem_launch_self(P->geom, bp[f], (c64*)dA[f], st))) return rc;
   if (P->timing && whole) { MA_HIP(hipEventRecord(P->ev[3], st)); P->ev_valid = true; }
