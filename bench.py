@@ -415,7 +415,7 @@ def main():
     n = mesh.n_elem
     freqs = mm.log_space(100.0, 8000.0, 64)
     K, W = args.steps, args.warmup
-    S = max(1, min(args.slots, 4, K))
+    S = max(1, min(args.slots, 6 if os.environ.get("MA_LU_LANE_ALIAS") else 4, K))
     # rank r solves the list's points r, r + N, ...: its s-th step is point (r + s N) mod 64 (the list wraps for long runs)
     mine = lambda first, count: [freqs[(rank + (first + s_) * world) % len(freqs)] for s_ in range(count)]
     plan = ma.BemPlan(mesh, device=local_rank)

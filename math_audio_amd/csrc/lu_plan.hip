@@ -74,6 +74,8 @@ struct ma_lu_plan {
   int midlane = 1;                // 1: on the system's look-ahead stream, 2: on a third stream per system, 0: on the caller's stream
   bool lookahead = true;          // factor panel q+1 on a second stream under panel q's trailing update (MA_LU_LOOKAHEAD=0 disables)
   int want_nb = 64;               // panel width (MA_LU_NB): 64 columns keep two systems' panels co-resident from the first column of a 10k system
+  int lane_alias = 0;             // MA_LU_LANE_ALIAS=<L> (experiment): slots m and m + L share ONE lane stream (m mod L), so that six systems run on the three
+                                  // lanes' hardware queues -- an update-bound system (early blocks) and a chain-bound one (late blocks) per lane
   bool block_step = false;        // round 4: the main lane's per-panel launches of a block (12 gathers / scatters, 6 trsm, 6 zgemv, 5 in-block updates) as
                                   // lu_block_row_moves_kernel + lu_block_trsm_kernel + one zgemv (MA_LU_BLOCK_STEP; default with the register pair panels)
   ZgemmMode zmode;                // the update kernel family, resolved from the MA_ZGEMM_* switches when the plan is created
@@ -251,6 +253,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     // (49.5 against 49.3 ms per frequency; 51.8 against 48.6 with eight panels per block): built, tested, off by default
     P->block_step = false;
     if (const char* eb = getenv("MA_LU_BLOCK_STEP")) P->block_step = atoi(eb) != 0 && P->reg_panel && P->reg_pair;
+    if (const char* el = getenv("MA_LU_LANE_ALIAS")) { const int v = atoi(el); if (v >= 1 && v < LU_BATCH_MAX) P->lane_alias = v; }
   }
   for (int m = 0; m < LU_BATCH_MAX; ++m) { P->pws_m[m].test_abort_col = -1; P->pws_m[m].diag_sleep = 0; }
   if (const char* ed = getenv("MA_DIAG_PANEL_SLEEP")) for (int m = 0; m < LU_BATCH_MAX; ++m) P->pws_m[m].diag_sleep = std::max(0, std::min(64, atoi(ed)));
@@ -765,7 +768,7 @@ struct Stage {
     int w = (int)((long long)big_cols * P->share_pct / 100) / 128 * 128;
     return std::max(0, std::min(w, big_cols - 128));
   }
-  hipStream_t lane_stream(int m) const { return (P->cu_split && P->chain_mask) ? P->chain_streams[m] : P->panel_streams[m]; }
+  hipStream_t lane_stream(int m) const { return (P->cu_split && P->chain_mask) ? P->chain_streams[m] : P->panel_streams[P->lane_alias > 0 ? m % P->lane_alias : m]; }
   hipStream_t pan_stream(int m) const { return (P->cu_split && P->pan_mask) ? P->pan_streams[m] : lane_stream(m); }
   hipStream_t big_stream() const { return P->cu_split ? P->big_stream : st; }
   int gemm(int M_, int N_, int K_, const c64* a, const c64* b_, c64* c, hipStream_t s_, bool big_ = false) {
@@ -851,7 +854,7 @@ struct Stage {
     return MA_OK;
   }
   // the per-panel work of block g right of the block, the update of the next block's columns, then the next lane
-  int mwork(int m, int g) {
+  int mwork(int m, int g, bool with_lane = true) {
     c64* A = P->cur_A[m]; c64* B = P->cur_B[m]; hipStream_t sm = lane_stream(m);
     const int a0 = k0s[blk_first(g)], e = blk_end(g), nright = n - e;
     const int enext = (g + 1 < G) ? blk_end(g + 1) : e;
@@ -899,7 +902,15 @@ struct Stage {
       if (narrow && m % P->stage_group != 0) { MA_HIP(hipEventRecord(P->ev_lane[m], sm)); P->stage_lane_pending[m] = true; }
       return MA_OK;
     }
-    if (narrow && (rc = lane(m, g + 1))) return rc;
+    if (with_lane && narrow && (rc = lane(m, g + 1))) return rc;
+    return MA_OK;
+  }
+  // the second half of mwork when a round issues the halves apart (lanes shared by two slots: every slot's work right of its block first --
+  // it releases the slot's big update --, then the next block columns, the chain-bound slot's first)
+  int next_lane(int m, int g) {
+    if (P->stage_group >= 2) return MA_OK;
+    const int e = blk_end(g);
+    if (n - e > 0 && g + 1 < G && (rc = lane(m, g + 1))) return rc;
     return MA_OK;
   }
   int big(int m, int g) {
@@ -975,7 +986,7 @@ int ma_lu_plan_stage_reset(ma_lu_plan_t* P, void* stream) {
 // slot's next system there, beside the other slots' work, and pass the same stream to stage_begin)
 int ma_lu_plan_slot_stream(ma_lu_plan_t* P, int32_t slot, void** stream) {
   MA_REQUIRE(P && stream && slot >= 0 && slot < LU_BATCH_MAX, MA_ERR_INVALID, "bad argument");
-  *stream = (void*)((P->cu_split && P->chain_mask) ? P->chain_streams[slot] : P->panel_streams[slot]);
+  *stream = (void*)((P->cu_split && P->chain_mask) ? P->chain_streams[slot] : P->panel_streams[P->lane_alias > 0 ? slot % P->lane_alias : slot]);
   return MA_OK;
 }
 // the stream the plan runs its big trailing updates on when the chip is split (MA_LU_CU_SPLIT): masked to the update CUs. A driver
@@ -1017,7 +1028,7 @@ int ma_lu_plan_stage_begin(ma_lu_plan_t* P, int32_t slot, void* dA, void* dB, in
   if (slot + 1 > P->last_batch) P->last_batch = slot + 1;
   MA_HIP(hipMemsetAsync(P->pws.info + slot, 0, sizeof(int), st));          // this slot's first-zero-pivot word
   MA_HIP(hipEventRecord(P->ev_prep[slot], st));
-  MA_HIP(hipStreamWaitEvent(P->panel_streams[slot], P->ev_prep[slot], 0));
+  MA_HIP(hipStreamWaitEvent(P->panel_streams[P->lane_alias > 0 ? slot % P->lane_alias : slot], P->ev_prep[slot], 0));
   if (P->cu_split && P->chain_mask) MA_HIP(hipStreamWaitEvent(P->chain_streams[slot], P->ev_prep[slot], 0));
   if (P->stage_group >= 2) {                               // group mode: the first panels start when the whole group has begun (stage_begin_group)
     if (slot % P->stage_group != 0) { MA_HIP(hipEventRecord(P->ev_lane[slot], P->panel_streams[slot])); P->stage_lane_pending[slot] = true; }
@@ -1070,10 +1081,16 @@ int ma_lu_plan_stage_round(ma_lu_plan_t* P, int32_t count, const int32_t* slots,
   MA_REQUIRE(P && slots && blocks && count >= 0 && count <= LU_BATCH_MAX, MA_ERR_INVALID, "bad argument");
   MA_HIP(hipSetDevice(P->device));
   Stage S(P, (hipStream_t)stream);
-  for (int i = 0; i < count; ++i) {
+  for (int i = 0; i < count; ++i)
     MA_REQUIRE(slots[i] >= 0 && slots[i] < LU_BATCH_MAX && P->cur_A[slots[i]] && blocks[i] >= 0 && blocks[i] < S.G, MA_ERR_INVALID, "slot %d / block %d", slots[i], blocks[i]);
-    int rc = S.mwork(slots[i], blocks[i]); if (rc) return rc;
-  }
+  if (P->lane_alias > 0 && P->stage_group < 2) {
+    int ord[LU_BATCH_MAX];
+    for (int i = 0; i < count; ++i) ord[i] = i;
+    std::sort(ord, ord + count, [&](int a, int b) { return blocks[a] > blocks[b]; });      // the slot closest to its end first
+    for (int i = 0; i < count; ++i) { int rc = S.mwork(slots[ord[i]], blocks[ord[i]], false); if (rc) return rc; }
+    for (int i = 0; i < count; ++i) { int rc = S.next_lane(slots[ord[i]], blocks[ord[i]]); if (rc) return rc; }
+  } else
+  for (int i = 0; i < count; ++i) { int rc = S.mwork(slots[i], blocks[i]); if (rc) return rc; }
   if (P->stage_group >= 2) {
     // every group present in this round (all its slots, same block) launches the panels of its next block
     for (int i = 0; i < count; ++i) {

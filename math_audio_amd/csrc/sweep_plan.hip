@@ -97,7 +97,8 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma
   MA_REQUIRE(S, MA_ERR_NOMEM, "host allocation failed");
   S->plan = plan; S->device = device; S->n = n; S->cap = max_frequencies;
   if (slots < 1) slots = 3;
-  if (slots > 4) slots = 4;
+  { const char* el = getenv("MA_LU_LANE_ALIAS"); const int max_slots = (el && atoi(el) >= 1) ? 6 : 4;     // experiment: two slots per lane stream
+    if (slots > max_slots) slots = max_slots; }
   if (slots > max_frequencies) slots = max_frequencies;
   S->slots = slots;
   auto fail = [&](int code) { S->release(); delete S; return code; };
@@ -220,7 +221,7 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
   // first update is its largest, the lane waits for it anyway -- and the stream waits for it two rounds later, before the solution
   // is parked and before any assembly may write the buffers again.
   struct Pend { int stage = 0; int i = -1; void* x = nullptr; int round = 0; };
-  Pend pend[4];
+  Pend pend[8];
   // (measured neutral: 49.3 against 49.1 ms per frequency, 50.8 against 50.5 over 20 -- the lane is not what a slot's next system waits for;
   // off unless MA_SWEEP_DEFER_FINISH=1)
   const bool defer_ok = [&] { const char* e = getenv("MA_SWEEP_DEFER_FINISH"); return e && atoi(e) != 0; }();
@@ -235,7 +236,7 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     }
     return r;
   };
-  auto collect_all = [&]() -> int { int r = MA_OK; for (int s = 0; s < 4 && !r; ++s) if (pend[s].stage) r = collect(s); return r; };
+  auto collect_all = [&]() -> int { int r = MA_OK; for (int s = 0; s < 8 && !r; ++s) if (pend[s].stage) r = collect(s); return r; };
   hipStream_t ast = S->asm_st ? S->asm_st : st;               // where the assembly-ahead runs
   auto issue_part = [&](AsmSet& t) -> int {
     int r = collect_all();                                                  // no assembly writes a buffer whose backward substitution is still out
@@ -307,7 +308,7 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     int issue_g = 1;                                             // the block of the NEXT system after whose round a deferred backward substitution is issued
     if (const char* eg = getenv("MA_SWEEP_DEFER_BLOCK")) issue_g = std::max(0, std::min(4, atoi(eg)));
     for (int r = 0; !rc; ++r) {
-      int32_t sl[4], bl[4]; int cnt = 0; bool live = false;
+      int32_t sl[8], bl[8]; int cnt = 0; bool live = false;
       for (int s = 0; s < slots && !rc; ++s) {
         const int lr = r - off[(size_t)s];
         if (lr < 0) { live = true; continue; }
