@@ -428,7 +428,9 @@ int ma_op_create_gathered(ma_op_t* inner, int64_t row0, int64_t row1, ma_gather_
  * process holds (the library binds librccl at first use with dlopen and so shares the copy already loaded); ma_rccl_get_unique_id /
  * ma_rccl_comm_create / ma_rccl_comm_destroy wrap ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy of that same copy for hosts
  * without an RCCL binding of their own (the 128-byte id travels from rank 0 to the others by the host's own means).
- * Every rank must take the same decisions (same iteration counts): the collective has no timeout. Unmeasured on > 1 GPU. */
+ * Every rank must take the same decisions (same iteration counts): the collective has no timeout. Each rank's block carries its
+ * "a kernel abandoned a wait" word, and every rank raises its own if any rank's was set: the Krylov drivers of ALL ranks then return
+ * MA_ERR_HIP at their end. Unmeasured on > 1 GPU. */
 int ma_op_create_gathered_rccl(ma_op_t* inner, void* nccl_comm, int32_t nranks, int32_t rank, ma_op_t** out);
 int ma_rccl_get_unique_id(void* id128);
 int ma_rccl_comm_create(int32_t nranks, int32_t rank, const void* id128, int device, void** comm);

@@ -361,6 +361,19 @@ RcclApi* rccl_api() {
     if (r_ != ncclSuccess) { set_error("%s failed: %s", #call, R->GetErrorString(r_)); return MA_ERR_HIP; }  \
   } while (0)
 struct RcclGather { ncclComm_t comm; int nranks, rank; long long per; c64* stage; int device; };
+// The ranks must agree on failure: every rank's block carries one extra entry, its device-wide "a kernel abandoned a wait"
+// word at the time of the exchange; after the gather every rank raises its own word if ANY rank's was set, so the Krylov driver of every
+// rank returns MA_ERR_HIP at its end instead of one rank leaving while the others wait in the next collective.
+__global__ void rccl_status_out_kernel(const unsigned* __restrict__ spin_err, c64* __restrict__ slot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { slot->re = (spin_err && *spin_err != 0u) ? 1.0 : 0.0; slot->im = 0.0; }
+}
+__global__ void rccl_status_in_kernel(const c64* __restrict__ stage, long long stride, int nranks, unsigned* __restrict__ spin_err) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && spin_err) {
+    bool any = false;
+    for (int r = 0; r < nranks; ++r) any = any || stage[(long long)r * stride + (stride - 1)].re != 0.0;
+    if (any) *spin_err = 1u;
+  }
+}
 void rccl_gather_free(void* u) {
   RcclGather* g = (RcclGather*)u;
   if (g->stage) { (void)hipSetDevice(g->device); (void)hipFree(g->stage); }
@@ -372,12 +385,21 @@ int rccl_gather_cb(void* user, void* d_y, int64_t n, int64_t row0, int64_t row1,
   RcclGather* g = (RcclGather*)user;
   RcclApi* R = rccl_api();
   hipStream_t st = (hipStream_t)stream;
-  c64* y = (c64*)d_y; c64* mine = g->stage + (size_t)g->rank * (size_t)g->per;
+  const size_t stride = (size_t)g->per + 1;                 // a rank's block: `per` rows + its status entry
+  c64* y = (c64*)d_y; c64* mine = g->stage + (size_t)g->rank * stride;
   if (row1 - row0 < g->per && hipMemsetAsync(mine, 0, sizeof(c64) * (size_t)g->per, st) != hipSuccess) return -2;
   if (row1 > row0 && hipMemcpyAsync(mine, y + row0, sizeof(c64) * (size_t)(row1 - row0), hipMemcpyDeviceToDevice, st) != hipSuccess) return -3;
-  const ncclResult_t r = R->AllGather(mine, g->stage, 2 * (size_t)g->per, ncclDouble, g->comm, st);
+  unsigned* werr = spin_error_word();
+  hipLaunchKernelGGL(rccl_status_out_kernel, dim3(1), dim3(64), 0, st, werr, mine + g->per);
+  const ncclResult_t r = R->AllGather(mine, g->stage, 2 * stride, ncclDouble, g->comm, st);
   if (r != ncclSuccess) { set_error("ncclAllGather failed: %s", R->GetErrorString(r)); return -4; }
-  if (hipMemcpyAsync(y, g->stage, sizeof(c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return -5;
+  hipLaunchKernelGGL(rccl_status_in_kernel, dim3(1), dim3(64), 0, st, g->stage, (long long)stride, g->nranks, werr);
+  // the ranks' rows back into y: block r holds rows [r per, min(n, (r + 1) per))
+  for (int q = 0; q < g->nranks; ++q) {
+    const long long a = (long long)q * g->per, b = std::min<long long>(n, a + g->per);
+    if (b > a && hipMemcpyAsync(y + a, g->stage + (size_t)q * stride, sizeof(c64) * (size_t)(b - a), hipMemcpyDeviceToDevice, st) != hipSuccess) return -5;
+  }
+  if (hipGetLastError() != hipSuccess) return -6;
   return 0;
 }
 }  // namespace
@@ -425,7 +447,7 @@ int ma_op_create_gathered_rccl(ma_op_t* inner, void* nccl_comm, int32_t nranks, 
   RcclGather* g = new (std::nothrow) RcclGather{(ncclComm_t)nccl_comm, nranks, rank, per, nullptr, inner->device};
   MA_REQUIRE(g, MA_ERR_NOMEM, "host allocation failed");
   (void)hipSetDevice(inner->device);
-  if (hipMalloc(&g->stage, sizeof(c64) * (size_t)per * (size_t)nranks) != hipSuccess) { delete g; set_error("rank-sharded operator: the gather's staging vector does not fit"); return MA_ERR_NOMEM; }
+  if (hipMalloc(&g->stage, sizeof(c64) * ((size_t)per + 1) * (size_t)nranks) != hipSuccess) { delete g; set_error("rank-sharded operator: the gather's staging vector does not fit"); return MA_ERR_NOMEM; }
   int rc = ma_op_create_gathered(inner, row0, row1, rccl_gather_cb, g, out);
   if (rc) { rccl_gather_free(g); return rc; }
   (*out)->gather_free = rccl_gather_free;
