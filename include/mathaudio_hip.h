@@ -192,6 +192,10 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
                                    const double* incident_vec3, double amp_re, double amp_im, int32_t slots, ma_c64* X_out, int32_t* status_or_null,
                                    double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies);
 int ma_sweep_owner(int32_t frequency_index, int32_t ndev);      /* index into devices[] of the owner of a frequency */
+/* the order in which the staged frequency loop (room_simulator_bem.rs:328-360 as `slots` staggered factorisations of `blocks` blocks, `spacing`
+ * rounds apart) begins its n_freq frequencies: order_out[q] = frequency of the q-th begin. Systems are assembled ahead only when this is the
+ * identity. Pure host arithmetic (no device). */
+int ma_sweep_begin_order(int32_t blocks, int32_t slots, int32_t spacing, int32_t n_freq, int32_t* order_out);
 
 /* The same solve with the reference's own signature, lu_solve(&a, &b) -> x: inputs untouched, factors not copied back. */
 int ma_lu_solve(int32_t n, const ma_c64* A_rowmajor, const ma_c64* b, ma_c64* x);

@@ -84,6 +84,32 @@ struct ma_bem_sweep {
 
 namespace {
 
+// The order in which the staged loop BEGINS the frequencies (pure: no device): slot s begins its j-th system, frequency s + slots j, at
+// round s spacing + j blocks; within a round the slots are walked in order. order[q] = the frequency of the q-th begin.
+int begin_order(int32_t blocks, int32_t slots, int32_t spacing, int32_t n_freq, std::vector<int32_t>& order) {
+  order.clear();
+  if (blocks < 1 || slots < 1 || spacing < 1 || n_freq < 0) return MA_ERR_INVALID;
+  for (long long r = 0; (int32_t)order.size() < n_freq; ++r) {
+    bool live = false;
+    for (int s = 0; s < slots; ++s) {
+      const long long lr = r - (long long)s * spacing;
+      if (lr < 0) { live = true; continue; }
+      const long long i = s + (long long)slots * (lr / blocks);
+      if (i >= n_freq) continue;
+      live = true;
+      if (lr % blocks == 0) order.push_back((int32_t)i);
+    }
+    if (!live) break;
+  }
+  return MA_OK;
+}
+bool begins_in_order(int32_t blocks, int32_t slots, int32_t spacing) {
+  std::vector<int32_t> o;
+  if (begin_order(blocks, slots, spacing, 4 * slots, o)) return false;
+  for (size_t q = 0; q < o.size(); ++q) if (o[q] != (int32_t)q) return false;
+  return o.size() == (size_t)(4 * slots);
+}
+
 int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep** out) {
   *out = nullptr;
   int32_t n = 0;
@@ -134,7 +160,7 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma
   if (const char* ea = getenv("MA_SWEEP_ASM_AHEAD")) ahead = std::max(1, std::min(3, atoi(ea)));
   if (ahead > max_frequencies) ahead = std::max(1, (int)max_frequencies);
   if (const char* ep = getenv("MA_SWEEP_ASM_PIECES")) S->ppp = std::max(1, std::min(16, atoi(ep)));
-  if (!S->staged || (slots - 1) * S->spacing >= S->G) ahead = 1;
+  if (!S->staged || !begins_in_order(S->G, slots, S->spacing)) ahead = 1;    // ( <=> (slots - 1) spacing < blocks: tests/test_capi_cpu.py )
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2.0 * (double)ahead * 16.0 * (double)n * (double)n > 0.5 * (double)free_b) ahead = 1;
@@ -406,6 +432,17 @@ int check_args(int32_t n_freq, const double* frequencies_hz, double speed_of_sou
 }  // namespace
 
 extern "C" {
+
+// the order in which a sweep of `slots` slots, `spacing` rounds apart, over plans of `blocks` blocks begins its frequencies (what decides
+// whether systems may be assembled ahead: only when this is 0, 1, 2, ...); pure host arithmetic, exposed for the tests
+int ma_sweep_begin_order(int32_t blocks, int32_t slots, int32_t spacing, int32_t n_freq, int32_t* order_out) {
+  MA_REQUIRE(order_out || n_freq == 0, MA_ERR_INVALID, "NULL argument");
+  std::vector<int32_t> o;
+  const int rc = begin_order(blocks, slots, spacing, n_freq, o);
+  MA_REQUIRE(rc == MA_OK && (int32_t)o.size() == n_freq, MA_ERR_INVALID, "blocks %d, slots %d, spacing %d, %d frequencies", blocks, slots, spacing, n_freq);
+  for (int32_t q = 0; q < n_freq; ++q) order_out[q] = o[(size_t)q];
+  return MA_OK;
+}
 
 int ma_bem_sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep_t** out) {
   MA_REQUIRE(plan && out && max_frequencies > 0, MA_ERR_INVALID, "bad argument");

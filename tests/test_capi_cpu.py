@@ -119,3 +119,28 @@ def test_multi_device_sweep_entry_validates_and_shards():
     assert args(C.byref(mesh.c), None, 1, 2) == ma.MA_ERR_INVALID
     if ma.device_count() == 0:
         assert args(C.byref(mesh.c), dv.ctypes.data, 1, 2) == ma.MA_ERR_NO_DEVICE
+
+
+def test_sweep_begin_order_decides_the_assembly_ahead():
+    """The staged frequency loop assembles systems AHEAD only when its slots take the frequencies in order (round 3's default failed on
+    tiny meshes because they do not: ADVICE r3). ma_sweep_begin_order is the loop's own arithmetic: slot s begins frequency s + slots j
+    at round s spacing + j blocks. Every frequency begins exactly once, and the order is 0, 1, 2, ... exactly when
+    (slots - 1) spacing < blocks -- the library's rule."""
+    L = ma.lib()
+    L.ma_sweep_begin_order.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+
+    def order(blocks, slots, spacing, n):
+        out = np.full(n, -1, dtype=np.int32)
+        assert L.ma_sweep_begin_order(blocks, slots, spacing, n, out.ctypes.data_as(C.c_void_p)) == ma.MA_OK
+        return out
+    for blocks in list(range(1, 13)) + [20, 27, 40]:
+        for slots in range(1, 7):
+            for spacing in sorted({1, 2, 3, max(1, (blocks + slots // 2) // slots), max(1, (blocks + slots) // (slots + 1)), blocks, blocks + 1}):
+                n = 5 * slots + 1
+                o = order(blocks, slots, spacing, n)
+                assert sorted(o.tolist()) == list(range(n)), (blocks, slots, spacing, o)
+                monotone = bool(np.array_equal(o, np.arange(n)))
+                assert monotone == ((slots - 1) * spacing < blocks), (blocks, slots, spacing, o)
+    assert order(1, 3, 1, 7).tolist() == [0, 3, 1, 6, 4, 2, 5]       # the 80-panel case of the advisor: slot 0 takes 0, 3, 6 while slots 1 and 2 are at 1 and 2
+    assert order(27, 3, 9, 7).tolist() == list(range(7))               # S10: three slots a third of a factorisation apart
+    assert L.ma_sweep_begin_order(0, 3, 1, 4, np.zeros(4, dtype=np.int32).ctypes.data_as(C.c_void_p)) == ma.MA_ERR_INVALID
