@@ -158,6 +158,10 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
 typedef struct ma_bem_sweep ma_bem_sweep_t;
 typedef struct ma_lu_plan ma_lu_plan_t;           /* workspace for device-resident solves of size n (ma_lu_plan_create below) */
 int ma_bem_sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep_t** out);
+/* the same with the pivoting of the sweep's LU plan chosen by the caller (MA_LU_PIVOT_PARTIAL / MA_LU_PIVOT_TOURNAMENT, see
+ * ma_lu_plan_create_pivoting; -1 = the sweep's default, which is what ma_bem_sweep_create and ma_bem_solve_sweep[_multi] use:
+ * tournament, MA_SWEEP_PIVOTING=partial overrides) */
+int ma_bem_sweep_create_pivoting(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, int32_t pivoting, ma_bem_sweep_t** out);
 int ma_bem_sweep_destroy(ma_bem_sweep_t* sweep);
 int ma_bem_sweep_run(ma_bem_sweep_t* sweep, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
                      double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
@@ -206,6 +210,19 @@ int ma_lu_factorization_solve(ma_lu_factorization_t* f, const ma_c64* b, ma_c64*
 int ma_lu_factorization_destroy(ma_lu_factorization_t* f);
 
 int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out);
+/* Pivoting of a plan's factorisations (round 5). MA_LU_PIVOT_PARTIAL: LAPACK's zgetrf pivots -- what every entry that hands
+ * pivots or factors across this boundary uses (ma_zgesv, ma_lu_factorize: lu.rs:83-137 exposes `pivots`). MA_LU_PIVOT_TOURNAMENT:
+ * the pivot rows of every 32-column panel by a tournament (communication-avoiding LU: local eliminations, then eliminations of the
+ * winners' rows), one chip-wide decision per panel instead of one per column; admissible behind lu_solve (lu.rs:142-153 returns x
+ * only) and the default of the frequency sweep. Same storage of L, U and of the interchange sequence; solutions agree with LAPACK's to
+ * rounding (tests/test_lu_gpu.py). ma_lu_plan_create makes a partial-pivoting plan (MA_LU_PIVOTING=tournament overrides, for A/B runs). */
+#define MA_LU_PIVOT_PARTIAL 0
+#define MA_LU_PIVOT_TOURNAMENT 1
+int ma_lu_plan_create_pivoting(int32_t n, int device, int32_t pivoting, ma_lu_plan_t** out);
+int ma_lu_plan_pivoting(ma_lu_plan_t* plan, int32_t* pivoting);
+/* ma_zgesv with the pivoting named (ma_zgesv itself: partial). With MA_LU_PIVOT_TOURNAMENT the factors and ipiv that come back are
+ * those of the tournament: P A = L U holds with them as it does with LAPACK's, the rows chosen differ. */
+int ma_zgesv_pivoting(int32_t n, ma_c64* A_rowmajor, ma_c64* b, int32_t* ipiv_or_null, int32_t pivoting);
 int ma_lu_plan_destroy(ma_lu_plan_t* plan);
 /* Factor d_A in place (row-major, device) and solve for nrhs right-hand sides stored as
  * d_B[nrhs][n] (each contiguous). Asynchronous on `stream`; the singularity flag is reported by

@@ -79,6 +79,10 @@ def lib():
             "ma_bem_plan_last_timing": [vp, vp],
             "ma_zgesv": [i32, vp, vp, vp],
             "ma_lu_plan_create": [i32, C.c_int, P(vp)],
+            "ma_lu_plan_create_pivoting": [i32, C.c_int, i32, P(vp)],
+            "ma_lu_plan_pivoting": [vp, P(i32)],
+            "ma_zgesv_pivoting": [i32, vp, vp, vp, i32],
+            "ma_bem_sweep_create_pivoting": [vp, i32, i32, i32, P(vp)],
             "ma_lu_plan_destroy": [vp],
             "ma_lu_plan_factor_solve_dev": [vp, vp, vp, i32, vp],
             "ma_lu_plan_solve_dev": [vp, vp, vp, i32, vp],
@@ -360,25 +364,54 @@ class BemPlan:
         return out
 
 
-def zgesv(A, b, return_pivots=False):
+PIVOT_PARTIAL, PIVOT_TOURNAMENT = 0, 1     # MA_LU_PIVOT_* of include/mathaudio_hip.h
+
+
+def _pivoting(p):
+    if p is None:
+        return None
+    if isinstance(p, str):
+        return {"partial": PIVOT_PARTIAL, "tournament": PIVOT_TOURNAMENT}[p]
+    return int(p)
+
+
+def zgesv(A, b, return_pivots=False, pivoting=None, return_factors=False):
     """Host-buffer drop-in of lu_solve (lu.rs:142): returns x; raises MaError(MA_ERR_SINGULAR / MA_ERR_DIM).
-    return_pivots: also the 0-based row interchanges (LAPACK ipiv - 1)."""
+    return_pivots: also the 0-based row interchanges (LAPACK ipiv - 1). pivoting: None / "partial" (ma_zgesv) or "tournament"
+    (ma_zgesv_pivoting). return_factors: also L \\ U as LAPACK stores them (with return_pivots)."""
     A = np.array(A, dtype=np.complex128, order="C")
     x = np.array(b, dtype=np.complex128)
     if A.ndim != 2 or A.shape[0] != A.shape[1] or x.shape != (A.shape[0],):
         raise MaError(MA_ERR_DIM, "A must be n x n and b of length n")
     piv = np.zeros(A.shape[0], dtype=np.int32)
-    check(lib().ma_zgesv(A.shape[0], _vp(A), _vp(x), _vp(piv) if return_pivots else None))
+    pv = _pivoting(pivoting)
+    want_piv = return_pivots or return_factors
+    if pv is None:
+        check(lib().ma_zgesv(A.shape[0], _vp(A), _vp(x), _vp(piv) if want_piv else None))
+    else:
+        check(lib().ma_zgesv_pivoting(A.shape[0], _vp(A), _vp(x), _vp(piv) if want_piv else None, pv))
+    if return_factors:
+        return x, piv, A
     return (x, piv) if return_pivots else x
 
 
 class LuPlan:
     """ma_lu_plan_t: workspace for device-resident factor+solve of an n x n complex128 system."""
 
-    def __init__(self, n, device=0):
+    def __init__(self, n, device=0, pivoting=None):
+        """pivoting: None (ma_lu_plan_create: partial), "partial" or "tournament" (ma_lu_plan_create_pivoting)."""
         self.n = n
         self.h = C.c_void_p()
-        check(lib().ma_lu_plan_create(n, device, C.byref(self.h)))
+        pv = _pivoting(pivoting)
+        if pv is None:
+            check(lib().ma_lu_plan_create(n, device, C.byref(self.h)))
+        else:
+            check(lib().ma_lu_plan_create_pivoting(n, device, pv, C.byref(self.h)))
+
+    def pivoting(self):
+        v = C.c_int32(0)
+        check(lib().ma_lu_plan_pivoting(self.h, C.byref(v)))
+        return "tournament" if v.value == PIVOT_TOURNAMENT else "partial"
 
     def close(self):
         if self.h:
@@ -393,6 +426,10 @@ class LuPlan:
 
     def factor_solve_dev(self, d_A, d_B, nrhs=1, stream=0):
         check(lib().ma_lu_plan_factor_solve_dev(self.h, C.c_void_p(d_A), C.c_void_p(d_B), nrhs, C.c_void_p(stream)))
+
+    def solve_dev(self, d_A_factored, d_B, nrhs=1, stream=0):
+        """ma_lu_plan_solve_dev: further right-hand sides with the factors the plan's last factor_solve_dev left in d_A."""
+        check(lib().ma_lu_plan_solve_dev(self.h, C.c_void_p(d_A_factored), C.c_void_p(d_B), nrhs, C.c_void_p(stream)))
 
     def factor_solve_batch_dev(self, d_As, d_Bs, nrhs=1, stream=0):
         """Interleaved factor+solve of len(d_As) independent systems (device pointers)."""
@@ -1054,9 +1091,11 @@ class BemSweep:
     """ma_bem_sweep_t: the frequency loop (room_simulator_bem.rs:328-360) behind a reusable handle -- LU plan, streams, the systems in
     flight, the spares of the assembly-ahead and the parked solutions are allocated once. The plan is borrowed."""
 
-    def __init__(self, plan, max_frequencies, slots=3):
+    def __init__(self, plan, max_frequencies, slots=3, pivoting=None):
+        """pivoting: None (the sweep's default: tournament), "partial" or "tournament" (ma_bem_sweep_create_pivoting)."""
         self.plan = plan; self.n = plan.num_dofs; self.h = C.c_void_p()
-        check(lib().ma_bem_sweep_create(plan.h, int(slots), int(max_frequencies), C.byref(self.h)))
+        pv = _pivoting(pivoting)
+        check(lib().ma_bem_sweep_create_pivoting(plan.h, int(slots), int(max_frequencies), -1 if pv is None else pv, C.byref(self.h)))
 
     def close(self):
         if self.h:

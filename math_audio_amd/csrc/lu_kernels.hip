@@ -18,57 +18,13 @@
 //                      (zgemm_sub_kernel: the 4-product form, 128 x 128 tiles).
 #include "lu_kernels.hpp"
 #include "ma_device_math.hpp"
+#include "lu_device.hpp"
 #include <climits>
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
 
 namespace ma {
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef unsigned long long u64;
-
-#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#ifndef LU_GROUPS
-#define LU_GROUPS 8              // candidate-gather groups of the panel kernel (workgroup b -> group b % 8 = its XCD)
-#endif
-#ifndef LU_POLL_SLEEP
-#define LU_POLL_SLEEP 1          // x 64 clocks between two sweeps of the group granules
-#endif
-#ifndef LU_GRANULE_STRIDE
-#define LU_GRANULE_STRIDE 16
-#endif
-
-__device__ __forceinline__ void st_sc1(u64* p, double v) { __hip_atomic_store(p, (u64)__double_as_longlong(v), RLX_AGENT); }
-__device__ __forceinline__ double ld_sc1(const u64* p) { return __longlong_as_double((long long)__hip_atomic_load(p, RLX_AGENT)); }
-__device__ __forceinline__ double cabs1(dc z) { return __builtin_fabs(z.re) + __builtin_fabs(z.im); }
-
-// reciprocal of a complex number the way LAPACK forms ONE / A(j,j) (Smith's division)
-__device__ __forceinline__ dc crecip(dc z) {
-  if (__builtin_fabs(z.im) < __builtin_fabs(z.re)) {
-    double e = z.im / z.re, f = z.re + z.im * e;
-    return dc_make(1.0 / f, -e / f);
-  }
-  double e = z.re / z.im, f = z.im + z.re * e;
-  return dc_make(e / f, -1.0 / f);
-}
-
-// the same reciprocal with v_rcp_f64 + two Newton steps in place of the three IEEE divisions (about 600 cycles on the critical
-// path of every column of lu_panel_reg_kernel): within 2 ulp of crecip
-__device__ __forceinline__ double rcp_nr(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-  return y;
-}
-__device__ __forceinline__ dc crecip_fast(dc z) {
-  if (__builtin_fabs(z.im) < __builtin_fabs(z.re)) {
-    const double e = z.im * rcp_nr(z.re), g = rcp_nr(__builtin_fma(z.im, e, z.re));
-    return dc_make(g, -e * g);
-  }
-  const double e = z.re * rcp_nr(z.im), g = rcp_nr(__builtin_fma(z.re, e, z.im));
-  return dc_make(e * g, -g);
-}
 
 // better (value, row) candidate: larger value, ties -> lower row (izamax takes the first maximum)
 __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) { return v > bv || (v == bv && r < br); }
@@ -91,18 +47,6 @@ __device__ __forceinline__ PanelCand wave_best(PanelCand c) {
     if (cand_better(ov, orow, c.v, c.row)) { c.v = ov; c.row = orow; }
   }
   return c;
-}
-
-// maximum of an unsigned value over the wavefront (DPP shifts inside the rows of 16 lanes, then the two row broadcasts);
-// lanes that receive nothing contribute 0
-__device__ __forceinline__ unsigned wave_umax(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8 -> lane 15 of a row holds the row's maximum
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, int n, int k0, int nb, int rpb, LuPanelWs ws,
@@ -442,15 +386,6 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
 // The kernel is meant for CUs that no throughput kernel shares (CU-masked streams, lu_plan.hip): there its exchange runs
 // at the idle round trip (profiles/r03_cumask_probe.txt), and its registers (about 200 per lane, one wavefront per SIMD)
 // are why it is admitted one workgroup per CU.
-__device__ __forceinline__ unsigned wave_umin(unsigned v) { return ~wave_umax(~v); }
-
-// compile-time loop: f(integral_constant<int, I>) for I = I0 .. N-1. Every index into the row registers is a constant when the
-// code is generated (a runtime-indexed array of 4 NB registers would live in scratch memory: the unroller alone left it there)
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
 template <int NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv, int* __restrict__ lists,
                          dc* __restrict__ lrows, int lcol0) {

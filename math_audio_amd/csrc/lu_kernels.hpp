@@ -51,6 +51,11 @@ int lu_launch_lane_step2(c64* A, int n, int k0, int nb, const int* lists1, const
                          const c64* l10, hipStream_t st);
 int lu_launch_lane_step(c64* A, int n, int k0, int nb, const int* lists, int x0, int ncols, c64* invd, const unsigned* poison, hipStream_t st);
 int lu_panel_reg_admissible(int nblk, int ncu);
+// Tournament pivoting (lu_calu.hip): the same panel, the same outputs, no workgroup waits for another. Per slot: cand[nodes][LU_REG_NB]
+// row indices and one arrival counter per tree node (zero between launches).
+struct LuCaluWs { int* cand = nullptr; unsigned* counters = nullptr; int max_nodes = 0; };
+int lu_calu_tree_nodes(int leaves);
+int lu_launch_panel_calu(c64* A, int n, int k0, int nb, const LuCaluWs& ws, int* info, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0);
 int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st);
 void lu_panel_forget_stream(int dev, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);

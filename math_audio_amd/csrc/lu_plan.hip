@@ -23,6 +23,9 @@ using namespace ma;
 #ifndef MA_LU_CU_SPLIT_DEFAULT
 #define MA_LU_CU_SPLIT_DEFAULT 64
 #endif
+#ifndef MA_LU_CU_SPLIT_TOURNAMENT
+#define MA_LU_CU_SPLIT_TOURNAMENT 64        // CUs the big updates stay off in a tournament-pivoting plan
+#endif
 #define LU_KB_MAX 8                         // panels per trailing update
 #define LU_LANE_TSTRIDE 512                   // the lane's interchanges touch at most (kb-1) panels' columns: 7 x 64 or 3 x 128
 
@@ -116,6 +119,11 @@ struct ma_lu_plan {
   int share_pct = 0, share_min_rows = 0;                  // staged schedule: blocks with at least share_min_rows rows left give share_pct % of their big update's columns to the slot's lane (see Stage::lane_share)
   int tail_rows = 0;                                      // staged schedule: blocks with at most this many rows left take their WHOLE trailing update on the slot's lane (see Stage::tail)
   int admit_cus = 0;                                      // MA_LU_ADMIT_CUS: the CU count the admission window counts register panels against (0: what the launch may use)
+  // round 5: MA_LU_PIVOT_TOURNAMENT -- the half-panels by lu_launch_panel_calu (lu_calu.hip: one tournament per 32 columns instead of one
+  // chip-wide exchange per column; no workgroup waits for another). The pivots differ from LAPACK's, the solution does not (to
+  // rounding): the mode of the sweep, where lu_solve's contract (x only, lu.rs:142-153) is the boundary. MA_LU_PIVOT_PARTIAL elsewhere.
+  int pivoting = MA_LU_PIVOT_PARTIAL;
+  LuCaluWs calu[LU_BATCH_MAX]{};
 };
 
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
@@ -157,6 +165,13 @@ int ma_lu_plan::ensure_batch(int nmat) {
     MA_HIP(hipMalloc(&d_half_invd[m], sizeof(c64) * 32 * 32));
     MA_HIP(hipMalloc(&d_half_l10[m], sizeof(c64) * 32 * 32));
     MA_HIP(hipMemset(d_half_l10[m], 0, sizeof(c64) * 32 * 32));
+    if (pivoting == MA_LU_PIVOT_TOURNAMENT) {
+      const int nodes = lu_calu_tree_nodes((n + 255) / 256);
+      MA_HIP(hipMalloc(&calu[m].cand, sizeof(int) * (size_t)nodes * LU_REG_NB));
+      MA_HIP(hipMalloc(&calu[m].counters, sizeof(unsigned) * (size_t)nodes));
+      MA_HIP(hipMemset(calu[m].counters, 0, sizeof(unsigned) * (size_t)nodes));
+      calu[m].max_nodes = nodes;
+    }
     // the memset above runs on the null stream; the plan's lanes and the callers' streams may be non-blocking streams that do
     // not order themselves against it: without this wait it can land AFTER a panel kernel has written its pivots (seen as
     // "pivot outside its range" under two host threads)
@@ -168,9 +183,23 @@ int ma_lu_plan::ensure_batch(int nmat) {
 extern "C" {
 
 int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
+  // MA_LU_PIVOTING=tournament|partial: the mode of plans made through this entry (the drop-in entries of lu.rs: partial)
+  int mode = MA_LU_PIVOT_PARTIAL;
+  if (const char* e = getenv("MA_LU_PIVOTING")) mode = (e[0] == 't' || e[0] == 'T' || e[0] == '1') ? MA_LU_PIVOT_TOURNAMENT : MA_LU_PIVOT_PARTIAL;
+  return ma_lu_plan_create_pivoting(n, device, mode, out);
+}
+
+int ma_lu_plan_pivoting(ma_lu_plan_t* P, int32_t* pivoting) {
+  MA_REQUIRE(P && pivoting, MA_ERR_INVALID, "NULL argument");
+  *pivoting = P->pivoting;
+  return MA_OK;
+}
+
+int ma_lu_plan_create_pivoting(int32_t n, int device, int32_t pivoting, ma_lu_plan_t** out) {
   MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
   *out = nullptr;
   MA_REQUIRE(n > 0, MA_ERR_DIM, "n must be positive (got %d)", n);
+  MA_REQUIRE(pivoting == MA_LU_PIVOT_PARTIAL || pivoting == MA_LU_PIVOT_TOURNAMENT, MA_ERR_INVALID, "pivoting mode %d", pivoting);
   int rc = use_device(device);
   if (rc) return rc;
   hipDeviceProp_t prop;
@@ -179,7 +208,7 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   MA_REQUIRE((long long)n <= 256LL * ncu, MA_ERR_UNSUPPORTED, "n = %d exceeds the co-resident panel capacity (%d rows)", n, 256 * ncu);
   ma_lu_plan* P = new (std::nothrow) ma_lu_plan();
   MA_REQUIRE(P, MA_ERR_NOMEM, "host allocation failed");
-  P->device = device; P->n = n; P->ncu = ncu;
+  P->device = device; P->n = n; P->ncu = ncu; P->pivoting = pivoting;
   const int mb = ncu;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -227,9 +256,11 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
   // the register panel kernel when the tallest panel's workgroups (256 rows each) are co-resident on the CUs its stream may use
   {
     const bool lds_tuned = P->rpb_env || getenv("MA_LU_NB") || P->batch_panel;
-    int want_reg = (n >= MA_LU_PAIR_MIN_N && n <= MA_LU_PAIR_MAX_N && ncu == 256 && !lds_tuned) ? 2 : 0;
-    if (const char* er = getenv("MA_LU_REG_PANEL")) want_reg = atoi(er);
-    int split = want_reg == 2 ? MA_LU_CU_SPLIT_DEFAULT : 0;
+    const bool tour = pivoting == MA_LU_PIVOT_TOURNAMENT;   // tournament panels: the pair structure at every size (nothing has to be co-resident)
+    int want_reg = (tour || (n >= MA_LU_PAIR_MIN_N && n <= MA_LU_PAIR_MAX_N && ncu == 256 && !lds_tuned)) ? 2 : 0;
+    if (const char* er = getenv("MA_LU_REG_PANEL")) { if (!tour) want_reg = atoi(er); }
+    int split = want_reg == 2 ? (tour ? MA_LU_CU_SPLIT_TOURNAMENT : MA_LU_CU_SPLIT_DEFAULT) : 0;
+    if (tour && !(n >= MA_LU_PAIR_MIN_N && n <= MA_LU_PAIR_MAX_N && ncu == 256)) split = 0;
     if (const char* es = getenv("MA_LU_CU_SPLIT")) split = atoi(es);
     if (const char* ec = getenv("MA_LU_CHAIN_MASK")) P->chain_mask = atoi(ec) != 0;
     if (const char* ep = getenv("MA_LU_PAN_MASK")) P->pan_mask = atoi(ep) != 0;
@@ -239,8 +270,9 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
     if (const char* et = getenv("MA_LU_LANE_SHARE_MIN_ROWS")) { const int v = atoi(et); if (v >= 0) P->share_min_rows = v; }
     if (split < 8 || split % 8 != 0 || split > ncu - 64 || ncu % 32 != 0 || !P->lookahead || !P->panel_overlap) split = 0;
     P->cu_split = split;
-    if (P->batch_panel) want_reg = 0;                      // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
-    if (!rc && want_reg && n <= 65535) {
+    if (P->batch_panel && !tour) want_reg = 0;             // the shared (wavefront-per-system) panel kernel is the LDS family: a plan stays in one family
+    if (tour) { P->batch_panel = false; P->pan_mask = 0; P->reg_panel = true; P->reg_pair = true; }
+    else if (!rc && want_reg && n <= 65535) {
       const int nblk0 = (n + 255) / 256;
       if (nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, (split && P->pan_mask) ? split : ncu) == MA_OK) { P->reg_panel = true; P->reg_pair = want_reg == 2; }
       else if (split && P->pan_mask && nblk0 <= P->pws.max_blocks && lu_panel_reg_admissible(nblk0, ncu) == MA_OK) { P->pan_mask = 0; P->reg_panel = true; P->reg_pair = want_reg == 2; }   // too tall for the panel CUs: panels anywhere
@@ -351,6 +383,7 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
     if (P->ev_pan[i]) (void)hipEventDestroy(P->ev_pan[i]); if (P->ev_chain[i]) (void)hipEventDestroy(P->ev_chain[i]); }
   if (P->big_stream) (void)hipStreamDestroy(P->big_stream);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
+    if (P->calu[i].cand) (void)hipFree(P->calu[i].cand); if (P->calu[i].counters) (void)hipFree(P->calu[i].counters);
     if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); if (P->d_half_lists[i]) (void)hipFree(P->d_half_lists[i]); if (P->d_half_invd[i]) (void)hipFree(P->d_half_invd[i]); if (P->d_half_l10[i]) (void)hipFree(P->d_half_l10[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   delete P;
@@ -435,7 +468,9 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     // this (lu_perm_kernel on 64 pivots, interchanges, U12, K = 64 updates, the main lane) is the 64-column schedule
     const int n = P->n, cus = P->admit_cus > 0 ? P->admit_cus : (masked ? P->panel_cus() : P->ncu);
     const int h1 = std::min(nb, LU_REG_NB), h2 = nb - h1;
-    int rc = lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st);
+    const bool tour = P->pivoting == MA_LU_PIVOT_TOURNAMENT;
+    int rc = tour ? lu_launch_panel_calu(A, n, k0, h1, P->calu[m], ws.info, ipiv, P->d_half_lists[m], st)
+                  : lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st);
     if (rc || h2 <= 0) return rc;
     const int a1 = k0 + h1;
     if ((rc = lu_launch_lane_step(A, n, k0, h1, P->d_half_lists[m], a1, h2, P->d_half_invd[m], P->pws.timeout, st))) return rc;
@@ -443,6 +478,7 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     if (skip_k32 < 32 && (rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m, false, &P->zmode))) return rc;
     // (the right half's interchanges on the LEFT half's columns -- part of the interchange itself inside a 64-column panel kernel --
     // are the first job of lu_lane_step2_kernel, which every caller launches next)
+    if (tour) return lu_launch_panel_calu(A, n, a1, h2, P->calu[m], ws.info, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, st, P->d_half_l10[m], k0);
     return lu_launch_panel_reg(A, n, a1, h2, (n - a1 + 255) / 256, cus, ws, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, false, st, P->d_half_l10[m], k0);
   }
   if (P->reg_panel) return lu_launch_panel_reg(A, P->n, k0, nb, nblk, masked ? P->panel_cus() : P->ncu, ws, ipiv, lists, clear_tags, st);
@@ -1046,6 +1082,7 @@ int ma_lu_plan_stage_set_group(ma_lu_plan_t* P, int32_t group_size) {
   // slot groups share ONE wavefront-per-system panel kernel, which is of the LDS family: a plan created with register panels
   // factors with the LDS family while groups are set (a plan stays in one family per factorisation: the two pivot the same
   // rows but round differently) and returns to its own with group_size < 2
+  MA_REQUIRE(group_size < 2 || P->pivoting != MA_LU_PIVOT_TOURNAMENT, MA_ERR_UNSUPPORTED, "slot groups share a partial-pivoting panel kernel: not with a tournament-pivoting plan");
   if (group_size >= 2 && P->reg_panel0) {
     P->reg_panel = false; P->reg_pair = false;
     std::vector<int> k0s, nbs, rpbs, nblks;
@@ -1299,14 +1336,16 @@ int ma_lu_plan_last_update_stats(ma_lu_plan_t* P, double* launches, double* flop
   return MA_OK;
 }
 
-int ma_zgesv(int32_t n, ma_c64* A, ma_c64* b, int32_t* ipiv) {
+int ma_zgesv(int32_t n, ma_c64* A, ma_c64* b, int32_t* ipiv) { return ma_zgesv_pivoting(n, A, b, ipiv, MA_LU_PIVOT_PARTIAL); }
+
+int ma_zgesv_pivoting(int32_t n, ma_c64* A, ma_c64* b, int32_t* ipiv, int32_t pivoting) {
   MA_REQUIRE(n >= 0, MA_ERR_DIM, "n is negative");
   if (n == 0) return MA_OK;
   MA_REQUIRE(A && b, MA_ERR_INVALID, "A or b is NULL");
   int dev = 0;
   if (const char* s = getenv("MA_DEVICE")) dev = atoi(s);
   ma_lu_plan_t* P = nullptr;
-  int rc = ma_lu_plan_create(n, dev, &P);
+  int rc = ma_lu_plan_create_pivoting(n, dev, pivoting, &P);
   if (rc) return rc;
   void *dA = nullptr, *db = nullptr;
   const size_t nn = (size_t)n;
@@ -1361,7 +1400,7 @@ int ma_lu_factorize(int32_t n, const ma_c64* A, ma_lu_factorization_t** out) {
   ma_lu_factorization* F = new (std::nothrow) ma_lu_factorization();
   MA_REQUIRE(F, MA_ERR_NOMEM, "host allocation failed");
   F->n = n;
-  int rc = ma_lu_plan_create(n, dev, &F->plan);
+  int rc = ma_lu_plan_create_pivoting(n, dev, MA_LU_PIVOT_PARTIAL, &F->plan);     // lu.rs:83-137 exposes `pivots`: LAPACK's
   const size_t nn = (size_t)n;
   if (!rc) {
     hipError_t e = hipMalloc(&F->dA, nn * nn * sizeof(c64));

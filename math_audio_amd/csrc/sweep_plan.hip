@@ -110,7 +110,13 @@ bool begins_in_order(int32_t blocks, int32_t slots, int32_t spacing) {
   return o.size() == (size_t)(4 * slots);
 }
 
-int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep** out) {
+// the sweep's pivoting when the caller does not say: tournament (see ma_lu_plan_create_pivoting); MA_SWEEP_PIVOTING=partial|tournament overrides
+int default_pivoting() {
+  if (const char* e = getenv("MA_SWEEP_PIVOTING")) return (e[0] == 'p' || e[0] == 'P' || e[0] == '0') ? MA_LU_PIVOT_PARTIAL : MA_LU_PIVOT_TOURNAMENT;
+  return MA_LU_PIVOT_TOURNAMENT;
+}
+
+int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, int32_t pivoting, ma_bem_sweep** out) {
   *out = nullptr;
   int32_t n = 0;
   int rc = ma_bem_plan_num_dofs(plan, &n);
@@ -128,7 +134,7 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma
   if (slots > max_frequencies) slots = max_frequencies;
   S->slots = slots;
   auto fail = [&](int code) { S->release(); delete S; return code; };
-  if ((rc = ma_lu_plan_create(n, device, &S->lu))) return fail(rc);
+  if ((rc = ma_lu_plan_create_pivoting(n, device, pivoting, &S->lu))) return fail(rc);
   // the sweep's own stream: the plan's big-update stream when the plan splits the chip (that stream is masked to the update CUs,
   // and a stream more would be one hardware queue more: profiles/r03_lu_panel_experiments.md), a stream of its own otherwise
   { void* ms = nullptr; if (ma_lu_plan_main_stream(S->lu, &ms) == MA_OK && ms) S->st = (hipStream_t)ms; }
@@ -445,10 +451,16 @@ int ma_sweep_begin_order(int32_t blocks, int32_t slots, int32_t spacing, int32_t
 }
 
 int ma_bem_sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, ma_bem_sweep_t** out) {
+  return ma_bem_sweep_create_pivoting(plan, slots, max_frequencies, -1, out);
+}
+
+int ma_bem_sweep_create_pivoting(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, int32_t pivoting, ma_bem_sweep_t** out) {
   MA_REQUIRE(plan && out && max_frequencies > 0, MA_ERR_INVALID, "bad argument");
+  MA_REQUIRE(pivoting == -1 || pivoting == MA_LU_PIVOT_PARTIAL || pivoting == MA_LU_PIVOT_TOURNAMENT, MA_ERR_INVALID, "pivoting mode %d", pivoting);
+  if (pivoting < 0) pivoting = default_pivoting();
   int prev = -1;
   const bool had = hipGetDevice(&prev) == hipSuccess;
-  const int rc = sweep_create(plan, slots, max_frequencies, out);
+  const int rc = sweep_create(plan, slots, max_frequencies, pivoting, out);
   if (had) (void)hipSetDevice(prev);
   return rc;
 }
@@ -588,7 +600,7 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
     int c = 0; for (int f = d; f < n_freq; f += ndev) ++c;
     const auto t0 = std::chrono::steady_clock::now();
     int r = c > 0 ? ma_bem_plan_create(mesh, devices[d], &plan) : MA_OK;
-    if (!r && c > 0) r = sweep_create(plan, slots, c, &S);
+    if (!r && c > 0) r = sweep_create(plan, slots, c, default_pivoting(), &S);
     const auto t1 = std::chrono::steady_clock::now();
     if (!r && c > 0) r = sweep_run(S, n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null);
     const auto t2 = std::chrono::steady_clock::now();
