@@ -220,6 +220,12 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out);
 #define MA_LU_PIVOT_TOURNAMENT 1
 int ma_lu_plan_create_pivoting(int32_t n, int device, int32_t pivoting, ma_lu_plan_t** out);
 int ma_lu_plan_pivoting(ma_lu_plan_t* plan, int32_t* pivoting);
+/* Plans that factor in 64-column panels of two halves (4 096..16 384 rows, every tournament plan) try each half-panel SPECULATIVELY first
+ * (lu_spec.hip): partial pivoting among the panel's top 32 rows, then the check that no row below holds a larger entry in any column --
+ * if it passes, zgetrf would have chosen the same rows, and the panel is done in two short launches without any exchange between
+ * workgroups; if not, the panel is restored and the plan's own panel kernel factors it. Boundary operators of the Burton-Miller form
+ * (tbem.rs:96-222) pass at every panel. Counts since the plan was made (synchronises the device); MA_LU_SPECULATE=0 switches it off. */
+int ma_lu_plan_speculation_stats(ma_lu_plan_t* plan, int64_t* accepted, int64_t* rejected);
 /* ma_zgesv with the pivoting named (ma_zgesv itself: partial). With MA_LU_PIVOT_TOURNAMENT the factors and ipiv that come back are
  * those of the tournament: P A = L U holds with them as it does with LAPACK's, the rows chosen differ. */
 int ma_zgesv_pivoting(int32_t n, ma_c64* A_rowmajor, ma_c64* b, int32_t* ipiv_or_null, int32_t pivoting);

@@ -81,6 +81,7 @@ def lib():
             "ma_lu_plan_create": [i32, C.c_int, P(vp)],
             "ma_lu_plan_create_pivoting": [i32, C.c_int, i32, P(vp)],
             "ma_lu_plan_pivoting": [vp, P(i32)],
+            "ma_lu_plan_speculation_stats": [vp, P(i64), P(i64)],
             "ma_zgesv_pivoting": [i32, vp, vp, vp, i32],
             "ma_bem_sweep_create_pivoting": [vp, i32, i32, i32, P(vp)],
             "ma_lu_plan_destroy": [vp],
@@ -407,6 +408,12 @@ class LuPlan:
             check(lib().ma_lu_plan_create(n, device, C.byref(self.h)))
         else:
             check(lib().ma_lu_plan_create_pivoting(n, device, pv, C.byref(self.h)))
+
+    def speculation_stats(self):
+        """ma_lu_plan_speculation_stats: (accepted, rejected) half-panels of the speculative panel since the plan was made."""
+        a = C.c_int64(0); r = C.c_int64(0)
+        check(lib().ma_lu_plan_speculation_stats(self.h, C.byref(a), C.byref(r)))
+        return a.value, r.value
 
     def pivoting(self):
         v = C.c_int32(0)

@@ -27,7 +27,6 @@ namespace ma {
 namespace {
 
 constexpr int CALU_FAN = 8;                      // children per tree node: 8 x 32 candidates = the 256 lanes of a workgroup
-constexpr unsigned CALU_NONE = 0xFFFFFFFFu;
 static_assert(CALU_FAN * LU_REG_NB == 256, "a tree node's candidates fill one workgroup");
 
 #ifdef MA_CALU_STAMPS
@@ -43,12 +42,10 @@ struct CaluLds {
   dc urow[2][LU_REG_NB];                         // [column parity]: the pivot row of the column (entries >= column)
   dc rinv[2];                                    // the reciprocal of its entry of the column
   __attribute__((aligned(16))) unsigned key[2][4];   // every wavefront's best key (0: no row left)
-  int win[LU_REG_NB];                            // the node's pivot rows, in pivot order (-1: the node ran out of rows)
   int flag;
-  // the root only
-  int ipiv[LU_REG_NB], ext_pos[LU_REG_NB], ext_src[LU_REG_NB], next;
-  int ldst[2 * LU_REG_NB], lsrc[2 * LU_REG_NB], lm;
+  PivotSeqLds seq;                               // seq.win: the node's pivot rows, in pivot order (-1: the node ran out of rows); the rest: the root only
 };
+static_assert(LU_REG_NB == 32, "PivotSeqLds holds 32 pivots");
 
 // crecip_fast without a branch (the same operations on the same operands, chosen by selects): every lane forms the reciprocal of
 // its own entry BESIDE the wavefront's reduction, so that no reciprocal sits between a column's barrier and its elimination
@@ -60,7 +57,7 @@ __device__ __forceinline__ dc crecip_sel(dc z) {
 }
 
 // Gaussian elimination with partial pivoting over the <= 256 rows a workgroup holds in registers (lane = row, `rowid` = the row's
-// index in the matrix), columns 0..nbc-1. Returns the column this thread's row became the pivot row of (-1: none); S.win[c] = the
+// index in the matrix), columns 0..nbc-1. Returns the column this thread's row became the pivot row of (-1: none); S.seq.win[c] = the
 // pivot row of column c.
 // What a column costs is LDS INSTRUCTIONS, not arithmetic (tools/lds_cost_probe.hip: the CU's LDS takes one b128 store per ~14
 // clocks and one b128 load per ~7.4 however many lanes are active, for all four wavefronts together): per column ONE wavefront
@@ -119,9 +116,9 @@ __device__ __forceinline__ int calu_gepp(dc (&a)[NB], bool valid, int rowid, int
     if (iam) {
       static_for<c, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; S.urow[buf][j] = a[j]; });
       S.rinv[buf] = rv;
-      S.win[c] = rowid;
+      S.seq.win[c] = rowid;
     }
-    if (!any && tid == 0) S.win[c] = -1;
+    if (!any && tid == 0) S.seq.win[c] = -1;
     CALU_SUB(3);
     __syncthreads();
     rank = iam ? c : rank;
@@ -159,9 +156,11 @@ __device__ __forceinline__ int calu_gepp(dc (&a)[NB], bool valid, int rowid, int
 template <int NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void lu_calu_panel_kernel(dc* __restrict__ A, int n, int k0, int nbc, int* __restrict__ cand, unsigned* __restrict__ counters,
-                          int* __restrict__ info, int* __restrict__ ipiv, int* __restrict__ lists, dc* __restrict__ lrows, int lcol0) {
+                          int* __restrict__ info, int* __restrict__ ipiv, int* __restrict__ lists, dc* __restrict__ lrows, int lcol0,
+                          const int* __restrict__ run_if_nonzero) {
   __shared__ CaluLds S;
   const int tid = threadIdx.x;
+  if (run_if_nonzero && __hip_atomic_load(run_if_nonzero, RLX_AGENT) == 0) return;   // the speculative panel (lu_spec.hip) was accepted: nothing to do (uniform over the grid)
   int level_n = (int)gridDim.x, base = 0, node = (int)blockIdx.x;
   int rowid = k0 + node * 256 + tid;
   bool valid = rowid < n;
@@ -188,7 +187,7 @@ void lu_calu_panel_kernel(dc* __restrict__ A, int n, int k0, int nbc, int* __res
     // publish the node's pivot rows; the workgroup that completes the parent's set of children carries on as the parent
     // (write-through stores, counted out before the counter moves; the reader's loads bypass its own L2 the same way: the exchange
     // idiom of lu_panel_reg_kernel -- a fence here would write back the whole L2 of the XCD, which an update kernel beside us keeps dirty)
-    if (tid < NB) { __hip_atomic_store(cand + (size_t)(base + node) * NB + tid, S.win[tid], RLX_AGENT); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (tid < NB) { __hip_atomic_store(cand + (size_t)(base + node) * NB + tid, S.seq.win[tid], RLX_AGENT); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
     const int parent = node / CALU_FAN;
     const int nchild = min(CALU_FAN, level_n - CALU_FAN * parent);
@@ -211,33 +210,7 @@ void lu_calu_panel_kernel(dc* __restrict__ A, int n, int k0, int nbc, int* __res
   }
 
   // ---- the root: the winners' registers hold the rows of L11 \ U11
-  const int lane = tid & 63;
-  if (tid < 64) {
-    // the interchange sequence that brings winner c to position k0 + c, c = 0, 1, ...: lanes 0..31 track what the panel's top
-    // positions hold, lanes 32.. the positions below that a swap has touched
-    int pos = lane < NB ? k0 + lane : -1, content = pos;
-    bool act = lane < nbc;
-    int next = 0;
-    for (int c = 0; c < nbc; ++c) {
-      const int gc = k0 + c, r = S.win[c];
-      if (r < 0) { if (lane == 0) S.ipiv[c] = gc; continue; }
-      const u64 hm = __ballot(act && content == r);
-      const int hl = hm ? (int)__builtin_ctzll(hm) : -1;
-      const int P = hl >= 0 ? __shfl(pos, hl, 64) : r;       // where row r is now
-      if (lane == 0) S.ipiv[c] = P;
-      const int old = __shfl(content, c, 64);
-      if (P != gc) {
-        if (hl >= 0) { if (lane == hl) content = old; }
-        else { if (lane == NB + next) { pos = P; content = old; act = true; } ++next; }
-        if (lane == c) content = r;
-      }
-    }
-    const bool keep = act && content != pos;
-    const u64 km = __ballot(keep);
-    if (keep) { const int o = __popcll(km & (((u64)1 << lane) - 1)); S.ldst[o] = pos; S.lsrc[o] = content; }
-    if (lane >= NB && lane < NB + next) { S.ext_pos[lane - NB] = pos; S.ext_src[lane - NB] = content; }
-    if (lane == 0) { S.lm = __popcll(km); S.next = next; }
-  }
+  if (tid < 64) pivot_sequence(S.seq, k0, nbc);
   // right half of a 64-column panel (lu_plan.hip, pair form): the pivot rows' entries of the LEFT half's columns [lcol0, lcol0 + 32),
   // the block L10 the step after the panel solves with (as lu_panel_reg_kernel leaves them)
   if (lrows && rank >= 0) {
@@ -253,8 +226,8 @@ void lu_calu_panel_kernel(dc* __restrict__ A, int n, int k0, int nbc, int* __res
   for (int q = 0; q < 4; ++q) {
     const int idx = tid + 256 * q, e = idx >> 5, col = idx & 31;
     mp[q] = -1; mv[q] = dc_make(0.0, 0.0);
-    if (e < S.next && col < nbc) {
-      const int sr = S.ext_src[e], ds = S.ext_pos[e];
+    if (e < S.seq.next && col < nbc) {
+      const int sr = S.seq.ext_src[e], ds = S.seq.ext_pos[e];
       if (sr >= k0 && sr < n && ds >= k0 && ds < n) { mv[q] = A[(size_t)sr * n + k0 + col]; mp[q] = ds; }
     }
   }
@@ -267,10 +240,10 @@ void lu_calu_panel_kernel(dc* __restrict__ A, int n, int k0, int nbc, int* __res
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) if (mp[q] >= 0) A[(size_t)mp[q] * n + k0 + ((tid + 256 * q) & 31)] = mv[q];
-  if (tid < nbc) ipiv[k0 + tid] = S.ipiv[tid];
+  if (tid < nbc) ipiv[k0 + tid] = S.seq.ipiv[tid];
   if (lists) {
-    if (tid == 0) lists[0] = S.lm;
-    if (tid < S.lm) { lists[1 + tid] = S.ldst[tid]; lists[1 + 2 * LU_NB_MAX + tid] = S.lsrc[tid]; }
+    if (tid == 0) lists[0] = S.seq.lm;
+    if (tid < S.seq.lm) { lists[1 + tid] = S.seq.ldst[tid]; lists[1 + 2 * LU_NB_MAX + tid] = S.seq.lsrc[tid]; }
   }
 #ifdef MA_CALU_STAMPS
   CALU_STAMP(6);
@@ -281,7 +254,8 @@ void lu_calu_panel_kernel(dc* __restrict__ A, int n, int k0, int nbc, int* __res
 // L = A U11^-1 for the rows below the panel's pivot block: lane = row, the row's entries in registers, U11 (and the reciprocals
 // of its diagonal) broadcast from LDS. Column by column the same operations, in the same order, as the elimination of calu_gepp.
 template <int NB>
-__global__ __launch_bounds__(256) void lu_calu_finish_kernel(dc* __restrict__ A, int n, int k0, int nbc) {
+__global__ __launch_bounds__(256) void lu_calu_finish_kernel(dc* __restrict__ A, int n, int k0, int nbc, const int* __restrict__ run_if_nonzero) {
+  if (run_if_nonzero && __hip_atomic_load(run_if_nonzero, RLX_AGENT) == 0) return;
   __shared__ __attribute__((aligned(16))) dc U[NB][NB];
   __shared__ __attribute__((aligned(16))) dc rinv[NB];
   __shared__ int sing[NB];
@@ -329,17 +303,17 @@ int lu_calu_tree_nodes(int leaves) {
   return total;
 }
 
-int lu_launch_panel_calu(c64* A, int n, int k0, int nb, const LuCaluWs& ws, int* info, int* ipiv, int* lists, hipStream_t st, c64* lrows, int lcol0) {
+int lu_launch_panel_calu(c64* A, int n, int k0, int nb, const LuCaluWs& ws, int* info, int* ipiv, int* lists, hipStream_t st, c64* lrows, int lcol0, const int* run_if_nonzero) {
   MA_REQUIRE(nb >= 1 && nb <= LU_REG_NB && k0 >= 0 && k0 + nb <= n, MA_ERR_INVALID, "panel [%d, %d) outside 0..%d", k0, k0 + nb, n);
   MA_REQUIRE(!lrows || (lcol0 >= 0 && lcol0 + LU_REG_NB <= k0), MA_ERR_INVALID, "left-half columns [%d, %d) not left of the panel at %d", lcol0, lcol0 + LU_REG_NB, k0);
   const int leaves = (n - k0 + 255) / 256;
   MA_REQUIRE(ws.cand && ws.counters && lu_calu_tree_nodes(leaves) <= ws.max_nodes, MA_ERR_INVALID, "tournament tree of %d leaves outside the workspace (%d nodes)", leaves, ws.max_nodes);
   hipLaunchKernelGGL(lu_calu_panel_kernel<LU_REG_NB>, dim3(leaves), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, ws.cand, ws.counters, info, ipiv, lists,
-                     reinterpret_cast<dc*>(lrows), lcol0);
+                     reinterpret_cast<dc*>(lrows), lcol0, run_if_nonzero);
   MA_HIP(hipGetLastError());
   const int below = n - k0 - nb;
   if (below > 0) {
-    hipLaunchKernelGGL(lu_calu_finish_kernel<LU_REG_NB>, dim3((below + 255) / 256), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb);
+    hipLaunchKernelGGL(lu_calu_finish_kernel<LU_REG_NB>, dim3((below + 255) / 256), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, run_if_nonzero);
     MA_HIP(hipGetLastError());
   }
   return MA_OK;

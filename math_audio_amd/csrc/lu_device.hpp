@@ -72,4 +72,41 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 
+// LAPACK-style pivots and the (destination, source) row list of a panel whose pivot rows are known: win[c] = the row (its index in
+// the matrix at the panel's start) that becomes pivot row c, c = 0..nbc-1 <= 32. One wavefront (all 64 lanes) replays the
+// interchange sequence "position k0 + c <-> wherever row win[c] is now": lanes 0..31 track what the panel's top positions hold,
+// lanes 32.. the positions below that a swap has touched. Out: ipiv[c] (position swapped with k0 + c), the moved rows as
+// (ldst[i], lsrc[i]), i < lm ("position ldst holds what row lsrc held"), and the touched positions below the top block as
+// (ext_pos[e], ext_src[e]), e < next: ext_src are top-block rows that did not become pivot rows.
+struct PivotSeqLds {
+  int win[32];
+  int ipiv[32], ext_pos[32], ext_src[32], next;
+  int ldst[64], lsrc[64], lm;
+};
+__device__ __forceinline__ void pivot_sequence(PivotSeqLds& S, int k0, int nbc) {
+  const int lane = threadIdx.x & 63;
+  int pos = lane < 32 ? k0 + lane : -1, content = pos;
+  bool act = lane < nbc;
+  int next = 0;
+  for (int c = 0; c < nbc; ++c) {
+    const int gc = k0 + c, r = S.win[c];
+    if (r < 0) { if (lane == 0) S.ipiv[c] = gc; continue; }
+    const u64 hm = __ballot(act && content == r);
+    const int hl = hm ? (int)__builtin_ctzll(hm) : -1;
+    const int P = hl >= 0 ? __builtin_amdgcn_readlane(pos, hl) : r;       // where row r is now
+    if (lane == 0) S.ipiv[c] = P;
+    const int old = __builtin_amdgcn_readlane(content, c);
+    if (P != gc) {
+      if (hl >= 0) { if (lane == hl) content = old; }
+      else { if (lane == 32 + next) { pos = P; content = old; act = true; } ++next; }
+      if (lane == c) content = r;
+    }
+  }
+  const bool keep = act && content != pos;
+  const u64 km = __ballot(keep);
+  if (keep) { const int o = __popcll(km & (((u64)1 << lane) - 1)); S.ldst[o] = pos; S.lsrc[o] = content; }
+  if (lane >= 32 && lane < 32 + next) { S.ext_pos[lane - 32] = pos; S.ext_src[lane - 32] = content; }
+  if (lane == 0) { S.lm = __popcll(km); S.next = next; }
+}
+
 }  // namespace ma

@@ -388,7 +388,10 @@ __global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, in
 // are why it is admitted one workgroup per CU.
 template <int NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void lu_panel_reg_kernel(dc* __restrict__ A, int n, int k0, int nbc, LuPanelWs ws, int* __restrict__ ipiv, int* __restrict__ lists,
-                         dc* __restrict__ lrows, int lcol0) {
+                         dc* __restrict__ lrows, int lcol0, const int* __restrict__ run_if_nonzero) {
+  // the speculative panel (lu_spec.hip) was accepted: nothing to do. The word is final before this grid starts and every workgroup
+  // reads the same value, so either all of them exchange or none does
+  if (run_if_nonzero && __hip_atomic_load(run_if_nonzero, RLX_AGENT) == 0) return;
   __shared__ __attribute__((aligned(16))) dc s_urow[2][NB];   // pivot rows of the current and the previous column
   __shared__ __attribute__((aligned(16))) dc s_stage[NB];     // the row a workgroup sends: written by the lane that holds it, read by 32 lanes
   __shared__ unsigned s_m[4];
@@ -2460,7 +2463,7 @@ static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 6
 // systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
 // CUs the stream may use (a CU-masked stream: the CUs of its mask).
 static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st,
-                            int* reg_lists = nullptr, c64* reg_lrows = nullptr, int reg_lcol0 = 0) {
+                            int* reg_lists = nullptr, c64* reg_lrows = nullptr, int reg_lcol0 = 0, const int* reg_run_if_nonzero = nullptr) {
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
@@ -2500,7 +2503,7 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
   if (clear_tags) for (int t = 0; t < nsys; ++t) MA_HIP(hipMemsetAsync(wss[t].cand, 0, lu_panel_granule_bytes(wss[t].max_blocks), st));
   if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0], reg_lists,
-                                    reinterpret_cast<dc*>(reg_lrows), reg_lcol0);
+                                    reinterpret_cast<dc*>(reg_lrows), reg_lcol0, reg_run_if_nonzero);
   else if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
   else {
     LuPanelBatch B;
@@ -2526,9 +2529,10 @@ int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, c
   return launch_panel_any(0, 1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
 }
 // the register-resident panel kernel: 256 rows per workgroup, nb <= LU_REG_NB columns; ncu = the CUs `st` may use
-int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, c64* lrows, int lcol0) {
+int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, c64* lrows, int lcol0,
+                        const int* run_if_nonzero) {
   MA_REQUIRE(!lrows || (lcol0 >= 0 && lcol0 + LU_REG_NB <= k0), MA_ERR_INVALID, "left-half columns [%d, %d) not left of the panel at %d", lcol0, lcol0 + LU_REG_NB, k0);
-  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st, lists, lrows, lcol0);
+  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st, lists, lrows, lcol0, run_if_nonzero);
 }
 // the step between two panels of a block column: interchanges + U = L11^-1 A12 on the columns [x0, x0 + ncols), and the inverted
 // diagonal block of L11 into invd (lists: what lu_launch_panel_reg wrote)

@@ -46,7 +46,7 @@ size_t lu_panel_granule_bytes(int max_blocks);
 int lu_panel_configure();
 int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
 int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st,
-                        c64* lrows = nullptr, int lcol0 = 0);
+                        c64* lrows = nullptr, int lcol0 = 0, const int* run_if_nonzero = nullptr);
 int lu_launch_lane_step2(c64* A, int n, int k0, int nb, const int* lists1, const int* lists2, int x0, int ncols, const int* ipiv, int* lists64, c64* invd, unsigned* poison,
                          const c64* l10, hipStream_t st);
 int lu_launch_lane_step(c64* A, int n, int k0, int nb, const int* lists, int x0, int ncols, c64* invd, const unsigned* poison, hipStream_t st);
@@ -55,7 +55,14 @@ int lu_panel_reg_admissible(int nblk, int ncu);
 // row indices and one arrival counter per tree node (zero between launches).
 struct LuCaluWs { int* cand = nullptr; unsigned* counters = nullptr; int max_nodes = 0; };
 int lu_calu_tree_nodes(int leaves);
-int lu_launch_panel_calu(c64* A, int n, int k0, int nb, const LuCaluWs& ws, int* info, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0);
+int lu_launch_panel_calu(c64* A, int n, int k0, int nb, const LuCaluWs& ws, int* info, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0,
+                         const int* run_if_nonzero = nullptr);   // run_if_nonzero: a device word; 0 = the kernels return at once (the speculative panel was accepted)
+// Speculative panel (lu_spec.hip): partial pivoting restricted to the panel's top 32 rows, VERIFIED against every row below -- accepted, it
+// is LAPACK's factorisation of the panel in two launches without any exchange between workgroups; rejected (verdict word != 0), the
+// panel's columns are restored and the caller's fallback panel (launched with run_if_nonzero = the verdict word) factors it.
+struct LuSpecWs { c64* u11 = nullptr; c64* rinv = nullptr; double* pivmag = nullptr; int* order = nullptr; int* verdict = nullptr; c64* backup = nullptr; int rows = 0;
+                  unsigned long long* stats = nullptr; /* [0] accepted, [1] rejected panels (the plan's counters) */ };
+int lu_launch_panel_spec(c64* A, int n, int k0, int nb, const LuSpecWs& ws, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0);
 int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st);
 void lu_panel_forget_stream(int dev, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);

@@ -124,6 +124,11 @@ struct ma_lu_plan {
   // rounding): the mode of the sweep, where lu_solve's contract (x only, lu.rs:142-153) is the boundary. MA_LU_PIVOT_PARTIAL elsewhere.
   int pivoting = MA_LU_PIVOT_PARTIAL;
   LuCaluWs calu[LU_BATCH_MAX]{};
+  // the speculative panel (lu_spec.hip) ahead of every half-panel of the pair structure, in either pivoting mode: accepted, it IS the
+  // partial-pivoting panel (verified); rejected, the mode's own panel kernel runs behind it. MA_LU_SPECULATE=0 switches it off.
+  bool speculate = false;
+  LuSpecWs spec[LU_BATCH_MAX]{};
+  unsigned long long* d_spec_stats = nullptr;
 };
 
 static void panel_schedule(const ma_lu_plan* P, std::vector<int>& k0s, std::vector<int>& nbs, std::vector<int>& rpbs, std::vector<int>& nblks);
@@ -165,6 +170,17 @@ int ma_lu_plan::ensure_batch(int nmat) {
     MA_HIP(hipMalloc(&d_half_invd[m], sizeof(c64) * 32 * 32));
     MA_HIP(hipMalloc(&d_half_l10[m], sizeof(c64) * 32 * 32));
     MA_HIP(hipMemset(d_half_l10[m], 0, sizeof(c64) * 32 * 32));
+    if (speculate) {
+      LuSpecWs& w = spec[m];
+      MA_HIP(hipMalloc(&w.u11, sizeof(c64) * LU_REG_NB * LU_REG_NB));
+      MA_HIP(hipMalloc(&w.rinv, sizeof(c64) * LU_REG_NB));
+      MA_HIP(hipMalloc(&w.pivmag, sizeof(double) * LU_REG_NB));
+      MA_HIP(hipMalloc(&w.order, sizeof(int) * LU_REG_NB));
+      MA_HIP(hipMalloc(&w.verdict, 64));
+      MA_HIP(hipMemset(w.verdict, 0, 64));
+      MA_HIP(hipMalloc(&w.backup, sizeof(c64) * (size_t)n * LU_REG_NB));
+      w.rows = n; w.stats = d_spec_stats;
+    }
     if (pivoting == MA_LU_PIVOT_TOURNAMENT) {
       const int nodes = lu_calu_tree_nodes((n + 255) / 256);
       MA_HIP(hipMalloc(&calu[m].cand, sizeof(int) * (size_t)nodes * LU_REG_NB));
@@ -209,6 +225,17 @@ int ma_lu_plan_create_pivoting(int32_t n, int device, int32_t pivoting, ma_lu_pl
   ma_lu_plan* P = new (std::nothrow) ma_lu_plan();
   MA_REQUIRE(P, MA_ERR_NOMEM, "host allocation failed");
   P->device = device; P->n = n; P->ncu = ncu; P->pivoting = pivoting;
+  // (decided before the first ensure_batch: that is where a slot's speculative-panel workspace is made)
+  {
+    const bool lds_tuned0 = getenv("MA_LU_RPB") || getenv("MA_LU_NB") || (getenv("MA_LU_BATCH_PANEL") && atoi(getenv("MA_LU_BATCH_PANEL")) != 0);
+    bool pair = pivoting == MA_LU_PIVOT_TOURNAMENT || (n >= MA_LU_PAIR_MIN_N && n <= MA_LU_PAIR_MAX_N && ncu == 256 && !lds_tuned0);
+    if (pivoting != MA_LU_PIVOT_TOURNAMENT) if (const char* er = getenv("MA_LU_REG_PANEL")) pair = atoi(er) == 2;
+    P->speculate = pair;
+    if (const char* es = getenv("MA_LU_SPECULATE")) P->speculate = pair && atoi(es) != 0;
+    if (P->speculate) {
+      if (hipMalloc(&P->d_spec_stats, 64) != hipSuccess || hipMemset(P->d_spec_stats, 0, 64) != hipSuccess) { set_error("hipMalloc of the LU plan's counters failed"); delete P; return MA_ERR_NOMEM; }
+    }
+  }
   const int mb = ncu;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -280,6 +307,7 @@ int ma_lu_plan_create_pivoting(int32_t n, int device, int32_t pivoting, ma_lu_pl
     if (!P->reg_panel) P->pan_mask = 0;                   // the LDS-resident panel kernel's grid does not fit a small CU set: only the big updates are masked
     if (!P->reg_panel && !getenv("MA_LU_CU_SPLIT")) P->cu_split = 0;   // the default split comes with the register panels only
     P->reg_panel0 = P->reg_panel; P->reg_pair0 = P->reg_pair;
+    if (!(P->reg_panel && P->reg_pair)) P->speculate = false;   // (the pair structure was refused after all: the workspace stays unused)
     // measured (profiles/r04_lu_schedule_experiments.md): three launches per block instead of 31 shorten every slot's chain (the stream's
     // waits 4.3 -> 3.8 ms per frequency) but the fused kernel's 157 four-wavefront workgroups cost the big updates what the chain gains
     // (49.5 against 49.3 ms per frequency; 51.8 against 48.6 with eight panels per block): built, tested, off by default
@@ -384,9 +412,26 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (P->big_stream) (void)hipStreamDestroy(P->big_stream);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
     if (P->calu[i].cand) (void)hipFree(P->calu[i].cand); if (P->calu[i].counters) (void)hipFree(P->calu[i].counters);
+    { LuSpecWs& w = P->spec[i]; if (w.u11) (void)hipFree(w.u11); if (w.rinv) (void)hipFree(w.rinv); if (w.pivmag) (void)hipFree(w.pivmag); if (w.order) (void)hipFree(w.order);
+      if (w.verdict) (void)hipFree(w.verdict); if (w.backup) (void)hipFree(w.backup); }
     if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); if (P->d_half_lists[i]) (void)hipFree(P->d_half_lists[i]); if (P->d_half_invd[i]) (void)hipFree(P->d_half_invd[i]); if (P->d_half_l10[i]) (void)hipFree(P->d_half_l10[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
+  if (P->d_spec_stats) (void)hipFree(P->d_spec_stats);
   delete P;
+  return MA_OK;
+}
+
+// half-panels the speculative panel factored (accepted) / handed to the mode's own panel kernel (rejected) since the plan was made;
+// synchronises the device
+int ma_lu_plan_speculation_stats(ma_lu_plan_t* P, int64_t* accepted, int64_t* rejected) {
+  MA_REQUIRE(P && accepted && rejected, MA_ERR_INVALID, "NULL argument");
+  *accepted = 0; *rejected = 0;
+  if (!P->d_spec_stats) return MA_OK;
+  MA_HIP(hipSetDevice(P->device));
+  MA_HIP(hipDeviceSynchronize());
+  unsigned long long h[2] = {0, 0};
+  MA_HIP(hipMemcpy(h, P->d_spec_stats, sizeof(h), hipMemcpyDeviceToHost));
+  *accepted = (int64_t)h[0]; *rejected = (int64_t)h[1];
   return MA_OK;
 }
 
@@ -469,8 +514,12 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     const int n = P->n, cus = P->admit_cus > 0 ? P->admit_cus : (masked ? P->panel_cus() : P->ncu);
     const int h1 = std::min(nb, LU_REG_NB), h2 = nb - h1;
     const bool tour = P->pivoting == MA_LU_PIVOT_TOURNAMENT;
-    int rc = tour ? lu_launch_panel_calu(A, n, k0, h1, P->calu[m], ws.info, ipiv, P->d_half_lists[m], st)
-                  : lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st);
+    const bool spec = P->speculate && P->spec[m].backup;
+    const int* gate = spec ? P->spec[m].verdict : nullptr;     // the mode's own panel kernel runs only where the speculative one was rejected
+    int rc = spec ? lu_launch_panel_spec(A, n, k0, h1, P->spec[m], ipiv, P->d_half_lists[m], st) : MA_OK;
+    if (rc) return rc;
+    rc = tour ? lu_launch_panel_calu(A, n, k0, h1, P->calu[m], ws.info, ipiv, P->d_half_lists[m], st, nullptr, 0, gate)
+              : lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st, nullptr, 0, gate);
     if (rc || h2 <= 0) return rc;
     const int a1 = k0 + h1;
     if ((rc = lu_launch_lane_step(A, n, k0, h1, P->d_half_lists[m], a1, h2, P->d_half_invd[m], P->pws.timeout, st))) return rc;
@@ -478,8 +527,9 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     if (skip_k32 < 32 && (rc = lu_launch_zgemm_sub(n - a1, h2, h1, A + (size_t)a1 * n + k0, (size_t)n, A + (size_t)k0 * n + a1, (size_t)n, A + (size_t)a1 * n + a1, (size_t)n, st, P->use_3m, false, &P->zmode))) return rc;
     // (the right half's interchanges on the LEFT half's columns -- part of the interchange itself inside a 64-column panel kernel --
     // are the first job of lu_lane_step2_kernel, which every caller launches next)
-    if (tour) return lu_launch_panel_calu(A, n, a1, h2, P->calu[m], ws.info, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, st, P->d_half_l10[m], k0);
-    return lu_launch_panel_reg(A, n, a1, h2, (n - a1 + 255) / 256, cus, ws, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, false, st, P->d_half_l10[m], k0);
+    if (spec && (rc = lu_launch_panel_spec(A, n, a1, h2, P->spec[m], ipiv, P->d_half_lists[m] + LU_LISTS_LEN, st, P->d_half_l10[m], k0))) return rc;
+    if (tour) return lu_launch_panel_calu(A, n, a1, h2, P->calu[m], ws.info, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, st, P->d_half_l10[m], k0, gate);
+    return lu_launch_panel_reg(A, n, a1, h2, (n - a1 + 255) / 256, cus, ws, ipiv, P->d_half_lists[m] + LU_LISTS_LEN, false, st, P->d_half_l10[m], k0, gate);
   }
   if (P->reg_panel) return lu_launch_panel_reg(A, P->n, k0, nb, nblk, masked ? P->panel_cus() : P->ncu, ws, ipiv, lists, clear_tags, st);
   return lu_launch_panel(A, P->n, k0, nb, rpb, nblk, P->ncu, ws, ipiv, clear_tags, st);

@@ -238,3 +238,94 @@ def test_tournament_batch_and_several_right_hand_sides(gpu):
         torch.cuda.synchronize()
         assert np.linalg.norm(A @ extra.cpu().numpy() - 2.0 * B[0]) / np.linalg.norm(B[0]) < 1e-11
     lu.close()
+
+
+# ---------------------------------------------------------------- the speculative panel (lu_spec.hip)
+def _block_dominant(n, seed, shuffle_inside_blocks=True):
+    """A matrix whose LAPACK pivots all lie inside the 32-row block of their panel: small random entries, one entry of 50..100 per
+    column placed on a row of the column's own block of 32 -- a different row of the block for every column (the diagonal, shuffled
+    inside the block), so that the interchanges inside the top block are not the identity."""
+    rng = np.random.default_rng(seed)
+    A = 0.3 * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    for b0 in range(0, n, 32):
+        w = min(32, n - b0)
+        perm = rng.permutation(w) if shuffle_inside_blocks else np.arange(w)
+        for j in range(w):
+            A[b0 + perm[j], b0 + j] += (50.0 + 50.0 * rng.random()) * np.exp(2j * np.pi * rng.random())
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    return A, b
+
+
+def _solve_on_plan(A, b, pivoting, env=None):
+    """One factor + solve on a fresh plan (device buffers): x, the factors, the plan's (accepted, rejected) counts."""
+    import torch
+    from test_lu_gpu import _with_env
+    n = A.shape[0]
+    dev = torch.device("cuda", 0)
+    with _with_env(**(env or {})):
+        lu = ma.LuPlan(n, pivoting=pivoting)
+    st = lu.main_stream() or torch.cuda.current_stream().cuda_stream
+    dA = torch.tensor(A, device=dev).reshape(-1); db = torch.tensor(b, device=dev)
+    lu.factor_solve_dev(dA.data_ptr(), db.data_ptr(), 1, st)
+    assert lu.status(st) == ma.MA_OK
+    stats = lu.speculation_stats()
+    out = db.cpu().numpy().copy(), dA.cpu().numpy().reshape(n, n).copy(), stats
+    lu.close()
+    return out
+
+
+@pytest.mark.parametrize("pivoting", ["tournament", "partial"])
+@pytest.mark.parametrize("n", [40, 64, 100, 700, 2100])
+def test_speculative_panel_accepted_is_lapacks_factorisation(gpu, n, pivoting):
+    """Every pivot inside its panel's top block: all half-panels are accepted (none reaches the mode's own panel kernel), the
+    interchanges are LAPACK's (scipy.linalg.lu_factor), the factors and the solution are bit for bit what the same plan computes
+    with the speculation switched off (MA_LU_SPECULATE=0: the spinning partial-pivoting kernel / the tournament chose the same rows)."""
+    import scipy.linalg as sla
+    A, b = _block_dominant(n, 100 + n)
+    env = {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
+    x, LU, (acc, rej) = _solve_on_plan(A, b, pivoting, env)
+    assert rej == 0 and acc == (n + 31) // 32, (acc, rej)
+    x0, LU0, (acc0, rej0) = _solve_on_plan(A, b, pivoting, dict(env, MA_LU_SPECULATE=0))
+    assert acc0 == 0 and rej0 == 0
+    assert np.array_equal(LU, LU0) and np.array_equal(x, x0)
+    assert np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * n
+    lu_ref, piv_ref = sla.lu_factor(A)
+    assert np.abs(np.tril(LU, -1)).max() <= 1.0 + 1e-12      # partial pivoting's bound on the multipliers
+    assert np.allclose(np.triu(LU), np.triu(lu_ref), rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("pivoting", ["tournament", "partial"])
+def test_speculative_panel_rejected_panels_fall_back(gpu, pivoting):
+    """A block-dominant matrix with ONE large entry far below the diagonal (column 300, row 1500): the half-panel that owns column 300
+    is rejected -- restored from its backup and factored by the mode's own kernel --, every other half-panel is accepted, and the
+    result is the factorisation of the matrix: residual, P A = L U, and (partial) LAPACK's pivots."""
+    import scipy.linalg as sla
+    n = 2100
+    A, b = _block_dominant(n, 77)
+    A[1500, 300] = 400.0
+    env = {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
+    x, LU, (acc, rej) = _solve_on_plan(A, b, pivoting, env)
+    assert rej >= 1 and acc >= (n + 31) // 32 - 4, (acc, rej)
+    assert np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * n
+    x0, LU0, _ = _solve_on_plan(A, b, pivoting, dict(env, MA_LU_SPECULATE=0))
+    if pivoting == "partial":
+        assert np.array_equal(LU, LU0) and np.array_equal(x, x0)            # the same rows either way: the same bits
+        lu_ref, _ = sla.lu_factor(A)
+        assert np.allclose(np.triu(LU), np.triu(lu_ref), rtol=1e-9, atol=1e-9)
+    else:
+        assert np.linalg.norm(x - x0) / np.linalg.norm(x0) <= 1e-12
+
+
+def test_speculative_panel_on_random_matrices_is_rejected_and_harmless(gpu):
+    """Generic data: the largest entry of a column is almost never among the top 32 rows, so (nearly) every half-panel is rejected;
+    the solution and LAPACK's pivots are what the partial-pivoting path gives without the speculation."""
+    import scipy.linalg as sla
+    from test_lu_gpu import _with_env
+    n = 1500
+    A, b = _rand(n, 31)
+    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64):
+        x, piv = ma.zgesv(A, b, return_pivots=True)
+    _, piv_ref = sla.lu_factor(A)
+    assert np.array_equal(piv, piv_ref)
+    _, _, (acc, rej) = _solve_on_plan(A, b, "partial", {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64})
+    assert rej >= 40 and acc <= 7, (acc, rej)                # (the last panels have few rows below them)

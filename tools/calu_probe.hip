@@ -27,9 +27,9 @@ int main(int argc, char** argv) {
     for (int r = 0; r < reps + 2; ++r) {
       if (r == 2) CK(hipMemcpyToSymbol(HIP_SYMBOL(g_calu_stamps), z, sizeof(z)));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(lu_calu_panel_kernel<LU_REG_NB>, dim3(leaves), dim3(256), 0, 0, reinterpret_cast<dc*>(dA), n, k0, 32, ws.cand, ws.counters, info, ipiv, lists, (dc*)nullptr, 0);
+      hipLaunchKernelGGL(lu_calu_panel_kernel<LU_REG_NB>, dim3(leaves), dim3(256), 0, 0, reinterpret_cast<dc*>(dA), n, k0, 32, ws.cand, ws.counters, info, ipiv, lists, (dc*)nullptr, 0, (const int*)nullptr);
       CK(hipEventRecord(e1));
-      hipLaunchKernelGGL(lu_calu_finish_kernel<LU_REG_NB>, dim3((n - k0 - 32 + 255) / 256), dim3(256), 0, 0, reinterpret_cast<dc*>(dA), n, k0, 32);
+      hipLaunchKernelGGL(lu_calu_finish_kernel<LU_REG_NB>, dim3((n - k0 - 32 + 255) / 256), dim3(256), 0, 0, reinterpret_cast<dc*>(dA), n, k0, 32, (const int*)nullptr);
       CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
       float a, b; CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
       if (r >= 2) { tp += a; tf += b; }
