@@ -431,6 +431,7 @@ def main():
     timing = not args.no_timing
     sweep.set_timing(timing)                        # events around the update launches and the assembly pieces; the pools are filled now, not inside the timed region
     run_freqs = mine(W, K)
+    spec0 = lu.speculation_stats()                  # (synchronises: outside the timed region)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -453,6 +454,7 @@ def main():
     if not np.all(np.isfinite(X.view(np.float64))):
         raise SystemExit("non-finite solution")
     tm = sweep.last_timing()
+    spec1 = lu.speculation_stats()
     if rank == 0:
         out = {
             "metric": "bem_sweep_panel_pairs_per_s", "value": float(n) * n * K * world / elapsed, "unit": "panel-pairs/s",
@@ -466,6 +468,12 @@ def main():
             "sweep_call": {"wall_s_inside_the_call": tm["wall_s"], "device_ms_first_to_last_event": tm["device_ms"],
                            "note": "the timed region is the ma_bem_sweep_run call plus the bracket's synchronisations; solutions (K x N complex128) come back to the host inside it"},
         }
+        out["lu_panels"] = {"pivoting": lu.pivoting(), "speculation": lu.speculation(),
+                            "half_panels_accepted_per_step": (spec1[0] - spec0[0]) / K, "half_panels_accepted_widened_per_step": (spec1[1] - spec0[1]) / K,
+                            "half_panels_rejected_per_step": (spec1[2] - spec0[2]) / K,
+                            "note": "lu_spec.hip: a half-panel (32 columns) is first factored with partial pivoting inside its top 32 rows and checked against every row below "
+                                    "(accepted = LAPACK's panel, two short launches); rows that fail the check join the candidates of a second, widened attempt; a half-panel both give up is factored "
+                                    "by the plan's own panel kernel (verified mode) or its system is solved again (optimistic mode: counted in sweep_redone)"}
         if timing and info["staged"]:
             l8 = lu.last_timing()
             n_all, f_all, _ = lu.last_update_stats()

@@ -39,7 +39,10 @@ enum {
   MA_ERR_UNSUPPORTED = 4,  /* input class not handled by the device path yet (listed per function)         */
   MA_ERR_HIP         = 5,  /* a HIP runtime call failed; text in ma_last_error_string()                    */
   MA_ERR_NO_DEVICE   = 6,  /* no gfx950 device visible                                                     */
-  MA_ERR_NOMEM       = 7   /* device or host allocation failed                                             */
+  MA_ERR_NOMEM       = 7,  /* device or host allocation failed                                             */
+  MA_ERR_RETRY       = 8   /* an LU plan in the optimistic speculation mode met a panel it cannot vouch for: the system
+                              must be solved again in the verified mode (ma_lu_plan_set_speculation). Never returned
+                              by the drop-in entries (ma_zgesv, ma_lu_solve, ma_lu_factorize, the sweeps): they retry. */
 };
 
 const char* ma_last_error_string(void);
@@ -223,9 +226,21 @@ int ma_lu_plan_pivoting(ma_lu_plan_t* plan, int32_t* pivoting);
 /* Plans that factor in 64-column panels of two halves (4 096..16 384 rows, every tournament plan) try each half-panel SPECULATIVELY first
  * (lu_spec.hip): partial pivoting among the panel's top 32 rows, then the check that no row below holds a larger entry in any column --
  * if it passes, zgetrf would have chosen the same rows, and the panel is done in two short launches without any exchange between
- * workgroups; if not, the panel is restored and the plan's own panel kernel factors it. Boundary operators of the Burton-Miller form
- * (tbem.rs:96-222) pass at every panel. Counts since the plan was made (synchronises the device); MA_LU_SPECULATE=0 switches it off. */
-int ma_lu_plan_speculation_stats(ma_lu_plan_t* plan, int64_t* accepted, int64_t* rejected);
+ * workgroups. Rows that fail the check (at most 32) join the candidates of a second, WIDENED attempt, checked the same way; a panel both
+ * attempts give up is restored and factored by the plan's own panel kernel. Boundary operators of the Burton-Miller form (tbem.rs:96-222)
+ * pass at the first attempt except near mesh singularities (the poles of a UV sphere: 6 % of the half-panels of BASELINE config #3),
+ * which the widened attempt takes. Counts since the plan was made (synchronises the device); MA_LU_SPECULATE=0 switches it off. */
+int ma_lu_plan_speculation_stats(ma_lu_plan_t* plan, int64_t* accepted, int64_t* accepted_widened, int64_t* rejected);
+/* MA_LU_SPECULATE_VERIFIED (what such a plan starts with): the plan's own panel kernel is launched behind every speculative panel and
+ * runs where the check failed -- every result is final. MA_LU_SPECULATE_OPTIMISTIC: nothing is launched behind it; a system that met a
+ * rejected panel carries status -1 (ma_lu_plan_stage_info_dev) / MA_ERR_RETRY (ma_lu_plan_status) and is the CALLER's to solve again in
+ * the verified mode -- what ma_bem_sweep_run does with the (never yet observed) frequencies whose operator is not diagonally dominant.
+ * MA_LU_SPECULATE_OFF: the plan's own panel kernel only. MA_ERR_UNSUPPORTED on plans without half-panel pairs (except OFF). */
+#define MA_LU_SPECULATE_OFF 0
+#define MA_LU_SPECULATE_VERIFIED 1
+#define MA_LU_SPECULATE_OPTIMISTIC 2
+int ma_lu_plan_set_speculation(ma_lu_plan_t* plan, int32_t mode);
+int ma_lu_plan_speculation(ma_lu_plan_t* plan, int32_t* mode);
 /* ma_zgesv with the pivoting named (ma_zgesv itself: partial). With MA_LU_PIVOT_TOURNAMENT the factors and ipiv that come back are
  * those of the tournament: P A = L U holds with them as it does with LAPACK's, the rows chosen differ. */
 int ma_zgesv_pivoting(int32_t n, ma_c64* A_rowmajor, ma_c64* b, int32_t* ipiv_or_null, int32_t pivoting);

@@ -16,9 +16,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MA_LIB_PATH") or os.path.join(_HERE, "lib", "libmathaudio_hip.so")     # MA_LIB_PATH: a diagnostic build (tools/)
 
-MA_OK, MA_ERR_SINGULAR, MA_ERR_DIM, MA_ERR_INVALID, MA_ERR_UNSUPPORTED, MA_ERR_HIP, MA_ERR_NO_DEVICE, MA_ERR_NOMEM = range(8)
+MA_OK, MA_ERR_SINGULAR, MA_ERR_DIM, MA_ERR_INVALID, MA_ERR_UNSUPPORTED, MA_ERR_HIP, MA_ERR_NO_DEVICE, MA_ERR_NOMEM, MA_ERR_RETRY = range(9)
 _STATUS_NAMES = ["MA_OK", "MA_ERR_SINGULAR", "MA_ERR_DIM", "MA_ERR_INVALID", "MA_ERR_UNSUPPORTED", "MA_ERR_HIP",
-                 "MA_ERR_NO_DEVICE", "MA_ERR_NOMEM"]
+                 "MA_ERR_NO_DEVICE", "MA_ERR_NOMEM", "MA_ERR_RETRY"]
 
 
 class MaError(RuntimeError):
@@ -81,7 +81,9 @@ def lib():
             "ma_lu_plan_create": [i32, C.c_int, P(vp)],
             "ma_lu_plan_create_pivoting": [i32, C.c_int, i32, P(vp)],
             "ma_lu_plan_pivoting": [vp, P(i32)],
-            "ma_lu_plan_speculation_stats": [vp, P(i64), P(i64)],
+            "ma_lu_plan_speculation_stats": [vp, P(i64), P(i64), P(i64)],
+            "ma_lu_plan_set_speculation": [vp, i32],
+            "ma_lu_plan_speculation": [vp, P(i32)],
             "ma_zgesv_pivoting": [i32, vp, vp, vp, i32],
             "ma_bem_sweep_create_pivoting": [vp, i32, i32, i32, P(vp)],
             "ma_lu_plan_destroy": [vp],
@@ -409,11 +411,21 @@ class LuPlan:
         else:
             check(lib().ma_lu_plan_create_pivoting(n, device, pv, C.byref(self.h)))
 
+    def set_speculation(self, mode):
+        """ma_lu_plan_set_speculation: "off" / 0, "verified" / 1 (fallback in line), "optimistic" / 2 (status MA_ERR_RETRY on a rejected panel)."""
+        m = {"off": 0, "verified": 1, "optimistic": 2}.get(mode, mode)
+        check(lib().ma_lu_plan_set_speculation(self.h, int(m)))
+
+    def speculation(self):
+        v = C.c_int32(0)
+        check(lib().ma_lu_plan_speculation(self.h, C.byref(v)))
+        return ("off", "verified", "optimistic")[v.value]
+
     def speculation_stats(self):
-        """ma_lu_plan_speculation_stats: (accepted, rejected) half-panels of the speculative panel since the plan was made."""
-        a = C.c_int64(0); r = C.c_int64(0)
-        check(lib().ma_lu_plan_speculation_stats(self.h, C.byref(a), C.byref(r)))
-        return a.value, r.value
+        """ma_lu_plan_speculation_stats: half-panels (accepted at the first attempt, accepted by the widened attempt, rejected) since the plan was made."""
+        a = C.c_int64(0); w = C.c_int64(0); r = C.c_int64(0)
+        check(lib().ma_lu_plan_speculation_stats(self.h, C.byref(a), C.byref(w), C.byref(r)))
+        return a.value, w.value, r.value
 
     def pivoting(self):
         v = C.c_int32(0)

@@ -60,9 +60,11 @@ int lu_launch_panel_calu(c64* A, int n, int k0, int nb, const LuCaluWs& ws, int*
 // Speculative panel (lu_spec.hip): partial pivoting restricted to the panel's top 32 rows, VERIFIED against every row below -- accepted, it
 // is LAPACK's factorisation of the panel in two launches without any exchange between workgroups; rejected (verdict word != 0), the
 // panel's columns are restored and the caller's fallback panel (launched with run_if_nonzero = the verdict word) factors it.
-struct LuSpecWs { c64* u11 = nullptr; c64* rinv = nullptr; double* pivmag = nullptr; int* order = nullptr; int* verdict = nullptr; c64* backup = nullptr; int rows = 0;
-                  unsigned long long* stats = nullptr; /* [0] accepted, [1] rejected panels (the plan's counters) */ };
-int lu_launch_panel_spec(c64* A, int n, int k0, int nb, const LuSpecWs& ws, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0);
+struct LuSpecWs { c64* u11 = nullptr; c64* rinv = nullptr; double* pivmag = nullptr; int* ctl = nullptr; /* [0] the verdict: 0 = factored */ int* vlist = nullptr; int* ext = nullptr;
+                  c64* backup = nullptr; int rows = 0;
+                  unsigned long long* stats = nullptr; /* the plan's counters: [0] half-panels tried, [1] rejected by the first attempt, [2] of those accepted by the widened one */ };
+int lu_launch_panel_spec(c64* A, int n, int k0, int nb, const LuSpecWs& ws, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0,
+                         bool optimistic = false, int* reject_info = nullptr);
 int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st);
 void lu_panel_forget_stream(int dev, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);

@@ -127,6 +127,8 @@ struct ma_lu_plan {
   // the speculative panel (lu_spec.hip) ahead of every half-panel of the pair structure, in either pivoting mode: accepted, it IS the
   // partial-pivoting panel (verified); rejected, the mode's own panel kernel runs behind it. MA_LU_SPECULATE=0 switches it off.
   bool speculate = false;
+  bool optimistic = false;                                // MA_LU_SPECULATE_OPTIMISTIC (ma_lu_plan_set_speculation): no fallback behind the speculative panel; a rejected one
+                                                          // leaves -1 in the system's status word (MA_ERR_RETRY) and the CALLER solves that system again in the verified mode
   LuSpecWs spec[LU_BATCH_MAX]{};
   unsigned long long* d_spec_stats = nullptr;
 };
@@ -175,9 +177,10 @@ int ma_lu_plan::ensure_batch(int nmat) {
       MA_HIP(hipMalloc(&w.u11, sizeof(c64) * LU_REG_NB * LU_REG_NB));
       MA_HIP(hipMalloc(&w.rinv, sizeof(c64) * LU_REG_NB));
       MA_HIP(hipMalloc(&w.pivmag, sizeof(double) * LU_REG_NB));
-      MA_HIP(hipMalloc(&w.order, sizeof(int) * LU_REG_NB));
-      MA_HIP(hipMalloc(&w.verdict, 64));
-      MA_HIP(hipMemset(w.verdict, 0, 64));
+      MA_HIP(hipMalloc(&w.ctl, 64));
+      MA_HIP(hipMemset(w.ctl, 0, 64));
+      MA_HIP(hipMalloc(&w.vlist, sizeof(int) * LU_REG_NB));
+      MA_HIP(hipMalloc(&w.ext, sizeof(int) * 2 * LU_REG_NB));
       MA_HIP(hipMalloc(&w.backup, sizeof(c64) * (size_t)n * LU_REG_NB));
       w.rows = n; w.stats = d_spec_stats;
     }
@@ -412,8 +415,8 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   if (P->big_stream) (void)hipStreamDestroy(P->big_stream);
   for (int i = 0; i < LU_BATCH_MAX; ++i) { if (P->d_tmp[i]) (void)hipFree(P->d_tmp[i]); if (P->d_ipiv[i]) (void)hipFree(P->d_ipiv[i]); if (P->d_lists[i]) (void)hipFree(P->d_lists[i]); if (P->d_invd[i]) (void)hipFree(P->d_invd[i]);
     if (P->calu[i].cand) (void)hipFree(P->calu[i].cand); if (P->calu[i].counters) (void)hipFree(P->calu[i].counters);
-    { LuSpecWs& w = P->spec[i]; if (w.u11) (void)hipFree(w.u11); if (w.rinv) (void)hipFree(w.rinv); if (w.pivmag) (void)hipFree(w.pivmag); if (w.order) (void)hipFree(w.order);
-      if (w.verdict) (void)hipFree(w.verdict); if (w.backup) (void)hipFree(w.backup); }
+    { LuSpecWs& w = P->spec[i]; if (w.u11) (void)hipFree(w.u11); if (w.rinv) (void)hipFree(w.rinv); if (w.pivmag) (void)hipFree(w.pivmag); if (w.ctl) (void)hipFree(w.ctl);
+      if (w.vlist) (void)hipFree(w.vlist); if (w.ext) (void)hipFree(w.ext); if (w.backup) (void)hipFree(w.backup); }
     if (P->d_tmp_l[i]) (void)hipFree(P->d_tmp_l[i]); if (P->d_half_lists[i]) (void)hipFree(P->d_half_lists[i]); if (P->d_half_invd[i]) (void)hipFree(P->d_half_invd[i]); if (P->d_half_l10[i]) (void)hipFree(P->d_half_l10[i]); }
   if (P->ws_block) (void)hipFree(P->ws_block);
   if (P->d_spec_stats) (void)hipFree(P->d_spec_stats);
@@ -421,17 +424,31 @@ int ma_lu_plan_destroy(ma_lu_plan_t* P) {
   return MA_OK;
 }
 
-// half-panels the speculative panel factored (accepted) / handed to the mode's own panel kernel (rejected) since the plan was made;
-// synchronises the device
-int ma_lu_plan_speculation_stats(ma_lu_plan_t* P, int64_t* accepted, int64_t* rejected) {
-  MA_REQUIRE(P && accepted && rejected, MA_ERR_INVALID, "NULL argument");
-  *accepted = 0; *rejected = 0;
+// 0: no speculation; 1: verified with the fallback in line (what a plan of the pair structure starts with); 2: optimistic
+int ma_lu_plan_set_speculation(ma_lu_plan_t* P, int32_t mode) {
+  MA_REQUIRE(P && mode >= MA_LU_SPECULATE_OFF && mode <= MA_LU_SPECULATE_OPTIMISTIC, MA_ERR_INVALID, "speculation mode %d", mode);
+  MA_REQUIRE(mode == MA_LU_SPECULATE_OFF || P->d_spec_stats, MA_ERR_UNSUPPORTED, "this plan does not factor in half-panel pairs: no speculative panel");
+  P->speculate = mode != MA_LU_SPECULATE_OFF && P->reg_panel && P->reg_pair;
+  P->optimistic = P->speculate && mode == MA_LU_SPECULATE_OPTIMISTIC;
+  return MA_OK;
+}
+int ma_lu_plan_speculation(ma_lu_plan_t* P, int32_t* mode) {
+  MA_REQUIRE(P && mode, MA_ERR_INVALID, "NULL argument");
+  *mode = !P->speculate ? MA_LU_SPECULATE_OFF : (P->optimistic ? MA_LU_SPECULATE_OPTIMISTIC : MA_LU_SPECULATE_VERIFIED);
+  return MA_OK;
+}
+
+// half-panels the speculative panel factored at the first attempt / at the widened attempt / handed to the plan's own panel kernel or
+// marked for another solve, since the plan was made; synchronises the device
+int ma_lu_plan_speculation_stats(ma_lu_plan_t* P, int64_t* accepted, int64_t* accepted_widened, int64_t* rejected) {
+  MA_REQUIRE(P && accepted && accepted_widened && rejected, MA_ERR_INVALID, "NULL argument");
+  *accepted = 0; *accepted_widened = 0; *rejected = 0;
   if (!P->d_spec_stats) return MA_OK;
   MA_HIP(hipSetDevice(P->device));
   MA_HIP(hipDeviceSynchronize());
-  unsigned long long h[2] = {0, 0};
+  unsigned long long h[3] = {0, 0, 0};
   MA_HIP(hipMemcpy(h, P->d_spec_stats, sizeof(h), hipMemcpyDeviceToHost));
-  *accepted = (int64_t)h[0]; *rejected = (int64_t)h[1];
+  *accepted = (int64_t)(h[0] - h[1]); *accepted_widened = (int64_t)h[2]; *rejected = (int64_t)(h[1] - h[2]);
   return MA_OK;
 }
 
@@ -515,9 +532,17 @@ static int launch_panel(ma_lu_plan* P, int m, c64* A, int k0, int nb, int rpb, i
     const int h1 = std::min(nb, LU_REG_NB), h2 = nb - h1;
     const bool tour = P->pivoting == MA_LU_PIVOT_TOURNAMENT;
     const bool spec = P->speculate && P->spec[m].backup;
-    const int* gate = spec ? P->spec[m].verdict : nullptr;     // the mode's own panel kernel runs only where the speculative one was rejected
-    int rc = spec ? lu_launch_panel_spec(A, n, k0, h1, P->spec[m], ipiv, P->d_half_lists[m], st) : MA_OK;
+    const int* gate = spec ? P->spec[m].ctl : nullptr;     // the mode's own panel kernel runs only where the speculative one was rejected
+    const bool opt = spec && P->optimistic;
+    int rc = spec ? lu_launch_panel_spec(A, n, k0, h1, P->spec[m], ipiv, P->d_half_lists[m], st, nullptr, 0, opt, ws.info) : MA_OK;
     if (rc) return rc;
+    if (opt) {                                               // nothing behind the speculative panels
+      if (h2 <= 0) return MA_OK;
+      const int a1o = k0 + h1;
+      if ((rc = lu_launch_lane_step(A, n, k0, h1, P->d_half_lists[m], a1o, h2, P->d_half_invd[m], P->pws.timeout, st))) return rc;
+      if ((rc = lu_launch_zgemm_sub(n - a1o, h2, h1, A + (size_t)a1o * n + k0, (size_t)n, A + (size_t)k0 * n + a1o, (size_t)n, A + (size_t)a1o * n + a1o, (size_t)n, st, P->use_3m, false, &P->zmode))) return rc;
+      return lu_launch_panel_spec(A, n, a1o, h2, P->spec[m], ipiv, P->d_half_lists[m] + LU_LISTS_LEN, st, P->d_half_l10[m], k0, true, ws.info);
+    }
     rc = tour ? lu_launch_panel_calu(A, n, k0, h1, P->calu[m], ws.info, ipiv, P->d_half_lists[m], st, nullptr, 0, gate)
               : lu_launch_panel_reg(A, n, k0, h1, nblk, cus, ws, ipiv, P->d_half_lists[m], clear_tags, st, nullptr, 0, gate);
     if (rc || h2 <= 0) return rc;
@@ -1326,8 +1351,10 @@ int ma_lu_plan_status(ma_lu_plan_t* P, void* stream) {
   MA_HIP(hipMemcpy(info, P->pws.info, sizeof(info), hipMemcpyDeviceToHost));
   MA_REQUIRE(info[LU_BATCH_MAX] != 2, MA_ERR_HIP, "a panel left a pivot outside its range: the factorisation was abandoned (no rows were moved with it)");
   MA_REQUIRE(info[LU_BATCH_MAX] == 0, MA_ERR_HIP, "panel factorisation abandoned: an exchange between the co-resident workgroups did not complete within its limit");
-  for (int m = 0; m < P->last_batch; ++m)
+  for (int m = 0; m < P->last_batch; ++m) {
+    MA_REQUIRE(info[m] >= 0, MA_ERR_RETRY, "system %d: a speculative panel was rejected and the plan runs without the fallback (optimistic mode): solve it again with ma_lu_plan_set_speculation(plan, MA_LU_SPECULATE_VERIFIED)", m);
     MA_REQUIRE(info[m] == 0, MA_ERR_SINGULAR, "system %d is singular: zero pivot at column %d", m, info[m] - 1);
+  }
   return MA_OK;
 }
 

@@ -27,6 +27,7 @@ namespace ma {
 namespace {
 
 constexpr int SP_NB = LU_REG_NB;
+constexpr int SP_WIDENED_ATTEMPTS = 2;          // attempts after the first, each with the rows the previous one's check turned up
 static_assert(SP_NB == 32, "one wavefront holds the top block: 32 rows in lanes 0..31");
 
 // crecip_fast with selects for its branch (the same operations on the same operands): see lu_calu.hip
@@ -37,22 +38,54 @@ __device__ __forceinline__ dc sp_crecip(dc z) {
   return sw ? dc_make(e * g, -g) : dc_make(g, -e * g);
 }
 
-template <int NB>
-__global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict__ A, int n, int k0, int nbc, dc* __restrict__ u11, dc* __restrict__ rinv,
-                                                           double* __restrict__ pivmag, int* __restrict__ order, int* __restrict__ verdict) {
+// The device words of one slot's speculative panels (LuSpecWs::ctl), all cleared by the first attempt's block kernel
+enum { SP_VERDICT = 0,   // 0: the panel is factored (accepted); != 0: not (yet)
+       SP_VCOUNT = 1,    // rows below the top block that failed the first attempt's check (their indices: LuSpecWs::vlist, the first 32)
+       SP_STAGE2 = 2,    // 1: the second attempt's block kernel produced a factorisation of the widened candidate set
+       SP_ARRIVE = 3, SP_VIOL2 = 4,   // the second attempt's finish: workgroups done, any violation
+       SP_NEXT = 5,      // positions below the top block that receive a displaced row (second attempt)
+       SP_WORDS = 16 };
+
+// Partial pivoting over the <= 64 candidate rows one wavefront holds (lane = row; `rowid` its index in the matrix, `mypos` the
+// position it holds under the interchanges so far: LAPACK's izamax takes the FIRST largest |re| + |im| in position order).
+// SECOND = false: the candidates are the panel's top rows, read from the matrix. SECOND = true (the widened attempt): the top rows plus
+// the rows that failed the first attempt's check, read from the backup the first attempt's finish kernel left.
+// Out (side buffers; the matrix is not written): u11[c][.] = row c of L11 \ U11, rinv / pivmag of the pivots, win[c] = the row that
+// became pivot row c; and, replayed by pivot_sequence: the LAPACK-style pivots, the row list for the step kernels, the positions
+// below the block that receive a displaced top row -- all tentative until the finish kernel's check has passed.
+template <int NB, bool SECOND>
+__global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict__ A, int n, int k0, int nbc, const dc* __restrict__ backup, dc* __restrict__ u11, dc* __restrict__ rinv,
+                                                           double* __restrict__ pivmag, int* __restrict__ ctl, const int* __restrict__ vlist, int* __restrict__ ext /* [2][32]: position, source row */,
+                                                           int* __restrict__ ipiv, int* __restrict__ lists, dc* __restrict__ lrows, int lcol0,
+                                                           int* __restrict__ reject_info, unsigned long long* __restrict__ stats, int last_attempt) {
   __shared__ __attribute__((aligned(16))) dc s_row[2][NB];
   __shared__ __attribute__((aligned(16))) dc s_ri[2];
+  __shared__ PivotSeqLds s_seq;
   const int lane = threadIdx.x;
-  const bool valid = lane < nbc;
+  int rowid = -1;
+  if constexpr (!SECOND) {
+    if (lane < SP_WORDS) __hip_atomic_store(ctl + lane, 0, RLX_AGENT);
+    if (lane == 0 && stats) atomicAdd(stats, 1ull);          // half-panels tried
+    if (lane < nbc) rowid = k0 + lane;
+  } else {
+    if (__hip_atomic_load(ctl + SP_VERDICT, RLX_AGENT) == 0) return;          // the first attempt was accepted
+    const int cnt = __hip_atomic_load(ctl + SP_VCOUNT, RLX_AGENT);
+    if (lane == 0) { __hip_atomic_store(ctl + SP_STAGE2, 0, RLX_AGENT); __hip_atomic_store(ctl + SP_ARRIVE, 0, RLX_AGENT); __hip_atomic_store(ctl + SP_VIOL2, 0, RLX_AGENT); }
+    if (cnt > 32) { if (lane == 0 && reject_info) __hip_atomic_store(reject_info, -1, RLX_AGENT); return; }   // too many rows want in: not a job for one wavefront
+    if (lane < nbc) rowid = k0 + lane;
+    else if (lane >= 32 && lane - 32 < cnt) rowid = vlist[lane - 32];
+    if (rowid >= n || (lane >= 32 && rowid < k0 + nbc)) rowid = -1;
+  }
+  const bool valid = rowid >= 0;
   dc a[NB];
   {
-    const dc* src = A + (size_t)(k0 + (valid ? lane : 0)) * n + k0;
+    const dc* src = SECOND ? backup + (size_t)((valid ? rowid : k0) - k0) * NB : A + (size_t)(valid ? rowid : k0) * n + k0;
     static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = (valid && j < nbc) ? src[j] : dc_make(0.0, 0.0); });
   }
-  if (lane == 0) __hip_atomic_store(verdict, 0, RLX_AGENT);
-  int mypos = lane;                                          // the position (0..31) this lane's row holds under the interchanges so far
+  int mypos = rowid;                                         // position in the matrix
   bool done = !valid;
-  bool bad = false;                                          // uniform: a column without a usable pivot -- the ordinary kernel decides what that means
+  bool bad = false;                                          // uniform: a column without a usable pivot -- the plan's own kernel decides what that means
+  int rank = -1;
   static_for<0, NB>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
     constexpr int buf = c & 1;
@@ -67,24 +100,29 @@ __global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict_
     const bool c1 = ok && hi == mh;
     const unsigned ml = wave_umax(c1 ? lo : 0u);
     const bool c2 = c1 && lo == ml;
-    const unsigned pm = wave_umin(c2 ? (unsigned)mypos : 0xFFFFFFFFu);
-    u64 wm = __ballot(c2 && (unsigned)mypos == pm);
-    if (!wm) { if (live) bad = true; wm = __ballot(!done && mypos == c); }   // nothing to offer (NaNs): the row on the diagonal stands in
+    u64 wm = __ballot(c2);
+    if (__popcll(wm) > 1) {                                  // equal magnitudes (rare): the lowest position
+      const unsigned pm = wave_umin(c2 ? (unsigned)mypos : 0xFFFFFFFFu);
+      wm = __ballot(c2 && (unsigned)mypos == pm);
+    }
+    if (!wm) { if (live) bad = true; wm = __ballot(!done && mypos == k0 + c); }   // nothing to offer (NaNs): the row on the diagonal stands in
     const int wl = wm ? (int)__builtin_ctzll(wm) : 0;
     const bool iam = wm != 0ull && lane == wl;
     const dc rv = sp_crecip(a[c]);
     if (iam) {
       static_for<c, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; s_row[buf][j] = a[j]; });
       s_ri[buf] = rv;
+      if (live) s_seq.win[c] = rowid;
     }
+    if (lane == 0 && (!live || !wm)) s_seq.win[c] = -1;
     __syncthreads();
     const dc piv = s_row[buf][c], ri = s_ri[buf];
     const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
     if (live && (singular || !wm)) bad = true;
     if (live && wm) {
       const int wpos = __builtin_amdgcn_readlane(mypos, wl);
-      if (iam) { done = true; mypos = c; }
-      else if (!done && mypos == c) mypos = wpos;            // the row that sat on the diagonal takes the pivot row's place
+      if (iam) { done = true; mypos = k0 + c; rank = c; }
+      else if (!done && mypos == k0 + c) mypos = wpos;       // the row that sat on the diagonal takes the pivot row's place
       if (lane == 0) { rinv[c] = ri; pivmag[c] = cabs1(piv); }
     }
     const bool act = live && wm != 0ull && !done && !singular;
@@ -99,30 +137,66 @@ __global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict_
       a[j].im = __builtin_fma(nli, u.re, __builtin_fma(nlr, u.im, a[j].im));
     });
   });
-  if (valid) {
-    dc* dst = u11 + (size_t)mypos * NB;
-    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[j] = a[j]; });
-    order[mypos] = lane;
+  if (bad) {                                                 // no factorisation to offer: the panel stays (or becomes) rejected
+    if (lane == 0) {
+      if (!SECOND) { __hip_atomic_store(ctl + SP_VERDICT, 1, RLX_AGENT); if (stats) atomicAdd(stats + 1, 1ull); }
+      __hip_atomic_store(ctl + SP_VCOUNT, 1000, RLX_AGENT);   // (no further attempt)
+      if (reject_info) __hip_atomic_store(reject_info, -1, RLX_AGENT);
+    }
+    return;
   }
-  if (bad && lane == 0) __hip_atomic_store(verdict, 1, RLX_AGENT);
+  if (rank >= 0) {
+    dc* dst = u11 + (size_t)rank * NB;
+    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[j] = a[j]; });
+    // right half of a 64-column panel (lu_plan.hip, pair form): the pivot rows' entries of the LEFT half's columns [lcol0, lcol0 + 32),
+    // the block L10 the step after the panel solves with (as lu_panel_reg_kernel leaves them)
+    if (lrows) {
+      const dc* lsrc = A + (size_t)rowid * n + lcol0;
+      dc* ldst = lrows + (size_t)rank * LU_REG_NB;
+      static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; ldst[j] = lsrc[j]; });
+    }
+  }
+  __syncthreads();
+  pivot_sequence(s_seq, k0, nbc);
+  __syncthreads();
+  if (lane < nbc) ipiv[k0 + lane] = s_seq.ipiv[lane];
+  if (lists) {
+    if (lane == 0) lists[0] = s_seq.lm;
+    if (lane < s_seq.lm) { lists[1 + lane] = s_seq.ldst[lane]; lists[1 + 2 * LU_NB_MAX + lane] = s_seq.lsrc[lane]; }
+  }
+  if (lane < s_seq.next) { ext[lane] = s_seq.ext_pos[lane]; ext[32 + lane] = s_seq.ext_src[lane]; }
+  if (lane == 0) {
+    __hip_atomic_store(ctl + SP_NEXT, s_seq.next, RLX_AGENT);
+    if (SECOND) __hip_atomic_store(ctl + SP_STAGE2, 1, RLX_AGENT);
+  }
 }
 
 struct SpecFinishLds {
   dc U[SP_NB][SP_NB];
   dc rinv[SP_NB];
   double pivmag[SP_NB];
-  PivotSeqLds seq;
+  int ext_pos[SP_NB], ext_src[SP_NB];
 };
 
-// One wavefront per workgroup, a lane per row of [k0, n): rows of the top block take their final content from the side buffer, the
-// others go through the forward substitution with the check. Workgroup 0 also writes the pivots, the row list and (right half of a
-// pair) the pivot rows' left-half entries.
-template <int NB>
+// One wavefront per workgroup, a lane per position of [k0, n): positions of the top block take their final content (rows of L11 \ U11)
+// from the side buffer, the others go through the forward substitution with the check.
+// SECOND = false (first attempt): rows are read from the matrix and leave their original entries in the backup; rows that fail the
+// check add themselves to the list of the widened attempt. SECOND = true: rows are read from the backup -- a position that receives a
+// displaced top row reads THAT row --, and the workgroup that finishes last settles the verdict.
+template <int NB, bool SECOND>
 __global__ __launch_bounds__(64) void lu_spec_finish_kernel(dc* __restrict__ A, int n, int k0, int nbc, const dc* __restrict__ u11, const dc* __restrict__ rinv,
-                                                            const double* __restrict__ pivmag, const int* __restrict__ order, int* __restrict__ verdict,
-                                                            dc* __restrict__ backup, int* __restrict__ ipiv, int* __restrict__ lists, dc* __restrict__ lrows, int lcol0) {
+                                                            const double* __restrict__ pivmag, int* __restrict__ ctl, int* __restrict__ vlist, const int* __restrict__ ext,
+                                                            dc* __restrict__ backup, int* __restrict__ reject_info, unsigned long long* __restrict__ stats, int last_attempt) {
   __shared__ __attribute__((aligned(16))) SpecFinishLds S;
   const int lane = threadIdx.x, b = (int)blockIdx.x;
+  int next = 0;
+  if constexpr (SECOND) {
+    if (__hip_atomic_load(ctl + SP_VERDICT, RLX_AGENT) == 0 || __hip_atomic_load(ctl + SP_STAGE2, RLX_AGENT) == 0) return;   // (final before this grid starts: uniform)
+    next = min(32, __hip_atomic_load(ctl + SP_NEXT, RLX_AGENT));
+    if (lane < next) { S.ext_pos[lane] = ext[lane]; S.ext_src[lane] = ext[32 + lane]; }
+  }
+  // (first attempt, the block kernel had nothing to offer: the rows still go to the backup -- the restore behind a rejected panel copies it back)
+  const bool backup_only = !SECOND && __hip_atomic_load(ctl + SP_VERDICT, RLX_AGENT) != 0;
   for (int idx = lane; idx < NB * NB; idx += 64) {
     const int i = idx / NB, j = idx % NB;
     S.U[i][j] = (i < nbc && j < nbc && j >= i) ? u11[(size_t)i * NB + j] : dc_make(0.0, 0.0);
@@ -130,33 +204,26 @@ __global__ __launch_bounds__(64) void lu_spec_finish_kernel(dc* __restrict__ A, 
   if (lane < NB) {
     S.rinv[lane] = lane < nbc ? rinv[lane] : dc_make(0.0, 0.0);
     S.pivmag[lane] = lane < nbc ? pivmag[lane] : 0.0;
-    if (b == 0) S.seq.win[lane] = lane < nbc ? k0 + order[lane] : -1;
   }
   __syncthreads();
   const int row = k0 + 64 * b + lane;
   const bool valid = row < n;
+  const bool top = row < k0 + nbc;
   dc a[NB];
   dc* p = A + (size_t)(valid ? row : k0) * n + k0;
-  static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = (valid && j < nbc) ? p[j] : dc_make(0.0, 0.0); });
-  if (valid) {
-    dc* bk = backup + (size_t)(row - k0) * NB;
-    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if (j < nbc) bk[j] = a[j]; });
-  }
-  if (b == 0) {
-    pivot_sequence(S.seq, k0, nbc);
-    __syncthreads();
-    if (lane < nbc) ipiv[k0 + lane] = S.seq.ipiv[lane];
-    if (lists) {
-      if (lane == 0) lists[0] = S.seq.lm;
-      if (lane < S.seq.lm) { lists[1 + lane] = S.seq.ldst[lane]; lists[1 + 2 * LU_NB_MAX + lane] = S.seq.lsrc[lane]; }
+  int src_row = row;                                       // the row (of the backup) this position's content comes from
+  if constexpr (!SECOND) {
+    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = (valid && j < nbc) ? p[j] : dc_make(0.0, 0.0); });
+    if (valid) {
+      dc* bk = backup + (size_t)(row - k0) * NB;
+      static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if (j < nbc) bk[j] = a[j]; });
     }
-    if (lrows && lane < nbc) {                             // as lu_panel_reg_kernel leaves them: row c = the pivot row of column c, its entries of the left half's columns
-      const dc* lsrc = A + (size_t)S.seq.win[lane] * n + lcol0;
-      dc* ldst = lrows + (size_t)lane * LU_REG_NB;
-      static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; ldst[j] = lsrc[j]; });
-    }
+    if (backup_only) return;
+  } else {
+    for (int e = 0; e < next; ++e) if (S.ext_pos[e] == row) src_row = S.ext_src[e];
+    const dc* bk = backup + (size_t)((valid ? src_row : k0) - k0) * NB;
+    static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; a[j] = (valid && j < nbc) ? bk[j] : dc_make(0.0, 0.0); });
   }
-  const bool top = row < k0 + nbc;
   bool viol = false;
   if (top) {
     const dc* src = u11 + (size_t)(row - k0) * NB;
@@ -179,14 +246,32 @@ __global__ __launch_bounds__(64) void lu_spec_finish_kernel(dc* __restrict__ A, 
     });
   }
   if (valid) static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; if (j < nbc) p[j] = a[j]; });
-  if (__any(valid && viol) && lane == 0) atomicOr(verdict, 1);
+  viol = viol && valid;
+  // a row that fails the check joins the candidates of the next attempt (a candidate cannot fail: the pivot is the largest of them)
+  if (viol) { const int idx = atomicAdd(ctl + SP_VCOUNT, 1); if (idx < 32) vlist[idx] = SECOND ? src_row : row; }
+  if constexpr (!SECOND) {
+    if (__any(viol) && lane == 0) {
+      if (atomicOr(ctl + SP_VERDICT, 1) == 0 && stats) atomicAdd(stats + 1, 1ull);   // the panel's first violation: the first attempt is rejected
+    }
+    // (whether the widened attempt can take it -- <= 32 rows in the list -- is for its block kernel to see; more than that, and the
+    // status word of an optimistic plan is set there)
+  } else {
+    if (__any(viol) && lane == 0) atomicOr(ctl + SP_VIOL2, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (lane == 0) {
+      const int old = atomicAdd(ctl + SP_ARRIVE, 1);
+      if (old == (int)gridDim.x - 1) {                       // the last workgroup settles it
+        const int v2 = __hip_atomic_load(ctl + SP_VIOL2, RLX_AGENT);
+        if (v2 == 0) { __hip_atomic_store(ctl + SP_VERDICT, 0, RLX_AGENT); if (stats) atomicAdd(stats + 2, 1ull); }   // accepted by the widened attempt
+        else if (reject_info && (last_attempt || __hip_atomic_load(ctl + SP_VCOUNT, RLX_AGENT) > 32)) __hip_atomic_store(reject_info, -1, RLX_AGENT);
+      }
+    }
+  }
 }
 
-__global__ __launch_bounds__(256) void lu_spec_restore_kernel(dc* __restrict__ A, int n, int k0, int nbc, const dc* __restrict__ backup, const int* __restrict__ verdict,
-                                                              unsigned long long* __restrict__ stats /* [0] accepted, [1] rejected panels */) {
-  const bool rejected = __hip_atomic_load(verdict, RLX_AGENT) != 0;
-  if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(stats + (rejected ? 1 : 0), 1ull);
-  if (!rejected) return;
+__global__ __launch_bounds__(256) void lu_spec_restore_kernel(dc* __restrict__ A, int n, int k0, int nbc, const dc* __restrict__ backup, const int* __restrict__ verdict) {
+  if (__hip_atomic_load(verdict, RLX_AGENT) == 0) return;
   const long long total = (long long)(n - k0) * SP_NB;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int r = (int)(idx / SP_NB), j = (int)(idx % SP_NB);
@@ -196,19 +281,30 @@ __global__ __launch_bounds__(256) void lu_spec_restore_kernel(dc* __restrict__ A
 
 }  // namespace
 
-int lu_launch_panel_spec(c64* A, int n, int k0, int nb, const LuSpecWs& ws, int* ipiv, int* lists, hipStream_t st, c64* lrows, int lcol0) {
+// The two attempts (block + finish each; the second pair returns at once where the first was accepted), then -- optimistic = false --
+// the restore of a panel both attempts had to give up, behind which the caller launches its own panel kernel gated by ws.ctl
+// (run_if_nonzero). optimistic = true: no restore, nothing behind: a panel given up leaves -1 in *reject_info (the system's status
+// word) and the CALLER solves that system again in the verified mode.
+int lu_launch_panel_spec(c64* A, int n, int k0, int nb, const LuSpecWs& ws, int* ipiv, int* lists, hipStream_t st, c64* lrows, int lcol0, bool optimistic, int* reject_info) {
   MA_REQUIRE(nb >= 1 && nb <= LU_REG_NB && k0 >= 0 && k0 + nb <= n, MA_ERR_INVALID, "panel [%d, %d) outside 0..%d", k0, k0 + nb, n);
   MA_REQUIRE(!lrows || (lcol0 >= 0 && lcol0 + LU_REG_NB <= k0), MA_ERR_INVALID, "left-half columns [%d, %d) not left of the panel at %d", lcol0, lcol0 + LU_REG_NB, k0);
-  MA_REQUIRE(ws.u11 && ws.rinv && ws.pivmag && ws.order && ws.verdict && ws.backup && ws.rows >= n - k0, MA_ERR_INVALID, "speculative-panel workspace missing or too small");
-  hipLaunchKernelGGL(lu_spec_block_kernel<LU_REG_NB>, dim3(1), dim3(64), 0, st, reinterpret_cast<const dc*>(A), n, k0, nb, reinterpret_cast<dc*>(ws.u11), reinterpret_cast<dc*>(ws.rinv),
-                     ws.pivmag, ws.order, ws.verdict);
+  MA_REQUIRE(ws.u11 && ws.rinv && ws.pivmag && ws.ctl && ws.vlist && ws.ext && ws.backup && ws.rows >= n - k0, MA_ERR_INVALID, "speculative-panel workspace missing or too small");
+  MA_REQUIRE(!optimistic || reject_info, MA_ERR_INVALID, "the optimistic form needs the system's status word");
+  int* rj = optimistic ? reject_info : nullptr;
+  dc* dA = reinterpret_cast<dc*>(A); dc* u11 = reinterpret_cast<dc*>(ws.u11); dc* ri = reinterpret_cast<dc*>(ws.rinv); dc* bk = reinterpret_cast<dc*>(ws.backup);
+  const dim3 fgrid((n - k0 + 63) / 64);
+  hipLaunchKernelGGL((lu_spec_block_kernel<LU_REG_NB, false>), dim3(1), dim3(64), 0, st, dA, n, k0, nb, bk, u11, ri, ws.pivmag, ws.ctl, ws.vlist, ws.ext, ipiv, lists, reinterpret_cast<dc*>(lrows), lcol0, rj, ws.stats, 0);
+  hipLaunchKernelGGL((lu_spec_finish_kernel<LU_REG_NB, false>), fgrid, dim3(64), 0, st, dA, n, k0, nb, u11, ri, ws.pivmag, ws.ctl, ws.vlist, ws.ext, bk, rj, ws.stats, 0);
+  for (int t = 0; t < SP_WIDENED_ATTEMPTS; ++t) {           // each returns at once where the panel has been accepted
+    const int last = t == SP_WIDENED_ATTEMPTS - 1;
+    hipLaunchKernelGGL((lu_spec_block_kernel<LU_REG_NB, true>), dim3(1), dim3(64), 0, st, dA, n, k0, nb, bk, u11, ri, ws.pivmag, ws.ctl, ws.vlist, ws.ext, ipiv, lists, reinterpret_cast<dc*>(lrows), lcol0, rj, ws.stats, last);
+    hipLaunchKernelGGL((lu_spec_finish_kernel<LU_REG_NB, true>), fgrid, dim3(64), 0, st, dA, n, k0, nb, u11, ri, ws.pivmag, ws.ctl, ws.vlist, ws.ext, bk, rj, ws.stats, last);
+  }
   MA_HIP(hipGetLastError());
-  hipLaunchKernelGGL(lu_spec_finish_kernel<LU_REG_NB>, dim3((n - k0 + 63) / 64), dim3(64), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, reinterpret_cast<const dc*>(ws.u11),
-                     reinterpret_cast<const dc*>(ws.rinv), ws.pivmag, ws.order, ws.verdict, reinterpret_cast<dc*>(ws.backup), ipiv, lists, reinterpret_cast<dc*>(lrows), lcol0);
-  MA_HIP(hipGetLastError());
+  if (optimistic) return MA_OK;
   const long long total = (long long)(n - k0) * LU_REG_NB;
   int gx = (int)std::min<long long>((total + 255) / 256, 1024);
-  hipLaunchKernelGGL(lu_spec_restore_kernel, dim3(gx), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, reinterpret_cast<const dc*>(ws.backup), ws.verdict, ws.stats);
+  hipLaunchKernelGGL(lu_spec_restore_kernel, dim3(gx), dim3(256), 0, st, dA, n, k0, nb, reinterpret_cast<const dc*>(ws.backup), ws.ctl);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

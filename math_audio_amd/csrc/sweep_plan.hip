@@ -49,6 +49,7 @@ struct ma_bem_sweep {
   hipEvent_t ev_run[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> ev_asm; size_t ev_asm_used = 0;
   double last_wall_s = 0.0, last_device_ms = 0.0, last_asm_ms = 0.0; int last_asm_pieces = 0, last_n = 0;
+  int last_redone = 0;                                     // frequencies of the last run that were solved a second time (their optimistic factorisation met a rejected panel)
   bool have_last = false;
 
   void free_spares() { for (auto& t : sets) for (int q = 0; q < 3; ++q) { if (t.A[q]) (void)hipFree(t.A[q]); if (t.x[q]) (void)hipFree(t.x[q]); t.A[q] = t.x[q] = nullptr; } }
@@ -135,6 +136,15 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, in
   S->slots = slots;
   auto fail = [&](int code) { S->release(); delete S; return code; };
   if ((rc = ma_lu_plan_create_pivoting(n, device, pivoting, &S->lu))) return fail(rc);
+  // The sweep runs the plan's speculative panels WITHOUT the fallback behind them (lu_spec.hip: Burton-Miller operators pass the check at
+  // every panel) and solves a frequency that did meet a rejected panel again, in the verified mode, after the pipeline has drained
+  // (sweep_run, "redo"). MA_SWEEP_SPECULATE=verified|off: the fallback in line / no speculation.
+  {
+    int mode = MA_LU_SPECULATE_OPTIMISTIC;
+    if (const char* e = getenv("MA_SWEEP_SPECULATE")) mode = (e[0] == 'v' || e[0] == '1') ? MA_LU_SPECULATE_VERIFIED : ((e[0] == 'o' && e[1] == 'f') || e[0] == '0') ? MA_LU_SPECULATE_OFF : MA_LU_SPECULATE_OPTIMISTIC;
+    int32_t cur = MA_LU_SPECULATE_OFF;
+    if (ma_lu_plan_speculation(S->lu, &cur) == MA_OK && cur != MA_LU_SPECULATE_OFF && (rc = ma_lu_plan_set_speculation(S->lu, mode))) return fail(rc);
+  }
   // the sweep's own stream: the plan's big-update stream when the plan splits the chip (that stream is masked to the update CUs,
   // and a stream more would be one hardware queue more: profiles/r03_lu_panel_experiments.md), a stream of its own otherwise
   { void* ms = nullptr; if (ma_lu_plan_main_stream(S->lu, &ms) == MA_OK && ms) S->st = (hipStream_t)ms; }
@@ -376,11 +386,31 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     if (!rc && S->timing && hipEventRecord(S->ev_run[1], st) != hipSuccess) { set_error("sweep: event record failed"); rc = MA_ERR_HIP; }
     if (!rc) {
       int stt = ma_lu_plan_status(lu, st);                     // synchronises; an abandoned panel (poisoned plan) surfaces here
-      if (stt != MA_OK && stt != MA_ERR_SINGULAR) rc = stt;
+      if (stt != MA_OK && stt != MA_ERR_SINGULAR && stt != MA_ERR_RETRY) rc = stt;
     }
     if (!rc) {
       std::vector<int32_t> hinfo((size_t)n_mine);
       hipError_t e = hipMemcpy(hinfo.data(), dinfo, sizeof(int32_t) * (size_t)n_mine, hipMemcpyDeviceToHost);
+#ifdef MA_DIAGNOSTICS
+      // diagnostic build only: pretend the i-th frequency of this device met a rejected panel (exercises the redo below)
+      if (const char* et = getenv("MA_TEST_SWEEP_REJECT")) { const int i = atoi(et); if (i >= 0 && i < n_mine) hinfo[(size_t)i] = -1; }
+#endif
+      // redo: frequencies whose optimistic factorisation met a rejected panel (status -1), one at a time in the verified mode
+      S->last_redone = 0;
+      for (int i = 0; i < n_mine && e == hipSuccess && !rc; ++i) {
+        if (hinfo[(size_t)i] >= 0) continue;
+        int32_t mode = MA_LU_SPECULATE_OFF;
+        rc = ma_lu_plan_speculation(lu, &mode);
+        if (!rc) rc = ma_lu_plan_set_speculation(lu, MA_LU_SPECULATE_VERIFIED);
+        if (!rc) rc = assemble(mine[(size_t)i], 0);
+        if (!rc) rc = ma_lu_plan_factor_solve_dev(lu, dA[0], dx[0], 1, st);
+        int stt = MA_OK;
+        if (!rc) { stt = ma_lu_plan_status(lu, st); if (stt != MA_OK && stt != MA_ERR_SINGULAR) rc = stt; }
+        if (!rc) { hinfo[(size_t)i] = stt == MA_ERR_SINGULAR ? 1 : 0; e = hipMemcpy(dX + (size_t)i * (size_t)n, dx[0], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice); }
+        const int back = ma_lu_plan_set_speculation(lu, mode);
+        if (!rc) rc = back;
+        ++S->last_redone;
+      }
       if (X_out) {
         if (stride == 1 && first == 0) { if (e == hipSuccess) e = hipMemcpy(X_out, dX, sizeof(ma_c64) * (size_t)n_mine * (size_t)n, hipMemcpyDeviceToHost); }
         else for (int i = 0; i < n_mine && e == hipSuccess; ++i)
@@ -408,7 +438,8 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     }
     return rc ? rc : worst;
   }
-  // look-ahead lanes switched off (MA_LU_LOOKAHEAD=0 / MA_LU_PANEL_OVERLAP=0): lock-step batches
+  // look-ahead lanes switched off (MA_LU_LOOKAHEAD=0 / MA_LU_PANEL_OVERLAP=0): lock-step batches (always with the fallback in line)
+  { int32_t mode = MA_LU_SPECULATE_OFF; if (ma_lu_plan_speculation(lu, &mode) == MA_OK && mode == MA_LU_SPECULATE_OPTIMISTIC) (void)ma_lu_plan_set_speculation(lu, MA_LU_SPECULATE_VERIFIED); }
   for (int i0 = 0; i0 < n_mine && !rc; i0 += slots) {
     const int cnt = std::min((int)slots, n_mine - i0);
     for (int s = 0; s < cnt && !rc; ++s) rc = assemble(mine[(size_t)(i0 + s)], s);

