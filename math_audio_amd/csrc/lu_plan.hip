@@ -24,7 +24,7 @@ using namespace ma;
 #define MA_LU_CU_SPLIT_DEFAULT 64
 #endif
 #ifndef MA_LU_CU_SPLIT_TOURNAMENT
-#define MA_LU_CU_SPLIT_TOURNAMENT 64        // CUs the big updates stay off in a tournament-pivoting plan
+#define MA_LU_CU_SPLIT_TOURNAMENT 32        // CUs the big updates stay off in a tournament-pivoting plan: one per shader engine of every XCD (see below)
 #endif
 #define LU_KB_MAX 8                         // panels per trailing update
 #define LU_LANE_TSTRIDE 512                   // the lane's interchanges touch at most (kb-1) panels' columns: 7 x 64 or 3 x 128

@@ -53,13 +53,16 @@ enum { SP_VERDICT = 0,   // 0: the panel is factored (accepted); != 0: not (yet)
 // Out (side buffers; the matrix is not written): u11[c][.] = row c of L11 \ U11, rinv / pivmag of the pivots, win[c] = the row that
 // became pivot row c; and, replayed by pivot_sequence: the LAPACK-style pivots, the row list for the step kernels, the positions
 // below the block that receive a displaced top row -- all tentative until the finish kernel's check has passed.
+// a double of lane `wl` (uniform) to every lane through the scalar registers: no LDS round trip, no barrier
+__device__ __forceinline__ double bcast_lane(double x, int wl) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), wl), __builtin_amdgcn_readlane(__double2loint(x), wl));
+}
+
 template <int NB, bool SECOND>
 __global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict__ A, int n, int k0, int nbc, const dc* __restrict__ backup, dc* __restrict__ u11, dc* __restrict__ rinv,
                                                            double* __restrict__ pivmag, int* __restrict__ ctl, const int* __restrict__ vlist, int* __restrict__ ext /* [2][32]: position, source row */,
                                                            int* __restrict__ ipiv, int* __restrict__ lists, dc* __restrict__ lrows, int lcol0,
                                                            int* __restrict__ reject_info, unsigned long long* __restrict__ stats, int last_attempt) {
-  __shared__ __attribute__((aligned(16))) dc s_row[2][NB];
-  __shared__ __attribute__((aligned(16))) dc s_ri[2];
   __shared__ PivotSeqLds s_seq;
   const int lane = threadIdx.x;
   int rowid = -1;
@@ -88,7 +91,6 @@ __global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict_
   int rank = -1;
   static_for<0, NB>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    constexpr int buf = c & 1;
     const bool live = c < nbc;
     // izamax over the rows not yet chosen: the full 64 bits of |re| + |im| (a non-negative double orders as its bit pattern), ties
     // to the lower position
@@ -108,15 +110,11 @@ __global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict_
     if (!wm) { if (live) bad = true; wm = __ballot(!done && mypos == k0 + c); }   // nothing to offer (NaNs): the row on the diagonal stands in
     const int wl = wm ? (int)__builtin_ctzll(wm) : 0;
     const bool iam = wm != 0ull && lane == wl;
+    // the pivot row reaches the other lanes through the scalar registers (v_readlane with a uniform lane): one wavefront, no LDS, no barrier
     const dc rv = sp_crecip(a[c]);
-    if (iam) {
-      static_for<c, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; s_row[buf][j] = a[j]; });
-      s_ri[buf] = rv;
-      if (live) s_seq.win[c] = rowid;
-    }
-    if (lane == 0 && (!live || !wm)) s_seq.win[c] = -1;
-    __syncthreads();
-    const dc piv = s_row[buf][c], ri = s_ri[buf];
+    const dc piv = dc_make(bcast_lane(a[c].re, wl), bcast_lane(a[c].im, wl));
+    const dc ri = dc_make(bcast_lane(rv.re, wl), bcast_lane(rv.im, wl));
+    if (lane == 0) s_seq.win[c] = (live && wm) ? __builtin_amdgcn_readlane(rowid, wl) : -1;
     const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
     if (live && (singular || !wm)) bad = true;
     if (live && wm) {
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(64) void lu_spec_block_kernel(const dc* __restrict_
     const double nlr = -l.re, nli = -l.im, li = l.im;
     static_for<c + 1, NB>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      const dc u = s_row[buf][j];
+      const dc u = dc_make(bcast_lane(a[j].re, wl), bcast_lane(a[j].im, wl));
       a[j].re = __builtin_fma(li, u.im, __builtin_fma(nlr, u.re, a[j].re));
       a[j].im = __builtin_fma(nli, u.re, __builtin_fma(nlr, u.im, a[j].im));
     });

@@ -118,13 +118,21 @@ def test_s10_sweep_as_benchmarked_equals_the_single_system_path(gpu):
     sw = ma.BemSweep(plan, len(freqs), slots=3)
     info = sw.info()
     assert info["staged"] and info["slots"] == 3 and info["systems_ahead"] == 3 and info["blocks"] >= 20, info   # the benchmarked configuration, not a fallback
-    assert sw.lu_plan().main_stream(), "the default 10 000-row plan runs its big updates on the CU-masked stream"
+    slu = sw.lu_plan()
+    assert slu.main_stream(), "the default 10 000-row plan runs its big updates on the CU-masked stream"
+    # round 5: the sweep's plan factors its half-panels speculatively (lu_spec.hip), without a fallback behind them (a frequency that met a
+    # rejected panel would be solved again), and its own panel kernel is the tournament
+    assert slu.pivoting() == "tournament" and slu.speculation() == "optimistic"
     X, st = sw.run(freqs, speed_of_sound=C_SOUND, beta_scale=4.0)
     assert np.all(st == ma.MA_OK) and np.all(np.isfinite(X.view(np.float64)))
+    acc, wid, rej = slu.speculation_stats()
+    print("S10, 9 frequencies: half-panels accepted at once %d, by a widened attempt %d, rejected %d" % (acc, wid, rej))
+    assert acc + wid + rej == 9 * 313 and rej == 0 and wid > 0      # the UV sphere's poles need the widened attempt; nothing is left to the tournament
     sw.close()
     dev = torch.device("cuda", 0)
     s0 = torch.cuda.current_stream().cuda_stream
-    lu = ma.LuPlan(n)
+    # the single-system path in the sweep's own pivoting mode (accepted half-panels carry LAPACK's pivots in either mode: the same bits)
+    lu = ma.LuPlan(n, pivoting="tournament")
     A = torch.empty(n * n, dtype=torch.complex128, device=dev); x = torch.empty(n, dtype=torch.complex128, device=dev)
     worst = 0.0
     for fi, k in enumerate(ks):
@@ -140,6 +148,26 @@ def test_s10_sweep_as_benchmarked_equals_the_single_system_path(gpu):
         res = float(torch.linalg.norm(A.view(n, n) @ xs - x) / torch.linalg.norm(x))
         assert res <= 1e-10, (idx[fi], res)
     lu.close()
+    # and against LAPACK-style partial pivoting without any speculation (the round-4 path), both ends of the list and the sign switch:
+    # two backward-stable solves of a well-conditioned system; with the growth of the factors printed (max |L|, max |U| / max |A|)
+    import os
+    os.environ["MA_LU_SPECULATE"] = "0"
+    try:
+        lup = ma.LuPlan(n)
+    finally:
+        del os.environ["MA_LU_SPECULATE"]
+    assert lup.pivoting() == "partial" and lup.speculation() == "off"
+    for fi in (0, 3, 8):
+        k = ks[fi]; beta = mm.burton_miller_beta_scaled(k, 4.0)
+        plan.assemble_dev(k, beta, A.data_ptr(), x.data_ptr(), stream=s0)
+        amax = float(A.abs().max())
+        xp = _single_system(plan, lup, k, beta, A, x, s0)
+        F = A.view(n, n)
+        lmax = float(torch.tril(F, -1).abs().max()); umax = float(torch.triu(F).abs().max())
+        print("S10 f[%d]: partial pivoting max |L| = %.3f, growth max |U| / max |A| = %.3f; sweep vs partial rel L2 = %.2e" % (idx[fi], lmax, umax / amax, rel_l2(X[fi], xp)))
+        assert lmax <= 1.0 + 1e-12 and umax / amax <= 4.0
+        assert rel_l2(X[fi], xp) <= 1e-11, (idx[fi], rel_l2(X[fi], xp))
+    lup.close()
     del A
     # the assembly as the sweep issues it: three systems per pass, in twelve pieces
     om = O.uv_sphere(RADIUS, 51, 100)
