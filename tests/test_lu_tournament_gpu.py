@@ -290,7 +290,7 @@ def test_speculative_panel_accepted_is_lapacks_factorisation(gpu, n, pivoting):
     assert np.array_equal(LU, LU0) and np.array_equal(x, x0)
     assert np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x)) <= 1e-14 * n
     lu_ref, piv_ref = sla.lu_factor(A)
-    assert np.abs(np.tril(LU, -1)).max() <= 1.0 + 1e-12      # partial pivoting's bound on the multipliers
+    assert np.abs(np.tril(LU, -1)).max() <= 2.0 ** 0.5 + 1e-12      # partial pivoting's bound on the multipliers (izamax compares |re| + |im|)
     assert np.allclose(np.triu(LU), np.triu(lu_ref), rtol=1e-10, atol=1e-10)
 
 

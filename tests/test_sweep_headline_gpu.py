@@ -165,7 +165,7 @@ def test_s10_sweep_as_benchmarked_equals_the_single_system_path(gpu):
         F = A.view(n, n)
         lmax = float(torch.tril(F, -1).abs().max()); umax = float(torch.triu(F).abs().max())
         print("S10 f[%d]: partial pivoting max |L| = %.3f, growth max |U| / max |A| = %.3f; sweep vs partial rel L2 = %.2e" % (idx[fi], lmax, umax / amax, rel_l2(X[fi], xp)))
-        assert lmax <= 1.0 + 1e-12 and umax / amax <= 4.0
+        assert lmax <= 2.0 ** 0.5 + 1e-9 and umax / amax <= 16.0     # izamax compares |re| + |im|: a multiplier's modulus can reach sqrt(2)
         assert rel_l2(X[fi], xp) <= 1e-11, (idx[fi], rel_l2(X[fi], xp))
     lup.close()
     del A
