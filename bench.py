@@ -372,7 +372,7 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the residual check of the last systems after the timed region")
     ap.add_argument("--inlib-multi", action="store_true", help="ONE process: ma_bem_solve_sweep_multi over --gpus N devices (a host thread per device inside the library) "
                                                                 "instead of one torch.distributed rank per GPU")
-    ap.add_argument("--devices", default="", help="--inlib-multi: comma-separated device list instead of 0..N-1 (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1 allows repeats)")
+    ap.add_argument("--devices", default="", help="--inlib-multi: comma-separated device list instead of 0..N-1 (repeats need the diagnostic build: MA_LIB_PATH=.../libmathaudio_hip_diag.so MA_TEST_ALLOW_DUPLICATE_DEVICES=1)")
     ap.add_argument("--slots", type=int, default=int(os.environ.get("MA_SWEEP_SLOTS", "3")), help="frequencies in flight per GPU (1..4)")
     ap.add_argument("--dump-updates", default="", help="diagnostic: save (start, end) ms of every big update of the timed run to this .npy and print the stream's gaps")
     args = ap.parse_args()
@@ -415,7 +415,7 @@ def main():
     n = mesh.n_elem
     freqs = mm.log_space(100.0, 8000.0, 64)
     K, W = args.steps, args.warmup
-    S = max(1, min(args.slots, 6 if os.environ.get("MA_LU_LANE_ALIAS") else 4, K))
+    S = max(1, min(args.slots, 4, K))
     # rank r solves the list's points r, r + N, ...: its s-th step is point (r + s N) mod 64 (the list wraps for long runs)
     mine = lambda first, count: [freqs[(rank + (first + s_) * world) % len(freqs)] for s_ in range(count)]
     plan = ma.BemPlan(mesh, device=local_rank)

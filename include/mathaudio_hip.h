@@ -268,9 +268,9 @@ int ma_lu_plan_reserve_events(ma_lu_plan_t* plan, int64_t count);   /* timing ev
 int ma_lu_plan_num_blocks(ma_lu_plan_t* plan, int32_t* blocks);
 int ma_lu_plan_stage_reset(ma_lu_plan_t* plan, void* stream);
 int ma_lu_plan_slot_stream(ma_lu_plan_t* plan, int32_t slot, void** stream);
-/* Round 3: a plan for 4 096..16 384 rows (or MA_LU_CU_SPLIT=<P>) runs its big trailing updates on a stream whose CU mask leaves
- * P = 64 CUs (P / 8 per XCD) to the latency-bound panel kernels (no reference counterpart: a schedule detail behind lu_solve,
- * math-solvers/src/direct/lu.rs:142-153). *stream = that stream, or NULL when the plan does not split the chip. A driver of the
+/* A plan for 4 096..16 384 rows (or MA_LU_CU_SPLIT=<0 | 32 | 64>) runs its big trailing updates on a stream whose CU mask leaves
+ * P CUs (P / 8 per XCD: 64 for a partial-pivoting plan, 32 for a tournament plan) to the latency-bound kernels of its lanes (no reference
+ * counterpart: a schedule detail behind lu_solve, math-solvers/src/direct/lu.rs:142-153). *stream = that stream, or NULL when the plan does not split the chip. A driver of the
  * staged schedule passes it as ITS stream (assemblies included): one hardware queue less. The masked stream is a blocking stream (the
  * only kind the runtime makes with a CU mask): stage_reset / stage_begin refuse the NULL stream on such a plan (MA_ERR_INVALID) -- work on
  * the NULL stream would serialise against every big update. */
@@ -282,19 +282,7 @@ int ma_lu_plan_cu_split(ma_lu_plan_t* plan, int32_t* panel_cus, int32_t* total_c
 int ma_lu_plan_stage_spacing(ma_lu_plan_t* plan, int32_t slots, int32_t* spacing);
 int ma_lu_plan_stage_begin(ma_lu_plan_t* plan, int32_t slot, void* d_A, void* d_B, int32_t nrhs, void* stream);
 int ma_lu_plan_stage_round(ma_lu_plan_t* plan, int32_t count, const int32_t* slots, const int32_t* blocks, void* stream);
-/* Groups of slots (up to 8 slots): with group_size 2..4 the slots [k g, (k+1) g) move in lock step and share ONE panel kernel per panel
- * (a wavefront per system), while different groups sit at different block indices. Set before stage_reset; every slot of a group
- * calls stage_begin, then one stage_begin_group(first slot) starts the group's first block column; in stage_round the slots of a
- * group appear together with equal block indices. group_size 0 / 1: every slot on its own (default). */
-int ma_lu_plan_stage_set_group(ma_lu_plan_t* plan, int32_t group_size);
-int ma_lu_plan_stage_begin_group(ma_lu_plan_t* plan, int32_t first_slot, void* stream);
 int ma_lu_plan_stage_finish(ma_lu_plan_t* plan, int32_t slot, void* stream);
-/* The finish in three steps, for a driver that gives the slot its next system in other buffers (ma_bem_sweep_run): _defer right after the
- * slot's last round (the factorisation is complete on `stream`: stage_info_dev may follow; nothing is launched), _issue later (the backward
- * substitution goes onto the slot's lane behind what the lane has been given since), _wait (`stream` waits for it; x is in the system's b). */
-int ma_lu_plan_stage_finish_defer(ma_lu_plan_t* plan, int32_t slot, void* stream);
-int ma_lu_plan_stage_finish_issue(ma_lu_plan_t* plan, int32_t slot);
-int ma_lu_plan_stage_finish_wait(ma_lu_plan_t* plan, int32_t slot, void* stream);
 /* after stage_finish: the slot's status word (0, or 1 + the column of the first zero pivot) copied to a device int on `stream` */
 int ma_lu_plan_stage_info_dev(ma_lu_plan_t* plan, int32_t slot, int32_t* d_out, void* stream);
 int ma_lu_plan_status(ma_lu_plan_t* plan, void* stream);
@@ -612,16 +600,21 @@ int ma_bem_plan_probe_pairs(ma_bem_plan_t* plan, const ma_physics_t* physics, in
 int ma_bem_plan_probe_self(ma_bem_plan_t* plan, const ma_physics_t* physics, ma_c64* out5);
 int ma_bem_plan_get_near_pairs(const ma_bem_plan_t* plan, int32_t* out_pairs);
 
-/* Test hook: C <- C - A*B (row-major, tight leading dimensions, host buffers) through the f64 MFMA
- * trailing-update kernel of the LU. */
-int ma_test_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma_c64* B, ma_c64* C);
+/* C <- C - A B (row-major, tight leading dimensions, host buffers) on the f64 matrix cores: the kernel of the LU's trailing update
+ * (three real products per complex product; what zgetrf's zgemm call becomes, lu.rs:142-153 -> LAPACK). */
+int ma_zgemm_sub(int32_t M, int32_t N, int32_t K, const ma_c64* A, const ma_c64* B, ma_c64* C);
 /* Measured issue rate of v_mfma_f64_16x16x4_f64 over the whole chip, TFLOP/s (roofline peak check). */
 int ma_probe_mfma_f64(int device, double* tflops);
-/* Diagnostics (tools/panel_cotenancy.py): `repeat` launches of the trailing-update kernel on device buffers (C[M][N] -= A[M][K] B[K][N],
- * tight leading dimensions) / of the matrix-core probe (d_out: 256 * blocks doubles) on `stream`, as background load. */
-int ma_lu_plan_dump_intervals(ma_lu_plan_t* plan, int32_t phase, double* out_pairs, int32_t capacity, int32_t* count);   /* diagnostic: (start, end) ms of the timed intervals of one phase */
+int ma_lu_plan_dump_intervals(ma_lu_plan_t* plan, int32_t phase, double* out_pairs, int32_t capacity, int32_t* count);   /* measurement: (start, end) ms of the timed intervals of one phase */
+#ifdef MA_DIAGNOSTICS
+/* The DIAGNOSTIC build only (make -C math_audio_amd/csrc diag -> lib/libmathaudio_hip_diag.so, loaded by tools and by the tests that
+ * need a hook through MA_LIB_PATH): `repeat` launches of the trailing-update kernel on device buffers / of the matrix-core probe on
+ * `stream` as background load. The shipped library exports neither these nor any switch that changes a result: the diagnostic build adds
+ * MA_LU_TEST_ABORT_COL (a panel workgroup gives up a wait), MA_TEST_ALLOW_DUPLICATE_DEVICES (one GPU listed several times) and
+ * MA_TEST_SWEEP_REJECT (a frequency of a sweep is treated as rejected by the speculative panels). */
 int ma_diag_zgemm_dev(int32_t M, int32_t N, int32_t K, const void* dA, const void* dB, void* dC, int32_t repeat, void* stream);
 int ma_diag_mfma_burn(void* d_out, int32_t blocks, int32_t iters, int32_t repeat, void* stream);
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * Diagnostics used by bench.py / tests: elapsed GPU time (ms) of the tagged phases of the most

@@ -121,8 +121,6 @@ def lib():
             "ma_lu_plan_stage_begin": [vp, i32, vp, vp, i32, vp],
             "ma_lu_plan_stage_round": [vp, i32, vp, vp, vp],
             "ma_lu_plan_stage_finish": [vp, i32, vp],
-            "ma_lu_plan_stage_set_group": [vp, i32],
-            "ma_lu_plan_stage_begin_group": [vp, i32, vp],
             "ma_lu_plan_stage_info_dev": [vp, i32, vp, vp],
             "ma_lu_plan_status": [vp, vp],
             "ma_lu_plan_set_timing": [vp, C.c_int],
@@ -207,7 +205,7 @@ def lib():
             "ma_room_build_matrix_adaptive": [i32, vp, i32, vp, dbl, C.c_int, vp],
             "ma_room_incident_derivative": [i32, vp, vp, i32, vp, vp, C.c_int, dbl, vp],
             "ma_room_field_pressure": [i32, vp, vp, vp, vp, i32, vp, vp, C.c_int, i32, vp, dbl, vp],
-            "ma_test_zgemm_sub": [i32, i32, i32, vp, vp, vp],
+            "ma_zgemm_sub": [i32, i32, i32, vp, vp, vp],
             "ma_probe_mfma_f64": [C.c_int, P(dbl)],
             "ma_diag_zgemm_dev": [i32, i32, i32, vp, vp, vp, i32, vp],
             "ma_diag_mfma_burn": [vp, i32, i32, i32, vp],
@@ -500,13 +498,6 @@ class LuPlan:
         a = (C.c_int32 * m)(*slots); b = (C.c_int32 * m)(*blocks)
         check(lib().ma_lu_plan_stage_round(self.h, m, a, b, C.c_void_p(stream)))
 
-    def stage_set_group(self, group_size):
-        """Slots [k g, (k+1) g) share one panel kernel per panel (ma_lu_plan_stage_set_group); 0 = every slot on its own."""
-        check(lib().ma_lu_plan_stage_set_group(self.h, int(group_size)))
-
-    def stage_begin_group(self, first_slot, stream=0):
-        check(lib().ma_lu_plan_stage_begin_group(self.h, int(first_slot), C.c_void_p(stream)))
-
     def stage_finish(self, slot, stream=0):
         check(lib().ma_lu_plan_stage_finish(self.h, int(slot), C.c_void_p(stream)))
 
@@ -535,11 +526,11 @@ class LuPlan:
         return a.value, b.value, c.value
 
 
-def test_zgemm_sub(A, B, Cm):
-    """C - A @ B through the MFMA trailing-update kernel (test hook)."""
+def zgemm_sub(A, B, Cm):
+    """ma_zgemm_sub: C - A @ B on host arrays through the LU's trailing-update kernel (f64 matrix cores)."""
     A = np.ascontiguousarray(A, dtype=np.complex128); B = np.ascontiguousarray(B, dtype=np.complex128)
     out = np.array(Cm, dtype=np.complex128, order="C")
-    check(lib().ma_test_zgemm_sub(A.shape[0], B.shape[1], A.shape[1], _vp(A), _vp(B), _vp(out)))
+    check(lib().ma_zgemm_sub(A.shape[0], B.shape[1], A.shape[1], _vp(A), _vp(B), _vp(out)))
     return out
 
 

@@ -265,7 +265,11 @@ int amg_setup_host(const HostCsr& A, const ma_amg_config_t& cfg, std::vector<Hos
   As.push_back(A);   // (the caller's copy; level 0 is not uploaded again)
   std::vector<int64_t> sp, sj, c2f;
   std::vector<char> pt;
-  const bool timing = getenv("MA_AMG_TIMING") != nullptr;
+#ifdef MA_DIAGNOSTICS
+  const bool timing = getenv("MA_AMG_TIMING") != nullptr;    // diagnostic build only: phase times of the setup on stderr
+#else
+  const bool timing = false;
+#endif
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   for (int l = 0; l + 1 < cfg.max_levels; ++l) {

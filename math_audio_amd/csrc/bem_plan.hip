@@ -371,8 +371,8 @@ static int assemble_multi_part(ma_bem_plan_t* P, int32_t nf, const ma_physics_t*
     if ((rc = bem_launch_far_multi(P->geom, cnt, bp + f0, As, st, b0, b1 - b0))) return rc;
   }
   if (P->timing && whole) MA_HIP(hipEventRecord(P->ev[1], st));
-  // the near pairs likewise three systems per pass (round 4: the leaves and the points' geometry are the mesh's); MA_BEM_NEAR_MULTI=0: a launch per system
-  static const bool near_multi = [] { const char* e = getenv("MA_BEM_NEAR_MULTI"); return !(e && atoi(e) == 0); }();
+  // the near pairs likewise three systems per pass (round 4: the leaves and the points' geometry are the mesh's)
+  const bool near_multi = true;
   if (last && near_multi)
     for (int f0 = 0; f0 < nf; f0 += 3) {
       c64* As[3]; const int cnt = std::min(3, nf - f0);

@@ -132,9 +132,8 @@ int build_sell(ma_csr* h, const int64_t* rowptr, const int64_t* col, const ma_c6
         } else sc[q] = (int)std::min<int64_t>(r < n ? r : 0, h->ncols - 1);   // padding: zero coefficient, a column that is in cache anyway (and exists)
       }
     }
-  // columns relative to the row in 16 bits when the whole operator allows it (MA_CSR_COL16=0 keeps 32-bit columns)
+  // columns relative to the row in 16 bits when the whole operator allows it
   bool c16 = true;
-  if (const char* e16 = getenv("MA_CSR_COL16")) c16 = atoi(e16) != 0;
   std::vector<short> sc16;
   if (c16) {
     sc16.assign((size_t)tot, 0);

@@ -464,8 +464,6 @@ static bool fmm_translate_batchable(const c64* dense, int nc, int P) { return de
 // points per workgroup of the batched launch: 16 NT with NT = 2 / 5 / 8 by the sphere rule of the level that carries the most work (the
 // last one listed: the leaves): P = 72 (6 x 12 points) fits NT = 5, so D is read once per level instead of three times
 static int fmm_levels_nt(int P) {
-  static const int forced = [] { const char* e = getenv("MA_FMM_LEVELS_NT"); return e ? atoi(e) : 0; }();
-  if (forced == 2 || forced == 5 || forced == 8) return forced;
   (void)P;
   return 2;                                                  // measured: 32 points per workgroup (221 us on the 50k tree) beat 80 (249 us): more workgroups, the D rows come from L2
 }
@@ -945,15 +943,12 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
   int G = 8; while (G < 64 && G < avg) G <<= 1;
   if (S->d_part) {
     const dc* bv = reinterpret_cast<const dc*>(S->d_bval); dc* part = reinterpret_cast<dc*>(S->d_part);
-    // beside the far chain (pass 1 on the second stream) the grid MAY be capped at MA_FMM_NEAR_WGS_PER_CU workgroups per CU (measured:
-    // every cap from 1 to 8 loses -- the near pass slows by more than the far chain gains; uncapped by default)
-    static const int cap_per_cu = [] { const char* e = getenv("MA_FMM_NEAR_WGS_PER_CU"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
-    const unsigned cap = (pass == 1 && cap_per_cu > 0) ? (unsigned)(256 * cap_per_cu) : 0xFFFFFFFFu;
-    auto grid = [&](long long want) { return dim3((unsigned)std::min<long long>(want, (long long)cap)); };
+    // (round 4 measured a cap on the grid beside the far chain: every cap from 1 to 8 workgroups per CU loses -- profiles/r04_fmm_apply.md)
+    auto grid = [&](long long want) { return dim3((unsigned)want); };
     if (pass == 2) { /* second pass only */ }
     else if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, grid((S->nblocks + 3) / 4), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
                                                    S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
-    else if (S->max_width <= 64 * FMM_NCH && !getenv("MA_FMM_WIDE_BLOCKS_OFF")) {
+    else if (S->max_width <= 64 * FMM_NCH) {
       if (S->max_width <= 128) hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<2>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
                                                   S->d_bcoff, S->nblocks, bv, x, part, tmode);
       else if (S->max_width <= 256) hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<4>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
@@ -1052,7 +1047,11 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
     for (int q = cl->near_ptr[c]; q < cl->near_ptr[c + 1]; ++q) MA_REQUIRE(cl->near_idx && cl->near_idx[q] >= 0 && cl->near_idx[q] < nc, MA_ERR_INVALID, "near cluster index out of range");
     for (int q = cl->far_ptr[c]; q < cl->far_ptr[c + 1]; ++q) MA_REQUIRE(cl->far_idx && cl->far_idx[q] >= 0 && cl->far_idx[q] < nc, MA_ERR_INVALID, "far cluster index out of range");
   }
-  const bool timing = getenv("MA_FMM_TIMING") != nullptr;
+#ifdef MA_DIAGNOSTICS
+  const bool timing = getenv("MA_FMM_TIMING") != nullptr;    // diagnostic build only: phase times of the setup on stderr
+#else
+  const bool timing = false;
+#endif
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto tt0 = tnow();
@@ -1222,7 +1221,7 @@ static bool slfmm_overlap_ready(ma_slfmm* S) {
       // kernels waiting for slots (the first upward-pass kernel took 350 us instead of 15 beside them)
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      { const char* ep = getenv("MA_FMM_NEAR_PRIO"); if (!(ep && atoi(ep) < 0)) lo = 0; }   // normal priority unless asked (-1: lowest)
+      lo = 0;                                               // normal priority (the lowest was measured worse: r04_fmm_apply.md)
       bool ok = hipStreamCreateWithPriority(&S->st2, hipStreamNonBlocking, lo) == hipSuccess && hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&S->ev_near, hipEventDisableTiming) == hipSuccess && hipMalloc(&S->d_yfar, sizeof(c64) * (size_t)S->n) == hipSuccess;
       if (ok) S->overlap_streams = 1; else (void)hipGetLastError();
@@ -1676,8 +1675,8 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     hipLaunchKernelGGL(mlfmm_m2m_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, Mc, reinterpret_cast<dc*>(L.d_M));
     MA_HIP(hipGetLastError());
   }
-  // translation at every level: the levels whose dense D takes the small-tile kernel travel in ONE launch (MA_FMM_BATCH_LEVELS=0: a launch per level)
-  static const bool batch_levels = [] { const char* e = getenv("MA_FMM_BATCH_LEVELS"); return !(e && atoi(e) == 0); }();
+  // translation at every level: the levels whose dense D takes the small-tile kernel travel in ONE launch
+  const bool batch_levels = true;
   FmmLevels V; V.nl = 0; V.first[0] = 0;
   const int nt = fmm_levels_nt(F->P);
   auto add_or_launch = [&](const int* fptr, const int* foth, const c64* fval, const c64* dense, int nc, int P, const c64* up, c64* tr) -> int {

@@ -29,348 +29,6 @@ namespace ma {
 // better (value, row) candidate: larger value, ties -> lower row (izamax takes the first maximum)
 __device__ __forceinline__ bool cand_better(double v, int r, double bv, int br) { return v > bv || (v == bv && r < br); }
 
-// ------------------------------------------------------------------ panel factorisation
-// Dynamic LDS: P[rpb][nb+1] | urow[2][nb] | drow[nb] | small scalars.
-// Per column c every workgroup publishes its best pivot candidate (value, row, the row's nb panel
-// entries) and, if it owns it, the current diagonal row; the granules are gathered in two levels (a leader per group of
-// <= 32 workgroups reduces its group, every workgroup sweeps the 8 group granules), all reduce to the same pivot and fetch its
-// row. Wavefront 0 carries this chain; wavefronts 1-3 do the bulk of the rank-1 update. The candidate of
-// column c+1 is published BEFORE the bulk of step c's rank-1 update: only column c+1 is brought up to date first, the
-// rows go out as they stand and the receivers finish step c's update on the one row they fetch. The chip-wide wait
-// therefore overlaps the local update, and nothing but the scan of column c+1 sits between a pivot and the next publish.
-struct PanelCand { double v; int row; };
-
-__device__ __forceinline__ PanelCand wave_best(PanelCand c) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double ov = __shfl_xor(c.v, off, 64); int orow = __shfl_xor(c.row, off, 64);
-    if (cand_better(ov, orow, c.v, c.row)) { c.v = ov; c.row = orow; }
-  }
-  return c;
-}
-
-__global__ __launch_bounds__(256, 1) void lu_panel_kernel(dc* __restrict__ A, int n, int k0, int nb, int rpb, LuPanelWs ws,
-                                                          int* __restrict__ ipiv) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int pitch = nb + 1;
-  dc* P = reinterpret_cast<dc*>(smem);
-  dc* urow_a = P + (size_t)rpb * pitch;                  // pivot rows of the current and the previous column (ping-pong)
-  dc* urow_b = urow_a + nb;
-  dc* drow = urow_b + nb;
-  double* s_wv = reinterpret_cast<double*>(drow + nb);   // [4] wave maxima
-  int* s_wr = reinterpret_cast<int*>(s_wv + 4);          // [4] rows
-  int* s_misc = s_wr + 4;                                // [0] best row, [3] fail
-  double* s_bestv = reinterpret_cast<double*>(s_misc + 4);
-
-  // The panel is a chain of short, latency-critical steps; when it shares a CU with throughput-bound
-  // wavefronts (another frequency's trailing update) its instructions should issue first.
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x, nblk = gridDim.x;
-  const int r0 = k0 + b * rpb;
-  const int nrows = min(rpb, n - r0);
-  const int myrow = r0 + tid;                            // thread-per-row phases
-
-  for (int idx = tid; idx < nrows * nb; idx += 256) {
-    int rr = idx / nb, j = idx - rr * nb;
-    P[rr * pitch + j] = A[(size_t)(r0 + rr) * n + k0 + j];
-  }
-  if (tid == 0) { s_misc[3] = 0; s_misc[2] = (int)__hip_atomic_load(ws.timeout, RLX_AGENT); }
-  __syncthreads();
-  // A plan whose earlier panel was aborted (exchange timed out, see below) is poisoned: every later panel kernel leaves at
-  // once and records identity pivots, so that nothing downstream ever sees an unwritten pivot. Workgroups that miss the
-  // flag here meet it in their first sweep.
-  if (s_misc[2] != 0) {
-    if (b == 0) for (int j = tid; j < nb; j += 256) ipiv[k0 + j] = k0 + j;
-    return;
-  }
-
-  // local candidate of column `col` among rows >= k0+col -> s_bestv[0], s_misc[0] (after the barriers)
-  auto scan_column = [&](int col) {
-    PanelCand cd; cd.v = -1.0; cd.row = INT_MAX;
-    if (nrows <= 64) {                                   // one wavefront sees every row: no cross-wave step
-      if (wave == 0) {
-        if (tid < nrows && myrow >= k0 + col) { cd.v = cabs1(P[tid * pitch + col]); cd.row = myrow; }
-        cd = wave_best(cd);
-        if (lane == 0) { s_bestv[0] = cd.v; s_misc[0] = cd.row; }
-      }
-      __syncthreads();
-      return;
-    }
-    if (tid < nrows && myrow >= k0 + col) { cd.v = cabs1(P[tid * pitch + col]); cd.row = myrow; }
-    cd = wave_best(cd);
-    if (lane == 0) { s_wv[wave] = cd.v; s_wr[wave] = cd.row; }
-    __syncthreads();
-    if (tid == 0) {
-      double v = s_wv[0]; int row = s_wr[0];
-      for (int w = 1; w < 4; ++w) if (cand_better(s_wv[w], s_wr[w], v, row)) { v = s_wv[w]; row = s_wr[w]; }
-      s_bestv[0] = v; s_misc[0] = row;
-    }
-    __syncthreads();
-  };
-  // publish the candidate (and the diagonal row, if owned) of column `col`. The 8-byte granule
-  // {high 32 bits of |re|+|im|, tag = col+1, row} is both the data and the flag: it is stored last,
-  // after every wave has drained the row payload (write-through stores), by ONE lane.
-  // Pivot selection therefore compares magnitudes to 21 significant bits (exponent + 20 mantissa
-  // bits); ties go to the lower row. The pivot is within 1e-6 relative of the column maximum.
-  auto publish = [&](int col) {
-    const int buf = col & 1;
-    const double bv = s_bestv[0]; const int br = s_misc[0];
-    const int gd = k0 + col;
-    const bool own_diag = gd >= r0 && gd < r0 + nrows;
-    // Wavefront 0 alone publishes (a row of <= 128 columns is 4 doubles per lane): it reads the rows from LDS, releases
-    // the other wavefronts to the bulk update with one barrier, and only then waits for its write-through stores.
-    double cv[4], dv[4];
-    if (wave == 0) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = lane + 64 * u;
-        cv[u] = (br != INT_MAX && t < 2 * nb) ? reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch)[t] : 0.0;
-        dv[u] = (own_diag && t < 2 * nb) ? reinterpret_cast<const double*>(P + (size_t)(gd - r0) * pitch)[t] : 0.0;
-      }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    if (br != INT_MAX) {
-      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (lane + 64 * u < 2 * nb) st_sc1(dst + lane + 64 * u, cv[u]);
-    }
-    if (own_diag) {
-      u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) if (lane + 64 * u < 2 * nb) st_sc1(dst + lane + 64 * u, dv[u]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the payload is out before the granule says so
-    if (lane == 0) {
-      const u64 hi = br != INT_MAX ? ((u64)__double_as_longlong(bv) >> 32) : 0ull;
-      const u64 lo = ((u64)(unsigned)(col + 1) << 24) | (u64)(br != INT_MAX ? (unsigned)br : 0xFFFFFFu);
-      __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE, (hi << 32) | lo, RLX_AGENT);
-    }
-  };
-
-  // group leader (the group's last member), wavefront 0: gather the group's granules of column `col` and publish the group's
-  // granule. Runs right after the leader's own publish, in place of its share of the bulk update: every workgroup waits for it.
-  const int g_ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
-  const int g_grp = b % g_ngrp;
-  const int g_per = (nblk - g_grp + g_ngrp - 1) / g_ngrp;  // members g_grp, g_grp + g_ngrp, ...
-  const bool lead = b == g_grp + (g_per - 1) * g_ngrp;
-  auto leader_gather = [&](int col) {
-    const int buf = col & 1;
-    const unsigned want = (unsigned)(col + 1);
-    const u64 t0 = __builtin_amdgcn_s_memrealtime();
-    const u64* mbase = ws.cand + ((size_t)buf * ws.max_blocks + g_grp) * LU_GRANULE_STRIDE;
-    unsigned bhi = 0, brow = 0xFFFFFFu; bool fail = false;
-    for (;;) {
-      bool ok = true; bhi = 0; brow = 0xFFFFFFu;
-      unsigned ab = 0u;
-      if (lane < g_per) {
-        const u64 g = __hip_atomic_load(mbase + (size_t)lane * g_ngrp * LU_GRANULE_STRIDE, RLX_AGENT);
-        ok = ((unsigned)(g >> 24) & 0xFFu) == want;
-        bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
-      } else if (lane == 63) ab = __hip_atomic_load(ws.timeout, RLX_AGENT);          // the plan's abort flag rides along
-      if (__all(ok)) break;
-      if (__any(ab != 0u)) { fail = true; break; }
-      __builtin_amdgcn_s_sleep(1);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }   // 4 s at 100 MHz: never hang (the sweep below reports it)
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
-      if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
-    }
-    if (lane == 0 && !fail)
-      __hip_atomic_store(ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS + g_grp) * LU_GRANULE_STRIDE,
-                         ((u64)bhi << 32) | ((u64)want << 24) | (u64)brow, RLX_AGENT);
-  };
-
-  scan_column(0);
-  publish(0);
-  if (lead && wave == 0) leader_gather(0);
-#ifdef MA_PANEL_STAMPS
-  u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  u64 stamp_t = __builtin_amdgcn_s_memrealtime();
-#define MA_STAMP(i) do { if (tid == 0) { u64 now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
-#else
-#define MA_STAMP(i) do { } while (0)
-#endif
-
-  bool pending = false;                                  // the previous column's rank-1 update is missing from the published rows
-  for (int c = 0; c < nb; ++c) {
-    const int gc = k0 + c;
-    const int buf = c & 1;
-    // ---- wavefront 0 sweeps every workgroup's granule until all carry this column's tag, and
-    // reduces them on the way (the data is the flag: no counter, no second round trip)
-    // ---- two-level gather of the candidates: workgroup b belongs to group b % 8 (its XCD under the round-robin placement);
-    // the group's last member gathers the group's <= 32 granules and publishes the group's granule, every workgroup
-    // sweeps only the 8 group granules (128 B apart). The leader's wavefront 0 starts its sweep right after publishing
-    // (it takes no part in the bulk update, see below): the group result is on the critical path of every workgroup.
-    if (wave == 0) {
-      const unsigned want = (unsigned)(c + 1);
-      const u64 t0 = __builtin_amdgcn_s_memrealtime();
-      const int ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
-      bool fail = false;
-      unsigned bhi = 0, brow = 0xFFFFFFu;
-      const u64* gbase = ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS) * LU_GRANULE_STRIDE;
-      if (gc == ws.test_abort_col && b == nblk - 1) fail = true;   // test hook: this workgroup behaves as if its wait had expired
-      while (!fail) {
-        bool ok = true; bhi = 0; brow = 0xFFFFFFu;
-        unsigned ab = 0u;
-        if (lane < ngrp) {
-          const u64 g = __hip_atomic_load(gbase + (size_t)lane * LU_GRANULE_STRIDE, RLX_AGENT);
-          ok = ((unsigned)(g >> 24) & 0xFFu) == want;
-          bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
-        } else if (lane == 63) ab = __hip_atomic_load(ws.timeout, RLX_AGENT);        // another workgroup (or system of the plan) gave up
-        if (__all(ok)) break;
-        if (__any(ab != 0u)) { fail = true; break; }
-        __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;
-      }
-#pragma unroll
-      for (int off = 4; off > 0; off >>= 1) {
-        const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
-        if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
-      }
-      if (lane == 0) {
-        u64 best = brow; int bblk;
-        if (fail) { __hip_atomic_store(ws.timeout, 1u, RLX_AGENT); s_misc[3] = 1; }
-        if (fail || best >= (u64)n || best < (u64)gc) { best = (u64)gc; bblk = -1; if (!fail && b == 0) atomicCAS(ws.info, 0, gc + 1); }
-        else bblk = ((int)best - k0) / rpb;              // rows are dealt to the workgroups in runs of rpb
-        s_misc[1] = (int)best; s_misc[2] = bblk;
-      }
-    }
-    __syncthreads();
-#ifdef MA_PANEL_STAMPS
-    if (c == 0 && tid == 0) stamp_acc[7] += __builtin_amdgcn_s_memrealtime() - stamp_t;   // residency wait: first column only
-#endif
-    MA_STAMP(0);
-    if (s_misc[3]) {                                     // uniform: the whole workgroup leaves; the columns it did not reach get
-      if (b == 0) for (int j = c + tid; j < nb; j += 256) ipiv[k0 + j] = k0 + j;   // identity pivots (the plan is poisoned: MA_ERR_HIP)
-      return;
-    }
-    const int p = s_misc[1], wb = s_misc[2];
-    MA_STAMP(1);
-    // ---- fetch the pivot row (and the displaced diagonal row) with sc1 loads. Rows are published as they stood BEFORE
-    // the bulk of the previous column's rank-1 update (publish() below), so the receiver finishes that update itself:
-    // row[j] -= row[c-1] * u_{c-1}[j] for j > c, with the previous pivot row still in LDS. Every workgroup does the
-    // same arithmetic on the same data, so all hold the same pivot row.
-    dc* urow = (c & 1) ? urow_b : urow_a;
-    const dc* uprev = (c & 1) ? urow_a : urow_b;
-    {
-      // wb < 0 (no candidate anywhere): the diagonal row stands in as the pivot row
-      const u64* src = wb >= 0 ? ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX) : ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      const u64* s2 = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      for (int j = tid; j < nb; j += 256) {
-        dc v = dc_make(ld_sc1(src + 2 * j), ld_sc1(src + 2 * j + 1));
-        dc d = dc_make(0.0, 0.0);
-        if (p != gc) d = dc_make(ld_sc1(s2 + 2 * j), ld_sc1(s2 + 2 * j + 1));
-        if (pending && j > c) {
-          const dc u = uprev[j];
-          const dc lv = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
-          v.re -= lv.re * u.re - lv.im * u.im; v.im -= lv.re * u.im + lv.im * u.re;
-          if (p != gc) {
-            const dc ld = dc_make(ld_sc1(s2 + 2 * (c - 1)), ld_sc1(s2 + 2 * (c - 1) + 1));
-            d.re -= ld.re * u.re - ld.im * u.im; d.im -= ld.re * u.im + ld.im * u.re;
-          }
-        }
-        urow[j] = v;
-        if (p != gc) drow[j] = d;
-      }
-    }
-    __syncthreads();
-    MA_STAMP(2);
-    // ---- interchange inside the panel
-    if (p != gc && p >= r0 && p < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(p - r0) * pitch + t] = drow[t];
-    // the diagonal slot always takes the pivot row as every workgroup holds it (also when p == gc: the owner's own copy went
-    // through the bulk update, the shared one through the receivers' completion above -- keep the one that was used)
-    if (gc >= r0 && gc < r0 + nrows) for (int t = tid; t < nb; t += 256) P[(size_t)(gc - r0) * pitch + t] = urow[t];
-    if (b == 0 && tid == 0) ipiv[gc] = p;
-    const dc piv = urow[c];
-    // lu.rs:106-110: a pivot column whose largest |z| is below 1e-30 is LuError::SingularMatrix (an exact zero is zgetf2's
-    // INFO); the elimination of that column is skipped either way
-    const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
-    if (singular && b == 0 && tid == 0) atomicCAS(ws.info, 0, gc + 1);   // first such pivot, 1-based
-    __syncthreads();
-    // ---- multipliers l = a / pivot (reciprocal scaling, zgetf2) and the update of column c+1 only
-    const bool more = c + 1 < nb;
-    dc anext = dc_make(0.0, 0.0);                        // this thread's row, column c+1, after the update
-    if (tid < nrows && myrow > gc) {
-      if (more) anext = P[tid * pitch + c + 1];
-      if (!singular) {
-        const dc l = P[tid * pitch + c] * crecip(piv);
-        P[tid * pitch + c] = l;
-        if (more) {
-          const dc u = urow[c + 1];
-          anext.re -= l.re * u.re - l.im * u.im; anext.im -= l.re * u.im + l.im * u.re;
-          P[tid * pitch + c + 1] = anext;
-        }
-      }
-    }
-    MA_STAMP(3);
-    if (more) {
-      if (nrows <= 64) {
-        // one wavefront holds every row: the next column's candidate straight from the registers. Magnitudes compare on
-        // their top 32 bits (what the granule carries anyway), ties go to the lowest row = lowest lane.
-        if (wave == 0) {
-          const double mag = cabs1(anext);
-          const bool valid = tid < nrows && myrow > gc && mag == mag;      // a NaN is never offered (as in scan_column)
-          const unsigned hi = valid ? (unsigned)((u64)__double_as_longlong(mag) >> 32) : 0u;
-          const unsigned m = wave_umax(hi);
-          const u64 mask = __ballot(valid && hi == m);
-          if (lane == 0) {
-            s_misc[0] = mask ? r0 + (int)__builtin_ctzll(mask) : INT_MAX;
-            s_bestv[0] = __longlong_as_double((long long)((u64)m << 32));
-          }
-        }
-        __syncthreads();
-      } else {
-        scan_column(c + 1);
-      }
-      MA_STAMP(4);
-      publish(c + 1);
-      MA_STAMP(5);
-      if (lead && wave == 0) leader_gather(c + 1);
-    }
-    // ---- bulk rank-1 update (overlaps the other workgroups' arrival): lane = row (the row pitch of
-    // nb+1 complex spreads the lanes over all LDS banks); each wavefront takes every 4th group of 4
-    // columns, loads the group before touching it so the LDS latency is paid once per group
-    const int bwn = 3, bw = wave - 1;                    // wavefront 0 is busy publishing (and, in a leader, gathering)
-    if (!singular && more && bw >= 0) {
-      for (int rbase = 0; rbase < nrows; rbase += 64) {
-        const int rr = rbase + lane;
-        const int gr = r0 + rr;
-        const bool on = rr < nrows && gr > gc;
-        const dc l = on ? P[rr * pitch + c] : dc_make(0.0, 0.0);
-        dc* Pr = P + (size_t)(on ? rr : 0) * pitch;
-        for (int j0 = c + 2 + 4 * bw; j0 < nb; j0 += 4 * bwn) {
-          dc u[4], a[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { const int j = min(j0 + q, nb - 1); u[q] = urow[j]; a[q] = Pr[j]; }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { a[q].re -= l.re * u[q].re - l.im * u[q].im; a[q].im -= l.re * u[q].im + l.im * u[q].re; }
-          if (on) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (j0 + q < nb) Pr[j0 + q] = a[q];
-          }
-        }
-      }
-    }
-    pending = !singular && more;
-    // LDS-only barrier: the granule store of publish() may still be in flight (write-through ack ~1 us)
-    // and nothing in the next column depends on it, so do not drain the vector-memory counter here.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    MA_STAMP(6);
-  }
-#ifdef MA_PANEL_STAMPS
-  if (tid == 0 && b == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, stamp_acc[i]);
-#endif
-  for (int idx = tid; idx < nrows * nb; idx += 256) {
-    int rr = idx / nb, j = idx - rr * nb;
-    A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
-  }
-}
-
 // ------------------------------------------------------------------ panel factorisation with the rows in registers (round 3)
 // lane = row: a thread keeps its row's NB panel entries in registers for the whole panel (4 NB vector registers), the column
 // loop is unrolled so that every register index is static, and a workgroup of 256 threads holds 256 rows: a 10 000-row panel
@@ -423,14 +81,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (b == 0) for (int j = tid; j < nbc; j += 256) ipiv[k0 + j] = k0 + j;
     return;
   }
-#ifdef MA_PANEL_STAMPS
-  // diagnostic build: [0] sender wave: B1 -> granule stored (ticks), [1] sender count, [2] wave 0: B1 -> sweep starts, [3] sweep time,
-  // [4] sweeps, [5] wave 0: B2 -> B1 of the next column, [6] columns x workgroups, [7] sender: B1 -> row stores issued
-  u64 stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  u64 stamp_b1 = __builtin_amdgcn_s_memrealtime(), stamp_b2 = stamp_b1;
-#define MA_NOW() __builtin_amdgcn_s_memrealtime()
-#endif
-#define MA_RSTAMP(i) do { } while (0)
   // this wavefront's candidate of column c: top 32 bits of |re| + |im|, ties to the lowest position
   auto candidate = [&](dc v) {
     const double mag = cabs1(v);
@@ -461,9 +111,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       if (pw != NONE && (bpos == NONE || mw > bmax || (mw == bmax && pw < bpos))) { bmax = mw; bpos = pw; bw = w; }
     }
     const bool sender = wave == bw;
-#ifdef MA_PANEL_STAMPS
-    stamp_b1 = MA_NOW();
-#endif
     if (sender && bpos != NONE) {
       // one lane's row through LDS to 32 lanes: two coalesced write-through stores instead of 64 single-lane ones (each of those
       // is a fabric write of its own: 2.0 us until every workgroup's granule was seen against 1.66 with the staging)
@@ -475,11 +122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX) + 2 * lane;
         st_sc1(dst, v.re); st_sc1(dst + 1, v.im);
       }
-#ifdef MA_PANEL_STAMPS
-      if (lane == 0) stamp_acc[7] += MA_NOW() - stamp_b1;
-#endif
     }
-    MA_RSTAMP(0);
     // ---- the bulk of the previous column's rank-1 update, on registers; it overlaps the write-through of the row above
     if constexpr (c > 0) {
       if (upd_pending) {
@@ -499,18 +142,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       if (lane == 0)
         __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE,
                            ((u64)(bpos != NONE ? bmax : 0u) << 32) | ((u64)want << 24) | (u64)bpos, RLX_AGENT);
-#ifdef MA_PANEL_STAMPS
-      if (lane == 0) { stamp_acc[0] += MA_NOW() - stamp_b1; stamp_acc[1] += 1; }
-#endif
     }
     // ---- wavefront 0: sweep every workgroup's granule until all carry this column's tag, reduce, fetch the winner's row
     if (wave == 0) {
-      for (int q = 0; q < ws.diag_sleep; ++q) __builtin_amdgcn_s_sleep(8);   // diagnostic only (0 in production): 512 cycles each
       const u64 t0 = __builtin_amdgcn_s_memrealtime();
-#ifdef MA_PANEL_STAMPS
-      if (lane == 0) { stamp_acc[2] += t0 - stamp_b1; stamp_acc[6] += 1; }
+#ifdef MA_DIAGNOSTICS
+      bool fail = gc == ws.test_abort_col && b == G - 1;   // diagnostic build only: this workgroup behaves as if its wait had expired
+#else
+      bool fail = false;
 #endif
-      bool fail = gc == ws.test_abort_col && b == G - 1;   // test hook: this workgroup behaves as if its wait had expired
       unsigned bhi = 0, bps = NONE; int bblk = -1;
       const u64* gbase = ws.cand + (size_t)buf * ws.max_blocks * LU_GRANULE_STRIDE;
       // The row of the best candidate SO FAR is fetched while the sweep is still waiting for the other workgroups (a granule that
@@ -543,18 +183,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const u64 wm = __ballot(pk == p && p != NONE);
         wb = wm ? __shfl(bblk, (int)__builtin_ctzll(wm), 64) : -1;
         const bool all = __all(ok);
-#ifdef MA_PANEL_STAMPS
-        if (lane == 0) stamp_acc[4] += 1;
-#endif
         if (wb >= 0 && wb != hb) fetch_row(wb);
         if (all) break;
         if (ab != 0u) { fail = true; break; }
         __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;   // 4 s at 100 MHz: never hang
       }
-#ifdef MA_PANEL_STAMPS
-      if (lane == 0) stamp_acc[3] += MA_NOW() - t0;
-#endif
       if (!fail) {
         dc v = dc_make(0.0, 0.0);                        // no candidate anywhere: a zero pivot row, the column is skipped as singular
         if (wb >= 0) {
@@ -577,9 +211,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       }
     }
     __syncthreads();                                     // B2(c): pivot row and position of column c are in LDS
-#ifdef MA_PANEL_STAMPS
-    stamp_b2 = MA_NOW();
-#endif
     if (s_misc[1]) {                                     // uniform: the whole workgroup gives up; the columns it did not reach get
       if (b == 0) for (int j = c + tid; j < nbc; j += 256) ipiv[k0 + j] = k0 + j;   // identity pivots (the plan is poisoned: MA_ERR_HIP)
       dead = true;
@@ -610,9 +241,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       if (c + 1 < nbc) {
         candidate(a[c + 1]);
         __syncthreads();                                 // B1(c + 1)
-#ifdef MA_PANEL_STAMPS
-        if (tid == 0) stamp_acc[5] += MA_NOW() - stamp_b2;
-#endif
       }
     }
     }
@@ -634,272 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       static_for<0, NB>([&](auto jc) { constexpr int j = decltype(jc)::value; ldst[j] = lsrc[j]; });
     }
   }
-#ifdef MA_PANEL_STAMPS
-  if (lane == 0) for (int i = 0; i < 8; ++i) if (stamp_acc[i]) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, stamp_acc[i]);
-#endif
 }
-
-// ------------------------------------------------------------------ panel factorisation of several systems, a wavefront each
-// The systems of a lock-step batch (frequencies of a sweep: same n, same panel) share ONE co-resident grid. A first form walked
-// the systems one after the other inside the workgroup (all four wavefronts on one system's column step, then the next system):
-// measured, it LOSES (0.63 ms per 32 columns of three systems = 6.6 us per system column against 5.8 alone; 99.9 ms per
-// frequency against 63.1 with a panel kernel per system) -- with the exchange hidden, the bulk rank-1 update that the
-// single-system kernel tucks under the exchange wait lands on the critical path of every step, and the steps' own memory
-// round trips (pivot-row fetch, write-through publish) are paid system after system.
-// Here every system of the batch has its OWN wavefront in the workgroup (<= 64 rows per workgroup: lane = row): the wavefront
-// runs the whole column step for its system -- poll, fetch, interchange, multipliers, next candidate, publish, rank-1 update
-// -- with no workgroup barrier anywhere, so the systems' chains advance independently and their latencies overlap on the
-// CU's SIMDs; one co-resident grid instead of nsys grids that slow each other down, and the per-system arithmetic (and
-// therefore every pivot, factor and solution) is the single-system kernel's at the same panel width.
-struct LuPanelBatch { int nsys; dc* A[LU_BATCH_MAX]; int* ipiv[LU_BATCH_MAX]; LuPanelWs ws[LU_BATCH_MAX]; };
-
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__global__ __launch_bounds__(256, 1) void lu_panel_wave_kernel(LuPanelBatch B, int n, int k0, int nb, int rpb, unsigned sys_lds) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int pitch = nb + 1;
-  __builtin_amdgcn_s_setprio(3);
-  const int lane = threadIdx.x & 63;
-  const int sy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // this wavefront's system
-  const int b = blockIdx.x, nblk = gridDim.x;
-  const int r0 = k0 + b * rpb;
-  const int nrows = min(rpb, n - r0);                    // <= 64: lane = row
-  const int myrow = r0 + lane;
-  const int g_ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
-  const int g_grp = b % g_ngrp;
-  const int g_per = (nblk - g_grp + g_ngrp - 1) / g_ngrp;
-  const bool lead = b == g_grp + (g_per - 1) * g_ngrp;
-  const LuPanelWs ws = B.ws[sy];
-  dc* __restrict__ A = B.A[sy];
-  int* __restrict__ ipiv = B.ipiv[sy];
-  unsigned* const poison = ws.timeout;
-
-  dc* const P = reinterpret_cast<dc*>(smem + (size_t)sy * sys_lds);
-  dc* const urow_a = P + (size_t)rpb * pitch;
-  dc* const urow_b = urow_a + nb;
-  dc* const drow = urow_b + nb;
-
-  for (int idx = lane; idx < nrows * nb; idx += 64) {
-    int rr = idx / nb, j = idx - rr * nb;
-    P[rr * pitch + j] = A[(size_t)(r0 + rr) * n + k0 + j];
-  }
-  if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(poison, RLX_AGENT)) != 0) {
-    if (b == 0) for (int j = lane; j < nb; j += 64) ipiv[k0 + j] = k0 + j;
-    return;
-  }
-  wave_sync_lds();
-
-  // candidate of a column from a per-lane magnitude: top 32 bits compared, ties to the lowest row (= lowest lane)
-  auto pick = [=](bool valid, double mag, int* row_out, double* val_out) {
-    const unsigned hi = valid ? (unsigned)((u64)__double_as_longlong(mag) >> 32) : 0u;
-    const unsigned m = wave_umax(hi);
-    const u64 mask = __ballot(valid && hi == m);
-    *row_out = mask ? r0 + (int)__builtin_ctzll(mask) : INT_MAX;
-    *val_out = __longlong_as_double((long long)((u64)m << 32));
-  };
-  auto publish = [&](int col, int br, double bv) {
-    const int buf = col & 1;
-    const int gd = k0 + col;
-    const bool own_diag = gd >= r0 && gd < r0 + nrows;
-    if (br != INT_MAX) {
-      const double* src = reinterpret_cast<const double*>(P + (size_t)(br - r0) * pitch);
-      u64* dst = ws.candrow + ((size_t)buf * ws.max_blocks + b) * (2 * LU_NB_MAX);
-      for (int t = lane; t < 2 * nb; t += 64) st_sc1(dst + t, src[t]);
-    }
-    if (own_diag) {
-      const double* src = reinterpret_cast<const double*>(P + (size_t)(gd - r0) * pitch);
-      u64* dst = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      for (int t = lane; t < 2 * nb; t += 64) st_sc1(dst + t, src[t]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the payload is out before the granule says so
-    if (lane == 0) {
-      const u64 hi = br != INT_MAX ? ((u64)__double_as_longlong(bv) >> 32) : 0ull;
-      const u64 lo = ((u64)(unsigned)(col + 1) << 24) | (u64)(br != INT_MAX ? (unsigned)br : 0xFFFFFFu);
-      __hip_atomic_store(ws.cand + ((size_t)buf * ws.max_blocks + b) * LU_GRANULE_STRIDE, (hi << 32) | lo, RLX_AGENT);
-    }
-  };
-  auto leader_gather = [&](int col) {
-    const int buf = col & 1;
-    const unsigned want = (unsigned)(col + 1);
-    const u64 t0 = __builtin_amdgcn_s_memrealtime();
-    const u64* mbase = ws.cand + ((size_t)buf * ws.max_blocks + g_grp) * LU_GRANULE_STRIDE;
-    unsigned bhi = 0, brow = 0xFFFFFFu; bool fail = false;
-    for (;;) {
-      bool ok = true; bhi = 0; brow = 0xFFFFFFu;
-      unsigned ab = 0u;
-      if (lane < g_per) {
-        const u64 g = __hip_atomic_load(mbase + (size_t)lane * g_ngrp * LU_GRANULE_STRIDE, RLX_AGENT);
-        ok = ((unsigned)(g >> 24) & 0xFFu) == want;
-        bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
-      } else if (lane == 63) ab = __hip_atomic_load(poison, RLX_AGENT);
-      if (__all(ok)) break;
-      if (__any(ab != 0u)) { fail = true; break; }
-      __builtin_amdgcn_s_sleep(1);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { fail = true; break; }
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-      const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
-      if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
-    }
-    if (lane == 0 && !fail)
-      __hip_atomic_store(ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS + g_grp) * LU_GRANULE_STRIDE,
-                         ((u64)bhi << 32) | ((u64)want << 24) | (u64)brow, RLX_AGENT);
-  };
-
-  {
-    int br; double bv;
-    // column 0: the full-magnitude comparison of lu_panel_kernel's scan_column (cand_better), lowest row on ties
-    PanelCand cd; cd.v = -1.0; cd.row = INT_MAX;
-    if (lane < nrows && myrow >= k0) { cd.v = cabs1(P[lane * pitch]); cd.row = myrow; }
-    cd = wave_best(cd);
-    br = __builtin_amdgcn_readfirstlane(cd.row); bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(cd.v)), __builtin_amdgcn_readfirstlane(__double2loint(cd.v)));
-    publish(0, br, bv);
-    if (lead) leader_gather(0);
-  }
-
-#ifdef MA_PANEL_STAMPS
-  u64 wst_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  u64 wst_t = __builtin_amdgcn_s_memrealtime();
-#define MA_WSTAMP(i) do { if (b == 0 && sy == 0) { u64 now_ = __builtin_amdgcn_s_memrealtime(); wst_acc[i] += now_ - wst_t; wst_t = now_; } } while (0)
-#else
-#define MA_WSTAMP(i) do { } while (0)
-#endif
-  bool pending = false;
-  for (int c = 0; c < nb; ++c) {
-    const int gc = k0 + c;
-    const int buf = c & 1;
-    int p, wb; bool fail = false;
-    {
-      const unsigned want = (unsigned)(c + 1);
-      const u64 t0 = __builtin_amdgcn_s_memrealtime();
-      const int ngrp = nblk < LU_GROUPS ? nblk : LU_GROUPS;
-      unsigned bhi = 0, brow = 0xFFFFFFu;
-      const u64* gbase = ws.cand + ((size_t)2 * ws.max_blocks + (size_t)buf * LU_GROUPS) * LU_GRANULE_STRIDE;
-      if (gc == ws.test_abort_col && b == nblk - 1 && sy == B.nsys - 1) fail = true;
-      while (!fail) {
-        bool ok = true; bhi = 0; brow = 0xFFFFFFu;
-        unsigned ab = 0u;
-        if (lane < ngrp) {
-          const u64 g = __hip_atomic_load(gbase + (size_t)lane * LU_GRANULE_STRIDE, RLX_AGENT);
-          ok = ((unsigned)(g >> 24) & 0xFFu) == want;
-          bhi = (unsigned)(g >> 32); brow = (unsigned)g & 0xFFFFFFu;
-        } else if (lane == 63) ab = __hip_atomic_load(poison, RLX_AGENT);
-        if (__all(ok)) break;
-        if (__any(ab != 0u)) { fail = true; break; }
-        __builtin_amdgcn_s_sleep(LU_POLL_SLEEP);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) fail = true;
-      }
-#pragma unroll
-      for (int off = 4; off > 0; off >>= 1) {
-        const unsigned ohi = __shfl_xor(bhi, off, 64), orow = __shfl_xor(brow, off, 64);
-        if (ohi > bhi || (ohi == bhi && orow < brow)) { bhi = ohi; brow = orow; }
-      }
-      const unsigned best = (unsigned)__builtin_amdgcn_readfirstlane((int)brow);
-      if (fail) {                                         // this system's chain gives up: poison the plan, identity pivots for what is left
-        if (lane == 0) __hip_atomic_store(poison, 1u, RLX_AGENT);
-        if (b == 0) for (int j = c + lane; j < nb; j += 64) ipiv[k0 + j] = k0 + j;
-        return;                                           // the other wavefronts (systems) meet the word in their next poll
-      }
-      if (best >= (unsigned)n || best < (unsigned)gc) { p = gc; wb = -1; if (b == 0 && lane == 0) atomicCAS(ws.info, 0, gc + 1); }
-      else { p = (int)best; wb = (p - k0) / rpb; }
-    }
-    MA_WSTAMP(0);
-    // ---- fetch the pivot row (and the displaced diagonal row); finish the previous column's pending update on them
-    dc* urow = (c & 1) ? urow_b : urow_a;
-    const dc* uprev = (c & 1) ? urow_a : urow_b;
-    {
-      const u64* src = wb >= 0 ? ws.candrow + ((size_t)buf * ws.max_blocks + wb) * (2 * LU_NB_MAX) : ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      const u64* s2 = ws.diagrow + (size_t)buf * (2 * LU_NB_MAX);
-      for (int j = lane; j < nb; j += 64) {
-        dc v = dc_make(ld_sc1(src + 2 * j), ld_sc1(src + 2 * j + 1));
-        dc d = dc_make(0.0, 0.0);
-        if (p != gc) d = dc_make(ld_sc1(s2 + 2 * j), ld_sc1(s2 + 2 * j + 1));
-        if (pending && j > c) {
-          const dc u = uprev[j];
-          const dc lv = dc_make(ld_sc1(src + 2 * (c - 1)), ld_sc1(src + 2 * (c - 1) + 1));
-          v.re -= lv.re * u.re - lv.im * u.im; v.im -= lv.re * u.im + lv.im * u.re;
-          if (p != gc) {
-            const dc ld = dc_make(ld_sc1(s2 + 2 * (c - 1)), ld_sc1(s2 + 2 * (c - 1) + 1));
-            d.re -= ld.re * u.re - ld.im * u.im; d.im -= ld.re * u.im + ld.im * u.re;
-          }
-        }
-        urow[j] = v;
-        if (p != gc) drow[j] = d;
-      }
-    }
-    wave_sync_lds();
-    MA_WSTAMP(1);
-    // ---- interchange inside the panel
-    if (p != gc && p >= r0 && p < r0 + nrows) for (int t = lane; t < nb; t += 64) P[(size_t)(p - r0) * pitch + t] = drow[t];
-    if (gc >= r0 && gc < r0 + nrows) for (int t = lane; t < nb; t += 64) P[(size_t)(gc - r0) * pitch + t] = urow[t];
-    if (b == 0 && lane == 0) ipiv[gc] = p;
-    const dc piv = urow[c];
-    const bool singular = !(piv.re * piv.re + piv.im * piv.im >= 1e-60);
-    if (singular && b == 0 && lane == 0) atomicCAS(ws.info, 0, gc + 1);
-    wave_sync_lds();
-    // ---- multipliers and the update of column c+1
-    const bool more = c + 1 < nb;
-    const bool below = lane < nrows && myrow > gc;
-    dc l = dc_make(0.0, 0.0), anext = dc_make(0.0, 0.0);
-    if (below) {
-      if (more) anext = P[lane * pitch + c + 1];
-      if (!singular) {
-        l = P[lane * pitch + c] * crecip(piv);
-        P[lane * pitch + c] = l;
-        if (more) {
-          const dc u = urow[c + 1];
-          anext.re -= l.re * u.re - l.im * u.im; anext.im -= l.re * u.im + l.im * u.re;
-          P[lane * pitch + c + 1] = anext;
-        }
-      }
-    }
-    if (more) {
-      const double mag = cabs1(anext);
-      int br; double bv;
-      pick(below && mag == mag, mag, &br, &bv);
-      wave_sync_lds();
-      MA_WSTAMP(2);
-      publish(c + 1, br, bv);
-      MA_WSTAMP(3);
-      if (lead) leader_gather(c + 1);
-      MA_WSTAMP(4);
-      // ---- bulk rank-1 update of this system's rows (hidden behind the other systems' steps and this one's exchange)
-      if (!singular && below) {
-        dc* Pr = P + (size_t)lane * pitch;
-        for (int j0 = c + 2; j0 < nb; j0 += 4) {
-          dc u[4], a[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { const int j = min(j0 + q, nb - 1); u[q] = urow[j]; a[q] = Pr[j]; }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { a[q].re -= l.re * u[q].re - l.im * u[q].im; a[q].im -= l.re * u[q].im + l.im * u[q].re; }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) if (j0 + q < nb) Pr[j0 + q] = a[q];
-        }
-      }
-    }
-    pending = !singular && more;
-    wave_sync_lds();
-    MA_WSTAMP(5);
-  }
-#ifdef MA_PANEL_STAMPS
-  if (lane == 0 && b == 0 && sy == 0) for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(ws.diagrow) + 2 * 2 * LU_NB_MAX + i, wst_acc[i]);
-#endif
-  for (int idx = lane; idx < nrows * nb; idx += 64) {
-    int rr = idx / nb, j = idx - rr * nb;
-    A[(size_t)(r0 + rr) * n + k0 + j] = P[rr * pitch + j];
-  }
-}
-
-// (A third form kept the rows in REGISTERS -- lane = row with its 32 panel entries in 128 vector registers, columns picked with
-// compare-and-select chains, published rows gathered with v_readlane, 200 VGPRs, no scratch once the 64 values were named
-// scalars instead of arrays: bit-identical again, but 61.9 ms of panel time per frequency against 31.7-37.5 for the LDS form
-// above: ~1500 vector instructions per column step, most of them selects and lane reads, cost more than the LDS traffic they
-// replace. Removed; the measurements are in DESIGN.md 4.)
 
 // ------------------------------------------------------------------ row interchanges outside the panel
 // One wavefront replays the panel's nb interchanges on an index map and emits (dst,src) row lists:
@@ -1086,66 +449,6 @@ __global__ __launch_bounds__(256) void lu_scatter_rows_kernel(dc* __restrict__ A
     const dc v = tmp[(size_t)idx * tstride + q];
     if (q < nxy) { const int col = q < nx ? x0 + q : y0 + (q - nx); A[(size_t)d * n + col] = v; }
     else B[(size_t)(q - nxy) * n + d] = v;
-  }
-}
-
-struct LuBlockPanels { int np; int k0[8]; int nb[8]; };   // a block's panels: first columns and widths
-
-// ------------------------------------------------------------------ a whole block's interchanges in one launch (round 4)
-// The main lane's per-panel gather + scatter (2 launches per panel, 12 per block of six) as ONE launch per block: the folded lists
-// of the block's `np` panels (lists + j * lstride: [0] = m <= 2 nb, dst[], src[]) applied one after the other to the columns
-// [x0, x1) U [y0, y1) and to the nrhs right-hand sides. Columns are independent, so a workgroup owns a strip of 32 columns and walks
-// the panels on its own: per panel every moved entry of the strip is read into registers (16 per thread: 128 rows x 32 columns over
-// 256 threads), then -- after a workgroup barrier, i.e. every read before any write -- written to its destination row; the next
-// panel's reads see these writes (one CU, workgroup scope). The last workgroup takes the right-hand sides (row stride 1, one
-// "column" per right-hand side). A poisoned plan moves nothing (the folded lists of an abandoned panel are empty anyway).
-// Columns of [x0, x1) that lie inside the block receive only the interchanges of the panels to their right (P.k0[j] > column).
-template <int NT>   // 8 NT = the most list entries a panel may have: 128 (panels of <= 64 columns: 16 registers of moved entries per thread) or 256
-__global__ __launch_bounds__(256) void lu_block_row_moves_kernel(dc* __restrict__ A, int n, const int* __restrict__ lists, int lstride, LuBlockPanels P, int x0, int x1, int y0, int y1,
-                                                                 dc* __restrict__ B, int nrhs, const unsigned* __restrict__ poison) {
-  __shared__ int s_dst[2 * LU_NB_MAX], s_src[2 * LU_NB_MAX];
-  __shared__ int s_m;
-  if (poison && __hip_atomic_load(poison, RLX_AGENT) != 0u) return;
-  const int tid = threadIdx.x;
-  const int nx = x1 - x0, nxy = nx + (y1 - y0);
-  const int nstrips = (nxy + 31) / 32;
-  const bool rhs = (int)blockIdx.x >= nstrips;
-  if (rhs && nrhs <= 0) return;
-  // a strip never straddles the two column ranges' seam in a way that matters: column q of the set is x0 + q or y0 + (q - nx)
-  const int q0 = 32 * (int)blockIdx.x;
-  const int col_l = tid & 31;
-  const int qc = q0 + col_l;
-  const bool col_ok = rhs ? col_l < nrhs : qc < nxy;
-  const size_t coff = rhs ? (size_t)col_l * (size_t)n : (size_t)(qc < nx ? x0 + qc : y0 + (qc - nx));
-  const size_t rstride = rhs ? 1 : (size_t)n;
-  dc* base = rhs ? B : A;
-  const bool xpart = !rhs && q0 < nx;                       // (uniform: strips are 32 columns from x0, the panels' first columns multiples of 32 from x0 -- checked by the launcher)
-  for (int j = 0; j < P.np; ++j) {
-    // inside the block a panel's interchanges go to the columns LEFT of the panel only: its own columns were permuted by the panel
-    // kernel, the block's columns right of it by the lane's step kernel
-    if (xpart && x0 + q0 >= P.k0[j]) continue;
-    const int* ls = lists + (size_t)j * lstride;
-    if (tid == 0) { int m = ls[0]; if (m < 0 || m > 8 * NT) m = 0; s_m = m; }
-    __syncthreads();
-    const int m = s_m;
-    if (m == 0) { __syncthreads(); continue; }
-    for (int i = tid; i < m; i += 256) { s_dst[i] = ls[1 + i]; s_src[i] = ls[1 + 2 * LU_NB_MAX + i]; }
-    __syncthreads();
-    dc mv[NT]; int md[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int idx = (tid >> 5) + 8 * t;
-      md[t] = -1; mv[t] = dc_make(0.0, 0.0);
-      if (idx < m && col_ok) {
-        const int sr = s_src[idx], ds = s_dst[idx];
-        if (sr >= 0 && sr < n && ds >= 0 && ds < n) { mv[t] = base[(size_t)sr * rstride + coff]; md[t] = ds; }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every read of the strip has returned ...
-    __syncthreads();                                       // ... in every thread, before the first write
-#pragma unroll
-    for (int t = 0; t < NT; ++t) if (md[t] >= 0) base[(size_t)md[t] * rstride + coff] = mv[t];
-    __syncthreads();                                       // workgroup scope: the next panel's reads see these writes
   }
 }
 
@@ -1360,102 +663,6 @@ __global__ __launch_bounds__(256) void lu_lane_step2_kernel(dc* __restrict__ A, 
 // its own columns only. The last workgroup of the launch (if nc2 > 0) does the same for the right-hand sides,
 // addressed with their own strides (row stride 1, column stride ldb): the forward substitution rides along.
 #define TM_PITCH 34
-__global__ __launch_bounds__(128) void lu_trsm_mfma_kernel(const dc* __restrict__ T, int ldt, int nb, const dc* __restrict__ invd,
-                                                           dc* __restrict__ X, size_t xrs, size_t xcs, int nc, int nmain,
-                                                           dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* Lre = reinterpret_cast<double*>(smem);
-  double* Lim = Lre + (size_t)max(32, ((nb + 15) >> 4) * 16) * TM_PITCH;   // the launch sizes the two planes for this nb
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lk = lane >> 4;
-  const bool extra = (int)blockIdx.x >= nmain;
-  dc* Xp = extra ? X2 : X;
-  const size_t rs = extra ? x2rs : xrs, cs = extra ? x2cs : xcs;
-  const int ncols = extra ? nc2 : nc;
-  const int c0 = extra ? wave * 16 : ((int)blockIdx.x * 2 + wave) * 16;
-  const bool active = c0 < ncols;
-  const int col = c0 + li;
-  const int NT = (nb + 15) >> 4;
-
-  v4d bre[8], bim[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    bre[t] = (v4d){0, 0, 0, 0}; bim[t] = (v4d){0, 0, 0, 0};
-    if (t < NT && active) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * t + lk + 4 * r;
-        if (row < nb && col < ncols) { const dc v = Xp[(size_t)row * rs + (size_t)col * cs]; bre[t][r] = v.re; bim[t][r] = v.im; }
-      }
-    }
-  }
-
-#pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
-    if (blk * 32 >= nb) break;
-    // slab rows: the (identity-padded) inverted diagonal block and everything below it, zero beyond nb up to the
-    // tile boundary: padded rows of a tile feed later products as k-slices and must stay exactly zero
-    const int rows = max(32, NT * 16 - blk * 32);
-    __syncthreads();
-    for (int idx = tid; idx < rows * 32; idx += 128) {
-      const int rr = idx >> 5, c = idx & 31;
-      dc v;
-      if (rr < 32) v = invd[((size_t)blk * 32 + rr) * 32 + c];
-      else v = (blk * 32 + rr < nb && blk * 32 + c < nb) ? T[(size_t)(blk * 32 + rr) * ldt + blk * 32 + c] : dc_make(0.0, 0.0);
-      Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
-    }
-    __syncthreads();
-    if (!active) continue;
-    const int t0 = 2 * blk, t1 = 2 * blk + 1;
-    v4d x0r = (v4d){0, 0, 0, 0}, x0i = x0r, x1r = x0r, x1i = x0r;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {                     // X1 = D[16:32, 0:32] (B_t0; B_t1)
-      const double ar = Lre[(16 + li) * TM_PITCH + ks * 4 + lk], ai = Lim[(16 + li) * TM_PITCH + ks * 4 + lk];
-      const double br = bre[t0 + (ks >> 2)][ks & 3], bi = bim[t0 + (ks >> 2)][ks & 3];
-      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x1r, 0, 0, 0);
-      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x1i, 0, 0, 0);
-      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x1r, 0, 0, 0);
-      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x1i, 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {                     // X0 = D[0:16, 0:16] B_t0
-      const double ar = Lre[li * TM_PITCH + ks * 4 + lk], ai = Lim[li * TM_PITCH + ks * 4 + lk];
-      const double br = bre[t0][ks], bi = bim[t0][ks];
-      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x0r, 0, 0, 0);
-      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x0i, 0, 0, 0);
-      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x0r, 0, 0, 0);
-      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x0i, 0, 0, 0);
-    }
-    bre[t0] = x0r; bim[t0] = x0i;
-    if (t1 < 8) { bre[t1 < 8 ? t1 : 7] = x1r; bim[t1 < 8 ? t1 : 7] = x1i; }
-#pragma unroll
-    for (int tj = t1 + 1; tj < 8; ++tj) {                // B_tj -= L[tj rows, slab] (X0; X1)
-      if (tj >= NT) break;
-      const int lr = tj * 16 - blk * 32 + li;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const double ar = Lre[lr * TM_PITCH + ks * 4 + lk], ai = Lim[lr * TM_PITCH + ks * 4 + lk];
-        const double xr = (ks < 4) ? x0r[ks & 3] : x1r[ks & 3], xi = (ks < 4) ? x0i[ks & 3] : x1i[ks & 3];
-        bre[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xr, bre[tj], 0, 0, 0);
-        bim[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xi, bim[tj], 0, 0, 0);
-        bre[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, xi, bre[tj], 0, 0, 0);
-        bim[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, xr, bim[tj], 0, 0, 0);
-      }
-    }
-  }
-  if (active) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t >= NT) break;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * t + lk + 4 * r;
-        if (row < nb && col < ncols) Xp[(size_t)row * rs + (size_t)col * cs] = dc_make(bre[t][r], bim[t][r]);
-      }
-    }
-  }
-}
-
 // The same solve for panels of <= 64 columns with the four 16-row tiles of the wavefront's block of A12 in NAMED accumulators
 // (an indexed array of tiles makes the compiler carry the whole array through every update): few registers, so the
 // wavefront fits beside two update wavefronts on a SIMD instead of queueing behind a running trailing update -- where these
@@ -1562,138 +769,6 @@ __global__ __launch_bounds__(128, 5) void lu_trsm64_kernel(const dc* __restrict_
   }
 }
 
-// ------------------------------------------------------------------ a whole block row of U in one launch (round 4)
-// The main lane's work on block g right of the block -- per panel j: U_j = L_jj^-1 A[p_j rows, e:n) (lu_trsm64_kernel), the
-// right-hand side's rows, and A[a_{j+1}:e, e:n) -= L[a_{j+1}:e, p_j] U_j (a K = 64 update launch), 3 launches per panel, 18 per
-// block of six -- as ONE launch: columns are independent, so a wavefront owns 16 columns of [e, n) and takes them through the block's
-// np <= 8 panels LEFT-looking: for panel i it fetches its 64 x 16 piece B_i of A12 (four accumulator tiles), subtracts
-// L[p_i rows, p_j columns] X_j for the panels j < i it has already solved (X_j comes back from memory in the accumulator layout,
-// which IS the MFMA B-operand layout; L in 64 x 32 pieces through LDS as re / im planes), solves with the inverted 32 x 32
-// diagonal blocks exactly as lu_trsm64_kernel does, and stores. Four wavefronts (64 columns) share the LDS pieces. The last
-// workgroup does the same for the right-hand sides (row stride 1): the forward substitution rides along, the rows below the
-// block get theirs from one zgemv afterwards.
-#define TB_ROWS 64
-__global__ __launch_bounds__(256) void lu_block_trsm_kernel(const dc* __restrict__ A, int lda, LuBlockPanels P, const dc* __restrict__ invd, int invd_stride,
-                                                            dc* __restrict__ X, size_t xrs, size_t xcs, int nc, int nmain,
-                                                            dc* __restrict__ X2, size_t x2rs, size_t x2cs, int nc2) {
-  __shared__ __attribute__((aligned(16))) double Lre[TB_ROWS * TM_PITCH];
-  __shared__ __attribute__((aligned(16))) double Lim[TB_ROWS * TM_PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lk = lane >> 4;
-  const bool extra = (int)blockIdx.x >= nmain;
-  dc* Xp = extra ? X2 : X;                                   // row 0 = the block's first row (P.k0[0])
-  const size_t rs = extra ? x2rs : xrs, cs = extra ? x2cs : xcs;
-  const int ncols = extra ? nc2 : nc;
-  const int c0 = extra ? wave * 16 : ((int)blockIdx.x * 4 + wave) * 16;
-  const bool active = c0 < ncols;
-  const int col = c0 + li;
-  const bool colok = active && col < ncols;
-  const int a0 = P.k0[0];
-  const v4d zero = (v4d){0, 0, 0, 0};
-  // tile t (16 rows) of panel q's rows, this wavefront's 16 columns: register r of lane (li, lk) = row 16 t + lk + 4 r, column li
-  auto load_tile = [&](int q, int t, v4d& br, v4d& bi) {
-    br = zero; bi = zero;
-    if (colok) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * t + lk + 4 * r;
-        if (row < P.nb[q]) { const dc v = Xp[(size_t)(P.k0[q] - a0 + row) * rs + (size_t)col * cs]; br[r] = v.re; bi[r] = v.im; }
-      }
-    }
-  };
-  auto store_tile = [&](int q, int t, const v4d& br, const v4d& bi) {
-    if (colok) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * t + lk + 4 * r;
-        if (row < P.nb[q]) Xp[(size_t)(P.k0[q] - a0 + row) * rs + (size_t)col * cs] = dc_make(br[r], bi[r]);
-      }
-    }
-  };
-  // LDS <- `rows` x 32 entries: what 0: the inverted diagonal block `blk` of panel q; 1: L[p_q rows r0.., p_j columns c0j..c0j+31] (zero beyond the panels)
-  auto load_rows = [&](int what, int q, int blk, int j, int r0, int cj, int rows) {
-    __syncthreads();
-    for (int idx = tid; idx < rows * 32; idx += 256) {
-      const int rr = idx >> 5, c = idx & 31;
-      dc v;
-      if (what == 0) v = invd[(size_t)q * invd_stride + ((size_t)blk * 32 + rr) * 32 + c];
-      else v = (r0 + rr < P.nb[q] && cj + c < P.nb[j]) ? A[(size_t)(P.k0[q] + r0 + rr) * lda + P.k0[j] + cj + c] : dc_make(0.0, 0.0);
-      Lre[rr * TM_PITCH + c] = v.re; Lim[rr * TM_PITCH + c] = v.im;
-    }
-    __syncthreads();
-  };
-  // T -= L[LDS rows lr0 + li, 32 columns] (Xa; Xb)
-  auto update_tile = [&](int lr0, v4d& tr, v4d& ti, const v4d& xar, const v4d& xai, const v4d& xbr, const v4d& xbi) {
-    const int lr = lr0 + li;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const double ar = Lre[lr * TM_PITCH + ks * 4 + lk], ai = Lim[lr * TM_PITCH + ks * 4 + lk];
-      const double xr = (ks < 4) ? xar[ks & 3] : xbr[ks & 3], xi = (ks < 4) ? xai[ks & 3] : xbi[ks & 3];
-      tr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xr, tr, 0, 0, 0);
-      ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ar, xi, ti, 0, 0, 0);
-      tr = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, xi, tr, 0, 0, 0);
-      ti = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, xr, ti, 0, 0, 0);
-    }
-  };
-  // (Ba; Bb) <- D (Ba; Bb) with the unit-lower-triangular inverse D in LDS rows 0..31 (lu_trsm64_kernel's solve_pair)
-  auto solve_pair = [&](v4d& ar_, v4d& ai_, v4d& br_, v4d& bi_) {
-    v4d x0r = zero, x0i = zero, x1r = zero, x1i = zero;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const double ar = Lre[(16 + li) * TM_PITCH + ks * 4 + lk], ai = Lim[(16 + li) * TM_PITCH + ks * 4 + lk];
-      const double br = (ks < 4) ? ar_[ks & 3] : br_[ks & 3], bi = (ks < 4) ? ai_[ks & 3] : bi_[ks & 3];
-      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x1r, 0, 0, 0);
-      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x1i, 0, 0, 0);
-      x1r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x1r, 0, 0, 0);
-      x1i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x1i, 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const double ar = Lre[li * TM_PITCH + ks * 4 + lk], ai = Lim[li * TM_PITCH + ks * 4 + lk];
-      const double br = ar_[ks], bi = ai_[ks];
-      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, x0r, 0, 0, 0);
-      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, x0i, 0, 0, 0);
-      x0r = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, x0r, 0, 0, 0);
-      x0i = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, br, x0i, 0, 0, 0);
-    }
-    ar_ = x0r; ai_ = x0i; br_ = x1r; bi_ = x1i;
-  };
-  for (int i = 0; i < P.np; ++i) {
-    v4d b0r, b0i, b1r, b1i, b2r, b2i, b3r, b3i;
-    load_tile(i, 0, b0r, b0i); load_tile(i, 1, b1r, b1i); load_tile(i, 2, b2r, b2i); load_tile(i, 3, b3r, b3i);
-    const int nti = (P.nb[i] + 15) >> 4;
-    for (int j = 0; j < i; ++j) {
-      v4d x0r, x0i, x1r, x1i;
-#pragma unroll 1
-      for (int cb = 0; cb < 2; ++cb) {
-        if (32 * cb >= P.nb[j]) break;                     // (uniform)
-        // the solved rows of panel j came back from this wavefront's own stores: same lanes, same addresses
-        load_tile(j, 2 * cb, x0r, x0i); load_tile(j, 2 * cb + 1, x1r, x1i);
-        load_rows(1, i, 0, j, 0, 32 * cb, TB_ROWS);
-        if (active) {
-          update_tile(0, b0r, b0i, x0r, x0i, x1r, x1i);
-          if (nti > 1) update_tile(16, b1r, b1i, x0r, x0i, x1r, x1i);
-          if (nti > 2) update_tile(32, b2r, b2i, x0r, x0i, x1r, x1i);
-          if (nti > 3) update_tile(48, b3r, b3i, x0r, x0i, x1r, x1i);
-        }
-      }
-    }
-    load_rows(0, i, 0, 0, 0, 0, 32);
-    if (active) solve_pair(b0r, b0i, b1r, b1i);
-    if (P.nb[i] > 32) {
-      load_rows(1, i, 0, i, 32, 0, 32);                    // L10 of panel i: rows 32.., columns 0..31
-      if (active) {
-        update_tile(0, b2r, b2i, b0r, b0i, b1r, b1i);
-        if (nti > 3) update_tile(16, b3r, b3i, b0r, b0i, b1r, b1i);
-      }
-      load_rows(0, i, 1, 0, 0, 0, 32);
-      if (active) solve_pair(b2r, b2i, b3r, b3i);
-    }
-    store_tile(i, 0, b0r, b0i); store_tile(i, 1, b1r, b1i); store_tile(i, 2, b2r, b2i); store_tile(i, 3, b3r, b3i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next panels read these rows back
-  }
-}
-
 // ------------------------------------------------------------------ triangular solves for the right-hand sides
 // x <- T^-1 x for one vector of nb <= 128 entries; one wavefront per right-hand side, lane l owns
 // rows l and l + 64 and streams its own rows of T (row-major: contiguous per lane); the solved
@@ -1749,105 +824,9 @@ __global__ __launch_bounds__(64) void lu_trsv_kernel(const dc* __restrict__ T, i
   if (r1 < nb) b[r1] = v1;
 }
 
-// ------------------------------------------------------------------ C -= A * B on the f64 matrix cores
-// A: M x K (lda), B: K x N (ldb), C: M x N (ldc), row-major complex128. Workgroup tile 128 x 128,
-// K in steps of 8 (two v_mfma_f64_16x16x4 k-steps), 512 threads = 8 wavefronts as 4 (M) x 2 (N);
-// each wavefront owns 32 x 64 = 2 x 4 MFMA tiles with separate real/imaginary accumulators.
-// LDS: As[2][8][128] (k-major: the A fragment of a tile is 16 consecutive complex), Bs[2][8][128].
-// Operand fragment of v_mfma_f64_16x16x4_f64: lane l holds A[i = l & 15][k = l >> 4] and
-// B[k = l >> 4][j = l & 15]; result register r of lane l is D[(l >> 4) + 4 r][l & 15].
-#define ZG_BM 128
-#define ZG_BN 128
-#define ZG_BK 8
-
-__global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
-                                                           const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
-  __shared__ __attribute__((aligned(16))) dc As[2][ZG_BK][ZG_BM];
-  __shared__ __attribute__((aligned(16))) dc Bs[2][ZG_BK][ZG_BN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;           // 4 x 2 wave grid
-  const int m0 = blockIdx.y * ZG_BM, n0 = blockIdx.x * ZG_BN;
-  const int li = lane & 15, lk = lane >> 4;
-
-  v4d accr[2][4], acci[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { accr[a][b] = (v4d){0, 0, 0, 0}; acci[a][b] = (v4d){0, 0, 0, 0}; }
-
-  // staging assignment: 1024 A elements and 1024 B elements per stage, 2 + 2 per thread
-  dc ra[2], rb[2];
-  auto load_stage = [&](int k0) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int e = tid + 512 * s;
-      const int row = e >> 3, kk = e & 7;                       // A: 8 consecutive k of one row = 128 B
-      const int gm = m0 + row, gk = k0 + kk;
-      ra[s] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : dc_make(0.0, 0.0);
-      const int bk = e >> 7, bn = e & 127;                      // B: 128 consecutive n of one k-row
-      const int gn = n0 + bn, gk2 = k0 + bk;
-      rb[s] = (gn < N && gk2 < K) ? B[(size_t)gk2 * ldb + gn] : dc_make(0.0, 0.0);
-    }
-  };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int e = tid + 512 * s;
-      As[buf][e & 7][(e >> 3) ^ (e & 7)] = ra[s];   // XOR swizzle: the 8 lanes of one row (k = 0..7, 1 KB apart) hit 8 different bank groups
-      Bs[buf][e >> 7][e & 127] = rb[s];
-    }
-  };
-
-  const int nstage = (K + ZG_BK - 1) / ZG_BK;
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstage) load_stage((st + 1) * ZG_BK);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kk = ks * 4 + lk;
-      dc af[2], bf[4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = As[buf][kk][(wm * 32 + a * 16 + li) ^ kk];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = Bs[buf][kk][wn * 64 + b * 16 + li];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const double nai = -af[a].im;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          accr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].re, bf[b].re, accr[a][b], 0, 0, 0);
-          accr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, bf[b].im, accr[a][b], 0, 0, 0);
-          acci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].re, bf[b].im, acci[a][b], 0, 0, 0);
-          acci[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].im, bf[b].re, acci[a][b], 0, 0, 0);
-        }
-      }
-    }
-    if (st + 1 < nstage) store_stage(buf ^ 1);
-    __syncthreads();
-  }
-  // epilogue: C -= acc
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gm = m0 + wm * 32 + a * 16 + lk + 4 * r;
-        const int gn = n0 + wn * 64 + b * 16 + li;
-        if (gm < M && gn < N) {
-          dc* pc = C + (size_t)gm * ldc + gn;
-          dc c = *pc;
-          c.re -= accr[a][b][r]; c.im -= acci[a][b][r];
-          *pc = c;
-        }
-      }
-}
-
+#define ZG_BK 8                              // k-slice of an LDS stage of the register-staged update kernel
 // ------------------------------------------------------------------ C -= A * B, 3M form
-// Same contract as zgemm_sub_kernel with three real products per complex product:
+// C -= A B (row-major, leading dimensions in elements) with three real products per complex product:
 //   T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi);  Re = T1 - T2,  Im = T3 - T1 - T2.
 // 25 % fewer matrix-core instructions than the 4-product form; normwise (not componentwise)
 // backward stable, which is what the LU update needs. Workgroup tile 64 x 64, 4 wavefronts as
@@ -1856,73 +835,20 @@ __global__ __launch_bounds__(512, 1) void zgemm_sub_kernel(int M, int N, int K, 
 // others' MFMA loops (with one 128 x 64 workgroup per CU the epilogue cost 22 % of the kernel); the sums Ar+Ai and Br+Bi are formed once per fragment load.
 #define Z3_BM 64
 #define Z3_BN 64
-#ifndef MA_ZGEMM_DMA_DEFAULT
-#define MA_ZGEMM_DMA_DEFAULT 1
-#endif
 #define Z3_STAGES 3                          // LDS stages of 16 KB: three workgroups of 48 KB share a CU
 
 #ifndef MA_ZGEMM_MAXWAVES
 #define MA_ZGEMM_MAXWAVES 2
 #endif
-// Tile order. ctr == nullptr: workgroup (bx, by) takes tile (bx, by). ctr != nullptr (large updates): a grid of <= 2 workgroups
-// per CU DRAWS its tiles: the tiles are grouped in blocks of 8 x 8, block s belongs to XCD s mod 8, and a workgroup asks the
-// counter of the XCD it runs on (XCC_ID, read at run time -- the dispatcher's placement is not a function of blockIdx once other
-// kernels are in flight) for the next tile of that XCD's blocks; 64 consecutive draws are one block, so the <= 64 workgroups
-// an XCD runs at a time share 8 row panels of A and 8 column panels of B in that XCD's L2 instead of fetching each over the
-// fabric (every tile needs 2 x 64 x K entries of A and B for 64 x 64 of C). An XCD whose blocks are exhausted draws from the
-// next XCD's. ctr[0..7] draws, ctr[8] workgroups that have left; the last one zeroes the counters for the launch that
-// reuses them.
-__device__ __forceinline__ unsigned zg_xcc_id() {
-  unsigned v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 7u;
-}
-// DRAW = false is the plain kernel (one tile per workgroup, tile = blockIdx): the tile loop and everything of the draw fold away
-template <bool DRAW>
+// One tile per workgroup, tile = blockIdx. (Rounds 2-3 also had a form whose workgroups DREW their tiles XCD by XCD: half the fabric
+// traffic, no time: profiles/r02_*_tiles_drawn.json.)
 __device__ __forceinline__ void zgemm3m_body(int M, int N, int K, const dc* __restrict__ A, size_t lda, const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc,
-                                             unsigned* __restrict__ ctr, int one_tile, dc (*As)[ZG_BK][Z3_BM], dc (*Bs)[ZG_BK][Z3_BN], int* s_tile) {
-  const int tid0 = threadIdx.x;
-  const int gx = (N + Z3_BN - 1) / Z3_BN, gy = (M + Z3_BM - 1) / Z3_BM;
-  const int sgx = (gx + 7) >> 3, NS = sgx * ((gy + 7) >> 3);
-  const unsigned myx = DRAW ? zg_xcc_id() : 0u;
-  for (bool first = true;; first = false) {
-  // the per-thread index arithmetic is redone for every tile (the opaque copy keeps it from being hoisted out of the tile loop
-  // and carried in registers across it: the kernel has to stay within 176 of them to share a SIMD with two panel wavefronts)
-  int tid = tid0;
-  if (DRAW) asm volatile("" : "+v"(tid));
+                                             dc (*As)[ZG_BK][Z3_BM], dc (*Bs)[ZG_BK][Z3_BN]) {
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 15, lk = lane >> 4;
-  int m0, n0;
-  if (!DRAW) {
-    if (!first) break;
-    m0 = blockIdx.y * Z3_BM; n0 = blockIdx.x * Z3_BN;
-  } else {
-    if (tid == 0) {
-      int ty = -1, tx = -1;
-      for (int v = 0; v < 8 && ty < 0; ++v) {
-        const int x = (int)((myx + (unsigned)v) & 7u);
-        const unsigned space = (unsigned)((NS - x + 7) / 8) * 64u;          // draws of XCD x: its blocks s = x, x + 8, ... times 64 tiles
-        for (;;) {
-          const unsigned r = atomicAdd(ctr + x, 1u);
-          if (r >= space) break;
-          const int sblk = x + 8 * (int)(r >> 6), t = (int)(r & 63u);
-          const int sy = sblk / sgx, sx = sblk - sy * sgx;
-          const int y = sy * 8 + (t >> 3), xx = sx * 8 + (t & 7);
-          if (y < gy && xx < gx) { ty = y; tx = xx; break; }
-        }
-      }
-      s_tile[0] = ty; s_tile[1] = tx;
-    }
-    __syncthreads();
-    const int ty = __builtin_amdgcn_readfirstlane(s_tile[0]), tx = __builtin_amdgcn_readfirstlane(s_tile[1]);   // uniform: keep the tile origin on the scalar side
-    __syncthreads();                                                        // s_tile is rewritten by the next draw
-    if (ty < 0) {
-      if (tid == 0 && atomicAdd(ctr + 8, 1u) == gridDim.x - 1u) { for (int i = 0; i < 9; ++i) ctr[i] = 0u; }
-      break;
-    }
-    m0 = ty * Z3_BM; n0 = tx * Z3_BN;
-  }
+  const int m0 = blockIdx.y * Z3_BM, n0 = blockIdx.x * Z3_BN;
 
   v4d t1[2][2], t2[2][2], t3[2][2];
 #pragma unroll
@@ -2016,29 +942,13 @@ __device__ __forceinline__ void zgemm3m_body(int M, int N, int K, const dc* __re
         if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = c;
       }
   }
-  if (DRAW) {
-    __syncthreads();                                                        // the next tile's first stage overwrites the LDS buffers
-    if (one_tile) {                                                         // one tile per workgroup (grid = tiles): leave, counting out
-      if (tid == 0 && atomicAdd(ctr + 8, 1u) == gridDim.x - 1u) { for (int i = 0; i < 9; ++i) ctr[i] = 0u; }
-      break;
-    }
-  }
-  }
 }
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
                                                              const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc) {
   __shared__ __attribute__((aligned(16))) dc As[Z3_STAGES][ZG_BK][Z3_BM];
   __shared__ __attribute__((aligned(16))) dc Bs[Z3_STAGES][ZG_BK][Z3_BN];
-  zgemm3m_body<false>(M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, As, Bs, nullptr);
+  zgemm3m_body(M, N, K, A, lda, B, ldb, C, ldc, As, Bs);
 }
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(1, MA_ZGEMM_MAXWAVES))) void zgemm3m_sub_drawn_kernel(int M, int N, int K, const dc* __restrict__ A, size_t lda,
-                                                             const dc* __restrict__ B, size_t ldb, dc* __restrict__ C, size_t ldc, unsigned* __restrict__ ctr, int one_tile) {
-  __shared__ __attribute__((aligned(16))) dc As[Z3_STAGES][ZG_BK][Z3_BM];
-  __shared__ __attribute__((aligned(16))) dc Bs[Z3_STAGES][ZG_BK][Z3_BN];
-  __shared__ int s_tile[2];
-  zgemm3m_body<true>(M, N, K, A, lda, B, ldb, C, ldc, ctr, one_tile, As, Bs, s_tile);
-}
-
 // ------------------------------------------------------------------ C -= A * B, 3M form, operands by LDS-DMA
 // What the matrix cores lose in zgemm3m_sub_kernel is its LDS traffic (tools/mfma_loop_probe.hip, profiles/r03_mfma_loop_probe.txt:
 // the bare loop of 24 MFMAs per stage runs at 76 TFLOP/s of 77; with the fragment reads 72; with the four ds_write_b128 of the
@@ -2241,16 +1151,6 @@ __global__ __launch_bounds__(256) void mfma_f64_probe_kernel(double* out, int it
 }
 
 // ------------------------------------------------------------------ launchers
-size_t lu_panel_lds_bytes(int nb, int rpb) {
-  return (size_t)rpb * (nb + 1) * sizeof(dc) + 3 * (size_t)nb * sizeof(dc) + 4 * sizeof(double) + 12 * sizeof(int) + sizeof(double) + 64;
-}
-
-int lu_panel_configure() {
-  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_panel_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  return MA_OK;
-}
-
 // ---- Residency of the panel kernels (the argument behind the admission rule below)
 // A panel kernel exchanges by spinning: none of its workgroups finishes before ALL of them are resident. Several panel
 // kernels may be in flight on a device (the systems of a batch, other plans, other host threads), next to kernels that
@@ -2294,8 +1194,7 @@ struct DeviceSequencer {
 DeviceSequencer g_seq_dev[16];
 struct KernelFacts {
   std::mutex mu;
-  int regs[3] = {0, 0, 0};   // vector registers per lane of lu_panel_kernel, lu_panel_wave_kernel, lu_panel_reg_kernel
-  int occ_checked_lds = 0;
+  int regs = 0;              // vector registers per lane of lu_panel_reg_kernel
   bool occ_checked_reg = false;
 };
 KernelFacts g_seq;
@@ -2313,27 +1212,14 @@ int lu_panel_slots_per_cu(size_t lds, int regs) {
 
 size_t lu_panel_granule_bytes(int max_blocks) { return sizeof(unsigned long long) * LU_GRANULE_STRIDE * (2 * (size_t)max_blocks + 2 * LU_GROUPS); }
 
-int lu_panel_regs(int kind) {
+int lu_panel_regs() {
   std::lock_guard<std::mutex> lock(g_seq.mu);
-  if (g_seq.regs[0] == 0) {
-    const void* f[3] = {reinterpret_cast<const void*>(lu_panel_kernel), reinterpret_cast<const void*>(lu_panel_wave_kernel), reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>)};
-    for (int q = 0; q < 3; ++q) {
-      hipFuncAttributes fa;
-      MA_HIP(hipFuncGetAttributes(&fa, f[q]));
-      g_seq.regs[q] = fa.numRegs > 0 ? fa.numRegs : 128;
-    }
+  if (g_seq.regs == 0) {
+    hipFuncAttributes fa;
+    MA_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>)));
+    g_seq.regs = fa.numRegs > 0 ? fa.numRegs : 128;
   }
-  return g_seq.regs[kind >= 0 && kind <= 2 ? kind : 0];
-}
-
-// MA_OK when a grid of nblk workgroups with this panel shape can be co-resident on ncu CUs on its own
-int lu_panel_admissible(int nb, int rpb, int nblk, int ncu) {
-  const size_t lds = lu_panel_lds_bytes(nb, rpb);
-  const int regs = lu_panel_regs(0);
-  const int p = lu_panel_slots_per_cu(lds, regs);
-  MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
-             "panel grid of %d workgroups x %zu B LDS (%d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nb, rpb, ncu, p);
-  return MA_OK;
+  return g_seq.regs;
 }
 
 // ---- the admission window as a guard any SPINNING kernel of the library goes through (LU panels, the flag-driven Gauss-Seidel
@@ -2459,40 +1345,33 @@ int spin_error_check(const char* what) {
 // LDS the register panel kernel declares (static: pivot row, staging row, a few words)
 static size_t lu_panel_reg_lds() { return 2 * (size_t)LU_REG_NB * sizeof(dc) + 64; }
 
-// admission + launch of a panel kernel. kind 0: lu_panel_kernel on (A[0], ws[0], ipiv[0]); kind 1: lu_panel_wave_kernel over nsys
-// systems; kind 2: lu_panel_reg_kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns). `ncu` is the number of
-// CUs the stream may use (a CU-masked stream: the CUs of its mask).
-static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st,
-                            int* reg_lists = nullptr, c64* reg_lrows = nullptr, int reg_lcol0 = 0, const int* reg_run_if_nonzero = nullptr) {
+// admission + launch of the register-resident panel kernel: 256 rows per workgroup, nb <= LU_REG_NB columns; `ncu` = the CUs `st` may use
+int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, c64* lrows, int lcol0,
+                        const int* run_if_nonzero) {
+  MA_REQUIRE(!lrows || (lcol0 >= 0 && lcol0 + LU_REG_NB <= k0), MA_ERR_INVALID, "left-half columns [%d, %d) not left of the panel at %d", lcol0, lcol0 + LU_REG_NB, k0);
   int dev = 0;
   MA_HIP(hipGetDevice(&dev));
   MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the panel sequencer table", dev);
-  MA_REQUIRE(nsys >= 1 && nsys <= LU_GROUP_MAX, MA_ERR_INVALID, "%d systems per panel kernel", nsys);
-  MA_REQUIRE(kind == 2 ? (nsys == 1 && rpb == 256 && nb >= 1 && nb <= LU_REG_NB) : (kind == (nsys == 1 ? 0 : 1)), MA_ERR_INVALID, "panel kernel kind %d with %d systems, %d rows per workgroup, %d columns", kind, nsys, rpb, nb);
-  const LuPanelWs& ws = wss[0];
+  MA_REQUIRE(nb >= 1 && nb <= LU_REG_NB, MA_ERR_INVALID, "panel of %d columns", nb);
   MA_REQUIRE(nblk >= 1 && nblk <= ws.max_blocks, MA_ERR_INVALID, "panel grid of %d workgroups outside the workspace (%d)", nblk, ws.max_blocks);
-  MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * rpb < n && (long long)k0 + (long long)nblk * rpb >= n, MA_ERR_INVALID,
-             "panel grid (%d workgroups of %d rows from row %d) does not tile the %d rows", nblk, rpb, k0, n);
+  MA_REQUIRE((long long)k0 + (long long)(nblk - 1) * 256 < n && (long long)k0 + (long long)nblk * 256 >= n, MA_ERR_INVALID,
+             "panel grid (%d workgroups of 256 rows from row %d) does not tile the %d rows", nblk, k0, n);
   MA_REQUIRE(n < 0xFFFFFF, MA_ERR_UNSUPPORTED, "row positions travel in 24 bits of the exchange granule");
-  const size_t sys_lds = (lu_panel_lds_bytes(nb, rpb) + 15) & ~(size_t)15;
-  const size_t lds = kind == 2 ? lu_panel_reg_lds() : (kind == 0 ? lu_panel_lds_bytes(nb, rpb) : sys_lds * (size_t)nsys);
-  const int regs = lu_panel_regs(kind);
+  const size_t lds = lu_panel_reg_lds();
+  const int regs = lu_panel_regs();
   {
     const int p = lu_panel_slots_per_cu(lds, regs);
     MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED,
-               "panel grid of %d workgroups x %zu B LDS (%d systems, %d columns, %d rows each) cannot be co-resident on %d CUs (%d per CU)", nblk, lds, nsys, nb, rpb, ncu, p);
+               "panel grid of %d workgroups (%d columns) cannot be co-resident on %d CUs (%d per CU)", nblk, nb, ncu, p);
   }
   {
     std::lock_guard<std::mutex> lock(g_seq.mu);
-    if (kind == 2 ? !g_seq.occ_checked_reg : (int)lds > g_seq.occ_checked_lds) {
+    if (!g_seq.occ_checked_reg) {
       // the runtime's own occupancy figure must not be below the slots the rule assumes (registers, waves, LDS granularity)
       int occ = 0;
-      if (kind == 0) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_kernel), 256, lds));
-      else if (kind == 1) MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_wave_kernel), 64 * nsys, lds));
-      else MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>), 256, 0));
-      MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU at %zu B LDS is below the %d slots the admission rule assumes",
-                 occ, lds, lu_panel_slots_per_cu(lds, regs));
-      if (kind == 2) g_seq.occ_checked_reg = true; else g_seq.occ_checked_lds = (int)lds;
+      MA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(lu_panel_reg_kernel<LU_REG_NB>), 256, 0));
+      MA_REQUIRE(occ >= lu_panel_slots_per_cu(lds, regs), MA_ERR_UNSUPPORTED, "panel kernel occupancy %d per CU is below the %d slots the admission rule assumes", occ, lu_panel_slots_per_cu(lds, regs));
+      g_seq.occ_checked_reg = true;
     }
   }
   SpinLaunch guard;
@@ -2501,17 +1380,8 @@ static int launch_panel_any(int kind, int nsys, c64* const* As, int n, int k0, i
   // see the previous launch's granules, which carry that launch's last two tags (nb and nb - 1): they differ from the
   // wanted 1 and 2 whenever the previous panel of this workspace had >= 4 columns. Otherwise (and at the start of a
   // factorisation, whose predecessor may have been aborted) the granules are cleared.
-  if (clear_tags) for (int t = 0; t < nsys; ++t) MA_HIP(hipMemsetAsync(wss[t].cand, 0, lu_panel_granule_bytes(wss[t].max_blocks), st));
-  if (kind == 2) hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, ws, ipivs[0], reg_lists,
-                                    reinterpret_cast<dc*>(reg_lrows), reg_lcol0, reg_run_if_nonzero);
-  else if (nsys == 1) hipLaunchKernelGGL(lu_panel_kernel, dim3(nblk), dim3(256), lds, st, reinterpret_cast<dc*>(As[0]), n, k0, nb, rpb, ws, ipivs[0]);
-  else {
-    LuPanelBatch B;
-    B.nsys = nsys;
-    for (int t = 0; t < LU_BATCH_MAX; ++t) { const int q = t < nsys ? t : 0; B.A[t] = reinterpret_cast<dc*>(As[q]); B.ipiv[t] = ipivs[q]; B.ws[t] = wss[q]; }
-    MA_REQUIRE(rpb <= 64, MA_ERR_INVALID, "the batched panel kernel holds <= 64 rows per workgroup (lane = row), got %d", rpb);
-    hipLaunchKernelGGL(lu_panel_wave_kernel, dim3(nblk), dim3(64 * nsys), lds, st, B, n, k0, nb, rpb, (unsigned)sys_lds);
-  }
+  if (clear_tags) MA_HIP(hipMemsetAsync(ws.cand, 0, lu_panel_granule_bytes(ws.max_blocks), st));
+  hipLaunchKernelGGL(lu_panel_reg_kernel<LU_REG_NB>, dim3(nblk), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, k0, nb, ws, ipiv, lists, reinterpret_cast<dc*>(lrows), lcol0, run_if_nonzero);
   MA_HIP(hipGetLastError());
   return guard.commit();
 }
@@ -2525,15 +1395,6 @@ void lu_panel_forget_stream(int dev, hipStream_t st) {
   for (int i = 0; i < kSeqRing; ++i) if (D.ring[i].used && D.ring[i].st == st) { D.ring[i].used = false; D.ring[i].st = nullptr; }
 }
 
-int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st) {
-  return launch_panel_any(0, 1, &A, n, k0, nb, rpb, nblk, ncu, &ws, &ipiv, clear_tags, st);
-}
-// the register-resident panel kernel: 256 rows per workgroup, nb <= LU_REG_NB columns; ncu = the CUs `st` may use
-int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st, c64* lrows, int lcol0,
-                        const int* run_if_nonzero) {
-  MA_REQUIRE(!lrows || (lcol0 >= 0 && lcol0 + LU_REG_NB <= k0), MA_ERR_INVALID, "left-half columns [%d, %d) not left of the panel at %d", lcol0, lcol0 + LU_REG_NB, k0);
-  return launch_panel_any(2, 1, &A, n, k0, nb, 256, nblk, ncu, &ws, &ipiv, clear_tags, st, lists, lrows, lcol0, run_if_nonzero);
-}
 // the step between two panels of a block column: interchanges + U = L11^-1 A12 on the columns [x0, x0 + ncols), and the inverted
 // diagonal block of L11 into invd (lists: what lu_launch_panel_reg wrote)
 int lu_launch_lane_step(c64* A, int n, int k0, int nb, const int* lists, int x0, int ncols, c64* invd, const unsigned* poison, hipStream_t st) {
@@ -2544,15 +1405,10 @@ int lu_launch_lane_step(c64* A, int n, int k0, int nb, const int* lists, int x0,
 }
 // MA_OK when a register-panel grid of nblk workgroups can be co-resident on ncu CUs on its own
 int lu_panel_reg_admissible(int nblk, int ncu) {
-  const int p = lu_panel_slots_per_cu(lu_panel_reg_lds(), lu_panel_regs(2));
+  const int p = lu_panel_slots_per_cu(lu_panel_reg_lds(), lu_panel_regs());
   MA_REQUIRE(p >= 1 && (long long)nblk <= (long long)p * ncu, MA_ERR_UNSUPPORTED, "register panel grid of %d workgroups cannot be co-resident on %d CUs (%d per CU)", nblk, ncu, p);
   return MA_OK;
 }
-// the same panel of nsys systems (a lock-step batch) in one co-resident grid, a wavefront per system: lu_panel_wave_kernel
-int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st) {
-  return launch_panel_any(1, nsys, As, n, k0, nb, rpb, nblk, ncu, wss, ipivs, clear_tags, st);
-}
-
 // Apply panel (k0, nb)'s interchanges to the columns [x0, x1) U [y0, y1) of A and to the nrhs right-hand sides.
 // `tmp` holds 2 nb rows of `tstride` >= (x1-x0)+(y1-y0)+nrhs entries. With `invd`, blocks 1.. of the first launch
 // also invert the 32 x 32 diagonal blocks of the panel's L11 for lu_trsm_mfma_kernel.
@@ -2583,22 +1439,6 @@ int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int t
 
 // the folded lists of a block's np panels (lists + j * lstride) applied in order to the columns [x0, x1) U [y0, y1) and the right-hand
 // sides: one launch (lu_block_row_moves_kernel). Panel j's list goes to a column c of [x0, x1) only if c < k0s[j].
-int lu_launch_block_row_moves(c64* A, int n, const int* lists, int lstride, int np, const int* k0s, const int* nbs, int x0, int x1, int y0, int y1, c64* B, int nrhs, const unsigned* poison, hipStream_t st) {
-  const int ncol = (x1 - x0) + (y1 - y0);
-  if (np <= 0 || (ncol <= 0 && nrhs <= 0)) return MA_OK;
-  MA_REQUIRE(np <= 8 && nrhs <= 32 && x0 <= x1 && y0 <= y1, MA_ERR_INVALID, "block row moves: bad shape");
-  LuBlockPanels P;
-  P.np = np;
-  int nb_max = 1;
-  for (int q = 0; q < 8; ++q) { P.k0[q] = q < np ? k0s[q] : 0; P.nb[q] = q < np ? nbs[q] : 0; if (q < np && nbs[q] > nb_max) nb_max = nbs[q]; }
-  for (int q = 0; q < np; ++q) MA_REQUIRE(nbs[q] >= 1 && nbs[q] <= LU_NB_MAX && (k0s[q] - x0) % 32 == 0, MA_ERR_INVALID, "block row moves: panel %d (%d columns from %d)", q, nbs[q], k0s[q]);
-  MA_REQUIRE((x1 - x0) % 32 == 0 || y1 == y0, MA_ERR_INVALID, "block row moves: the left range must be whole strips");
-  const int grid = (ncol + 31) / 32 + (nrhs > 0 ? 1 : 0);
-  if (nb_max <= 64) hipLaunchKernelGGL(lu_block_row_moves_kernel<16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, lists, lstride, P, x0, x1, y0, y1, reinterpret_cast<dc*>(B), nrhs, poison);
-  else hipLaunchKernelGGL(lu_block_row_moves_kernel<32>, dim3(grid), dim3(256), 0, st, reinterpret_cast<dc*>(A), n, lists, lstride, P, x0, x1, y0, y1, reinterpret_cast<dc*>(B), nrhs, poison);
-  MA_HIP(hipGetLastError());
-  return MA_OK;
-}
 
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
                     c64* invd, unsigned* poison, hipStream_t st) {
@@ -2607,25 +1447,17 @@ int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, 
   return lu_launch_row_moves(A, n, nb, lists, tmp, tstride, x0, x1, y0, y1, B, nrhs, st);
 }
 
-int lu_trsm_configure() {
-  MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lu_trsm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * TM_PITCH * 8));
+int lu_trsm_configure() { return MA_OK; }
 
-  return MA_OK;
-}
-
-// X (nb x ncols, row stride ldx) <- L11^-1 X and the nrhs right-hand sides b_r = B + r*ldb (nb entries each) <- L11^-1 b_r,
-// with the inverted diagonal blocks `invd` of lu_launch_swaps
+// X (nb <= 64 rows x ncols, row stride ldx) <- L11^-1 X and the nrhs right-hand sides b_r = B + r*ldb (nb entries each) <- L11^-1 b_r,
+// with the inverted diagonal blocks `invd` of lu_launch_lane_step2 / lu_launch_swaps
 int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st) {
   if (nb <= 0 || (ncols <= 0 && nrhs <= 0)) return MA_OK;
-  MA_REQUIRE(nb <= LU_NB_MAX && nrhs <= 32, MA_ERR_DIM, "trsm: nb %d / nrhs %d beyond the kernel's tiles", nb, nrhs);
+  MA_REQUIRE(nb <= 64 && nrhs <= 32, MA_ERR_DIM, "trsm: nb %d / nrhs %d beyond the kernel's tiles", nb, nrhs);
   const int nmain = ncols > 0 ? (ncols + 31) / 32 : 0;
-  // LDS for the slab of this nb only (34.8 KB at nb = 64): the launch then fits on a CU that already holds two panel
-  // workgroups (with the full 128-row 69.6 KB it never did, and queued behind them)
-  static const bool wide_only_ = [] { const char* e = getenv("MA_LU_TRSM_WIDE"); return e && atoi(e) != 0; }();
-  const size_t lds = (nb <= 64 && !wide_only_) ? 2 * (size_t)32 * TM_PITCH * 8 : 2 * (size_t)std::max(32, ((nb + 15) / 16) * 16) * TM_PITCH * 8;
-  static const bool wide_only = [] { const char* e = getenv("MA_LU_TRSM_WIDE"); return e && atoi(e) != 0; }();   // diagnostic: the 8-tile kernel for every width
-  auto kern = (nb <= 64 && !wide_only) ? lu_trsm64_kernel : lu_trsm_mfma_kernel;
-  hipLaunchKernelGGL(kern, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
+  // LDS for a 32-row slab (17 KB): the launch fits on a CU that already holds panel and update workgroups
+  const size_t lds = 2 * (size_t)32 * TM_PITCH * 8;
+  hipLaunchKernelGGL(lu_trsm64_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(128), lds, st, reinterpret_cast<const dc*>(T), ldt, nb,
                      reinterpret_cast<const dc*>(invd), reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
   MA_HIP(hipGetLastError());
   return MA_OK;
@@ -2642,23 +1474,6 @@ int lu_launch_lane_step2(c64* A, int n, int k0, int nb, const int* lists1, const
   return MA_OK;
 }
 
-// U12 of a whole block (np <= 8 panels of <= 64 columns each, first columns k0s[], widths nbs[]) on the columns X (row 0 = the block's
-// first row) and the nrhs right-hand sides: in-block updates included (lu_block_trsm_kernel). invd: the panels' inverted diagonal blocks,
-// invd_stride entries apart.
-int lu_launch_block_trsm(const c64* A, int n, int np, const int* k0s, const int* nbs, const c64* invd, int invd_stride, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st) {
-  if (np <= 0 || (ncols <= 0 && nrhs <= 0)) return MA_OK;
-  MA_REQUIRE(np <= 8 && nrhs <= 32, MA_ERR_DIM, "block trsm: %d panels / %d right-hand sides beyond the kernel's limits", np, nrhs);
-  LuBlockPanels P;
-  P.np = np;
-  for (int q = 0; q < 8; ++q) { P.k0[q] = q < np ? k0s[q] : 0; P.nb[q] = q < np ? nbs[q] : 0; }
-  for (int q = 0; q < np; ++q) MA_REQUIRE(nbs[q] >= 1 && nbs[q] <= 64 && (q == 0 || k0s[q] == k0s[q - 1] + nbs[q - 1]), MA_ERR_DIM, "block trsm: panel %d (%d columns from %d)", q, nbs[q], k0s[q]);
-  const int nmain = ncols > 0 ? (ncols + 63) / 64 : 0;
-  hipLaunchKernelGGL(lu_block_trsm_kernel, dim3(nmain + (nrhs > 0 ? 1 : 0)), dim3(256), 0, st, reinterpret_cast<const dc*>(A), n, P, reinterpret_cast<const dc*>(invd), invd_stride,
-                     reinterpret_cast<dc*>(X), ldx, (size_t)1, ncols, nmain, reinterpret_cast<dc*>(B), (size_t)1, ldb, nrhs);
-  MA_HIP(hipGetLastError());
-  return MA_OK;
-}
-
 // nrhs vectors b_r = B + r*ldb (nb entries each): b_r <- T^-1 b_r
 int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st) {
   if (nrhs <= 0 || nb <= 0) return MA_OK;
@@ -2668,95 +1483,38 @@ int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb
   return MA_OK;
 }
 
-ZgemmMode zgemm_mode_from_env() {
-  ZgemmMode m;
-  if (const char* e = getenv("MA_ZGEMM_DMA")) m.dma = atoi(e);
-  if (const char* e = getenv("MA_ZGEMM_TILE_ORDER")) m.tile_order = atoi(e) != 0;
-  if (const char* e = getenv("MA_ZGEMM_XCD_TILES")) m.xcd_min_tiles = atoi(e);
-  if (const char* e = getenv("MA_ZGEMM_XCD_PERSIST")) m.persist = atoi(e) != 0;
-  return m;
-}
-
-// `mode`: which kernel family runs the update. A plan resolves the switches ONCE, when it is created, and hands the same mode to
-// every launch of its factorisations (the bitwise guarantees between schedules assume one family per factorisation, and getenv
-// per launch raced with the tests' setenv under several host threads); NULL = the process-wide mode, read at its first use.
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big, const ZgemmMode* mode) {
+// C -= A B. big: the trailing update on the caller's stream (its own kernel instantiation, so that a trace tells it from the lanes'
+// updates). dma = false: the register-staged kernel (what K not a multiple of 8 gets anyway); the two are bit-identical.
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool big, bool dma) {
   if (M <= 0 || N <= 0 || K <= 0) return MA_OK;
-  static const ZgemmMode process_mode = zgemm_mode_from_env();
-  const ZgemmMode& zm = mode ? *mode : process_mode;
-  if (use_3m && K % ZD_BK == 0 && zm.xcd_min_tiles <= 0) {               // an explicit request for the drawn-tile kernel wins
-    const int dma_mode = zm.dma;
-    if (dma_mode == 1 || dma_mode == 2) {
-      // more than 64 KB of LDS per workgroup: the limit is raised per function AND per device (a process may drive several)
-      {
-        static std::mutex mu;
-        static bool done[16] = {};
-        int dev = 0;
-        MA_HIP(hipGetDevice(&dev));
-        MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the table", dev);
-        std::lock_guard<std::mutex> lock(mu);
-        if (!done[dev]) {
-          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
-          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
-          MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * ZD_BK * 16));
-          done[dev] = true;
-        }
-      }
-      // big updates: a one-dimensional grid, tiles dealt out XCD by XCD in blocks of 4 x 4 (see the kernel); MA_ZGEMM_TILE_ORDER=0: plain
-      const bool xcd_order = zm.tile_order && (long long)((N + 127) / 128) * ((M + 63) / 64) >= 512;
-      const int T22 = ((N + 127) / 128) * ((M + 63) / 64);
-      const dim3 g22 = xcd_order ? dim3(8 * ((T22 + 7) / 8), 1) : dim3((N + 127) / 128, (M + 63) / 64);
-      if (dma_mode == 1 && big) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, true>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
-                                                   reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, xcd_order ? 1 : 0);
-      else if (dma_mode == 1) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, false>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
-                                                 reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, xcd_order ? 1 : 0);
-      else hipLaunchKernelGGL((zgemm3m_dma_kernel<4, 2, false>), dim3((N + 127) / 128, (M + 127) / 128), dim3(512), 3 * (128 + 128) * ZD_BK * 16, st, M, N, K,
-                              reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, 0);
-      MA_HIP(hipGetLastError());
-      return MA_OK;
-    }
-  }
-  if (use_3m) {
-    dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
-    // large updates draw their tiles XCD by XCD (see the kernel): a ring of counter blocks per device, one block per launch,
-    // zeroed at allocation and again by the last workgroup of the launch that used it
-    const int xcd_min_tiles = zm.xcd_min_tiles;                             // off unless asked for: it halves the fabric traffic and buys no time
-    unsigned* ctr = nullptr;
-    unsigned grid_draw = 0;
-    if (xcd_min_tiles > 0 && (long long)g3.x * g3.y >= xcd_min_tiles) {
+  if (dma && K % ZD_BK == 0) {
+    // more than 64 KB of LDS per workgroup: the limit is raised per function AND per device (a process may drive several)
+    {
+      static std::mutex mu;
+      static bool done[16] = {};
       int dev = 0;
       MA_HIP(hipGetDevice(&dev));
-      if (dev >= 0 && dev < 16) {
-        static std::mutex mu;
-        static unsigned* ring[16] = {};
-        static unsigned long long seq[16] = {};
-        static int ncu[16] = {};
-        std::lock_guard<std::mutex> lock(mu);
-        if (!ring[dev]) {
-          hipDeviceProp_t prop;
-          MA_HIP(hipGetDeviceProperties(&prop, dev));
-          ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-          MA_HIP(hipMalloc(&ring[dev], sizeof(unsigned) * 16 * 4096));
-          MA_HIP(hipMemset(ring[dev], 0, sizeof(unsigned) * 16 * 4096));
-          MA_HIP(hipDeviceSynchronize());
-        }
-        ctr = ring[dev] + 16 * (size_t)(seq[dev]++ % 4096ull);
-        grid_draw = (unsigned)std::min<long long>((long long)g3.x * g3.y, 2LL * ncu[dev]);
+      MA_REQUIRE(dev >= 0 && dev < 16, MA_ERR_UNSUPPORTED, "device index %d beyond the table", dev);
+      std::lock_guard<std::mutex> lock(mu);
+      if (!done[dev]) {
+        MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
+        MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zgemm3m_dma_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (64 + 128) * ZD_BK * 16));
+        done[dev] = true;
       }
     }
-    const bool one_tile = !zm.persist;
-    if (ctr && one_tile) hipLaunchKernelGGL(zgemm3m_sub_drawn_kernel, dim3(g3.x * g3.y), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
-                                reinterpret_cast<dc*>(C), ldc, ctr, 1);
-    else if (ctr) hipLaunchKernelGGL(zgemm3m_sub_drawn_kernel, dim3(grid_draw), dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
-                                reinterpret_cast<dc*>(C), ldc, ctr, 0);
-    else hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
-                            reinterpret_cast<dc*>(C), ldc);
+    // large updates: a one-dimensional grid, tiles dealt out XCD by XCD in blocks of 4 x 4 (see the kernel)
+    const int T22 = ((N + 127) / 128) * ((M + 63) / 64);
+    const bool xcd_order = T22 >= 512;
+    const dim3 g22 = xcd_order ? dim3(8 * ((T22 + 7) / 8), 1) : dim3((N + 127) / 128, (M + 63) / 64);
+    if (big) hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, true>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
+                                reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, xcd_order ? 1 : 0);
+    else hipLaunchKernelGGL((zgemm3m_dma_kernel<2, 2, false>), g22, dim3(256), 3 * (64 + 128) * ZD_BK * 16, st, M, N, K,
+                            reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc, xcd_order ? 1 : 0);
     MA_HIP(hipGetLastError());
     return MA_OK;
   }
-  dim3 grid((N + ZG_BN - 1) / ZG_BN, (M + ZG_BM - 1) / ZG_BM), block(512);
-  hipLaunchKernelGGL(zgemm_sub_kernel, grid, block, 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb,
-                     reinterpret_cast<dc*>(C), ldc);
+  dim3 g3((N + Z3_BN - 1) / Z3_BN, (M + Z3_BM - 1) / Z3_BM);
+  hipLaunchKernelGGL(zgemm3m_sub_kernel, g3, dim3(256), 0, st, M, N, K, reinterpret_cast<const dc*>(A), lda, reinterpret_cast<const dc*>(B), ldb, reinterpret_cast<dc*>(C), ldc);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

@@ -5,7 +5,7 @@
 #define LU_NB_MAX 128
 #define LU_REG_NB 32            /* panel width of lu_panel_reg_kernel: a row's entries live in 4 * LU_REG_NB vector registers */
 #define LU_BATCH_MAX 8          /* systems (slots) a plan keeps resources for */
-#define LU_GROUP_MAX 4          /* systems one panel kernel factors together (a wavefront each) / lock-step batch size of the public API */
+#define LU_GROUP_MAX 4          /* lock-step batch size of the public API */
 
 namespace ma {
 
@@ -21,9 +21,7 @@ struct LuPanelWs {
   unsigned long long* candrow;  // [2][max_blocks][2*LU_NB_MAX] candidate row of the panel
   unsigned long long* diagrow;  // [2][2*LU_NB_MAX]            current diagonal row of the panel
   int max_blocks;
-  int test_abort_col;           // test hook (MA_LU_TEST_ABORT_COL): the last workgroup gives up at this global column; -1 = off
-  int diag_sleep;               // diagnostic (MA_DIAG_PANEL_SLEEP=<q>): q x 0.21 us added to every column of the register panel kernel -- the
-                                // slope of the sweep's step time against the panel's time per column (profiles/r04_lu_schedule_experiments.md)
+  int test_abort_col;           // diagnostic build only (MA_LU_TEST_ABORT_COL): the last workgroup gives up at this global column; -1 = off
 };
 
 // Admission of a kernel whose workgroups wait for one another (all of them must be resident): see "Residency" in lu_kernels.hip.
@@ -41,10 +39,9 @@ struct SpinLaunch {
 unsigned* spin_error_word();            // device word raised by any spinning kernel that abandons a wait (NULL if it cannot be allocated)
 int spin_error_check(const char* what); // MA_ERR_HIP (and clears the word) if it is set; synchronous 4-byte copy
 
-size_t lu_panel_lds_bytes(int nb, int rpb);
 size_t lu_panel_granule_bytes(int max_blocks);
-int lu_panel_configure();
-int lu_launch_panel(c64* A, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, bool clear_tags, hipStream_t st);
+// the spinning partial-pivoting panel kernel (rows in registers, 256 rows per workgroup, <= LU_REG_NB columns); run_if_nonzero: a device
+// word, 0 = the kernel returns at once (the speculative panel ahead of it was accepted)
 int lu_launch_panel_reg(c64* A, int n, int k0, int nb, int nblk, int ncu, const LuPanelWs& ws, int* ipiv, int* lists, bool clear_tags, hipStream_t st,
                         c64* lrows = nullptr, int lcol0 = 0, const int* run_if_nonzero = nullptr);
 int lu_launch_lane_step2(c64* A, int n, int k0, int nb, const int* lists1, const int* lists2, int x0, int ncols, const int* ipiv, int* lists64, c64* invd, unsigned* poison,
@@ -65,25 +62,17 @@ struct LuSpecWs { c64* u11 = nullptr; c64* rinv = nullptr; double* pivmag = null
                   unsigned long long* stats = nullptr; /* the plan's counters: [0] half-panels tried, [1] rejected by the first attempt, [2] of those accepted by the widened one */ };
 int lu_launch_panel_spec(c64* A, int n, int k0, int nb, const LuSpecWs& ws, int* ipiv, int* lists, hipStream_t st, c64* lrows = nullptr, int lcol0 = 0,
                          bool optimistic = false, int* reject_info = nullptr);
-int lu_launch_panel_batch(int nsys, c64* const* As, int n, int k0, int nb, int rpb, int nblk, int ncu, const LuPanelWs* wss, int* const* ipivs, bool clear_tags, hipStream_t st);
 void lu_panel_forget_stream(int dev, hipStream_t st);
 int lu_launch_perm(const c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* invd, unsigned* poison, hipStream_t st);
 int lu_panel_slots_per_cu(size_t lds, int regs);
-int lu_panel_regs(int kind);   /* 0 lu_panel_kernel, 1 lu_panel_wave_kernel, 2 lu_panel_reg_kernel */
-int lu_panel_admissible(int nb, int rpb, int nblk, int ncu);
+int lu_panel_regs();           /* vector registers per lane of lu_panel_reg_kernel */
 int lu_launch_row_moves(c64* A, int n, int nb, const int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs, hipStream_t st);
-int lu_launch_block_row_moves(c64* A, int n, const int* lists, int lstride, int np, const int* k0s, const int* nbs, int x0, int x1, int y0, int y1, c64* B, int nrhs, const unsigned* poison, hipStream_t st);
 int lu_launch_swaps(c64* A, int n, int k0, int nb, const int* ipiv, int* lists, c64* tmp, int tstride, int x0, int x1, int y0, int y1, c64* B, int nrhs,
                     c64* invd, unsigned* poison, hipStream_t st);
 int lu_launch_trsm_mfma(const c64* T, int ldt, int nb, const c64* invd, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st);
-int lu_launch_block_trsm(const c64* A, int n, int np, const int* k0s, const int* nbs, const c64* invd, int invd_stride, c64* X, size_t ldx, int ncols, c64* B, size_t ldb, int nrhs, hipStream_t st);
 int lu_trsm_configure();
 int lu_launch_trsv(bool upper, const c64* T, int ldt, int nb, c64* B, size_t ldb, int nrhs, hipStream_t st);
-// which kernel family runs C -= A B (MA_ZGEMM_DMA / _TILE_ORDER / _XCD_TILES / _XCD_PERSIST): resolved once per plan, never per launch
-struct ZgemmMode { int dma = 1; bool tile_order = true; int xcd_min_tiles = 0; bool persist = false; };
-ZgemmMode zgemm_mode_from_env();
-int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool use_3m, bool big = false,
-                        const ZgemmMode* mode = nullptr);   // big: the trailing update on the caller's stream (its own kernel instantiation); mode NULL: the process-wide one
+int lu_launch_zgemm_sub(int M, int N, int K, const c64* A, size_t lda, const c64* B, size_t ldb, c64* C, size_t ldc, hipStream_t st, bool big = false, bool dma = true);
 int lu_launch_zgemv_sub(int M, int K, const c64* A, size_t lda, const c64* x, c64* y, hipStream_t st);
 int lu_launch_mfma_probe(double* out, int blocks, int iters, hipStream_t st);
 int lu_cumask_selfcheck(hipStream_t masked, int expect_cus, bool* ok);   // the masked stream uses exactly expect_cus CUs, spread evenly over the 8 XCDs

@@ -196,8 +196,13 @@ int ma_op_create_tbem_multi(const ma_mesh_t* mesh, const ma_physics_t* physics, 
   MA_REQUIRE(count > 0, MA_ERR_NO_DEVICE, "no gfx950 device visible");
   for (int g = 0; g < ndev; ++g) {
     MA_REQUIRE(devices[g] >= 0 && devices[g] < count, MA_ERR_INVALID, "device %d (entry %d) outside 0..%d", devices[g], g, count - 1);
-    // (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1: several shards on one GPU, so that a one-GPU box exercises the exchange)
-    for (int q = 0; q < g; ++q) MA_REQUIRE(devices[q] != devices[g] || getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES"), MA_ERR_INVALID, "device %d listed twice", devices[g]);
+#ifdef MA_DIAGNOSTICS
+    // diagnostic build only (MA_TEST_ALLOW_DUPLICATE_DEVICES=1): several shards on one GPU, so that a one-GPU box exercises the exchange
+    const bool dup_ok = getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES") != nullptr;
+#else
+    const bool dup_ok = false;
+#endif
+    for (int q = 0; q < g; ++q) MA_REQUIRE(devices[q] != devices[g] || dup_ok, MA_ERR_INVALID, "device %d listed twice", devices[g]);
   }
   ma_op* o = new (std::nothrow) ma_op(); MA_REQUIRE(o, MA_ERR_NOMEM, "host allocation failed");
   o->kind = 3; o->device = devices[0];
@@ -692,7 +697,7 @@ static int amg_prepare_coarse(ma_precond* M, hipStream_t st) {
   for (const AmgLevelDev& L : M->lv) epoch += ma_csr_epoch(L.A) + (L.P ? ma_csr_epoch(L.P) + ma_csr_epoch(L.R) : 0ull);
   if (M->coarse_tried && epoch == M->coarse_epoch) return MA_OK;
   M->coarse_tried = true; M->coarse_epoch = epoch; M->coarse_from = -1;
-  static const long long fuse_rows = [] { const char* e = getenv("MA_AMG_FUSE_ROWS"); return e ? atoll(e) : 0ll; }();   // off: a lone workgroup pays 3-4 us per dependent pass, more than the launches it replaces (profiles/r03_amg_cycle_variants.json)
+  constexpr long long fuse_rows = 0;   // off: a lone workgroup pays 3-4 us per dependent pass, more than the launches it replaces (profiles/r03_amg_cycle_variants.json)
   if (M->amg_smoother == 2 || fuse_rows <= 0 || M->lv.size() < 2) return MA_OK;
   size_t from = M->lv.size();
   while (from > 1 && M->lv[from - 1].n <= fuse_rows && (from == M->lv.size() || M->lv[from - 1].P)) --from;   // contiguous tail of small levels (never the finest)
@@ -894,7 +899,12 @@ int ma_precond_create_amg_from_csr(ma_csr_t* A, const ma_amg_config_t* cfg, ma_p
   if (rc) { for (ma_csr* h : owned) (void)ma_csr_destroy(h); return rc; }
   M->amg_owned = owned; M->amg_gc = gc; M->amg_oc = oc;
   M->amg_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (getenv("MA_AMG_TIMING")) fprintf(stderr, "[amg setup] read back %.0f, hierarchy %.0f, uploads + level vectors %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+#ifdef MA_DIAGNOSTICS
+  if (getenv("MA_AMG_TIMING"))                               // diagnostic build only
+#else
+  if (false)
+#endif
+    fprintf(stderr, "[amg setup] read back %.0f, hierarchy %.0f, uploads + level vectors %.0f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
                                        std::chrono::duration<double, std::milli>(t2 - t1).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
   *out = M; return MA_OK;
 }
@@ -1118,8 +1128,9 @@ int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stre
   }
   const bool amg_lazy = M->kind == 5 && amg_first_sweep_writes(M, 0);          // z = 0 is then written by the cycle's first sweep
   if (M->kind == 5 && M->amg_smoother != 2) {
-    // one graph launch per application once the same (z, r, level values) have been seen before (MA_AMG_GRAPH=0: always eager)
-    static const bool graphs = [] { const char* e = getenv("MA_AMG_GRAPH"); return e && atoi(e) != 0; }();   // off: measured 1.39 ms per replayed cycle against 1.06 ms eager
+    // one graph launch per application once the same (z, r, level values) have been seen before: OFF -- measured 1.39 ms per replayed
+    // cycle against 1.06 ms eager (profiles/r03_amg_cycle_variants.json); the capture code below stays for a runtime whose graph replay is cheaper
+    constexpr bool graphs = false;
     unsigned long long epoch = 0;
     for (const AmgLevelDev& L : M->lv) epoch += ma_csr_epoch(L.A) + (L.P ? ma_csr_epoch(L.P) + ma_csr_epoch(L.R) : 0ull);
     const bool same = M->g_z == d_z && M->g_r == d_r && M->g_epoch == epoch;

@@ -39,11 +39,6 @@ struct ma_bem_sweep {
   AsmSet sets[2];
   int32_t G = 0, spacing = 1; bool staged = false;
   ma_c64* dX = nullptr; int32_t* dinfo = nullptr;
-  // MA_SWEEP_ASM_STREAM (experiment, off by default): the assembly-ahead on a stream of its own -- 1: masked to the CUs the LU plan
-  // leaves to its panel kernels (their vector ALUs idle while a panel waits for its exchange; the far-pair kernel is ALU-bound and
-  // writes 16 bytes per 1.2 kflop), 2: unmasked. A whole set (three systems) is issued when its spares become free; the slot that
-  // takes a system makes the sweep's stream wait for the set's event.
-  hipStream_t asm_st = nullptr; hipEvent_t ev_gate = nullptr, ev_set[2] = {nullptr, nullptr};
   // timing of the last run (ma_bem_sweep_set_timing): events around the run and around every piece of assembly, on the sweep's stream
   bool timing = false;
   hipEvent_t ev_run[2] = {nullptr, nullptr};
@@ -66,19 +61,15 @@ struct ma_bem_sweep {
     for (hipEvent_t e : ev_asm) (void)hipEventDestroy(e);
     ev_asm.clear();
     for (auto& e : ev_run) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    if (asm_st) { (void)hipStreamSynchronize(asm_st); (void)hipStreamDestroy(asm_st); asm_st = nullptr; }
-    if (ev_gate) (void)hipEventDestroy(ev_gate);
-    for (auto& e : ev_set) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    ev_gate = nullptr;
     if (lu) ma_lu_plan_destroy(lu);
     lu = nullptr;
     if (own_stream && st) (void)hipStreamDestroy(st);
     st = nullptr;
   }
-  int asm_mark(hipStream_t on = nullptr) {                 // one event on the stream the assembly runs on, from the pool
+  int asm_mark() {                                         // one event on the sweep's stream, from the pool
     if (!timing) return MA_OK;
     if (ev_asm_used >= ev_asm.size()) { hipEvent_t e; MA_HIP(hipEventCreate(&e)); ev_asm.push_back(e); }
-    MA_HIP(hipEventRecord(ev_asm[ev_asm_used++], on ? on : st));
+    MA_HIP(hipEventRecord(ev_asm[ev_asm_used++], st));
     return MA_OK;
   }
 };
@@ -130,8 +121,7 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, in
   MA_REQUIRE(S, MA_ERR_NOMEM, "host allocation failed");
   S->plan = plan; S->device = device; S->n = n; S->cap = max_frequencies;
   if (slots < 1) slots = 3;
-  { const char* el = getenv("MA_LU_LANE_ALIAS"); const int max_slots = (el && atoi(el) >= 1) ? 6 : 4;     // experiment: two slots per lane stream
-    if (slots > max_slots) slots = max_slots; }
+  if (slots > 4) slots = 4;
   if (slots > max_frequencies) slots = max_frequencies;
   S->slots = slots;
   auto fail = [&](int code) { S->release(); delete S; return code; };
@@ -168,14 +158,11 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, in
   // ma_bem_plan_assemble_multi_part_dev (their far pairs share one pass over the quadrature points) in pieces of the far pairs'
   // rows, one piece per round in the rounds just before a slot begins: there the sum of the slots' updates is smallest and the
   // stream would wait for the slots' panel chains. What has not been issued when a system is needed is issued then. Only when the
-  // spares fit comfortably (MA_SWEEP_ASM_AHEAD=1: every system assembled when its slot begins) and when the slots take their
-  // systems in the order of the frequencies: slot s begins its j-th system at round s * spacing + j * G, which is monotone in the
-  // frequency index only while (slots - 1) * spacing < G -- a plan of one or two blocks (a few hundred rows) starts several slots
-  // in one round and a later frequency before an earlier one; there every system is assembled when its slot begins.
-  int ahead = 3;
-  if (const char* ea = getenv("MA_SWEEP_ASM_AHEAD")) ahead = std::max(1, std::min(3, atoi(ea)));
-  if (ahead > max_frequencies) ahead = std::max(1, (int)max_frequencies);
-  if (const char* ep = getenv("MA_SWEEP_ASM_PIECES")) S->ppp = std::max(1, std::min(16, atoi(ep)));
+  // spares fit comfortably and when the slots take their systems in the order of the frequencies (checked per run, with the run's own
+  // slot count: sweep_run): slot s begins its j-th system at round s * spacing + j * G, which is monotone in the frequency index only
+  // while (slots - 1) * spacing < G -- a plan of one or two blocks (a few hundred rows) starts several slots in one round and a later
+  // frequency before an earlier one; there every system is assembled when its slot begins.
+  int ahead = std::min<int>(3, std::max<int>(1, max_frequencies));
   if (!S->staged || !begins_in_order(S->G, slots, S->spacing)) ahead = 1;    // ( <=> (slots - 1) spacing < blocks: tests/test_capi_cpu.py )
   {
     size_t free_b = 0, total_b = 0;
@@ -188,21 +175,6 @@ int sweep_create(ma_bem_plan_t* plan, int32_t slots, int32_t max_frequencies, in
     if (!ok) { S->free_spares(); ahead = 1; (void)hipGetLastError(); }
   }
   S->ahead = ahead;
-  if (const char* ea = getenv("MA_SWEEP_ASM_STREAM")) {
-    const int mode = atoi(ea);
-    int32_t pcus = 0, ncus = 0;
-    if (mode > 0 && ahead > 1 && ma_lu_plan_cu_split(S->lu, &pcus, &ncus) == MA_OK) {
-      hipError_t e = hipSuccess;
-      if (mode == 1 && pcus > 0 && ncus % 32 == 0) {
-        std::vector<uint32_t> mask((size_t)ncus / 32, 0u);
-        for (int i = 0; i < pcus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-        e = hipExtStreamCreateWithCUMask(&S->asm_st, (uint32_t)mask.size(), mask.data());
-      } else e = hipStreamCreateWithFlags(&S->asm_st, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_gate, hipEventDisableTiming);
-      for (int q = 0; q < 2 && e == hipSuccess; ++q) e = hipEventCreateWithFlags(&S->ev_set[q], hipEventDisableTiming);
-      if (e != hipSuccess) { set_error("sweep: the assembly stream could not be made: %s", hipGetErrorString(e)); return fail(MA_ERR_HIP); }
-    }
-  }
   if (S->staged) {
     if (hipMalloc(&S->dX, sizeof(ma_c64) * (size_t)max_frequencies * (size_t)n) != hipSuccess || hipMalloc(&S->dinfo, sizeof(int32_t) * (size_t)max_frequencies) != hipSuccess) {
       set_error("sweep: the solutions of %d frequencies do not fit the device", max_frequencies);
@@ -247,53 +219,27 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     if (!r) r = S->asm_mark();
     return r;
   };
-  const int ahead = std::min(S->ahead, std::max(1, n_mine));
+  int32_t run_spacing = 1;
+  if (S->staged) (void)ma_lu_plan_stage_spacing(lu, slots, &run_spacing);
+  // (the order of the begins decides whether systems may be assembled ahead: with THIS run's slot count and spacing)
+  const int ahead = (S->staged && begins_in_order(S->G, slots, run_spacing)) ? std::min(S->ahead, std::max(1, n_mine)) : 1;
   const int ppp = S->ppp;
   const int nparts = ppp * ahead;
   AsmSet* sets = S->sets;
   for (int q = 0; q < 2; ++q) { sets[q].first = -1; sets[q].cnt = 0; sets[q].part = 0; sets[q].taken = 0; }
   auto set_idle = [](const AsmSet& t) { return t.first < 0 || t.taken == (1u << t.cnt) - 1u; };
-  auto start_job = [&](AsmSet& t, int first_i, int max_cnt = 3) {
-    t.first = first_i; t.cnt = std::min(std::min(ahead, max_cnt), n_mine - first_i); t.part = 0; t.taken = 0;
+  auto start_job = [&](AsmSet& t, int first_i) {
+    t.first = first_i; t.cnt = std::min(ahead, n_mine - first_i); t.part = 0; t.taken = 0;
     for (int q = 0; q < t.cnt; ++q) { physics_of(mine[(size_t)(first_i + q)], &t.ph[q], &t.bi[q]); t.br[q] = 0.0; }
   };
-  // Deferred finishes (ma_lu_plan_stage_finish_defer / _issue / _wait): with spares, a slot's next system arrives in OTHER buffers, so
-  // the backward substitution of the one it has just factored need not sit between its last block and the next system's first
-  // panels (314 short launches, 6 ms on the lane): it is issued behind the next system's first two block columns -- that system's
-  // first update is its largest, the lane waits for it anyway -- and the stream waits for it two rounds later, before the solution
-  // is parked and before any assembly may write the buffers again.
-  struct Pend { int stage = 0; int i = -1; void* x = nullptr; int round = 0; };
-  Pend pend[8];
-  // (measured neutral: 49.3 against 49.1 ms per frequency, 50.8 against 50.5 over 20 -- the lane is not what a slot's next system waits for;
-  // off unless MA_SWEEP_DEFER_FINISH=1)
-  const bool defer_ok = [&] { const char* e = getenv("MA_SWEEP_DEFER_FINISH"); return e && atoi(e) != 0; }();
-  auto collect = [&](int s) -> int {
-    Pend& p = pend[s];
-    int r = MA_OK;
-    if (p.stage == 1) { r = ma_lu_plan_stage_finish_issue(lu, s); if (!r) p.stage = 2; }
-    if (!r && p.stage == 2) {
-      r = ma_lu_plan_stage_finish_wait(lu, s, st);
-      if (!r && hipMemcpyAsync(S->dX + (size_t)p.i * (size_t)n, p.x, sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); r = MA_ERR_HIP; }
-      p.stage = 0;
-    }
-    return r;
-  };
-  auto collect_all = [&]() -> int { int r = MA_OK; for (int s = 0; s < 8 && !r; ++s) if (pend[s].stage) r = collect(s); return r; };
-  hipStream_t ast = S->asm_st ? S->asm_st : st;               // where the assembly-ahead runs
   auto issue_part = [&](AsmSet& t) -> int {
-    int r = collect_all();                                                  // no assembly writes a buffer whose backward substitution is still out
-    if (!r && S->asm_st && t.part == 0) {                                  // the spares are free from HERE on the sweep's stream: the assembly stream starts behind that point
-      if (hipEventRecord(S->ev_gate, st) != hipSuccess || hipStreamWaitEvent(S->asm_st, S->ev_gate, 0) != hipSuccess) { set_error("sweep: assembly stream gate failed"); r = MA_ERR_HIP; }
-    }
-    if (!r) r = S->asm_mark(ast);
-    if (!r) r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, ast);
+    int r = S->asm_mark();
+    if (!r) r = ma_bem_plan_assemble_multi_part_dev(plan, t.cnt, t.ph, t.br, t.bi, t.A, t.x, t.part, nparts, st);
     if (r) return r;
-    if (++t.part == nparts) {
+    if (++t.part == nparts)
       for (int q = 0; q < t.cnt && !r; ++q)
-        r = ma_bem_plan_incident_rhs_dev(plan, &t.ph[q], 0.0, t.bi[q], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, t.x[q], ast);
-      if (!r && S->asm_st && hipEventRecord(S->ev_set[&t == &sets[0] ? 0 : 1], S->asm_st) != hipSuccess) { set_error("sweep: assembly stream event failed"); r = MA_ERR_HIP; }
-    }
-    if (!r) r = S->asm_mark(ast);
+        r = ma_bem_plan_incident_rhs_dev(plan, &t.ph[q], 0.0, t.bi[q], a.incident_kind, a.incident_vec3, a.amp_re, a.amp_im, 1, t.x[q], st);
+    if (!r) r = S->asm_mark();
     return r;
   };
   // system of this device's i-th frequency into slot s
@@ -304,17 +250,12 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     if (!t) {
       for (int c = 0; c < 2; ++c) if (!t && set_idle(sets[c])) t = &sets[c];
       if (!t) return assemble(mine[(size_t)i], s);                           // neither set holds it and neither is free: this one directly (the order of a tiny plan)
-      // MA_SWEEP_FIRST_ALONE=1: the run's FIRST system travels alone, so that the first slot's panels start after one system's assembly
-      // instead of three's (measured: 50.35-50.55 against 50.17-50.36 ms over 20 steps -- the lone pass loses the shared geometry; off)
-      static const bool first_alone = [] { const char* e = getenv("MA_SWEEP_FIRST_ALONE"); return e && atoi(e) != 0; }();
-      const int c0 = (i == 0 && first_alone) ? 1 : 3;
-      start_job(*t, i, c0);
+      start_job(*t, i);
       AsmSet& o = t == &sets[0] ? sets[1] : sets[0];
       if (set_idle(o) && i + t->cnt < n_mine) start_job(o, i + t->cnt);     // the set after this one: in pieces, from now on
     }
     int r = MA_OK;
     while (t->part < nparts && !r) r = issue_part(*t);                       // not finished in the gaps: the rest now
-    if (!r && S->asm_st && hipStreamWaitEvent(st, S->ev_set[t == &sets[0] ? 0 : 1], 0) != hipSuccess) { set_error("sweep: waiting for the assembly stream failed"); r = MA_ERR_HIP; }
     if (r) return r;
     const int q = i - t->first;
     std::swap(dA[(size_t)s], t->A[q]); std::swap(dx[(size_t)s], t->x[q]);
@@ -328,10 +269,6 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
   };
   // after the updates of round r: one piece of the set being assembled, in the last ppp rounds before a slot begins
   auto assembly_tick = [&](int r, int spacing) -> int {
-    if (ahead > 1 && S->asm_st) {                                          // a stream of its own paces itself: everything that is free goes out now
-      for (int c = 0; c < 2; ++c) while (sets[c].first >= 0 && sets[c].part < nparts && sets[c].taken == 0) { int q = issue_part(sets[c]); if (q) return q; }
-      return MA_OK;
-    }
     if (ahead <= 1 || (r % spacing) < spacing - ppp) return MA_OK;
     AsmSet* pick = nullptr;                                                  // the unfinished set that is needed first
     for (int c = 0; c < 2; ++c) if (sets[c].first >= 0 && sets[c].part < nparts && sets[c].taken == 0 && (!pick || sets[c].first < pick->first)) pick = &sets[c];
@@ -343,12 +280,8 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
     rc = ma_lu_plan_stage_reset(lu, st);
     if (!rc && S->timing && hipEventRecord(S->ev_run[0], st) != hipSuccess) { set_error("sweep: event record failed"); rc = MA_ERR_HIP; }
     std::vector<int> off((size_t)slots);
-    int32_t spacing = std::max(1, (G + slots) / (slots + 1));
-    (void)ma_lu_plan_stage_spacing(lu, slots, &spacing);
-    if (const char* es = getenv("MA_STAGE_SPACING")) { const int v = atoi(es); if (v >= 1) spacing = v; }   // diagnostic
+    const int32_t spacing = run_spacing;
     for (int s = 0; s < slots; ++s) off[(size_t)s] = s * spacing;
-    int issue_g = 1;                                             // the block of the NEXT system after whose round a deferred backward substitution is issued
-    if (const char* eg = getenv("MA_SWEEP_DEFER_BLOCK")) issue_g = std::max(0, std::min(4, atoi(eg)));
     for (int r = 0; !rc; ++r) {
       int32_t sl[8], bl[8]; int cnt = 0; bool live = false;
       for (int s = 0; s < slots && !rc; ++s) {
@@ -367,22 +300,13 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
       if (cnt) rc = ma_lu_plan_stage_round(lu, cnt, sl, bl, st);
       for (int q = 0; q < cnt && !rc; ++q) {
         const int s = sl[q], i = s + slots * ((r - off[(size_t)s]) / G);
-        if (bl[q] == issue_g && pend[s].stage == 1) { rc = ma_lu_plan_stage_finish_issue(lu, s); pend[s].stage = 2; pend[s].round = r; }
-        if (bl[q] != G - 1 || rc) continue;
-        if (defer_ok && ahead > 1 && i + slots < n_mine && G > issue_g + 2) {   // the slot has a next system, which arrives in other buffers
-          if (pend[s].stage) rc = collect(s);
-          if (!rc) rc = ma_lu_plan_stage_finish_defer(lu, s, st);
-          if (!rc) { pend[s].stage = 1; pend[s].i = i; pend[s].x = dx[(size_t)s]; pend[s].round = r; }
-        } else {
-          rc = ma_lu_plan_stage_finish(lu, s, st);
-          if (!rc && hipMemcpyAsync(dX + (size_t)i * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
-        }
+        if (bl[q] != G - 1) continue;
+        rc = ma_lu_plan_stage_finish(lu, s, st);
+        if (!rc && hipMemcpyAsync(dX + (size_t)i * (size_t)n, dx[(size_t)s], sizeof(ma_c64) * (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("sweep: parking a solution failed"); rc = MA_ERR_HIP; }
         if (!rc) rc = ma_lu_plan_stage_info_dev(lu, s, dinfo + i, st);
       }
-      for (int s = 0; s < slots && !rc; ++s) if (pend[s].stage == 2 && r >= pend[s].round + 2) rc = collect(s);
       if (!rc) rc = assembly_tick(r, spacing);
     }
-    if (!rc) rc = collect_all();
     if (!rc && S->timing && hipEventRecord(S->ev_run[1], st) != hipSuccess) { set_error("sweep: event record failed"); rc = MA_ERR_HIP; }
     if (!rc) {
       int stt = ma_lu_plan_status(lu, st);                     // synchronises; an abandoned panel (poisoned plan) surfaces here
@@ -619,8 +543,13 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
   MA_REQUIRE(count > 0, MA_ERR_NO_DEVICE, "no gfx950 device visible");
   for (int d = 0; d < ndev; ++d) {
     MA_REQUIRE(devices[d] >= 0 && devices[d] < count, MA_ERR_INVALID, "device %d (entry %d) outside 0..%d", devices[d], d, count - 1);
-    // (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES=1: several host threads on one GPU, so that a one-GPU box exercises the sharding)
-    for (int o = 0; o < d; ++o) MA_REQUIRE(devices[o] != devices[d] || getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES"), MA_ERR_INVALID, "device %d listed twice", devices[d]);
+#ifdef MA_DIAGNOSTICS
+    // diagnostic build only (MA_TEST_ALLOW_DUPLICATE_DEVICES=1): several host threads on one GPU, so that a one-GPU box exercises the sharding
+    const bool dup_ok = getenv("MA_TEST_ALLOW_DUPLICATE_DEVICES") != nullptr;
+#else
+    const bool dup_ok = false;
+#endif
+    for (int o = 0; o < d; ++o) MA_REQUIRE(devices[o] != devices[d] || dup_ok, MA_ERR_INVALID, "device %d listed twice", devices[d]);
   }
   const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im};
   std::vector<int> rcs((size_t)ndev, MA_OK);

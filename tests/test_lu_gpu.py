@@ -26,48 +26,28 @@ def test_zgemm_sub_kernel(gpu, M, N, K):
     A = rng.standard_normal((M, K)) + 1j * rng.standard_normal((M, K))
     B = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
     Cm = rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))
-    got = ma.test_zgemm_sub(A, B, Cm)
+    got = ma.zgemm_sub(A, B, Cm)
     ref = Cm - A @ B
     assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 128, 8), (65, 129, 16), (1, 1, 8), (300, 70, 384), (129, 1000, 24), (1000, 1000, 64), (2100, 4100, 16), (40, 66000, 8)])
-def test_zgemm_dma_kernels_are_bitwise_the_register_staged_one(gpu, M, N, K):
+def test_zgemm_dma_kernel_is_bitwise_the_register_staged_one(gpu, M, N, K):
     """K a multiple of 8: the update runs in zgemm3m_dma_kernel (operands global -> LDS by LDS-DMA, 32 x 64 of C per wavefront);
-    MA_ZGEMM_DMA=0 is the register-staged zgemm3m_sub_kernel (the kernel for ragged K), =2 the 128 x 128-tile form. Every entry of C
-    accumulates the same products in the same order in all three: equal bits, ragged edges included (rows and columns beyond the
-    matrix are fetched from the last valid one and never stored)."""
+    MA_ZGEMM_DMA=0 is the register-staged zgemm3m_sub_kernel (the kernel for ragged K). Every entry of C accumulates the same products in
+    the same order in both: equal bits, ragged edges included (rows and columns beyond the matrix are fetched from the last valid one
+    and never stored); from 512 tiles on the tiles are dealt out XCD by XCD in blocks of 4 x 4 (the last two shapes)."""
     rng = np.random.default_rng(M * 3 + N * 5 + K)
     A = rng.standard_normal((M, K)) + 1j * rng.standard_normal((M, K))
     B = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
     Cm = rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))
     ref = Cm - A @ B
     got = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1):
         with _with_env(MA_ZGEMM_DMA=mode):
-            got[mode] = ma.test_zgemm_sub(A, B, Cm)
+            got[mode] = ma.zgemm_sub(A, B, Cm)
         assert np.abs(got[mode] - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
-    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
-    # from 512 tiles on the tiles are dealt out XCD by XCD in blocks of 4 x 4 (a one-dimensional grid): every tile once, the same bits
-    with _with_env(MA_ZGEMM_DMA=1, MA_ZGEMM_TILE_ORDER=0):
-        assert np.array_equal(ma.test_zgemm_sub(A, B, Cm), got[0])
-
-
-@pytest.mark.parametrize("M,N,K,persist", [(700, 1100, 64, 0), (1300, 900, 256, 0), (515, 2100, 40, 1), (64, 64, 8, 0)])
-def test_zgemm_sub_kernel_drawing_its_tiles(gpu, M, N, K, persist):
-    """Large updates draw their tiles XCD by XCD (8 x 8 blocks of tiles per XCD, counters per launch, stealing when an XCD runs
-    dry; lu_kernels.hip): every tile exactly once whatever the placement, ragged edges, blocks that are partly outside the
-    matrix, and the counters are left at zero for the launch that reuses them (the same shape twice)."""
-    rng = np.random.default_rng(M + N + K)
-    A = rng.standard_normal((M, K)) + 1j * rng.standard_normal((M, K))
-    B = rng.standard_normal((K, N)) + 1j * rng.standard_normal((K, N))
-    Cm = rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))
-    ref = Cm - A @ B
-    with _with_env(MA_ZGEMM_XCD_TILES=1, MA_ZGEMM_XCD_PERSIST=persist):
-        for _ in range(2):
-            got = ma.test_zgemm_sub(A, B, Cm)
-            assert np.abs(got - ref).max() <= 1e-12 * K * max(1.0, np.abs(ref).max())
-    assert np.array_equal(ma.test_zgemm_sub(A, B, Cm), got)      # the plain tile order gives the same bits: tiles are independent
+    assert np.array_equal(got[0], got[1])
 
 
 def test_lu_solve_real_2x2(gpu):            # lu.rs:163-175
@@ -115,14 +95,16 @@ def test_lu_random_matches_lapack(gpu, n):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-13 * kappa
 
 
+@pytest.mark.parametrize("spec", [1, 0])
 @pytest.mark.parametrize("n", [33, 65, 66, 70, 97, 129, 130, 193, 777, 1500])
-def test_pair_panels_match_lapack(gpu, n):
-    """The schedule of the 4 096-16 384-row plans at small sizes (MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64): a 64-column panel as two
-    register half-panels, lu_lane_step_kernel between them, lu_lane_step2_kernel after them, ragged last panels and strips of 1, 2,
-    4, 6 columns (where the step kernel once read L10 from rows another workgroup was permuting). LAPACK's pivots, LAPACK's solution."""
+def test_pair_panels_match_lapack(gpu, n, spec):
+    """A 64-column panel as two half-panels, lu_lane_step_kernel between them, lu_lane_step2_kernel after them, ragged last panels and
+    strips of 1, 2, 4, 6 columns (where the step kernel once read L10 from rows another workgroup was permuting), with the big updates
+    on the masked stream (MA_LU_CU_SPLIT=64) -- with the speculative panels ahead of the spinning kernel (rejected on this data, so the
+    restore path runs at every panel) and without them. LAPACK's pivots, LAPACK's solution."""
     import scipy.linalg as sla
     A, b = _rand(n, 4000 + n)
-    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64):
+    with _with_env(MA_LU_CU_SPLIT=64, MA_LU_SPECULATE=spec):
         x, piv = ma.zgesv(A, b, return_pivots=True)
     _, piv_ref = sla.lu_factor(A)
     assert np.array_equal(piv, piv_ref)
@@ -130,28 +112,6 @@ def test_pair_panels_match_lapack(gpu, n):
     res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
     assert res <= 1e-14 * n
     assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-13 * (np.linalg.cond(A) if n <= 400 else 1e4)
-
-
-@pytest.mark.parametrize("n", [66, 130, 450, 777, 1500, 2100])
-def test_block_step_matches_lapack(gpu, n):
-    """MA_LU_BLOCK_STEP=1 (round 4; built, measured neutral, off by default): the main lane's per-panel launches of a block of six
-    64-column panels -- 12 gathers / scatters, 6 triangular solves, 6 zgemv, 5 in-block updates -- as lu_block_row_moves_kernel (every
-    panel's interchanges on a strip of columns, panel after panel) + lu_block_trsm_kernel (U12 of the whole block row left-looking on
-    the matrix cores, the right-hand side riding along) + one zgemv: LAPACK's pivots and solution; ragged last panels and blocks."""
-    import scipy.linalg as sla
-    A, b = _rand(n, 5000 + n)
-    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64, MA_LU_BLOCK_STEP=1):
-        x, piv = ma.zgesv(A, b, return_pivots=True)
-        F = ma.LuFactorization(A)                            # the stored factors serve later right-hand sides (the row order of L is LAPACK's)
-        x2 = F.solve(2.0 * b)
-        F.close()
-    _, piv_ref = sla.lu_factor(A)
-    assert np.array_equal(piv, piv_ref)
-    xr = np.linalg.solve(A, b)
-    res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
-    assert res <= 1e-14 * n
-    assert np.linalg.norm(x - xr) / np.linalg.norm(xr) <= 1e-13 * (np.linalg.cond(A) if n <= 400 else 1e4)
-    assert np.linalg.norm(x2 - 2.0 * xr) / np.linalg.norm(xr) <= 1e-12 * (np.linalg.cond(A) if n <= 400 else 1e4)
 
 
 def test_split_plan_refuses_the_null_stream_for_its_staged_schedule(gpu):
@@ -159,7 +119,7 @@ def test_split_plan_refuses_the_null_stream_for_its_staged_schedule(gpu):
     a driver on the NULL stream would serialise against every update and silently lose the lanes' overlap: stage_reset / stage_begin
     say so (MA_ERR_INVALID) instead."""
     import torch
-    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64):
+    with _with_env(MA_LU_CU_SPLIT=64):
         lu = ma.LuPlan(900)
     assert lu.main_stream()
     with pytest.raises(ma.MaError) as e:
@@ -174,8 +134,8 @@ def test_split_plan_refuses_the_null_stream_for_its_staged_schedule(gpu):
 
 
 def test_default_schedule_of_a_4200_row_plan(gpu):
-    """4 096-16 384 rows: the plan splits the chip by default (ma_lu_plan_main_stream is the masked update stream) and factors with
-    the register pair panels and the LDS-DMA update kernel; pivots and solution against LAPACK at a size inside that range."""
+    """4 096-16 384 rows: the plan splits the chip by default (ma_lu_plan_main_stream is the masked update stream); pivots and
+    solution against LAPACK at a size inside that range."""
     import scipy.linalg as sla
     n = 4200
     A, b = _rand(n, 4200)
@@ -189,7 +149,7 @@ def test_default_schedule_of_a_4200_row_plan(gpu):
     res = np.linalg.norm(A @ x - b) / (np.linalg.norm(A) * np.linalg.norm(x))
     assert res <= 1e-14 * n
     small = ma.LuPlan(900)
-    assert not small.main_stream()                          # outside the range: the round-2 schedule on the whole chip
+    assert not small.main_stream()                          # outside the range: the whole chip for everything
     small.close()
 
 
@@ -230,18 +190,14 @@ def test_lu_on_bem_system_matches_oracle(gpu):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
 
 
-@pytest.mark.parametrize("batch_panel", [1, 0])
-def test_batched_factor_solve_is_bitwise_the_single_one(gpu, batch_panel):
-    """Frequencies in flight: factoring independent systems together must not change any of them. batch_panel = 1: one panel
-    kernel walks the systems round-robin inside every column (lu_panel_batch_kernel, 32-column panels) -- each system's
-    arithmetic is the single-system kernel's at that panel width, whatever the rows per workgroup; batch_panel = 0: a panel
-    kernel per system, interleaved."""
+def test_batched_factor_solve_is_bitwise_the_single_one(gpu):
+    """Frequencies in flight: factoring independent systems together (a lane per system, the big updates back to back on the caller's
+    stream) must not change any of them."""
     import torch
     n = 900
     dev = torch.device("cuda", 0)
     mats = [_rand(n, 100 + i) for i in range(3)]
-    with _with_env(MA_LU_NB=32 if batch_panel else 64, MA_LU_BATCH_PANEL=batch_panel):
-        lu = ma.LuPlan(n)                                  # the switches are read once per plan
+    lu = ma.LuPlan(n)
     st = torch.cuda.current_stream().cuda_stream
     singles = []
     for A, b in mats:
@@ -311,17 +267,15 @@ def test_lu_factorize_then_solve_and_lu_solve(gpu, n):
     assert e.value.status == ma.MA_ERR_SINGULAR
 
 
-_SCHEDULES = {"default": {}, "pair": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64}, "pair_tail": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64, "MA_LU_TAIL_ROWS": 400},
-              "pair_block": {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64, "MA_LU_BLOCK_STEP": 1}}
+_SCHEDULES = {"whole_chip": {}, "split_64": {"MA_LU_CU_SPLIT": 64}, "split_32_no_speculation": {"MA_LU_CU_SPLIT": 32, "MA_LU_SPECULATE": 0}}
 
 
-@pytest.mark.parametrize("sched", ["default", "pair", "pair_tail", "pair_block"])
+@pytest.mark.parametrize("sched", ["whole_chip", "split_64", "split_32_no_speculation"])
 def test_staged_pipeline_is_bitwise_the_single_solve(gpu, sched):
     """The staged plan API (slots at their own block index, staggered by a fraction of a factorisation) runs the same kernels on
-    the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit. `pair`: the
-    schedule plans of 4 096-16 384 rows get by default (64-column panels as two register half-panels, the fused step kernels, the
-    big updates on a stream masked off 64 CUs, which the driver then uses as its own); `pair_tail`: with the last blocks' whole
-    updates on the lanes."""
+    the same data as a single factor+solve: seven systems through three slots, every factor and solution bit for bit -- on the whole
+    chip, and with the big updates on a stream masked off 64 / 32 CUs (what plans of 4 096-16 384 rows get by default), which the
+    driver then uses as its own."""
     import torch
     n = 900
     dev = torch.device("cuda", 0)
@@ -329,7 +283,7 @@ def test_staged_pipeline_is_bitwise_the_single_solve(gpu, sched):
     with _with_env(**_SCHEDULES[sched]):
         lu = ma.LuPlan(n)
     st = torch.cuda.current_stream().cuda_stream
-    if sched != "default":
+    if sched != "whole_chip":
         assert lu.main_stream()
         st = lu.main_stream()
     singles = []
@@ -383,80 +337,9 @@ def test_staged_pipeline_is_bitwise_the_single_solve(gpu, sched):
     lu.close()
 
 
-def test_staged_groups_are_bitwise_the_single_solve(gpu):
-    """The staged API with GROUPS: two groups of three slots, each group in lock step with ONE panel kernel per panel for its
-    three systems (lu_panel_wave_kernel, a wavefront per system, 32-column panels), the groups staggered by half a
-    factorisation. Twelve systems; every factor and solution bit for bit what a single factor+solve with 32-column panels gives."""
-    import torch
-    n = 900
-    dev = torch.device("cuda", 0)
-    mats = [_rand(n, 500 + i) for i in range(12)]
-    st = torch.cuda.current_stream().cuda_stream
-    with _with_env(MA_LU_NB=32):
-        lu1 = ma.LuPlan(n)
-    singles = []
-    for A, b in mats:
-        dA = torch.tensor(A, device=dev).reshape(-1); db = torch.tensor(b, device=dev)
-        lu1.factor_solve_dev(dA.data_ptr(), db.data_ptr(), 1, st)
-        assert lu1.status(st) == ma.MA_OK
-        singles.append((dA.cpu().numpy().copy(), db.cpu().numpy().copy()))
-    lu1.close()
-    lu = ma.LuPlan(n)
-    gsz, U = 3, 2
-    lu.stage_set_group(gsz)
-    G = lu.num_blocks()
-    S = gsz * U
-    bufA = [torch.empty(n * n, dtype=torch.complex128, device=dev) for _ in range(S)]
-    bufB = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(S)]
-    srcA = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; srcB = [torch.tensor(b, device=dev) for _, b in mats]
-    outA = [None] * len(mats); outB = [None] * len(mats)
-    off = [u * (G // U) for u in range(U)]
-    lu.stage_reset(st)
-    r = 0
-    while True:
-        sl, bl, live = [], [], False
-        for u in range(U):
-            lr = r - off[u]
-            if lr < 0:
-                live = True
-                continue
-            sysno, g = divmod(lr, G)
-            base = (u + U * sysno) * gsz
-            if base + gsz > len(mats):
-                continue
-            live = True
-            if g == 0:
-                for t in range(gsz):
-                    s_ = u * gsz + t
-                    bufA[s_].copy_(srcA[base + t]); bufB[s_].copy_(srcB[base + t])
-                    lu.stage_begin(s_, bufA[s_].data_ptr(), bufB[s_].data_ptr(), 1, st)
-                lu.stage_begin_group(u * gsz, st)
-            for t in range(gsz):
-                sl.append(u * gsz + t); bl.append(g)
-        if not live:
-            break
-        if sl:
-            lu.stage_round(sl, bl, st)
-        for s_, g in zip(sl, bl):
-            if g == G - 1:
-                lu.stage_finish(s_, st)
-                u, t = divmod(s_, gsz)
-                idx = (u + U * ((r - off[u]) // G)) * gsz + t
-                outA[idx] = bufA[s_].clone(); outB[idx] = bufB[s_].clone()
-        r += 1
-    assert lu.status(st) == ma.MA_OK
-    for i, (Af, xf) in enumerate(singles):
-        assert np.array_equal(outA[i].cpu().numpy(), Af), i
-        assert np.array_equal(outB[i].cpu().numpy(), xf), i
-    with pytest.raises(ma.MaError):
-        lu.stage_round([0, 1], [0, 0], st)                 # a group must appear whole
-    lu.close()
-
-
-def test_lu_tall_system_switches_panel_width(gpu):
-    """Above 36 352 rows a 64-column panel no longer fits the LDS of the co-resident workgroups: the factorisation starts with
-    32-column panels (8 per trailing update) and widens to 64 once the remaining rows fit. 36 900 rows cross that boundary;
-    the residual of the device solve is checked with a device matvec (21 GB matrix + copy: everything stays in HBM)."""
+def test_lu_tall_system(gpu):
+    """36 900 rows: 145 workgroups of the spinning panel kernel co-resident from the first column on (one per CU), 577 panels; the
+    residual of the device solve is checked with a device matvec (21 GB matrix + copy: everything stays in HBM)."""
     import torch
     n = 36900
     dev = torch.device("cuda", 0)
@@ -493,42 +376,68 @@ def _with_env(**kv):
     return cm()
 
 
-@pytest.mark.parametrize("batch_panel", [0, 1])
-def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu, batch_panel):
+def _run_with_diagnostic_library(code, env=None, timeout=600):
+    """Run `code` in a process of its own with the DIAGNOSTIC build of the library (make -C math_audio_amd/csrc diag: -DMA_DIAGNOSTICS;
+    the shipped library has no test hooks) loaded through MA_LIB_PATH. Returns the CompletedProcess."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "math_audio_amd", "lib", "libmathaudio_hip_diag.so")
+    assert os.path.exists(diag), "build it with `make -C math_audio_amd/csrc diag` (__graft_entry__.build() does)"
+    pre = "import os, sys\nsys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\nimport torch; torch.cuda.is_available()\n" % (root, root)
+    e = dict(os.environ, MA_LIB_PATH=diag)
+    e.update({k: str(v) for k, v in (env or {}).items()})
+    return subprocess.run([sys.executable, "-c", pre + code], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu):
     """The failure path behind the round-1 memory fault (DESIGN 4 "Residency", lu_kernels.hip): a panel kernel whose exchange
     does not complete must (1) make every workgroup of every panel kernel of the plan leave at once -- the poison word is
     read in every poll, no 4 s wait per workgroup --, (2) leave identity pivots behind, so that the interchange kernels,
     which are already enqueued, move no rows, (3) surface as MA_ERR_HIP, and (4) leave the plan usable after the next
-    factorisation clears the word. The test hook makes the last workgroup of the panel that owns global column 200 give up
-    in a 3-system batch of 11 panels each; every later kernel of all three systems still runs, on garbage but in bounds."""
-    import time
+    factorisation clears the word. The hook of the DIAGNOSTIC build (MA_LU_TEST_ABORT_COL; the shipped library has none) makes the
+    last workgroup of the panel that owns global column 200 give up in a 3-system batch of 11 panels each; every later kernel of all
+    three systems still runs, on garbage but in bounds."""
     import torch
-    n = 700
-    dev = torch.device("cuda", 0)
-    st = torch.cuda.current_stream().cuda_stream
-    mats = [_rand(n, 300 + i) for i in range(3)]
-    with _with_env(MA_LU_TEST_ABORT_COL=200, MA_LU_BATCH_PANEL=batch_panel):      # 1: one panel kernel for the three systems, a wavefront each
-        lu = ma.LuPlan(n)
-    dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
-    guard = torch.full((1 << 20,), 7.0, dtype=torch.float64, device=dev)       # a canary allocated right after the operands
-    t0 = time.perf_counter()
-    lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
-    rc = lu.status(st)
-    dt = time.perf_counter() - t0
-    assert rc == ma.MA_ERR_HIP
-    assert b"abandoned" in ma.lib().ma_last_error_string()
-    assert dt < 2.0, dt                                    # nobody sat out the 4 s limit
-    assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
-    lu.close()
-    # the same three systems on a plan without the hook: bit for bit the single solves
-    lu = ma.LuPlan(n)
-    dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
-    lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
-    assert lu.status(st) == ma.MA_OK
-    for (A, b), db in zip(mats, dbs):
-        x = db.cpu().numpy()
-        assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-11
-    lu.close()
+    code = r'''
+import time, numpy as np
+import math_audio_amd as ma
+n = 700
+rng = np.random.default_rng(300)
+mats = [(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)), rng.standard_normal(n) + 1j * rng.standard_normal(n)) for _ in range(3)]
+dev = torch.device("cuda", 0)
+st = torch.cuda.current_stream().cuda_stream
+lu = ma.LuPlan(n)
+dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
+guard = torch.full((1 << 20,), 7.0, dtype=torch.float64, device=dev)       # a canary allocated right after the operands
+t0 = time.perf_counter()
+lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
+rc = lu.status(st)
+dt = time.perf_counter() - t0
+assert rc == ma.MA_ERR_HIP, rc
+assert b"abandoned" in ma.lib().ma_last_error_string()
+assert dt < 2.0, dt                                    # nobody sat out the 4 s limit
+assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
+# the next factorisation clears the word: the same plan, same systems
+dAs = [torch.tensor(A, device=dev).reshape(-1) for A, _ in mats]; dbs = [torch.tensor(b, device=dev) for _, b in mats]
+os.environ.pop("MA_LU_TEST_ABORT_COL")
+lu.close()
+lu = ma.LuPlan(n)
+lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
+assert lu.status(st) == ma.MA_OK
+for (A, b), db in zip(mats, dbs):
+    x = db.cpu().numpy()
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-11
+lu.close()
+print("ok")
+'''
+    r = _run_with_diagnostic_library(code, {"MA_LU_TEST_ABORT_COL": 200})
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    # the shipped library has no such switch: the same variable changes nothing
+    n = 300
+    A, b = _rand(n, 12)
+    with _with_env(MA_LU_TEST_ABORT_COL=100):
+        x = ma.zgesv(A, b)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-11
 
 
 def test_nan_column_and_tiny_pivot_inside_a_batch(gpu):
@@ -564,20 +473,17 @@ def test_nan_column_and_tiny_pivot_inside_a_batch(gpu):
     assert np.linalg.norm(A2 @ x - b2) / np.linalg.norm(b2) < 1e-6
 
 
-def test_round1_fault_configuration_now_runs(gpu):
-    """MA_LU_RPB=32 with 128-column panels and three systems in flight is the configuration of gpurun_out/bench_rpb32.log
-    (70 KB of LDS per spinning workgroup). The old admission counted floor(160 KB / 70 KB) = 2 slots per CU and let two
-    256-workgroup grids in; the fragmentation-safe count is 1 (lu_kernels.hip "Residency"), so the grids now run one at a
-    time -- and complete."""
+def test_three_tall_systems_in_flight(gpu):
+    """Three 6 000-row systems in lock step: three grids of 24 spinning panel workgroups each go through the admission window together
+    (random data: every speculative panel is rejected, so the spinning kernel factors every half-panel) -- and complete."""
     import torch
     n = 6000
     dev = torch.device("cuda", 0)
-    st = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator(device=dev); gen.manual_seed(5)
     As = [torch.randn(n, n, dtype=torch.complex128, device=dev, generator=gen) for _ in range(3)]
     bs = [torch.randn(n, dtype=torch.complex128, device=dev, generator=gen) for _ in range(3)]
-    with _with_env(MA_LU_RPB=32, MA_LU_NB=128):
-        lu = ma.LuPlan(n)
+    lu = ma.LuPlan(n)
+    st = lu.main_stream() or torch.cuda.current_stream().cuda_stream
     dAs = [A.clone().reshape(-1) for A in As]; dbs = [b.clone() for b in bs]
     lu.factor_solve_batch_dev([t.data_ptr() for t in dAs], [t.data_ptr() for t in dbs], 1, st)
     assert lu.status(st) == ma.MA_OK, ma.lib().ma_last_error_string()

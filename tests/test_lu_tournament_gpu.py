@@ -136,12 +136,9 @@ def test_tournament_on_bem_system_matches_oracle(gpu):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
 
 
-def test_tournament_plan_reports_its_mode_and_refuses_groups(gpu):
+def test_plans_report_their_mode(gpu):
     lu = ma.LuPlan(900, pivoting="tournament")
-    assert lu.pivoting() == "tournament"
-    with pytest.raises(ma.MaError) as e:
-        lu.stage_set_group(2)                                 # slot groups share ONE partial-pivoting panel kernel
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED
+    assert lu.pivoting() == "tournament" and lu.speculation() == "verified"
     lu.close()
     lu = ma.LuPlan(900)
     assert lu.pivoting() == "partial"                        # what every entry that hands pivots across the boundary uses
@@ -282,7 +279,7 @@ def test_speculative_panel_accepted_is_lapacks_factorisation(gpu, n, pivoting):
     with the speculation switched off (MA_LU_SPECULATE=0: the spinning partial-pivoting kernel / the tournament chose the same rows)."""
     import scipy.linalg as sla
     A, b = _block_dominant(n, 100 + n)
-    env = {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
+    env = {"MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
     x, LU, (acc, wid, rej) = _solve_on_plan(A, b, pivoting, env)
     assert rej == 0 and wid == 0 and acc == (n + 31) // 32, (acc, wid, rej)
     x0, LU0, st0 = _solve_on_plan(A, b, pivoting, dict(env, MA_LU_SPECULATE=0))
@@ -308,7 +305,7 @@ def test_speculative_panel_widened_attempt_and_fallback(gpu, pivoting, below):
     for t in range(below):
         A[1500 + 7 * t, 300] = 400.0 + 10.0 * t
     A[1024, 1000] = 300.0
-    env = {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
+    env = {"MA_LU_CU_SPLIT": 64} if pivoting == "partial" else {}
     x, LU, (acc, wid, rej) = _solve_on_plan(A, b, pivoting, env)
     assert acc + wid + rej == (n + 31) // 32
     if below <= 3:
@@ -334,11 +331,11 @@ def test_speculative_panel_on_random_matrices_is_rejected_and_harmless(gpu):
     from test_lu_gpu import _with_env
     n = 1500
     A, b = _rand(n, 31)
-    with _with_env(MA_LU_REG_PANEL=2, MA_LU_CU_SPLIT=64):
+    with _with_env(MA_LU_CU_SPLIT=64):
         x, piv = ma.zgesv(A, b, return_pivots=True)
     _, piv_ref = sla.lu_factor(A)
     assert np.array_equal(piv, piv_ref)
-    _, _, (acc, wid, rej) = _solve_on_plan(A, b, "partial", {"MA_LU_REG_PANEL": 2, "MA_LU_CU_SPLIT": 64})
+    _, _, (acc, wid, rej) = _solve_on_plan(A, b, "partial", {"MA_LU_CU_SPLIT": 64})
     assert rej >= 38 and acc + wid <= 9, (acc, wid, rej)     # (the last panels have few rows below them)
 
 
@@ -371,12 +368,6 @@ def test_optimistic_speculation_reports_retry_and_the_verified_mode_solves(gpu):
     rc, xd, LUd = solve(Ad, bd)
     assert rc == ma.MA_OK and np.array_equal(xd, xd_opt) and np.array_equal(LUd, LUd_opt)
     lu.close()
-    small = ma.LuPlan(900)                                    # no half-panel pairs: nothing to speculate with
-    assert small.speculation() == "off"
-    with pytest.raises(ma.MaError) as e:
-        small.set_speculation("optimistic")
-    assert e.value.status == ma.MA_ERR_UNSUPPORTED
-    small.close()
 
 
 def test_sweep_solves_a_rejected_frequency_again(gpu):
@@ -384,14 +375,10 @@ def test_sweep_solves_a_rejected_frequency_again(gpu):
     the verified mode. No Burton-Miller operator has produced one, so the DIAGNOSTIC build of the library (make diag: -DMA_DIAGNOSTICS,
     loaded with MA_LIB_PATH in a process of its own) marks one frequency as rejected after the pipeline has drained: the sweep's
     solutions are the same with and without it (the other frequencies bit for bit)."""
-    import os, subprocess, sys, tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    diag = os.path.join(root, "math_audio_amd", "lib", "libmathaudio_hip_diag.so")
-    assert os.path.exists(diag), "build it with `make -C math_audio_amd/csrc diag` (__graft_entry__.build() does)"
+    import os, tempfile
+    from test_lu_gpu import _run_with_diagnostic_library
     code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
-import torch; torch.cuda.is_available()
+import numpy as np
 import math_audio_amd as ma
 from math_audio_amd import mesh as mm
 mesh = mm.generate_icosphere_mesh(0.1, 3)
@@ -403,19 +390,17 @@ assert sw.lu_plan().speculation() == "optimistic", sw.lu_plan().speculation()
 X, st = sw.run(freqs, speed_of_sound=343.0, beta_scale=4.0)
 sw.close()
 assert np.all(st == 0)
-np.save(sys.argv[1], X)
-''' % (root, root)
+np.save(os.environ["MA_TEST_OUT"], X)
+'''
     outs = []
     for reject in (None, "4"):
-        env = dict(os.environ, MA_LIB_PATH=diag)
-        env.pop("MA_TEST_SWEEP_REJECT", None)
-        if reject is not None:
-            env["MA_TEST_SWEEP_REJECT"] = reject
         with tempfile.TemporaryDirectory() as d:
-            out = os.path.join(d, "x.npy")
-            r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=600)
+            env = {"MA_TEST_OUT": os.path.join(d, "x.npy")}
+            if reject is not None:
+                env["MA_TEST_SWEEP_REJECT"] = reject
+            r = _run_with_diagnostic_library(code, env)
             assert r.returncode == 0, r.stderr[-2000:]
-            outs.append(np.load(out))
+            outs.append(np.load(env["MA_TEST_OUT"]))
     keep = [i for i in range(7) if i != 4]
     assert np.array_equal(outs[0][keep], outs[1][keep])
     # the redone frequency was assembled on its own (tbem_far_kernel<1>: another order of summation than the three-system pass)

@@ -278,41 +278,53 @@ def test_stored_operator_equals_matrix_free(gpu):
     stored.close(); free.close(); plan.close()
 
 
-def test_row_sharded_operator_inside_the_library(gpu, monkeypatch):
+def test_row_sharded_operator_inside_the_library(gpu):
     """ma_op_create_tbem_multi: the matrix-free operator row-sharded over devices with the y all-gather done by peer copies
     inside the library, driven by the library's own device GMRES. A one-GPU box runs the shards on
-    the same device (test hook MA_TEST_ALLOW_DUPLICATE_DEVICES): block bounds, the x broadcast, the slice gather, the
-    summed transposed apply, the diagonal preconditioner and GMRES are all the multi-GPU code path."""
-    monkeypatch.setenv("MA_TEST_ALLOW_DUPLICATE_DEVICES", "1")
+    the same device -- which only the DIAGNOSTIC build of the library accepts (MA_TEST_ALLOW_DUPLICATE_DEVICES; a process of its own):
+    block bounds, the x broadcast, the slice gather, the summed transposed apply, the diagonal preconditioner and GMRES are all the
+    multi-GPU code path. The shipped library refuses a device listed twice."""
+    from test_lu_gpu import _run_with_diagnostic_library
+    code = r'''
+import numpy as np
+import oracle_lib as O
+import math_audio_amd as ma
+from helpers import to_ma_mesh, k_from_ka, RADIUS, rel_l2
+om = O.icosphere(RADIUS, 2)
+k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+mesh = to_ma_mesh(om)
+A, _ = ma.assemble_tbem(mesh, k, beta)
+n = om.n_elem
+i = np.arange(n)
+x = np.sin(0.1 * i) + 1j * np.cos(0.2 * i)
+for devs in ([0], [0, 0], [0, 0, 0]):
+    op = ma.LinearOperator.tbem_multi(mesh, k, beta, devs)
+    rows, dv = op.shards()
+    assert list(rows) == [n * g // len(devs) for g in range(len(devs))] and list(dv) == devs
+    y = op.apply(x)
+    assert np.abs(y - A @ x).max() <= 1e-12 * np.abs(A @ x).max()
+    assert np.abs(op.apply_transpose(x) - A.T @ x).max() <= 1e-12 * np.abs(A.T @ x).max()
+    assert np.abs(op.apply_hermitian(x) - A.conj().T @ x).max() <= 1e-12 * np.abs(A.T @ x).max()
+    b = ma.incident_rhs(om.center, om.normal, k, beta)
+    single = ma.LinearOperator.tbem(ma.BemPlan(mesh), k, beta)
+    xr, ir = ma.gmres(single, b, restart=30, max_iterations=10, tol=1e-8)
+    xs, info = ma.gmres(op, b, restart=30, max_iterations=10, tol=1e-8)
+    assert info.converged == 1 and info.iterations == ir.iterations and info.restarts == ir.restarts
+    assert rel_l2(xs, xr) <= 1e-10
+    Mp = ma.Preconditioner(op, kind="diagonal")
+    z = Mp.apply(x)
+    assert np.abs(z - x / np.diag(A)).max() <= 1e-12 * np.abs(z).max()
+    xp, ip = ma.gmres_preconditioned(op, Mp, b, restart=30, max_iterations=10, tol=1e-8)
+    assert ip.converged == 1 and np.linalg.norm(A @ xp - b) <= 1e-6 * np.linalg.norm(b)
+    Mp.close(); op.close(); single.close()
+print("ok")
+'''
+    r = _run_with_diagnostic_library(code, {"MA_TEST_ALLOW_DUPLICATE_DEVICES": 1})
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     om = O.icosphere(RADIUS, 2)
     k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
-    mesh = to_ma_mesh(om)
-    A, _ = ma.assemble_tbem(mesh, k, beta)
-    n = om.n_elem
-    x = _xvec(n)
-    for devs in ([0], [0, 0], [0, 0, 0]):
-        op = ma.LinearOperator.tbem_multi(mesh, k, beta, devs)
-        rows, dv = op.shards()
-        assert list(rows) == [n * g // len(devs) for g in range(len(devs))] and list(dv) == devs
-        y = op.apply(x)
-        assert np.abs(y - A @ x).max() <= 1e-12 * np.abs(A @ x).max()
-        assert np.abs(op.apply_transpose(x) - A.T @ x).max() <= 1e-12 * np.abs(A.T @ x).max()
-        assert np.abs(op.apply_hermitian(x) - A.conj().T @ x).max() <= 1e-12 * np.abs(A.T @ x).max()
-        b = ma.incident_rhs(om.center, om.normal, k, beta)
-        single = ma.LinearOperator.tbem(ma.BemPlan(mesh), k, beta)
-        xr, ir = ma.gmres(single, b, restart=30, max_iterations=10, tol=1e-8)
-        xs, info = ma.gmres(op, b, restart=30, max_iterations=10, tol=1e-8)
-        assert info.converged == 1 and info.iterations == ir.iterations and info.restarts == ir.restarts
-        assert rel_l2(xs, xr) <= 1e-10
-        Mp = ma.Preconditioner(op, kind="diagonal")
-        z = Mp.apply(x)
-        assert np.abs(z - x / np.diag(A)).max() <= 1e-12 * np.abs(z).max()
-        xp, ip = ma.gmres_preconditioned(op, Mp, b, restart=30, max_iterations=10, tol=1e-8)
-        assert ip.converged == 1 and np.linalg.norm(A @ xp - b) <= 1e-6 * np.linalg.norm(b)
-        Mp.close(); op.close(); single.close()
-    monkeypatch.delenv("MA_TEST_ALLOW_DUPLICATE_DEVICES")
     with pytest.raises(ma.MaError) as e:
-        ma.LinearOperator.tbem_multi(mesh, k, beta, [0, 0])
+        ma.LinearOperator.tbem_multi(to_ma_mesh(om), k, beta, [0, 0])
     assert e.value.status == ma.MA_ERR_INVALID
 
 

@@ -147,22 +147,6 @@ def test_full_size_sphere_properties(gpu, fidx):
     lu.close()
 
 
-def test_lookahead_and_plain_schedules_agree(gpu):
-    """The look-ahead schedule only reorders independent kernels: same pivots, same factors."""
-    import subprocess, sys, json
-    code = ("import sys,numpy as np;sys.path.insert(0,'.');import math_audio_amd as ma;"
-            "rng=np.random.default_rng(0);n=700;A=rng.standard_normal((n,n))+1j*rng.standard_normal((n,n));b=rng.standard_normal(n)+0j;"
-            "x=ma.zgesv(A,b);print(repr(float(np.abs(x).sum())),repr(float(np.abs(A@x-b).max())))")
-    outs = []
-    for la in ("0", "1"):
-        env = dict(os.environ, MA_LU_LOOKAHEAD=la)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
-        assert r.returncode == 0, r.stderr
-        outs.append(r.stdout.strip().split())
-    assert outs[0][0] == outs[1][0]                       # bitwise-identical solution checksum
-    assert float(outs[0][1]) < 1e-10
-
-
 def test_solve_sweep_driver_matches_per_frequency_path(gpu):
     """ma_bem_solve_sweep = the drivers' loop (room_simulator_bem.rs:329-360): per frequency assembly + incident RHS + solve,
     several systems per interleaved batch, against the one-shot path and the CPU restatement."""
@@ -219,11 +203,13 @@ def test_two_host_threads_one_frequency_each(gpu):
         assert np.array_equal(out[t], serial[t])
 
 
-def test_multi_device_sweep_inside_the_library(gpu, monkeypatch):
+def test_multi_device_sweep_inside_the_library(gpu):
     """ma_bem_solve_sweep_multi: frequency f on devices[f mod ndev], one host thread, BEM plan, LU plan and stream per device
-    inside the library (SURVEY 8e.1 behind the C-ABI). On a one-GPU box the 'devices' are the same GPU twice / three times
-    (test hook): the sharding rule, the threads, the strided solution scatter and the per-frequency status are the multi-GPU
-    code path; results must equal the single-device sweep bit for bit (same kernels, same order per system)."""
+    inside the library (SURVEY 8e.1 behind the C-ABI). On a one-GPU box the 'devices' are the same GPU twice / three times -- which
+    only the DIAGNOSTIC build of the library accepts (MA_TEST_ALLOW_DUPLICATE_DEVICES; a process of its own): the sharding rule, the
+    threads, the strided solution scatter and the per-frequency status are the multi-GPU code path; results must equal the
+    single-device sweep (same kernels, same order per system). The shipped library refuses a device listed twice."""
+    from test_lu_gpu import _run_with_diagnostic_library
     om = O.icosphere(RADIUS, 2)
     mesh = to_ma_mesh(om)
     freqs = [150.0, 545.9, 900.0, 1400.0, 2100.0, 2600.0, 3100.0]
@@ -232,16 +218,32 @@ def test_multi_device_sweep_inside_the_library(gpu, monkeypatch):
     plan.close()
     Xa, sa = ma.solve_sweep_multi(mesh, [0], freqs, slots=2)
     assert np.array_equal(Xa, X1) and np.array_equal(sa, s1)
-    monkeypatch.setenv("MA_TEST_ALLOW_DUPLICATE_DEVICES", "1")
-    for devs in ([0, 0], [0, 0, 0]):
-        Xm, sm = ma.solve_sweep_multi(mesh, devs, freqs, slots=2)
-        assert np.all(sm == ma.MA_OK)
-        for f in range(len(freqs)):
-            assert rel_l2(Xm[f], X1[f]) <= 1e-12, (devs, f)
-    monkeypatch.delenv("MA_TEST_ALLOW_DUPLICATE_DEVICES")
-    with pytest.raises(ma.MaError) as e:
-        ma.solve_sweep_multi(mesh, [0, 0], freqs)
-    assert e.value.status == ma.MA_ERR_INVALID
+    code = r'''
+import numpy as np
+import oracle_lib as O
+import math_audio_amd as ma
+from helpers import to_ma_mesh, RADIUS, rel_l2
+mesh = to_ma_mesh(O.icosphere(RADIUS, 2))
+freqs = [150.0, 545.9, 900.0, 1400.0, 2100.0, 2600.0, 3100.0]
+plan = ma.BemPlan(mesh)
+X1, s1 = ma.solve_sweep(plan, freqs, slots=2)
+plan.close()
+for devs in ([0, 0], [0, 0, 0]):
+    Xm, sm = ma.solve_sweep_multi(mesh, devs, freqs, slots=2)
+    assert np.all(sm == ma.MA_OK)
+    for f in range(len(freqs)):
+        assert rel_l2(Xm[f], X1[f]) <= 1e-12, (devs, f)
+print("ok")
+'''
+    r = _run_with_diagnostic_library(code, {"MA_TEST_ALLOW_DUPLICATE_DEVICES": 1})
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    os.environ["MA_TEST_ALLOW_DUPLICATE_DEVICES"] = "1"           # the shipped library has no such switch
+    try:
+        with pytest.raises(ma.MaError) as e:
+            ma.solve_sweep_multi(mesh, [0, 0], freqs)
+        assert e.value.status == ma.MA_ERR_INVALID
+    finally:
+        del os.environ["MA_TEST_ALLOW_DUPLICATE_DEVICES"]
     with pytest.raises(ma.MaError) as e:
         ma.solve_sweep_multi(mesh, [ma.device_count()], freqs)
     assert e.value.status == ma.MA_ERR_INVALID
