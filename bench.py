@@ -111,11 +111,19 @@ def cpu_baseline(n_theta, n_phi, freq, seconds_target=12.0):
     t_lu, lib = lapack(ns) if ns > 2000 else (t_probe_lu, lib)
     solve_gflops = lu_flops(ns) / t_lu / 1e9
     t_step = n * n / asm_pairs_per_s + lu_flops(n) / (solve_gflops * 1e9)
+    # how many threads the host's BLAS used for that (threadpoolctl reads the loaded libraries; the environment may cap them)
+    try:
+        from threadpoolctl import threadpool_info
+        blas = "; ".join("%s %s: %s threads" % (i.get("internal_api"), i.get("version"), i.get("num_threads")) for i in threadpool_info() if i.get("user_api") == "blas") or "no BLAS pool reported"
+    except Exception as e:
+        blas = "thread count unknown (%s)" % type(e).__name__
+    blas += ", OMP_NUM_THREADS=%s" % os.environ.get("OMP_NUM_THREADS", "unset")
     return {
         "value": n * n / t_step, "unit": "panel-pairs/s", "cores": cores, "kind": "port",
         "sample": "oracle C restatement of build_tbem_system_with_beta: %d of %d rows at %.0f Hz on %d threads (%.1f s) -> %.3e pairs/s; "
-                  "dense solve: %s, n=%d%s, %.2f s -> %.1f GFLOP/s; step time = N^2/asm + ((8/3)N^3+8N^2)/solve" % (
-                      rows, n, freq, cores, t_probe, asm_pairs_per_s, lib, ns, " (the workload's own size)" if ns == n else " (scaled by flops to n=%d)" % n, t_lu, solve_gflops),
+                  "dense solve: %s [%s], n=%d%s, %.2f s -> %.1f GFLOP/s; step time = N^2/asm + ((8/3)N^3+8N^2)/solve" % (
+                      rows, n, freq, cores, t_probe, asm_pairs_per_s, lib, blas, ns, " (the workload's own size)" if ns == n else " (scaled by flops to n=%d)" % n, t_lu, solve_gflops),
+        "blas_threads": blas,
         "solve_n": ns,
         "assembly_pairs_per_s": asm_pairs_per_s, "solve_gflops": solve_gflops,
         "assembly_pairs_per_s_one_thread": asm_1thread,
@@ -316,21 +324,28 @@ def inlib_multi(args):
 
     def flist(first, count):
         return [freqs[(d + (first + s_) * N) % len(freqs)] for s_ in range(count) for d in range(N)]
+    # the reusable handle (ma_bem_sweep_multi_create: a BEM plan and a sweep handle per device) is made once, outside the timed region,
+    # as the single-device handle is; the timed region is ONE ma_bem_sweep_multi_run
+    ts = time.perf_counter()
+    handle = ma.BemSweepMulti(mesh, devices, max(args.steps, args.warmup, 1) * N, slots=args.slots)
+    setup = [time.perf_counter() - ts] * N
     if args.warmup > 0:
-        ma.solve_sweep_multi_timed(mesh, devices, flist(0, args.warmup), speed_of_sound=C_SOUND, beta_scale=4.0, slots=args.slots)
+        handle.run(flist(0, args.warmup), speed_of_sound=C_SOUND, beta_scale=4.0)
     t0 = time.perf_counter()
-    X, st, secs, setup, cnt = ma.solve_sweep_multi_timed(mesh, devices, flist(args.warmup, args.steps), speed_of_sound=C_SOUND, beta_scale=4.0, slots=args.slots)
+    X, st = handle.run(flist(args.warmup, args.steps), speed_of_sound=C_SOUND, beta_scale=4.0)
     wall = time.perf_counter() - t0
+    secs, cnt = handle.last_timing()
+    handle.close()
     if not np.all(st == 0) or not np.all(np.isfinite(X.view(np.float64))) or any(int(c) != args.steps for c in cnt):
         raise SystemExit("the multi-device sweep failed: status %s, counts %s" % (sorted(set(int(v) for v in st)), list(map(int, cnt))))
     elapsed, K = float(max(secs)), args.steps
     print(json.dumps({"metric": "bem_sweep_panel_pairs_per_s", "value": float(n) * n * K * N / elapsed, "unit": "panel-pairs/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
                       "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
                       "config": {"workload": workload_text(args, n), "panels": n, "frequencies_per_gpu": K, "frequencies_in_flight_per_gpu": args.slots,
-                                 "mode": "in-library, one process: ma_bem_solve_sweep_multi (a host thread per device)", "devices": devices,
+                                 "mode": "in-library, one process: ma_bem_sweep_multi_run on a reusable handle (a host thread per device)", "devices": devices,
                                  "sharding": "frequency sweep, no data-path collective"},
                       "per_device_ms_per_step": [float(v) / K * 1e3 for v in secs], "per_device_plan_setup_s": [float(v) for v in setup], "wall_s_of_the_call": wall,
-                      "note": "value uses the slowest device's run (solutions copied back included); plan + handle creation per device is in per_device_plan_setup_s"}))
+                      "note": "value uses the slowest device's run (solutions copied back included); the handle's creation (all devices in parallel, outside the timed region) is in per_device_plan_setup_s"}))
 
 
 def workload_text(args, n):
@@ -421,7 +436,8 @@ def main():
     plan = ma.BemPlan(mesh, device=local_rank)
     # The library's frequency loop behind its reusable handle: LU plan, streams, S systems in flight, the spare systems of the
     # assembly-ahead and the parked solutions are allocated HERE, once, outside the timed region (inputs resident in HBM).
-    sweep = ma.BemSweep(plan, max(K, W, 1), slots=S)
+    proxy = world == 1 and not args.no_extras
+    sweep = ma.BemSweep(plan, max(K, W, 64 if proxy else 1), slots=S)
     info = sweep.info()
     lu = sweep.lu_plan()
     if W > 0:
@@ -523,6 +539,27 @@ def main():
                 gaps = iv[1:, 0] - iv[:-1, 1]; dur = iv[:, 1] - iv[:, 0]; span = iv[-1, 1] - iv[0, 0]
                 sys.stderr.write("big updates: %d, busy %.1f ms of %.1f ms (%.3f); gaps: total %.1f ms; > 0.5 ms: %d (%.1f ms); > 2 ms: %d (%.1f ms)\n"
                                  % (len(iv), dur.sum(), span, dur.sum() / span, gaps.sum(), (gaps > 0.5).sum(), gaps[gaps > 0.5].sum(), (gaps > 2).sum(), gaps[gaps > 2].sum()))
+        if proxy:
+            # Strong-scaling proxy of BASELINE config #3 (64 frequencies over 1 / 2 / 4 / 8 GPUs; room_simulator_bem.rs:328-360): this handle at
+            # the per-rank loads of N = 1, 2, 4, 8 -- K = 64, 32, 16, 8 frequencies of the list, strided as rank 0's share would be. A rank's
+            # time at N GPUs is the K = 64 / N run's, so the projected efficiency is T(64) / (N T(64 / N)). NOT a multi-GPU measurement.
+            sweep.set_timing(False)
+            tk = {}
+            for Np in (1, 2, 4, 8):
+                Kp = 64 // Np
+                fk = [freqs[(s_ * Np) % len(freqs)] for s_ in range(Kp)]
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                _, st_k = sweep.run(fk, speed_of_sound=C_SOUND, beta_scale=4.0)
+                torch.cuda.synchronize()
+                tk[Np] = time.perf_counter() - tq
+                if not np.all(st_k == 0):
+                    raise SystemExit("strong-scaling proxy: a frequency failed")
+            out["strong_scaling_proxy"] = {
+                "frequencies_per_rank": {str(Np): 64 // Np for Np in tk}, "ms_per_step": {str(Np): tk[Np] / (64 // Np) * 1e3 for Np in tk},
+                "wall_s": {str(Np): tk[Np] for Np in tk}, "projected_efficiency": {str(Np): tk[1] / (Np * tk[Np]) for Np in tk},
+                "note": "one GPU running the per-rank load of an N-GPU sweep of the 64-point list (K = 64 / N frequencies through the same handle): "
+                        "projected_efficiency[N] = T(64) / (N T(64 / N)); the fill and drain of the three-slot pipeline are what a short run pays. A projection, not a multi-GPU measurement"}
         sweep.close()                                   # 9 matrices of 1.6 GB go back before the checker and the extras allocate theirs
         if not args.no_check:
             out["check"] = residual_check(ma, mm, torch, plan, n, dev, run_freqs, X, min(S, K))

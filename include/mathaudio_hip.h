@@ -199,6 +199,18 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
                                    const double* incident_vec3, double amp_re, double amp_im, int32_t slots, ma_c64* X_out, int32_t* status_or_null,
                                    double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies);
 int ma_sweep_owner(int32_t frequency_index, int32_t ndev);      /* index into devices[] of the owner of a frequency */
+/* The multi-device loop behind a reusable handle (round 5): one BEM plan and one sweep handle per device -- geometry, LU plan, streams, the
+ * systems in flight, the spares of the assembly-ahead, the parked solutions -- made once for runs of up to max_frequencies frequencies
+ * (over all devices) and kept across ma_bem_sweep_multi_run calls (arguments as ma_bem_solve_sweep_multi; frequency f on
+ * devices[f mod ndev], one host thread per device, no collective). The reference's driver sweeps once per source position over one mesh
+ * (room_simulator_bem.rs:243-256, :328-360): a Rust caller keeps this handle beside its mesh and implements Drop with _destroy.
+ * ma_bem_solve_sweep_multi[_timed] is create + run + destroy. _last_timing: wall seconds and frequencies per device of the last run. */
+typedef struct ma_bem_sweep_multi ma_bem_sweep_multi_t;
+int ma_bem_sweep_multi_create(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t slots, int32_t max_frequencies, ma_bem_sweep_multi_t** out);
+int ma_bem_sweep_multi_run(ma_bem_sweep_multi_t* handle, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau,
+                           double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im, ma_c64* X_out, int32_t* status_or_null);
+int ma_bem_sweep_multi_last_timing(ma_bem_sweep_multi_t* handle, double* device_seconds, int32_t* device_frequencies);
+int ma_bem_sweep_multi_destroy(ma_bem_sweep_multi_t* handle);
 /* the order in which the staged frequency loop (room_simulator_bem.rs:328-360 as `slots` staggered factorisations of `blocks` blocks, `spacing`
  * rounds apart) begins its n_freq frequencies: order_out[q] = frequency of the q-th begin. Systems are assembled ahead only when this is the
  * identity. Pure host arithmetic (no device). */
@@ -614,6 +626,12 @@ int ma_lu_plan_dump_intervals(ma_lu_plan_t* plan, int32_t phase, double* out_pai
  * MA_TEST_SWEEP_REJECT (a frequency of a sweep is treated as rejected by the speculative panels). */
 int ma_diag_zgemm_dev(int32_t M, int32_t N, int32_t K, const void* dA, const void* dB, void* dC, int32_t repeat, void* stream);
 int ma_diag_mfma_burn(void* d_out, int32_t blocks, int32_t iters, int32_t repeat, void* stream);
+/* Virtual ranks for ma_op_create_gathered_rccl on ONE device (RCCL refuses two ranks on one GPU): nranks loopback communicators whose
+ * all-gather is a host-barrier copy between ranks that are host threads of this process; it replaces ncclAllGather for the rest of the
+ * process. _poison: that rank's status entry reads "a wait was abandoned" in every later exchange (-1: none). */
+int ma_rccl_test_loopback_create(int32_t nranks, int device, void** comms);
+int ma_rccl_test_loopback_poison(void* comm, int32_t rank);
+int ma_rccl_test_loopback_destroy(void** comms, int32_t nranks);
 #endif
 
 /* ------------------------------------------------------------------------------------------

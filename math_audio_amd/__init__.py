@@ -1181,6 +1181,50 @@ def solve_sweep_multi(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_
     return X, st
 
 
+class BemSweepMulti:
+    """ma_bem_sweep_multi_t: the multi-device frequency loop behind a reusable handle -- one BEM plan and one sweep handle per device, made
+    once (room_simulator_bem.rs runs one sweep per source position over one mesh). Frequency f on devices[f mod ndev]."""
+
+    def __init__(self, mesh, devices, max_frequencies, slots=3):
+        self.devices = [int(d) for d in devices]
+        self.n = int((mesh.is_eval == 0).sum()) if mesh.is_eval is not None else mesh.n_elem
+        dv = np.ascontiguousarray(self.devices, dtype=np.int32)
+        self.h = C.c_void_p()
+        L = lib()
+        L.ma_bem_sweep_multi_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.ma_bem_sweep_multi_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.ma_bem_sweep_multi_last_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ma_bem_sweep_multi_destroy.argtypes = [C.c_void_p]
+        check(L.ma_bem_sweep_multi_create(C.byref(mesh.c), _vp(dv), len(dv), int(slots), int(max_frequencies), C.byref(self.h)))
+
+    def run(self, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, harmonic=1.0, tau=1.0):
+        """ma_bem_sweep_multi_run: (X[n_freq, n], status[n_freq])."""
+        f = np.ascontiguousarray(frequencies_hz, dtype=np.float64); v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)
+        X = np.empty((len(f), self.n), dtype=np.complex128); st = np.zeros(len(f), dtype=np.int32)
+        rc = lib().ma_bem_sweep_multi_run(self.h, len(f), _vp(f), float(speed_of_sound), float(harmonic), float(tau), float(beta_scale), int(kind), _vp(v),
+                                          amp.real, amp.imag, _vp(X), _vp(st))
+        if rc not in (MA_OK, MA_ERR_SINGULAR):
+            check(rc)
+        return X, st
+
+    def last_timing(self):
+        """(wall seconds, frequencies) per device of the last run."""
+        secs = np.zeros(len(self.devices)); cnt = np.zeros(len(self.devices), dtype=np.int32)
+        check(lib().ma_bem_sweep_multi_last_timing(self.h, _vp(secs), _vp(cnt)))
+        return secs, cnt
+
+    def close(self):
+        if self.h:
+            lib().ma_bem_sweep_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def solve_sweep_multi_timed(mesh, devices, frequencies_hz, speed_of_sound=343.0, beta_scale=4.0, kind=0, vec=(0.0, 0.0, 1.0), amp=1.0, slots=3, harmonic=1.0, tau=1.0):
     """ma_bem_solve_sweep_multi_timed: (X, status, device_seconds, device_setup_seconds, device_frequencies)."""
     f = np.ascontiguousarray(frequencies_hz, dtype=np.float64); v = np.ascontiguousarray(vec, dtype=np.float64); amp = complex(amp)

@@ -13,6 +13,7 @@
 #include <new>
 #include <cmath>
 #include <mutex>
+#include <condition_variable>
 #include <dlfcn.h>
 #include <rccl/rccl.h>     // types and prototypes only: the library is bound at first use (dlopen), not at link time
 
@@ -360,6 +361,51 @@ RcclApi* rccl_api() {
   });
   return &api;
 }
+#ifdef MA_DIAGNOSTICS
+// Diagnostic build only: VIRTUAL ranks in one process on one device, so that a one-GPU box runs the nranks > 1 arithmetic of
+// rccl_gather_cb (block offsets, the padded last block, the status entries, the copies back) which RCCL itself refuses there (two ranks
+// on one device). A "communicator" of the loopback is {group, rank}; the collective has the semantics of ncclAllGather for ranks that are
+// host threads: every rank posts its block on the group's board (its stream, synchronised), all meet at a host barrier, every rank
+// copies the whole board into its receive buffer, all meet again. ma_rccl_test_loopback_* below; installed INSTEAD of ncclAllGather.
+struct LoopGroup {
+  int nranks = 0, device = 0; size_t bytes = 0; char* board = nullptr;
+  std::mutex mu; std::condition_variable cv; int arrived = 0; long long gen = 0;
+  int poison_rank = -1;                                      // this rank's status entry is forced to "a wait was abandoned" on the board
+};
+struct LoopComm { unsigned magic; LoopGroup* g; int rank; };
+void loop_barrier(LoopGroup* g) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  const long long my = g->gen;
+  if (++g->arrived == g->nranks) { g->arrived = 0; ++g->gen; g->cv.notify_all(); }
+  else g->cv.wait(lk, [&] { return g->gen != my; });
+}
+ncclResult_t loop_allgather(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t comm, hipStream_t st) {
+  LoopComm* c = (LoopComm*)comm;
+  if (!c || c->magic != 0x4c4f4f50u) return ncclInvalidArgument;
+  LoopGroup* g = c->g;
+  const size_t bytes = count * sizeof(double);
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!g->board || g->bytes != bytes) {
+      if (g->board) (void)hipFree(g->board);
+      if (hipMalloc(&g->board, bytes * (size_t)g->nranks) != hipSuccess) return ncclSystemError;
+      g->bytes = bytes;
+    }
+  }
+  if (hipMemcpyAsync(g->board + (size_t)c->rank * bytes, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclSystemError;
+  if (g->poison_rank == c->rank) {                           // the block's last complex entry is the rank's status
+    const double one[2] = {1.0, 0.0};
+    if (hipMemcpyAsync(g->board + (size_t)c->rank * bytes + bytes - sizeof(one), one, sizeof(one), hipMemcpyHostToDevice, st) != hipSuccess) return ncclSystemError;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return ncclSystemError;
+  loop_barrier(g);                                           // every rank has posted
+  if (hipMemcpyAsync(recv, g->board, bytes * (size_t)g->nranks, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclSystemError;
+  if (hipStreamSynchronize(st) != hipSuccess) return ncclSystemError;
+  loop_barrier(g);                                           // nobody posts the next round before everybody has read this one
+  return ncclSuccess;
+}
+#endif
+
 #define MA_RCCL(call)                                                                                        \
   do {                                                                                                       \
     ncclResult_t r_ = (call);                                                                                \
@@ -412,7 +458,8 @@ int rccl_gather_cb(void* user, void* d_y, int64_t n, int64_t row0, int64_t row1,
 int ma_rccl_get_unique_id(void* id128) {
   MA_REQUIRE(id128, MA_ERR_INVALID, "NULL argument");
   RcclApi* R = rccl_api();
-  MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  { const char* why = R->ok ? nullptr : dlerror();           // (one call: dlerror() clears its state when read)
+    MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", why ? why : "symbols missing"); }
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   MA_RCCL(R->GetUniqueId((ncclUniqueId*)id128));
   return MA_OK;
@@ -451,13 +498,49 @@ int ma_op_create_gathered_rccl(ma_op_t* inner, void* nccl_comm, int32_t nranks, 
              "rank %d of %d owns rows [%lld, %lld); the inner operator was created for [%d, %d)", rank, nranks, row0, row1, inner->row0, inner->row1);
   RcclGather* g = new (std::nothrow) RcclGather{(ncclComm_t)nccl_comm, nranks, rank, per, nullptr, inner->device};
   MA_REQUIRE(g, MA_ERR_NOMEM, "host allocation failed");
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;        // the caller's current device is left as it was
   (void)hipSetDevice(inner->device);
-  if (hipMalloc(&g->stage, sizeof(c64) * ((size_t)per + 1) * (size_t)nranks) != hipSuccess) { delete g; set_error("rank-sharded operator: the gather's staging vector does not fit"); return MA_ERR_NOMEM; }
-  int rc = ma_op_create_gathered(inner, row0, row1, rccl_gather_cb, g, out);
-  if (rc) { rccl_gather_free(g); return rc; }
-  (*out)->gather_free = rccl_gather_free;
+  int rc = MA_OK;
+  if (hipMalloc(&g->stage, sizeof(c64) * ((size_t)per + 1) * (size_t)nranks) != hipSuccess) { delete g; g = nullptr; set_error("rank-sharded operator: the gather's staging vector does not fit"); rc = MA_ERR_NOMEM; }
+  if (!rc) {
+    rc = ma_op_create_gathered(inner, row0, row1, rccl_gather_cb, g, out);
+    if (rc) rccl_gather_free(g); else (*out)->gather_free = rccl_gather_free;
+  }
+  if (had) (void)hipSetDevice(prev);
+  return rc;
+}
+
+#ifdef MA_DIAGNOSTICS
+// Diagnostic build only: `nranks` loopback communicators (virtual ranks on `device`, see loop_allgather) in comms[0..nranks), and the
+// loopback collective in place of ncclAllGather for every communicator of the process from here on; _poison: rank `rank`'s status entry
+// reads "a wait was abandoned" in every later exchange (-1: none); _destroy frees the group.
+int ma_rccl_test_loopback_create(int32_t nranks, int device, void** comms) {
+  MA_REQUIRE(comms && nranks >= 1 && nranks <= 64, MA_ERR_INVALID, "bad argument");
+  RcclApi* R = rccl_api();
+  MA_REQUIRE(R->ok, MA_ERR_UNSUPPORTED, "librccl could not be loaded");
+  LoopGroup* g = new (std::nothrow) LoopGroup();
+  MA_REQUIRE(g, MA_ERR_NOMEM, "host allocation failed");
+  g->nranks = nranks; g->device = device;
+  for (int r = 0; r < nranks; ++r) comms[r] = new LoopComm{0x4c4f4f50u, g, r};
+  R->AllGather = loop_allgather;
   return MA_OK;
 }
+int ma_rccl_test_loopback_poison(void* comm, int32_t rank) {
+  LoopComm* c = (LoopComm*)comm;
+  MA_REQUIRE(c && c->magic == 0x4c4f4f50u, MA_ERR_INVALID, "not a loopback communicator");
+  c->g->poison_rank = rank;
+  return MA_OK;
+}
+int ma_rccl_test_loopback_destroy(void** comms, int32_t nranks) {
+  MA_REQUIRE(comms && nranks >= 1, MA_ERR_INVALID, "bad argument");
+  LoopGroup* g = ((LoopComm*)comms[0])->g;
+  if (g->board) { (void)hipSetDevice(g->device); (void)hipFree(g->board); }
+  for (int r = 0; r < nranks; ++r) delete (LoopComm*)comms[r];
+  delete g;
+  return MA_OK;
+}
+#endif
 
 int ma_op_destroy(ma_op_t* o) {
   if (!o) return MA_OK;

@@ -221,6 +221,9 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
   };
   int32_t run_spacing = 1;
   if (S->staged) (void)ma_lu_plan_stage_spacing(lu, slots, &run_spacing);
+#ifdef MA_DIAGNOSTICS
+  if (const char* es = getenv("MA_TEST_STAGE_SPACING")) { const int v = atoi(es); if (v >= 1) run_spacing = v; }   // diagnostic build only: the rounds between two slots' starts
+#endif
   // (the order of the begins decides whether systems may be assembled ahead: with THIS run's slot count and spacing)
   const int ahead = (S->staged && begins_in_order(S->G, slots, run_spacing)) ? std::min(S->ahead, std::max(1, n_mine)) : 1;
   const int ppp = S->ppp;
@@ -529,16 +532,34 @@ int ma_bem_solve_sweep(ma_bem_plan_t* plan, int32_t n_freq, const double* freque
 // to device slot f mod ndev (room_simulator_bem.rs:329's loop dealt round-robin).
 int ma_sweep_owner(int32_t frequency_index, int32_t ndev) { return ndev > 0 ? frequency_index % ndev : 0; }
 
-// the same with a per-device account for the caller: device_seconds[d] = wall time of device d's sweep run (plan and handle
-// creation excluded), device_setup_seconds[d] = its plan + handle creation, device_frequencies[d] = frequencies it solved; any may be NULL
-int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
-                                   double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
-                                   int32_t slots, ma_c64* X_out, int32_t* status_or_null, double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies) {
-  MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && X_out, MA_ERR_INVALID, "bad argument");
-  int rc = check_args(n_freq, frequencies_hz, speed_of_sound, incident_vec3);
-  if (rc) return rc;
+// The multi-device loop behind a reusable handle (round 5): per device one BEM plan (geometry upload, near-pair list) and one sweep
+// handle (LU plan, streams, the systems in flight, the spares, the parked solutions), made once and kept across runs -- the reference's
+// driver sweeps once per source position (room_simulator_bem.rs:243-256 builds the mesh once, :328-360 loops over the frequencies), and
+// ma_bem_solve_sweep_multi paid 9 hipMallocs of 1.6 GB per device per call. A run gives device d the frequencies d, d + ndev, ... on a
+// host thread of its own; no collective on the data path.
+struct ma_bem_sweep_multi {
+  std::vector<int32_t> devices; std::vector<ma_bem_plan_t*> plans; std::vector<ma_bem_sweep*> sweeps;
+  int32_t cap = 0;                                           // frequencies per run, over all devices
+  std::vector<double> last_seconds; std::vector<int32_t> last_count;
+};
+
+int ma_bem_sweep_multi_destroy(ma_bem_sweep_multi_t* M) {
+  if (!M) return MA_OK;
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  for (size_t d = 0; d < M->sweeps.size(); ++d) if (M->sweeps[d]) { M->sweeps[d]->release(); delete M->sweeps[d]; }
+  for (ma_bem_plan_t* p : M->plans) if (p) ma_bem_plan_destroy(p);
+  delete M;
+  if (had) (void)hipSetDevice(prev);
+  return MA_OK;
+}
+
+int ma_bem_sweep_multi_create(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t slots, int32_t max_frequencies, ma_bem_sweep_multi_t** out) {
+  MA_REQUIRE(out, MA_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && max_frequencies > 0, MA_ERR_INVALID, "bad argument");
   int count = 0;
-  rc = ma_device_count(&count);
+  int rc = ma_device_count(&count);
   if (rc) return rc;
   MA_REQUIRE(count > 0, MA_ERR_NO_DEVICE, "no gfx950 device visible");
   for (int d = 0; d < ndev; ++d) {
@@ -551,26 +572,52 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
 #endif
     for (int o = 0; o < d; ++o) MA_REQUIRE(devices[o] != devices[d] || dup_ok, MA_ERR_INVALID, "device %d listed twice", devices[d]);
   }
+  ma_bem_sweep_multi* M = new (std::nothrow) ma_bem_sweep_multi();
+  MA_REQUIRE(M, MA_ERR_NOMEM, "host allocation failed");
+  M->devices.assign(devices, devices + ndev); M->plans.assign((size_t)ndev, nullptr); M->sweeps.assign((size_t)ndev, nullptr);
+  M->cap = max_frequencies; M->last_seconds.assign((size_t)ndev, 0.0); M->last_count.assign((size_t)ndev, 0);
+  std::vector<int> rcs((size_t)ndev, MA_OK);
+  std::vector<std::string> texts((size_t)ndev);
+  auto work = [&](int d) {
+    const int c = (max_frequencies - d + ndev - 1) / ndev;   // the most frequencies device slot d sees in a run
+    int r = c > 0 ? ma_bem_plan_create(mesh, devices[d], &M->plans[(size_t)d]) : MA_OK;
+    if (!r && c > 0) r = sweep_create(M->plans[(size_t)d], slots, c, default_pivoting(), &M->sweeps[(size_t)d]);
+    if (r) texts[(size_t)d] = ma_last_error_string();
+    rcs[(size_t)d] = r;
+  };
+  int prev = -1;
+  const bool had = hipGetDevice(&prev) == hipSuccess;
+  std::vector<std::thread> th;
+  for (int d = 1; d < ndev; ++d) th.emplace_back(work, d);
+  work(0);
+  for (auto& t : th) t.join();
+  if (had) (void)hipSetDevice(prev);
+  for (int d = 0; d < ndev; ++d)
+    if (rcs[(size_t)d]) { const int code = rcs[(size_t)d]; const std::string why = texts[(size_t)d]; ma_bem_sweep_multi_destroy(M); set_error("sweep handle on device %d: %s", devices[d], why.c_str()); return code; }
+  *out = M;
+  return MA_OK;
+}
+
+// arguments as ma_bem_solve_sweep_multi; X_out (n_freq x num_dofs) and status_or_null are indexed by the frequency
+int ma_bem_sweep_multi_run(ma_bem_sweep_multi_t* M, int32_t n_freq, const double* frequencies_hz, double speed_of_sound, double harmonic_factor, double tau, double beta_scale,
+                           int incident_kind, const double* incident_vec3, double amp_re, double amp_im, ma_c64* X_out, int32_t* status_or_null) {
+  MA_REQUIRE(M && X_out, MA_ERR_INVALID, "bad argument");
+  int rc = check_args(n_freq, frequencies_hz, speed_of_sound, incident_vec3);
+  if (rc) return rc;
+  MA_REQUIRE(n_freq <= M->cap, MA_ERR_INVALID, "%d frequencies for a handle created for %d", n_freq, M->cap);
+  const int ndev = (int)M->devices.size();
   const SweepArgs a{speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im};
   std::vector<int> rcs((size_t)ndev, MA_OK);
   std::vector<std::string> texts((size_t)ndev);
   auto work = [&](int d) {
-    // one host thread per device: its own plans, stream and buffers; errors are thread-local and carried back as text
-    ma_bem_plan_t* plan = nullptr; ma_bem_sweep* S = nullptr;
+    // one host thread per device; errors are thread-local and carried back as text
     int c = 0; for (int f = d; f < n_freq; f += ndev) ++c;
-    const auto t0 = std::chrono::steady_clock::now();
-    int r = c > 0 ? ma_bem_plan_create(mesh, devices[d], &plan) : MA_OK;
-    if (!r && c > 0) r = sweep_create(plan, slots, c, default_pivoting(), &S);
     const auto t1 = std::chrono::steady_clock::now();
-    if (!r && c > 0) r = sweep_run(S, n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null);
-    const auto t2 = std::chrono::steady_clock::now();
+    int r = (c > 0 && M->sweeps[(size_t)d]) ? sweep_run(M->sweeps[(size_t)d], n_freq, frequencies_hz, d, ndev, a, X_out, status_or_null) : MA_OK;
     if (r && r != MA_ERR_SINGULAR) texts[(size_t)d] = ma_last_error_string();
-    if (S) { S->release(); delete S; }
-    if (plan) ma_bem_plan_destroy(plan);
     rcs[(size_t)d] = r;
-    if (device_setup_seconds) device_setup_seconds[d] = std::chrono::duration<double>(t1 - t0).count();
-    if (device_seconds) device_seconds[d] = std::chrono::duration<double>(t2 - t1).count();
-    if (device_frequencies) device_frequencies[d] = c;
+    M->last_seconds[(size_t)d] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    M->last_count[(size_t)d] = c;
   };
   int prev = -1;
   const bool had = hipGetDevice(&prev) == hipSuccess;       // work(0) runs on the calling thread and selects devices[0]: the caller's device is restored below
@@ -583,10 +630,36 @@ int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices
   for (int d = 0; d < ndev; ++d) {
     if (rcs[(size_t)d] == MA_OK) continue;
     if (rcs[(size_t)d] == MA_ERR_SINGULAR) { if (worst == MA_OK) worst = MA_ERR_SINGULAR; continue; }
-    set_error("sweep on device %d: %s", devices[d], texts[(size_t)d].c_str());
+    set_error("sweep on device %d: %s", M->devices[(size_t)d], texts[(size_t)d].c_str());
     return rcs[(size_t)d];
   }
   return worst;
+}
+
+// per-device account of the last run: device_seconds[d] = wall time of device d's share, device_frequencies[d] = frequencies it solved (either may be NULL)
+int ma_bem_sweep_multi_last_timing(ma_bem_sweep_multi_t* M, double* device_seconds, int32_t* device_frequencies) {
+  MA_REQUIRE(M, MA_ERR_INVALID, "NULL handle");
+  for (size_t d = 0; d < M->devices.size(); ++d) { if (device_seconds) device_seconds[d] = M->last_seconds[d]; if (device_frequencies) device_frequencies[d] = M->last_count[d]; }
+  return MA_OK;
+}
+
+// create + run + destroy, with a per-device account for the caller: device_seconds[d] = wall time of device d's sweep run, device_setup_seconds[d]
+// = the handle's creation (all devices in parallel: the same figure for each), device_frequencies[d] = frequencies it solved; any may be NULL
+int ma_bem_solve_sweep_multi_timed(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,
+                                   double harmonic_factor, double tau, double beta_scale, int incident_kind, const double* incident_vec3, double amp_re, double amp_im,
+                                   int32_t slots, ma_c64* X_out, int32_t* status_or_null, double* device_seconds, double* device_setup_seconds, int32_t* device_frequencies) {
+  MA_REQUIRE(mesh && devices && ndev >= 1 && ndev <= 64 && X_out, MA_ERR_INVALID, "bad argument");
+  int rc = check_args(n_freq, frequencies_hz, speed_of_sound, incident_vec3);
+  if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  ma_bem_sweep_multi_t* M = nullptr;
+  if ((rc = ma_bem_sweep_multi_create(mesh, devices, ndev, slots, n_freq, &M))) return rc;
+  const double setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  rc = ma_bem_sweep_multi_run(M, n_freq, frequencies_hz, speed_of_sound, harmonic_factor, tau, beta_scale, incident_kind, incident_vec3, amp_re, amp_im, X_out, status_or_null);
+  (void)ma_bem_sweep_multi_last_timing(M, device_seconds, device_frequencies);
+  if (device_setup_seconds) for (int d = 0; d < ndev; ++d) device_setup_seconds[d] = setup;
+  ma_bem_sweep_multi_destroy(M);
+  return rc;
 }
 
 int ma_bem_solve_sweep_multi(const ma_mesh_t* mesh, const int32_t* devices, int32_t ndev, int32_t n_freq, const double* frequencies_hz, double speed_of_sound,

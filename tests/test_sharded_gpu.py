@@ -99,3 +99,85 @@ def test_rccl_gather_inside_the_library_world_of_one(gpu):
     for o in (gop, inner, wrong):
         o.close()
     comm.close(); plan.close()
+
+
+def test_rccl_gather_arithmetic_with_three_virtual_ranks(gpu):
+    """VERDICT r4 item 3 / ADVICE r4: the nranks > 1 arithmetic of ma_op_create_gathered_rccl's exchange -- per = ceil(n / nranks) + 1
+    entries per block, the padded LAST block (n = 320, 3 ranks: 107 + 107 + 106 rows), the in-place offsets, every rank's status entry
+    at stride - 1, the copies back -- on ONE GPU, where RCCL itself refuses two ranks. The DIAGNOSTIC build of the library (a process of
+    its own) installs a loopback collective for three virtual ranks that are host threads: each owns its row block of the matrix-free
+    operator, apply == the unsharded operator, GMRES runs the unsharded iteration on every rank, and a status entry poisoned on ONE rank
+    raises the abandoned-wait word (shared by the virtual ranks: they live on one device), which fails the next Krylov driver.
+    The exchange over real RCCL with more than one rank stays UNMEASURED on hardware."""
+    from test_lu_gpu import _run_with_diagnostic_library
+    code = r'''
+import ctypes as C, threading, numpy as np
+import oracle_lib as O
+import math_audio_amd as ma
+from math_audio_amd import sharded
+from helpers import to_ma_mesh, k_from_ka, RADIUS
+om = O.icosphere(RADIUS, 2)
+n = om.n_elem
+assert n == 320
+k = k_from_ka(1.0); beta, _ = O.beta_adaptive(k, RADIUS)
+mesh = to_ma_mesh(om)
+A, _ = ma.assemble_tbem(mesh, k, beta)
+b = ma.incident_rhs(om.center, om.normal, k, beta)
+rng = np.random.default_rng(5)
+x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+NR = 3
+L = ma.lib()
+comms = (C.c_void_p * NR)()
+L.ma_rccl_test_loopback_create.argtypes = [C.c_int32, C.c_int, C.c_void_p]
+L.ma_rccl_test_loopback_poison.argtypes = [C.c_void_p, C.c_int32]
+L.ma_rccl_test_loopback_destroy.argtypes = [C.c_void_p, C.c_int32]
+ma.check(L.ma_rccl_test_loopback_create(NR, 0, comms))
+plain_plan = ma.BemPlan(mesh)
+plain = ma.LinearOperator.tbem(plain_plan, k, beta)
+xr, ir = ma.gmres(plain, b, restart=30, max_iterations=10, tol=1e-8)
+assert ir.converged == 1
+res = [None] * NR
+def rank(r, poisoned):
+    try:
+        plan = ma.BemPlan(mesh)
+        r0, r1 = sharded.row_block(n, r, NR)
+        assert (r0, r1) == (107 * r, min(n, 107 * (r + 1)))
+        inner = ma.LinearOperator.tbem(plan, k, beta, rows=(r0, r1))
+        gop = ma.LinearOperator.gathered_rccl(inner, int(comms[r]), NR, r)
+        y = gop.apply(x)
+        out = {"apply": float(np.abs(y - A @ x).max() / np.abs(A @ x).max())}
+        if not poisoned:
+            xs, info = ma.gmres(gop, b, restart=30, max_iterations=10, tol=1e-8)
+            out.update(conv=info.converged, it=info.iterations, rs=info.restarts, err=float(np.linalg.norm(xs - xr) / np.linalg.norm(xr)))
+        gop.close(); inner.close(); plan.close()
+        res[r] = out
+    except Exception as e:
+        res[r] = repr(e)
+for poisoned in (False, True):
+    if poisoned:
+        ma.check(L.ma_rccl_test_loopback_poison(comms[0], 2))
+    th = [threading.Thread(target=rank, args=(r, poisoned)) for r in range(NR)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    assert all(isinstance(v, dict) for v in res), res
+    assert all(v["apply"] <= 1e-12 for v in res), res
+    if not poisoned:
+        assert all(v["conv"] == 1 and v["it"] == ir.iterations and v["rs"] == ir.restarts and v["err"] <= 1e-10 for v in res), (res, ir.iterations)
+        x2, i2 = ma.gmres(plain, b, restart=30, max_iterations=10, tol=1e-8)      # nothing was raised
+        assert i2.converged == 1
+    else:
+        # rank 2's status entry said "a wait was abandoned": every rank's exchange raised the device's word; the next driver must not return MA_OK
+        try:
+            ma.gmres(plain, b, restart=30, max_iterations=10, tol=1e-8)
+            raise SystemExit("the poisoned status entry was not seen")
+        except ma.MaError as e:
+            assert e.status == ma.MA_ERR_HIP, e.status
+        x3, i3 = ma.gmres(plain, b, restart=30, max_iterations=10, tol=1e-8)      # raised once, cleared by the driver that reported it
+        assert i3.converged == 1
+ma.check(L.ma_rccl_test_loopback_poison(comms[0], -1))
+ma.check(L.ma_rccl_test_loopback_destroy(comms, NR))
+plain.close(); plain_plan.close()
+print("ok")
+'''
+    r = _run_with_diagnostic_library(code)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-800:], r.stderr[-3000:])

@@ -218,6 +218,14 @@ def test_multi_device_sweep_inside_the_library(gpu):
     plan.close()
     Xa, sa = ma.solve_sweep_multi(mesh, [0], freqs, slots=2)
     assert np.array_equal(Xa, X1) and np.array_equal(sa, s1)
+    h = ma.BemSweepMulti(mesh, [0], len(freqs), slots=2)      # the reusable handle on the shipped library: one device
+    for _ in range(2):
+        Xh, sh = h.run(freqs)
+        assert np.array_equal(Xh, X1) and np.array_equal(sh, s1)
+    with pytest.raises(ma.MaError) as e:
+        h.run(freqs + [3500.0])                               # more frequencies than the handle was made for
+    assert e.value.status == ma.MA_ERR_INVALID
+    h.close()
     code = r'''
 import numpy as np
 import oracle_lib as O
@@ -233,6 +241,14 @@ for devs in ([0, 0], [0, 0, 0]):
     assert np.all(sm == ma.MA_OK)
     for f in range(len(freqs)):
         assert rel_l2(Xm[f], X1[f]) <= 1e-12, (devs, f)
+    # the reusable handle: two runs (the second with fewer frequencies) on plans and sweep handles made once
+    h = ma.BemSweepMulti(mesh, devs, len(freqs), slots=2)
+    Xh, sh = h.run(freqs)
+    Xh2, sh2 = h.run(freqs[:4])
+    secs, cnt = h.last_timing()
+    h.close()
+    assert np.array_equal(Xh, Xm) and np.array_equal(Xh2, Xm[:4]) and np.all(sh == 0) and np.all(sh2 == 0)
+    assert int(cnt.sum()) == 4 and np.all(secs[cnt > 0] > 0.0)
 print("ok")
 '''
     r = _run_with_diagnostic_library(code, {"MA_TEST_ALLOW_DUPLICATE_DEVICES": 1})
