@@ -496,9 +496,7 @@ def main():
             t_all = (l8[3] + l8[7]) * 1e-3                         # every update launch: the big ones on the sweep's stream + the lanes' K = 32 / 64 / 384 ones
             n_big, f_big, t_big = max(1, tm["big_update_launches"]), tm["big_update_flops"], tm["big_update_ms"] * 1e-3
             asm_t = tm["assembly_ms"] * 1e-3
-            cu_split = 64 if lu.main_stream() else 0
-            if lu.main_stream() and os.environ.get("MA_LU_CU_SPLIT"):
-                cu_split = int(os.environ["MA_LU_CU_SPLIT"])
+            cu_split = lu.cu_split()[0]
             bach = f_big / t_big / 1e12
             ach_all = f_all / t_all / 1e12
             e2e = lu_flops(n) * K / elapsed / 1e12
@@ -515,7 +513,7 @@ def main():
                                         "note": "every update launch (big ones + the lanes' K = 32 / 64 / 384 ones), each timed by its own events under co-tenancy: the basis of rounds 1-2"},
                 "end_to_end_frac": e2e / FP64_MFMA_PEAK_TF, "end_to_end_tflops": e2e,
                 "end_to_end_note": "((8/3) N^3 + 8 N^2) x steps / the timed region / peak: assembly, panels, waits and ramps included -- the figure that compares like for like across rounds",
-                "cus_note": ("the big updates run on a stream masked to %d of 256 CUs (the other %d are left to the panel kernels: lu_plan.hip, MA_LU_CU_SPLIT); peak is the whole chip's"
+                "cus_note": ("the big updates run on a stream masked to %d of 256 CUs (the other %d are left to the kernels of the slots' lanes: lu_plan.hip, MA_LU_CU_SPLIT); peak is the whole chip's"
                              % (256 - cu_split, cu_split)) if cu_split else "updates on the whole chip"}
             out["solve_gflops"] = lu_flops(n) * K / max(elapsed - asm_t, 1e-9) / 1e9
             out["assembly_pairs_per_s"] = float(n) * n * K / asm_t if asm_t > 0 else None

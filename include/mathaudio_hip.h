@@ -428,6 +428,9 @@ typedef struct {
 int ma_op_create_slfmm(ma_bem_plan_t* plan, const ma_clusters_t* clusters, const ma_physics_t* physics,
                        int32_t n_theta, int32_t n_phi, int32_t n_terms, ma_op_t** out);
 int ma_op_slfmm_near_matrix(ma_op_t* op, ma_c64* A_rowmajor);
+/* how the operator's upward / downward passes get the phases w_p exp(i k s_p.(x_j - C)): 2 recomputed with the bounded-argument sin / cos
+ * (sphere rules of <= 1024 points), 1 from a stored table (larger rules, or MA_FMM_STORE_PHASES=1), 0 recomputed with libm (=0: the first version) */
+int ma_op_slfmm_phase_mode(ma_op_t* op, int32_t* mode);
 /* Multi-level fast multipole operator.
  * Replaces: build_cluster_tree(elements, target_elements_per_leaf, physics) -> Vec<ClusterLevel>   math-bem/src/core/assembly/mlfmm.rs:979-1038
  *           (estimate_num_levels :954-974, subdivide_level :1056-1180, compute_near_far_lists :1183-1223): host code, the reference's

@@ -474,6 +474,13 @@ class LuPlan:
         check(lib().ma_lu_plan_main_stream(self.h, C.byref(p)))
         return p.value
 
+    def cu_split(self):
+        """ma_lu_plan_cu_split: (CUs the big updates stay off, CUs of the chip)."""
+        a = C.c_int32(0); b = C.c_int32(0)
+        lib().ma_lu_plan_cu_split.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        check(lib().ma_lu_plan_cu_split(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def dump_intervals(self, phase, capacity=200000):
         """ma_lu_plan_dump_intervals: (start, end) ms of the timed intervals of one phase of the last timed staged run."""
         out = np.zeros((capacity, 2), dtype=np.float64)
@@ -798,6 +805,13 @@ class LinearOperator:
         h = C.c_void_p()
         check(lib().ma_op_create_mlfmm(plan.h, tree.h, C.byref(ph), C.byref(h)))
         return LinearOperator(h, plan)
+
+    def slfmm_phase_mode(self):
+        """ma_op_slfmm_phase_mode: 2 phases recomputed (fast), 1 stored table, 0 libm."""
+        v = C.c_int32(-1)
+        lib().ma_op_slfmm_phase_mode.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        check(lib().ma_op_slfmm_phase_mode(self.h, C.byref(v)))
+        return v.value
 
     def slfmm_near_matrix(self):
         """SlfmmSystem::extract_near_field_matrix (slfmm.rs:104-132)."""

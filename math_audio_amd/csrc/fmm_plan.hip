@@ -995,6 +995,7 @@ int slfmm_self_diagonal(ma_slfmm* S, c64* d_diag, hipStream_t st) {
   return MA_OK;
 }
 
+int slfmm_phase_mode(const ma_slfmm* S) { return S->fast_phases ? 2 : (S->d_phase ? 1 : 0); }
 long long slfmm_num_dofs(const ma_slfmm* S) { return S->n; }
 int slfmm_device(const ma_slfmm* S) { return S->device; }
 
@@ -1194,9 +1195,12 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   }
   { const char* ev = getenv("MA_FMM_STORE_PHASES");
     const size_t listed = (size_t)eptr.back();
-    const int mode = ev ? atoi(ev) : 2;
-    // the fast form's arguments are k x an element-to-centre distance (far below the 2^30 its reduction allows); P must fit its LDS arrays
+    int mode = ev ? atoi(ev) : 2;
+    // the fast form's arguments are k x an element-to-centre distance (far below the 2^30 its reduction allows); P must fit its LDS
+    // arrays -- a sphere rule of more than FMM_FAST_PTS points gets the stored table instead (it used to fall to the libm
+    // form, the slowest of the three, and lost the two-stream apply with it)
     if (mode == 2 && P <= FMM_FAST_PTS) S->fast_phases = true;
+    else if (mode == 2) mode = 1;
     if (!rc && mode == 1 && listed > 0 && hipMalloc(&S->d_phase, sizeof(c64) * listed * (size_t)P) == hipSuccess) {
       hipLaunchKernelGGL(slfmm_phase_table_kernel, dim3(nc), dim3(256), 0, nullptr, plan->geom, S->d_eptr, S->d_eidx, S->d_cc, S->d_sc, S->d_sw, P, S->k,
                          reinterpret_cast<dc*>(S->d_phase));

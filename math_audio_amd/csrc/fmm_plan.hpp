@@ -11,6 +11,7 @@ int slfmm_apply(ma_slfmm* S, const ma::c64* d_x, ma::c64* d_y, int transpose, hi
 int slfmm_near_matrix(ma_slfmm* S, ma::c64* d_A, hipStream_t st);
 int slfmm_self_diagonal(ma_slfmm* S, ma::c64* d_diag, hipStream_t st);   // n entries, zero where a dof sits in no cluster
 long long slfmm_num_dofs(const ma_slfmm* S);
+int slfmm_phase_mode(const ma_slfmm* S);   // how the upward / downward passes get their phases: 2 recomputed (bounded-argument sin / cos), 1 stored table, 0 libm
 int slfmm_device(const ma_slfmm* S);
 
 // ---- multi-level operator (math-bem/src/core/assembly/mlfmm.rs)

@@ -1552,6 +1552,7 @@ int lu_cumask_selfcheck(hipStream_t masked, int expect_cus, bool* ok) {
   constexpr int NB = 4096;
   unsigned* d = nullptr;
   MA_HIP(hipMalloc(&d, sizeof(unsigned) * NB));
+  MA_HIP(hipDeviceSynchronize());                            // the census counts the CUs that take its workgroups: on an otherwise idle device
   hipLaunchKernelGGL(lu_cu_census_kernel, dim3(NB), dim3(64), 0, masked, d, 2000);          // 20 us at 100 MHz
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(masked);
@@ -1567,8 +1568,9 @@ int lu_cumask_selfcheck(hipStream_t masked, int expect_cus, bool* ok) {
   // and the census did not miss more than a CU per XCD (a CU the dispatcher happened to skip must not cost the plan its schedule)
   bool good = expect_cus % 8 == 0 && (int)h.size() <= expect_cus && (int)h.size() >= expect_cus - 8;
   for (int x = 0; x < 8 && good; ++x) good = per_xcc[x] <= expect_cus / 8 && per_xcc[x] >= expect_cus / 8 - 1;
-  std::lock_guard<std::mutex> lock(mu);
-  seen.push_back({key, good});
+  // only a POSITIVE verdict is remembered: a census that ran while another host thread's sweep occupied the device may
+  // miss CUs; a plan that gets a negative one runs unsplit (ma_lu_plan_cu_split reports 0 CUs), the next plan asks again
+  if (good) { std::lock_guard<std::mutex> lock(mu); seen.push_back({key, true}); }
   *ok = good;
   return MA_OK;
 }

@@ -288,6 +288,12 @@ int ma_op_create_mlfmm(ma_bem_plan_t* plan, const ma_cluster_tree_t* tree, const
   if (rc) { op_free(o); delete o; return rc; }
   *out = o; return MA_OK;
 }
+// which of the three forms of the upward / downward passes an SLFMM operator runs (2 phases recomputed, 1 stored table, 0 libm)
+int ma_op_slfmm_phase_mode(ma_op_t* o, int32_t* mode) {
+  MA_REQUIRE(o && mode && o->kind == 4 && o->fmm, MA_ERR_INVALID, "not an SLFMM operator");
+  *mode = slfmm_phase_mode(o->fmm);
+  return MA_OK;
+}
 // SlfmmSystem::extract_near_field_matrix (slfmm.rs:104-132): [N] as a dense num_dofs x num_dofs matrix (host buffer, row-major)
 int ma_op_slfmm_near_matrix(ma_op_t* o, ma_c64* A_rowmajor) {
   MA_REQUIRE(o && A_rowmajor && o->kind == 4 && o->fmm, MA_ERR_INVALID, "not a single-level FMM operator");

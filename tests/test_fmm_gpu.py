@@ -51,6 +51,29 @@ def test_slfmm_operator_matches_the_restatement(gpu, sub, ka, cell, nt, nphi):
     op.close(); plan.close()
 
 
+def test_slfmm_sphere_rule_beyond_the_fast_passes(gpu):
+    """ADVICE r4: a sphere rule of more than 1024 points (24 x 48 = 1152) does not fit the LDS arrays of the recomputed-phase passes;
+    the operator must then run the STORED-TABLE passes (mode 1) -- it used to fall silently to the libm form (mode 0), the slowest of the
+    three -- and still be the restatement's operator. A rule of 288 points runs the recomputed form (mode 2)."""
+    om = O.icosphere(RADIUS, 2)
+    k = k_from_ka(2.0)
+    cl = grid_clusters(om.center, 0.07)
+    plan = ma.BemPlan(to_ma_mesh(om))
+    n = om.n_elem
+    small = ma.LinearOperator.slfmm(plan, cl, k, 12, 24, 5)
+    assert small.slfmm_phase_mode() == 2
+    small.close()
+    op = ma.LinearOperator.slfmm(plan, cl, k, 24, 48, 5)
+    assert op.slfmm_phase_mode() == 1
+    ref = O.Slfmm(om, cl, k, 24, 48, 5)
+    x = _xvec(n)
+    y = op.apply(x); yr = ref.matvec(x)
+    assert np.abs(y - yr).max() <= 1e-10 * np.abs(yr).max()
+    yt = op.apply_transpose(x); ytr = ref.matvec(x, transpose=True)
+    assert np.abs(yt - ytr).max() <= 1e-10 * np.abs(ytr).max()
+    op.close(); plan.close()
+
+
 def test_slfmm_on_the_box_and_input_validation(gpu):
     m = mm.generate_box_mesh(0.30, 0.40, 0.60, 5, 6, 9)
     om = O.Mesh(m.nodes, m.conn)
