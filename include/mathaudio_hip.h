@@ -230,16 +230,16 @@ int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out);
  * the pivot rows of every 32-column panel by a tournament (communication-avoiding LU: local eliminations, then eliminations of the
  * winners' rows), one chip-wide decision per panel instead of one per column; admissible behind lu_solve (lu.rs:142-153 returns x
  * only) and the default of the frequency sweep. Same storage of L, U and of the interchange sequence; solutions agree with LAPACK's to
- * rounding (tests/test_lu_gpu.py). ma_lu_plan_create makes a partial-pivoting plan (MA_LU_PIVOTING=tournament overrides, for A/B runs). */
+ * rounding (tests/test_lu_gpu.py). ma_lu_plan_create makes a partial-pivoting plan. */
 #define MA_LU_PIVOT_PARTIAL 0
 #define MA_LU_PIVOT_TOURNAMENT 1
 int ma_lu_plan_create_pivoting(int32_t n, int device, int32_t pivoting, ma_lu_plan_t** out);
 int ma_lu_plan_pivoting(ma_lu_plan_t* plan, int32_t* pivoting);
-/* Plans that factor in 64-column panels of two halves (4 096..16 384 rows, every tournament plan) try each half-panel SPECULATIVELY first
+/* Every plan factors its 64-column panels as two 32-column half-panels and tries each half-panel SPECULATIVELY first
  * (lu_spec.hip): partial pivoting among the panel's top 32 rows, then the check that no row below holds a larger entry in any column --
  * if it passes, zgetrf would have chosen the same rows, and the panel is done in two short launches without any exchange between
- * workgroups. Rows that fail the check (at most 32) join the candidates of a second, WIDENED attempt, checked the same way; a panel both
- * attempts give up is restored and factored by the plan's own panel kernel. Boundary operators of the Burton-Miller form (tbem.rs:96-222)
+ * workgroups. Rows that fail the check (at most 32) join the candidates of a WIDENED attempt, checked the same way (two such attempts,
+ * the second with the first's new violators); a panel all attempts give up is restored and factored by the plan's own panel kernel. Boundary operators of the Burton-Miller form (tbem.rs:96-222)
  * pass at the first attempt except near mesh singularities (the poles of a UV sphere: 6 % of the half-panels of BASELINE config #3),
  * which the widened attempt takes. Counts since the plan was made (synchronises the device); MA_LU_SPECULATE=0 switches it off. */
 int ma_lu_plan_speculation_stats(ma_lu_plan_t* plan, int64_t* accepted, int64_t* accepted_widened, int64_t* rejected);
@@ -247,7 +247,7 @@ int ma_lu_plan_speculation_stats(ma_lu_plan_t* plan, int64_t* accepted, int64_t*
  * runs where the check failed -- every result is final. MA_LU_SPECULATE_OPTIMISTIC: nothing is launched behind it; a system that met a
  * rejected panel carries status -1 (ma_lu_plan_stage_info_dev) / MA_ERR_RETRY (ma_lu_plan_status) and is the CALLER's to solve again in
  * the verified mode -- what ma_bem_sweep_run does with the (never yet observed) frequencies whose operator is not diagonally dominant.
- * MA_LU_SPECULATE_OFF: the plan's own panel kernel only. MA_ERR_UNSUPPORTED on plans without half-panel pairs (except OFF). */
+ * MA_LU_SPECULATE_OFF: the plan's own panel kernel only. */
 #define MA_LU_SPECULATE_OFF 0
 #define MA_LU_SPECULATE_VERIFIED 1
 #define MA_LU_SPECULATE_OPTIMISTIC 2

@@ -127,10 +127,7 @@ int ma_lu_plan::ensure_batch(int nmat) {
 extern "C" {
 
 int ma_lu_plan_create(int32_t n, int device, ma_lu_plan_t** out) {
-  // MA_LU_PIVOTING=tournament|partial: the mode of plans made through this entry (the drop-in entries of lu.rs: partial)
-  int mode = MA_LU_PIVOT_PARTIAL;
-  if (const char* e = getenv("MA_LU_PIVOTING")) mode = (e[0] == 't' || e[0] == 'T' || e[0] == '1') ? MA_LU_PIVOT_TOURNAMENT : MA_LU_PIVOT_PARTIAL;
-  return ma_lu_plan_create_pivoting(n, device, mode, out);
+  return ma_lu_plan_create_pivoting(n, device, MA_LU_PIVOT_PARTIAL, out);          // the drop-in entries of lu.rs: LAPACK's pivoting
 }
 
 int ma_lu_plan_pivoting(ma_lu_plan_t* P, int32_t* pivoting) {

@@ -221,9 +221,6 @@ int sweep_run(ma_bem_sweep* S, int32_t n_freq, const double* frequencies_hz, int
   };
   int32_t run_spacing = 1;
   if (S->staged) (void)ma_lu_plan_stage_spacing(lu, slots, &run_spacing);
-#ifdef MA_DIAGNOSTICS
-  if (const char* es = getenv("MA_TEST_STAGE_SPACING")) { const int v = atoi(es); if (v >= 1) run_spacing = v; }   // diagnostic build only: the rounds between two slots' starts
-#endif
   // (the order of the begins decides whether systems may be assembled ahead: with THIS run's slot count and spacing)
   const int ahead = (S->staged && begins_in_order(S->G, slots, run_spacing)) ? std::min(S->ahead, std::max(1, n_mine)) : 1;
   const int ppp = S->ppp;

@@ -209,3 +209,37 @@ def test_full_size_hierarchy_properties(gpu):
     xg, info = ma.gmres_preconditioned(lin, amg, b, restart=30, max_iterations=300, tol=1e-8)
     assert info.converged and np.linalg.norm(A @ xg - b) <= 1e-6 * r0
     amg.close(); lin.close(); op.close()
+
+
+def test_hierarchy_does_not_depend_on_the_host_thread_count(gpu):
+    """MA_HOST_THREADS (default min(16, cores)): the setup's products run over row blocks on host threads from 8 192 rows on; every
+    row's result sits in its own slot, so one thread and the default count build the SAME hierarchy, bit for bit (27 x 27 x 27 box:
+    21 952 nodes, the sparse products of the Galerkin operator split in five blocks)."""
+    import os
+    A = _helmholtz(27, 27, 27, 1.832 + 0.01j)
+    assert A.shape[0] >= 5 * 4096
+    op = _operator(A)
+    cfg = ma.AmgConfig.preset("for_parallel")
+    amg = ma.AmgFromCsr(op, cfg)
+    old = os.environ.get("MA_HOST_THREADS")
+    os.environ["MA_HOST_THREADS"] = "1"
+    try:
+        amg1 = ma.AmgFromCsr(op, cfg)
+    finally:
+        if old is None:
+            del os.environ["MA_HOST_THREADS"]
+        else:
+            os.environ["MA_HOST_THREADS"] = old
+    d, d1 = amg.diagnostics(), amg1.diagnostics()
+    assert d["num_levels"] == d1["num_levels"] >= 2 and d["level_dofs"] == d1["level_dofs"] and d["level_nnz"] == d1["level_nnz"]
+    for l in range(d["num_levels"]):
+        a, b = amg.level(l), amg1.level(l)
+        for key in ("A", "P", "R"):
+            if a[key] is None:
+                assert b[key] is None
+                continue
+            assert a[key]["shape"] == b[key]["shape"] and (a[key]["row_ptrs"] == b[key]["row_ptrs"]).all()
+            assert (a[key]["col_indices"] == b[key]["col_indices"]).all() and (a[key]["values"] == b[key]["values"]).all(), (l, key)
+    r = _xvec(A.shape[0])
+    assert (amg.apply(r) == amg1.apply(r)).all()
+    amg.close(); amg1.close(); op.close()

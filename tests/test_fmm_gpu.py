@@ -52,7 +52,7 @@ def test_slfmm_operator_matches_the_restatement(gpu, sub, ka, cell, nt, nphi):
 
 
 def test_slfmm_sphere_rule_beyond_the_fast_passes(gpu):
-    """ADVICE r4: a sphere rule of more than 1024 points (24 x 48 = 1152) does not fit the LDS arrays of the recomputed-phase passes;
+    """ADVICE r4: a sphere rule of more than 1024 points (20 x 56 = 1120; 20 is the largest tabulated Gauss order) does not fit the LDS arrays of the recomputed-phase passes;
     the operator must then run the STORED-TABLE passes (mode 1) -- it used to fall silently to the libm form (mode 0), the slowest of the
     three -- and still be the restatement's operator. A rule of 288 points runs the recomputed form (mode 2)."""
     om = O.icosphere(RADIUS, 2)
@@ -63,9 +63,9 @@ def test_slfmm_sphere_rule_beyond_the_fast_passes(gpu):
     small = ma.LinearOperator.slfmm(plan, cl, k, 12, 24, 5)
     assert small.slfmm_phase_mode() == 2
     small.close()
-    op = ma.LinearOperator.slfmm(plan, cl, k, 24, 48, 5)
+    op = ma.LinearOperator.slfmm(plan, cl, k, 20, 56, 5)
     assert op.slfmm_phase_mode() == 1
-    ref = O.Slfmm(om, cl, k, 24, 48, 5)
+    ref = O.Slfmm(om, cl, k, 20, 56, 5)
     x = _xvec(n)
     y = op.apply(x); yr = ref.matvec(x)
     assert np.abs(y - yr).max() <= 1e-10 * np.abs(yr).max()
@@ -134,7 +134,19 @@ def test_operator_apply_is_linear_and_reproducible_at_size(gpu):
                 os.environ[v] = val
     y0 = op0.apply(x); yt0 = op0.apply_transpose(x)
     assert np.abs(y0 - y).max() <= 1e-12 * np.abs(y).max() and np.abs(yt0 - yt).max() <= 1e-12 * np.abs(yt).max()
-    op0.close(); op.close()
+    # MA_FMM_OVERLAP=0 (read at an operator's first apply): near and far field on one stream, the same vector to rounding
+    old_ov = os.environ.get("MA_FMM_OVERLAP")
+    try:
+        os.environ["MA_FMM_OVERLAP"] = "0"
+        op1 = ma.LinearOperator.slfmm(plan, cl, k, 6, 12, 5)
+        y1 = op1.apply(x)
+    finally:
+        if old_ov is None:
+            os.environ.pop("MA_FMM_OVERLAP", None)
+        else:
+            os.environ["MA_FMM_OVERLAP"] = old_ov
+    assert np.abs(y1 - y).max() <= 1e-12 * np.abs(y).max() and (op1.apply(x) == y1).all()
+    op1.close(); op0.close(); op.close()
 
 
 def test_slfmm_over_octree_leaves(gpu):

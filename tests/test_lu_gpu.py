@@ -389,6 +389,20 @@ def _run_with_diagnostic_library(code, env=None, timeout=600):
     return subprocess.run([sys.executable, "-c", pre + code], env=e, capture_output=True, text=True, timeout=timeout)
 
 
+def test_ma_device_selects_the_device_of_the_host_buffer_entries(gpu):
+    """MA_DEVICE (default 0): the device the one-shot host-buffer entries (ma_zgesv, ma_lu_factorize, ma_bem_assemble_tbem, ...) run on.
+    0 is the default device; an index past the last device is MA_ERR_INVALID, not device 0."""
+    import torch
+    A, b = _rand(96, 5)
+    x0 = ma.zgesv(A, b)
+    with _with_env(MA_DEVICE=0):
+        assert (ma.zgesv(A, b) == x0).all()
+    with _with_env(MA_DEVICE=torch.cuda.device_count()):
+        with pytest.raises(ma.MaError) as e:
+            ma.zgesv(A, b)
+        assert e.value.status == ma.MA_ERR_INVALID
+
+
 def test_abandoned_panel_poisons_the_plan_and_nothing_else(gpu):
     """The failure path behind the round-1 memory fault (DESIGN 4 "Residency", lu_kernels.hip): a panel kernel whose exchange
     does not complete must (1) make every workgroup of every panel kernel of the plan leave at once -- the poison word is

@@ -89,6 +89,43 @@ def test_sweep_handle_with_spares_on_a_small_plan(gpu):
     plan.close()
 
 
+def test_sweep_mode_switches_on_a_small_plan(gpu):
+    """MA_SWEEP_PIVOTING / MA_SWEEP_SPECULATE (read when a handle is created): the sweep's plan in partial pivoting, with verified
+    speculation, and with none, on the 640-panel staged plan -- each against the default handle (tournament, optimistic) to 1e-12:
+    an accepted half-panel carries LAPACK's pivots in every mode, a tournament panel other rows of a stable factorisation."""
+    import os
+    om = O.icosphere(RADIUS, 3)
+    mesh = to_ma_mesh(om)
+    freqs = list(np.geomspace(150.0, 3000.0, 7))
+    saved = {v: os.environ.get(v) for v in ("MA_LU_KB", "MA_SWEEP_PIVOTING", "MA_SWEEP_SPECULATE")}
+    os.environ["MA_LU_KB"] = "1"
+    try:
+        plan = ma.BemPlan(mesh)
+        sw = ma.BemSweep(plan, len(freqs), slots=3)
+        assert sw.lu_plan().pivoting() == "tournament" and sw.lu_plan().speculation() == "optimistic"
+        X, st = sw.run(freqs, speed_of_sound=C_SOUND, beta_scale=4.0)
+        sw.close()
+        assert np.all(st == ma.MA_OK)
+        for piv, spec, want in (("partial", "verified", ("partial", "verified")), ("tournament", "off", ("tournament", "off")),
+                                ("partial", "off", ("partial", "off")), ("tournament", "verified", ("tournament", "verified"))):
+            os.environ["MA_SWEEP_PIVOTING"] = piv; os.environ["MA_SWEEP_SPECULATE"] = spec
+            sw = ma.BemSweep(plan, len(freqs), slots=3)
+            got = (sw.lu_plan().pivoting(), sw.lu_plan().speculation())
+            Xm, stm = sw.run(freqs, speed_of_sound=C_SOUND, beta_scale=4.0)
+            sw.close()
+            assert got == want, (got, want)
+            assert np.all(stm == ma.MA_OK)
+            for fi in range(len(freqs)):
+                assert rel_l2(Xm[fi], X[fi]) <= 1e-12, (piv, spec, fi, rel_l2(Xm[fi], X[fi]))
+        plan.close()
+    finally:
+        for v, val in saved.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
+
+
 def test_s10_sweep_as_benchmarked_equals_the_single_system_path(gpu):
     """VERDICT r3 item 2. S10 through ma_bem_sweep_run with the default plan, nine frequencies of the 64-point list spanning the
     ka = 0.5 sign switch (indices 14 / 15: ka = 0.485 / 0.520) and both ends: every solution against the single-system path

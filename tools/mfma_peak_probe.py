@@ -1,7 +1,12 @@
 """Diagnostic: what the f64 matrix cores sustain on this chip (ma_diag_mfma_burn: 12 independent accumulators per wavefront, no
 memory traffic), at 1 / 2 / 3 wavefronts per SIMD. The update kernel's fraction of peak is priced against 78.6 TFLOP/s."""
 import ctypes as C
+import os
 import sys
+# ma_diag_mfma_burn exists only in the diagnostic build (make -C math_audio_amd/csrc diag); the shipped library has ma_probe_mfma_f64
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MA_LIB_PATH", os.path.join(_root, "math_audio_amd", "lib", "libmathaudio_hip_diag.so"))
+sys.path.insert(0, _root)
 import torch
 import math_audio_amd as ma
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: MA_TEST_STAGE_SPACING was a hook of the diagnostic build while the spacing was being measured; it has been removed since)
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
