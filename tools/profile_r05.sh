@@ -3,6 +3,8 @@ set -o pipefail
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05prof; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
+# a counter pass writes nothing for minutes: a heartbeat under gpurun_out/ keeps the run from being taken for hung
+( while sleep 45; do date >> $O/heartbeat.txt; done ) & HB=$!
 python bench.py > $O/bench.json 2> $O/bench.err && tail -c 300 $O/bench.json && echo
 python bench.py --steps 20 > $O/bench_20_steps.json 2> $O/bench20.err && echo 20 ok
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/trace.err && echo trace ok
@@ -14,3 +16,4 @@ find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write
 PYTHONPATH=. python tools/mfma_peak_probe.py > $O/mfma_peak_probe.txt 2>&1
 du -sh $O; ls $O
+kill $HB; rm -f $O/heartbeat.txt

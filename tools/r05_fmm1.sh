@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: MA_FMM_NEAR_BLOCKS=2, MA_TMP_STRIP_WGS, MA_TMP_NEAR_U, MA_TMP_FMM_MASK existed only in the experimental builds described in profiles/r05_fmm_apply.md; tools/r05_fmm_strips_experiment.patch holds the strips kernel)
 # round 5: the near blocks as strips (MA_FMM_NEAR_BLOCKS=2, the default) against the block kernels of rounds 2-4 (=1)
 set -o pipefail
 cd "$(dirname "$0")/.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of an experiment: MA_FMM_NEAR_BLOCKS=2, MA_TMP_STRIP_WGS, MA_TMP_NEAR_U, MA_TMP_FMM_MASK existed only in the experimental builds described in profiles/r05_fmm_apply.md; tools/r05_fmm_strips_experiment.patch holds the strips kernel)
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp PYTHONPATH=.
