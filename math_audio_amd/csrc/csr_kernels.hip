@@ -126,103 +126,6 @@ static int launch_sell(const CsrView& A, int epi, const c64* x, const c64* b, c6
   return A.sell_col16 ? launch_sell2<KM, true>(A, epi, x, b, out, omega, st) : launch_sell2<KM, false>(A, epi, x, b, out, omega, st);
 }
 
-// ------------------------------------------------------------------ the coarse end of an AMG V-cycle in ONE launch (round 3)
-// On a 15-level hierarchy of 9 x 10^5 unknowns the eight coarsest levels hold < 3000 unknowns each, and a level costs 7 dependent
-// launches of ~10 us whatever its size: 0.56 of the cycle's 1.06 ms. Here ONE workgroup of 1024 threads walks those levels --
-// pre-smoothing, residual, restriction down to the coarsest level's sweeps, then prolongation and post-smoothing back up -- with a
-// workgroup barrier where the launches had a kernel boundary. Thread = row; every row's arithmetic is csr_rows_kernel's epilogue for
-// the same operation (EPI 0-4) with the row's sum taken in storage order. Stored values only (AMG levels below the finest are).
-__device__ __forceinline__ void amgc_rows(const CsrView& A, const dc* x, const dc* b, dc* out, int epi, double omega) {
-  constexpr int G = 8;                                     // lanes per row: the row's loads go out together (a thread per row walked its
-  const int lg = threadIdx.x & (G - 1);                    // entries one dependent load after the other: 8 us per pass)
-  for (long long row0 = threadIdx.x / G; row0 < ((A.n + blockDim.x / G - 1) / (blockDim.x / G)) * (blockDim.x / G); row0 += blockDim.x / G) {
-    const bool on = row0 < A.n;
-    const long long row = on ? row0 : 0;
-    const long long beg = A.row_ptr[row], end = on ? A.row_ptr[row + 1] : beg;
-    double sr = 0.0, si = 0.0;
-    for (long long idx = beg + lg; idx < end; idx += G) {
-      const dc v = A.val[idx]; const dc xv = x[A.col[idx]];
-      sr += v.re * xv.re - v.im * xv.im;
-      si += v.re * xv.im + v.im * xv.re;
-    }
-    sr = group_sum<G>(sr); si = group_sum<G>(si);
-    if (!on || lg != 0) continue;
-    if (epi == 0) out[row] = dc_make(sr, si);
-    else if (epi == 4) { const dc bb = b[row]; out[row] = dc_make(bb.re + sr, bb.im + si); }
-    else {
-      const dc bb = b[row];
-      const double rr = bb.re - sr, ri = bb.im - si;
-      if (epi == 1) out[row] = dc_make(rr, ri);
-      else if (epi == 2) {
-        const dc d = A.dinv[row]; const dc xo = x[row];
-        const double wr = omega * d.re, wi = omega * d.im;
-        out[row] = dc_make(xo.re + (wr * rr - wi * ri), xo.im + (wr * ri + wi * rr));
-      } else {
-        const double l = A.l1[row]; const dc xo = x[row];
-        out[row] = dc_make(xo.re + rr / l, xo.im + ri / l);
-      }
-    }
-  }
-}
-// jacobi_sweeps of csr_plan.hip: `sweeps` sweeps that end in x; a zero iterate's first sweep is the diagonal scaling
-__device__ void amgc_smooth(const CsrView& A, dc* x, dc* tmp, const dc* b, int sweeps, bool zero, int l1mode, double omega) {
-  if (sweeps <= 0) return;
-  dc* cur = x; dc* nxt = tmp; int s0 = 0;
-  if (zero) {
-    dc* first = (sweeps % 2 == 1) ? x : tmp;
-    for (long long row = threadIdx.x; row < A.n; row += blockDim.x) {
-      const dc bb = b[row];
-      const double rr = bb.re - 0.0, ri = bb.im - 0.0;
-      if (!l1mode) { const dc d = A.dinv[row]; const double wr = omega * d.re, wi = omega * d.im; first[row] = dc_make(0.0 + (wr * rr - wi * ri), 0.0 + (wr * ri + wi * rr)); }
-      else { const double l = A.l1[row]; first[row] = dc_make(0.0 + rr / l, 0.0 + ri / l); }
-    }
-    __syncthreads();
-    cur = first; nxt = first == x ? tmp : x; s0 = 1;
-  }
-  for (int s = s0; s < sweeps; ++s) {
-    amgc_rows(A, cur, b, nxt, l1mode ? 3 : 2, omega);
-    __syncthreads();
-    dc* t = cur; cur = nxt; nxt = t;
-  }
-  if (cur != x) {
-    for (long long row = threadIdx.x; row < A.n; row += blockDim.x) x[row] = cur[row];
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(1024) void amg_coarse_cycle_kernel(const AmgCoarseLevelDev* __restrict__ lv, int nlev, int l1mode, double omega, int pre, int post, int coarsest,
-                                                                int top_zero) {
-  // down
-  for (int l = 0; l + 1 < nlev; ++l) {
-    const AmgCoarseLevelDev L = lv[l];
-    const bool zero = l == 0 ? top_zero != 0 : pre >= 1;          // a level entered from above starts at zero: written by its first sweep, or cleared below
-    amgc_smooth(L.A, L.x, L.tmp, L.b, pre, zero, l1mode, omega);
-    amgc_rows(L.A, L.x, L.b, L.r, 1, 0.0);                        // r = b - A x
-    __syncthreads();
-    const AmgCoarseLevelDev C = lv[l + 1];
-    amgc_rows(L.R, L.r, nullptr, C.b, 0, 0.0);                    // r_c = R r
-    const bool cz = (l + 2 == nlev ? coarsest : pre) >= 1;
-    if (!cz) for (long long row = threadIdx.x; row < C.A.n; row += blockDim.x) C.x[row] = dc_make(0.0, 0.0);
-    __syncthreads();
-  }
-  {
-    const AmgCoarseLevelDev L = lv[nlev - 1];
-    amgc_smooth(L.A, L.x, L.tmp, L.b, coarsest, nlev == 1 ? top_zero != 0 : true, l1mode, omega);
-  }
-  // up
-  for (int l = nlev - 2; l >= 0; --l) {
-    const AmgCoarseLevelDev L = lv[l]; const AmgCoarseLevelDev C = lv[l + 1];
-    amgc_rows(L.P, C.x, L.x, L.x, 4, 0.0);                        // x = x + P e_c (a row reads and writes its own x only)
-    __syncthreads();
-    amgc_smooth(L.A, L.x, L.tmp, L.b, post, false, l1mode, omega);
-  }
-}
-int csr_launch_amg_coarse(const AmgCoarseLevelDev* d_levels, int nlev, int l1mode, double omega, int pre, int post, int coarsest, int top_zero, hipStream_t st) {
-  if (nlev <= 0) return MA_OK;
-  hipLaunchKernelGGL(amg_coarse_cycle_kernel, dim3(1), dim3(1024), 0, st, d_levels, nlev, l1mode, omega, pre, post, coarsest, top_zero);
-  MA_HIP(hipGetLastError());
-  return MA_OK;
-}
-
 // per-wavenumber diagonal data: dinv_i = 1 / a_ii (1 if |a_ii| <= 1e-15, amg.rs:400-413) and
 // l1_i = sum_j |a_ij| (1 if <= 1e-15, amg.rs:895-908)
 template <bool KM>

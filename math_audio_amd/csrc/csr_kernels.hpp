@@ -27,9 +27,6 @@ struct CsrView {
   double zero_diag_dinv;       // 1/a_ii stand-in for |a_ii| <= 1e-15: 1 (amg.rs:400-413) or 0 = leave the row alone (smoother.rs:143-146)
 };
 
-// one level of the coarse end of an AMG hierarchy as amg_coarse_cycle_kernel sees it (device pointers; P / R unused on the last one)
-struct AmgCoarseLevelDev { CsrView A, P, R; ::ma::dc* x; ::ma::dc* b; ::ma::dc* r; ::ma::dc* tmp; };
-int csr_launch_amg_coarse(const AmgCoarseLevelDev* d_levels, int nlev, int l1mode, double omega, int pre, int post, int coarsest, int top_zero, hipStream_t st);
 int csr_launch_rows(const CsrView& A, bool km, int group, int epi, const c64* x, const c64* b, c64* out, double omega, hipStream_t st);
 int csr_launch_gs_persistent(const CsrView& A, bool km, int mode, const int* rows, const long long* lev_ptr, int nlev, int grid, c64* x, const c64* b,
                              unsigned* bar, unsigned base, unsigned gbase, hipStream_t st);

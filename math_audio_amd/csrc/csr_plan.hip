@@ -639,16 +639,6 @@ int ma_csr_status(ma_csr_t* h) {
   }
   return MA_OK;
 }
-// (internal to the library) the device view of a handle for the fused coarse AMG cycle: stored complex values only, diagonal data
-// brought up to date on `stream`. MA_ERR_UNSUPPORTED for a K/M pair (its values are formed in registers by the row kernels).
-int ma_csr_coarse_view(ma_csr_t* h, int need_diag, void* view_out, void* stream) {
-  MA_REQUIRE(h && view_out, MA_ERR_INVALID, "NULL argument");
-  MA_REQUIRE(!h->fused_km() && h->d_val, MA_ERR_UNSUPPORTED, "a K/M operator has no stored values");
-  MA_HIP(hipSetDevice(h->device));
-  if (need_diag) { int rc = ensure_diag(h, (hipStream_t)stream); if (rc) return rc; }
-  *reinterpret_cast<CsrView*>(view_out) = h->view();
-  return MA_OK;
-}
 // number of dependency levels of the forward / backward Gauss-Seidel schedule (diagnostics: launches per sweep)
 int ma_csr_gauss_seidel_levels(ma_csr_t* h, int64_t* forward, int64_t* backward) {
   MA_REQUIRE(h && h->ncols == h->n, MA_ERR_INVALID, "ma_csr_gauss_seidel_levels needs a square operator");

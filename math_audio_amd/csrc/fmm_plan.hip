@@ -469,9 +469,8 @@ static int fmm_levels_nt(int P) {
 }
 static int fmm_launch_translate_levels(const FmmLevels& V, int nt, hipStream_t st) {
   if (V.nl <= 0) return MA_OK;
-  if (nt == 2) hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 2>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
-  else if (nt == 5) hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 5>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
-  else hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 8>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
+  (void)nt;                                                  // 32 points per workgroup: the only form kept (80 and 128 were slower: fmm_levels_nt)
+  hipLaunchKernelGGL((fmm_translate_levels_kernel<8, 2>), dim3((unsigned)V.first[V.nl]), dim3(64 * 8), 0, st, V);
   MA_HIP(hipGetLastError());
   return MA_OK;
 }

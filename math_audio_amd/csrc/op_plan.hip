@@ -742,13 +742,6 @@ struct ma_precond {
   // kind 7: AdditiveSchwarzPreconditioner (schwarz.rs): restriction E onto the stacked subdomains, ILU(0) of their block-diagonal matrix,
   // weighted prolongation back; sch_stats = subdomains, min / max size, total size
   ma_precond* sch_inner = nullptr; ma_csr* sch_E = nullptr; ma_csr* sch_Et = nullptr; c64* sch_a = nullptr; c64* sch_b = nullptr; long long sch_stats[4] = {0, 0, 0, 0};
-  // kind 5, Jacobi-type smoothers: the cycle is a fixed sequence of ~7 launches per level -- captured once per (z, r) pair and set of
-  // level values on an internal stream, replayed as ONE graph launch (the host then issues one call per cycle instead of ~105 on a
-  // 15-level hierarchy). g_seen: applications seen with this key (the first runs eagerly: lazy builds inside the handles happen there).
-  // kind 5, Jacobi-type smoothers: levels [coarse_from, end) have <= MA_AMG_FUSE_ROWS rows each and stored values: their part of the
-  // cycle is ONE launch (amg_coarse_cycle_kernel); d_coarse: their descriptors; coarse_epoch: the level values they were taken for
-  int coarse_from = -1; AmgCoarseLevelDev* d_coarse = nullptr; unsigned long long coarse_epoch = ~0ull; bool coarse_tried = false;
-  hipGraphExec_t g_exec = nullptr; hipStream_t g_stream = nullptr; hipEvent_t g_ev = nullptr; const void* g_z = nullptr; const void* g_r = nullptr; unsigned long long g_epoch = 0; int g_seen = 0;
 };
 
 extern "C" int ma_csr_jacobi_dev(ma_csr* h, void* d_x, const void* d_b, double omega, int sweeps, void* d_tmp, void* stream);
@@ -779,36 +772,7 @@ static bool amg_first_sweep_writes(const ma_precond* M, size_t level) {
   const bool coarsest = level + 1 == M->lv.size() || !M->lv[level].P;
   return M->amg_smoother != 2 && (coarsest ? 20 : M->amg_pre) >= 1;
 }
-extern "C" int ma_csr_coarse_view(ma_csr* h, int need_diag, void* view_out, void* stream);
-// the levels from `coarse_from` on as one launch: descriptors built once per set of level values
-static int amg_prepare_coarse(ma_precond* M, hipStream_t st) {
-  unsigned long long epoch = 0;
-  for (const AmgLevelDev& L : M->lv) epoch += ma_csr_epoch(L.A) + (L.P ? ma_csr_epoch(L.P) + ma_csr_epoch(L.R) : 0ull);
-  if (M->coarse_tried && epoch == M->coarse_epoch) return MA_OK;
-  M->coarse_tried = true; M->coarse_epoch = epoch; M->coarse_from = -1;
-  constexpr long long fuse_rows = 0;   // off: a lone workgroup pays 3-4 us per dependent pass, more than the launches it replaces (profiles/r03_amg_cycle_variants.json)
-  if (M->amg_smoother == 2 || fuse_rows <= 0 || M->lv.size() < 2) return MA_OK;
-  size_t from = M->lv.size();
-  while (from > 1 && M->lv[from - 1].n <= fuse_rows && (from == M->lv.size() || M->lv[from - 1].P)) --from;   // contiguous tail of small levels (never the finest)
-  if (M->lv.size() - from < 2) return MA_OK;               // one level alone: its launches are the kernel's work already
-  std::vector<AmgCoarseLevelDev> hv(M->lv.size() - from);
-  for (size_t l = from; l < M->lv.size(); ++l) {
-    AmgLevelDev& L = M->lv[l]; AmgCoarseLevelDev& D = hv[l - from];
-    if (ma_csr_coarse_view(L.A, 1, &D.A, st) != MA_OK) return MA_OK;                      // a K/M level: stay with the launches
-    const bool last = l + 1 == M->lv.size() || !L.P;
-    if (!last && (ma_csr_coarse_view(L.P, 0, &D.P, st) != MA_OK || ma_csr_coarse_view(L.R, 0, &D.R, st) != MA_OK)) return MA_OK;
-    if (last && l + 1 != M->lv.size()) return MA_OK;
-    D.x = reinterpret_cast<dc*>(L.x); D.b = reinterpret_cast<dc*>(L.b); D.r = reinterpret_cast<dc*>(L.r); D.tmp = reinterpret_cast<dc*>(L.tmp);
-  }
-  if (!M->d_coarse) MA_HIP(hipMalloc(&M->d_coarse, sizeof(AmgCoarseLevelDev) * M->lv.size()));
-  MA_HIP(hipMemcpyAsync(M->d_coarse, hv.data(), sizeof(AmgCoarseLevelDev) * hv.size(), hipMemcpyHostToDevice, st));
-  MA_HIP(hipStreamSynchronize(st));                       // hv is a local
-  M->coarse_from = (int)from;
-  return MA_OK;
-}
 static int amg_v_cycle(ma_precond* M, size_t level, c64* x, const c64* b, hipStream_t st, bool x_is_zero = false) {
-  if (M->coarse_from > 0 && (int)level == M->coarse_from)   // x == lv[level].x, b == lv[level].b here (levels > 0 are entered from amg_v_cycle only)
-    return csr_launch_amg_coarse(M->d_coarse, (int)(M->lv.size() - level), M->amg_smoother == 1 ? 1 : 0, M->omega, M->amg_pre, M->amg_post, 20, x_is_zero ? 1 : 0, st);
   AmgLevelDev& L = M->lv[level];
   if (level + 1 == M->lv.size() || !L.P)
     return amg_smooth(M, L, x, b, M->amg_smoother == 2 ? 10 : 20, st, x_is_zero);
@@ -922,10 +886,6 @@ int ma_precond_create_amg(int32_t nlevels, ma_csr_t* const* A, ma_csr_t* const* 
 }
 int ma_precond_destroy(ma_precond_t* M) {
   if (!M) return MA_OK;
-  if (M->d_coarse) (void)hipFree(M->d_coarse);
-  if (M->g_exec) (void)hipGraphExecDestroy(M->g_exec);
-  if (M->g_stream) (void)hipStreamDestroy(M->g_stream);
-  if (M->g_ev) (void)hipEventDestroy(M->g_ev);
   for (AmgLevelDev& L : M->lv) { void* p[] = {L.x, L.b, L.r, L.tmp}; for (void* q : p) if (q) (void)hipFree(q); }
   if (M->d_tmp) (void)hipFree(M->d_tmp);
   if (M->d_invdiag) (void)hipFree(M->d_invdiag);
@@ -1184,8 +1144,7 @@ int ma_precond_schwarz_stats(ma_precond_t* M, int64_t* num_subdomains, int64_t* 
 // z = M^-1 r on device vectors (z and r distinct)
 // AmgPreconditioner::apply (amg.rs:1068-1103) after z = 0: the cycle (V; W = the V-cycle twice; F = a second V-cycle on the residual)
 static int amg_apply_body(ma_precond* M, c64* z, const c64* r, hipStream_t st, bool amg_lazy) {
-  int rc = amg_prepare_coarse(M, st);
-  if (!rc) rc = amg_v_cycle(M, 0, z, r, st, amg_lazy);
+  int rc = amg_v_cycle(M, 0, z, r, st, amg_lazy);
   if (!rc && M->amg_cycle == 1) rc = amg_v_cycle(M, 0, z, r, st);             // W: the V-cycle twice (:1084-1087)
   if (!rc && M->amg_cycle == 2) {                                              // F: a second V-cycle on the residual (:1088-1094)
     c64* res = M->d_tmp; c64* corr = M->d_tmp + M->n;
@@ -1216,34 +1175,8 @@ int ma_precond_apply_dev(ma_precond_t* M, const void* d_r, void* d_z, void* stre
     return rc;
   }
   const bool amg_lazy = M->kind == 5 && amg_first_sweep_writes(M, 0);          // z = 0 is then written by the cycle's first sweep
-  if (M->kind == 5 && M->amg_smoother != 2) {
-    // one graph launch per application once the same (z, r, level values) have been seen before: OFF -- measured 1.39 ms per replayed
-    // cycle against 1.06 ms eager (profiles/r03_amg_cycle_variants.json); the capture code below stays for a runtime whose graph replay is cheaper
-    constexpr bool graphs = false;
-    unsigned long long epoch = 0;
-    for (const AmgLevelDev& L : M->lv) epoch += ma_csr_epoch(L.A) + (L.P ? ma_csr_epoch(L.P) + ma_csr_epoch(L.R) : 0ull);
-    const bool same = M->g_z == d_z && M->g_r == d_r && M->g_epoch == epoch;
-    if (!same) { M->g_z = d_z; M->g_r = d_r; M->g_epoch = epoch; M->g_seen = 0; if (M->g_exec) { (void)hipGraphExecDestroy(M->g_exec); M->g_exec = nullptr; } }
-    if (graphs && same && M->g_exec) { MA_HIP(hipGraphLaunch(M->g_exec, (hipStream_t)stream)); return MA_OK; }
-    if (graphs && same && M->g_seen >= 1 && !M->g_exec) {
-      if (!M->g_stream) { MA_HIP(hipStreamCreateWithFlags(&M->g_stream, hipStreamNonBlocking)); MA_HIP(hipEventCreateWithFlags(&M->g_ev, hipEventDisableTiming)); }
-      hipGraph_t graph = nullptr;
-      MA_HIP(hipStreamBeginCapture(M->g_stream, hipStreamCaptureModeThreadLocal));
-      int crc = MA_OK;
-      if (!amg_lazy && hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, M->g_stream) != hipSuccess) crc = MA_ERR_HIP;
-      if (!crc) crc = amg_apply_body(M, (c64*)d_z, (const c64*)d_r, M->g_stream, amg_lazy);
-      const hipError_t ee = hipStreamEndCapture(M->g_stream, &graph);
-      if (!crc && ee == hipSuccess && graph && hipGraphInstantiate(&M->g_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-        (void)hipGraphDestroy(graph);
-        MA_HIP(hipGraphLaunch(M->g_exec, (hipStream_t)stream));
-        return MA_OK;
-      }
-      if (graph) (void)hipGraphDestroy(graph);
-      (void)hipGetLastError();
-      M->g_exec = nullptr; M->g_seen = -1000000;              // this hierarchy does not capture: stay eager
-    }
-    if (M->g_seen >= 0) M->g_seen++;
-  }
+  // (round 3 measured the cycle as ONE graph replay, 1.39 ms against 1.06 ms eager, and the coarse levels in one workgroup, 1.08-1.40 ms:
+  // profiles/r03_amg_cycle_variants.json; both are gone)
   if (!amg_lazy) MA_HIP(hipMemsetAsync(d_z, 0, sizeof(c64) * (size_t)M->n, (hipStream_t)stream));
   if (M->kind == 5) return amg_apply_body(M, (c64*)d_z, (const c64*)d_r, (hipStream_t)stream, amg_lazy);
   if (M->kind == 1) return ma_csr_jacobi_dev(M->csr, d_z, d_r, M->omega, M->sweeps, M->d_tmp, stream);
