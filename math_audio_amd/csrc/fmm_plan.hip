@@ -590,15 +590,13 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
 constexpr int FMM_NCH = 8;
 constexpr int FMM_WIDE_ROWS = 512;                            // rows of a block whose x entries are staged in LDS (taller blocks read x per row)
 template <int NCH>   // column chunks of 64 a lane may hold: 2 / 4 (next rows prefetched) / 8
-__global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ bsrc,
-                                                                     const int* __restrict__ bfld, const long long* __restrict__ boff,
-                                                                     const long long* __restrict__ broff, const long long* __restrict__ bcoff, int nblocks,
-                                                                     const dc* __restrict__ bval, const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
-  __shared__ dc cpart[4 * 64 * NCH];
-  constexpr bool PIPE = NCH <= 4;
-  __shared__ dc xrow[FMM_WIDE_ROWS];                          // round 4: x of the block's rows, gathered once (the row loop then holds block loads only)
+__device__ __forceinline__ void near_wide_block(int b, dc* __restrict__ cpart, dc* __restrict__ xrow, const int* __restrict__ eptr, const int* __restrict__ edof,
+                                                const int* __restrict__ bsrc, const int* __restrict__ bfld, const long long* __restrict__ boff,
+                                                const long long* __restrict__ broff, const long long* __restrict__ bcoff,
+                                                const dc* __restrict__ bval, const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
+  constexpr bool PIPE = NCH <= 2;                            // (the prefetching form of four chunks takes 240 registers: one wavefront per SIMD)
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {    // grid-stride (see slfmm_near_blocks_kernel)
+  {
   const int a = bsrc[b], f = bfld[b];
   const int a0 = eptr[a], ns = eptr[a + 1] - a0, f0 = eptr[f], nf = eptr[f + 1] - f0;
   const dc* B = bval + boff[b];
@@ -606,8 +604,7 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
   dc* prow = part + broff[b];
   dc* pcol = both ? part + bcoff[b] : prow;
   const int nch = (nf + 63) >> 6;                            // <= NCH (the launcher's choice)
-  const bool staged = ns <= FMM_WIDE_ROWS;
-  if (staged) for (int i = threadIdx.x; i < ns; i += 256) xrow[i] = x[edof[a0 + i]];
+  for (int i = threadIdx.x; i < ns; i += 256) xrow[i] = x[edof[a0 + i]];            // ns <= FMM_WIDE_ROWS: the launcher's condition
   dc xf[NCH]; double cr[NCH], ci[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -619,23 +616,24 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
   constexpr int U = 4;
   // the next rows' entries are fetched while this iteration's products run (two sets of U x nch loads in flight per lane)
   dc bb[PIPE ? NCH : 1][U], bn[PIPE ? NCH : 1][U];
+  // every load UNCONDITIONAL (rows clamped into the block, columns of absent chunks to column 0): under a branch the compiler cannot count
+  // the loads in flight and waits for all of them
   auto fetch = [&](int i0, dc (*dst)[U]) {
 #pragma unroll
-    for (int ch = 0; ch < (PIPE ? NCH : 1); ++ch)
-      if (ch < nch) {
-        const int j = ch * 64 + lane;
-        const int jc = j < nf ? j : 0;
+    for (int ch = 0; ch < (PIPE ? NCH : 1); ++ch) {
+      const int j = ch * 64 + lane;
+      const int jc = j < nf ? j : 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; dst[ch][u] = B[(long long)(i < ns ? i : i0) * nf + jc]; }
-      }
+      for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; dst[ch][u] = B[(long long)(i < ns ? i : ns - 1) * nf + jc]; }
+    }
   };
-  if (PIPE && w < ns) fetch(w, bb);
+  if (PIPE) fetch(w, bb);
   for (int i0 = w; i0 < ns; i0 += 4 * U) {
     const bool more = PIPE && i0 + 4 * U < ns;
-    if constexpr (PIPE) { if (more) fetch(i0 + 4 * U, bn); }
+    if constexpr (PIPE) { fetch(i0 + 4 * U, bn); __builtin_amdgcn_sched_barrier(0); }   // the next rows' loads go out first and stay there (the scheduler would sink them to their use)
     dc xa[U]; double pr[U], pi[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; const int ii = i < ns ? i : i0; xa[u] = staged ? xrow[ii] : x[edof[a0 + ii]]; pr[u] = 0.0; pi[u] = 0.0; }
+    for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; xa[u] = i < ns ? xrow[i] : dc_make(0.0, 0.0); pr[u] = 0.0; pi[u] = 0.0; }   // rows past the block meet a zero (no mask on the products)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (ch < nch) {                                        // uniform
@@ -643,15 +641,13 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
         const bool vj = j < nf;
         if constexpr (!PIPE) {                               // many chunks: this chunk's U loads only (the whole row set would take every register)
 #pragma unroll
-          for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; bb[0][u] = B[(long long)(i < ns ? i : i0) * nf + (vj ? j : 0)]; }
+          for (int u = 0; u < U; ++u) { const int i = i0 + 4 * u; bb[0][u] = B[(long long)(i < ns ? i : ns - 1) * nf + (vj ? j : 0)]; }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (vj && i0 + 4 * u < ns) {
-            const dc v = bb[PIPE ? ch : 0][u];
-            pr[u] += v.re * xf[ch].re - v.im * xf[ch].im; pi[u] += v.re * xf[ch].im + v.im * xf[ch].re;
-            cr[ch] += v.re * xa[u].re - v.im * xa[u].im; ci[ch] += v.re * xa[u].im + v.im * xa[u].re;
-          }
+        for (int u = 0; u < U; ++u) {                         // branch-free: columns past the block meet xf = 0, rows past it xa = 0; what they leave in
+          const dc v = bb[PIPE ? ch : 0][u];                  // sums that are never stored does not matter
+          pr[u] += v.re * xf[ch].re - v.im * xf[ch].im; pi[u] += v.re * xf[ch].im + v.im * xf[ch].re;
+          cr[ch] += v.re * xa[u].re - v.im * xa[u].im; ci[ch] += v.re * xa[u].im + v.im * xa[u].re;
         }
       }
     }
@@ -662,12 +658,11 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
       if (lane == 0 && i < ns && !self_t) prow[i] = dc_make(sr, si);
     }
     if constexpr (PIPE) {
-      if (more) {
+      (void)more;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
+      for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-          for (int u = 0; u < U; ++u) bb[ch][u] = bn[ch][u];
-      }
+        for (int u = 0; u < U; ++u) bb[ch][u] = bn[ch][u];
     }
   }
   if (both || self_t) {                                      // uniform over the block
@@ -682,6 +677,21 @@ __global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* 
     }
   }
   __syncthreads();                                           // cpart and xrow are reused by the workgroup's next block
+  }
+}
+// one workgroup per block; the block's width picks the body (round 5: one launch used to run the widest block's form -- 8 chunks, no
+// prefetch -- for every block, although nine blocks in ten of a grid clustering are two chunks wide)
+__global__ __launch_bounds__(256) void slfmm_near_wide_blocks_kernel(const int* __restrict__ eptr, const int* __restrict__ edof, const int* __restrict__ bsrc,
+                                                                     const int* __restrict__ bfld, const long long* __restrict__ boff,
+                                                                     const long long* __restrict__ broff, const long long* __restrict__ bcoff, int nblocks,
+                                                                     const dc* __restrict__ bval, const dc* __restrict__ x, dc* __restrict__ part, int tmode) {
+  __shared__ dc cpart[4 * 64 * FMM_NCH];
+  __shared__ dc xrow[FMM_WIDE_ROWS];                          // round 4: x of the block's rows, gathered once (the row loop then holds block loads only)
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {    // grid-stride (see slfmm_near_blocks_kernel)
+    const int f = bfld[b];
+    const int nch = (eptr[f + 1] - eptr[f] + 63) >> 6;       // uniform over the workgroup
+    if (nch <= 2) near_wide_block<2>(b, cpart, xrow, eptr, edof, bsrc, bfld, boff, broff, bcoff, bval, x, part, tmode);
+    else near_wide_block<8>(b, cpart, xrow, eptr, edof, bsrc, bfld, boff, broff, bcoff, bval, x, part, tmode);
   }
 }
 // (Round 4, measured and removed: the wide blocks CHUNK-major -- one chunk's x and column sum per lane, the rows' sums waiting in LDS
@@ -947,13 +957,9 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
     if (pass == 2) { /* second pass only */ }
     else if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, grid((S->nblocks + 3) / 4), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
                                                    S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
-    else if (S->max_width <= 64 * FMM_NCH) {
-      if (S->max_width <= 128) hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<2>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
-                                                  S->d_bcoff, S->nblocks, bv, x, part, tmode);
-      else if (S->max_width <= 256) hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<4>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
-                                                       S->d_bcoff, S->nblocks, bv, x, part, tmode);
-      else hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel<8>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
-                              S->d_bcoff, S->nblocks, bv, x, part, tmode);
+    else if (S->max_width <= 64 * FMM_NCH && S->max_rows <= FMM_WIDE_ROWS) {
+      hipLaunchKernelGGL(slfmm_near_wide_blocks_kernel, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
+                         S->d_bcoff, S->nblocks, bv, x, part, tmode);
     }
     else hipLaunchKernelGGL(slfmm_near_blocks_kernel<4>, grid(S->nblocks), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff,
                             S->d_bcoff, S->nblocks, bv, x, part, tmode);
