@@ -41,6 +41,7 @@ struct ma_slfmm {
   c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=1; 0: recomputed with libm)
   bool fast_phases = false;        // round 4 (the default, MA_FMM_STORE_PHASES=2): recomputed with the bounded-argument sin / cos, no table
   bool overlap = false;            // an element may sit in several clusters (mlfmm.rs' octant rule): rows are summed with atomics
+  bool covers_all = false;         // every dof is listed exactly once and the near field runs in two passes: its second pass WRITES all of y, the apply need not clear it
   // round 4: the near blocks' first pass runs on a second stream beside the far chain (up -> translate -> down), whose result goes to
   // d_yfar and is added by the near field's second pass -- the apply costs max(near, far) + one short pass instead of their sum
   // (MA_FMM_OVERLAP=0: one stream, the round-2 order). Created on first use.
@@ -1155,6 +1156,9 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
   const auto tt2 = tnow();
   int rc = MA_OK;
 #define UP(dst, src) if (!rc) rc = upload(&S->dst, src)
+  { std::vector<char> seen_dof((size_t)S->n, 0); bool once = (long long)edof.size() == S->n;
+    for (size_t q = 0; once && q < edof.size(); ++q) { const long long dq = edof[q]; if (dq < 0 || dq >= S->n || seen_dof[(size_t)dq]) once = false; else seen_dof[(size_t)dq] = 1; }
+    S->covers_all = once && !allow_overlap; }
   UP(d_eptr, eptr); UP(d_eidx, eidx); UP(d_edof, edof); UP(d_cc, cc); UP(d_sc, sc); UP(d_sw, sw); UP(d_cptr, cptr); UP(d_cent, cent);
   UP(d_fptr, fptr); UP(d_foth, foth); UP(d_fval, fval); UP(d_tptr, tptr); UP(d_toth, toth); UP(d_tval, tval);
 #undef UP
@@ -1261,7 +1265,7 @@ static int slfmm_join_near(ma_slfmm* S, dc* y, double s_dn, hipStream_t st) {
 
 int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_t st) {
   MA_HIP(hipSetDevice(S->device));
-  MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));        // dofs outside every cluster receive nothing
+  if (!(S->covers_all && S->d_part)) MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));   // dofs outside every cluster receive nothing (none: the second pass writes all of y)
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
   if (slfmm_overlap_ready(S)) {
     const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
@@ -1665,7 +1669,7 @@ int mlfmm_create(ma_bem_plan* plan, const ma_cluster_tree* T, const ma_physics_t
 int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   MA_HIP(hipSetDevice(S->device));
   ma_slfmm* F = S->leaf;
-  MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
+  if (!(F->covers_all && F->d_part)) MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
   // round 4: with a far field, the near blocks' products run on the leaf operator's second stream beside the whole far chain
   const bool two = S->far_field && slfmm_overlap_ready(F);

@@ -13,7 +13,7 @@ for which in ml sl; do
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "fillBuffer" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "slfmm_up_" in r["Kernel_Name"]]    # an apply starts with the upward pass (round 5: no memset any more)
 i0 = idx[-1]
 t0 = int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i0 + 30]:
