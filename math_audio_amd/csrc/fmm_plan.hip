@@ -23,7 +23,9 @@
 
 using namespace ma;
 
-struct SlfmmEntry { long long boff; long long poff; int other; int tflag; };   // a near block seen from one of its two clusters; poff: its partial sums for this side
+struct SlfmmEntry { long long boff; long long poff; int other; int tflag; };
+// round 5: a leaf-sized near block as ONE record (the leaf kernel reads it with one scalar load instead of walking bsrc / bfld -> eptr -> boff ...)
+struct NearBlockDesc { long long boff; long long broff; long long bcoff; int a0; int f0; int ns; int nf; int both; int pad; };   // a near block seen from one of its two clusters; poff: its partial sums for this side
 
 struct ma_slfmm {
   int device = 0; ma_bem_plan* plan = nullptr;
@@ -37,6 +39,7 @@ struct ma_slfmm {
   c64* d_fdense = nullptr; c64* d_tdense = nullptr;                         // the same two as dense nc x nc matrices, when the lists are nearly full
   int* d_bsrc = nullptr; int* d_bfld = nullptr; long long* d_boff = nullptr; int nblocks = 0;   // the near blocks one by one
   long long* d_broff = nullptr; long long* d_bcoff = nullptr; c64* d_part = nullptr; long long max_block = 0, max_width = 0, max_rows = 0;   // their partial sums (rows, columns)
+  NearBlockDesc* d_bdesc = nullptr; c64* d_xp = nullptr; long long listed = 0;   // round 5 (leaf-sized blocks): one record per block, x in cluster order
   c64* d_up = nullptr; c64* d_tr = nullptr;
   c64* d_phase = nullptr;          // w_p e^{i k s_p.(x_j - C_c)} per listed element and sphere point, when stored (MA_FMM_STORE_PHASES=1; 0: recomputed with libm)
   bool fast_phases = false;        // round 4 (the default, MA_FMM_STORE_PHASES=2): recomputed with the bounded-argument sin / cos, no table
@@ -585,6 +588,66 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
   }
   }
 }
+// Leaf-sized blocks (at most 64 rows and 64 columns: the multi-level operator's near field), round 5. The kernel above spends a block's
+// time on DEPENDENT loads: bsrc / bfld -> eptr -> the block, and inside the row loop edof -> x for every row -- four memory round trips
+// before the first product and two more per pass, which eight wavefronts per SIMD only partly hide (382 us for the 50k tree's 164 000
+// blocks). Here a block is ONE record (a scalar load, the next block's fetched while this one is worked on), x comes in cluster order
+// (one coalesced load for the rows, staged in LDS, one for the columns), and eight rows per lane set are loaded at once, unconditionally
+// (clamped into the block; what lies beyond meets a zero of x) and pinned ahead of the arithmetic: record -> loads -> products.
+__global__ __launch_bounds__(256) void fmm_cluster_order_kernel(const int* __restrict__ edof, long long listed, const dc* __restrict__ x, dc* __restrict__ xp) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e < listed) xp[e] = x[edof[e]];
+}
+__global__ __launch_bounds__(256) void slfmm_near_leaf_blocks_kernel(const NearBlockDesc* __restrict__ desc, int nblocks, const dc* __restrict__ bval,
+                                                                     const dc* __restrict__ xp, dc* __restrict__ part, int tmode) {
+  __shared__ dc xs_all[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  dc* xs = xs_all[wave];
+  constexpr int U = 4;
+  const int nw = gridDim.x * 4;
+  int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (b >= nblocks) return;
+  NearBlockDesc d = desc[b];
+  for (;;) {
+    const int bn = b + nw;
+    const NearBlockDesc dn = desc[bn < nblocks ? bn : b];   // the next block's record travels while this block is worked on
+    const int ns = d.ns, nf = d.nf;
+    const dc* B = bval + d.boff;
+    const bool both = d.both != 0, self_t = !both && tmode != 0;   // the transpose of a diagonal block: its column sums take the row slot
+    dc* prow = part + d.broff;
+    dc* pcol = both ? part + d.bcoff : prow;
+    int G = 8; while (G < 64 && G < nf) G <<= 1;
+    const int JG = 64 / G, jg = lane / G, lg = lane % G;
+    const dc xr = xp[d.a0 + (lane < ns ? lane : ns - 1)];
+    const dc xf0 = xp[d.f0 + (lg < nf ? lg : nf - 1)];
+    const int jc = lg < nf ? lg : nf - 1;
+    double cr = 0.0, ci = 0.0;
+    for (int i0 = 0; i0 < ns; i0 += JG * U) {
+      dc bb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = i0 + u * JG + jg; bb[u] = B[(i < ns ? i : ns - 1) * nf + jc]; }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i0 == 0) xs[lane] = lane < ns ? xr : dc_make(0.0, 0.0);   // one wavefront: its LDS operations stay in order
+      const dc xf = lg < nf ? xf0 : dc_make(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * JG + jg;
+        const bool ok = i < ns;                              // the same for the whole lane set
+        const dc xa = xs[ok ? i : 0];
+        double pr = bb[u].re * xf.re - bb[u].im * xf.im, pi = bb[u].re * xf.im + bb[u].im * xf.re;    // xf = 0 past the block's columns
+        pr = fmm_set_sum(pr, G); pi = fmm_set_sum(pi, G);
+        if (ok && lg == 0 && !self_t) prow[i] = dc_make(pr, pi);
+        if (ok) { cr += bb[u].re * xa.re - bb[u].im * xa.im; ci += bb[u].re * xa.im + bb[u].im * xa.re; }
+      }
+    }
+    if (both || self_t) {                                    // uniform over the block
+      for (int off = G; off < 64; off <<= 1) { cr += __shfl_xor(cr, off, 64); ci += __shfl_xor(ci, off, 64); }
+      if (jg == 0 && lg < nf) pcol[lg] = dc_make(cr, ci);
+    }
+    if (bn >= nblocks) break;
+    b = bn; d = dn;
+  }
+}
 // Large blocks (wider than one lane set): the same two products with the rows outside and the column chunks inside. A lane keeps
 // x[cols] of its NCH <= 8 chunks and their column sums in registers, a row is reduced over the lanes ONCE (not once per chunk) and
 // written once. One workgroup per block, the four wavefronts take rows w, w + 4, ...; their column sums meet in LDS in wavefront order.
@@ -956,6 +1019,11 @@ static int slfmm_launch_near(const ma_slfmm* S, const dc* x, dc* y, int tmode, h
     // (round 4 measured a cap on the grid beside the far chain: every cap from 1 to 8 workgroups per CU loses -- profiles/r04_fmm_apply.md)
     auto grid = [&](long long want) { return dim3((unsigned)want); };
     if (pass == 2) { /* second pass only */ }
+    else if (S->d_bdesc) {
+      dc* xp = reinterpret_cast<dc*>(S->d_xp);
+      hipLaunchKernelGGL(fmm_cluster_order_kernel, dim3((unsigned)((S->listed + 255) / 256)), dim3(256), 0, st, S->d_edof, S->listed, x, xp);
+      hipLaunchKernelGGL(slfmm_near_leaf_blocks_kernel, grid((S->nblocks + 3) / 4), dim3(256), 0, st, S->d_bdesc, S->nblocks, bv, xp, part, tmode);
+    }
     else if (S->max_block <= 64 * 64) hipLaunchKernelGGL(slfmm_near_blocks_kernel<1>, grid((S->nblocks + 3) / 4), dim3(256), 0, st, S->d_eptr, S->d_edof, S->d_bsrc, S->d_bfld,
                                                    S->d_boff, S->d_broff, S->d_bcoff, S->nblocks, bv, x, part, tmode);
     else if (S->max_width <= 64 * FMM_NCH && S->max_rows <= FMM_WIDE_ROWS) {
@@ -1009,7 +1077,7 @@ void slfmm_destroy(ma_slfmm* S) {
   if (!S) return;
   (void)hipSetDevice(S->device);
   void* p[] = {S->d_eptr, S->d_eidx, S->d_edof, S->d_cc, S->d_sc, S->d_sw, S->d_bval, S->d_cptr, S->d_cent, S->d_fptr, S->d_foth, S->d_fval, S->d_tptr, S->d_toth,
-               S->d_tval, S->d_up, S->d_tr, S->d_fdense, S->d_tdense, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff, S->d_bcoff, S->d_part, S->d_phase};
+               S->d_tval, S->d_up, S->d_tr, S->d_fdense, S->d_tdense, S->d_bsrc, S->d_bfld, S->d_boff, S->d_broff, S->d_bcoff, S->d_part, S->d_phase, S->d_bdesc, S->d_xp};
   for (void* q : p) if (q) (void)hipFree(q);
   if (S->d_yfar) (void)hipFree(S->d_yfar);
   if (S->st2) { (void)hipStreamSynchronize(S->st2); (void)hipStreamDestroy(S->st2); }
@@ -1172,6 +1240,20 @@ static int slfmm_create_ex(ma_bem_plan* plan, const ma_clusters_t* cl, const ma_
       if (!rc) rc = upload(&S->d_broff, broff);
       if (!rc) rc = upload(&S->d_bcoff, bcoff);
       if (!rc && hipMalloc(&S->d_part, sizeof(c64) * (size_t)std::max(npart, 1LL)) != hipSuccess) { set_error("near-field partial sums"); rc = MA_ERR_NOMEM; }
+      if (!rc && S->max_rows <= 64 && S->max_width <= 64 && S->max_rows > 0) {       // leaf-sized blocks: one record per block, x in cluster order
+        std::vector<NearBlockDesc> bd(bsrc.size());
+        for (size_t b = 0; b < bsrc.size(); ++b) {
+          const int a = bsrc[b], f = bfld[b];
+          bd[b] = {boff[b], broff[b], bcoff[b], eptr[(size_t)a], eptr[(size_t)f], eptr[(size_t)a + 1] - eptr[(size_t)a], eptr[(size_t)f + 1] - eptr[(size_t)f], a != f ? 1 : 0, 0};
+        }
+        bool all = true;
+        for (const NearBlockDesc& q : bd) if (q.ns <= 0 || q.nf <= 0) all = false;      // an empty cluster: the general kernel
+        S->listed = (long long)eptr.back();
+        if (all) {
+          rc = upload(&S->d_bdesc, bd);
+          if (!rc && hipMalloc(&S->d_xp, sizeof(c64) * (size_t)std::max<long long>(S->listed, 1)) != hipSuccess) { set_error("near-field x copy"); rc = MA_ERR_NOMEM; }
+        }
+      }
     } }
   if (!rc && free_term) rc = fmm_dense_from_lists(tptr, toth, tval, nc, &S->d_tdense);   // the multi-level operator's leaf (no free term) is never applied transposed
   if (rc) return fail(rc);
