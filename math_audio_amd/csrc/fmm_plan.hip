@@ -49,6 +49,8 @@ struct ma_slfmm {
   // d_yfar and is added by the near field's second pass -- the apply costs max(near, far) + one short pass instead of their sum
   // (MA_FMM_OVERLAP=0: one stream, the round-2 order). Created on first use.
   hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_near = nullptr; c64* d_yfar = nullptr; int overlap_streams = -1;
+  // round 5 (multi-level operator): the leaf level's translation on a third stream beside the upward chain of the levels above it
+  hipStream_t st3 = nullptr; hipEvent_t ev_up = nullptr, ev_leaf = nullptr;
   // host copies for extract_near_field_matrix
   std::vector<int> h_eptr, h_edof, h_bsrc, h_bfld; std::vector<long long> h_boff;
 };
@@ -1083,6 +1085,9 @@ void slfmm_destroy(ma_slfmm* S) {
   if (S->st2) { (void)hipStreamSynchronize(S->st2); (void)hipStreamDestroy(S->st2); }
   if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
   if (S->ev_near) (void)hipEventDestroy(S->ev_near);
+  if (S->st3) { (void)hipStreamSynchronize(S->st3); (void)hipStreamDestroy(S->st3); }
+  if (S->ev_up) (void)hipEventDestroy(S->ev_up);
+  if (S->ev_leaf) (void)hipEventDestroy(S->ev_leaf);
   delete S;
 }
 
@@ -1318,25 +1323,32 @@ static bool slfmm_overlap_ready(ma_slfmm* S) {
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       lo = 0;                                               // normal priority (the lowest was measured worse: r04_fmm_apply.md)
       bool ok = hipStreamCreateWithPriority(&S->st2, hipStreamNonBlocking, lo) == hipSuccess && hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&S->ev_near, hipEventDisableTiming) == hipSuccess && hipMalloc(&S->d_yfar, sizeof(c64) * (size_t)S->n) == hipSuccess;
+                hipEventCreateWithFlags(&S->ev_near, hipEventDisableTiming) == hipSuccess && hipMalloc(&S->d_yfar, sizeof(c64) * (size_t)S->n) == hipSuccess &&
+                hipStreamCreateWithFlags(&S->st3, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&S->ev_up, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&S->ev_leaf, hipEventDisableTiming) == hipSuccess;
       if (ok) S->overlap_streams = 1; else (void)hipGetLastError();
     }
   }
   return S->overlap_streams == 1;
 }
-// fork: the near blocks' products on the second stream, ordered after what `st` holds so far (x is ready, y is cleared)
-static int slfmm_fork_near(ma_slfmm* S, const dc* x, int tmode, hipStream_t st) {
+// fork: the near field on the second stream, ordered after what `st` holds so far (x is ready, y is cleared where it has to be).
+// whole = false (the single-level operator): the blocks' products only -- its downward pass is as long as the near blocks and runs beside
+// them into d_yfar; the short per-cluster pass then adds the two on `st`. whole = true (the multi-level operator, round 5): the
+// per-cluster pass too, into y -- its far chain is the longer side, and that pass (55 us on the 50k box) used to sit behind it.
+static int slfmm_fork_near(ma_slfmm* S, const dc* x, dc* y, int tmode, hipStream_t st, bool whole) {
   MA_HIP(hipEventRecord(S->ev_fork, st));
   MA_HIP(hipStreamWaitEvent(S->st2, S->ev_fork, 0));
-  int rc = slfmm_launch_near(S, x, nullptr, tmode, S->st2, 1);
+  int rc = slfmm_launch_near(S, x, y, tmode, S->st2, whole ? 0 : 1);
   if (rc) return rc;
   MA_HIP(hipEventRecord(S->ev_near, S->st2));
   return MA_OK;
 }
-// join: `st` (which has the far field in d_yfar, or will add it to y itself when elements sit in several clusters) takes the near
-// field's second pass
-static int slfmm_join_near(ma_slfmm* S, dc* y, double s_dn, hipStream_t st) {
+// join. whole = false: `st` (which has the far field in d_yfar, or will add it to y itself when elements sit in several clusters) takes
+// the near field's second pass, which adds the two. whole = true: the near field is in y, the downward pass ADDS the far field's share.
+// Either way near, then + far: the sum the one-stream order forms, bit for bit.
+static int slfmm_join_near(ma_slfmm* S, dc* y, double s_dn, hipStream_t st, bool whole) {
   MA_HIP(hipStreamWaitEvent(st, S->ev_near, 0));
+  if (whole) return slfmm_launch_down(S, s_dn, y, st);
   if (S->overlap) {                                            // atomic adds into the cleared y: near sums, then the far field
     int rc = slfmm_launch_near(S, nullptr, y, 0, st, 2);
     if (!rc) rc = slfmm_launch_down(S, s_dn, y, st);
@@ -1351,12 +1363,12 @@ int slfmm_apply(ma_slfmm* S, const c64* d_x, c64* d_y, int transpose, hipStream_
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
   if (slfmm_overlap_ready(S)) {
     const double s_up = transpose ? 1.0 : -1.0, s_dn = transpose ? -1.0 : 1.0;
-    int rc = slfmm_fork_near(S, x, transpose, st);
+    int rc = slfmm_fork_near(S, x, y, transpose, st, false);
     if (!rc) rc = slfmm_launch_up(S, s_up, x, st);
     if (!rc) rc = fmm_launch_translate(transpose ? S->d_tptr : S->d_fptr, transpose ? S->d_toth : S->d_foth, transpose ? S->d_tval : S->d_fval,
                                        transpose ? S->d_tdense : S->d_fdense, S->nc, S->P, S->d_up, S->d_tr, st);
     if (!rc && !S->overlap) rc = slfmm_launch_down(S, s_dn, reinterpret_cast<dc*>(S->d_yfar), st, true);
-    if (!rc) rc = slfmm_join_near(S, y, s_dn, st);
+    if (!rc) rc = slfmm_join_near(S, y, s_dn, st, false);
     return rc;
   }
   { int rc = slfmm_launch_near(S, x, y, transpose, st); if (rc) return rc; }
@@ -1753,14 +1765,39 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
   ma_slfmm* F = S->leaf;
   if (!(F->covers_all && F->d_part)) MA_HIP(hipMemsetAsync(d_y, 0, sizeof(c64) * (size_t)S->n, st));
   const dc* x = reinterpret_cast<const dc*>(d_x); dc* y = reinterpret_cast<dc*>(d_y);
-  // round 4: with a far field, the near blocks' products run on the leaf operator's second stream beside the whole far chain
+  // rounds 4-5: with a far field, the whole near field runs on the leaf operator's second stream beside the far chain
   const bool two = S->far_field && slfmm_overlap_ready(F);
-  if (two) { int rc = slfmm_fork_near(F, x, 0, st); if (rc) return rc; }
+  const bool whole = two && !F->overlap;                    // the per-cluster pass too (overlapping leaves accumulate with atomics: the round-4 order)
+  if (two) { int rc = slfmm_fork_near(F, x, y, 0, st, whole); if (rc) return rc; }
   else { int rc = slfmm_launch_near(F, x, y, 0, st); if (rc) return rc; }
   if (!S->far_field) return MA_OK;
   // upward pass: leaf multipoles, then level by level to the top level that has far pairs
   { int rc = slfmm_launch_up(F, -1.0, x, st); if (rc) return rc; }
   const int nu = (int)S->up.size();
+  const int nt = fmm_levels_nt(F->P);
+  // translation at every level: the levels whose dense D takes the small-tile kernel travel in one launch per stream
+  auto add_or_launch = [&](FmmLevels& V, const int* fptr, const int* foth, const c64* fval, const c64* dense, int nc, int P, const c64* up, c64* tr, hipStream_t s_) -> int {
+    if (V.nl < 8 && fmm_translate_batchable(dense, nc, P)) {
+      const int q = V.nl++;
+      V.rows[q] = (nc + 15) / 16; V.nc[q] = nc; V.P[q] = P;
+      V.DT[q] = reinterpret_cast<const dc*>(dense); V.up[q] = reinterpret_cast<const dc*>(up); V.tr[q] = reinterpret_cast<dc*>(tr);
+      V.first[q + 1] = V.first[q] + V.rows[q] * ((P + 16 * nt - 1) / (16 * nt));
+      return MA_OK;
+    }
+    return fmm_launch_translate(fptr, foth, fval, dense, nc, P, up, tr, s_);
+  };
+  // round 5: the leaf level's translation (the largest; it needs the leaf multipoles only) on a third stream beside the upward chain of
+  // the levels above, their translations and the downward chain as far as the leaves' fathers; the last l2l step, which ADDS the
+  // fathers' locals to what the leaf translation WROTE, waits for it
+  const bool three = two && nu > 0 && F->st3;
+  if (three) {
+    MA_HIP(hipEventRecord(F->ev_up, st));
+    MA_HIP(hipStreamWaitEvent(F->st3, F->ev_up, 0));
+    FmmLevels VL; VL.nl = 0; VL.first[0] = 0;
+    { int rc = add_or_launch(VL, F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr, F->st3); if (rc) return rc; }
+    { int rc = fmm_launch_translate_levels(VL, nt, F->st3); if (rc) return rc; }
+    MA_HIP(hipEventRecord(F->ev_leaf, F->st3));
+  }
   for (int l = nu - 1; l >= 0; --l) {
     MlLevel& L = S->up[(size_t)l];
     const bool below_is_leaf = l == nu - 1;
@@ -1770,25 +1807,12 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     hipLaunchKernelGGL(mlfmm_m2m_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, Mc, reinterpret_cast<dc*>(L.d_M));
     MA_HIP(hipGetLastError());
   }
-  // translation at every level: the levels whose dense D takes the small-tile kernel travel in ONE launch
-  const bool batch_levels = true;
   FmmLevels V; V.nl = 0; V.first[0] = 0;
-  const int nt = fmm_levels_nt(F->P);
-  auto add_or_launch = [&](const int* fptr, const int* foth, const c64* fval, const c64* dense, int nc, int P, const c64* up, c64* tr) -> int {
-    if (batch_levels && V.nl < 8 && fmm_translate_batchable(dense, nc, P)) {
-      const int q = V.nl++;
-      V.rows[q] = (nc + 15) / 16; V.nc[q] = nc; V.P[q] = P;
-      V.DT[q] = reinterpret_cast<const dc*>(dense); V.up[q] = reinterpret_cast<const dc*>(up); V.tr[q] = reinterpret_cast<dc*>(tr);
-      V.first[q + 1] = V.first[q] + V.rows[q] * ((P + 16 * nt - 1) / (16 * nt));
-      return MA_OK;
-    }
-    return fmm_launch_translate(fptr, foth, fval, dense, nc, P, up, tr, st);
-  };
   for (int l = 0; l < nu; ++l) {
     MlLevel& L = S->up[(size_t)l];
-    { int rc = add_or_launch(L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.nc, L.P, L.d_M, L.d_L); if (rc) return rc; }
+    { int rc = add_or_launch(V, L.d_fptr, L.d_foth, L.d_fval, L.d_fdense, L.nc, L.P, L.d_M, L.d_L, st); if (rc) return rc; }
   }
-  { int rc = add_or_launch(F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr); if (rc) return rc; }
+  if (!three) { int rc = add_or_launch(V, F->d_fptr, F->d_foth, F->d_fval, F->d_fdense, F->nc, F->P, F->d_up, F->d_tr, st); if (rc) return rc; }
   { int rc = fmm_launch_translate_levels(V, nt, st); if (rc) return rc; }
   // downward pass
   for (int l = 0; l < nu; ++l) {
@@ -1797,14 +1821,14 @@ int mlfmm_apply(ma_mlfmm* S, const c64* d_x, c64* d_y, hipStream_t st) {
     const double* ccc = below_is_leaf ? F->d_cc : S->up[(size_t)l + 1].d_cc;
     const int Pc = below_is_leaf ? F->P : S->up[(size_t)l + 1].P;
     dc* Lc = reinterpret_cast<dc*>(below_is_leaf ? F->d_tr : S->up[(size_t)l + 1].d_L);
+    if (below_is_leaf && three) MA_HIP(hipStreamWaitEvent(st, F->ev_leaf, 0));
     hipLaunchKernelGGL(mlfmm_l2l_kernel, dim3(L.nc), dim3(256), 0, st, L.d_sptr, L.d_sidx, L.d_cc, ccc, L.d_sc, L.d_sw, L.P, Pc, S->k, reinterpret_cast<const dc*>(L.d_L), Lc);
     MA_HIP(hipGetLastError());
   }
   if (two) {
-    // the far field's share per dof into the leaf operator's own vector (elements in one cluster each), then the near field's second
-    // pass adds the two; with overlapping leaves both accumulate into the cleared y with atomics, as before
-    if (!F->overlap) { int rc = slfmm_launch_down(F, 1.0, reinterpret_cast<dc*>(F->d_yfar), st, true); if (rc) return rc; }
-    return slfmm_join_near(F, y, 1.0, st);
+    // whole: the near field is in y, the downward pass adds the far field's share. Otherwise (overlapping leaves) both accumulate into
+    // the cleared y with atomics, near sums first, as before
+    return slfmm_join_near(F, y, 1.0, st, whole);
   }
   { int rc = slfmm_launch_down(F, 1.0, y, st); if (rc) return rc; }
   return MA_OK;
