@@ -326,9 +326,9 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_dense_kernel(const dc* 
   const int steps = (nc + 3) / 4, per = (steps + KS - 1) / KS;
   const int kb = w * per, ke = kb + per < steps ? kb + per : steps;
   const dc* acol = DT + (c0 + lr < nc ? c0 + lr : nc - 1);
-  fmm_v4d cr[NT], ci[NT];
+  fmm_v4d cr[NT], ci[NT], cs[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { cr[t] = (fmm_v4d){0, 0, 0, 0}; ci[t] = cr[t]; }
+  for (int t = 0; t < NT; ++t) { cr[t] = (fmm_v4d){0, 0, 0, 0}; ci[t] = cr[t]; cs[t] = cr[t]; }
   dc a, bv[NT], an, bn[NT];
   auto fetch = [&](int ks, dc& fa, dc* fb) {
     const int sidx = ks * 4 + lk;
@@ -346,10 +346,11 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_dense_kernel(const dc* 
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (t < nt) {
+        // three real products per complex one (round 5; the LU's trailing update does the same): t1 = Re Re, t2 = Im Im, t3 = (Re + Im)(Re + Im);
+        // re = t1 - t2, im = t3 - t1 - t2 at the end -- normwise, not componentwise, accurate
         cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].re, cr[t], 0, 0, 0);
-        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].im, ci[t], 0, 0, 0);
-        cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, bv[t].im, cr[t], 0, 0, 0);
-        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, bv[t].re, ci[t], 0, 0, 0);
+        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, bv[t].im, ci[t], 0, 0, 0);
+        cs[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, bv[t].re + bv[t].im, cs[t], 0, 0, 0);
       }
     a = an;
 #pragma unroll
@@ -364,8 +365,9 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_dense_kernel(const dc* 
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             dc* o = part + (lk + 4 * g) * (16 * NT) + 16 * t + lr;
-            if (q == 0) *o = dc_make(cr[t][g], ci[t][g]);
-            else { o->re += cr[t][g]; o->im += ci[t][g]; }
+            const double pre = cr[t][g] - ci[t][g], pim = cs[t][g] - cr[t][g] - ci[t][g];
+            if (q == 0) *o = dc_make(pre, pim);
+            else { o->re += pre; o->im += pim; }
           }
         }
     }
@@ -416,9 +418,9 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_levels_kernel(FmmLevels
   const int steps = (nc + 3) / 4, per = (steps + KS - 1) / KS;
   const int kb = w * per, ke = kb + per < steps ? kb + per : steps;
   const dc* acol = DT + (c0 + lr < nc ? c0 + lr : nc - 1);
-  fmm_v4d cr[NT], ci[NT];
+  fmm_v4d cr[NT], ci[NT], cs[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) { cr[t] = (fmm_v4d){0, 0, 0, 0}; ci[t] = cr[t]; }
+  for (int t = 0; t < NT; ++t) { cr[t] = (fmm_v4d){0, 0, 0, 0}; ci[t] = cr[t]; cs[t] = cr[t]; }
   dc a, bv[NT], an, bn[NT];
   auto fetch = [&](int ks, dc& fa, dc* fb) {
     const int sidx = ks * 4 + lk;
@@ -436,10 +438,11 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_levels_kernel(FmmLevels
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       if (t < nt) {
+        // three real products per complex one (round 5; the LU's trailing update does the same): t1 = Re Re, t2 = Im Im, t3 = (Re + Im)(Re + Im);
+        // re = t1 - t2, im = t3 - t1 - t2 at the end -- normwise, not componentwise, accurate
         cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].re, cr[t], 0, 0, 0);
-        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re, bv[t].im, ci[t], 0, 0, 0);
-        cr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.im, bv[t].im, cr[t], 0, 0, 0);
-        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, bv[t].re, ci[t], 0, 0, 0);
+        ci[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.im, bv[t].im, ci[t], 0, 0, 0);
+        cs[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.re + a.im, bv[t].re + bv[t].im, cs[t], 0, 0, 0);
       }
     a = an;
 #pragma unroll
@@ -453,8 +456,9 @@ __global__ __launch_bounds__(64 * KS) void fmm_translate_levels_kernel(FmmLevels
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             dc* o = part + (lk + 4 * g) * (16 * NT) + 16 * t + lr;
-            if (q == 0) *o = dc_make(cr[t][g], ci[t][g]);
-            else { o->re += cr[t][g]; o->im += ci[t][g]; }
+            const double pre = cr[t][g] - ci[t][g], pim = cs[t][g] - cr[t][g] - ci[t][g];
+            if (q == 0) *o = dc_make(pre, pim);
+            else { o->re += pre; o->im += pim; }
           }
         }
     }
