@@ -306,7 +306,7 @@ template <typename T> int upload(T** d, const std::vector<T>& h) {
 
 // The far lists of this method hold every cluster that is not near, so D is a nearly full nc x nc matrix and tr = D up a dense
 // complex product [nc x nc] [nc x P]. The list kernel above re-reads a row of `up` from L2 for every pair (6 GB per leaf level of the
-// 50k box: L2-bound, 0.5 ms). Here it runs on v_mfma_f64_16x16x4_f64, four real products per complex one. D is stored by SOURCE
+// 50k box: L2-bound, 0.5 ms). Here it runs on v_mfma_f64_16x16x4_f64, three real products per complex one (four until round 5). D is stored by SOURCE
 // (DT[s][c], the receiving cluster c contiguous), so the A operand of a step (16 receiving clusters x 4 sources) is four 256-byte
 // runs and the B operands (4 sources x 16 points) rows of `up`. A wavefront owns 16 receiving clusters and up to 128 points; the KS
 // wavefronts of a workgroup split the sources and add their parts in wavefront order through LDS, so the result does not depend on
