@@ -594,6 +594,14 @@ __global__ __launch_bounds__(256) void slfmm_near_blocks_kernel(const int* __res
   }
   }
 }
+// One butterfly step of a transposing reduction: two vectors A, B in, one out whose lanes with `bit` clear hold A[l] + A[partner] and
+// whose lanes with `bit` set hold B[l] + B[partner] (partner by the DPP control CTRL). Three such steps take eight vectors -- the real
+// and imaginary partial sums of four rows -- to ONE register (7 folds of 7 instructions) where summing each alone takes 8 x 3 steps of 3.
+template <int CTRL>
+__device__ __forceinline__ double fmm_fold(double a, double b, bool bit) {
+  const double keep = bit ? b : a, send = bit ? a : b;
+  return keep + fmm_dpp<CTRL>(send);
+}
 // Leaf-sized blocks (at most 64 rows and 64 columns: the multi-level operator's near field), round 5. The kernel above spends a block's
 // time on DEPENDENT loads: bsrc / bfld -> eptr -> the block, and inside the row loop edof -> x for every row -- four memory round trips
 // before the first product and two more per pass, which eight wavefronts per SIMD only partly hide (382 us for the 50k tree's 164 000
@@ -628,23 +636,36 @@ __global__ __launch_bounds__(256) void slfmm_near_leaf_blocks_kernel(const NearB
     const dc xf0 = xp[d.f0 + (lg < nf ? lg : nf - 1)];
     const int jc = lg < nf ? lg : nf - 1;
     double cr = 0.0, ci = 0.0;
+    // lane bits 0 and 1 taken relative to bit 2, so that the cheap row_half_mirror pairs lanes that hold the same vector
+    const int b2 = (lane >> 2) & 1;
+    const bool bit0 = ((lane ^ b2) & 1) != 0, bit1 = (((lane >> 1) ^ b2) & 1) != 0, bit2 = b2 != 0;
     for (int i0 = 0; i0 < ns; i0 += JG * U) {
       dc bb[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { const int i = i0 + u * JG + jg; bb[u] = B[(i < ns ? i : ns - 1) * nf + jc]; }
+      for (int u = 0; u < U; ++u) { const int i = i0 + jg * U + u; bb[u] = B[(i < ns ? i : ns - 1) * nf + jc]; }   // a lane set takes four consecutive rows
       __builtin_amdgcn_sched_barrier(0);
       if (i0 == 0) xs[lane] = lane < ns ? xr : dc_make(0.0, 0.0);   // one wavefront: its LDS operations stay in order
       const dc xf = lg < nf ? xf0 : dc_make(0.0, 0.0);
+      double pr[U], pi[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * JG + jg;
+        const int i = i0 + jg * U + u;
         const bool ok = i < ns;                              // the same for the whole lane set
         const dc xa = xs[ok ? i : 0];
-        double pr = bb[u].re * xf.re - bb[u].im * xf.im, pi = bb[u].re * xf.im + bb[u].im * xf.re;    // xf = 0 past the block's columns
-        pr = fmm_set_sum(pr, G); pi = fmm_set_sum(pi, G);
-        if (ok && lg == 0 && !self_t) prow[i] = dc_make(pr, pi);
+        pr[u] = bb[u].re * xf.re - bb[u].im * xf.im; pi[u] = bb[u].re * xf.im + bb[u].im * xf.re;    // xf = 0 past the block's columns
         if (ok) { cr += bb[u].re * xa.re - bb[u].im * xa.im; ci += bb[u].re * xa.im + bb[u].im * xa.re; }
       }
+      // the four rows' sums: eight vectors folded to one register on lane bits 0, 1, 2, then summed over the set's remaining lane bits;
+      // lanes 0..7 of the set then hold (re, im) of its four rows
+      const double r0 = fmm_fold<0xB1>(pr[0], pi[0], bit0), r1 = fmm_fold<0xB1>(pr[1], pi[1], bit0);
+      const double r2 = fmm_fold<0xB1>(pr[2], pi[2], bit0), r3 = fmm_fold<0xB1>(pr[3], pi[3], bit0);
+      const double q0 = fmm_fold<0x4E>(r0, r1, bit1), q1 = fmm_fold<0x4E>(r2, r3, bit1);
+      double z = fmm_fold<0x141>(q0, q1, bit2);
+      if (G >= 16) z += fmm_dpp<0x128>(z);                   // row_ror:8 = the lane 8 further inside the row of 16
+      if (G >= 32) z += __shfl_xor(z, 16, 64);
+      if (G >= 64) z += __shfl_xor(z, 32, 64);
+      const int irow = i0 + jg * U + (bit1 ? 1 : 0) + (bit2 ? 2 : 0);
+      if (lg < 8 && irow < ns && !self_t) reinterpret_cast<double*>(prow + irow)[bit0 ? 1 : 0] = z;
     }
     if (both || self_t) {                                    // uniform over the block
       for (int off = G; off < 64; off <<= 1) { cr += __shfl_xor(cr, off, 64); ci += __shfl_xor(ci, off, 64); }
