@@ -742,11 +742,21 @@ __device__ __forceinline__ void near_wide_block(int b, dc* __restrict__ cpart, d
         }
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const double sr = fmm_set_sum(pr[u], 64), si = fmm_set_sum(pi[u], 64);
-      const int i = i0 + 4 * u;
-      if (lane == 0 && i < ns && !self_t) prow[i] = dc_make(sr, si);
+    {
+      // the four rows' sums by the transposing butterfly (fmm_fold): eight vectors to one register on lane bits 0, 1, 2, then over bits 3, 4, 5;
+      // lanes 0..7 hold (re, im) of rows i0, i0 + 4, i0 + 8, i0 + 12
+      static_assert(U == 4, "the butterfly folds four rows");
+      const int b2 = (lane >> 2) & 1;
+      const bool bit0 = ((lane ^ b2) & 1) != 0, bit1 = (((lane >> 1) ^ b2) & 1) != 0, bit2 = b2 != 0;
+      const double r0 = fmm_fold<0xB1>(pr[0], pi[0], bit0), r1 = fmm_fold<0xB1>(pr[1], pi[1], bit0);
+      const double r2 = fmm_fold<0xB1>(pr[2], pi[2], bit0), r3 = fmm_fold<0xB1>(pr[3], pi[3], bit0);
+      const double q0 = fmm_fold<0x4E>(r0, r1, bit1), q1 = fmm_fold<0x4E>(r2, r3, bit1);
+      double z = fmm_fold<0x141>(q0, q1, bit2);
+      z += fmm_dpp<0x128>(z);                                // row_ror:8
+      z += __shfl_xor(z, 16, 64);
+      z += __shfl_xor(z, 32, 64);
+      const int i = i0 + 4 * ((bit1 ? 1 : 0) + (bit2 ? 2 : 0));
+      if (lane < 8 && i < ns && !self_t) reinterpret_cast<double*>(prow + i)[bit0 ? 1 : 0] = z;
     }
     if constexpr (PIPE) {
       (void)more;
